@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""bench.py -- cost-volumes/sec of the plane-sweep build on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE
+JSON line on rank 0.  For N>1 the driver launches it under
+``python -m torch.distributed.run`` (one rank per GPU, RCCL).
+
+A "step" = one pass of the hot path (dfm_plane_sweep_fwd: re-block the two
+feature maps + write the (B,2C,D,H,W) volume) over one batch of B=8 synthetic
+KITTI-shape frame pairs that are already resident in HBM.  The batch shards
+over ranks with no data-path collective (weak scaling: B=8 per GPU).
+
+Workloads (``--workload``):
+  nstar (default, the BASELINE.json metric): B=8, C=256, D=112, 94x311, bf16,
+        feat_sample_factor=4, cost_sample_factor=1
+  kitti : config K of configs/dfm/dfm_r34_1x8_kitti-3d-3class.py: B=8 (the
+        config runs 1/GPU), C=32, 320x1280 fp32, csf=4, D=72 -> (64,72,80,320)
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791],
+                     [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
+
+WORKLOADS = {
+    # name: B, C, H, W, D, fsf, csf, crop, dtype
+    'nstar': dict(B=8, C=256, H=94, W=311, D=112, fsf=4, csf=1, crop=(0, 0), dtype='bf16',
+                  dmin=2.0, dmax=59.6),
+    'kitti': dict(B=8, C=32, H=320, W=1280, D=72, fsf=1, csf=4, crop=(0, 55), dtype='f32',
+                  dmin=2.0, dmax=59.6),
+}
+
+
+def poses(batch, seed):
+    """forward t_z~U(-1.5,-0.3) m, lateral t_x~U(-0.1,0.1), yaw~U(-2,2) deg"""
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(batch):
+        yaw, tx, tz = np.radians(rng.uniform(-2, 2)), rng.uniform(-0.1, 0.1), rng.uniform(-1.5, -0.3)
+        c, s = np.cos(yaw), np.sin(yaw)
+        out.append([[c, 0, s, tx], [0, 1, 0, 0], [-s, 0, c, tz], [0, 0, 0, 1]])
+    return np.asarray(out, np.float32)
+
+
+def depth_planes(num, dmin, dmax):
+    return np.array([dmin + (i + 0.5) * ((dmax - dmin) / num) for i in range(num)], np.float32)
+
+
+def algorithmic_bytes(w, elem):
+    """s*(2*C*H_in*W_in + 2*C*D*H_out*W_out) per volume."""
+    h_out, w_out = round(w['H'] / w['csf']), round(w['W'] / w['csf'])
+    return elem * (2 * w['C'] * w['H'] * w['W'] + 2 * w['C'] * w['D'] * h_out * w_out)
+
+
+def cpu_baseline(w, budget_s=15.0):
+    """The oracle (a C port of the reference algorithm, OpenMP over rows) timed
+    on this host's cores on a BOUNDED sample: one sample's volume restricted
+    to a channel subset, extrapolated linearly in C (the work is exactly
+    proportional to the channel count)."""
+    from oracle import dfm_oracle as orc
+    lib = orc.lib()
+    cores = max(1, min(lib.dfm_oracle_max_threads(), os.cpu_count() or 1))
+    lib.dfm_oracle_set_threads(cores)
+    rng = np.random.RandomState(0)
+    P = KITTI_P2
+    Pinv = torch.inverse(torch.from_numpy(P.copy())).numpy()
+    T = poses(1, 2)[0]
+    depths = depth_planes(w['D'], w['dmin'], w['dmax'])
+    prm = orc.sweep_params(w['H'], w['W'], w['D'], w['fsf'], w['csf'], P, Pinv, T, (375, 1242),
+                           False, w['crop'], 1.0)
+
+    def run(c_sub):
+        cur = rng.randn(c_sub, w['H'], w['W']).astype(np.float32)
+        prev = rng.randn(c_sub, w['H'], w['W']).astype(np.float32)
+        out = np.zeros((2 * c_sub, prm.D, prm.h_out, prm.w_out), np.float32)  # pre-faulted
+        t0 = time.perf_counter()
+        lib.dfm_oracle_build_dfm_cost(ctypes.byref(prm), orc._vp(depths), orc._vp(cur),
+                                      orc._vp(prev), ctypes.c_int(c_sub), orc._vp(out))
+        return time.perf_counter() - t0
+
+    t1 = run(2)  # calibration
+    c_sub = int(max(2, min(w['C'], budget_s / max(t1 / 2, 1e-6))))
+    t = run(c_sub)
+    sec_per_volume = t * (w['C'] / c_sub)
+    return {
+        'value': 1.0 / sec_per_volume,
+        'unit': 'cost-volumes/s',
+        'cores': cores,
+        'kind': 'port',
+        'sample': f'1 sample, {c_sub} of {w["C"]} channels x all D={w["D"]} planes x '
+                  f'{prm.h_out}x{prm.w_out}, fp32, {t:.1f} s measured, scaled by C',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='nstar', choices=sorted(WORKLOADS))
+    ap.add_argument('--kernel', type=int, default=0, help='0 auto, 1 gather, 2 LDS (A/B runs)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--traffic-bytes', type=float, default=None,
+                    help='HBM bytes per launch from a separate rocprofv3 --pmc pass')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU: there is no CPU product path'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    pkg = importlib.import_module('depth-from-motion_amd')
+    sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+    lib = pkg._capi.lib()
+    lib.dfm_plane_sweep_force_kernel(args.kernel)
+
+    w = WORKLOADS[args.workload]
+    tdtype = torch.bfloat16 if w['dtype'] == 'bf16' else torch.float32
+    elem = 2 if w['dtype'] == 'bf16' else 4
+    B = w['B']
+    # synthetic inputs: cur seed 0, prev seed 1 (+rank so shards differ)
+    gc = torch.Generator().manual_seed(0 + 1000 * rank)
+    gp = torch.Generator().manual_seed(1 + 1000 * rank)
+    cur = torch.randn(B, w['C'], w['H'], w['W'], generator=gc).to(dev).to(tdtype)
+    prev = torch.randn(B, w['C'], w['H'], w['W'], generator=gp).to(dev).to(tdtype)
+    depths = torch.from_numpy(depth_planes(w['D'], w['dmin'], w['dmax'])).to(dev)
+    desc = sweep._make_desc(cur, w['D'], w['fsf'], w['csf'], (375, 1242), False, w['crop'], 1.0)
+    P, Pinv, T = sweep.camera_matrices(torch.from_numpy(np.stack([KITTI_P2] * B)),
+                                       torch.from_numpy(poses(B, 2 + rank)), B, dev)
+    out = torch.empty((B, 2 * w['C'], w['D'], desc.h_out, desc.w_out), dtype=tdtype, device=dev)
+
+    def step():
+        sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T, out=out)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    pkg._capi.check(lib.dfm_profile_begin(args.steps))
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kms, klaunches = ctypes.c_double(0), ctypes.c_int(0)
+    pkg._capi.check(lib.dfm_profile_end(ctypes.byref(kms), ctypes.byref(klaunches)))
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = B * world / (ms_per_step / 1e3)
+
+    if rank == 0:
+        bytes_per_launch = algorithmic_bytes(w, elem) * B
+        avg_kernel_ms = kms.value / max(klaunches.value, 1)
+        achieved = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
+        line = {
+            'metric': 'cost-volumes/sec',
+            'value': round(value, 2),
+            'unit': 'cost-volumes/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': w['dtype'],
+            'data': 'synthetic',
+            'config': {
+                'workload': f'{args.workload}: plane-sweep cost-volume build '
+                            f'B={B}/GPU x (2C={2 * w["C"]}, D={w["D"]}, {desc.h_out}x{desc.w_out}), '
+                            f'feats {w["C"]}x{w["H"]}x{w["W"]} {w["dtype"]}, fsf={w["fsf"]} '
+                            f'csf={w["csf"]}',
+                'global_batch': B * world,
+                'parallelism': f'dp{world}',
+                'kernel': {1: 'sweep_gather', 2: 'sweep_lds'}.get(
+                    lib.dfm_plane_sweep_last_kernel(), 'none'),
+            },
+            'roofline': {
+                'bound': 'hbm',
+                'achieved': round(achieved, 1),
+                'peak': HBM_PEAK_GBPS,
+                'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBPS, 4),
+                'traffic': args.traffic_bytes,
+                'kernel_ms': round(avg_kernel_ms, 4),
+                'algorithmic_bytes_per_launch': bytes_per_launch,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(w)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

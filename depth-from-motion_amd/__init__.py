@@ -1,0 +1,16 @@
+"""depth-from-motion_amd -- MI355X (gfx950) native plane-sweep cost-volume path
+of Depth-from-Motion.
+
+The directory name carries a hyphen (it is the project name); import it as
+``import dfm_amd`` (alias module at the repo root) or
+``importlib.import_module('depth-from-motion_amd')``.
+
+Everything numerical runs in hand-written HIP kernels behind the C ABI of
+``include/dfm_hip.h`` (``lib/libdfm_hip.so``).  There is NO CPU or eager
+PyTorch fallback: if the shared library is missing or no GPU is visible the
+ops raise.
+"""
+from . import _capi  # noqa: F401
+from .plane_sweep import build_dfm_cost, plane_sweep_grid  # noqa: F401
+
+__all__ = ['build_dfm_cost', 'plane_sweep_grid']

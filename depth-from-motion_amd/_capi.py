@@ -1,0 +1,95 @@
+"""ctypes binding of lib/libdfm_hip.so (C ABI: include/dfm_hip.h).
+
+Loud by design: a missing library is an ImportError with the build command,
+never a silent fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libdfm_hip.so')
+
+DFM_F32, DFM_BF16 = 0, 1
+
+# every symbol include/dfm_hip.h declares (tests/test_capi_symbols.py checks
+# the header against this list and against the built library)
+EXPORTS = (
+    'dfm_version',
+    'dfm_last_error',
+    'dfm_profile_begin',
+    'dfm_profile_end',
+    'dfm_plane_sweep_workspace_bytes',
+    'dfm_plane_sweep_fwd',
+    'dfm_plane_sweep_bwd',
+    'dfm_plane_sweep_grid',
+    'dfm_plane_sweep_last_kernel',
+    'dfm_plane_sweep_force_kernel',
+)
+
+
+class SweepDesc(ctypes.Structure):
+    """struct dfm_sweep_desc"""
+    _fields_ = [
+        ('batch', ctypes.c_int32),
+        ('channels', ctypes.c_int32),
+        ('h_in', ctypes.c_int32),
+        ('w_in', ctypes.c_int32),
+        ('num_depths', ctypes.c_int32),
+        ('h_out', ctypes.c_int32),
+        ('w_out', ctypes.c_int32),
+        ('feat_sample_factor', ctypes.c_float),
+        ('cost_sample_factor', ctypes.c_float),
+        ('img_scale_factor', ctypes.c_float),
+        ('crop_x', ctypes.c_float),
+        ('crop_y', ctypes.c_float),
+        ('org_w', ctypes.c_float),
+        ('flip', ctypes.c_int32),
+        ('dtype', ctypes.c_int32),
+    ]
+
+
+class DfmHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} not found: build it with '
+            '`python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+    h = ctypes.CDLL(LIB_PATH)
+    vp, fp, i32, sz = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_size_t
+    dp = ctypes.POINTER(SweepDesc)
+    h.dfm_version.restype = ctypes.c_int
+    h.dfm_last_error.restype = ctypes.c_char_p
+    h.dfm_profile_begin.restype = ctypes.c_int
+    h.dfm_profile_begin.argtypes = [ctypes.c_int]
+    h.dfm_profile_end.restype = ctypes.c_int
+    h.dfm_profile_end.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    h.dfm_plane_sweep_workspace_bytes.restype = sz
+    h.dfm_plane_sweep_workspace_bytes.argtypes = [dp]
+    h.dfm_plane_sweep_fwd.restype = ctypes.c_int
+    h.dfm_plane_sweep_fwd.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp]
+    h.dfm_plane_sweep_bwd.restype = ctypes.c_int
+    h.dfm_plane_sweep_bwd.argtypes = [dp, vp, fp, fp, fp, fp, fp, fp, vp]
+    h.dfm_plane_sweep_grid.restype = ctypes.c_int
+    h.dfm_plane_sweep_grid.argtypes = [dp, i32, fp, fp, fp, fp, fp, fp, vp]
+    h.dfm_plane_sweep_last_kernel.restype = ctypes.c_int
+    h.dfm_plane_sweep_force_kernel.restype = None
+    h.dfm_plane_sweep_force_kernel.argtypes = [ctypes.c_int]
+    _lib = h
+    return h
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().dfm_last_error().decode('utf-8', 'replace')
+        raise DfmHipError(f'libdfm_hip error {rc}: {msg}')

@@ -1,0 +1,50 @@
+"""Ahead-of-time build of lib/libdfm_hip.so with hipcc for gfx950.
+
+No JIT, no torch.utils.cpp_extension: the library is a plain C-ABI shared
+object (include/dfm_hip.h) that ctypes loads; the built .so stays in-tree so
+it travels to the GPU box with the repo snapshot.
+"""
+import glob
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_DIR = os.path.join(_HERE, 'lib')
+LIB = os.path.join(LIB_DIR, 'libdfm_hip.so')
+
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+# -ffp-contract=off is part of the numerics contract (csrc/dfm_common.h)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+         '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
+        glob.glob(os.path.join(ROOT, 'include', '*.h'))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force=False, verbose=False):
+    """Compile every csrc/*.hip into lib/libdfm_hip.so. Returns the path."""
+    if not force and not _stale():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [HIPCC] + FLAGS + ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + sources() + \
+        ['-o', LIB]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_hip(force=True, verbose=True))

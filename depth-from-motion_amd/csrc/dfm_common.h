@@ -1,0 +1,182 @@
+// dfm_common.h -- shared device helpers for the gfx950 plane-sweep kernels.
+//
+// Numerics contract (DESIGN.md "Numerics"): all coordinate arithmetic is fp32
+// with exactly one IEEE rounding per reference torch op.  This translation
+// unit is compiled with -ffp-contract=off; fused multiply-adds appear ONLY
+// where written as __builtin_fmaf (they restate the k-ordered fma chain of
+// torch's fp32 (N,4)@(4,4) CPU matmul and of ATen's bilinear accumulation).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dfm_hip.h"
+
+namespace dfm {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v)
+{
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+
+// round-to-nearest-even, NaN -> quiet NaN (same as torch's c10::BFloat16)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+    static constexpr int CB = 4;  // elements per 16-byte channel block
+    static __device__ __forceinline__ float load(float v) { return v; }
+    static __device__ __forceinline__ float store(float v) { return v; }
+};
+template <> struct elem<bf16_t> {
+    static constexpr int CB = 8;
+    static __device__ __forceinline__ float load(bf16_t v) { return bf16_to_f32(v); }
+    static __device__ __forceinline__ bf16_t store(float v) { return f32_to_bf16(v); }
+};
+
+// unpack one 16-byte channel block into CB floats
+__device__ __forceinline__ void unpack16(const uint4 &q, float (&f)[4])
+{
+    f[0] = __uint_as_float(q.x);
+    f[1] = __uint_as_float(q.y);
+    f[2] = __uint_as_float(q.z);
+    f[3] = __uint_as_float(q.w);
+}
+__device__ __forceinline__ void unpack16(const uint4 &q, float (&f)[8])
+{
+    f[0] = __uint_as_float(q.x << 16);
+    f[1] = __uint_as_float(q.x & 0xffff0000u);
+    f[2] = __uint_as_float(q.y << 16);
+    f[3] = __uint_as_float(q.y & 0xffff0000u);
+    f[4] = __uint_as_float(q.z << 16);
+    f[5] = __uint_as_float(q.z & 0xffff0000u);
+    f[6] = __uint_as_float(q.w << 16);
+    f[7] = __uint_as_float(q.w & 0xffff0000u);
+}
+
+// row of (v @ M^T): sum_k v[k]*M[k], k-ordered fma chain
+// (torch fp32 mm on CPU; reference call sites utils.py:208,246 and
+//  dfm_backbone.py:270)
+__device__ __forceinline__ float dot4_chain(float a0, float a1, float a2, float a3,
+                                            const float *__restrict__ M)
+{
+    float acc = a0 * M[0];
+    acc = __builtin_fmaf(a1, M[1], acc);
+    acc = __builtin_fmaf(a2, M[2], acc);
+    acc = __builtin_fmaf(a3, M[3], acc);
+    return acc;
+}
+
+// kernel-side geometry (mirror of dfm_sweep_desc, plus derived sizes)
+struct SweepGeom {
+    int32_t C, h_in, w_in, D, h_out, w_out;
+    int32_t nblk;  // ceil(C / CB)
+    int32_t flip;
+    float fsf, csf, scale, crop_x, crop_y, org_w;
+    long long N;  // D*h_out*w_out
+};
+
+// One lattice point -> UNNORMALISED pixel coordinates in the cur and prev
+// feature maps (what F.grid_sample computes internally from the reference's
+// normalised grid).  Also returns the normalised grid when `norm` != nullptr.
+// Follows dfm_backbone.py:247-294 + ATen grid_sampler_unnormalize op by op.
+__device__ __forceinline__ void sweep_point(const SweepGeom &g, const float *__restrict__ P,
+                                            const float *__restrict__ Pinv,
+                                            const float *__restrict__ Tm, float depth, int hi,
+                                            int wi, float &cx, float &cy, float &px, float &py,
+                                            float *norm)
+{
+    float x = ((float)wi * g.fsf) * g.csf;
+    float y = ((float)hi * g.fsf) * g.csf;
+    x = x + g.crop_x;
+    y = y + g.crop_y;
+    x = x / g.scale;
+    y = y / g.scale;
+    if (g.flip) x = g.org_w - x;
+    // points_img2cam
+    const float h0 = x * depth, h1 = y * depth, h2 = depth;
+    const float X0 = dot4_chain(h0, h1, h2, 1.0f, Pinv + 0);
+    const float X1 = dot4_chain(h0, h1, h2, 1.0f, Pinv + 4);
+    const float X2 = dot4_chain(h0, h1, h2, 1.0f, Pinv + 8);
+    // cur: points_cam2img with the 4x4
+    float a = dot4_chain(X0, X1, X2, 1.0f, P + 0);
+    float b = dot4_chain(X0, X1, X2, 1.0f, P + 4);
+    float c = dot4_chain(X0, X1, X2, 1.0f, P + 8);
+    float cu = a / c, cv = b / c;
+    // prev: cur2prev then project
+    const float Y0 = dot4_chain(X0, X1, X2, 1.0f, Tm + 0);
+    const float Y1 = dot4_chain(X0, X1, X2, 1.0f, Tm + 4);
+    const float Y2 = dot4_chain(X0, X1, X2, 1.0f, Tm + 8);
+    a = dot4_chain(Y0, Y1, Y2, 1.0f, P + 0);
+    b = dot4_chain(Y0, Y1, Y2, 1.0f, P + 4);
+    c = dot4_chain(Y0, Y1, Y2, 1.0f, P + 8);
+    float pu = a / c, pv = b / c;
+    if (g.flip) {
+        cu = g.org_w - cu;
+        pu = g.org_w - pu;
+    }
+    cu = cu * g.scale; cv = cv * g.scale;
+    pu = pu * g.scale; pv = pv * g.scale;
+    cu = cu - g.crop_x; cv = cv - g.crop_y;
+    pu = pu - g.crop_x; pv = pv - g.crop_y;
+    cu = cu / g.fsf; cv = cv / g.fsf;
+    pu = pu / g.fsf; pv = pv / g.fsf;
+    const float wm1 = (float)(g.w_in - 1), hm1 = (float)(g.h_in - 1);
+    const float ncx = cu / wm1 * 2.0f - 1.0f;
+    const float ncy = cv / hm1 * 2.0f - 1.0f;
+    const float npx = pu / wm1 * 2.0f - 1.0f;
+    const float npy = pv / hm1 * 2.0f - 1.0f;
+    if (norm) {
+        norm[0] = ncx; norm[1] = ncy; norm[2] = npx; norm[3] = npy;
+    }
+    // grid_sampler_unnormalize, align_corners=True
+    cx = ((ncx + 1.0f) / 2.0f) * wm1;
+    cy = ((ncy + 1.0f) / 2.0f) * hm1;
+    px = ((npx + 1.0f) / 2.0f) * wm1;
+    py = ((npy + 1.0f) / 2.0f) * hm1;
+}
+
+// Bilinear footprint of one sample point: top-left integer corner, the four
+// corner weights (ATen compute_interp_params) and per-corner in-bounds bits.
+struct Tap {
+    int ix, iy;          // clamped so that (iy, ix) .. (iy+1, ix+1) are addressable
+    float nw, ne, sw, se;
+    uint32_t ok;         // bit0 nw, bit1 ne, bit2 sw, bit3 se
+    int dx, dy;          // 0/1: offset to the east / south tap after clamping
+};
+
+__device__ __forceinline__ Tap make_tap(float x, float y, int H, int W)
+{
+    Tap t;
+    const bool fin = (fabsf(x) <= 3.0e38f) && (fabsf(y) <= 3.0e38f);  // false for NaN/Inf
+    const float xw = floorf(x), yn = floorf(y);
+    const float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
+    t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
+    // in-bounds tests in the float domain (exact for |v| < 2^24; beyond that
+    // everything is out of bounds, like ATen's saturating int conversion)
+    const bool wok = fin && xw >= 0.0f && xw <= (float)(W - 1);
+    const bool eok = fin && xw >= -1.0f && xw <= (float)(W - 2);
+    const bool nok = fin && yn >= 0.0f && yn <= (float)(H - 1);
+    const bool sok = fin && yn >= -1.0f && yn <= (float)(H - 2);
+    t.ok = (uint32_t)(wok && nok) | ((uint32_t)(eok && nok) << 1) | ((uint32_t)(wok && sok) << 2) |
+           ((uint32_t)(eok && sok) << 3);
+    // clamp the corner so every address we form is inside the plane
+    float xc = fminf(fmaxf(xw, 0.0f), (float)(W - 1));
+    float yc = fminf(fmaxf(yn, 0.0f), (float)(H - 1));
+    if (!fin) { xc = 0.0f; yc = 0.0f; }
+    t.ix = (int)xc; t.iy = (int)yc;
+    t.dx = (wok && eok) ? 1 : 0;
+    t.dy = (nok && sok) ? 1 : 0;
+    // when only the east (south) tap is valid the clamped corner IS that tap
+    // (xw == -1 -> xc == 0): its value must be read at +0, see sample().
+    return t;
+}
+
+}  // namespace dfm

@@ -1,0 +1,423 @@
+// plane_sweep.hip -- gfx950 kernels + C ABI for build_dfm_cost
+// (reference: mmdet3d/models/backbones/dfm_backbone.py:217-314).
+//
+// Data layout in HBM
+//   cur/prev  : caller tensors (B, C, H, W), T in {f32, bf16}
+//   workspace : the same two maps re-blocked to [B][nblk][H][W][CB] with
+//               CB*sizeof(T) == 16 B, so ONE 16-byte load fetches CB channels
+//               of a pixel and a row of pixels of one channel block is one
+//               contiguous run (coalesced by a wave, linear for LDS staging).
+//   out       : (B, 2C, D, h_out, w_out) written exactly once.
+//
+// Kernels
+//   pack_blocked_kernel : NCHW -> blocked copy (reads+writes 2*|feats|, <1 %
+//                         of the volume bytes).
+//   sweep_gather_kernel : one lane = one lattice point; loops channel blocks,
+//                         four 16-B taps per map straight from L2/L1.
+//   sweep_bwd_kernel    : scatter-add of grad_out into fp32 feature grads.
+//   sweep_grid_kernel   : parity aid, dumps the normalised grids.
+#include "dfm_common.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+using namespace dfm;
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local int g_last_kernel = 0;
+int g_force_kernel = 0;
+
+// optional per-launch timing of the dominant (volume-writing) kernel with HIP
+// events on the caller's stream (bench.py's roofline leg)
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> ev;  // pairs
+    int used = 0;
+} g_prof;
+
+int fail(int code, const char *fmt, const char *detail = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) return fail(DFM_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// NCHW -> [B][nblk][H][W][CB]
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__ src,
+                                                           uint4 *__restrict__ dst, int C, int HW,
+                                                           int nblk)
+{
+    constexpr int CB = elem<T>::CB;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int blk = blockIdx.y;
+    const int b = blockIdx.z;
+    if (pix >= HW) return;
+    T v[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int c = blk * CB + j;
+        v[j] = (c < C) ? src[((size_t)b * C + c) * HW + pix] : T(0);
+    }
+    uint4 q;
+    memcpy(&q, v, 16);
+    dst[((size_t)b * nblk + blk) * HW + pix] = q;
+}
+
+// ---------------------------------------------------------------------------
+// bilinear blend of four 16-byte channel blocks, ATen order:
+// fma(se_v, se, fma(sw_v, sw, fma(ne_v, ne, nw_v * nw)))
+// ---------------------------------------------------------------------------
+template <int CB>
+__device__ __forceinline__ void blend(const Tap &t, const uint4 &qnw, const uint4 &qne,
+                                      const uint4 &qsw, const uint4 &qse, float (&r)[CB])
+{
+    float a[CB], b[CB], c[CB], d[CB];
+    unpack16(qnw, a);
+    unpack16(qne, b);
+    unpack16(qsw, c);
+    unpack16(qse, d);
+    const bool k0 = t.ok & 1u, k1 = t.ok & 2u, k2 = t.ok & 4u, k3 = t.ok & 8u;
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const float vnw = k0 ? a[j] : 0.0f;
+        const float vne = k1 ? b[j] : 0.0f;
+        const float vsw = k2 ? c[j] : 0.0f;
+        const float vse = k3 ? d[j] : 0.0f;
+        float acc = vnw * t.nw;
+        acc = __builtin_fmaf(vne, t.ne, acc);
+        acc = __builtin_fmaf(vsw, t.sw, acc);
+        acc = __builtin_fmaf(vse, t.se, acc);
+        r[j] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// direct-gather forward: grid (ceil(N/256), B)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sweep_gather_kernel(
+    SweepGeom g, const uint4 *__restrict__ cur_blk, const uint4 *__restrict__ prev_blk,
+    const float *__restrict__ depths, const float *__restrict__ P, const float *__restrict__ Pinv,
+    const float *__restrict__ Tm, T *__restrict__ out)
+{
+    constexpr int CB = elem<T>::CB;
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= g.N) return;
+    const int hw = g.h_out * g.w_out;
+    const int d = (int)(n / hw);
+    const int rem = (int)(n - (long long)d * hw);
+    const int hi = rem / g.w_out;
+    const int wi = rem - hi * g.w_out;
+
+    float cx, cy, px, py;
+    sweep_point(g, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, cx, cy, px, py,
+                nullptr);
+    const Tap tc = make_tap(cx, cy, g.h_in, g.w_in);
+    const Tap tp = make_tap(px, py, g.h_in, g.w_in);
+
+    const int HW = g.h_in * g.w_in;
+    const int c00 = tc.iy * g.w_in + tc.ix, c01 = c00 + tc.dx;
+    const int c10 = c00 + tc.dy * g.w_in, c11 = c10 + tc.dx;
+    const int p00 = tp.iy * g.w_in + tp.ix, p01 = p00 + tp.dx;
+    const int p10 = p00 + tp.dy * g.w_in, p11 = p10 + tp.dx;
+
+    const uint4 *cb = cur_blk + (size_t)b * g.nblk * HW;
+    const uint4 *pb = prev_blk + (size_t)b * g.nblk * HW;
+    T *ocur = out + ((size_t)b * 2 * g.C) * g.N + n;
+    T *oprev = ocur + (size_t)g.C * g.N;
+
+    for (int blk = 0; blk < g.nblk; ++blk) {
+        const uint4 qc0 = cb[c00], qc1 = cb[c01], qc2 = cb[c10], qc3 = cb[c11];
+        const uint4 qp0 = pb[p00], qp1 = pb[p01], qp2 = pb[p10], qp3 = pb[p11];
+        float rc[CB], rp[CB];
+        blend<CB>(tc, qc0, qc1, qc2, qc3, rc);
+        blend<CB>(tp, qp0, qp1, qp2, qp3, rp);
+        const int cbase = blk * CB;
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            if (cbase + j < g.C) {
+                ocur[(size_t)(cbase + j) * g.N] = elem<T>::store(rc[j]);
+                oprev[(size_t)(cbase + j) * g.N] = elem<T>::store(rp[j]);
+            }
+        }
+        cb += HW;
+        pb += HW;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward: grad feats += scatter(grad_out * weights); grid (ceil(N/256), B)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sweep_bwd_kernel(
+    SweepGeom g, const T *__restrict__ gout, const float *__restrict__ depths,
+    const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
+    float *__restrict__ gcur, float *__restrict__ gprev)
+{
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= g.N) return;
+    const int hw = g.h_out * g.w_out;
+    const int d = (int)(n / hw);
+    const int rem = (int)(n - (long long)d * hw);
+    const int hi = rem / g.w_out;
+    const int wi = rem - hi * g.w_out;
+    float cx, cy, px, py;
+    sweep_point(g, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, cx, cy, px, py,
+                nullptr);
+    const Tap tc = make_tap(cx, cy, g.h_in, g.w_in);
+    const Tap tp = make_tap(px, py, g.h_in, g.w_in);
+    const int HW = g.h_in * g.w_in;
+    const int c00 = tc.iy * g.w_in + tc.ix, c01 = c00 + tc.dx;
+    const int c10 = c00 + tc.dy * g.w_in, c11 = c10 + tc.dx;
+    const int p00 = tp.iy * g.w_in + tp.ix, p01 = p00 + tp.dx;
+    const int p10 = p00 + tp.dy * g.w_in, p11 = p10 + tp.dx;
+    const T *gc = gout + ((size_t)b * 2 * g.C) * g.N + n;
+    const T *gp = gc + (size_t)g.C * g.N;
+    float *dc = gcur + (size_t)b * g.C * HW;
+    float *dp = gprev + (size_t)b * g.C * HW;
+    for (int c = 0; c < g.C; ++c) {
+        const float go_c = elem<T>::load(gc[(size_t)c * g.N]);
+        const float go_p = elem<T>::load(gp[(size_t)c * g.N]);
+        if (tc.ok & 1u) atomicAdd(dc + c00, go_c * tc.nw);
+        if (tc.ok & 2u) atomicAdd(dc + c01, go_c * tc.ne);
+        if (tc.ok & 4u) atomicAdd(dc + c10, go_c * tc.sw);
+        if (tc.ok & 8u) atomicAdd(dc + c11, go_c * tc.se);
+        if (tp.ok & 1u) atomicAdd(dp + p00, go_p * tp.nw);
+        if (tp.ok & 2u) atomicAdd(dp + p01, go_p * tp.ne);
+        if (tp.ok & 4u) atomicAdd(dp + p10, go_p * tp.sw);
+        if (tp.ok & 8u) atomicAdd(dp + p11, go_p * tp.se);
+        dc += HW;
+        dp += HW;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// parity aid: normalised grids of sample b
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sweep_grid_kernel(SweepGeom g, int b,
+                                                         const float *__restrict__ depths,
+                                                         const float *__restrict__ P,
+                                                         const float *__restrict__ Pinv,
+                                                         const float *__restrict__ Tm,
+                                                         float *__restrict__ cur_grid,
+                                                         float *__restrict__ prev_grid)
+{
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= g.N) return;
+    const int hw = g.h_out * g.w_out;
+    const int d = (int)(n / hw);
+    const int rem = (int)(n - (long long)d * hw);
+    const int hi = rem / g.w_out;
+    const int wi = rem - hi * g.w_out;
+    float cx, cy, px, py, norm[4];
+    sweep_point(g, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, cx, cy, px, py, norm);
+    cur_grid[2 * n] = norm[0];
+    cur_grid[2 * n + 1] = norm[1];
+    prev_grid[2 * n] = norm[2];
+    prev_grid[2 * n + 1] = norm[3];
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+int check_desc(const dfm_sweep_desc *d)
+{
+    if (!d) return fail(DFM_ERR_INVALID_ARG, "desc is NULL%s");
+    if (d->batch <= 0 || d->channels <= 0 || d->h_in <= 0 || d->w_in <= 0 || d->num_depths <= 0 ||
+        d->h_out <= 0 || d->w_out <= 0)
+        return fail(DFM_ERR_INVALID_ARG, "non-positive size in dfm_sweep_desc%s");
+    if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
+        return fail(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16%s");
+    if ((long long)d->h_in * d->w_in >= (1ll << 31) / 64)
+        return fail(DFM_ERR_UNSUPPORTED, "feature map too large for 32-bit tap offsets%s");
+    if (d->batch > 65535) return fail(DFM_ERR_UNSUPPORTED, "batch > 65535%s");
+    return DFM_OK;
+}
+
+SweepGeom make_geom(const dfm_sweep_desc *d)
+{
+    SweepGeom g;
+    g.C = d->channels;
+    g.h_in = d->h_in;
+    g.w_in = d->w_in;
+    g.D = d->num_depths;
+    g.h_out = d->h_out;
+    g.w_out = d->w_out;
+    const int CB = d->dtype == DFM_BF16 ? 8 : 4;
+    g.nblk = (d->channels + CB - 1) / CB;
+    g.flip = d->flip;
+    g.fsf = d->feat_sample_factor;
+    g.csf = d->cost_sample_factor;
+    g.scale = d->img_scale_factor;
+    g.crop_x = d->crop_x;
+    g.crop_y = d->crop_y;
+    g.org_w = d->org_w;
+    g.N = (long long)d->num_depths * d->h_out * d->w_out;
+    return g;
+}
+
+size_t blocked_bytes(const dfm_sweep_desc *d)
+{
+    const int CB = d->dtype == DFM_BF16 ? 8 : 4;
+    const size_t nblk = (d->channels + CB - 1) / CB;
+    size_t one = (size_t)d->batch * nblk * d->h_in * d->w_in * 16;
+    return (one + 255) & ~(size_t)255;
+}
+
+template <typename T>
+int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const float *depths,
+               const float *P, const float *Pinv, const float *Tm, void *out, void *ws,
+               hipStream_t st)
+{
+    const SweepGeom g = make_geom(d);
+    const int HW = d->h_in * d->w_in;
+    uint4 *cur_blk = (uint4 *)ws;
+    uint4 *prev_blk = (uint4 *)((char *)ws + blocked_bytes(d));
+    dim3 pg((HW + 255) / 256, g.nblk, d->batch);
+    hipLaunchKernelGGL(pack_blocked_kernel<T>, pg, dim3(256), 0, st, (const T *)cur, cur_blk, g.C,
+                       HW, g.nblk);
+    hipLaunchKernelGGL(pack_blocked_kernel<T>, pg, dim3(256), 0, st, (const T *)prev, prev_blk,
+                       g.C, HW, g.nblk);
+    const long long nb = (g.N + 255) / 256;
+    if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
+    dim3 grid((unsigned)nb, d->batch);
+    const bool timed = g_prof.on && g_prof.used + 2 <= (int)g_prof.ev.size();
+    if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+    hipLaunchKernelGGL(sweep_gather_kernel<T>, grid, dim3(256), 0, st, g, cur_blk, prev_blk, depths,
+                       P, Pinv, Tm, (T *)out);
+    if (timed) {
+        (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+        g_prof.used += 2;
+    }
+    g_last_kernel = 1;
+    HIP_TRY(hipGetLastError());
+    return DFM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+DFM_API int dfm_version(void) { return 1; }
+DFM_API const char *dfm_last_error(void) { return g_err; }
+DFM_API int dfm_plane_sweep_last_kernel(void) { return g_last_kernel; }
+DFM_API void dfm_plane_sweep_force_kernel(int which) { g_force_kernel = which; }
+
+DFM_API int dfm_profile_begin(int max_launches)
+{
+    if (max_launches <= 0 || max_launches > 65536)
+        return fail(DFM_ERR_INVALID_ARG, "max_launches out of range%s");
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.assign(2 * (size_t)max_launches, nullptr);
+    for (auto &e : g_prof.ev) HIP_TRY(hipEventCreate(&e));
+    g_prof.used = 0;
+    g_prof.on = true;
+    return DFM_OK;
+}
+
+DFM_API int dfm_profile_end(double *total_ms, int *launches)
+{
+    if (!total_ms || !launches) return fail(DFM_ERR_INVALID_ARG, "NULL output%s");
+    g_prof.on = false;
+    double sum = 0.0;
+    for (int i = 0; i + 1 < g_prof.used; i += 2) {
+        HIP_TRY(hipEventSynchronize(g_prof.ev[i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = g_prof.used / 2;
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.used = 0;
+    return DFM_OK;
+}
+
+DFM_API size_t dfm_plane_sweep_workspace_bytes(const dfm_sweep_desc *desc)
+{
+    if (check_desc(desc) != DFM_OK) return 0;
+    return 2 * blocked_bytes(desc);
+}
+
+DFM_API int dfm_plane_sweep_fwd(const dfm_sweep_desc *desc, const void *cur, const void *prev,
+                                const float *depths, const float *cam2img,
+                                const float *cam2img_inv, const float *cur2prev, void *out,
+                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_desc(desc);
+    if (rc != DFM_OK) return rc;
+    if (!cur || !prev || !depths || !cam2img || !cam2img_inv || !cur2prev || !out)
+        return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
+    if (!workspace || workspace_bytes < 2 * blocked_bytes(desc))
+        return fail(DFM_ERR_WORKSPACE, "workspace smaller than dfm_plane_sweep_workspace_bytes%s");
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)out & 1))
+        return fail(DFM_ERR_INVALID_ARG, "workspace must be 16-byte aligned%s");
+    hipStream_t st = (hipStream_t)stream;
+    if (desc->dtype == DFM_F32)
+        return launch_fwd<float>(desc, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out,
+                                 workspace, st);
+    return launch_fwd<bf16_t>(desc, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out,
+                              workspace, st);
+}
+
+DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out,
+                                const float *depths, const float *cam2img,
+                                const float *cam2img_inv, const float *cur2prev, float *grad_cur,
+                                float *grad_prev, void *stream)
+{
+    int rc = check_desc(desc);
+    if (rc != DFM_OK) return rc;
+    if (!grad_out || !depths || !cam2img || !cam2img_inv || !cur2prev || !grad_cur || !grad_prev)
+        return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
+    const SweepGeom g = make_geom(desc);
+    const long long nb = (g.N + 255) / 256;
+    if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
+    dim3 grid((unsigned)nb, desc->batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (desc->dtype == DFM_F32)
+        hipLaunchKernelGGL(sweep_bwd_kernel<float>, grid, dim3(256), 0, st, g,
+                           (const float *)grad_out, depths, cam2img, cam2img_inv, cur2prev,
+                           grad_cur, grad_prev);
+    else
+        hipLaunchKernelGGL(sweep_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, g,
+                           (const bf16_t *)grad_out, depths, cam2img, cam2img_inv, cur2prev,
+                           grad_cur, grad_prev);
+    HIP_TRY(hipGetLastError());
+    return DFM_OK;
+}
+
+DFM_API int dfm_plane_sweep_grid(const dfm_sweep_desc *desc, int32_t b, const float *depths,
+                                 const float *cam2img, const float *cam2img_inv,
+                                 const float *cur2prev, float *cur_grid, float *prev_grid,
+                                 void *stream)
+{
+    int rc = check_desc(desc);
+    if (rc != DFM_OK) return rc;
+    if (b < 0 || b >= desc->batch) return fail(DFM_ERR_INVALID_ARG, "sample index out of range%s");
+    if (!depths || !cam2img || !cam2img_inv || !cur2prev || !cur_grid || !prev_grid)
+        return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
+    const SweepGeom g = make_geom(desc);
+    const long long nb = (g.N + 255) / 256;
+    if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
+    hipLaunchKernelGGL(sweep_grid_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g,
+                       b, depths, cam2img, cam2img_inv, cur2prev, cur_grid, prev_grid);
+    HIP_TRY(hipGetLastError());
+    return DFM_OK;
+}
+
+}  // extern "C"

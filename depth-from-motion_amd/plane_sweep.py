@@ -1,0 +1,197 @@
+"""Host-side mirror of the reference's ``build_dfm_cost``
+(mmdet3d/models/backbones/dfm_backbone.py:217-314): same name, arguments and
+argument meaning; the body is one call into the HIP library.
+
+Differences from the reference, all deliberate and documented in DESIGN.md:
+  * B > 1 is supported with the obviously intended per-sample semantics (the
+    reference loop is only correct for B == 1, dfm_backbone.py:257-275).
+  * non-finite sampling coordinates (a plane exactly through the camera
+    centre) give 0 like torch's GPU grid_sample; torch's CPU kernel gives NaN.
+"""
+import ctypes
+
+import torch
+
+from . import _capi
+
+_DTYPES = {torch.float32: _capi.DFM_F32, torch.bfloat16: _capi.DFM_BF16}
+
+
+def _require_gpu(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f'{name} must live on the GPU: depth-from-motion_amd has no CPU path '
+            '(the HIP kernels are the product; the CPU oracle is test-only)')
+
+
+def _pad4x4(m):
+    """pad (3,3)/(3,4)/(4,4) to the 4x4 the reference builds in
+    points_img2cam / points_cam2img (utils.py:199-203, 239-240)."""
+    out = torch.eye(4, dtype=torch.float32)
+    m = m[:3] if m.shape[0] == 4 else m
+    out[:m.shape[0], :m.shape[1]] = m
+    return out
+
+
+def camera_matrices(cam2imgs, cur2prevs, batch_size, device):
+    """(B,16) fp32 device tensors: padded cam2img, its fp32 inverse, cur2prev.
+
+    The inverse is taken on the host with torch.inverse in fp32, exactly the
+    op the reference's PyTorch-CPU path runs (utils.py:241); it is 16 floats
+    per sample, not a hot path.
+    """
+    cam2imgs = torch.as_tensor(cam2imgs, dtype=torch.float32).detach().cpu()
+    cur2prevs = torch.as_tensor(cur2prevs, dtype=torch.float32).detach().cpu()
+    P = torch.stack([_pad4x4(cam2imgs[i]) for i in range(batch_size)])
+    Pinv = torch.stack([torch.inverse(P[i]) for i in range(batch_size)])
+    T = torch.stack([cur2prevs[i] for i in range(batch_size)]).contiguous()
+    pack = torch.stack([P, Pinv, T]).reshape(3, batch_size, 16).contiguous()
+    pack = pack.to(device, non_blocking=True)
+    return pack[0], pack[1], pack[2]
+
+
+def _make_desc(cur_feats, num_depths, feat_sample_factor, cost_sample_factor, img_shape, flip,
+               img_crop_offset, img_scale_factor):
+    batch_size, channels, h_in, w_in = cur_feats.shape
+    desc = _capi.SweepDesc()
+    desc.batch, desc.channels, desc.h_in, desc.w_in = batch_size, channels, h_in, w_in
+    desc.num_depths = num_depths
+    # Python round (banker's), dfm_backbone.py:242-243
+    desc.h_out = round(h_in / cost_sample_factor)
+    desc.w_out = round(w_in / cost_sample_factor)
+    desc.feat_sample_factor = float(feat_sample_factor)
+    desc.cost_sample_factor = float(cost_sample_factor)
+    desc.img_scale_factor = float(img_scale_factor)
+    desc.crop_x = float(img_crop_offset[0])
+    desc.crop_y = float(img_crop_offset[1])
+    desc.org_w = float(img_shape[1])
+    desc.flip = 1 if flip else 0
+    desc.dtype = _DTYPES[cur_feats.dtype]
+    return desc
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _Workspace:
+    """Per-device scratch for the blocked feature copies, grown on demand and
+    kept so that the steady state allocates nothing."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, device, nbytes):
+        buf = cls._bufs.get(device)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            cls._bufs[device] = buf
+        return buf
+
+
+def plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T, out=None):
+    """Raw launch: everything already on the device."""
+    lib = _capi.lib()
+    device = cur_feats.device
+    if out is None:
+        out = torch.empty((desc.batch, 2 * desc.channels, desc.num_depths, desc.h_out, desc.w_out),
+                          dtype=cur_feats.dtype, device=device)
+    nbytes = lib.dfm_plane_sweep_workspace_bytes(ctypes.byref(desc))
+    ws = _Workspace.get(device, nbytes)
+    with torch.cuda.device(device):
+        _capi.check(
+            lib.dfm_plane_sweep_fwd(ctypes.byref(desc), _ptr(cur_feats), _ptr(prev_feats),
+                                    _ptr(depths), _ptr(P), _ptr(Pinv), _ptr(T), _ptr(out), _ptr(ws),
+                                    nbytes, _stream_ptr(device)))
+    return out
+
+
+class _PlaneSweepFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, cur_feats, prev_feats, depths, P, Pinv, T, desc):
+        ctx.desc = desc
+        ctx.save_for_backward(depths, P, Pinv, T)
+        ctx.in_dtype = cur_feats.dtype
+        return plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        depths, P, Pinv, T = ctx.saved_tensors
+        desc = ctx.desc
+        lib = _capi.lib()
+        grad_out = grad_out.contiguous()
+        device = grad_out.device
+        shape = (desc.batch, desc.channels, desc.h_in, desc.w_in)
+        g_cur = torch.zeros(shape, dtype=torch.float32, device=device)
+        g_prev = torch.zeros(shape, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            _capi.check(
+                lib.dfm_plane_sweep_bwd(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P),
+                                        _ptr(Pinv), _ptr(T), _ptr(g_cur), _ptr(g_prev),
+                                        _stream_ptr(device)))
+        return g_cur.to(ctx.in_dtype), g_prev.to(ctx.in_dtype), None, None, None, None, None
+
+
+def build_dfm_cost(cur_feats,
+                   prev_feats,
+                   depths,
+                   feat_sample_factor,
+                   cost_sample_factor,
+                   cam2imgs,
+                   cur2prevs,
+                   img_shape,
+                   flip=False,
+                   img_crop_offset=(0, 0),
+                   img_scale_factor=1.0):
+    """Plane-sweep cost volume, drop-in for the reference function.
+
+    Args:
+        cur_feats/prev_feats: [B, C, H, W] fp32 or bf16, on the GPU
+        depths: [D] or [1, D]
+        cam2imgs: [B, 4, 4] original intrinsics (``ori_cam2img``)
+        cur2prevs: [>=B, 4, 4]; indexed by the batch index like the reference
+            (dfm_backbone.py:270)
+        img_shape: (org_h, org_w) of the original image (flip only)
+
+    Returns:
+        cost_volume: [B, 2C, D, H_out, W_out], same dtype as the inputs
+    """
+    _require_gpu(cur_feats, 'cur_feats')
+    _require_gpu(prev_feats, 'prev_feats')
+    if cur_feats.dtype not in _DTYPES or prev_feats.dtype != cur_feats.dtype:
+        raise TypeError('cur_feats/prev_feats must both be float32 or bfloat16')
+    assert cur_feats.dim() == 4 and cur_feats.shape == prev_feats.shape
+    device = cur_feats.device
+    cur_feats = cur_feats.contiguous()
+    prev_feats = prev_feats.contiguous()
+    depths = depths.reshape(-1).to(device=device, dtype=torch.float32).contiguous()
+    batch_size = cur_feats.shape[0]
+    desc = _make_desc(cur_feats, depths.numel(), feat_sample_factor, cost_sample_factor, img_shape,
+                      flip, img_crop_offset, img_scale_factor)
+    P, Pinv, T = camera_matrices(cam2imgs, cur2prevs, batch_size, device)
+    return _PlaneSweepFn.apply(cur_feats, prev_feats, depths, P, Pinv, T, desc)
+
+
+def plane_sweep_grid(cur_feats, depths, feat_sample_factor, cost_sample_factor, cam2imgs, cur2prevs,
+                     img_shape, flip=False, img_crop_offset=(0, 0), img_scale_factor=1.0, sample=0):
+    """Parity aid: the normalised (cur_grid, prev_grid), each (D*H_out*W_out, 2),
+    that the reference feeds to F.grid_sample (dfm_backbone.py:291-294)."""
+    _require_gpu(cur_feats, 'cur_feats')
+    lib = _capi.lib()
+    device = cur_feats.device
+    depths = depths.reshape(-1).to(device=device, dtype=torch.float32).contiguous()
+    desc = _make_desc(cur_feats, depths.numel(), feat_sample_factor, cost_sample_factor, img_shape,
+                      flip, img_crop_offset, img_scale_factor)
+    P, Pinv, T = camera_matrices(cam2imgs, cur2prevs, cur_feats.shape[0], device)
+    n = desc.num_depths * desc.h_out * desc.w_out
+    cur_grid = torch.empty((n, 2), dtype=torch.float32, device=device)
+    prev_grid = torch.empty((n, 2), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _capi.check(
+            lib.dfm_plane_sweep_grid(ctypes.byref(desc), sample, _ptr(depths), _ptr(P), _ptr(Pinv),
+                                     _ptr(T), _ptr(cur_grid), _ptr(prev_grid), _stream_ptr(device)))
+    return cur_grid, prev_grid

@@ -1,0 +1,146 @@
+/*
+ * dfm_hip.h -- C ABI of libdfm_hip.so: the MI355X (gfx950) plane-sweep
+ * cost-volume path of Depth-from-Motion.
+ *
+ * Drop-in boundary.  The reference has no FFI of its own -- its hot path is
+ * Python calling torch ops -- so each entry point below replaces the torch-op
+ * sequence of one reference function and is what a maintainer binds (ctypes,
+ * see INTEGRATION.md) from inside that function:
+ *
+ *   dfm_plane_sweep_fwd      <- build_dfm_cost
+ *                               mmdet3d/models/backbones/dfm_backbone.py:217-314
+ *   dfm_plane_sweep_bwd      <- autograd of the two F.grid_sample calls,
+ *                               dfm_backbone.py:296-311
+ *   dfm_point_sample_mv_fwd  <- point_sample x (frames x views) + view/frame
+ *                               reduction, fusion_layers/point_fusion.py:14-106
+ *                               and detectors/multiview_dfm.py:119-208
+ *   dfm_frustum_to_voxel_fwd <- FrustumToVoxel.forward sampling stage
+ *                               necks/feature_transformation.py:82-158
+ *   dfm_depth_head_fwd       <- DepthHead.forward (upsample x4 trilinear,
+ *                               softmax over depth, expectation)
+ *                               dense_heads/depth_head.py:205-210
+ *
+ * Conventions
+ *   - plain C: device pointers are `void*` / `float*` (hipMalloc'ed or a torch
+ *     tensor's data_ptr()), sizes are explicit, no torch types.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the null stream) and re-entrant per device.
+ *   - return value: DFM_OK (0) or a negative dfm_status; never throws.
+ *     dfm_last_error() returns a thread-local message for the last failure.
+ *   - dtype: DFM_F32 or DFM_BF16 is the storage type of feature/volume
+ *     tensors; coordinates, weights and accumulation are always fp32.
+ *   - arithmetic: sampling coordinates follow the reference's fp32 operation
+ *     order (one rounding per torch op, fma chains where torch.mm uses them)
+ *     so DFM_F32 results are bit-identical to the reference's PyTorch-CPU
+ *     output for finite coordinates (see DESIGN.md "Numerics").
+ */
+#ifndef DFM_HIP_H
+#define DFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFM_API __attribute__((visibility("default")))
+
+typedef enum dfm_status {
+    DFM_OK = 0,
+    DFM_ERR_INVALID_ARG = -1,
+    DFM_ERR_UNSUPPORTED = -2,
+    DFM_ERR_WORKSPACE = -3,
+    DFM_ERR_HIP = -4
+} dfm_status;
+
+typedef enum dfm_dtype { DFM_F32 = 0, DFM_BF16 = 1 } dfm_dtype;
+
+/* ---------------------------------------------------------------------- */
+/* library                                                                 */
+/* ---------------------------------------------------------------------- */
+DFM_API int dfm_version(void);            /* ABI version, currently 1     */
+DFM_API const char *dfm_last_error(void); /* thread-local, never NULL     */
+
+/* Per-launch device timing of the volume-writing kernel, measured with HIP
+ * events recorded on the caller's stream around that kernel only (not the
+ * small re-blocking pre-pass).  begin() arms up to max_launches pairs;
+ * end() waits for them and returns the summed kernel time and the count. */
+DFM_API int dfm_profile_begin(int max_launches);
+DFM_API int dfm_profile_end(double *total_ms, int *launches);
+
+/* ---------------------------------------------------------------------- */
+/* plane sweep (build_dfm_cost)                                            */
+/* ---------------------------------------------------------------------- */
+
+/* Geometry of one plane-sweep call.  Field meaning = the reference
+ * arguments of build_dfm_cost (dfm_backbone.py:217-227). */
+typedef struct dfm_sweep_desc {
+    int32_t batch;      /* B                                               */
+    int32_t channels;   /* C of cur/prev feats; output has 2C              */
+    int32_t h_in, w_in; /* feature map size                                */
+    int32_t num_depths; /* D                                               */
+    int32_t h_out, w_out; /* round(h_in/csf), round(w_in/csf) (caller)     */
+    float feat_sample_factor;
+    float cost_sample_factor;
+    float img_scale_factor;
+    float crop_x, crop_y; /* img_crop_offset                               */
+    float org_w;          /* img_shape[1], only used when flip             */
+    int32_t flip;
+    int32_t dtype;        /* dfm_dtype of cur/prev/out                     */
+} dfm_sweep_desc;
+
+/* Scratch the call needs (blocked copy of the two feature maps). */
+DFM_API size_t dfm_plane_sweep_workspace_bytes(const dfm_sweep_desc *desc);
+
+/*
+ * cur, prev : (B, C, h_in, w_in) contiguous, desc->dtype          [device]
+ * depths    : (D) fp32                                           [device]
+ * cam2img   : (B, 16) fp32, ori_cam2img padded to 4x4, row major [device]
+ * cam2img_inv: (B, 16) fp32, inverse of the above (the reference computes
+ *             it with torch.inverse in fp32, utils.py:239-241)   [device]
+ * cur2prev  : (B, 16) fp32 row major                              [device]
+ * out       : (B, 2C, D, h_out, w_out) contiguous, desc->dtype    [device]
+ * workspace : >= dfm_plane_sweep_workspace_bytes(desc), 256-B aligned
+ *
+ * Semantics for B > 1: sample b uses cam2img[b], cur2prev[b]; the
+ * augmentation scalars in `desc` are shared (the reference's caller passes
+ * img_metas[0]'s, dfm_backbone.py:169-172).  The reference loop itself is
+ * only correct for B == 1 (:257-275); B > 1 here == the reference looped
+ * over single-sample batches.
+ */
+DFM_API int dfm_plane_sweep_fwd(const dfm_sweep_desc *desc, const void *cur, const void *prev,
+                                const float *depths, const float *cam2img,
+                                const float *cam2img_inv, const float *cur2prev, void *out,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Backward of the two bilinear samplings w.r.t. the feature maps.
+ * grad_out : (B, 2C, D, h_out, w_out) desc->dtype
+ * grad_cur, grad_prev : (B, C, h_in, w_in) FP32, must be zero-filled by the
+ *   caller (the kernel accumulates with atomics); cast to bf16 by the caller
+ *   if needed.
+ */
+DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out,
+                                const float *depths, const float *cam2img,
+                                const float *cam2img_inv, const float *cur2prev,
+                                float *grad_cur, float *grad_prev, void *stream);
+
+/* Debug/parity aid: the normalised sampling grids the reference hands to
+ * F.grid_sample (dfm_backbone.py:291-294) for sample `b`:
+ * cur_grid, prev_grid : (D*h_out*w_out, 2) fp32 [device]. */
+DFM_API int dfm_plane_sweep_grid(const dfm_sweep_desc *desc, int32_t b, const float *depths,
+                                 const float *cam2img, const float *cam2img_inv,
+                                 const float *cur2prev, float *cur_grid, float *prev_grid,
+                                 void *stream);
+
+/* Which kernel the last dfm_plane_sweep_fwd on this thread dispatched:
+ * 0 = none yet, 1 = direct-gather kernel, 2 = LDS-staged kernel. */
+DFM_API int dfm_plane_sweep_last_kernel(void);
+/* Force a kernel for A/B measurements: 0 = auto, 1 = gather, 2 = LDS. */
+DFM_API void dfm_plane_sweep_force_kernel(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFM_HIP_H */

@@ -1,0 +1,111 @@
+"""numpy front-end of libdfm_oracle.so -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  The C file restates the reference's fp32 algorithm
+(oracle/dfm_oracle.c cites file:line); this wrapper only marshals arrays.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'libdfm_oracle.so')
+
+
+def build(force=False):
+    """gcc -O2 -ffp-contract=off ... (oracle/Makefile)."""
+    src = os.path.join(_HERE, 'dfm_oracle.c')
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-s', '-B', 'libdfm_oracle.so'])
+    return _SO
+
+
+class SweepParams(ctypes.Structure):
+    """struct dfm_oracle_sweep_params"""
+    _fields_ = [('D', ctypes.c_int32), ('h_out', ctypes.c_int32), ('w_out', ctypes.c_int32),
+                ('h_in', ctypes.c_int32), ('w_in', ctypes.c_int32), ('fsf', ctypes.c_float),
+                ('csf', ctypes.c_float), ('scale', ctypes.c_float), ('crop_x', ctypes.c_float),
+                ('crop_y', ctypes.c_float), ('flip', ctypes.c_int32), ('org_w', ctypes.c_float),
+                ('P', ctypes.c_float * 16), ('Pinv', ctypes.c_float * 16),
+                ('T', ctypes.c_float * 16)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.dfm_oracle_version.restype = ctypes.c_int
+    return _lib
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def sweep_params(h_in, w_in, num_depths, fsf, csf, P, Pinv, T, img_shape, flip, crop, scale):
+    p = SweepParams()
+    p.D, p.h_in, p.w_in = int(num_depths), int(h_in), int(w_in)
+    p.h_out, p.w_out = round(h_in / csf), round(w_in / csf)  # dfm_backbone.py:242-243
+    p.fsf, p.csf, p.scale = float(fsf), float(csf), float(scale)
+    p.crop_x, p.crop_y = float(crop[0]), float(crop[1])
+    p.flip, p.org_w = int(bool(flip)), float(img_shape[1])
+    for name, m in (('P', P), ('Pinv', Pinv), ('T', T)):
+        arr = getattr(p, name)
+        for i, v in enumerate(_f32(m).reshape(16)):
+            arr[i] = float(v)
+    return p
+
+
+def plane_sweep_grid(p, depths):
+    n = p.D * p.h_out * p.w_out
+    cg = np.empty((n, 2), np.float32)
+    pg = np.empty((n, 2), np.float32)
+    depths = _f32(depths)
+    lib().dfm_oracle_plane_sweep_grid(ctypes.byref(p), _vp(depths), _vp(cg), _vp(pg))
+    return cg, pg
+
+
+def build_dfm_cost(cur, prev, depths, fsf, csf, P, Pinv, T, img_shape, flip=False, crop=(0, 0),
+                   scale=1.0):
+    """cur/prev (B,C,H,W) fp32; P/Pinv/T (B,4,4); -> (B,2C,D,h_out,w_out).
+    The batch is looped with single-sample reference semantics."""
+    cur, prev, depths = _f32(cur), _f32(prev), _f32(depths).reshape(-1)
+    B, C, H, W = cur.shape
+    outs = []
+    for b in range(B):
+        p = sweep_params(H, W, depths.size, fsf, csf, P[b], Pinv[b], T[b], img_shape, flip, crop,
+                         scale)
+        out = np.empty((2 * C, p.D, p.h_out, p.w_out), np.float32)
+        lib().dfm_oracle_build_dfm_cost(ctypes.byref(p), _vp(depths), _vp(cur[b]), _vp(prev[b]),
+                                        ctypes.c_int(C), _vp(out))
+        outs.append(out)
+    return np.stack(outs)
+
+
+def grid_sample2d(inp, grid, mode='bilinear'):
+    """inp (C,H,W), grid (N,2) normalised -> (C,N); zeros, align_corners=True."""
+    inp, grid = _f32(inp), _f32(grid)
+    C, H, W = inp.shape
+    out = np.empty((C, grid.shape[0]), np.float32)
+    lib().dfm_oracle_grid_sample2d(_vp(inp), C, H, W, _vp(grid), ctypes.c_int64(grid.shape[0]),
+                                   0 if mode == 'bilinear' else 1, _vp(out))
+    return out
+
+
+def bf16_round(a):
+    """fp32 -> bf16 (round-to-nearest-even) -> fp32, numpy."""
+    u = _f32(a).view(np.uint32)
+    nan = (u & 0x7fffffff) > 0x7f800000
+    r = (u + (0x7fff + ((u >> 16) & 1))) & 0xffff0000
+    r = np.where(nan, np.uint32(0x7fc00000), r).astype(np.uint32)
+    return r.view(np.float32)

@@ -1,0 +1,166 @@
+"""Generate golden fixtures by running the REFERENCE's own code on PyTorch-CPU.
+
+Run in the build container only (needs /root/reference, which does not exist
+on the GPU box):   python tests/golden/make_golden.py
+
+The reference cannot be imported as a package (mmcv / mmdet are not
+installed), so its functions are lifted from their source files by AST and
+exec'd UNMODIFIED; nothing of the reference is copied into this repo -- only
+inputs and the outputs it produced are stored (tests/golden/*.npz).
+
+Pinned here:
+  * plane_sweep_*.npz : build_dfm_cost (dfm_backbone.py:217-314) outputs AND
+    the normalised grids it passes to F.grid_sample, on seeded inputs with
+    flip / crop / scale / cost_sample_factor variants and a pose that sends
+    part of the sweep behind the camera.
+  * helpers.npz : the reference tests' own golden vectors for points_cam2img
+    (tests/test_utils/test_box3d.py:1653-1680), points_img2cam
+    (tests/test_utils/test_utils.py:186-193) and point_sample
+    (tests/test_models/test_fusion/test_point_fusion.py:13-61), re-derived by
+    running the reference functions so the fixture carries inputs + outputs.
+"""
+import ast
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = '/root/reference/mmdet3d/'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def extract(path, names, glb):
+    """exec the named top-level functions of a reference file, decorators off"""
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            node.decorator_list = []
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, 'exec'), glb)
+    return glb
+
+
+def load_reference():
+    g = {'torch': torch, 'F': F, 'np': np, 'nn': torch.nn}
+    extract(REF + 'core/bbox/structures/utils.py', ['points_cam2img', 'points_img2cam'], g)
+    extract(REF + 'models/backbones/dfm_backbone.py', ['build_dfm_cost'], g)
+    g['apply_3d_transformation'] = lambda pts, coord_type, img_meta, reverse=False: pts
+    extract(REF + 'models/fusion_layers/point_fusion.py', ['point_sample'], g)
+    return g
+
+
+KITTI_P2 = [[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791],
+            [0, 0, 1, 0.002745884], [0, 0, 0, 1]]
+
+
+def pose(yaw_deg, tx, ty, tz):
+    c, s = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
+    return [[c, 0, s, tx], [0, 1, 0, ty], [-s, 0, c, tz], [0, 0, 0, 1]]
+
+
+# name, C, H, W, D, fsf, csf, flip, crop, scale, pose, depth range
+SWEEP_CASES = [
+    ('nstar_like', 5, 24, 78, 6, 16, 1, False, (0, 0), 1.0, pose(1.3, 0.05, 0.01, -1.1), (2, 59.6)),
+    ('kitti_like', 4, 48, 160, 5, 1, 4, False, (0, 55), 1.0, pose(-0.7, -0.03, 0.0, -0.8), (2, 59.6)),
+    ('flip_crop_scale', 3, 24, 78, 4, 16, 1, True, (11, 55), 1.03, pose(2.0, 0.1, -0.02, -1.4),
+     (2, 59.6)),
+    ('kitti_flip_f32scale', 3, 48, 160, 4, 1, 4, True, (7, 55), np.float32(0.97),
+     pose(0.4, 0.0, 0.0, -0.5), (2, 59.6)),
+    # cur2prev pushes the nearest planes behind the previous camera (z <= 0
+    # after the warp): unguarded divide in the reference, zeros from padding
+    ('behind_camera', 3, 24, 78, 6, 16, 1, False, (0, 0), 1.0, pose(5.0, 0.3, 0.0, -9.0), (2, 20)),
+    ('odd_channels_bigshift', 9, 20, 64, 3, 8, 2, False, (3, 5), 1.0, pose(-8.0, 1.5, 0.2, 2.5),
+     (2, 40)),
+]
+
+
+def make_sweep(g):
+    captured = []
+    orig = F.grid_sample
+
+    def capture(inp, grid, **kw):
+        captured.append(grid.clone())
+        return orig(inp, grid, **kw)
+
+    for i, (name, C, H, W, D, fsf, csf, flip, crop, scale, T, (dmin, dmax)) in enumerate(SWEEP_CASES):
+        gen = torch.Generator().manual_seed(100 + i)
+        cur = torch.randn(1, C, H, W, generator=gen)
+        prev = torch.randn(1, C, H, W, generator=gen)
+        depths = torch.tensor([dmin + (k + 0.5) * ((dmax - dmin) / D) for k in range(D)],
+                              dtype=torch.float32)
+        P = torch.tensor(KITTI_P2, dtype=torch.float32)
+        Tm = torch.tensor(T, dtype=torch.float32)
+        captured.clear()
+        F.grid_sample = capture
+        try:
+            out = g['build_dfm_cost'](cur, prev, depths, fsf, csf, P[None], Tm[None], (375, 1242),
+                                      flip, crop, scale)
+        finally:
+            F.grid_sample = orig
+        Ppad = torch.eye(4)
+        Ppad[:3, :4] = P[:3]
+        np.savez_compressed(
+            os.path.join(HERE, f'plane_sweep_{name}.npz'),
+            cur=cur.numpy(), prev=prev.numpy(), depths=depths.numpy(), P=P.numpy(),
+            Pinv=torch.inverse(Ppad).numpy(), T=Tm.numpy(), fsf=np.float64(fsf),
+            csf=np.float64(csf), flip=np.bool_(flip), crop=np.asarray(crop, np.float64),
+            scale=np.float64(scale), img_shape=np.asarray((375, 1242)),
+            ref_out=out.numpy(), ref_cur_grid=captured[0].numpy().reshape(-1, 2),
+            ref_prev_grid=captured[1].numpy().reshape(-1, 2))
+        print(name, tuple(out.shape), 'nan:', int(torch.isnan(out).sum()))
+
+
+def make_helpers(g):
+    d = {}
+    # points_cam2img golden (reference tests/test_utils/test_box3d.py:1653-1680)
+    torch.manual_seed(0)  # the reference test calls set_random_seed(0)
+    np.random.seed(0)
+    points = torch.rand([5, 3])
+    proj_mat = torch.rand([4, 4])
+    d['cam2img_points'] = points.numpy()
+    d['cam2img_proj'] = proj_mat.numpy()
+    d['cam2img_out'] = g['points_cam2img'](points, proj_mat).numpy()
+    d['cam2img_out_depth'] = g['points_cam2img'](points, proj_mat, with_depth=True).numpy()
+    d['cam2img_expected'] = np.array([[0.5832, 0.6496], [0.6146, 0.7910], [0.6994, 0.7782],
+                                      [0.5623, 0.6303], [0.4359, 0.6532]], np.float32)
+    # points_img2cam golden (reference tests/test_utils/test_utils.py:186-193)
+    pts = torch.tensor([[0.5764, 0.9109, 0.7576], [0.6656, 0.5498, 0.9813]])
+    cam2img = torch.tensor([[700., 0., 450., 0.], [0., 700., 200., 0.], [0., 0., 1., 0.]])
+    d['img2cam_points'] = pts.numpy()
+    d['img2cam_cam2img'] = cam2img.numpy()
+    d['img2cam_out'] = g['points_img2cam'](pts, cam2img).numpy()
+    d['img2cam_expected'] = np.array([[-0.4864, -0.2155, 0.7576], [-0.6299, -0.2796, 0.9813]],
+                                     np.float32)
+    # point_sample golden (reference tests/test_models/test_fusion/test_point_fusion.py:13-40)
+    img_meta = {'img_shape': (370, 1224), 'pad_shape': (370, 1224), 'ori_shape': (370, 1224)}
+    lidar2img = torch.tensor([[6.0294e+02, -7.0791e+02, -1.2275e+01, -1.7094e+02],
+                              [1.7678e+02, 8.8088e+00, -7.0794e+02, -1.0257e+02],
+                              [9.9998e-01, -1.5283e-03, -5.2907e-03, -3.2757e-01],
+                              [0.0, 0.0, 0.0, 1.0]])
+    img = torch.arange(370 * 1224, dtype=torch.float32).reshape(1, 1, 370, 1224) / (370 * 1224)
+    pts = torch.tensor([[8.356, -4.312, -0.445], [11.777, -6.724, -0.564], [6.453, 2.53, -1.612],
+                        [6.227, -3.839, -0.563]])
+    # PointFusion.sample_single defaults (point_fusion.py:298-320): scale 1,
+    # crop 0, no flip, aligned (bilinear), zeros, align_corners=True
+    out = g['point_sample'](img_meta, img, pts, lidar2img, 'LIDAR', 1, 0, False, (370, 1224),
+                            (370, 1224), aligned=True, padding_mode='zeros', align_corners=True)
+    # the ramp image is arange(370*1224)/(370*1224): rebuilt by the test, not stored
+    d['ps_points'] = pts.numpy()
+    d['ps_lidar2img'] = lidar2img.numpy()
+    d['ps_out'] = out.numpy()
+    d['ps_expected'] = np.array([0.5560822, 0.5476625, 0.9687978, 0.6241757], np.float32)
+    np.savez_compressed(os.path.join(HERE, 'helpers.npz'), **d)
+    print('cam2img', np.abs(d['cam2img_out'] - d['cam2img_expected']).max(), 'img2cam',
+          np.abs(d['img2cam_out'] - d['img2cam_expected']).max(), 'point_sample',
+          np.abs(d['ps_out'].reshape(-1) - d['ps_expected']).max())
+
+
+if __name__ == '__main__':
+    if not os.path.isdir(REF):
+        sys.exit('reference not mounted; fixtures are committed, nothing to do')
+    torch.set_num_threads(1)
+    ref = load_reference()
+    make_sweep(ref)
+    make_helpers(ref)

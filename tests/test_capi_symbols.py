@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol that
+include/dfm_hip.h declares (no compute calls -- there is no GPU here)."""
+import ctypes
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    importlib.import_module('depth-from-motion_amd.build').build_hip()
+    return importlib.import_module('depth-from-motion_amd')
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'dfm_hip.h')).read()
+    return sorted(set(re.findall(r'DFM_API\s+[\w\s\*]+?\b(dfm_\w+)\s*\(', text)))
+
+
+def test_header_declares_what_the_binding_lists(pkg):
+    assert header_symbols() == sorted(pkg._capi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    h = ctypes.CDLL(pkg._capi.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(h, name), f'{name} declared in dfm_hip.h but not exported'
+
+
+def test_version_and_error_string(pkg):
+    lib = pkg._capi.lib()
+    assert lib.dfm_version() == 1
+    assert isinstance(lib.dfm_last_error(), bytes)
+
+
+def test_invalid_desc_is_rejected_without_touching_the_gpu(pkg):
+    lib = pkg._capi.lib()
+    desc = pkg._capi.SweepDesc()  # all zero -> invalid sizes
+    assert lib.dfm_plane_sweep_workspace_bytes(ctypes.byref(desc)) == 0
+    rc = lib.dfm_plane_sweep_fwd(ctypes.byref(desc), None, None, None, None, None, None, None,
+                                 None, 0, None)
+    assert rc == -1
+    assert b'size' in lib.dfm_last_error()
+    desc.batch = desc.channels = desc.h_in = desc.w_in = 4
+    desc.num_depths = desc.h_out = desc.w_out = 4
+    desc.dtype = 7
+    assert lib.dfm_plane_sweep_fwd(ctypes.byref(desc), None, None, None, None, None, None, None,
+                                   None, 0, None) == -2
+    desc.dtype = 0
+    assert lib.dfm_plane_sweep_workspace_bytes(ctypes.byref(desc)) == 2 * 256 * ((4 * 1 * 16 * 16 + 255) // 256)
+    # NULL pointers
+    assert lib.dfm_plane_sweep_fwd(ctypes.byref(desc), None, None, None, None, None, None, None,
+                                   None, 0, None) == -1
+
+
+def test_ops_refuse_cpu_tensors(pkg):
+    import torch
+    x = torch.zeros(1, 4, 8, 8)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        pkg.build_dfm_cost(x, x, torch.ones(3), 1, 1, torch.eye(4)[None], torch.eye(4)[None],
+                           (8, 8))

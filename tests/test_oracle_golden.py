@@ -1,0 +1,58 @@
+"""CPU: the oracle (oracle/dfm_oracle.c) against the fixtures the REFERENCE
+produced (tests/golden/make_golden.py).  Bar: bit-exact -- the oracle restates
+the reference's fp32 op order, including the fma chains of torch.mm and of
+ATen's bilinear accumulation."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dfm_oracle as orc
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def sweep_cases(golden_dir=None):
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    return sorted(glob.glob(os.path.join(here, 'plane_sweep_*.npz')))
+
+
+@pytest.mark.parametrize('path', sweep_cases(), ids=lambda p: os.path.basename(p)[12:-4])
+def test_plane_sweep_grid_bitexact(path):
+    z = np.load(path)
+    _, _, H, W = z['cur'].shape
+    p = orc.sweep_params(H, W, z['depths'].size, float(z['fsf']), float(z['csf']), z['P'],
+                         z['Pinv'], z['T'], z['img_shape'], bool(z['flip']), z['crop'],
+                         float(z['scale']))
+    cg, pg = orc.plane_sweep_grid(p, z['depths'])
+    assert np.array_equal(_bits(cg), _bits(z['ref_cur_grid']))
+    assert np.array_equal(_bits(pg), _bits(z['ref_prev_grid']))
+
+
+@pytest.mark.parametrize('path', sweep_cases(), ids=lambda p: os.path.basename(p)[12:-4])
+def test_build_dfm_cost_bitexact(path):
+    z = np.load(path)
+    out = orc.build_dfm_cost(z['cur'], z['prev'], z['depths'], float(z['fsf']), float(z['csf']),
+                             z['P'][None], z['Pinv'][None], z['T'][None], z['img_shape'],
+                             bool(z['flip']), z['crop'], float(z['scale']))
+    ref = z['ref_out']
+    assert out.shape == ref.shape
+    assert np.isfinite(ref).all()
+    # value-equal everywhere (treats +0 == -0), and bit-equal
+    assert np.array_equal(out, ref)
+    assert np.array_equal(_bits(out), _bits(ref))
+
+
+def test_behind_camera_case_really_goes_out_of_bounds():
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    z = np.load(os.path.join(here, 'plane_sweep_behind_camera.npz'))
+    C = z['cur'].shape[1]
+    prev_half = z['ref_out'][0, C:]
+    # plane 0 (d=3.5) lands BEHIND the previous camera (z' = d-9 < 0: mirrored,
+    # still sampled); plane 2 (z' ~ 0.5) leaves the image -> zeros from padding
+    zero_frac = [(prev_half[:, d] == 0).mean() for d in range(prev_half.shape[1])]
+    assert zero_frac[0] < 0.1 and max(zero_frac) > 0.99
+    assert np.abs(z['ref_prev_grid']).max() > 10.0

@@ -1,0 +1,193 @@
+"""GPU parity tests of the plane-sweep kernels, through the C ABI.
+
+Bar (DESIGN.md "Numerics"): fp32 storage -> BIT-EXACT against the oracle and
+against the reference's own PyTorch-CPU output (tests/golden); bf16 storage ->
+bit-exact against bf16(oracle(bf16-rounded inputs)) (interpolation in fp32,
+one final rounding).  Backward (atomics, order not fixed): rtol 1e-4 /
+atol 1e-5 against torch's CPU grid_sample autograd on the oracle's grids.
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dfm_oracle as orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU (no fallback path exists)'
+    p = importlib.import_module('depth-from-motion_amd')
+    assert os.path.exists(p._capi.LIB_PATH)
+    return p
+
+
+def run_hip(pkg, cur, prev, depths, fsf, csf, P, T, img_shape, flip, crop, scale, dtype=torch.float32):
+    dev = torch.device('cuda:0')
+    c = torch.from_numpy(np.ascontiguousarray(cur)).to(dev).to(dtype)
+    p = torch.from_numpy(np.ascontiguousarray(prev)).to(dev).to(dtype)
+    out = pkg.build_dfm_cost(c, p, torch.from_numpy(np.asarray(depths, np.float32)).to(dev), fsf,
+                             csf, torch.from_numpy(np.asarray(P, np.float32)),
+                             torch.from_numpy(np.asarray(T, np.float32)), img_shape, flip, crop,
+                             scale)
+    torch.cuda.synchronize()
+    return out
+
+
+def fixture_args(z):
+    return (float(z['fsf']), float(z['csf']), z['P'][None], z['T'][None],
+            tuple(int(v) for v in z['img_shape']), bool(z['flip']),
+            tuple(float(v) for v in z['crop']), float(z['scale']))
+
+
+@pytest.mark.parametrize('path', util.sweep_fixture_paths(),
+                         ids=lambda p: os.path.basename(p)[12:-4])
+def test_fp32_bitexact_vs_reference_fixture(pkg, path):
+    z = np.load(path)
+    out = run_hip(pkg, z['cur'], z['prev'], z['depths'], *fixture_args(z)).cpu().numpy()
+    assert out.shape == z['ref_out'].shape
+    assert np.array_equal(out, z['ref_out'])
+    assert np.array_equal(util.bits(out), util.bits(z['ref_out']))
+
+
+@pytest.mark.parametrize('path', util.sweep_fixture_paths(),
+                         ids=lambda p: os.path.basename(p)[12:-4])
+def test_grid_bitexact_vs_reference_fixture(pkg, path):
+    z = np.load(path)
+    fsf, csf, P, T, img_shape, flip, crop, scale = fixture_args(z)
+    dev = torch.device('cuda:0')
+    cg, pg = pkg.plane_sweep_grid(torch.from_numpy(z['cur']).to(dev),
+                                  torch.from_numpy(z['depths']).to(dev), fsf, csf,
+                                  torch.from_numpy(P), torch.from_numpy(T), img_shape, flip, crop,
+                                  scale)
+    assert np.array_equal(util.bits(cg.cpu().numpy()), util.bits(z['ref_cur_grid']))
+    assert np.array_equal(util.bits(pg.cpu().numpy()), util.bits(z['ref_prev_grid']))
+
+
+@pytest.mark.parametrize('path', util.sweep_fixture_paths(),
+                         ids=lambda p: os.path.basename(p)[12:-4])
+def test_bf16_exact_vs_oracle(pkg, path):
+    z = np.load(path)
+    fsf, csf, P, T, img_shape, flip, crop, scale = fixture_args(z)
+    cur16, prev16 = orc.bf16_round(z['cur']), orc.bf16_round(z['prev'])
+    ref = orc.bf16_round(
+        orc.build_dfm_cost(cur16, prev16, z['depths'], fsf, csf, P, z['Pinv'][None], T, img_shape,
+                           flip, crop, scale))
+    out = run_hip(pkg, cur16, prev16, z['depths'], fsf, csf, P, T, img_shape, flip, crop, scale,
+                  dtype=torch.bfloat16)
+    assert out.dtype == torch.bfloat16
+    assert np.array_equal(util.bits(out.float().cpu().numpy()), util.bits(ref))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_batched_per_sample_semantics(pkg, dtype):
+    """B=3, different pose and intrinsics per sample == oracle looped at B=1."""
+    rng = np.random.RandomState(7)
+    B, C, H, W, D = 3, 12, 30, 101, 7
+    cur = orc.bf16_round(rng.randn(B, C, H, W).astype(np.float32))
+    prev = orc.bf16_round(rng.randn(B, C, H, W).astype(np.float32))
+    P = np.stack([util.KITTI_P2] * B).copy()
+    P[1, 0, 2] += 3.5
+    P[2, 1, 1] *= 1.01
+    T = util.random_poses(B, seed=11)
+    depths = util.depth_planes(D)
+    Pinv = util.host_inverse(P)
+    ref = orc.build_dfm_cost(cur, prev, depths, 12, 1, P, Pinv, T, (375, 1242), False, (0, 0), 1.0)
+    out = run_hip(pkg, cur, prev, depths, 12, 1, P, T, (375, 1242), False, (0, 0), 1.0, dtype)
+    if dtype == torch.bfloat16:
+        ref = orc.bf16_round(ref)
+    assert np.array_equal(util.bits(out.float().cpu().numpy()), util.bits(ref))
+
+
+def test_kitti_shape_subvolume_vs_oracle(pkg):
+    """config K geometry (320x1280 feats, csf=4, crop (0,55)) at reduced C/D."""
+    rng = np.random.RandomState(3)
+    C, H, W, D = 8, 320, 1280, 4
+    cur = rng.randn(1, C, H, W).astype(np.float32)
+    prev = rng.randn(1, C, H, W).astype(np.float32)
+    P, T = util.KITTI_P2[None], util.random_poses(1, seed=5)
+    depths = util.depth_planes(72)[[0, 17, 40, 71]]
+    ref = orc.build_dfm_cost(cur, prev, depths, 1, 4, P, util.host_inverse(P), T, (375, 1242),
+                             False, (0, 55), 1.0)
+    out = run_hip(pkg, cur, prev, depths, 1, 4, P, T, (375, 1242), False, (0, 55), 1.0)
+    assert out.shape == (1, 2 * C, D, 80, 320)
+    assert np.array_equal(util.bits(out.cpu().numpy()), util.bits(ref))
+
+
+def test_north_star_shape_slices_and_properties(pkg):
+    """Full N* geometry (C=256, D=112, 94x311, bf16) for one sample:
+    (a) a few depth planes x channels against the oracle, bit-exact;
+    (b) identity pose + prev==cur  =>  prev half == cur half (bitwise);
+    (c) scaling the inputs by 2 scales the volume by exactly 2."""
+    rng = np.random.RandomState(0)
+    C, H, W, D = 256, 94, 311, 112
+    cur = orc.bf16_round(rng.randn(1, C, H, W).astype(np.float32))
+    prev = orc.bf16_round(rng.randn(1, C, H, W).astype(np.float32))
+    P, T = util.KITTI_P2[None], util.random_poses(1, seed=2)
+    depths = util.depth_planes(D)
+    common = (4, 1, P, T, (375, 1242), False, (0, 0), 1.0)
+    out = run_hip(pkg, cur, prev, depths, *common, dtype=torch.bfloat16)
+    assert out.shape == (1, 2 * C, D, H, W)
+    dsel, csel = [0, 55, 111], [0, 1, 100, 255]
+    ref = orc.bf16_round(
+        orc.build_dfm_cost(cur[:, csel], prev[:, csel], depths[dsel], 4, 1, P,
+                           util.host_inverse(P), T, (375, 1242), False, (0, 0), 1.0))
+    got = out[:, csel + [C + c for c in csel]][:, :, dsel].float().cpu().numpy()
+    assert np.array_equal(util.bits(got), util.bits(ref))
+    # (c) exact linearity under power-of-two scaling
+    out2 = run_hip(pkg, 2 * cur, 2 * prev, depths, *common, dtype=torch.bfloat16)
+    assert torch.equal(out2, out * 2)
+    del out2
+    # (b) identity pose
+    eye = np.eye(4, dtype=np.float32)[None]
+    outi = run_hip(pkg, cur, cur, depths, 4, 1, P, eye, (375, 1242), False, (0, 0), 1.0,
+                   dtype=torch.bfloat16)
+    assert torch.equal(outi[:, :C], outi[:, C:])
+
+
+def test_backward_matches_torch_cpu_autograd(pkg):
+    rng = np.random.RandomState(5)
+    B, C, H, W, D = 2, 6, 20, 64, 3
+    cur = rng.randn(B, C, H, W).astype(np.float32)
+    prev = rng.randn(B, C, H, W).astype(np.float32)
+    P = np.stack([util.KITTI_P2] * B)
+    T = util.random_poses(B, seed=9)
+    Pinv = util.host_inverse(P)
+    depths = util.depth_planes(D)
+    gout = rng.randn(B, 2 * C, D, H // 2, W // 2).astype(np.float32)
+    dev = torch.device('cuda:0')
+    c = torch.from_numpy(cur).to(dev).requires_grad_(True)
+    p = torch.from_numpy(prev).to(dev).requires_grad_(True)
+    out = pkg.build_dfm_cost(c, p, torch.from_numpy(depths).to(dev), 8, 2, torch.from_numpy(P),
+                             torch.from_numpy(T), (375, 1242), False, (3, 5), 1.0)
+    out.backward(torch.from_numpy(gout).to(dev))
+    torch.cuda.synchronize()
+    # reference gradient: torch CPU autograd through grid_sample on the oracle's grids
+    for b in range(B):
+        prm = orc.sweep_params(H, W, D, 8, 2, P[b], Pinv[b], T[b], (375, 1242), False, (3, 5), 1.0)
+        cg, pg = orc.plane_sweep_grid(prm, depths)
+        for feats, grid, got, sl in ((cur, cg, c.grad, slice(0, C)), (prev, pg, p.grad, slice(C, 2 * C))):
+            f = torch.from_numpy(feats[b:b + 1]).requires_grad_(True)
+            o = torch.nn.functional.grid_sample(f, torch.from_numpy(grid).view(1, 1, -1, 2),
+                                                mode='bilinear', padding_mode='zeros',
+                                                align_corners=True)
+            o.backward(torch.from_numpy(gout[b:b + 1, sl]).reshape(o.shape))
+            np.testing.assert_allclose(got[b].cpu().numpy(), f.grad[0].numpy(), rtol=1e-4,
+                                       atol=1e-5)
+
+
+def test_type_and_shape_errors(pkg):
+    dev = torch.device('cuda:0')
+    x = torch.zeros(1, 4, 8, 8, device=dev)
+    eye = torch.eye(4)[None]
+    with pytest.raises(TypeError):
+        pkg.build_dfm_cost(x.half(), x.half(), torch.ones(3), 1, 1, eye, eye, (8, 8))
+    with pytest.raises(TypeError):
+        pkg.build_dfm_cost(x, x.bfloat16(), torch.ones(3), 1, 1, eye, eye, (8, 8))
+    with pytest.raises(AssertionError):
+        pkg.build_dfm_cost(x, x[:, :2], torch.ones(3), 1, 1, eye, eye, (8, 8))

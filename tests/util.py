@@ -1,0 +1,47 @@
+"""Shared helpers for the tests (synthetic cameras / poses, fixture loading)."""
+import math
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791],
+                     [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
+
+
+def pose(yaw_deg, tx, ty, tz):
+    c, s = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
+    return np.array([[c, 0, s, tx], [0, 1, 0, ty], [-s, 0, c, tz], [0, 0, 0, 1]], np.float32)
+
+
+def random_poses(batch, seed=2):
+    """forward t_z ~ U(-1.5,-0.3) m, lateral t_x ~ U(-0.1,0.1), yaw ~ U(-2,2) deg."""
+    rng = np.random.RandomState(seed)
+    return np.stack([
+        pose(rng.uniform(-2, 2), rng.uniform(-0.1, 0.1), 0.0, rng.uniform(-1.5, -0.3))
+        for _ in range(batch)
+    ])
+
+
+def depth_planes(num, dmin=2.0, dmax=59.6):
+    return np.array([dmin + (i + 0.5) * ((dmax - dmin) / num) for i in range(num)], np.float32)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def sweep_fixture_paths():
+    import glob
+    return sorted(glob.glob(os.path.join(GOLDEN, 'plane_sweep_*.npz')))
+
+
+def host_inverse(P):
+    """fp32 torch.inverse on the host -- the op the reference runs
+    (utils.py:241); used for BOTH the oracle and the HIP path in parity tests."""
+    import torch
+    P = np.asarray(P, np.float32)
+    if P.ndim == 2:
+        return torch.inverse(torch.from_numpy(P.copy())).numpy()
+    return np.stack([torch.inverse(torch.from_numpy(p.copy())).numpy() for p in P])
