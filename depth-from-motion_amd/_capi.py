@@ -24,6 +24,7 @@ EXPORTS = (
     'dfm_plane_sweep_grid',
     'dfm_plane_sweep_last_kernel',
     'dfm_plane_sweep_force_kernel',
+    'dfm_plane_sweep_tune',
 )
 
 
@@ -85,6 +86,8 @@ def lib():
     h.dfm_plane_sweep_last_kernel.restype = ctypes.c_int
     h.dfm_plane_sweep_force_kernel.restype = None
     h.dfm_plane_sweep_force_kernel.argtypes = [ctypes.c_int]
+    h.dfm_plane_sweep_tune.restype = ctypes.c_int
+    h.dfm_plane_sweep_tune.argtypes = [ctypes.c_int, ctypes.c_int]
     _lib = h
     return h
 

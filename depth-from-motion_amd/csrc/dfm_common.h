@@ -29,6 +29,19 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f)
     return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16x2 (lo = a, hi = b), round-to-nearest-even
+// (v_cvt_pk_bf16_f32 on gfx950)
+typedef __bf16 bf16x2_vec __attribute__((ext_vector_type(2)));
+typedef float f32x2_vec __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)
+{
+    f32x2_vec f = {a, b};
+    bf16x2_vec h = __builtin_convertvector(f, bf16x2_vec);
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
+}
+
 template <typename T> struct elem;
 template <> struct elem<float> {
     static constexpr int CB = 4;  // elements per 16-byte channel block

@@ -137,8 +137,13 @@ DFM_API int dfm_plane_sweep_grid(const dfm_sweep_desc *desc, int32_t b, const fl
 /* Which kernel the last dfm_plane_sweep_fwd on this thread dispatched:
  * 0 = none yet, 1 = direct-gather kernel, 2 = LDS-staged kernel. */
 DFM_API int dfm_plane_sweep_last_kernel(void);
-/* Force a kernel for A/B measurements: 0 = auto, 1 = gather, 2 = LDS. */
+/* A/B measurements: 1 = always the gather kernel; 0 or 2 = auto (the LDS
+ * kernel whenever D*h_out*w_out is a multiple of 16/sizeof(T), else gather). */
 DFM_API void dfm_plane_sweep_force_kernel(int which);
+/* Launch shape of the LDS-staged kernel (process-wide): lanes per workgroup
+ * (128 or 256) and dynamic LDS per workgroup in KiB (4..160).  A tile whose
+ * feature rows do not fit falls back to direct taps inside the kernel. */
+DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib);
 
 #ifdef __cplusplus
 }

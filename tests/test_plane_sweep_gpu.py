@@ -27,6 +27,26 @@ def pkg():
     return p
 
 
+# kernel variants every parity case runs through: (force_kernel, lanes, lds KiB)
+#   gather    : direct-tap kernel
+#   lds128/256: LDS-staged kernel, 128- / 256-lane workgroups
+#   lds_spill : LDS budget too small for any tile -> every tile takes the
+#               flagged direct-tap spill kernel
+MODES = {'gather': (1, 128, 72), 'lds128': (2, 128, 72), 'lds256': (2, 256, 150),
+         'lds_spill': (2, 128, 4)}
+
+
+@pytest.fixture(params=sorted(MODES), autouse=True)
+def kernel_mode(request, pkg):
+    force, lanes, kib = MODES[request.param]
+    lib = pkg._capi.lib()
+    lib.dfm_plane_sweep_force_kernel(force)
+    pkg._capi.check(lib.dfm_plane_sweep_tune(lanes, kib))
+    yield request.param
+    lib.dfm_plane_sweep_force_kernel(0)
+    pkg._capi.check(lib.dfm_plane_sweep_tune(128, 72))
+
+
 def run_hip(pkg, cur, prev, depths, fsf, csf, P, T, img_shape, flip, crop, scale, dtype=torch.float32):
     dev = torch.device('cuda:0')
     c = torch.from_numpy(np.ascontiguousarray(cur)).to(dev).to(dtype)
@@ -36,6 +56,7 @@ def run_hip(pkg, cur, prev, depths, fsf, csf, P, T, img_shape, flip, crop, scale
                              torch.from_numpy(np.asarray(T, np.float32)), img_shape, flip, crop,
                              scale)
     torch.cuda.synchronize()
+    assert pkg._capi.lib().dfm_plane_sweep_last_kernel() in (1, 2)
     return out
 
 
@@ -84,11 +105,12 @@ def test_bf16_exact_vs_oracle(pkg, path):
     assert np.array_equal(util.bits(out.float().cpu().numpy()), util.bits(ref))
 
 
+@pytest.mark.parametrize('W', [101, 104])  # 101: D*H*W not a multiple of 8 -> gather kernel
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_batched_per_sample_semantics(pkg, dtype):
+def test_batched_per_sample_semantics(pkg, dtype, W):
     """B=3, different pose and intrinsics per sample == oracle looped at B=1."""
     rng = np.random.RandomState(7)
-    B, C, H, W, D = 3, 12, 30, 101, 7
+    B, C, H, D = 3, 12, 30, 7
     cur = orc.bf16_round(rng.randn(B, C, H, W).astype(np.float32))
     prev = orc.bf16_round(rng.randn(B, C, H, W).astype(np.float32))
     P = np.stack([util.KITTI_P2] * B).copy()
