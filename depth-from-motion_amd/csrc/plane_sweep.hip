@@ -31,8 +31,8 @@ thread_local char g_err[512] = "";
 thread_local int g_last_kernel = 0;
 int g_force_kernel = 0;
 // LDS-kernel launch shape (tunable for A/B runs: dfm_plane_sweep_tune)
-int g_lds_nt = 128;  // lanes per workgroup: 128 or 256
-int g_lds_kb = 72;   // dynamic LDS per workgroup, KiB
+int g_lds_nt = 256;  // lanes per workgroup: 128 or 256
+int g_lds_kb = 52;   // dynamic LDS per workgroup, KiB (3 workgroups per CU)
 
 // optional per-launch timing of the dominant (volume-writing) kernel with HIP
 // events on the caller's stream (bench.py's roofline leg)
@@ -184,25 +184,33 @@ __global__ __launch_bounds__(256) void sweep_gather_kernel(
 // ---------------------------------------------------------------------------
 // LDS-staged forward.
 //
-// One workgroup = NT lanes = a tile of NT*V consecutive lattice points of one
-// sample (V = 16 B / sizeof(T): the points whose values of one channel make
-// one aligned 16-byte store).  Per lane: the V bilinear footprints of each
-// map are computed ONCE (coordinates do not depend on the channel) and kept
-// in registers; then for every 16-byte channel block
-//   1. the workgroup copies the rows of the cur and prev maps its tile
-//      touches (full rows: one contiguous run of the blocked layout) to LDS,
+// One workgroup = NT lanes = (a tile of NT*V consecutive lattice points of one
+// sample) x (ONE of the two maps: cur or prev).  V = 16 B / sizeof(T): the
+// points whose values of one channel make one aligned 16-byte store.
+// Per lane: the V bilinear footprints are computed ONCE (coordinates do not
+// depend on the channel) and kept in registers; then for every 16-byte
+// channel block
+//   1. the workgroup DMAs (global_load_lds, 16 B/lane, no VGPR round trip) the
+//      rows of the map its tile touches -- full rows, one contiguous run of
+//      the blocked layout -- into LDS, XOR-swizzled at 16-byte granularity,
 //   2. each lane blends its V points x CB channels from LDS taps
-//      (ds_read_b128: one tap = CB channels),
-//   3. and writes, per channel, ONE aligned 16-byte vector (V points) --
-//      a wave stores 1 KiB contiguous per channel plane.
-// HBM traffic: volume written once; feature rows re-read from L2/MALL.
-// If the rows of a tile do not fit the LDS budget (extreme poses) the
-// workgroup falls back to direct global taps for that tile -- same results.
+//      (ds_read_b128: one tap = CB channels of one pixel),
+//   3. and writes, per channel, ONE aligned 16-byte vector (V points): a wave
+//      stores 1 KiB contiguous per channel plane (non-temporal).
+// HBM traffic: the volume is written once; feature rows are re-read from
+// L2/MALL (block id % batch == sample keeps a sample's maps on one XCD's L2
+// when batch == 8).
+// LDS swizzle: lanes of a wave read pixels 8 apart (V = 8 points per lane), a
+// 128-byte stride that would put a 16-lane ds_read_b128 group on two bank
+// quads (8-way conflict).  slot(q) = q ^ ((q >> 4) & 7) spreads them over all
+// 16 quads; the DMA writes LDS linearly, so the swizzle is applied to the
+// SOURCE pixel each lane fetches (an involution) and again on the tap reads.
+// If the rows of a tile do not fit the LDS budget (extreme poses) the tile is
+// flagged and sweep_spill_kernel redoes it with direct global taps.
 // ---------------------------------------------------------------------------
-struct LaneTap {       // compact per-point footprint for the LDS path
-    int aN, aS;        // LDS byte address of the west tap in the north / south row
-    float w, n;        // fractional offsets (ATen: w = x - floor(x), n = y - floor(y))
-};
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int swz(int q) { return q ^ ((q >> 4) & 7); }
 
 // footprint of one point in one map: rows (clamped into the map), west column
 // in [-1, W-1] (east = west + 1), fractions and the 4 in-bounds bits
@@ -218,60 +226,12 @@ __device__ __forceinline__ uint32_t footprint(float x, float y, int H, int W, in
     return t.ok;
 }
 
-// rare path: the tile's feature rows do not fit the LDS budget.  Recomputes the
-// footprints and reads taps straight from the blocked maps (same arithmetic).
-template <typename T>
-__device__ __forceinline__ void sweep_tile_direct(const SweepGeom &g, int b, long long n0,
-                                               const uint4 *__restrict__ cur_blk,
-                                               const uint4 *__restrict__ prev_blk,
-                                               const float *__restrict__ depths,
-                                               const float *__restrict__ P,
-                                               const float *__restrict__ Pinv,
-                                               const float *__restrict__ Tm, T *__restrict__ out)
-{
-    constexpr int CB = elem<T>::CB;
-    constexpr int V = CB;
-    const int HW = g.h_in * g.w_in;
-    const int hw = g.h_out * g.w_out;
-    const uint4 *cb = cur_blk + (size_t)b * g.nblk * HW;
-    const uint4 *pb = prev_blk + (size_t)b * g.nblk * HW;
-#pragma unroll 1
-    for (int j = 0; j < V; ++j) {
-        const long long n = n0 + j;
-        const int d = (int)(n / hw);
-        const int rem = (int)(n - (long long)d * hw);
-        const int hi = rem / g.w_out;
-        const int wi = rem - hi * g.w_out;
-        float cx, cy, px, py;
-        sweep_point(g, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, cx, cy, px, py,
-                    nullptr);
-        const Tap tc = make_tap(cx, cy, g.h_in, g.w_in);
-        const Tap tp = make_tap(px, py, g.h_in, g.w_in);
-        const int c00 = tc.iy * g.w_in + tc.ix, c01 = c00 + tc.dx;
-        const int c10 = c00 + tc.dy * g.w_in, c11 = c10 + tc.dx;
-        const int p00 = tp.iy * g.w_in + tp.ix, p01 = p00 + tp.dx;
-        const int p10 = p00 + tp.dy * g.w_in, p11 = p10 + tp.dx;
-        T *ocur = out + ((size_t)b * 2 * g.C) * g.N + n;
-        T *oprev = ocur + (size_t)g.C * g.N;
-#pragma unroll 1
-        for (int blk = 0; blk < g.nblk; ++blk) {
-            const uint4 *cq = cb + (size_t)blk * HW, *pq = pb + (size_t)blk * HW;
-            float rc[CB], rp[CB];
-            blend<CB>(tc, cq[c00], cq[c01], cq[c10], cq[c11], rc);
-            blend<CB>(tp, pq[p00], pq[p01], pq[p10], pq[p11], rp);
-#pragma unroll
-            for (int k = 0; k < CB; ++k) {
-                if (blk * CB + k < g.C) {
-                    ocur[(size_t)(blk * CB + k) * g.N] = elem<T>::store(rc[k]);
-                    oprev[(size_t)(blk * CB + k) * g.N] = elem<T>::store(rp[k]);
-                }
-            }
-        }
-    }
-}
-
-template <typename T, int NT>
-__global__ __launch_bounds__(NT) void sweep_lds_kernel(
+// LDS == true : the staged kernel described above.
+// LDS == false: same lane/point/store structure, taps straight from the blocked
+//               map in global memory; runs only the tiles flagged by the LDS
+//               kernel (spill_flags) -- or every tile when flags == nullptr.
+template <typename T, int NT, bool LDS>
+__global__ __launch_bounds__(NT) void sweep_tile_kernel(
     SweepGeom g, int batch, int lds_slots, const uint4 *__restrict__ cur_blk,
     const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
     const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
@@ -279,25 +239,34 @@ __global__ __launch_bounds__(NT) void sweep_lds_kernel(
 {
     constexpr int CB = elem<T>::CB;
     constexpr int V = CB;  // points per lane (one 16-byte store per channel)
+    constexpr int PAD = 8; // slots in front of the rows (keeps q = p + PAD >= 7)
+    constexpr int SLAB = 8;  // slab starts at a multiple of 8 so the swizzle stays inside it
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-    int *bb = (int *)lds;  // slot 0: {cur ymin, cur ymax, prev ymin, prev ymax}
+    int *bb = (int *)lds;  // slot 0: {ymin, ymax}
+
+    if (!LDS && spill_flags && !spill_flags[blockIdx.x]) return;
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.x % batch;          // sample fastest: block id % 8 == XCD
-    const long long tile = blockIdx.x / batch;
+    // block id = (tile*2 + half)*batch + b : sample fastest (id % 8 == XCD)
+    const int b = blockIdx.x % batch;
+    const int th = blockIdx.x / batch;
+    const int half = th & 1;
+    const long long tile = th >> 1;
     const long long n0 = (tile * NT + tid) * V;
     const bool active = n0 < g.N;
     const int W = g.w_in, H = g.h_in;
+    const int HW = H * W;
 
-    if (tid == 0) {
-        bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1;
+    if (LDS) {
+        if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; }
+        __syncthreads();
     }
-    __syncthreads();
 
-    // ---- per-lane footprints (addresses relative to row 0, fixed up below) ----
-    LaneTap lc[V], lp[V];
-    uint32_t c_ok = 0, p_ok = 0;  // 4 bits per point
-    int cymin = 0x7fffffff, cymax = -1, pymin = 0x7fffffff, pymax = -1;
+    // ---- per-lane footprints: pixel index relative to row 0 of the map ----------
+    int qN[V], qS[V];
+    float fw[V], fn[V];
+    uint32_t okbits = 0;  // 4 bits per point
+    int ymin = 0x7fffffff, ymax = -1;
     if (active) {
         const int hw = g.h_out * g.w_out;
         int d = (int)(n0 / hw);
@@ -310,135 +279,131 @@ __global__ __launch_bounds__(NT) void sweep_lds_kernel(
             float cx, cy, px, py;
             sweep_point(g, Pb, Pib, Tb, depths[d], hi, wi, cx, cy, px, py, nullptr);
             int rN, rS, ix;
-            uint32_t ok = footprint(cx, cy, H, W, rN, rS, ix, lc[j].w, lc[j].n);
-            lc[j].aN = rN * W + ix; lc[j].aS = rS * W + ix;
-            c_ok |= ok << (4 * j);
-            if (ok) { cymin = min(cymin, rN); cymax = max(cymax, rS); }
-            ok = footprint(px, py, H, W, rN, rS, ix, lp[j].w, lp[j].n);
-            lp[j].aN = rN * W + ix; lp[j].aS = rS * W + ix;
-            p_ok |= ok << (4 * j);
-            if (ok) { pymin = min(pymin, rN); pymax = max(pymax, rS); }
+            const uint32_t ok =
+                footprint(half ? px : cx, half ? py : cy, H, W, rN, rS, ix, fw[j], fn[j]);
+            qN[j] = rN * W + ix;
+            qS[j] = rS * W + ix;
+            okbits |= ok << (4 * j);
+            if (ok) { ymin = min(ymin, rN); ymax = max(ymax, rS); }
             if (++wi == g.w_out) { wi = 0; if (++hi == g.h_out) { hi = 0; ++d; } }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // workgroup bounding rows
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        cymin = min(cymin, __shfl_xor(cymin, o)); cymax = max(cymax, __shfl_xor(cymax, o));
-        pymin = min(pymin, __shfl_xor(pymin, o)); pymax = max(pymax, __shfl_xor(pymax, o));
-    }
-    if ((tid & 63) == 0) {
-        atomicMin(&bb[0], cymin); atomicMax(&bb[1], cymax);
-        atomicMin(&bb[2], pymin); atomicMax(&bb[3], pymax);
-    }
-    __syncthreads();
-    int cy0 = bb[0], cy1 = bb[1], py0 = bb[2], py1 = bb[3];
-    if (cy1 < cy0) { cy0 = 0; cy1 = 0; }  // nothing of this tile lands inside the map
-    if (py1 < py0) { py0 = 0; py1 = 0; }
-    const int c_cnt = (cy1 - cy0 + 1) * W, p_cnt = (py1 - py0 + 1) * W;
-    // LDS: [bbox scratch][pad][cur rows][pad][pad][prev rows][pad], 16-B slots
-    const int c_base = 2, p_base = c_base + c_cnt + 2;
-    const bool fits = p_base + p_cnt + 1 <= lds_slots;
-    // a tile whose rows do not fit is left to sweep_spill_kernel (flag per tile)
-    if (tid == 0) spill_flags[blockIdx.x] = fits ? 0 : 1;
-    if (!fits) return;
+    T *o = out + ((size_t)b * 2 * g.C + (size_t)half * g.C) * g.N + n0;
+    const uint32_t full = (V == 8) ? 0xffffffffu : 0xffffu;
+    const bool all_in = __all(!active || okbits == full);
 
-    // ---- fix up: slot relative to row 0  ->  LDS byte address -------------------
-    {
-        const int coff = c_base - cy0 * W, poff = p_base - py0 * W;
+    int cnt = 0, nslots = 0;
+    const uint4 *src = (half ? prev_blk : cur_blk) + (size_t)b * g.nblk * HW;
+    if (LDS) {
+        // workgroup bounding rows
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            ymin = min(ymin, __shfl_xor(ymin, s));
+            ymax = max(ymax, __shfl_xor(ymax, s));
+        }
+        if ((tid & 63) == 0) { atomicMin(&bb[0], ymin); atomicMax(&bb[1], ymax); }
+        __syncthreads();
+        const int y0 = bb[0], y1 = bb[1];
+        if (y1 < y0) {
+            // no point of this tile lands inside the map: the volume is zero here
+            if (tid == 0) spill_flags[blockIdx.x] = 0;
+            if (active) {
+                const u32x4_t z = {0u, 0u, 0u, 0u};
+                for (int c = 0; c < g.C; ++c)
+                    __builtin_nontemporal_store(z, (u32x4_t *)(o + (size_t)c * g.N));
+            }
+            return;
+        }
+        cnt = (y1 - y0 + 1) * W;  // pixels (16-B slots) to stage per block
+        nslots = (PAD + cnt + 1 + 7) & ~7;
+        const bool fits = SLAB + nslots <= lds_slots;
+        if (tid == 0) spill_flags[blockIdx.x] = fits ? 0 : 1;
+        if (!fits) return;
+        // q = pixel index in the slab + PAD (fully masked points -> a valid slot)
+        const int off = PAD - y0 * W;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const bool cany = (c_ok >> (4 * j)) & 15u, pany = (p_ok >> (4 * j)) & 15u;
-            lc[j].aN = (cany ? lc[j].aN + coff : c_base) * 16;
-            lc[j].aS = (cany ? lc[j].aS + coff : c_base) * 16;
-            lp[j].aN = (pany ? lp[j].aN + poff : p_base) * 16;
-            lp[j].aS = (pany ? lp[j].aS + poff : p_base) * 16;
+            const bool any = (okbits >> (4 * j)) & 15u;
+            qN[j] = any ? qN[j] + off : PAD;
+            qS[j] = any ? qS[j] + off : PAD;
+        }
+        src += (size_t)y0 * W;
+    } else {
+        if (!active) return;
+        // direct taps: keep every index inside the map (masked taps are discarded)
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const bool any = (okbits >> (4 * j)) & 15u;
+            qN[j] = any ? qN[j] : 0;
+            qS[j] = any ? qS[j] : 0;
         }
     }
-    const uint32_t full = (V == 8) ? 0xffffffffu : 0xffffu;
-    const bool c_all = __all(!active || c_ok == full);
-    const bool p_all = __all(!active || p_ok == full);
-
-    const int HW = H * W;
-    T *ocur = out + ((size_t)b * 2 * g.C) * g.N + n0;
-    T *oprev = ocur + (size_t)g.C * g.N;
-    const uint4 *csrc = cur_blk + ((size_t)b * g.nblk * H + cy0) * W;
-    const uint4 *psrc = prev_blk + ((size_t)b * g.nblk * H + py0) * W;
-    const char *ldsb = (const char *)lds;
+    const char *slab = (const char *)(lds + SLAB);
+    const int wave = tid >> 6, lane = tid & 63;
 
     for (int blk = 0; blk < g.nblk; ++blk) {
-        // ---- stage the rows of this channel block ------------------------------
-        for (int i = tid; i < c_cnt; i += NT) lds[c_base + i] = csrc[i];
-        for (int i = tid; i < p_cnt; i += NT) lds[p_base + i] = psrc[i];
-        csrc += HW;
-        psrc += HW;
-        __syncthreads();
+        if (LDS) {
+            // ---- stage this channel block's rows: LDS slot s <- pixel swz(s) - PAD ----
+            for (int s0 = wave * 64; s0 < nslots; s0 += NT) {
+                const int p = swz(s0 + lane) - PAD;
+                if (p >= 0 && p < cnt)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src + p),
+                        (__attribute__((address_space(3))) void *)(lds + SLAB + s0), 16, 0, 0);
+            }
+            __syncthreads();  // drains the DMA (vmcnt) and makes the slab visible
+        }
         if (active) {
             const int cbase = blk * CB;
-            // two passes: cur half, prev half; points in pairs so that only
-            // 8 taps are in flight (register budget) and bf16 pairs pack at once
+            uint32_t pk[CB][4];  // per channel: one 16-byte vector of V points
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const LaneTap *lt = half ? lp : lc;
-                const uint32_t okbits = half ? p_ok : c_ok;
-                const bool all_in = half ? p_all : c_all;
-                uint32_t pk[CB][4];  // per channel: one 16-byte vector of V points
+            for (int j = 0; j < V; j += 2) {
+                float ra[CB], rb[CB];
 #pragma unroll
-                for (int j = 0; j < V; j += 2) {
-                    float ra[CB], rb[CB];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const LaneTap &l = lt[j + u];
-                        const uint4 qnw = *(const uint4 *)(ldsb + l.aN);
-                        const uint4 qne = *(const uint4 *)(ldsb + l.aN + 16);
-                        const uint4 qsw = *(const uint4 *)(ldsb + l.aS);
-                        const uint4 qse = *(const uint4 *)(ldsb + l.aS + 16);
-                        Tap t;
-                        const float w = l.w, n = l.n, e = 1.0f - w, s2 = 1.0f - n;
-                        t.nw = s2 * e; t.ne = s2 * w; t.sw = n * e; t.se = n * w;
-                        t.ok = (okbits >> (4 * (j + u))) & 15u;
-                        if (all_in) blend_nomask<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
-                        else blend<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
+                for (int u = 0; u < 2; ++u) {
+                    const int a = qN[j + u], c = qS[j + u];
+                    uint4 qnw, qne, qsw, qse;
+                    if (LDS) {
+                        qnw = *(const uint4 *)(slab + (swz(a) << 4));
+                        qne = *(const uint4 *)(slab + (swz(a + 1) << 4));
+                        qsw = *(const uint4 *)(slab + (swz(c) << 4));
+                        qse = *(const uint4 *)(slab + (swz(c + 1) << 4));
+                    } else {
+                        qnw = src[max(a, 0)];
+                        qne = src[min(a + 1, HW - 1)];
+                        qsw = src[max(c, 0)];
+                        qse = src[min(c + 1, HW - 1)];
                     }
-#pragma unroll
-                    for (int k = 0; k < CB; ++k) {
-                        if constexpr (sizeof(T) == 4) {
-                            pk[k][j] = __float_as_uint(ra[k]);
-                            pk[k][j + 1] = __float_as_uint(rb[k]);
-                        } else {
-                            pk[k][j >> 1] = pack_bf16x2(ra[k], rb[k]);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    Tap t;
+                    const float w = fw[j + u], n = fn[j + u], e = 1.0f - w, s2 = 1.0f - n;
+                    t.nw = s2 * e; t.ne = s2 * w; t.sw = n * e; t.se = n * w;
+                    t.ok = (okbits >> (4 * (j + u))) & 15u;
+                    if (all_in) blend_nomask<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
+                    else blend<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
                 }
-                T *o = half ? oprev : ocur;
 #pragma unroll
                 for (int k = 0; k < CB; ++k) {
-                    if (cbase + k < g.C)
-                        *(uint4 *)(o + (size_t)(cbase + k) * g.N) =
-                            make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
+                    if constexpr (sizeof(T) == 4) {
+                        pk[k][j] = __float_as_uint(ra[k]);
+                        pk[k][j + 1] = __float_as_uint(rb[k]);
+                    } else {
+                        pk[k][j >> 1] = pack_bf16x2(ra[k], rb[k]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                if (cbase + k < g.C) {
+                    u32x4_t v = {pk[k][0], pk[k][1], pk[k][2], pk[k][3]};
+                    __builtin_nontemporal_store(v, (u32x4_t *)(o + (size_t)(cbase + k) * g.N));
+                }
+            }
         }
-        __syncthreads();
+        src += HW;
+        if (LDS) __syncthreads();  // everyone is done with the slab before it is refilled
     }
-}
-
-// tiles the LDS kernel flagged (rows did not fit its LDS budget): direct taps
-template <typename T, int NT>
-__global__ __launch_bounds__(NT) void sweep_spill_kernel(
-    SweepGeom g, int batch, const uint4 *__restrict__ cur_blk, const uint4 *__restrict__ prev_blk,
-    const float *__restrict__ depths, const float *__restrict__ P, const float *__restrict__ Pinv,
-    const float *__restrict__ Tm, T *__restrict__ out, const unsigned char *__restrict__ spill_flags)
-{
-    if (!spill_flags[blockIdx.x]) return;
-    constexpr int V = elem<T>::CB;
-    const int b = blockIdx.x % batch;
-    const long long tile = blockIdx.x / batch;
-    const long long n0 = (tile * NT + threadIdx.x) * V;
-    if (n0 < g.N) sweep_tile_direct<T>(g, b, n0, cur_blk, prev_blk, depths, P, Pinv, Tm, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -567,7 +532,7 @@ size_t flag_bytes(const dfm_sweep_desc *d)
     const int V = d->dtype == DFM_BF16 ? 8 : 4;
     const long long N = (long long)d->num_depths * d->h_out * d->w_out;
     const long long tiles = (N / V + 127) / 128 + 1;
-    return ((size_t)tiles * d->batch + 255) & ~(size_t)255;
+    return ((size_t)tiles * 2 * d->batch + 255) & ~(size_t)255;
 }
 
 template <typename T>
@@ -588,7 +553,13 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
     constexpr int V = elem<T>::CB;
     // the LDS kernel stores one aligned 16-byte vector of V points per channel:
     // it needs every channel plane (N elements) to start 16-byte aligned
-    const int which = (g_force_kernel != 1 && g.N % V == 0 && ((uintptr_t)out & 15) == 0) ? 2 : 1;
+    // Dense sampling (about one feature pixel per lattice step) reuses staged rows
+    // well; a strided sweep (cost_sample_factor >= 2) would stage mostly unused
+    // pixels, so it takes the same tile kernel with direct taps (3).
+    const bool vec_ok = g.N % V == 0 && ((uintptr_t)out & 15) == 0;
+    int which = !vec_ok ? 1 : (d->cost_sample_factor < 1.5f ? 2 : 3);
+    if (g_force_kernel == 1 || (g_force_kernel == 3 && vec_ok)) which = g_force_kernel;
+    if (g_force_kernel == 2 && vec_ok) which = 2;
     if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
     if (which == 1) {
         const long long nb = (g.N + 255) / 256;
@@ -600,18 +571,22 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
         const int nt = g_lds_nt;
         const int lds_bytes = g_lds_kb * 1024;
         const long long tiles = (g.N / V + nt - 1) / nt;
-        const long long nb = tiles * d->batch;
+        const long long nb = tiles * 2 * d->batch;  // (tile, cur|prev, sample)
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
         if ((size_t)nb > flag_bytes(d)) return fail(DFM_ERR_WORKSPACE, "flag area too small%s");
         unsigned char *flags = (unsigned char *)ws + 2 * blocked_bytes(d);
-        auto kern = nt == 128 ? sweep_lds_kernel<T, 128> : sweep_lds_kernel<T, 256>;
-        auto spill = nt == 128 ? sweep_spill_kernel<T, 128> : sweep_spill_kernel<T, 256>;
+        auto kern = nt == 128 ? sweep_tile_kernel<T, 128, true> : sweep_tile_kernel<T, 256, true>;
+        auto spill = nt == 128 ? sweep_tile_kernel<T, 128, false> : sweep_tile_kernel<T, 256, false>;
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     lds_bytes));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nt), lds_bytes, st, g, d->batch,
-                           lds_bytes / 16, cur_blk, prev_blk, depths, P, Pinv, Tm, (T *)out, flags);
-        hipLaunchKernelGGL(spill, dim3((unsigned)nb), dim3(nt), 0, st, g, d->batch, cur_blk,
-                           prev_blk, depths, P, Pinv, Tm, (T *)out, flags);
+        if (which == 2)
+            hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nt), lds_bytes, st, g, d->batch,
+                               lds_bytes / 16, cur_blk, prev_blk, depths, P, Pinv, Tm, (T *)out,
+                               flags);
+        // flagged tiles (rows beyond the LDS budget), or all tiles for which == 3
+        hipLaunchKernelGGL(spill, dim3((unsigned)nb), dim3(nt), 16, st, g, d->batch, 0, cur_blk,
+                           prev_blk, depths, P, Pinv, Tm, (T *)out,
+                           which == 2 ? flags : (unsigned char *)nullptr);
     }
     if (timed) {
         (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);

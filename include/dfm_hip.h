@@ -135,10 +135,12 @@ DFM_API int dfm_plane_sweep_grid(const dfm_sweep_desc *desc, int32_t b, const fl
                                  void *stream);
 
 /* Which kernel the last dfm_plane_sweep_fwd on this thread dispatched:
- * 0 = none yet, 1 = direct-gather kernel, 2 = LDS-staged kernel. */
+ * 0 = none yet, 1 = lane-per-point gather kernel, 2 = LDS-staged tile kernel
+ * (+ direct-tap pass over flagged tiles), 3 = tile kernel with direct taps. */
 DFM_API int dfm_plane_sweep_last_kernel(void);
-/* A/B measurements: 1 = always the gather kernel; 0 or 2 = auto (the LDS
- * kernel whenever D*h_out*w_out is a multiple of 16/sizeof(T), else gather). */
+/* A/B measurements: 0 = auto; 1/2/3 = force that kernel (2 and 3 need
+ * D*h_out*w_out to be a multiple of 16/sizeof(T), else the call uses 1).
+ * auto = 2 for dense sweeps (cost_sample_factor < 1.5), 3 for strided ones. */
 DFM_API void dfm_plane_sweep_force_kernel(int which);
 /* Launch shape of the LDS-staged kernel (process-wide): lanes per workgroup
  * (128 or 256) and dynamic LDS per workgroup in KiB (4..160).  A tile whose

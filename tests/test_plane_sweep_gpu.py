@@ -28,12 +28,13 @@ def pkg():
 
 
 # kernel variants every parity case runs through: (force_kernel, lanes, lds KiB)
-#   gather    : direct-tap kernel
-#   lds128/256: LDS-staged kernel, 128- / 256-lane workgroups
-#   lds_spill : LDS budget too small for any tile -> every tile takes the
-#               flagged direct-tap spill kernel
-MODES = {'gather': (1, 128, 72), 'lds128': (2, 128, 72), 'lds256': (2, 256, 150),
-         'lds_spill': (2, 128, 4)}
+#   gather    : lane-per-point kernel (also what non-vectorisable shapes take)
+#   lds128/256: LDS-staged tile kernel, 128- / 256-lane workgroups
+#   lds_spill : LDS budget too small for any tile -> every tile is flagged and
+#               redone by the direct-tap pass
+#   direct    : tile kernel with direct taps for every tile (strided sweeps)
+MODES = {'gather': (1, 256, 52), 'lds128': (2, 128, 36), 'lds256': (2, 256, 52),
+         'lds_spill': (2, 128, 4), 'direct': (3, 256, 52)}
 
 
 @pytest.fixture(params=sorted(MODES), autouse=True)
@@ -44,7 +45,7 @@ def kernel_mode(request, pkg):
     pkg._capi.check(lib.dfm_plane_sweep_tune(lanes, kib))
     yield request.param
     lib.dfm_plane_sweep_force_kernel(0)
-    pkg._capi.check(lib.dfm_plane_sweep_tune(128, 72))
+    pkg._capi.check(lib.dfm_plane_sweep_tune(256, 52))
 
 
 def run_hip(pkg, cur, prev, depths, fsf, csf, P, T, img_shape, flip, crop, scale, dtype=torch.float32):
@@ -56,7 +57,7 @@ def run_hip(pkg, cur, prev, depths, fsf, csf, P, T, img_shape, flip, crop, scale
                              torch.from_numpy(np.asarray(T, np.float32)), img_shape, flip, crop,
                              scale)
     torch.cuda.synchronize()
-    assert pkg._capi.lib().dfm_plane_sweep_last_kernel() in (1, 2)
+    assert pkg._capi.lib().dfm_plane_sweep_last_kernel() in (1, 2, 3)
     return out
 
 
