@@ -156,6 +156,67 @@ __device__ __forceinline__ void sweep_point(const SweepGeom &g, const float *__r
     py = ((npy + 1.0f) / 2.0f) * hm1;
 }
 
+// Same arithmetic as sweep_point, but only the map the caller samples
+// (HALF 0 = cur, 1 = prev), and with the divisions that are exact no-ops or
+// exact scalings folded: x / 1.0f == x, x / 2^k == x * 2^-k (both bit-exact
+// for the normal-range values this path sees; wave-uniform branches).
+struct SweepFast {
+    int32_t scale_is_one;  // img_scale_factor == 1.0f
+    int32_t fsf_pow2;      // feat_sample_factor is a power of two
+    float inv_fsf;         // 1 / fsf, exact when fsf_pow2
+};
+
+template <int HALF>
+__device__ __forceinline__ void sweep_point_map(const SweepGeom &g, const SweepFast &f,
+                                                const float *__restrict__ P,
+                                                const float *__restrict__ Pinv,
+                                                const float *__restrict__ Tm, float depth, int hi,
+                                                int wi, float &ox, float &oy)
+{
+    float x = ((float)wi * g.fsf) * g.csf;
+    float y = ((float)hi * g.fsf) * g.csf;
+    x = x + g.crop_x;
+    y = y + g.crop_y;
+    if (!f.scale_is_one) {
+        x = x / g.scale;
+        y = y / g.scale;
+    }
+    if (g.flip) x = g.org_w - x;
+    const float h0 = x * depth, h1 = y * depth, h2 = depth;
+    float X0 = dot4_chain(h0, h1, h2, 1.0f, Pinv + 0);
+    float X1 = dot4_chain(h0, h1, h2, 1.0f, Pinv + 4);
+    float X2 = dot4_chain(h0, h1, h2, 1.0f, Pinv + 8);
+    if (HALF) {
+        const float Y0 = dot4_chain(X0, X1, X2, 1.0f, Tm + 0);
+        const float Y1 = dot4_chain(X0, X1, X2, 1.0f, Tm + 4);
+        const float Y2 = dot4_chain(X0, X1, X2, 1.0f, Tm + 8);
+        X0 = Y0; X1 = Y1; X2 = Y2;
+    }
+    const float a = dot4_chain(X0, X1, X2, 1.0f, P + 0);
+    const float b = dot4_chain(X0, X1, X2, 1.0f, P + 4);
+    const float c = dot4_chain(X0, X1, X2, 1.0f, P + 8);
+    float u = a / c, v = b / c;
+    if (g.flip) u = g.org_w - u;
+    if (!f.scale_is_one) {
+        u = u * g.scale;
+        v = v * g.scale;
+    }
+    u = u - g.crop_x;
+    v = v - g.crop_y;
+    if (f.fsf_pow2) {
+        u = u * f.inv_fsf;
+        v = v * f.inv_fsf;
+    } else {
+        u = u / g.fsf;
+        v = v / g.fsf;
+    }
+    const float wm1 = (float)(g.w_in - 1), hm1 = (float)(g.h_in - 1);
+    const float nx = u / wm1 * 2.0f - 1.0f;
+    const float ny = v / hm1 * 2.0f - 1.0f;
+    ox = ((nx + 1.0f) * 0.5f) * wm1;
+    oy = ((ny + 1.0f) * 0.5f) * hm1;
+}
+
 // Bilinear footprint of one sample point: top-left integer corner, the four
 // corner weights (ATen compute_interp_params) and per-corner in-bounds bits.
 struct Tap {

@@ -19,8 +19,10 @@
 #include "dfm_common.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 using namespace dfm;
@@ -32,7 +34,8 @@ thread_local int g_last_kernel = 0;
 int g_force_kernel = 0;
 // LDS-kernel launch shape (tunable for A/B runs: dfm_plane_sweep_tune)
 int g_lds_nt = 256;  // lanes per workgroup: 128 or 256
-int g_lds_kb = 52;   // dynamic LDS per workgroup, KiB (3 workgroups per CU)
+int g_lds_kb = 64;   // dynamic LDS per workgroup, KiB
+int g_blocks_per_group = 1 << 20;  // channel blocks per workgroup (default: all)
 
 // optional per-launch timing of the dominant (volume-writing) kernel with HIP
 // events on the caller's stream (bench.py's roofline leg)
@@ -226,13 +229,22 @@ __device__ __forceinline__ uint32_t footprint(float x, float y, int H, int W, in
     return t.ok;
 }
 
+struct TileGrid {
+    int batch;
+    int bands;             // tiles per depth plane
+    int band_pts;          // points per tile (multiple of 8, <= NT*V)
+    int blocks_per_group;  // channel blocks one workgroup sweeps
+    int ablate;            // perf experiments only (DFM_ABLATE): 1 no staging,
+                           // 2 no volume stores, 4 no taps/blend; results are wrong
+};
+
 // LDS == true : the staged kernel described above.
 // LDS == false: same lane/point/store structure, taps straight from the blocked
 //               map in global memory; runs only the tiles flagged by the LDS
 //               kernel (spill_flags) -- or every tile when flags == nullptr.
 template <typename T, int NT, bool LDS>
 __global__ __launch_bounds__(NT) void sweep_tile_kernel(
-    SweepGeom g, int batch, int lds_slots, const uint4 *__restrict__ cur_blk,
+    SweepGeom g, SweepFast fast, TileGrid tg, int lds_slots, const uint4 *__restrict__ cur_blk,
     const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
     const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
     T *__restrict__ out, unsigned char *__restrict__ spill_flags)
@@ -247,18 +259,39 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
     if (!LDS && spill_flags && !spill_flags[blockIdx.x]) return;
 
     const int tid = threadIdx.x;
-    // block id = (tile*2 + half)*batch + b : sample fastest (id % 8 == XCD)
+    // Tiles: every depth plane (hw points) is cut into `bands` pieces of
+    // `band_pts` points whose boundaries are multiples of 8 in the flat
+    // (d,h,w) index, so every lane's V points form one aligned 16-byte store.
+    // block id = (((group*bands + band)*2 + half)*D + d)*batch + b
+    //   sample fastest -> id % 8 == XCD keeps one sample's maps in one L2 (batch 8)
+    //   depth next     -> the workgroups resident on an XCD sweep the SAME band
+    //                     of the SAME map over consecutive depth planes: they
+    //                     stage the same (cur) or neighbouring (prev) feature
+    //                     rows, which therefore stay in that XCD's L2
+    const int batch = tg.batch;
     const int b = blockIdx.x % batch;
-    const int th = blockIdx.x / batch;
+    int th = blockIdx.x / batch;
+    const int d_tile = th % g.D;
+    th /= g.D;
     const int half = th & 1;
-    const long long tile = th >> 1;
-    const long long n0 = (tile * NT + tid) * V;
-    const bool active = n0 < g.N;
+    th >>= 1;
+    const int band = th % tg.bands;
+    const int group = th / tg.bands;
+    const int blk_lo = group * tg.blocks_per_group;
+    const int blk_hi = min(blk_lo + tg.blocks_per_group, g.nblk);
+    const long long hw_ll = (long long)g.h_out * g.w_out;
+    const long long a0 = (d_tile * hw_ll) & ~7ll;
+    const long long a1 = d_tile == g.D - 1 ? g.N : (((d_tile + 1) * hw_ll) & ~7ll);
+    const long long t_end = min(a0 + (long long)(band + 1) * tg.band_pts, a1);
+    const long long n0 = a0 + (long long)band * tg.band_pts + (long long)tid * V;
+    const bool active = n0 < t_end;
     const int W = g.w_in, H = g.h_in;
     const int HW = H * W;
 
     if (LDS) {
-        if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; }
+        // slot 0: bbox scratch; slot 1: sixteen zero bytes, the tap every
+        // out-of-bounds corner reads (grid_sample's zeros padding)
+        if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; lds[1] = make_uint4(0u, 0u, 0u, 0u); }
         __syncthreads();
     }
 
@@ -276,11 +309,11 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
         const float *Pb = P + b * 16, *Pib = Pinv + b * 16, *Tb = Tm + b * 16;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            float cx, cy, px, py;
-            sweep_point(g, Pb, Pib, Tb, depths[d], hi, wi, cx, cy, px, py, nullptr);
+            float sx, sy;
+            if (half) sweep_point_map<1>(g, fast, Pb, Pib, Tb, depths[d], hi, wi, sx, sy);
+            else sweep_point_map<0>(g, fast, Pb, Pib, Tb, depths[d], hi, wi, sx, sy);
             int rN, rS, ix;
-            const uint32_t ok =
-                footprint(half ? px : cx, half ? py : cy, H, W, rN, rS, ix, fw[j], fn[j]);
+            const uint32_t ok = footprint(sx, sy, H, W, rN, rS, ix, fw[j], fn[j]);
             qN[j] = rN * W + ix;
             qS[j] = rS * W + ix;
             okbits |= ok << (4 * j);
@@ -294,7 +327,8 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
     const bool all_in = __all(!active || okbits == full);
 
     int cnt = 0, nslots = 0;
-    const uint4 *src = (half ? prev_blk : cur_blk) + (size_t)b * g.nblk * HW;
+    int ta[V][4];  // LDS path: byte address of the nw / ne / sw / se corner
+    const uint4 *src = (half ? prev_blk : cur_blk) + ((size_t)b * g.nblk + blk_lo) * HW;
     if (LDS) {
         // workgroup bounding rows
 #pragma unroll
@@ -310,7 +344,7 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
             if (tid == 0) spill_flags[blockIdx.x] = 0;
             if (active) {
                 const u32x4_t z = {0u, 0u, 0u, 0u};
-                for (int c = 0; c < g.C; ++c)
+                for (int c = blk_lo * CB; c < min(blk_hi * CB, g.C); ++c)
                     __builtin_nontemporal_store(z, (u32x4_t *)(o + (size_t)c * g.N));
             }
             return;
@@ -320,13 +354,18 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
         const bool fits = SLAB + nslots <= lds_slots;
         if (tid == 0) spill_flags[blockIdx.x] = fits ? 0 : 1;
         if (!fits) return;
-        // q = pixel index in the slab + PAD (fully masked points -> a valid slot)
+        // LDS byte address of each corner: swizzled slot of pixel q (= index in
+        // the staged rows + PAD), or the zero slot for an out-of-bounds corner.
+        // Nothing in the channel loop depends on the in-bounds bits any more.
         const int off = PAD - y0 * W;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const bool any = (okbits >> (4 * j)) & 15u;
-            qN[j] = any ? qN[j] + off : PAD;
-            qS[j] = any ? qS[j] + off : PAD;
+            const uint32_t ok = (okbits >> (4 * j)) & 15u;
+            const int a = qN[j] + off, c = qS[j] + off;
+            ta[j][0] = (ok & 1u) ? (SLAB + swz(a)) << 4 : 16;
+            ta[j][1] = (ok & 2u) ? (SLAB + swz(a + 1)) << 4 : 16;
+            ta[j][2] = (ok & 4u) ? (SLAB + swz(c)) << 4 : 16;
+            ta[j][3] = (ok & 8u) ? (SLAB + swz(c + 1)) << 4 : 16;
         }
         src += (size_t)y0 * W;
     } else {
@@ -339,11 +378,10 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
             qS[j] = any ? qS[j] : 0;
         }
     }
-    const char *slab = (const char *)(lds + SLAB);
     const int wave = tid >> 6, lane = tid & 63;
 
-    for (int blk = 0; blk < g.nblk; ++blk) {
-        if (LDS) {
+    for (int blk = blk_lo; blk < blk_hi; ++blk) {
+        if (LDS && !(tg.ablate & 1)) {
             // ---- stage this channel block's rows: LDS slot s <- pixel swz(s) - PAD ----
             for (int s0 = wave * 64; s0 < nslots; s0 += NT) {
                 const int p = swz(s0 + lane) - PAD;
@@ -352,35 +390,43 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
                         (const __attribute__((address_space(1))) void *)(src + p),
                         (__attribute__((address_space(3))) void *)(lds + SLAB + s0), 16, 0, 0);
             }
-            __syncthreads();  // drains the DMA (vmcnt) and makes the slab visible
         }
+        if (LDS) __syncthreads();  // drains the DMA (vmcnt) and makes the slab visible
         if (active) {
             const int cbase = blk * CB;
             uint32_t pk[CB][4];  // per channel: one 16-byte vector of V points
+            if (tg.ablate & 4) {
+#pragma unroll
+                for (int k = 0; k < CB; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pk[k][j] = (uint32_t)qN[j] + k + blk;
+            } else
 #pragma unroll
             for (int j = 0; j < V; j += 2) {
                 float ra[CB], rb[CB];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int a = qN[j + u], c = qS[j + u];
                     uint4 qnw, qne, qsw, qse;
-                    if (LDS) {
-                        qnw = *(const uint4 *)(slab + (swz(a) << 4));
-                        qne = *(const uint4 *)(slab + (swz(a + 1) << 4));
-                        qsw = *(const uint4 *)(slab + (swz(c) << 4));
-                        qse = *(const uint4 *)(slab + (swz(c + 1) << 4));
+                    Tap t;
+                    const float w = fw[j + u], n = fn[j + u], e = 1.0f - w, s2 = 1.0f - n;
+                    t.nw = s2 * e; t.ne = s2 * w; t.sw = n * e; t.se = n * w;
+                    if constexpr (LDS) {
+                        const char *lb = (const char *)lds;
+                        qnw = *(const uint4 *)(lb + ta[j + u][0]);
+                        qne = *(const uint4 *)(lb + ta[j + u][1]);
+                        qsw = *(const uint4 *)(lb + ta[j + u][2]);
+                        qse = *(const uint4 *)(lb + ta[j + u][3]);
+                        blend_nomask<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
                     } else {
+                        const int a = qN[j + u], c = qS[j + u];
                         qnw = src[max(a, 0)];
                         qne = src[min(a + 1, HW - 1)];
                         qsw = src[max(c, 0)];
                         qse = src[min(c + 1, HW - 1)];
+                        t.ok = (okbits >> (4 * (j + u))) & 15u;
+                        if (all_in) blend_nomask<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
+                        else blend<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
                     }
-                    Tap t;
-                    const float w = fw[j + u], n = fn[j + u], e = 1.0f - w, s2 = 1.0f - n;
-                    t.nw = s2 * e; t.ne = s2 * w; t.sw = n * e; t.se = n * w;
-                    t.ok = (okbits >> (4 * (j + u))) & 15u;
-                    if (all_in) blend_nomask<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
-                    else blend<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
                 }
 #pragma unroll
                 for (int k = 0; k < CB; ++k) {
@@ -395,7 +441,7 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
             }
 #pragma unroll
             for (int k = 0; k < CB; ++k) {
-                if (cbase + k < g.C) {
+                if (cbase + k < g.C && (!(tg.ablate & 2) || pk[k][0] == 0x12345u)) {
                     u32x4_t v = {pk[k][0], pk[k][1], pk[k][2], pk[k][3]};
                     __builtin_nontemporal_store(v, (u32x4_t *)(o + (size_t)(cbase + k) * g.N));
                 }
@@ -530,9 +576,10 @@ size_t blocked_bytes(const dfm_sweep_desc *d)
 size_t flag_bytes(const dfm_sweep_desc *d)
 {
     const int V = d->dtype == DFM_BF16 ? 8 : 4;
-    const long long N = (long long)d->num_depths * d->h_out * d->w_out;
-    const long long tiles = (N / V + 127) / 128 + 1;
-    return ((size_t)tiles * 2 * d->batch + 255) & ~(size_t)255;
+    const long long hw = (long long)d->h_out * d->w_out;
+    const long long bands = (hw + 7 + 128ll * V - 1) / (128ll * V);  // smallest tile (128 lanes)
+    const long long nblk = (d->channels + V - 1) / V;  // worst case: one block per group
+    return ((size_t)(bands * d->num_depths * 2 * d->batch * nblk) + 255) & ~(size_t)255;
 }
 
 template <typename T>
@@ -570,21 +617,40 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
     } else {
         const int nt = g_lds_nt;
         const int lds_bytes = g_lds_kb * 1024;
-        const long long tiles = (g.N / V + nt - 1) / nt;
-        const long long nb = tiles * 2 * d->batch;  // (tile, cur|prev, sample)
+        const int bpg = which == 2 ? std::min(g_blocks_per_group, g.nblk) : g.nblk;
+        const int groups = (g.nblk + bpg - 1) / bpg;
+        const long long hw = (long long)g.h_out * g.w_out;
+        TileGrid tg;
+        tg.batch = d->batch;
+        tg.bands = (int)((hw + 7 + (long long)nt * V - 1) / ((long long)nt * V));
+        tg.band_pts = (int)((((hw + 7 + tg.bands - 1) / tg.bands) + 7) & ~7ll);
+        tg.blocks_per_group = bpg;
+        {
+            const char *ab = getenv("DFM_ABLATE");  // perf experiments only
+            tg.ablate = ab ? atoi(ab) : 0;
+        }
+        const long long nb = (long long)tg.bands * g.D * 2 * d->batch * groups;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
         if ((size_t)nb > flag_bytes(d)) return fail(DFM_ERR_WORKSPACE, "flag area too small%s");
         unsigned char *flags = (unsigned char *)ws + 2 * blocked_bytes(d);
+        SweepFast fast;
+        fast.scale_is_one = d->img_scale_factor == 1.0f;
+        {
+            int e = 0;
+            const float m = frexpf(d->feat_sample_factor, &e);
+            fast.fsf_pow2 = (m == 0.5f) && e > -60 && e < 60;
+            fast.inv_fsf = 1.0f / d->feat_sample_factor;
+        }
         auto kern = nt == 128 ? sweep_tile_kernel<T, 128, true> : sweep_tile_kernel<T, 256, true>;
         auto spill = nt == 128 ? sweep_tile_kernel<T, 128, false> : sweep_tile_kernel<T, 256, false>;
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     lds_bytes));
         if (which == 2)
-            hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nt), lds_bytes, st, g, d->batch,
+            hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nt), lds_bytes, st, g, fast, tg,
                                lds_bytes / 16, cur_blk, prev_blk, depths, P, Pinv, Tm, (T *)out,
                                flags);
         // flagged tiles (rows beyond the LDS budget), or all tiles for which == 3
-        hipLaunchKernelGGL(spill, dim3((unsigned)nb), dim3(nt), 16, st, g, d->batch, 0, cur_blk,
+        hipLaunchKernelGGL(spill, dim3((unsigned)nb), dim3(nt), 16, st, g, fast, tg, 0, cur_blk,
                            prev_blk, depths, P, Pinv, Tm, (T *)out,
                            which == 2 ? flags : (unsigned char *)nullptr);
     }
@@ -605,12 +671,15 @@ DFM_API int dfm_version(void) { return 1; }
 DFM_API const char *dfm_last_error(void) { return g_err; }
 DFM_API int dfm_plane_sweep_last_kernel(void) { return g_last_kernel; }
 DFM_API void dfm_plane_sweep_force_kernel(int which) { g_force_kernel = which; }
-DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib)
+DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int blocks_per_group)
 {
-    if ((lanes_per_workgroup != 128 && lanes_per_workgroup != 256) || lds_kib < 4 || lds_kib > 160)
-        return fail(DFM_ERR_INVALID_ARG, "tune: lanes in {128,256}, 4 <= lds_kib <= 160%s");
+    if ((lanes_per_workgroup != 128 && lanes_per_workgroup != 256) || lds_kib < 4 ||
+        lds_kib > 160 || blocks_per_group < 1)
+        return fail(DFM_ERR_INVALID_ARG,
+                    "tune: lanes in {128,256}, 4 <= lds_kib <= 160, blocks_per_group >= 1%s");
     g_lds_nt = lanes_per_workgroup;
     g_lds_kb = lds_kib;
+    g_blocks_per_group = blocks_per_group;
     return DFM_OK;
 }
 
