@@ -116,6 +116,7 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='LDS kernel lanes/workgroup (128|256)')
     ap.add_argument('--lds-kib', type=int, default=0, help='LDS kernel KiB/workgroup')
     ap.add_argument('--bpg', type=int, default=0, help='LDS kernel channel blocks per group')
+    ap.add_argument('--planes', type=int, default=0, help='LDS kernel depth planes per workgroup')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass')
@@ -137,8 +138,9 @@ def main():
     sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
     lib = pkg._capi.lib()
     lib.dfm_plane_sweep_force_kernel(args.kernel)
-    if args.lanes or args.lds_kib or args.bpg:
-        pkg._capi.check(lib.dfm_plane_sweep_tune(args.lanes or 256, args.lds_kib or 64, args.bpg or 4))
+    if args.lanes or args.lds_kib or args.bpg or args.planes:
+        pkg._capi.check(lib.dfm_plane_sweep_tune(args.lanes or 256, args.lds_kib or 52,
+                                                 args.bpg or (1 << 20), args.planes or 4))
 
     w = WORKLOADS[args.workload]
     tdtype = torch.bfloat16 if w['dtype'] == 'bf16' else torch.float32

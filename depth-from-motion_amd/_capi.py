@@ -87,7 +87,7 @@ def lib():
     h.dfm_plane_sweep_force_kernel.restype = None
     h.dfm_plane_sweep_force_kernel.argtypes = [ctypes.c_int]
     h.dfm_plane_sweep_tune.restype = ctypes.c_int
-    h.dfm_plane_sweep_tune.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    h.dfm_plane_sweep_tune.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     _lib = h
     return h
 

@@ -34,7 +34,9 @@ thread_local int g_last_kernel = 0;
 int g_force_kernel = 0;
 // LDS-kernel launch shape (tunable for A/B runs: dfm_plane_sweep_tune)
 int g_lds_nt = 256;  // lanes per workgroup: 128 or 256
-int g_lds_kb = 64;   // dynamic LDS per workgroup, KiB
+int g_lds_kb = 52;   // dynamic LDS per workgroup, KiB
+unsigned long long *g_trace = nullptr;  // debug: see dfm_debug_set_trace
+int g_planes = 4;             // depth planes per workgroup of the LDS kernel
 int g_blocks_per_group = 1 << 20;  // channel blocks per workgroup (default: all)
 
 // optional per-launch timing of the dominant (volume-writing) kernel with HIP
@@ -213,6 +215,12 @@ __global__ __launch_bounds__(256) void sweep_gather_kernel(
 // ---------------------------------------------------------------------------
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
+// s_waitcnt immediate (gfx9 encoding) that waits only on vmcnt <= n
+__device__ __forceinline__ constexpr int waitcnt_vm(int n)
+{
+    return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14);
+}
+
 __device__ __forceinline__ int swz(int q) { return q ^ ((q >> 4) & 7); }
 
 // footprint of one point in one map: rows (clamped into the map), west column
@@ -232,8 +240,12 @@ __device__ __forceinline__ uint32_t footprint(float x, float y, int H, int W, in
 struct TileGrid {
     int batch;
     int bands;             // tiles per depth plane
-    int band_pts;          // points per tile (multiple of 8, <= NT*V)
+    int band_pts;          // points per tile and plane (multiple of 8, <= NT*V/planes)
+    int planes;            // depth planes per workgroup (divides NT/64)
+    int dgroups;           // ceil(D / planes)
     int blocks_per_group;  // channel blocks one workgroup sweeps
+    unsigned long long *trace;  // perf experiments only: per-phase s_memtime stamps
+    int stage_mode;        // 0 LDS-DMA, 1 load + ds_write (A/B: DFM_STAGE)
     int ablate;            // perf experiments only (DFM_ABLATE): 1 no staging,
                            // 2 no volume stores, 4 no taps/blend; results are wrong
 };
@@ -268,30 +280,36 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
     //                     of the SAME map over consecutive depth planes: they
     //                     stage the same (cur) or neighbouring (prev) feature
     //                     rows, which therefore stay in that XCD's L2
+    // A workgroup = `planes` consecutive depth planes x one band: wave w sweeps
+    // plane (w / waves_per_plane).  All of them sample the same band of the map,
+    // so one staged slab serves `planes` times as many volume bytes (the cur
+    // rows are identical for every plane, the prev rows shift slowly with depth).
     const int batch = tg.batch;
     const int b = blockIdx.x % batch;
     int th = blockIdx.x / batch;
-    const int d_tile = th % g.D;
-    th /= g.D;
+    const int dgroup = th % tg.dgroups;
+    th /= tg.dgroups;
     const int half = th & 1;
     th >>= 1;
     const int band = th % tg.bands;
     const int group = th / tg.bands;
     const int blk_lo = group * tg.blocks_per_group;
     const int blk_hi = min(blk_lo + tg.blocks_per_group, g.nblk);
+    const int lanes_per_plane = NT / tg.planes;
+    const int d_tile = dgroup * tg.planes + tid / lanes_per_plane;
+    const int tid_p = tid % lanes_per_plane;
     const long long hw_ll = (long long)g.h_out * g.w_out;
     const long long a0 = (d_tile * hw_ll) & ~7ll;
-    const long long a1 = d_tile == g.D - 1 ? g.N : (((d_tile + 1) * hw_ll) & ~7ll);
-    const long long t_end = min(a0 + (long long)(band + 1) * tg.band_pts, a1);
-    const long long n0 = a0 + (long long)band * tg.band_pts + (long long)tid * V;
+    const long long a1 = d_tile >= g.D - 1 ? g.N : (((d_tile + 1) * hw_ll) & ~7ll);
+    const long long t_end = d_tile < g.D ? min(a0 + (long long)(band + 1) * tg.band_pts, a1) : 0;
+    const long long n0 = a0 + (long long)band * tg.band_pts + (long long)tid_p * V;
     const bool active = n0 < t_end;
     const int W = g.w_in, H = g.h_in;
     const int HW = H * W;
 
     if (LDS) {
-        // slot 0: bbox scratch; slot 1: sixteen zero bytes, the tap every
-        // out-of-bounds corner reads (grid_sample's zeros padding)
-        if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; lds[1] = make_uint4(0u, 0u, 0u, 0u); }
+        // slot 0: bbox scratch
+        if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; }
         __syncthreads();
     }
 
@@ -358,14 +376,20 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
         // the staged rows + PAD), or the zero slot for an out-of-bounds corner.
         // Nothing in the channel loop depends on the in-bounds bits any more.
         const int off = PAD - y0 * W;
+        // zero corner: slab slot 0 (q < PAD is never a pixel, and the swizzle keeps
+        // slots 0..7 among themselves), zeroed here once
+        constexpr int ZERO = SLAB << 4;
+        if (tid == 0) {
+            lds[SLAB] = make_uint4(0u, 0u, 0u, 0u);
+        }
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const uint32_t ok = (okbits >> (4 * j)) & 15u;
             const int a = qN[j] + off, c = qS[j] + off;
-            ta[j][0] = (ok & 1u) ? (SLAB + swz(a)) << 4 : 16;
-            ta[j][1] = (ok & 2u) ? (SLAB + swz(a + 1)) << 4 : 16;
-            ta[j][2] = (ok & 4u) ? (SLAB + swz(c)) << 4 : 16;
-            ta[j][3] = (ok & 8u) ? (SLAB + swz(c + 1)) << 4 : 16;
+            ta[j][0] = (ok & 1u) ? (SLAB + swz(a)) << 4 : ZERO;
+            ta[j][1] = (ok & 2u) ? (SLAB + swz(a + 1)) << 4 : ZERO;
+            ta[j][2] = (ok & 4u) ? (SLAB + swz(c)) << 4 : ZERO;
+            ta[j][3] = (ok & 8u) ? (SLAB + swz(c + 1)) << 4 : ZERO;
         }
         src += (size_t)y0 * W;
     } else {
@@ -379,76 +403,152 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
         }
     }
     const int wave = tid >> 6, lane = tid & 63;
+    // debug trace: wave 0 of every 509th workgroup stamps its phases
+    unsigned long long *tr = (tg.trace && (blockIdx.x % 509) == 0 && tid == 0)
+                                 ? tg.trace + (size_t)(blockIdx.x / 509) * 64 : nullptr;
+    int tri = 0;
+#define TRACE_STAMP()                                                                       \
+    do {                                                                                    \
+        if (tr && tri < 64) {                                                               \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+            tr[tri++] = t_;                                                                 \
+        }                                                                                   \
+    } while (0)
+    TRACE_STAMP();
 
-    for (int blk = blk_lo; blk < blk_hi; ++blk) {
-        if (LDS && !(tg.ablate & 1)) {
-            // ---- stage this channel block's rows: LDS slot s <- pixel swz(s) - PAD ----
-            for (int s0 = wave * 64; s0 < nslots; s0 += NT) {
-                const int p = swz(s0 + lane) - PAD;
-                if (p >= 0 && p < cnt)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(src + p),
-                        (__attribute__((address_space(3))) void *)(lds + SLAB + s0), 16, 0, 0);
-            }
-        }
-        if (LDS) __syncthreads();  // drains the DMA (vmcnt) and makes the slab visible
-        if (active) {
-            const int cbase = blk * CB;
-            uint32_t pk[CB][4];  // per channel: one 16-byte vector of V points
-            if (tg.ablate & 4) {
+    // blend the V points x CB channels of one channel block and store them
+    auto compute_store = [&](int blk, const uint4 *gsrc) {
+        const int cbase = blk * CB;
+        uint32_t pk[CB][4];  // per channel: one 16-byte vector of V points
+        if (tg.ablate & 4) {
 #pragma unroll
-                for (int k = 0; k < CB; ++k)
+            for (int k = 0; k < CB; ++k)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pk[k][j] = (uint32_t)qN[j] + k + blk;
-            } else
+                for (int j = 0; j < 4; ++j) pk[k][j] = (uint32_t)qN[j] + k + blk;
+        } else if constexpr (LDS) {
+            // Taps come from LDS through inline-asm ds_read_b128 (hipcc would put
+            // a vmcnt(0) in front of the first LDS read after an LDS-DMA was
+            // issued, and serialises reads against blends).  Software pipeline:
+            // the 4 corner reads of point j+1 are in flight while point j blends;
+            // LDS returns in order, so lgkmcnt(4) == "point j has landed".
+            u32x4_t q[2][4];
+            float keep[CB];  // even point of a pair, waiting for its odd partner
+            asm volatile("ds_read_b128 %0, %1" : "=v"(q[0][0]) : "v"(ta[0][0]));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(q[0][1]) : "v"(ta[0][1]));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(q[0][2]) : "v"(ta[0][2]));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(q[0][3]) : "v"(ta[0][3]));
 #pragma unroll
-            for (int j = 0; j < V; j += 2) {
-                float ra[CB], rb[CB];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    uint4 qnw, qne, qsw, qse;
-                    Tap t;
-                    const float w = fw[j + u], n = fn[j + u], e = 1.0f - w, s2 = 1.0f - n;
-                    t.nw = s2 * e; t.ne = s2 * w; t.sw = n * e; t.se = n * w;
-                    if constexpr (LDS) {
-                        const char *lb = (const char *)lds;
-                        qnw = *(const uint4 *)(lb + ta[j + u][0]);
-                        qne = *(const uint4 *)(lb + ta[j + u][1]);
-                        qsw = *(const uint4 *)(lb + ta[j + u][2]);
-                        qse = *(const uint4 *)(lb + ta[j + u][3]);
-                        blend_nomask<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
-                    } else {
-                        const int a = qN[j + u], c = qS[j + u];
-                        qnw = src[max(a, 0)];
-                        qne = src[min(a + 1, HW - 1)];
-                        qsw = src[max(c, 0)];
-                        qse = src[min(c + 1, HW - 1)];
-                        t.ok = (okbits >> (4 * (j + u))) & 15u;
-                        if (all_in) blend_nomask<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
-                        else blend<CB>(t, qnw, qne, qsw, qse, u ? rb : ra);
-                    }
+            for (int j = 0; j < V; ++j) {
+                const int cb = j & 1, nb = cb ^ 1;
+                if (j + 1 < V) {
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(q[nb][0]) : "v"(ta[j + 1][0]));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(q[nb][1]) : "v"(ta[j + 1][1]));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(q[nb][2]) : "v"(ta[j + 1][2]));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(q[nb][3]) : "v"(ta[j + 1][3]));
+                    asm volatile("s_waitcnt lgkmcnt(4)"
+                                 : "+v"(q[cb][0]), "+v"(q[cb][1]), "+v"(q[cb][2]), "+v"(q[cb][3]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(q[cb][0]), "+v"(q[cb][1]), "+v"(q[cb][2]), "+v"(q[cb][3]));
                 }
+                Tap t;
+                const float w = fw[j], n = fn[j], e = 1.0f - w, s2 = 1.0f - n;
+                t.nw = s2 * e; t.ne = s2 * w; t.sw = n * e; t.se = n * w;
+                float r[CB];
+                blend_nomask<CB>(t, make_uint4(q[cb][0].x, q[cb][0].y, q[cb][0].z, q[cb][0].w),
+                                 make_uint4(q[cb][1].x, q[cb][1].y, q[cb][1].z, q[cb][1].w),
+                                 make_uint4(q[cb][2].x, q[cb][2].y, q[cb][2].z, q[cb][2].w),
+                                 make_uint4(q[cb][3].x, q[cb][3].y, q[cb][3].z, q[cb][3].w), r);
 #pragma unroll
                 for (int k = 0; k < CB; ++k) {
                     if constexpr (sizeof(T) == 4) {
-                        pk[k][j] = __float_as_uint(ra[k]);
-                        pk[k][j + 1] = __float_as_uint(rb[k]);
+                        pk[k][j] = __float_as_uint(r[k]);
                     } else {
-                        pk[k][j >> 1] = pack_bf16x2(ra[k], rb[k]);
+                        if (j & 1) pk[k][j >> 1] = pack_bf16x2(keep[k], r[k]);
+                        else keep[k] = r[k];
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
 #pragma unroll
-            for (int k = 0; k < CB; ++k) {
-                if (cbase + k < g.C && (!(tg.ablate & 2) || pk[k][0] == 0x12345u)) {
-                    u32x4_t v = {pk[k][0], pk[k][1], pk[k][2], pk[k][3]};
-                    __builtin_nontemporal_store(v, (u32x4_t *)(o + (size_t)(cbase + k) * g.N));
+            for (int j = 0; j < V; ++j) {
+                Tap t;
+                const float w = fw[j], n = fn[j], e = 1.0f - w, s2 = 1.0f - n;
+                t.nw = s2 * e; t.ne = s2 * w; t.sw = n * e; t.se = n * w;
+                const int a = qN[j], c = qS[j];
+                const uint4 qnw = gsrc[max(a, 0)], qne = gsrc[min(a + 1, HW - 1)];
+                const uint4 qsw = gsrc[max(c, 0)], qse = gsrc[min(c + 1, HW - 1)];
+                t.ok = (okbits >> (4 * j)) & 15u;
+                float r[CB];
+                if (all_in) blend_nomask<CB>(t, qnw, qne, qsw, qse, r);
+                else blend<CB>(t, qnw, qne, qsw, qse, r);
+#pragma unroll
+                for (int k = 0; k < CB; ++k) {
+                    if constexpr (sizeof(T) == 4) pk[k][j] = __float_as_uint(r[k]);
+                    else if (j & 1) pk[k][j >> 1] |= (uint32_t)f32_to_bf16(r[k]) << 16;
+                    else pk[k][j >> 1] = (uint32_t)f32_to_bf16(r[k]);
                 }
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        src += HW;
-        if (LDS) __syncthreads();  // everyone is done with the slab before it is refilled
+        TRACE_STAMP();
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            if (cbase + k < g.C && (!(tg.ablate & 2) || pk[k][0] == 0x12345u)) {
+                u32x4_t v = {pk[k][0], pk[k][1], pk[k][2], pk[k][3]};
+                __builtin_nontemporal_store(v, (u32x4_t *)(o + (size_t)(cbase + k) * g.N));
+            }
+        }
+    };
+
+    if constexpr (!LDS) {
+        for (int blk = blk_lo; blk < blk_hi; ++blk) {
+            compute_store(blk, src);
+            src += HW;
+        }
+    } else {
+        // stage one channel block's rows into LDS, pixel p -> slot swz(p + PAD).
+        //  mode 0: LDS-DMA (global_load_lds, no VGPR round trip; the DMA writes
+        //          LDS linearly, so the swizzle goes on the SOURCE pixel)
+        //  mode 1: global_load_dwordx4 -> VGPR -> ds_write_b128, 8 loads in flight
+        auto stage = [&](int buf_slot0, const uint4 *gsrc) {
+            if (tg.ablate & 1) return;
+            if (tg.stage_mode == 0) {
+                for (int s0 = wave * 64; s0 < nslots; s0 += NT) {
+                    const int p = swz(s0 + lane) - PAD;
+                    if (p >= 0 && p < cnt)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(gsrc + p),
+                            (__attribute__((address_space(3))) void *)(lds + buf_slot0 + s0), 16, 0,
+                            0);
+                }
+            } else {
+                for (int p0 = tid; p0 < cnt; p0 += 8 * NT) {
+                    uint4 v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (p0 + i * NT < cnt) v[i] = gsrc[p0 + i * NT];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (p0 + i * NT < cnt) lds[buf_slot0 + swz(p0 + i * NT + PAD)] = v[i];
+                }
+            }
+        };
+        // stage -> barrier -> blend+store -> barrier.  (A double-buffered variant
+        // with counted vmcnt measured no faster on MI355X and doubled the LDS per
+        // workgroup; profiles/r01_v6_double_buffer_variants.txt.)
+        for (int blk = blk_lo; blk < blk_hi; ++blk) {
+            stage(SLAB, src);
+            TRACE_STAMP();
+            __syncthreads();  // drains the DMA (vmcnt) and makes the rows visible
+            TRACE_STAMP();
+            if (active) compute_store(blk, src);
+            TRACE_STAMP();
+            src += HW;
+            __syncthreads();  // everyone is done with the rows before the refill
+            TRACE_STAMP();
+        }
     }
 }
 
@@ -577,7 +677,7 @@ size_t flag_bytes(const dfm_sweep_desc *d)
 {
     const int V = d->dtype == DFM_BF16 ? 8 : 4;
     const long long hw = (long long)d->h_out * d->w_out;
-    const long long bands = (hw + 7 + 128ll * V - 1) / (128ll * V);  // smallest tile (128 lanes)
+    const long long bands = (hw + 7 + 64ll * V - 1) / (64ll * V);  // smallest tile (one wave per plane)
     const long long nblk = (d->channels + V - 1) / V;  // worst case: one block per group
     return ((size_t)(bands * d->num_depths * 2 * d->batch * nblk) + 255) & ~(size_t)255;
 }
@@ -622,14 +722,21 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
         const long long hw = (long long)g.h_out * g.w_out;
         TileGrid tg;
         tg.batch = d->batch;
-        tg.bands = (int)((hw + 7 + (long long)nt * V - 1) / ((long long)nt * V));
+        tg.planes = std::max(1, std::min(g_planes, nt / 64));
+        while ((nt / 64) % tg.planes) --tg.planes;  // whole waves per plane
+        tg.dgroups = (g.D + tg.planes - 1) / tg.planes;
+        const long long per_plane = (long long)(nt / tg.planes) * V;  // points per plane and tile
+        tg.bands = (int)((hw + 7 + per_plane - 1) / per_plane);
         tg.band_pts = (int)((((hw + 7 + tg.bands - 1) / tg.bands) + 7) & ~7ll);
         tg.blocks_per_group = bpg;
+        tg.trace = g_trace;
+        tg.stage_mode = 0;
+        if (const char *sm = getenv("DFM_STAGE")) tg.stage_mode = atoi(sm);  // A/B runs
         {
             const char *ab = getenv("DFM_ABLATE");  // perf experiments only
             tg.ablate = ab ? atoi(ab) : 0;
         }
-        const long long nb = (long long)tg.bands * g.D * 2 * d->batch * groups;
+        const long long nb = (long long)tg.bands * tg.dgroups * 2 * d->batch * groups;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
         if ((size_t)nb > flag_bytes(d)) return fail(DFM_ERR_WORKSPACE, "flag area too small%s");
         unsigned char *flags = (unsigned char *)ws + 2 * blocked_bytes(d);
@@ -671,15 +778,21 @@ DFM_API int dfm_version(void) { return 1; }
 DFM_API const char *dfm_last_error(void) { return g_err; }
 DFM_API int dfm_plane_sweep_last_kernel(void) { return g_last_kernel; }
 DFM_API void dfm_plane_sweep_force_kernel(int which) { g_force_kernel = which; }
-DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int blocks_per_group)
+// internal (not in dfm_hip.h): device buffer of 64 x u64 per traced workgroup
+DFM_API void dfm_debug_set_trace(void *buf) { g_trace = (unsigned long long *)buf; }
+
+DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int blocks_per_group,
+                                 int planes_per_workgroup)
 {
     if ((lanes_per_workgroup != 128 && lanes_per_workgroup != 256) || lds_kib < 4 ||
-        lds_kib > 160 || blocks_per_group < 1)
+        lds_kib > 160 || blocks_per_group < 1 || planes_per_workgroup < 1)
         return fail(DFM_ERR_INVALID_ARG,
-                    "tune: lanes in {128,256}, 4 <= lds_kib <= 160, blocks_per_group >= 1%s");
+                    "tune: lanes in {128,256}, 4 <= lds_kib <= 160, blocks_per_group >= 1, "
+                    "planes_per_workgroup >= 1%s");
     g_lds_nt = lanes_per_workgroup;
     g_lds_kb = lds_kib;
     g_blocks_per_group = blocks_per_group;
+    g_planes = planes_per_workgroup;
     return DFM_OK;
 }
 

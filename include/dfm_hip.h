@@ -143,11 +143,13 @@ DFM_API int dfm_plane_sweep_last_kernel(void);
  * auto = 2 for dense sweeps (cost_sample_factor < 1.5), 3 for strided ones. */
 DFM_API void dfm_plane_sweep_force_kernel(int which);
 /* Launch shape of the LDS-staged kernel (process-wide): lanes per workgroup
- * (128 or 256), dynamic LDS per workgroup in KiB (4..160) and how many 16-byte
- * channel blocks one workgroup sweeps before the next tile (the L2 working
- * set is blocks_per_group x 2 maps x H*W*16 B per sample).  A tile whose
- * feature rows do not fit the LDS is redone with direct taps. */
-DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int blocks_per_group);
+ * (128 or 256), dynamic LDS per workgroup in KiB (4..160), how many 16-byte
+ * channel blocks one workgroup sweeps before the next tile, and how many
+ * consecutive depth planes share one workgroup's staged feature rows (rounded
+ * down to a divisor of lanes/64).  A tile whose feature rows do not fit the
+ * LDS is redone with direct taps. */
+DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int blocks_per_group,
+                                 int planes_per_workgroup);
 
 #ifdef __cplusplus
 }
