@@ -140,7 +140,7 @@ def main():
     lib.dfm_plane_sweep_force_kernel(args.kernel)
     if args.lanes or args.lds_kib or args.bpg or args.planes:
         pkg._capi.check(lib.dfm_plane_sweep_tune(args.lanes or 256, args.lds_kib or 52,
-                                                 args.bpg or (1 << 20), args.planes or 4))
+                                                 args.bpg or (1 << 20), args.planes or 2))
 
     w = WORKLOADS[args.workload]
     tdtype = torch.bfloat16 if w['dtype'] == 'bf16' else torch.float32

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libdfm_hip.so')
+LIB_PATH = os.environ.get('DFM_HIP_LIB', os.path.join(_HERE, 'lib', 'libdfm_hip.so'))
 
 DFM_F32, DFM_BF16 = 0, 1
 

@@ -36,7 +36,7 @@ int g_force_kernel = 0;
 int g_lds_nt = 256;  // lanes per workgroup: 128 or 256
 int g_lds_kb = 52;   // dynamic LDS per workgroup, KiB
 unsigned long long *g_trace = nullptr;  // debug: see dfm_debug_set_trace
-int g_planes = 4;             // depth planes per workgroup of the LDS kernel
+int g_planes = 2;             // depth planes per workgroup of the LDS kernel (measured best)
 int g_blocks_per_group = 1 << 20;  // channel blocks per workgroup (default: all)
 
 // optional per-launch timing of the dominant (volume-writing) kernel with HIP
@@ -245,7 +245,6 @@ struct TileGrid {
     int dgroups;           // ceil(D / planes)
     int blocks_per_group;  // channel blocks one workgroup sweeps
     unsigned long long *trace;  // perf experiments only: per-phase s_memtime stamps
-    int stage_mode;        // 0 LDS-DMA, 1 load + ds_write (A/B: DFM_STAGE)
     int ablate;            // perf experiments only (DFM_ABLATE): 1 no staging,
                            // 2 no volume stores, 4 no taps/blend; results are wrong
 };
@@ -508,31 +507,18 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
             src += HW;
         }
     } else {
-        // stage one channel block's rows into LDS, pixel p -> slot swz(p + PAD).
-        //  mode 0: LDS-DMA (global_load_lds, no VGPR round trip; the DMA writes
-        //          LDS linearly, so the swizzle goes on the SOURCE pixel)
-        //  mode 1: global_load_dwordx4 -> VGPR -> ds_write_b128, 8 loads in flight
+        // stage one channel block's rows into LDS, pixel p -> slot swz(p + PAD), by
+        // LDS-DMA (global_load_lds: no VGPR round trip; the DMA writes LDS linearly,
+        // so the swizzle goes on the SOURCE pixel).  A global_load -> ds_write
+        // variant measured 2x slower and cost 20 VGPRs (r01 profiles).
         auto stage = [&](int buf_slot0, const uint4 *gsrc) {
             if (tg.ablate & 1) return;
-            if (tg.stage_mode == 0) {
-                for (int s0 = wave * 64; s0 < nslots; s0 += NT) {
-                    const int p = swz(s0 + lane) - PAD;
-                    if (p >= 0 && p < cnt)
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void *)(gsrc + p),
-                            (__attribute__((address_space(3))) void *)(lds + buf_slot0 + s0), 16, 0,
-                            0);
-                }
-            } else {
-                for (int p0 = tid; p0 < cnt; p0 += 8 * NT) {
-                    uint4 v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (p0 + i * NT < cnt) v[i] = gsrc[p0 + i * NT];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (p0 + i * NT < cnt) lds[buf_slot0 + swz(p0 + i * NT + PAD)] = v[i];
-                }
+            for (int s0 = wave * 64; s0 < nslots; s0 += NT) {
+                const int p = swz(s0 + lane) - PAD;
+                if (p >= 0 && p < cnt)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(gsrc + p),
+                        (__attribute__((address_space(3))) void *)(lds + buf_slot0 + s0), 16, 0, 0);
             }
         };
         // stage -> barrier -> blend+store -> barrier.  (A double-buffered variant
@@ -730,8 +716,6 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
         tg.band_pts = (int)((((hw + 7 + tg.bands - 1) / tg.bands) + 7) & ~7ll);
         tg.blocks_per_group = bpg;
         tg.trace = g_trace;
-        tg.stage_mode = 0;
-        if (const char *sm = getenv("DFM_STAGE")) tg.stage_mode = atoi(sm);  // A/B runs
         {
             const char *ab = getenv("DFM_ABLATE");  // perf experiments only
             tg.ablate = ab ? atoi(ab) : 0;

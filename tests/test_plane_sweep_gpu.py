@@ -48,7 +48,7 @@ def kernel_mode(request, pkg):
     pkg._capi.check(lib.dfm_plane_sweep_tune(lanes, kib, bpg, planes))
     yield request.param
     lib.dfm_plane_sweep_force_kernel(0)
-    pkg._capi.check(lib.dfm_plane_sweep_tune(256, 52, 1 << 20, 4))
+    pkg._capi.check(lib.dfm_plane_sweep_tune(256, 52, 1 << 20, 2))
 
 
 def run_hip(pkg, cur, prev, depths, fsf, csf, P, T, img_shape, flip, crop, scale, dtype=torch.float32):

@@ -31,6 +31,30 @@ __global__ void k(float *out, int iters, float s) {
             } else if (MODE == 5) {  // v_cvt_pk_bf16_f32 x8
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s)); }
+            } else if (MODE == 7) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(65536u)); }
+            } else if (MODE == 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(u[i]) : "v"(0u)); }
+            } else if (MODE == 9) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { asm volatile("v_lshl_add_u32 %0, %0, 16, %1" : "+v"(u[i]) : "v"(0u)); }
+            } else if (MODE == 10) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(u[i]) : "v"(0u)); }
+            } else if (MODE == 11) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(u[i]) : "v"(65536u), "v"(0u)); }
+            } else if (MODE == 12) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { asm volatile("v_cvt_f32_bf16 %0, %0" : "+v"(u[i])); }
+            } else if (MODE == 13) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { asm volatile("v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "+v"(u[i]) : "v"(16u)); }
+            } else if (MODE == 14) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { asm volatile("v_mov_b32_sdwa %0, %0 dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "+v"(u[i])); }
             } else if (MODE == 6) {  // v_perm_b32 x8
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "s"(0x07060302)); }
@@ -58,5 +82,10 @@ int main() {
     float *out; CK(hipMalloc(&out, 64));
     run<0>("v_fma_f32", out); run<1>("v_pk_fma_f32", out); run<2>("v_and_b32", out); run<3>("v_lshlrev_b32", out);
     run<4>("v_mul_f32", out); run<5>("v_cvt_pk_bf16_f32", out); run<6>("v_perm_b32", out);
+    run<7>("v_mul_u32_u24", out); run<8>("v_alignbit_b32", out); run<9>("v_lshl_add_u32", out);
+    run<10>("v_lshl_or_b32", out); run<11>("v_mad_u32_u24", out);
+#ifdef TRY_EXOTIC
+    run<12>("v_cvt_f32_bf16", out); run<13>("v_lshlrev_sdwa", out); run<14>("v_mov_sdwa_w1", out);
+#endif
     return 0;
 }
