@@ -25,6 +25,8 @@ EXPORTS = (
     'dfm_plane_sweep_last_kernel',
     'dfm_plane_sweep_force_kernel',
     'dfm_plane_sweep_tune',
+    'dfm_point_sample_mv_workspace_bytes',
+    'dfm_point_sample_mv_fwd',
 )
 
 
@@ -45,6 +47,32 @@ class SweepDesc(ctypes.Structure):
         ('crop_y', ctypes.c_float),
         ('org_w', ctypes.c_float),
         ('flip', ctypes.c_int32),
+        ('dtype', ctypes.c_int32),
+    ]
+
+
+class MvDesc(ctypes.Structure):
+    """struct dfm_mv_desc"""
+    _fields_ = [
+        ('num_views', ctypes.c_int32),
+        ('num_frames', ctypes.c_int32),
+        ('channels', ctypes.c_int32),
+        ('feat_h', ctypes.c_int32),
+        ('feat_w', ctypes.c_int32),
+        ('nx', ctypes.c_int32),
+        ('ny', ctypes.c_int32),
+        ('nz', ctypes.c_int32),
+        ('num_points', ctypes.c_int64),
+        ('scale_x', ctypes.c_float),
+        ('scale_y', ctypes.c_float),
+        ('crop_x', ctypes.c_float),
+        ('crop_y', ctypes.c_float),
+        ('flip', ctypes.c_int32),
+        ('pad_h', ctypes.c_float),
+        ('pad_w', ctypes.c_float),
+        ('mode', ctypes.c_int32),
+        ('aggregate', ctypes.c_int32),
+        ('valid_sample', ctypes.c_int32),
         ('dtype', ctypes.c_int32),
     ]
 
@@ -88,6 +116,11 @@ def lib():
     h.dfm_plane_sweep_force_kernel.argtypes = [ctypes.c_int]
     h.dfm_plane_sweep_tune.restype = ctypes.c_int
     h.dfm_plane_sweep_tune.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    mp = ctypes.POINTER(MvDesc)
+    h.dfm_point_sample_mv_workspace_bytes.restype = sz
+    h.dfm_point_sample_mv_workspace_bytes.argtypes = [mp]
+    h.dfm_point_sample_mv_fwd.restype = ctypes.c_int
+    h.dfm_point_sample_mv_fwd.argtypes = [mp, vp, fp, fp, fp, vp, vp, vp, sz, vp]
     _lib = h
     return h
 

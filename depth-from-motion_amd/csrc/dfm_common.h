@@ -13,6 +13,10 @@
 
 namespace dfm {
 
+// records the thread-local message dfm_last_error() returns; defined in
+// plane_sweep.hip, shared by every translation unit of the library
+int set_error(int code, const char *msg);
+
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v)

@@ -52,6 +52,15 @@ int fail(int code, const char *fmt, const char *detail = "")
     snprintf(g_err, sizeof(g_err), fmt, detail);
     return code;
 }
+}  // namespace
+
+int dfm::set_error(int code, const char *msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+namespace {
 
 #define HIP_TRY(expr)                                                                    \
     do {                                                                                 \

@@ -1,0 +1,255 @@
+// point_sample.hip -- multi-view voxel lifting (gfx950)
+//
+// Reference: point_sample (mmdet3d/models/fusion_layers/point_fusion.py:14-106)
+// called once per (frame, view) by MultiViewDfM.feature_transformation
+// (mmdet3d/models/detectors/multiview_dfm.py:119-208), followed by the
+// valid-count reduction over views and frames and the (Nz,Ny,Nx,C) ->
+// (C,Nx,Ny,Nz) permute.  Here ONE launch does all views and frames of a sample
+// and writes the final volume: no (N,C) per-view temporaries, no stack/sum/
+// permute passes.
+//
+// Layout in HBM
+//   feats     : caller tensor (F*Nv, C, Hf, Wf), f32 or bf16
+//   workspace : the same re-blocked to [F*Nv][C/CB][Hf][Wf][CB], CB*sizeof(T)=16 B
+//               (one 16-byte load = CB channels of the sampled pixel)
+//   out       : volume (C*F', Nx, Ny, Nz) or flat (N, C)
+// Bound: HBM write of the volume + L2-resident gathers; no reuse to stage.
+#include "dfm_common.h"
+
+#include <stdio.h>
+
+using namespace dfm;
+
+namespace {
+
+int fail_ps(int code, const char *msg) { return dfm::set_error(code, msg); }
+
+struct MvGeom {
+    int32_t num_views, num_frames, C, Hf, Wf, nblk;
+    int32_t nx, ny, nz;  // nz == 0 : flat (N, C) output
+    long long N;
+    float scale_x, scale_y, crop_x, crop_y, pad_h, pad_w;
+    int32_t flip, mode, aggregate, valid_sample;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_views_kernel(const T *__restrict__ src,
+                                                         uint4 *__restrict__ dst, int C, int HW,
+                                                         int nblk)
+{
+    constexpr int CB = elem<T>::CB;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int blk = blockIdx.y;
+    const int b = blockIdx.z;
+    if (pix >= HW) return;
+    T v[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int c = blk * CB + j;
+        v[j] = (c < C) ? src[((size_t)b * C + c) * HW + pix] : T(0);
+    }
+    uint4 q;
+    memcpy(&q, v, 16);
+    dst[((size_t)b * nblk + blk) * HW + pix] = q;
+}
+
+// projection + image transform of one point into one view; returns validity
+// (point_fusion.py:61-84,99-101) and the normalised grid coordinates
+__device__ __forceinline__ bool project_view(const MvGeom &g, const float *__restrict__ M,
+                                             float ori_w, float px, float py, float pz, float &nx,
+                                             float &ny)
+{
+    const float a = dot4_chain(px, py, pz, 1.0f, M + 0);
+    const float b = dot4_chain(px, py, pz, 1.0f, M + 4);
+    const float c = dot4_chain(px, py, pz, 1.0f, M + 8);
+    float x = a / c, y = b / c;
+    x = x * g.scale_x;
+    y = y * g.scale_y;
+    x = x - g.crop_x;
+    y = y - g.crop_y;
+    if (g.flip) x = ori_w - x;
+    ny = y / g.pad_h * 2.0f - 1.0f;
+    nx = x / g.pad_w * 2.0f - 1.0f;
+    return (x < g.pad_w) && (x > 0.0f) && (y < g.pad_h) && (y > 0.0f) && (c > 0.0f);
+}
+
+// one thread = one voxel (output order) ; loops channel blocks, frames, views
+template <typename T>
+__global__ __launch_bounds__(256) void mv_sample_kernel(
+    MvGeom g, const uint4 *__restrict__ feats, const float *__restrict__ points,
+    const float *__restrict__ proj, const float *__restrict__ ori_w, T *__restrict__ out,
+    unsigned char *__restrict__ valid_out)
+{
+    constexpr int CB = elem<T>::CB;
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= g.N) return;
+    long long pidx = o;
+    if (g.nz > 0) {
+        const int z = (int)(o % g.nz);
+        const long long t = o / g.nz;
+        const int y = (int)(t % g.ny);
+        const int x = (int)(t / g.ny);
+        pidx = ((long long)z * g.ny + y) * g.nx + x;  // anchor order: z-major, then y, then x
+    }
+    const float px = points[3 * pidx], py = points[3 * pidx + 1], pz = points[3 * pidx + 2];
+    const int HW = g.Hf * g.Wf;
+    const int nvf = g.num_views * g.num_frames;
+    const size_t chan_stride = g.nz > 0 ? (size_t)g.N : 1;  // volume: (C, N) ; flat: (N, C)
+    T *obase = g.nz > 0 ? out + o : out + (size_t)o * g.C * (g.aggregate ? g.num_frames : 1);
+    const int c_out = g.C * (g.aggregate ? g.num_frames : 1);
+
+    // valid counts do not depend on the channel block
+    int cnt_total = 0;
+    for (int i = 0; i < nvf; ++i) {
+        float nx, ny;
+        cnt_total += project_view(g, proj + 16 * i, ori_w[i], px, py, pz, nx, ny) ? 1 : 0;
+    }
+    if (valid_out) valid_out[o] = cnt_total > 0;
+
+    for (int blk = 0; blk < g.nblk; ++blk) {
+        float tot[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) tot[k] = 0.0f;
+        int tot_cnt = 0;
+        for (int f = 0; f < g.num_frames; ++f) {
+            float acc[CB];
+#pragma unroll
+            for (int k = 0; k < CB; ++k) acc[k] = 0.0f;
+            int cnt = 0;
+            for (int v = 0; v < g.num_views; ++v) {
+                const int i = f * g.num_views + v;
+                float nx, ny;
+                const bool ok = project_view(g, proj + 16 * i, ori_w[i], px, py, pz, nx, ny);
+                if (g.valid_sample && !ok) continue;  // valid_features[~valid] = 0
+                ++cnt;
+                const float x = ((nx + 1.0f) * 0.5f) * (float)(g.Wf - 1);
+                const float y = ((ny + 1.0f) * 0.5f) * (float)(g.Hf - 1);
+                const uint4 *fb = feats + ((size_t)i * g.nblk + blk) * HW;
+                float r[CB];
+                if (g.mode == 0) {
+                    // nearest: nearbyint (round half to even), zeros outside
+                    const float xr = rintf(x), yr = rintf(y);
+                    const bool in = (fabsf(x) <= 3.0e38f) && (fabsf(y) <= 3.0e38f) && xr >= 0.0f &&
+                                    xr <= (float)(g.Wf - 1) && yr >= 0.0f && yr <= (float)(g.Hf - 1);
+                    if (in) {
+                        unpack16(fb[(int)yr * g.Wf + (int)xr], r);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < CB; ++k) r[k] = 0.0f;
+                    }
+                } else {
+                    const Tap t = make_tap(x, y, g.Hf, g.Wf);
+                    const int i00 = t.iy * g.Wf + t.ix, i01 = i00 + t.dx;
+                    const int i10 = i00 + t.dy * g.Wf, i11 = i10 + t.dx;
+                    const uint4 q0 = fb[i00], q1 = fb[i01], q2 = fb[i10], q3 = fb[i11];
+                    float a[CB], b2[CB], c2[CB], d2[CB];
+                    unpack16(q0, a); unpack16(q1, b2); unpack16(q2, c2); unpack16(q3, d2);
+#pragma unroll
+                    for (int k = 0; k < CB; ++k) {
+                        const float vnw = (t.ok & 1u) ? a[k] : 0.0f, vne = (t.ok & 2u) ? b2[k] : 0.0f;
+                        const float vsw = (t.ok & 4u) ? c2[k] : 0.0f, vse = (t.ok & 8u) ? d2[k] : 0.0f;
+                        float s = vnw * t.nw;
+                        s = __builtin_fmaf(vne, t.ne, s);
+                        s = __builtin_fmaf(vsw, t.sw, s);
+                        s = __builtin_fmaf(vse, t.se, s);
+                        r[k] = s;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CB; ++k) acc[k] = acc[k] + r[k];  // stack(views).sum(0)
+            }
+            if (g.aggregate) {
+                // 'concat': per-frame mean over its valid views, multiview_dfm.py:196-203
+                const float den = (float)max(cnt, 1);
+#pragma unroll
+                for (int k = 0; k < CB; ++k) {
+                    const int c = blk * CB + k;
+                    if (c < g.C) obase[(size_t)(f * g.C + c) * chan_stride] = elem<T>::store(acc[k] / den);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CB; ++k) tot[k] = tot[k] + acc[k];  // stack(frames).sum(0)
+                tot_cnt += cnt;
+            }
+        }
+        if (!g.aggregate) {
+            // 'mean': sum over frames / clamp(total valid, 1), multiview_dfm.py:188-195
+            const float den = (float)max(tot_cnt, 1);
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                const int c = blk * CB + k;
+                if (c < g.C) obase[(size_t)c * chan_stride] = elem<T>::store(tot[k] / den);
+            }
+        }
+    }
+    (void)c_out;
+}
+
+}  // namespace
+
+extern "C" {
+
+DFM_API size_t dfm_point_sample_mv_workspace_bytes(const dfm_mv_desc *d)
+{
+    if (!d || d->num_views <= 0 || d->num_frames <= 0 || d->channels <= 0 || d->feat_h <= 0 ||
+        d->feat_w <= 0)
+        return 0;
+    const int CB = d->dtype == DFM_BF16 ? 8 : 4;
+    const size_t nblk = (d->channels + CB - 1) / CB;
+    const size_t bytes = (size_t)d->num_views * d->num_frames * nblk * d->feat_h * d->feat_w * 16;
+    return (bytes + 255) & ~(size_t)255;
+}
+
+DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *d, const void *feats, const float *points,
+                                    const float *proj, const float *ori_w, void *out,
+                                    unsigned char *valid_out, void *workspace,
+                                    size_t workspace_bytes, void *stream)
+{
+    if (!d) return fail_ps(DFM_ERR_INVALID_ARG, "desc is NULL");
+    if (d->num_views <= 0 || d->num_frames <= 0 || d->channels <= 0 || d->feat_h <= 0 ||
+        d->feat_w <= 0 || d->num_points <= 0)
+        return fail_ps(DFM_ERR_INVALID_ARG, "non-positive size in dfm_mv_desc");
+    if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
+        return fail_ps(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (d->mode != 0 && d->mode != 1) return fail_ps(DFM_ERR_UNSUPPORTED, "mode must be 0 or 1");
+    if (d->nz > 0 && (long long)d->nx * d->ny * d->nz != d->num_points)
+        return fail_ps(DFM_ERR_INVALID_ARG, "nx*ny*nz != num_points");
+    if (!feats || !points || !proj || !ori_w || !out)
+        return fail_ps(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (!workspace || workspace_bytes < dfm_point_sample_mv_workspace_bytes(d))
+        return fail_ps(DFM_ERR_WORKSPACE, "workspace smaller than dfm_point_sample_mv_workspace_bytes");
+    MvGeom g;
+    g.num_views = d->num_views; g.num_frames = d->num_frames; g.C = d->channels;
+    g.Hf = d->feat_h; g.Wf = d->feat_w;
+    const int CB = d->dtype == DFM_BF16 ? 8 : 4;
+    g.nblk = (d->channels + CB - 1) / CB;
+    g.nx = d->nx; g.ny = d->ny; g.nz = d->nz; g.N = d->num_points;
+    g.scale_x = d->scale_x; g.scale_y = d->scale_y; g.crop_x = d->crop_x; g.crop_y = d->crop_y;
+    g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.flip = d->flip; g.mode = d->mode;
+    g.aggregate = d->aggregate;
+    g.valid_sample = d->valid_sample;
+    if (!d->valid_sample && (d->num_views != 1 || d->num_frames != 1))
+        return fail_ps(DFM_ERR_UNSUPPORTED, "valid_sample=0 is only supported for a single view");
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = d->feat_h * d->feat_w;
+    const int nvf = d->num_views * d->num_frames;
+    dim3 pg((HW + 255) / 256, g.nblk, nvf);
+    const long long nb = (g.N + 255) / 256;
+    if (nb > 2147483647ll) return fail_ps(DFM_ERR_UNSUPPORTED, "too many points");
+    if (d->dtype == DFM_F32) {
+        hipLaunchKernelGGL(pack_views_kernel<float>, pg, dim3(256), 0, st, (const float *)feats,
+                           (uint4 *)workspace, g.C, HW, g.nblk);
+        hipLaunchKernelGGL(mv_sample_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, g,
+                           (const uint4 *)workspace, points, proj, ori_w, (float *)out, valid_out);
+    } else {
+        hipLaunchKernelGGL(pack_views_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t *)feats,
+                           (uint4 *)workspace, g.C, HW, g.nblk);
+        hipLaunchKernelGGL(mv_sample_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, g,
+                           (const uint4 *)workspace, points, proj, ori_w, (bf16_t *)out, valid_out);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_ps(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+}  // extern "C"

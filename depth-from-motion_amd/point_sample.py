@@ -1,0 +1,150 @@
+"""Host-side mirrors of the reference's multi-view voxel lifting:
+
+* ``point_sample``  -- mmdet3d/models/fusion_layers/point_fusion.py:14-106
+* ``mv_feature_transformation`` -- the sampling/reduction part of
+  ``MultiViewDfM.feature_transformation`` (mmdet3d/models/detectors/
+  multiview_dfm.py:119-208, ``valid_sample=True``)
+* ``voxel_centers`` -- the sample points the detector takes from
+  ``AlignedAnchor3DRangeGenerator`` (core/anchor/anchor_3d_generator.py:285-332)
+
+One HIP launch (``dfm_point_sample_mv_fwd``) replaces the per-(frame, view)
+``point_sample`` calls, the stack/sum/count/divide passes and the permute.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _capi
+from .plane_sweep import _DTYPES, _Workspace, _ptr, _require_gpu, _stream_ptr
+
+
+def voxel_centers(voxel_range, n_voxels):
+    """(Nz*Ny*Nx, 3) fp32 voxel centres, ordered z-major then y then x, computed
+    with the torch ops of AlignedAnchor3DRangeGenerator.anchors_single_range
+    (align_corner=False) on the CPU."""
+    nx, ny, nz = (int(v) for v in n_voxels)
+    rng = torch.tensor(voxel_range, dtype=torch.float32)
+    z = torch.linspace(rng[2], rng[5], nz + 1)
+    y = torch.linspace(rng[1], rng[4], ny + 1)
+    x = torch.linspace(rng[0], rng[3], nx + 1)
+    z = z + (z[1] - z[0]) / 2
+    y = y + (y[1] - y[0]) / 2
+    x = x + (x[1] - x[0]) / 2
+    zz, yy, xx = torch.meshgrid(z[:nz], y[:ny], x[:nx], indexing='ij')
+    return torch.stack([xx, yy, zz], dim=-1).reshape(-1, 3).contiguous()
+
+
+def _scale_xy(img_scale_factor):
+    if torch.is_tensor(img_scale_factor) or isinstance(img_scale_factor, np.ndarray):
+        s = np.asarray(torch.as_tensor(img_scale_factor).detach().cpu(), dtype=np.float32).reshape(-1)
+        return (float(s[0]), float(s[1])) if s.size >= 2 else (float(s[0]), float(s[0]))
+    return float(img_scale_factor), float(img_scale_factor)
+
+
+def _crop_xy(img_crop_offset):
+    if torch.is_tensor(img_crop_offset) or isinstance(img_crop_offset, (np.ndarray, list, tuple)):
+        c = np.asarray(torch.as_tensor(img_crop_offset).detach().cpu(), dtype=np.float32).reshape(-1)
+        return float(c[0]), float(c[1])
+    return float(img_crop_offset), float(img_crop_offset)
+
+
+def _launch(feats, points, proj, ori_w, nxyz, num_views, num_frames, scale, crop, flip, pad_shape,
+            aligned, aggregate, valid_sample, want_valid):
+    lib = _capi.lib()
+    device = feats.device
+    nvf, C, Hf, Wf = feats.shape
+    assert nvf == num_views * num_frames
+    desc = _capi.MvDesc()
+    desc.num_views, desc.num_frames, desc.channels = num_views, num_frames, C
+    desc.feat_h, desc.feat_w = Hf, Wf
+    desc.nx, desc.ny, desc.nz = nxyz if nxyz is not None else (0, 0, 0)
+    desc.num_points = points.shape[0]
+    desc.scale_x, desc.scale_y = scale
+    desc.crop_x, desc.crop_y = crop
+    desc.flip = 1 if flip else 0
+    desc.pad_h, desc.pad_w = float(pad_shape[0]), float(pad_shape[1])
+    desc.mode = 1 if aligned else 0
+    desc.aggregate = 1 if aggregate == 'concat' else 0
+    desc.valid_sample = 1 if valid_sample else 0
+    desc.dtype = _DTYPES[feats.dtype]
+    c_out = C * (num_frames if aggregate == 'concat' else 1)
+    if nxyz is not None:
+        out = torch.empty((c_out,) + tuple(nxyz), dtype=feats.dtype, device=device)
+    else:
+        out = torch.empty((points.shape[0], c_out), dtype=feats.dtype, device=device)
+    valid = torch.empty(points.shape[0], dtype=torch.uint8, device=device) if want_valid else None
+    nbytes = lib.dfm_point_sample_mv_workspace_bytes(ctypes.byref(desc))
+    ws = _Workspace.get(device, nbytes)
+    with torch.cuda.device(device):
+        _capi.check(
+            lib.dfm_point_sample_mv_fwd(ctypes.byref(desc), _ptr(feats), _ptr(points), _ptr(proj),
+                                        _ptr(ori_w), _ptr(out), _ptr(valid) if want_valid else None,
+                                        _ptr(ws), nbytes, _stream_ptr(device)))
+    return out, valid
+
+
+def point_sample(img_meta,
+                 img_features,
+                 points,
+                 proj_mat,
+                 coord_type,
+                 img_scale_factor,
+                 img_crop_offset,
+                 img_flip,
+                 img_pad_shape,
+                 img_shape,
+                 aligned=True,
+                 padding_mode='zeros',
+                 align_corners=True,
+                 valid_flag=False):
+    """Drop-in for the reference ``point_sample``: (N, C) features of one view
+    [+ (N,) bool validity when ``valid_flag``]."""
+    if padding_mode != 'zeros' or not align_corners:
+        raise NotImplementedError('only padding_mode="zeros", align_corners=True (what DfM uses)')
+    if img_meta is not None and img_meta.get('transformation_3d_flow'):
+        raise NotImplementedError('3-D augmentation flows are not part of the DfM multi-view path')
+    _require_gpu(img_features, 'img_features')
+    assert img_features.dim() == 4 and img_features.shape[0] == 1
+    device = img_features.device
+    feats = img_features.contiguous()
+    pts = torch.as_tensor(points, dtype=torch.float32).to(device).contiguous()
+    proj = torch.as_tensor(proj_mat, dtype=torch.float32).reshape(1, 16).to(device).contiguous()
+    ori_w = torch.tensor([float(img_shape[1])], dtype=torch.float32, device=device)
+    out, valid = _launch(feats, pts, proj, ori_w, None, 1, 1, _scale_xy(img_scale_factor),
+                         _crop_xy(img_crop_offset), img_flip, img_pad_shape, aligned, 'mean',
+                         valid_flag, valid_flag)
+    if valid_flag:
+        return out, valid.bool()
+    return out
+
+
+def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, voxel_range, n_voxels,
+                              temporal_aggregate='mean', points=None):
+    """(B, F*Nv, C, Hf, Wf) view features -> (B, C or C*F, Nx, Ny, Nz) voxel volume,
+    the tensor the reference hands to ``neck_3d`` (multiview_dfm.py:206-209)."""
+    _require_gpu(batch_feats, 'batch_feats')
+    device = batch_feats.device
+    if points is None:
+        points = voxel_centers(voxel_range, n_voxels)
+    points = torch.as_tensor(points, dtype=torch.float32).to(device).contiguous()
+    nxyz = tuple(int(v) for v in n_voxels)
+    vols = []
+    for feature, img_meta in zip(batch_feats, img_metas):
+        if 'scale_factor' in img_meta:
+            sf = img_meta['scale_factor']
+            scale = _scale_xy(sf[:2] if isinstance(sf, np.ndarray) and len(sf) >= 2 else sf)
+        else:
+            scale = (1.0, 1.0)
+        flip = img_meta.get('flip', False)
+        crop = _crop_xy(img_meta['img_crop_offset']) if 'img_crop_offset' in img_meta else (0.0, 0.0)
+        nvf = num_views * num_frames
+        proj = torch.as_tensor(np.asarray(img_meta['ori_lidar2img'][:nvf], dtype=np.float32)
+                               ).reshape(nvf, 16).to(device)
+        ori_w = torch.tensor([float(img_meta['img_shape'][i][1]) for i in range(nvf)],
+                             dtype=torch.float32, device=device)
+        out, _ = _launch(feature.contiguous(), points, proj, ori_w, nxyz, num_views, num_frames,
+                         scale, crop, flip, img_meta['input_shape'], False, temporal_aggregate,
+                         True, False)
+        vols.append(out)
+    return torch.stack(vols)

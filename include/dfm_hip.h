@@ -151,6 +151,51 @@ DFM_API void dfm_plane_sweep_force_kernel(int which);
 DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int blocks_per_group,
                                  int planes_per_workgroup);
 
+/* ---------------------------------------------------------------------- */
+/* multi-view voxel lifting (point_sample x views x frames + reduction)    */
+/* ---------------------------------------------------------------------- */
+
+/* Field meaning = the arguments of point_sample (point_fusion.py:14-27) as
+ * MultiViewDfM.feature_transformation passes them (multiview_dfm.py:130-170). */
+typedef struct dfm_mv_desc {
+    int32_t num_views;   /* Nv                                                  */
+    int32_t num_frames;  /* F (1 + num_ref_frames)                              */
+    int32_t channels;    /* C of every view's feature map                       */
+    int32_t feat_h, feat_w;
+    int32_t nx, ny, nz;  /* volume output (C*F', nx, ny, nz); point index =
+                          * (z*ny + y)*nx + x (AlignedAnchor3DRangeGenerator
+                          * order).  nz == 0: flat output (num_points, C*F').   */
+    int64_t num_points;
+    float scale_x, scale_y; /* img_scale_factor (w, h)                          */
+    float crop_x, crop_y;   /* img_crop_offset                                  */
+    int32_t flip;
+    float pad_h, pad_w;     /* img_pad_shape (img_meta['input_shape'])          */
+    int32_t mode;           /* 0 nearest (aligned=False), 1 bilinear            */
+    int32_t aggregate;      /* 0 'mean' over frames (F' = 1), 1 'concat' (F'=F) */
+    int32_t valid_sample;   /* 1: valid-count semantics (MultiViewDfM default);
+                             * 0: plain grid_sample output, single view only
+                             * (point_sample(valid_flag=False))               */
+    int32_t dtype;          /* dfm_dtype of feats and out                       */
+} dfm_mv_desc;
+
+DFM_API size_t dfm_point_sample_mv_workspace_bytes(const dfm_mv_desc *desc);
+
+/*
+ * feats  : (F*Nv, C, feat_h, feat_w) contiguous, frame-major        [device]
+ * points : (num_points, 3) fp32 LiDAR coordinates                    [device]
+ * proj   : (F*Nv, 16) fp32 lidar2img per (frame, view), row major    [device]
+ * ori_w  : (F*Nv) fp32, img_shape[1] of each view (used when flip)   [device]
+ * out    : volume or flat, see desc                                  [device]
+ * valid  : optional (num_points) bytes, 1 where any view sees the point
+ * valid_sample=True semantics: a view contributes only where 0 < x < pad_w,
+ * 0 < y < pad_h and depth > 0; sums are divided by the number of valid views
+ * (clamped to 1).
+ */
+DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *desc, const void *feats,
+                                    const float *points, const float *proj, const float *ori_w,
+                                    void *out, unsigned char *valid, void *workspace,
+                                    size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,6 +242,60 @@ ORACLE_API void dfm_oracle_build_dfm_cost(const dfm_oracle_sweep_params *p, cons
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* point_sample: mmdet3d/models/fusion_layers/point_fusion.py:14-106         */
+/* (apply_3d_transformation is the identity for the DfM configs: no          */
+/*  transformation_3d_flow in the multi-view pipelines)                      */
+/* feat (C,Hf,Wf); points (N,3); proj 4x4 row major; out (N,C); valid (N)     */
+/* mode 0 = nearest (aligned=False), 1 = bilinear (aligned=True)             */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t C, Hf, Wf;
+    float scale_x, scale_y;   /* img_scale_factor (w, h)                       */
+    float crop_x, crop_y;     /* img_crop_offset                               */
+    int32_t flip;
+    float ori_w;              /* img_shape[1]                                  */
+    float pad_h, pad_w;       /* img_pad_shape                                 */
+    int32_t mode;
+    float proj[16];
+} dfm_oracle_ps_params;
+
+ORACLE_API void dfm_oracle_point_sample(const dfm_oracle_ps_params *p, const float *feat,
+                                        const float *points, int64_t N, float *out,
+                                        uint8_t *valid)
+{
+    const size_t plane = (size_t)p->Hf * p->Wf;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        /* points_cam2img(points, proj_mat, with_depth=True), utils.py:206-212 */
+        const float p4[4] = {points[3 * i], points[3 * i + 1], points[3 * i + 2], 1.0f};
+        const float a = dot4_chain(p4, p->proj + 0);
+        const float b = dot4_chain(p4, p->proj + 4);
+        const float c = dot4_chain(p4, p->proj + 8);
+        float x = a / c, y = b / c;
+        const float depth = c;
+        /* :70-80 scale -> crop -> flip */
+        x = x * p->scale_x;
+        y = y * p->scale_y;
+        x = x - p->crop_x;
+        y = y - p->crop_y;
+        if (p->flip) x = p->ori_w - x;
+        /* :82-84 */
+        const float ny = y / p->pad_h * 2.0f - 1.0f;
+        const float nx = x / p->pad_w * 2.0f - 1.0f;
+        /* :99-101 */
+        const int ok = (x < p->pad_w) && (x > 0.0f) && (y < p->pad_h) && (y > 0.0f) && (depth > 0.0f);
+        if (valid) valid[i] = (uint8_t)ok;
+        for (int ch = 0; ch < p->C; ++ch) {
+            float v = 0.0f;
+            if (ok || !valid)
+                v = p->mode ? bilinear_plane(feat + ch * plane, p->Hf, p->Wf, nx, ny)
+                            : nearest_plane(feat + ch * plane, p->Hf, p->Wf, nx, ny);
+            out[(size_t)i * p->C + ch] = v; /* valid_features[~valid] = 0, :103 */
+        }
+    }
+}
+
 ORACLE_API int dfm_oracle_version(void) { return 1; }
 
 #ifdef _OPENMP

@@ -102,6 +102,69 @@ def grid_sample2d(inp, grid, mode='bilinear'):
     return out
 
 
+class PSParams(ctypes.Structure):
+    """struct dfm_oracle_ps_params"""
+    _fields_ = [('C', ctypes.c_int32), ('Hf', ctypes.c_int32), ('Wf', ctypes.c_int32),
+                ('scale_x', ctypes.c_float), ('scale_y', ctypes.c_float),
+                ('crop_x', ctypes.c_float), ('crop_y', ctypes.c_float), ('flip', ctypes.c_int32),
+                ('ori_w', ctypes.c_float), ('pad_h', ctypes.c_float), ('pad_w', ctypes.c_float),
+                ('mode', ctypes.c_int32), ('proj', ctypes.c_float * 16)]
+
+
+def point_sample(feat, points, proj, scale=(1.0, 1.0), crop=(0.0, 0.0), flip=False, ori_w=0.0,
+                 pad_shape=(1, 1), aligned=True, valid_flag=False):
+    """feat (C,Hf,Wf), points (N,3) -> (N,C) [, valid (N,) bool]; reference
+    point_fusion.py:14-106 with identity 3-D transformation."""
+    feat, points = _f32(feat), _f32(points)
+    p = PSParams()
+    p.C, p.Hf, p.Wf = feat.shape
+    p.scale_x, p.scale_y = float(scale[0]), float(scale[1])
+    p.crop_x, p.crop_y = float(crop[0]), float(crop[1])
+    p.flip, p.ori_w = int(bool(flip)), float(ori_w)
+    p.pad_h, p.pad_w = float(pad_shape[0]), float(pad_shape[1])
+    p.mode = 1 if aligned else 0
+    for i, v in enumerate(_f32(proj).reshape(16)):
+        p.proj[i] = float(v)
+    n = points.shape[0]
+    out = np.empty((n, p.C), np.float32)
+    valid = np.empty(n, np.uint8) if valid_flag else None
+    lib().dfm_oracle_point_sample(ctypes.byref(p), _vp(feat), _vp(points), ctypes.c_int64(n),
+                                  _vp(out), _vp(valid) if valid_flag else None)
+    return (out, valid.astype(bool)) if valid_flag else out
+
+
+def mv_feature_transformation(feats, points, lidar2img, n_voxels, num_views, num_frames,
+                              input_shape, img_shape, scale=None, flip=False, crop=None,
+                              aggregate='mean'):
+    """One sample of MultiViewDfM.feature_transformation (detectors/multiview_dfm.py:119-208,
+    valid_sample=True): feats (F*Nv, C, Hf, Wf) -> (C or C*F, Nx, Ny, Nz)."""
+    sc = (1.0, 1.0) if scale is None or len(scale) == 0 else (scale[0], scale[1])
+    cr = (0.0, 0.0) if crop is None or len(crop) == 0 else (crop[0], crop[1])
+    frame_vol, frame_valid = [], []
+    for f in range(num_frames):
+        vol, cnt = None, None
+        for v in range(num_views):
+            i = f * num_views + v
+            o, ok = point_sample(feats[i], points, lidar2img[i], sc, cr, flip, img_shape[1],
+                                 input_shape, aligned=False, valid_flag=True)
+            vol = o.copy() if vol is None else vol + o          # stack().sum(0): in view order
+            cnt = ok.astype(np.int64) if cnt is None else cnt + ok
+        vol[cnt == 0] = 0
+        frame_vol.append(vol)
+        frame_valid.append(cnt)
+    if aggregate == 'mean':
+        vol, cnt = frame_vol[0], frame_valid[0]
+        for f in range(1, num_frames):
+            vol, cnt = vol + frame_vol[f], cnt + frame_valid[f]
+        vol[cnt == 0] = 0
+        vol = vol / np.maximum(cnt, 1)[:, None].astype(np.float32)
+    else:
+        vol = np.concatenate([fv / np.maximum(fc, 1)[:, None].astype(np.float32)
+                              for fv, fc in zip(frame_vol, frame_valid)], axis=1)
+    nx, ny, nz = (int(v) for v in n_voxels)
+    return np.ascontiguousarray(vol.astype(np.float32).reshape(nz, ny, nx, -1).transpose(3, 2, 1, 0))
+
+
 def bf16_round(a):
     """fp32 -> bf16 (round-to-nearest-even) -> fp32, numpy."""
     u = _f32(a).view(np.uint32)

@@ -42,12 +42,31 @@ def extract(path, names, glb):
     return glb
 
 
+def extract_method(path, cls, name, glb, rename=None):
+    """exec method `cls.name` of a reference file as a plain function"""
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == name:
+                    sub.decorator_list = []
+                    if rename:
+                        sub.name = rename
+                    exec(compile(ast.Module(body=[sub], type_ignores=[]), path, 'exec'), glb)
+                    return glb
+    raise KeyError(f'{cls}.{name} not found in {path}')
+
+
 def load_reference():
     g = {'torch': torch, 'F': F, 'np': np, 'nn': torch.nn}
     extract(REF + 'core/bbox/structures/utils.py', ['points_cam2img', 'points_img2cam'], g)
     extract(REF + 'models/backbones/dfm_backbone.py', ['build_dfm_cost'], g)
     g['apply_3d_transformation'] = lambda pts, coord_type, img_meta, reverse=False: pts
     extract(REF + 'models/fusion_layers/point_fusion.py', ['point_sample'], g)
+    extract_method(REF + 'models/detectors/multiview_dfm.py', 'MultiViewDfM',
+                   'feature_transformation', g, rename='mv_feature_transformation')
+    extract_method(REF + 'core/anchor/anchor_3d_generator.py', 'AlignedAnchor3DRangeGenerator',
+                   'anchors_single_range', g, rename='aligned_anchors_single_range')
     return g
 
 
@@ -157,6 +176,86 @@ def make_helpers(g):
           np.abs(d['ps_out'].reshape(-1) - d['ps_expected']).max())
 
 
+def waymo_like_cameras(num_views, num_frames, seed):
+    """lidar2img (4x4) per (frame, view): cameras at yaw 0, +-45, +-90 deg around
+    the ego vehicle, Waymo-like intrinsics scaled to the 1/1 padded input, and a
+    per-frame ego motion folded in (loading.py:122-142 pre-folds it the same way)."""
+    rng = np.random.RandomState(seed)
+    yaws = [0.0, 45.0, -45.0, 90.0, -90.0][:num_views]
+    mats = []
+    for f in range(num_frames):
+        ego = np.eye(4)
+        if f > 0:
+            a = np.radians(rng.uniform(-3, 3))
+            ego[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+            ego[:3, 3] = [rng.uniform(0.5, 2.0), rng.uniform(-0.2, 0.2), 0.0]
+        for yaw in yaws:
+            a = np.radians(yaw)
+            # lidar (x fwd, y left, z up) -> camera (x right, y down, z fwd), camera yawed by a
+            R_yaw = np.array([[np.cos(a), np.sin(a), 0], [-np.sin(a), np.cos(a), 0], [0, 0, 1]])
+            R_axes = np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0]], float)
+            ext = np.eye(4)
+            ext[:3, :3] = R_axes @ R_yaw
+            ext[:3, 3] = R_axes @ R_yaw @ -np.array([1.5, 0.0, 2.0])
+            K = np.eye(4)
+            K[0, 0] = K[1, 1] = 130.0 + rng.uniform(-2, 2)
+            K[0, 2], K[1, 2] = 78.0, 50.0
+            mats.append((K @ ext @ ego).astype(np.float32))
+    return np.stack(mats)
+
+
+# name, num_views, num_frames, C, feature HxW, input (pad) shape, n_voxels (x,y,z), range,
+# scale_factor, flip, crop offset, temporal aggregate
+MV_CASES = [
+    ('mv_mean_1frame', 5, 1, 6, (26, 39), (104, 156), (22, 30, 4),
+     [-11.0, -15.0, -2.0, 11.0, 15.0, 2.0], None, False, None, 'mean'),
+    ('mv_concat_2frames_aug', 5, 2, 5, (26, 39), (104, 156), (22, 30, 4),
+     [-11.0, -15.0, -2.0, 11.0, 15.0, 2.0], np.array([0.95, 1.05, 0.95, 1.05], np.float32), True,
+     np.array([3.0, 2.0], np.float32), 'concat'),
+    ('mv_mean_2frames', 3, 2, 4, (26, 39), (104, 156), (20, 28, 8),
+     [-10.0, -14.0, -2.0, 10.0, 14.0, 2.0], None, False, None, 'mean'),
+]
+
+
+def make_mv(g):
+    from types import SimpleNamespace
+    for i, (name, nv, nf, C, (hf, wf), pad, nvox, rng_, scale, flip, crop, agg) in enumerate(MV_CASES):
+        gen = torch.Generator().manual_seed(200 + i)
+        feats = torch.randn(1, nv * nf, C, hf, wf, generator=gen)
+        lidar2img = waymo_like_cameras(nv, nf, 300 + i)
+        gen_self = SimpleNamespace(align_corner=False, custom_values=[])
+
+        def grid_anchors(featmap_sizes, device='cpu'):
+            a = g['aligned_anchors_single_range'](gen_self, featmap_sizes[0], rng_, 1,
+                                                  sizes=[[0.0, 0.0, 0.0]], rotations=[0.0],
+                                                  device=device)
+            return [a.reshape(-1, a.size(-1))]
+
+        self_ = SimpleNamespace(
+            anchor_generator=SimpleNamespace(grid_anchors=grid_anchors), n_voxels=list(nvox),
+            valid_sample=True, temporal_aggregate=agg, with_backbone_3d=False,
+            with_depth_head=False, with_neck_3d=False)
+        meta = {'ori_lidar2img': [m for m in lidar2img], 'input_shape': pad,
+                'img_shape': [(pad[0] - 4, pad[1] - 6, 3)] * (nv * nf)}
+        if scale is not None:
+            meta['scale_factor'] = scale
+        if flip:
+            meta['flip'] = True
+        if crop is not None:
+            meta['img_crop_offset'] = crop
+        out = g['mv_feature_transformation'](self_, feats, [meta], nv, nf)[0]
+        points = grid_anchors([list(nvox)[::-1]])[0][:, :3]
+        np.savez_compressed(
+            os.path.join(HERE, f'{name}.npz'), feats=feats.numpy(), lidar2img=lidar2img,
+            points=points.numpy(), n_voxels=np.asarray(nvox), voxel_range=np.asarray(rng_),
+            input_shape=np.asarray(pad), img_shape=np.asarray(meta['img_shape'][0][:2]),
+            scale=np.zeros(0, np.float32) if scale is None else scale, flip=np.bool_(flip),
+            crop=np.zeros(0, np.float32) if crop is None else crop, aggregate=agg,
+            num_views=nv, num_frames=nf, ref_out=out.numpy())
+        nz = (out != 0).float().mean().item()
+        print(name, tuple(out.shape), f'nonzero {nz:.3f}')
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference not mounted; fixtures are committed, nothing to do')
@@ -164,3 +263,4 @@ if __name__ == '__main__':
     ref = load_reference()
     make_sweep(ref)
     make_helpers(ref)
+    make_mv(ref)
