@@ -27,6 +27,7 @@ EXPORTS = (
     'dfm_plane_sweep_tune',
     'dfm_point_sample_mv_workspace_bytes',
     'dfm_point_sample_mv_fwd',
+    'dfm_frustum_to_voxel_fwd',
 )
 
 
@@ -77,6 +78,14 @@ class MvDesc(ctypes.Structure):
     ]
 
 
+class F2vDesc(ctypes.Structure):
+    """struct dfm_f2v_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        'batch', 'channels', 'd', 'h', 'w', 'ds', 'hs', 'ws', 'sem_channels', 'hsem', 'wsem', 'nz',
+        'ny', 'nx')] + [(n, ctypes.c_float) for n in ('pad_h', 'pad_w', 'depth_min', 'depth_span')
+                        ] + [('dtype', ctypes.c_int32)]
+
+
 class DfmHipError(RuntimeError):
     pass
 
@@ -121,6 +130,8 @@ def lib():
     h.dfm_point_sample_mv_workspace_bytes.argtypes = [mp]
     h.dfm_point_sample_mv_fwd.restype = ctypes.c_int
     h.dfm_point_sample_mv_fwd.argtypes = [mp, vp, fp, fp, fp, vp, vp, vp, sz, vp]
+    h.dfm_frustum_to_voxel_fwd.restype = ctypes.c_int
+    h.dfm_frustum_to_voxel_fwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, vp, fp, fp, vp, vp]
     _lib = h
     return h
 

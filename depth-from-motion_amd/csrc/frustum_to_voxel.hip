@@ -1,0 +1,165 @@
+// frustum_to_voxel.hip -- sampling stage of FrustumToVoxel.forward (gfx950)
+//
+// Reference: mmdet3d/models/necks/feature_transformation.py:82-158 -- per voxel
+// project with cam2img[:3], normalise (u, v, depth), three 3-D grid_samples
+// (cost volume, depth distribution, 2-D semantic feature at z := 0), validity
+// masks, depth-probability weighting, channel concat.  One launch writes the
+// concatenated (B, C+Cs, Nz, Ny, Nx) volume: no coordinate tensors, no three
+// separate sampled volumes, no mask multiplies, no cat.
+//
+// Arithmetic = ATen grid_sampler_3d_cpu_impl (scalar path): corner weights
+// (x1-ix)*(y1-iy)*(z1-iz) ..., out = 0; out += v*w over the in-bounds corners in
+// the order tnw,tne,tsw,tse,bnw,bne,bsw,bse, multiply and add unfused.
+//
+// Layout: everything in the caller's layouts (NCDHW / NCHW); lanes are adjacent
+// voxels along x, so the 8 corner loads of a wave fall in a few cache lines.
+// Bound: HBM write of the volume (the three sources are L2/MALL resident).
+#include "dfm_common.h"
+
+using namespace dfm;
+
+namespace {
+
+struct F2vGeom {
+    int32_t C, D, H, W, Ds, Hs, Ws, Cs, Hsem, Wsem, Nz, Ny, Nx;
+    float pad_h, pad_w, depth_min, depth_span;
+};
+
+struct Tri {
+    int o[8];     // element offsets of the 8 corners (valid only where ok bit set)
+    float w[8];   // corner weights, ATen order
+    uint32_t ok;
+};
+
+__device__ __forceinline__ Tri make_tri(float gx, float gy, float gz, int D, int H, int W)
+{
+    Tri t;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
+    t.w[0] = (x1 - ix) * (y1 - iy) * (z1 - iz);
+    t.w[1] = (ix - x0) * (y1 - iy) * (z1 - iz);
+    t.w[2] = (x1 - ix) * (iy - y0) * (z1 - iz);
+    t.w[3] = (ix - x0) * (iy - y0) * (z1 - iz);
+    t.w[4] = (x1 - ix) * (y1 - iy) * (iz - z0);
+    t.w[5] = (ix - x0) * (y1 - iy) * (iz - z0);
+    t.w[6] = (x1 - ix) * (iy - y0) * (iz - z0);
+    t.w[7] = (ix - x0) * (iy - y0) * (iz - z0);
+    const bool fin = fabsf(ix) <= 1.0e9f && fabsf(iy) <= 1.0e9f && fabsf(iz) <= 1.0e9f;  // no NaN/Inf
+    const bool bx0 = fin && x0 >= 0.0f && x0 <= (float)(W - 1), bx1 = fin && x1 >= 0.0f && x1 <= (float)(W - 1);
+    const bool by0 = fin && y0 >= 0.0f && y0 <= (float)(H - 1), by1 = fin && y1 >= 0.0f && y1 <= (float)(H - 1);
+    const bool bz0 = fin && z0 >= 0.0f && z0 <= (float)(D - 1), bz1 = fin && z1 >= 0.0f && z1 <= (float)(D - 1);
+    const int xi = bx0 ? (int)x0 : 0, yi = by0 ? (int)y0 : 0, zi = bz0 ? (int)z0 : 0;
+    const int xj = bx1 ? (int)x1 : 0, yj = by1 ? (int)y1 : 0, zj = bz1 ? (int)z1 : 0;
+    t.o[0] = (zi * H + yi) * W + xi; t.o[1] = (zi * H + yi) * W + xj;
+    t.o[2] = (zi * H + yj) * W + xi; t.o[3] = (zi * H + yj) * W + xj;
+    t.o[4] = (zj * H + yi) * W + xi; t.o[5] = (zj * H + yi) * W + xj;
+    t.o[6] = (zj * H + yj) * W + xi; t.o[7] = (zj * H + yj) * W + xj;
+    t.ok = (uint32_t)(bz0 && by0 && bx0) | ((uint32_t)(bz0 && by0 && bx1) << 1) |
+           ((uint32_t)(bz0 && by1 && bx0) << 2) | ((uint32_t)(bz0 && by1 && bx1) << 3) |
+           ((uint32_t)(bz1 && by0 && bx0) << 4) | ((uint32_t)(bz1 && by0 && bx1) << 5) |
+           ((uint32_t)(bz1 && by1 && bx0) << 6) | ((uint32_t)(bz1 && by1 && bx1) << 7);
+    return t;
+}
+
+template <typename T>
+__device__ __forceinline__ float tri_sample(const Tri &t, const T *__restrict__ vol)
+{
+    float out = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (t.ok & (1u << k)) out = out + elem<T>::load(vol[t.o[k]]) * t.w[k];
+    return out;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void f2v_kernel(F2vGeom g, const T *__restrict__ stereo,
+                                                  const T *__restrict__ soft,
+                                                  const T *__restrict__ sem,
+                                                  const float *__restrict__ coords,
+                                                  const float *__restrict__ cam2img,
+                                                  T *__restrict__ out)
+{
+    const long long N = (long long)g.Nz * g.Ny * g.Nx;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= N) return;
+    const float xs = coords[3 * i], ys = coords[3 * i + 1], zs = coords[3 * i + 2];
+    const float *P = cam2img + 16 * b;  // rows 0..2 of the 4x4 == cam2img[:3]
+    const float a = dot4_chain(-ys, -zs, xs, 1.0f, P + 0);
+    const float bb = dot4_chain(-ys, -zs, xs, 1.0f, P + 4);
+    const float c = dot4_chain(-ys, -zs, xs, 1.0f, P + 8);
+    const float u = a / c, v = bb / c;
+    const bool valid2d = (u >= 0.0f) && (u <= g.pad_w) && (v >= 0.0f) && (v <= g.pad_h);
+    float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
+    float gz = (xs - g.depth_min) / g.depth_span;
+    gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
+    const float valid = (valid2d && gz >= -1.0f && gz <= 1.0f) ? 1.0f : 0.0f;
+
+    const size_t vol = (size_t)g.D * g.H * g.W;
+    T *o = out + (size_t)b * (g.C + g.Cs) * N + i;
+    {
+        const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
+        const T *sv = stereo + (size_t)b * g.C * vol;
+        for (int ch = 0; ch < g.C; ++ch)
+            o[(size_t)ch * N] = elem<T>::store(tri_sample<T>(t, sv + ch * vol) * valid);
+    }
+    if (g.Cs > 0) {
+        const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+        const float disp =
+            tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws) * valid;
+        const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
+        const float v2d = valid2d ? 1.0f : 0.0f;
+        const size_t plane = (size_t)g.Hsem * g.Wsem;
+        const T *sp = sem + (size_t)b * g.Cs * plane;
+        for (int ch = 0; ch < g.Cs; ++ch) {
+            float s = tri_sample<T>(t2, sp + ch * plane);
+            s = s * v2d;
+            o[(size_t)(g.C + ch) * N] = elem<T>::store(s * disp);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, const void *softmax,
+                                     const void *sem, const float *coords, const float *cam2img,
+                                     void *out, void *stream)
+{
+    if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
+    if (d->batch <= 0 || d->channels <= 0 || d->d <= 0 || d->h <= 0 || d->w <= 0 || d->nz <= 0 ||
+        d->ny <= 0 || d->nx <= 0 || d->sem_channels < 0)
+        return set_error(DFM_ERR_INVALID_ARG, "non-positive size in dfm_f2v_desc");
+    if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!stereo || !coords || !cam2img || !out || (d->sem_channels > 0 && (!sem || !softmax)))
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if ((long long)d->ds * d->hs * d->ws >= (1ll << 31) || (long long)d->d * d->h * d->w >= (1ll << 31))
+        return set_error(DFM_ERR_UNSUPPORTED, "volume too large for 32-bit corner offsets");
+    if (d->batch > 65535) return set_error(DFM_ERR_UNSUPPORTED, "batch > 65535");
+    F2vGeom g;
+    g.C = d->channels; g.D = d->d; g.H = d->h; g.W = d->w;
+    g.Ds = d->ds; g.Hs = d->hs; g.Ws = d->ws;
+    g.Cs = d->sem_channels; g.Hsem = d->hsem; g.Wsem = d->wsem;
+    g.Nz = d->nz; g.Ny = d->ny; g.Nx = d->nx;
+    g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.depth_min = d->depth_min; g.depth_span = d->depth_span;
+    const long long N = (long long)d->nz * d->ny * d->nx;
+    dim3 grid((unsigned)((N + 255) / 256), d->batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == DFM_F32)
+        hipLaunchKernelGGL(f2v_kernel<float>, grid, dim3(256), 0, st, g, (const float *)stereo,
+                           (const float *)softmax, (const float *)sem, coords, cam2img, (float *)out);
+    else
+        hipLaunchKernelGGL(f2v_kernel<bf16_t>, grid, dim3(256), 0, st, g, (const bf16_t *)stereo,
+                           (const bf16_t *)softmax, (const bf16_t *)sem, coords, cam2img,
+                           (bf16_t *)out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+}  // extern "C"

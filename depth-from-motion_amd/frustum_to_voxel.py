@@ -1,0 +1,62 @@
+"""Host-side mirror of the sampling stage of ``FrustumToVoxel.forward``
+(mmdet3d/models/necks/feature_transformation.py:82-158): one HIP launch
+(``dfm_frustum_to_voxel_fwd``) produces cat(Voxel, Voxel_2D), the input of
+``voxel_convs``."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _capi
+from .plane_sweep import _DTYPES, _ptr, _require_gpu, _stream_ptr
+
+
+def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem_feats,
+                            coordinates_3d, depth_cfg):
+    """
+    Args:
+        stereo_feat: (B, C, D, H, W) cost-volume features
+        stereo_feat_softmax: (B, 1, Ds, Hs, Ws) depth distribution (used detached,
+            like the reference, feature_transformation.py:136)
+        img_metas: list of dicts with 'cam2img' (4x4) and 'pad_shape'
+        cur_sem_feats: (B, Cs, H, W) or None (cat_img_feature=False)
+        coordinates_3d: (Nz, Ny, Nx, 3) voxel centres in pseudo-LiDAR coordinates
+        depth_cfg: dict with 'depth_min', 'depth_max'
+    Returns:
+        (B, C + Cs, Nz, Ny, Nx), same dtype as stereo_feat
+    """
+    _require_gpu(stereo_feat, 'stereo_feat')
+    lib = _capi.lib()
+    device = stereo_feat.device
+    if stereo_feat.dtype not in _DTYPES:
+        raise TypeError('stereo_feat must be float32 or bfloat16')
+    stereo = stereo_feat.contiguous()
+    B, C, D, H, W = stereo.shape
+    desc = _capi.F2vDesc()
+    desc.batch, desc.channels, desc.d, desc.h, desc.w = B, C, D, H, W
+    sem = soft = None
+    if cur_sem_feats is not None:
+        sem = cur_sem_feats.to(stereo.dtype).contiguous()
+        soft = stereo_feat_softmax.detach().to(stereo.dtype).contiguous()
+        desc.ds, desc.hs, desc.ws = soft.shape[2:]
+        desc.sem_channels, desc.hsem, desc.wsem = sem.shape[1:]
+    coords = coordinates_3d.to(device=device, dtype=torch.float32).contiguous()
+    desc.nz, desc.ny, desc.nx = coords.shape[:3]
+    pad_shape = img_metas[0]['pad_shape']  # the reference uses sample 0's for all (:101)
+    desc.pad_h, desc.pad_w = float(pad_shape[0]), float(pad_shape[1])
+    desc.depth_min = float(depth_cfg['depth_min'])
+    desc.depth_span = float(depth_cfg['depth_max'] - depth_cfg['depth_min'])
+    desc.dtype = _DTYPES[stereo.dtype]
+    cam = torch.as_tensor(np.asarray([m['cam2img'] for m in img_metas], dtype=np.float32))
+    cam4 = torch.eye(4).repeat(B, 1, 1)
+    cam4[:, :cam.shape[1], :cam.shape[2]] = cam
+    cam4 = cam4.reshape(B, 16).to(device)
+    out = torch.empty((B, C + desc.sem_channels, desc.nz, desc.ny, desc.nx), dtype=stereo.dtype,
+                      device=device)
+    with torch.cuda.device(device):
+        _capi.check(
+            lib.dfm_frustum_to_voxel_fwd(ctypes.byref(desc), _ptr(stereo),
+                                         _ptr(soft) if soft is not None else None,
+                                         _ptr(sem) if sem is not None else None, _ptr(coords),
+                                         _ptr(cam4), _ptr(out), _stream_ptr(device)))
+    return out

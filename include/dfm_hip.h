@@ -196,6 +196,39 @@ DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *desc, const void *feats,
                                     void *out, unsigned char *valid, void *workspace,
                                     size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------- */
+/* FrustumToVoxel sampling stage                                           */
+/* ---------------------------------------------------------------------- */
+
+/* necks/feature_transformation.py:82-158.  Sizes of the three sources and of
+ * the voxel grid; pad_* = img_metas[0]['pad_shape'] (the reference uses sample
+ * 0's for the whole batch, :101); depth_min / depth_span = depth_cfg
+ * ['depth_min'] and fp32(depth_max - depth_min). */
+typedef struct dfm_f2v_desc {
+    int32_t batch;
+    int32_t channels;      /* C of stereo_feat                               */
+    int32_t d, h, w;       /* stereo_feat (B, C, d, h, w)                     */
+    int32_t ds, hs, ws;    /* stereo_feat_softmax (B, 1, ds, hs, ws)          */
+    int32_t sem_channels;  /* Cs of cur_sem_feats, 0 = cat_img_feature False  */
+    int32_t hsem, wsem;    /* cur_sem_feats (B, Cs, hsem, wsem)               */
+    int32_t nz, ny, nx;    /* coordinates_3d (nz, ny, nx, 3)                  */
+    float pad_h, pad_w;
+    float depth_min, depth_span;
+    int32_t dtype;         /* dfm_dtype of the three sources and of out       */
+} dfm_f2v_desc;
+
+/*
+ * stereo, softmax, sem : contiguous, desc->dtype                    [device]
+ * coords   : (nz, ny, nx, 3) fp32 pseudo-LiDAR voxel centres        [device]
+ * cam2img  : (B, 16) fp32, img_meta['cam2img'] as 4x4 (rows 0..2)   [device]
+ * out      : (B, C + Cs, nz, ny, nx) = cat(Voxel, Voxel_2D) of the reference,
+ *            the input of voxel_convs (sem_atten_feat=True,
+ *            stereo_atten_feat=False: the shipped config)
+ */
+DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *desc, const void *stereo,
+                                     const void *softmax, const void *sem, const float *coords,
+                                     const float *cam2img, void *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

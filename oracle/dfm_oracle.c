@@ -296,6 +296,103 @@ ORACLE_API void dfm_oracle_point_sample(const dfm_oracle_ps_params *p, const flo
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* FrustumToVoxel sampling stage                                             */
+/* reference: mmdet3d/models/necks/feature_transformation.py:82-158          */
+/* 3-D grid_sample = ATen native/GridSampler.cpp grid_sampler_3d_cpu_impl    */
+/* (scalar path): unnormalise ((g+1)/2)*(size-1); corner weights             */
+/*   tnw = (ix_bse-ix)*(iy_bse-iy)*(iz_bse-iz) ...; out = 0; out += v*w for   */
+/* the in-bounds corners in the order tnw,tne,tsw,tse,bnw,bne,bsw,bse (plain  */
+/* multiply then add: that file is not built with FMA).                      */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t C;           /* cost-volume channels                              */
+    int32_t D, H, W;     /* cost volume (stereo_feat) size                    */
+    int32_t Ds, Hs, Ws;  /* depth-distribution volume size (softmax)          */
+    int32_t Csem;        /* semantic channels (0: cat_img_feature=False)      */
+    int32_t Hsem, Wsem;
+    int32_t Nz, Ny, Nx;
+    float pad_h, pad_w;  /* img_metas[0]['pad_shape']                         */
+    float depth_min;     /* coordinate offset  (fp32 of the python number)    */
+    float depth_span;    /* fp32(depth_max - depth_min)                       */
+    float P[12];         /* cam2img[:3] (3x4), row major                      */
+} dfm_oracle_f2v_params;
+
+static inline float trilinear(const float *vol, int D, int H, int W, float gx, float gy, float gz)
+{
+    const float ix = unnormalize_ac(gx, W), iy = unnormalize_ac(gy, H), iz = unnormalize_ac(gz, D);
+    if (!isfinite(ix) || !isfinite(iy) || !isfinite(iz)) return 0.0f;
+    if (fabsf(ix) > 1e9f || fabsf(iy) > 1e9f || fabsf(iz) > 1e9f) return 0.0f;
+    const int64_t x0 = (int64_t)floorf(ix), y0 = (int64_t)floorf(iy), z0 = (int64_t)floorf(iz);
+    const int64_t x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    const float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)y0, fy1 = (float)y1;
+    const float fz0 = (float)z0, fz1 = (float)z1;
+    const float tnw = (fx1 - ix) * (fy1 - iy) * (fz1 - iz);
+    const float tne = (ix - fx0) * (fy1 - iy) * (fz1 - iz);
+    const float tsw = (fx1 - ix) * (iy - fy0) * (fz1 - iz);
+    const float tse = (ix - fx0) * (iy - fy0) * (fz1 - iz);
+    const float bnw = (fx1 - ix) * (fy1 - iy) * (iz - fz0);
+    const float bne = (ix - fx0) * (fy1 - iy) * (iz - fz0);
+    const float bsw = (fx1 - ix) * (iy - fy0) * (iz - fz0);
+    const float bse = (ix - fx0) * (iy - fy0) * (iz - fz0);
+#define IN3(z, y, x) ((z) >= 0 && (z) < D && (y) >= 0 && (y) < H && (x) >= 0 && (x) < W)
+#define AT3(z, y, x) vol[((size_t)(z) * H + (y)) * W + (x)]
+    float out = 0.0f;
+    if (IN3(z0, y0, x0)) out += AT3(z0, y0, x0) * tnw;
+    if (IN3(z0, y0, x1)) out += AT3(z0, y0, x1) * tne;
+    if (IN3(z0, y1, x0)) out += AT3(z0, y1, x0) * tsw;
+    if (IN3(z0, y1, x1)) out += AT3(z0, y1, x1) * tse;
+    if (IN3(z1, y0, x0)) out += AT3(z1, y0, x0) * bnw;
+    if (IN3(z1, y0, x1)) out += AT3(z1, y0, x1) * bne;
+    if (IN3(z1, y1, x0)) out += AT3(z1, y1, x0) * bsw;
+    if (IN3(z1, y1, x1)) out += AT3(z1, y1, x1) * bse;
+#undef IN3
+#undef AT3
+    return out;
+}
+
+/* one sample: stereo (C,D,H,W), soft (1,Ds,Hs,Ws), sem (Csem,Hsem,Wsem) or NULL,
+ * coords (Nz,Ny,Nx,3) pseudo-LiDAR voxel centres -> out (C+Csem, Nz,Ny,Nx) */
+ORACLE_API void dfm_oracle_frustum_to_voxel(const dfm_oracle_f2v_params *p, const float *stereo,
+                                            const float *soft, const float *sem,
+                                            const float *coords, float *out)
+{
+    const int64_t N = (int64_t)p->Nz * p->Ny * p->Nx;
+    const size_t vol = (size_t)p->D * p->H * p->W;
+    const size_t semplane = (size_t)p->Hsem * p->Wsem;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        const float xs = coords[3 * i], ys = coords[3 * i + 1], zs = coords[3 * i + 2];
+        /* :176-178 pseudo-LiDAR -> rect camera; :181-188 project with the 3x4 */
+        const float r4[4] = {-ys, -zs, xs, 1.0f};
+        const float a = dot4_chain(r4, p->P + 0), b = dot4_chain(r4, p->P + 4);
+        const float c = dot4_chain(r4, p->P + 8);
+        const float u = a / c, v = b / c, depth = xs; /* :95 cat c3d[..., 2:] */
+        /* :102-105 */
+        const int valid2d = (u >= 0.0f) && (u <= p->pad_w) && (v >= 0.0f) && (v <= p->pad_h);
+        /* :110-119 */
+        float gx = (u - 0.0f) / (p->pad_w - 1.0f), gy = (v - 0.0f) / (p->pad_h - 1.0f);
+        float gz = (depth - p->depth_min) / p->depth_span;
+        gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
+        /* :125-127 */
+        const float valid = (valid2d && gz >= -1.0f && gz <= 1.0f) ? 1.0f : 0.0f;
+        /* :130-139 */
+        for (int ch = 0; ch < p->C; ++ch)
+            out[(size_t)ch * N + i] =
+                trilinear(stereo + ch * vol, p->D, p->H, p->W, gx, gy, gz) * valid;
+        if (p->Csem > 0) {
+            const float disp = trilinear(soft, p->Ds, p->Hs, p->Ws, gx, gy, gz) * valid;
+            const float v2d = valid2d ? 1.0f : 0.0f;
+            /* :146-155 semantic feature at z := 0, masked, depth-weighted */
+            for (int ch = 0; ch < p->Csem; ++ch) {
+                float s2 = trilinear(sem + ch * semplane, 1, p->Hsem, p->Wsem, gx, gy, 0.0f);
+                s2 = s2 * v2d;
+                out[(size_t)(p->C + ch) * N + i] = s2 * disp;
+            }
+        }
+    }
+}
+
 ORACLE_API int dfm_oracle_version(void) { return 1; }
 
 #ifdef _OPENMP

@@ -165,6 +165,49 @@ def mv_feature_transformation(feats, points, lidar2img, n_voxels, num_views, num
     return np.ascontiguousarray(vol.astype(np.float32).reshape(nz, ny, nx, -1).transpose(3, 2, 1, 0))
 
 
+class F2VParams(ctypes.Structure):
+    """struct dfm_oracle_f2v_params"""
+    _fields_ = [('C', ctypes.c_int32), ('D', ctypes.c_int32), ('H', ctypes.c_int32),
+                ('W', ctypes.c_int32), ('Ds', ctypes.c_int32), ('Hs', ctypes.c_int32),
+                ('Ws', ctypes.c_int32), ('Csem', ctypes.c_int32), ('Hsem', ctypes.c_int32),
+                ('Wsem', ctypes.c_int32), ('Nz', ctypes.c_int32), ('Ny', ctypes.c_int32),
+                ('Nx', ctypes.c_int32), ('pad_h', ctypes.c_float), ('pad_w', ctypes.c_float),
+                ('depth_min', ctypes.c_float), ('depth_span', ctypes.c_float),
+                ('P', ctypes.c_float * 12)]
+
+
+def frustum_to_voxel(stereo, softmax, sem, coordinates_3d, cam2img, pad_shape, depth_min,
+                     depth_max):
+    """Sampling stage of FrustumToVoxel.forward (feature_transformation.py:82-158):
+    stereo (B,C,D,H,W), softmax (B,1,Ds,Hs,Ws), sem (B,Cs,H,W) or None, cam2img (B,4,4)
+    -> (B, C+Cs, Nz, Ny, Nx).  pad_shape of sample 0 is used for all (reference :101)."""
+    stereo, softmax = _f32(stereo), _f32(softmax)
+    coords = _f32(coordinates_3d)
+    B, C, D, H, W = stereo.shape
+    nz, ny, nx = coords.shape[:3]
+    cs = 0 if sem is None else sem.shape[1]
+    outs = []
+    for b in range(B):
+        p = F2VParams()
+        p.C, p.D, p.H, p.W = C, D, H, W
+        p.Ds, p.Hs, p.Ws = softmax.shape[2:]
+        p.Csem = cs
+        if cs:
+            p.Hsem, p.Wsem = sem.shape[2:]
+        p.Nz, p.Ny, p.Nx = nz, ny, nx
+        p.pad_h, p.pad_w = float(pad_shape[0]), float(pad_shape[1])
+        p.depth_min = float(depth_min)
+        p.depth_span = float(depth_max) - float(depth_min)  # python double, then fp32
+        for i, v in enumerate(_f32(cam2img[b])[:3].reshape(12)):
+            p.P[i] = float(v)
+        out = np.empty((C + cs, nz, ny, nx), np.float32)
+        s = _f32(sem[b]) if cs else None
+        lib().dfm_oracle_frustum_to_voxel(ctypes.byref(p), _vp(stereo[b]), _vp(softmax[b]),
+                                          _vp(s) if cs else None, _vp(coords), _vp(out))
+        outs.append(out)
+    return np.stack(outs)
+
+
 def bf16_round(a):
     """fp32 -> bf16 (round-to-nearest-even) -> fp32, numpy."""
     u = _f32(a).view(np.uint32)

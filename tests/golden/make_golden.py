@@ -30,6 +30,7 @@ import torch.nn.functional as F
 
 REF = '/root/reference/mmdet3d/'
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 
 
 def extract(path, names, glb):
@@ -256,6 +257,52 @@ def make_mv(g):
         print(name, tuple(out.shape), f'nonzero {nz:.3f}')
 
 
+# name, C, (D,H,W) of the cost volume, point cloud range, voxel size, depth range, batch
+F2V_CASES = [
+    ('f2v_small', 4, (6, 10, 32), [2, -6.0, -3, 14.0, 6.0, 1], [0.5, 0.5, 0.5], (2, 14.0), 1),
+    ('f2v_batch2', 3, (5, 12, 24), [1, -5.0, -2, 11.0, 5.0, 2], [0.5, 0.5, 1.0], (1, 11.0), 2),
+]
+
+
+def make_f2v():
+    import ref_stubs
+    from types import SimpleNamespace
+    ref_stubs.install()
+    ft = ref_stubs.load_file('mmdet3d/models/necks/feature_transformation.py', 'ref_ft')
+    g = {'torch': torch, 'np': np}
+    extract_method(REF + 'models/detectors/dfm.py', 'DfM', 'prepare_coordinates_3d', g)
+    torch.Tensor.cuda = lambda self, *a, **k: self  # feature_transformation.py:82,93 hard-code .cuda()
+    for i, (name, C, (D, H, W), pcr, vs, (dmin, dmax), B) in enumerate(F2V_CASES):
+        gen = torch.Generator().manual_seed(400 + i)
+        m = ft.FrustumToVoxel(cv_channels=C, out_channels=C, in_sem_channels=C,
+                              norm_cfg=dict(type='GN', num_groups=1, requires_grad=True))
+        m.voxel_convs = torch.nn.Identity()   # capture the sampled (B,2C,Nz,Ny,Nx) volume
+        m.voxel_pool = torch.nn.Identity()
+        holder = SimpleNamespace()
+        g['prepare_coordinates_3d'](holder, dict(point_cloud_range=pcr, voxel_size=vs))
+        m.coordinates_3d = holder.coordinates_3d
+        m.depth_cfg = dict(depth_min=dmin, depth_max=dmax)
+        stereo = torch.randn(B, C, D, H, W, generator=gen)
+        soft = torch.softmax(torch.randn(B, 1, 4 * D, 4 * H, 4 * W, generator=gen), dim=2)
+        sem = torch.randn(B, C, H, W, generator=gen)
+        pad = (4 * H, 4 * W)
+        metas = []
+        for b in range(B):
+            K = np.eye(4, dtype=np.float32)
+            K[0, 0] = K[1, 1] = 70.0 + 3 * b
+            K[0, 2], K[1, 2] = pad[1] / 2 + b, pad[0] / 2 - b
+            K[0, 3], K[1, 3], K[2, 3] = 4.5, 0.2, 0.003
+            metas.append({'cam2img': K.tolist(), 'pad_shape': pad + (3,)})
+        out = m(stereo, soft, metas, sem)
+        np.savez_compressed(
+            os.path.join(HERE, f'{name}.npz'), stereo=stereo.numpy(), softmax=soft.numpy(),
+            sem=sem.numpy(), coordinates_3d=holder.coordinates_3d.numpy(),
+            cam2img=np.stack([np.asarray(mm['cam2img'], np.float32) for mm in metas]),
+            pad_shape=np.asarray(pad), depth_min=np.float64(dmin), depth_max=np.float64(dmax),
+            ref_out=out.numpy())
+        print(name, tuple(out.shape), 'nonzero', float((out != 0).float().mean()))
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference not mounted; fixtures are committed, nothing to do')
@@ -264,3 +311,4 @@ if __name__ == '__main__':
     make_sweep(ref)
     make_helpers(ref)
     make_mv(ref)
+    make_f2v()

@@ -1,0 +1,127 @@
+"""Minimal stand-ins for the un-vendored mmcv / mmdet symbols the reference's
+hot-path module files import, so those files can be executed UNMODIFIED from
+/root/reference on PyTorch-CPU (build container only).
+
+This is our own code: `ConvModule` restates mmcv 1.6's documented composition
+(conv -> norm -> activation, `bias='auto'` = no conv bias when a norm follows,
+norm sub-module named after its type: gn / bn, ReLU default).  Weights are
+always copied between the reference module and ours through `state_dict`, so
+mmcv's initialisation scheme is irrelevant to parity.
+"""
+import importlib.util
+import sys
+import types
+
+import torch
+from torch import nn
+
+REF_ROOT = '/root/reference'
+
+
+class Registry:
+
+    def __init__(self, name='models'):
+        self.name = name
+        self.module_dict = {}
+
+    def register_module(self, name=None, force=False, module=None):
+
+        def _reg(cls):
+            self.module_dict[name or cls.__name__] = cls
+            return cls
+
+        return _reg(module) if module is not None else _reg
+
+    def build(self, cfg):
+        cfg = dict(cfg)
+        return self.module_dict[cfg.pop('type')](**cfg)
+
+
+class BaseModule(nn.Module):
+
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+
+    def init_weights(self):
+        pass
+
+
+_CONV = {'Conv2d': nn.Conv2d, 'Conv3d': nn.Conv3d, None: nn.Conv2d}
+
+
+def build_norm(norm_cfg, num_features):
+    cfg = dict(norm_cfg)
+    t = cfg.pop('type')
+    requires_grad = cfg.pop('requires_grad', True)
+    if t == 'GN':
+        layer, name = nn.GroupNorm(num_channels=num_features, **cfg), 'gn'
+    elif t in ('BN', 'BN2d'):
+        layer, name = nn.BatchNorm2d(num_features, **cfg), 'bn'
+    elif t == 'BN3d':
+        layer, name = nn.BatchNorm3d(num_features, **cfg), 'bn'
+    else:
+        raise KeyError(t)
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return name, layer
+
+
+class ConvModule(nn.Module):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias='auto', conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'),
+                 inplace=True, order=('conv', 'norm', 'act')):
+        super().__init__()
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        conv = _CONV[None if conv_cfg is None else conv_cfg['type']]
+        self.conv = conv(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                         dilation=dilation, groups=groups, bias=bias)
+        if self.with_norm:
+            self.norm_name, norm = build_norm(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            assert act_cfg['type'] == 'ReLU'
+            self.activate = nn.ReLU(inplace=act_cfg.get('inplace', inplace))
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = getattr(self, self.norm_name)(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x
+
+
+def install():
+    """Put the stubs where the reference files' import statements look."""
+    reg = Registry()
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    mod('mmcv')
+    mod('mmcv.cnn', ConvModule=ConvModule)
+    mod('mmcv.runner', BaseModule=BaseModule, force_fp32=lambda *a, **k: (lambda f: f))
+    mod('mmdet')
+    mod('mmdet.models')
+    mod('mmdet.models.builder', BACKBONES=reg, NECKS=reg, HEADS=reg, DETECTORS=reg)
+    return reg
+
+
+def load_file(relpath, modname, extra_modules=None):
+    """exec a reference source file as module `modname` (no package import)"""
+    for k, v in (extra_modules or {}).items():
+        sys.modules[k] = v
+    spec = importlib.util.spec_from_file_location(modname, f'{REF_ROOT}/{relpath}')
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = m
+    spec.loader.exec_module(m)
+    return m

@@ -1,0 +1,104 @@
+"""FrustumToVoxel sampling stage: oracle vs fixtures produced by the reference
+module (CPU, bit-exact) and HIP vs oracle / fixtures (GPU, bit-exact fp32;
+bf16 storage exact vs bf16(oracle(bf16-rounded inputs)))."""
+import glob
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dfm_oracle as orc
+from tests import util
+
+
+def cases():
+    return sorted(glob.glob(os.path.join(util.GOLDEN, 'f2v_*.npz')))
+
+
+def oracle_run(z, sem=True):
+    return orc.frustum_to_voxel(z['stereo'], z['softmax'], z['sem'] if sem else None,
+                                z['coordinates_3d'], z['cam2img'], z['pad_shape'],
+                                float(z['depth_min']), float(z['depth_max']))
+
+
+@pytest.mark.parametrize('path', cases(), ids=lambda p: os.path.basename(p)[:-4])
+def test_oracle_bitexact_vs_reference_module(path):
+    z = np.load(path)
+    out = oracle_run(z)
+    assert np.array_equal(util.bits(out), util.bits(z['ref_out']))
+    # the fixture covers both masks: some voxels project outside, some are beyond the depth range
+    C = z['stereo'].shape[1]
+    assert 0.05 < (z['ref_out'][:, :C] == 0).mean() < 0.95
+
+
+def hip_run(z, dtype=torch.float32, sem=True):
+    pkg = importlib.import_module('depth-from-motion_amd')
+    dev = torch.device('cuda:0')
+    metas = [{'cam2img': c.tolist(), 'pad_shape': tuple(int(v) for v in z['pad_shape']) + (3,)}
+             for c in z['cam2img']]
+    out = pkg.frustum_to_voxel_sample(
+        torch.from_numpy(z['stereo']).to(dev).to(dtype), torch.from_numpy(z['softmax']).to(dev).to(dtype),
+        metas, torch.from_numpy(z['sem']).to(dev).to(dtype) if sem else None,
+        torch.from_numpy(z['coordinates_3d']),
+        dict(depth_min=float(z['depth_min']), depth_max=float(z['depth_max'])))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', cases(), ids=lambda p: os.path.basename(p)[:-4])
+def test_hip_fp32_bitexact_vs_reference_fixture(path):
+    z = np.load(path)
+    out = hip_run(z).cpu().numpy()
+    assert out.shape == z['ref_out'].shape
+    assert np.array_equal(util.bits(out), util.bits(z['ref_out']))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', cases(), ids=lambda p: os.path.basename(p)[:-4])
+def test_hip_bf16_exact_vs_oracle(path):
+    z = dict(np.load(path))
+    for k in ('stereo', 'softmax', 'sem'):
+        z[k] = orc.bf16_round(z[k])
+    ref = orc.bf16_round(oracle_run(z))
+    out = hip_run(z, torch.bfloat16)
+    assert np.array_equal(util.bits(out.float().cpu().numpy()), util.bits(ref))
+
+
+@pytest.mark.gpu
+def test_hip_without_semantic_branch():
+    z = np.load(cases()[0])
+    ref = oracle_run(z, sem=False)
+    out = hip_run(z, sem=False).cpu().numpy()
+    assert out.shape[1] == z['stereo'].shape[1]
+    assert np.array_equal(util.bits(out), util.bits(ref))
+
+
+@pytest.mark.gpu
+def test_hip_kitti_config_shape_vs_oracle():
+    """config K sizes: (1,32,72,80,320) cost volume, 288x320x1280 depth distribution,
+    20x304x288 voxel grid; a z-slab of the grid is checked against the oracle."""
+    rng = np.random.RandomState(0)
+    C, D, H, W = 32, 72, 80, 320
+    stereo = rng.randn(1, C, D, H, W).astype(np.float32)
+    logits = torch.from_numpy(rng.randn(1, 1, 4 * D, 4 * H, 4 * W).astype(np.float32))
+    soft = torch.softmax(logits, dim=2).numpy()
+    sem = rng.randn(1, C, H, W).astype(np.float32)
+    zs = torch.linspace(-3 + 0.1, 1 - 0.1, 20)
+    ys = torch.linspace(-30.4 + 0.1, 30.4 - 0.1, 304)
+    xs = torch.linspace(2 + 0.1, 59.6 - 0.1, 288)
+    zz, yy, xx = torch.meshgrid(zs, ys, xs, indexing='ij')
+    coords = torch.stack([xx, yy, zz], -1).numpy()
+    K = util.KITTI_P2.copy()
+    K[0, 2] -= 0.0
+    K[1, 2] -= 55.0  # crop_offset (0, 55) folded into the augmented cam2img
+    z = dict(stereo=stereo, softmax=soft, sem=sem, coordinates_3d=coords, cam2img=K[None],
+             pad_shape=np.array([320, 1280]), depth_min=2.0, depth_max=59.6)
+    out = hip_run(z).cpu().numpy()
+    assert out.shape == (1, 64, 20, 304, 288)
+    zsub = dict(z, coordinates_3d=coords[7:9])
+    ref = oracle_run(zsub)
+    assert np.array_equal(util.bits(out[:, :, 7:9]), util.bits(ref))
+    assert 0.2 < (ref != 0).mean()
