@@ -28,6 +28,7 @@ EXPORTS = (
     'dfm_point_sample_mv_workspace_bytes',
     'dfm_point_sample_mv_fwd',
     'dfm_frustum_to_voxel_fwd',
+    'dfm_depth_head_fwd',
 )
 
 
@@ -132,6 +133,8 @@ def lib():
     h.dfm_point_sample_mv_fwd.argtypes = [mp, vp, fp, fp, fp, vp, vp, vp, sz, vp]
     h.dfm_frustum_to_voxel_fwd.restype = ctypes.c_int
     h.dfm_frustum_to_voxel_fwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, vp, fp, fp, vp, vp]
+    h.dfm_depth_head_fwd.restype = ctypes.c_int
+    h.dfm_depth_head_fwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, vp]
     _lib = h
     return h
 

@@ -229,6 +229,22 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *desc, const void *stere
                                      const void *softmax, const void *sem, const float *coords,
                                      const float *cam2img, void *out, void *stream);
 
+/* ---------------------------------------------------------------------- */
+/* DepthHead.forward (with_convs=False), dense_heads/depth_head.py:205-210  */
+/* ---------------------------------------------------------------------- */
+/*
+ * cost          : (B, 1, d, h, w) mono/stereo cost, dtype            [device]
+ * depth_samples : (scale*d) fp32 bin centres (DfM.prepare_depth)      [device]
+ * depth_volumes : (B, 1, scale*d, scale*h, scale*w) trilinear x scale upsample
+ *                 (align_corners=True), bit-exact vs torch CPU
+ * softmax       : same shape, softmax over depth
+ * depth_preds   : (B, 1, scale*h, scale*w) = sum(softmax * depth_samples)
+ */
+DFM_API int dfm_depth_head_fwd(int32_t batch, int32_t d, int32_t h, int32_t w, int32_t scale,
+                               int32_t dtype, const void *cost, const float *depth_samples,
+                               void *depth_volumes, void *softmax, void *depth_preds,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -393,6 +393,77 @@ ORACLE_API void dfm_oracle_frustum_to_voxel(const dfm_oracle_f2v_params *p, cons
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* DepthHead.forward (with_convs=False)                                      */
+/* reference: mmdet3d/models/dense_heads/depth_head.py:205-210               */
+/*  nn.Upsample(scale, 'trilinear', align_corners=True): ATen                 */
+/*  native/cpu/UpSampleKernel.cpp -- index0 = min(floor(scale*i), in-1),      */
+/*  lambda1 = clamp(scale*i - index0, 0, 1), scale = (in-1)/(out-1) in fp32,  */
+/*  value = fma(w0, a, w1*b) nested W -> H -> D (pinned bit-exact by           */
+/*  tests/golden/depth_head_*.npz).                                           */
+/*  softmax(dim=2) and sum(softmax*depth): torch uses a vectorised Sleef exp; */
+/*  this restatement uses libm expf -- equal to rounding error, NOT bitwise   */
+/*  (parity tolerance rtol 2e-6 for softmax, 1e-5 for the expectation).       */
+/* ------------------------------------------------------------------------ */
+static inline void up_index(int i, int in, int out, int *i0, int *i1, float *w0, float *w1)
+{
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f;
+    const float real = scale * (float)i;
+    int a = (int)floorf(real);
+    if (a > in - 1) a = in - 1;
+    float l = real - (float)a;
+    l = l < 0.0f ? 0.0f : (l > 1.0f ? 1.0f : l);
+    *i0 = a;
+    *i1 = a + 1 < in ? a + 1 : in - 1;
+    *w1 = l;
+    *w0 = 1.0f - l;
+}
+static inline float lerp_fma(float w0, float a, float w1, float b) { return fmaf(w0, a, w1 * b); }
+
+/* in (D,H,W) one sample; s = upsample factor; depth_samples (s*D);
+ * vol, soft (s*D, s*H, s*W); pred (s*H, s*W) */
+ORACLE_API void dfm_oracle_depth_head(const float *in, int D, int H, int W, int s,
+                                      const float *depth_samples, float *vol, float *soft,
+                                      float *pred)
+{
+    const int Do = D * s, Ho = H * s, Wo = W * s;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int h = 0; h < Ho; ++h)
+        for (int w = 0; w < Wo; ++w) {
+            int h0, h1, w0, w1;
+            float wh0, wh1, ww0, ww1;
+            up_index(h, H, Ho, &h0, &h1, &wh0, &wh1);
+            up_index(w, W, Wo, &w0, &w1, &ww0, &ww1);
+            float mx = -INFINITY;
+            for (int d = 0; d < Do; ++d) {
+                int d0, d1;
+                float wd0, wd1;
+                up_index(d, D, Do, &d0, &d1, &wd0, &wd1);
+                const float *p0 = in + (size_t)d0 * H * W, *p1 = in + (size_t)d1 * H * W;
+                const float a0 = lerp_fma(ww0, p0[h0 * W + w0], ww1, p0[h0 * W + w1]);
+                const float b0 = lerp_fma(ww0, p0[h1 * W + w0], ww1, p0[h1 * W + w1]);
+                const float a1 = lerp_fma(ww0, p1[h0 * W + w0], ww1, p1[h0 * W + w1]);
+                const float b1 = lerp_fma(ww0, p1[h1 * W + w0], ww1, p1[h1 * W + w1]);
+                const float v = lerp_fma(wd0, lerp_fma(wh0, a0, wh1, b0), wd1, lerp_fma(wh0, a1, wh1, b1));
+                vol[((size_t)d * Ho + h) * Wo + w] = v;
+                if (v > mx) mx = v;
+            }
+            float sum = 0.0f;
+            for (int d = 0; d < Do; ++d) {
+                const float e = expf(vol[((size_t)d * Ho + h) * Wo + w] - mx);
+                soft[((size_t)d * Ho + h) * Wo + w] = e;
+                sum += e;
+            }
+            float acc = 0.0f;
+            for (int d = 0; d < Do; ++d) {
+                const float pr = soft[((size_t)d * Ho + h) * Wo + w] / sum;
+                soft[((size_t)d * Ho + h) * Wo + w] = pr;
+                acc += pr * depth_samples[d];
+            }
+            pred[(size_t)h * Wo + w] = acc;
+        }
+}
+
 ORACLE_API int dfm_oracle_version(void) { return 1; }
 
 #ifdef _OPENMP

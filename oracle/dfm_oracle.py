@@ -208,6 +208,22 @@ def frustum_to_voxel(stereo, softmax, sem, coordinates_3d, cam2img, pad_shape, d
     return np.stack(outs)
 
 
+def depth_head(stereo_features, depth_samples, scale=4):
+    """DepthHead.forward with with_convs=False (depth_head.py:205-210):
+    (B,1,D,H,W) -> depth_volumes, softmax (B,1,sD,sH,sW), depth_preds (B,1,sH,sW)."""
+    x = _f32(stereo_features)
+    ds = _f32(depth_samples).reshape(-1)
+    B, one, D, H, W = x.shape
+    assert one == 1 and ds.size == scale * D
+    vol = np.empty((B, 1, scale * D, scale * H, scale * W), np.float32)
+    soft = np.empty_like(vol)
+    pred = np.empty((B, 1, scale * H, scale * W), np.float32)
+    for b in range(B):
+        lib().dfm_oracle_depth_head(_vp(x[b, 0]), D, H, W, int(scale), _vp(ds), _vp(vol[b, 0]),
+                                    _vp(soft[b, 0]), _vp(pred[b, 0]))
+    return vol, soft, pred
+
+
 def bf16_round(a):
     """fp32 -> bf16 (round-to-nearest-even) -> fp32, numpy."""
     u = _f32(a).view(np.uint32)

@@ -303,6 +303,27 @@ def make_f2v():
         print(name, tuple(out.shape), 'nonzero', float((out != 0).float().mean()))
 
 
+def make_depth_head():
+    import ref_stubs
+    ref_stubs.install()
+    dh = ref_stubs.load_file('mmdet3d/models/dense_heads/depth_head.py', 'ref_depth_head')
+    for i, (name, B, D, H, W) in enumerate([('depth_head_small', 2, 6, 5, 9),
+                                            ('depth_head_wide', 1, 18, 4, 40)]):
+        gen = torch.Generator().manual_seed(500 + i)
+        m = dh.DepthHead(depth_cfg=dict(mode='UD', num_bins=4 * D, min_depth=2, max_depth=59.6),
+                         with_convs=False, depth_loss=dict(type='ce', loss_weight=1.0),
+                         downsample_factor=4, num_views=1)
+        interval = (59.6 - 2) / (4 * D)
+        m.depth_samples = torch.tensor([(k + 0.5) * interval + 2 for k in range(4 * D)],
+                                       dtype=torch.float32)  # DfM.prepare_depth, dfm.py:170-172
+        x = torch.randn(B, 1, D, H, W, generator=gen) * 3
+        vol, soft, pred = m(x)
+        np.savez_compressed(os.path.join(HERE, f'{name}.npz'), x=x.numpy(),
+                            depth_samples=m.depth_samples.numpy(), ref_vol=vol.numpy(),
+                            ref_soft=soft.numpy(), ref_pred=pred.numpy())
+        print(name, tuple(vol.shape), tuple(pred.shape))
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference not mounted; fixtures are committed, nothing to do')
@@ -312,3 +333,4 @@ if __name__ == '__main__':
     make_helpers(ref)
     make_mv(ref)
     make_f2v()
+    make_depth_head()
