@@ -11,6 +11,7 @@ PyTorch fallback: if the shared library is missing or no GPU is visible the
 ops raise.
 """
 from . import _capi  # noqa: F401
+from . import modules, registry  # noqa: F401  (registers the module classes)
 from .plane_sweep import build_dfm_cost, plane_sweep_grid  # noqa: F401
 from .depth_head import depth_head_forward  # noqa: F401
 from .frustum_to_voxel import frustum_to_voxel_sample  # noqa: F401

@@ -1,0 +1,349 @@
+"""Registry modules of the plane-sweep path with the reference's constructor
+arguments, forward signatures, attribute-injection points and ``state_dict``
+keys, so checkpoints and ``configs/dfm/*`` carry over:
+
+  DfMBackbone        mmdet3d/models/backbones/dfm_backbone.py:14-214
+  hourglass          mmdet3d/models/utils/conv_modules.py:73-149
+  DepthHead          mmdet3d/models/dense_heads/depth_head.py:13-73,190-212 (forward)
+  FrustumToVoxel     mmdet3d/models/necks/feature_transformation.py:12-173
+  ResModule / OutdoorImVoxelNeck   mmdet3d/models/necks/imvoxel_neck.py
+  DfMNeck            mmdet3d/models/necks/dfm_neck.py
+
+The sampling stages call the HIP kernels (plane sweep, frustum-to-voxel,
+depth head).  The 3-D convolution / normalisation stacks are dense
+contractions that currently run on MIOpen through torch: a hand-written MFMA
+implicit-GEMM Conv3d is the "next" row of SURVEY.md 8f and is NOT built yet.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .depth_head import depth_head_forward
+from .frustum_to_voxel import frustum_to_voxel_sample
+from .plane_sweep import build_dfm_cost
+from .registry import register_module
+
+
+# --------------------------------------------------------------------------
+# conv -> norm -> act block with mmcv.cnn.ConvModule's sub-module names
+# (`conv`, `gn` / `bn`, `activate`) and bias rule (no conv bias under a norm)
+# --------------------------------------------------------------------------
+def _make_norm(norm_cfg, channels):
+    cfg = dict(norm_cfg)
+    kind = cfg.pop('type')
+    trainable = cfg.pop('requires_grad', True)
+    if kind == 'GN':
+        name, layer = 'gn', nn.GroupNorm(num_channels=channels, **cfg)
+    elif kind == 'BN3d':
+        name, layer = 'bn', nn.BatchNorm3d(channels, **cfg)
+    elif kind in ('BN', 'BN2d'):
+        name, layer = 'bn', nn.BatchNorm2d(channels, **cfg)
+    else:
+        raise NotImplementedError(f'norm type {kind}')
+    for p in layer.parameters():
+        p.requires_grad = trainable
+    return name, layer
+
+
+class ConvModule(nn.Module):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0,
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU')):
+        super().__init__()
+        conv_type = 'Conv2d' if conv_cfg is None else conv_cfg['type']
+        conv_cls = {'Conv2d': nn.Conv2d, 'Conv3d': nn.Conv3d}[conv_type]
+        self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride,
+                             padding=padding, bias=norm_cfg is None)
+        self.norm_name = None
+        if norm_cfg is not None:
+            self.norm_name, norm = _make_norm(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        self.activate = None
+        if act_cfg is not None:
+            if act_cfg['type'] != 'ReLU':
+                raise NotImplementedError(act_cfg['type'])
+            self.activate = nn.ReLU(inplace=act_cfg.get('inplace', True))
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.norm_name is not None:
+            x = getattr(self, self.norm_name)(x)
+        if self.activate is not None:
+            x = self.activate(x)
+        return x
+
+
+def _conv3(cin, cout, norm_cfg, act=True, stride=1, padding=1):
+    return ConvModule(cin, cout, 3, stride=stride, padding=padding, conv_cfg=dict(type='Conv3d'),
+                      norm_cfg=norm_cfg, act_cfg=dict(type='ReLU', inplace=True) if act else None)
+
+
+# --------------------------------------------------------------------------
+# hourglass (conv_modules.py:73-149): keys conv1.0.0, conv2.0, ..., conv5.0/1
+# --------------------------------------------------------------------------
+def _convgn3d(cin, cout, stride):
+    return nn.Sequential(nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False),
+                         nn.GroupNorm(32, cout))
+
+
+class hourglass(nn.Module):  # noqa: N801  (reference class name)
+
+    def __init__(self, inplanes, gn=True):
+        super().__init__()
+        if not gn:
+            raise NotImplementedError('DfM builds its hourglass with GroupNorm (dfm_backbone.py:37,70)')
+        c = inplanes
+        self.conv1 = nn.Sequential(_convgn3d(c, 2 * c, 2), nn.ReLU(inplace=True))
+        self.conv2 = _convgn3d(2 * c, 2 * c, 1)
+        self.conv3 = nn.Sequential(_convgn3d(2 * c, 2 * c, 2), nn.ReLU(inplace=True))
+        self.conv4 = nn.Sequential(_convgn3d(2 * c, 2 * c, 1), nn.ReLU(inplace=True))
+        self.conv5 = nn.Sequential(
+            nn.ConvTranspose3d(2 * c, 2 * c, 3, padding=1, output_padding=1, stride=2, bias=False),
+            nn.GroupNorm(32, 2 * c))
+        self.conv6 = nn.Sequential(
+            nn.ConvTranspose3d(2 * c, c, 3, padding=1, output_padding=1, stride=2, bias=False),
+            nn.GroupNorm(32, c))
+
+    def forward(self, x, presqu, postsqu):
+        down1 = self.conv1(x)
+        pre = self.conv2(down1)
+        pre = F.relu(pre if postsqu is None else pre + postsqu)
+        bottom = self.conv4(self.conv3(pre))
+        skip = pre if presqu is None else presqu
+        post = F.relu(self.conv5(bottom) + skip)
+        return self.conv6(post), pre, post
+
+
+# --------------------------------------------------------------------------
+# DfMBackbone
+# --------------------------------------------------------------------------
+@register_module
+class DfMBackbone(nn.Module):
+
+    def __init__(self,
+                 in_channels,
+                 num_hg=1,
+                 cost_sample_factor=4,
+                 feat_sample_factor=1,
+                 cv_channels=32,
+                 depth_cfg=dict(mode='UD', num_bins=288, depth_min=2, depth_max=59.6,
+                                downsample_factor=4),
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True),
+                 init_cfg=None):
+        super().__init__()
+        self.norm_cfg = norm_cfg
+        self.GN = True
+        self.cost_sample_factor = cost_sample_factor
+        self.feat_sample_factor = feat_sample_factor
+        self.num_hg = num_hg
+        self.cv_channels = cv_channels
+        self.in_channels = in_channels
+        cv = cv_channels
+
+        def branch(cin):
+            return (_conv3(cin, cv, norm_cfg), _conv3(cv, cv, norm_cfg, act=False),
+                    nn.ModuleList(hourglass(cv, gn=True) for _ in range(num_hg)),
+                    nn.ModuleList(
+                        nn.Sequential(_conv3(cv, cv, norm_cfg),
+                                      nn.Conv3d(cv, 1, 3, 1, 1, bias=False))
+                        for _ in range(num_hg)))
+
+        self.dres0, self.dres1, self.hg_stereo, self.pred_stereo = branch(2 * in_channels)
+        self.dres0_mono, self.dres1_mono, self.hg_mono, self.pred_mono = branch(in_channels)
+        planes = round(depth_cfg['num_bins'] // depth_cfg['downsample_factor'])
+        self.aggregate_cost = nn.Conv2d(2 * planes, planes, kernel_size=1, bias=False)
+        # injected by the detector (dfm.py:88-89); a tensor of plane depths
+        self.downsampled_depth = None
+
+    def init_weights(self):
+        pass
+
+    @staticmethod
+    def _aggregate(first, second, hgs, x):
+        cost = first(x)
+        cost = second(cost) + cost
+        outs = []
+        for hg in hgs:
+            residual, _, _ = hg(cost, None, None)
+            cost = cost + residual
+            outs.append(cost)
+        return outs if outs else [cost]
+
+    def forward(self, cur_stereo_feats, prev_stereo_feats, img_metas, cur_sem_feats=None):
+        ori_cam2imgs = torch.as_tensor(np.asarray([m['ori_cam2img'] for m in img_metas]),
+                                       dtype=torch.float32)
+        cur2prevs = torch.stack([torch.as_tensor(m['cur2prevs']) for m in img_metas])
+        meta0 = img_metas[0]
+        # plane sweep: HIP kernel (reference: build_dfm_cost, batch semantics per sample)
+        cost_raw = build_dfm_cost(
+            cur_stereo_feats, prev_stereo_feats, self.downsampled_depth, self.feat_sample_factor,
+            self.cost_sample_factor, ori_cam2imgs, cur2prevs[:, 0], meta0['ori_shape'][:2],
+            meta0.get('flip', False), meta0['crop_offset'],
+            img_scale_factor=meta0.get('scale_factor', [1.0])[0])
+        stereo = self._aggregate(self.dres0, self.dres1, self.hg_stereo, cost_raw)
+        mono = self._aggregate(self.dres0_mono, self.dres1_mono, self.hg_mono,
+                               cost_raw[:, :self.in_channels])
+        assert len(stereo) == 1 and len(mono) == 1, 'Only support num_hg=1 for now.'
+        s_cost = self.pred_stereo[0](stereo[0])
+        m_cost = self.pred_mono[0](mono[0])
+        both = torch.cat((s_cost, m_cost), dim=1).flatten(start_dim=1, end_dim=2)
+        gate = self.aggregate_cost(both).unsqueeze(dim=1).sigmoid()
+        return gate * s_cost + (1 - gate) * m_cost, stereo[0], mono[0]
+
+
+# --------------------------------------------------------------------------
+# DepthHead (forward path; the loss is outside SURVEY.md 8a)
+# --------------------------------------------------------------------------
+@register_module
+class DepthHead(nn.Module):
+
+    def __init__(self, depth_cfg, in_channels=32, with_convs=True,
+                 depth_loss=dict(type='ce', loss_weight=1.0), downsample_factor=4, num_views=5,
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True)):
+        super().__init__()
+        self.in_channels = in_channels
+        self.depth_cfg = depth_cfg
+        self.with_convs = with_convs
+        self.depth_loss = depth_loss
+        self.downsample_factor = downsample_factor
+        self.num_views = num_views
+        self.norm_cfg = norm_cfg
+        self.min_depth = depth_cfg['min_depth']
+        self.max_depth = depth_cfg['max_depth']
+        if with_convs:
+            self.conv_depth = nn.Conv3d(in_channels, 1, 3, 1, 1, bias=False)
+        self.depth_samples = None  # injected by the detector (dfm.py:90)
+
+    def forward(self, stereo_features):
+        _, _, D, H, W = stereo_features.shape
+        x = stereo_features
+        if self.with_convs:
+            x = self.conv_depth(x).view(-1, self.num_views, D, H, W)
+        if x.shape[1] != 1:
+            # several views share one launch: fold them into the batch and back
+            B, V = x.shape[:2]
+            vol, soft, pred = depth_head_forward(x.reshape(B * V, 1, D, H, W), self.depth_samples,
+                                                 self.downsample_factor)
+            s = self.downsample_factor
+            return (vol.view(B, V, s * D, s * H, s * W), soft.view(B, V, s * D, s * H, s * W),
+                    pred.view(B, V, s * H, s * W))
+        return depth_head_forward(x, self.depth_samples, self.downsample_factor)
+
+    def loss(self, *args, **kwargs):
+        raise NotImplementedError('DepthHead.loss is outside the plane-sweep hot path (SURVEY 8a)')
+
+
+# --------------------------------------------------------------------------
+# FrustumToVoxel
+# --------------------------------------------------------------------------
+@register_module
+class FrustumToVoxel(nn.Module):
+
+    def __init__(self, num_3dconvs=1, cv_channels=32, out_channels=32, in_sem_channels=32,
+                 sem_atten_feat=True, stereo_atten_feat=False, cat_img_feature=True,
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True), init_cfg=None):
+        super().__init__()
+        if stereo_atten_feat or (cat_img_feature and not sem_atten_feat):
+            raise NotImplementedError('only the shipped setting: sem_atten_feat=True, '
+                                      'stereo_atten_feat=False')
+        self.GN = True
+        self.num_3dconvs = num_3dconvs
+        self.cv_channels = cv_channels
+        self.out_channels = out_channels
+        self.in_sem_channels = in_sem_channels
+        self.sem_atten_feat = sem_atten_feat
+        self.stereo_atten_feat = stereo_atten_feat
+        self.cat_img_feature = bool(cat_img_feature)
+        cin = cv_channels + (in_sem_channels if self.cat_img_feature else 0)
+        self.voxel_convs = nn.Sequential(*[
+            nn.Sequential(_conv3(cin if i == 0 else out_channels, out_channels, norm_cfg))
+            for i in range(num_3dconvs)
+        ])
+        self.voxel_pool = nn.AvgPool3d((4, 1, 1), stride=(4, 1, 1))
+        self.coordinates_3d = None  # injected by the detector (dfm.py:99-100)
+        self.depth_cfg = None       # injected by the detector (dfm.py:86)
+
+    def init_weights(self):
+        pass
+
+    def forward(self, stereo_feat, stereo_feat_softmax, img_metas, cur_sem_feats=None):
+        voxel = frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas,
+                                        cur_sem_feats if self.cat_img_feature else None,
+                                        self.coordinates_3d, self.depth_cfg)
+        return self.voxel_pool(self.voxel_convs(voxel))
+
+
+# --------------------------------------------------------------------------
+# voxel necks
+# --------------------------------------------------------------------------
+class ResModule(nn.Module):
+
+    def __init__(self, n_channels, norm_cfg=dict(type='BN3d')):
+        super().__init__()
+        self.conv0 = _conv3(n_channels, n_channels, norm_cfg)
+        self.conv1 = _conv3(n_channels, n_channels, norm_cfg, act=False)
+        self.activation = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.activation(x + self.conv1(self.conv0(x)))
+
+
+def _bev_stack(c_in, widths, out_channels, norm_cfg):
+    """Res(c_in) -> conv s(1,1,2) -> Res -> conv s(1,1,2) -> Res -> conv p(1,1,0):
+    collapses Nz 12 -> 6 -> 3 -> 1 (imvoxel_neck.py:26-55)."""
+    c0, c1, c2 = widths
+    return nn.Sequential(
+        ResModule(c_in, norm_cfg=norm_cfg),
+        _conv3(c_in, c1, norm_cfg, stride=(1, 1, 2)),
+        ResModule(c1, norm_cfg=norm_cfg),
+        _conv3(c1, c2, norm_cfg, stride=(1, 1, 2)),
+        ResModule(c2, norm_cfg=norm_cfg),
+        _conv3(c2, out_channels, norm_cfg, padding=(1, 1, 0)))
+
+
+def _to_bev(x):
+    assert x.shape[-1] == 1
+    return x[..., 0].transpose(-1, -2)  # Anchor3DHead axis order (y, x)
+
+
+@register_module
+class OutdoorImVoxelNeck(nn.Module):
+
+    def __init__(self, in_channels, out_channels, norm_cfg=dict(type='BN3d'), output_bev=True):
+        super().__init__()
+        self.output_bev = output_bev
+        widths = in_channels if isinstance(in_channels, list) else \
+            [in_channels, in_channels * 2, in_channels * 4]
+        self.model = _bev_stack(widths[0], widths, out_channels, norm_cfg)
+
+    def forward(self, x):
+        assert self.output_bev
+        return [_to_bev(self.model(x))]
+
+    def init_weights(self):
+        pass
+
+
+@register_module
+class DfMNeck(nn.Module):
+
+    def __init__(self, in_channels, out_channels, norm_cfg=dict(type='BN3d'), num_frames=2):
+        super().__init__()
+        widths = in_channels if isinstance(in_channels, list) else \
+            [in_channels, in_channels * 2, in_channels * 4]
+        self.in_channels = widths
+        self.num_frames = num_frames
+        self.mono_layers = _bev_stack(widths[0], widths, out_channels, norm_cfg)
+        self.stereo_layers = _bev_stack(widths[0] * num_frames, widths, out_channels, norm_cfg)
+        self.aggregate_layer = nn.Conv2d(2 * out_channels, 1, kernel_size=1, bias=False)
+
+    def forward(self, x):
+        assert x.shape[1] == self.in_channels[0] * self.num_frames
+        mono = _to_bev(self.mono_layers(x[:, :self.in_channels[0]]))
+        stereo = _to_bev(self.stereo_layers(x))
+        gate = self.aggregate_layer(torch.cat([mono, stereo], dim=1)).sigmoid()
+        return [gate * mono + (1 - gate) * stereo]
+
+    def init_weights(self):
+        pass

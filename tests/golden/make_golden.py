@@ -324,6 +324,61 @@ def make_depth_head():
         print(name, tuple(vol.shape), tuple(pred.shape))
 
 
+def make_modules():
+    """Whole-module fixtures: the reference modules (executed unmodified under
+    ref_stubs) with the deterministic weights of tests/util.synthetic_state_dict."""
+    import ref_stubs
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests import util
+    ref = ref_stubs.load_hot_path_modules()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {}
+    # --- DfMBackbone: 2 x (1,4,16,32) feats, csf 4, 8 planes
+    depth_cfg = dict(mode='UD', num_bins=32, depth_min=2, depth_max=59.6, downsample_factor=4)
+    m = ref['dfm_backbone'].DfMBackbone(in_channels=4, cv_channels=32, cost_sample_factor=4,
+                                        depth_cfg=depth_cfg).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, 11))
+    interval = (59.6 - 2) / 32
+    m.downsampled_depth = torch.tensor([(i + 0.5) * 4 * interval + 2 for i in range(8)])
+    gen = torch.Generator().manual_seed(12)
+    cur, prev = torch.randn(1, 4, 16, 32, generator=gen), torch.randn(1, 4, 16, 32, generator=gen)
+    K = KITTI_P2
+    meta = dict(ori_cam2img=K, cur2prevs=torch.tensor(pose(1.0, 0.05, 0.0, -0.9))[None],
+                ori_shape=(375, 1242, 3), pad_shape=(16, 32, 3), crop_offset=[600, 150],
+                flip=False, scale_factor=[1.0])
+    with torch.no_grad():
+        cost, sfeat, mfeat = m(cur, prev, [meta])
+    out.update(bb_cur=cur.numpy(), bb_prev=prev.numpy(), bb_cost=cost.numpy(),
+               bb_stereo=sfeat.numpy(), bb_mono=mfeat.numpy(),
+               bb_depths=m.downsampled_depth.numpy())
+    # --- FrustumToVoxel with its conv + pool
+    z = np.load(os.path.join(HERE, 'f2v_small.npz'))
+    C = z['stereo'].shape[1]
+    m = ref['feature_transformation'].FrustumToVoxel(
+        cv_channels=C, out_channels=8, in_sem_channels=C,
+        norm_cfg=dict(type='GN', num_groups=4, requires_grad=True)).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, 21))
+    m.coordinates_3d = torch.from_numpy(z['coordinates_3d'])
+    m.depth_cfg = dict(depth_min=float(z['depth_min']), depth_max=float(z['depth_max']))
+    metas = [{'cam2img': c.tolist(), 'pad_shape': tuple(z['pad_shape']) + (3,)} for c in z['cam2img']]
+    with torch.no_grad():
+        out['f2v_out'] = m(torch.from_numpy(z['stereo']), torch.from_numpy(z['softmax']), metas,
+                           torch.from_numpy(z['sem'])).numpy()
+    # --- voxel necks, eval-mode BN
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 8, 6, 5, 12, generator=gen)
+    m = ref['imvoxel_neck'].OutdoorImVoxelNeck(in_channels=8, out_channels=16).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, 32))
+    with torch.no_grad():
+        out.update(neck_x=x.numpy(), imvoxel_out=m(x)[0].numpy())
+    m = ref['dfm_neck'].DfMNeck(in_channels=4, out_channels=16, num_frames=2).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, 33))
+    with torch.no_grad():
+        out['dfmneck_out'] = m(x)[0].numpy()
+    np.savez_compressed(os.path.join(HERE, 'modules.npz'), **out)
+    print('modules:', {k: v.shape for k, v in out.items()})
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference not mounted; fixtures are committed, nothing to do')
@@ -334,3 +389,4 @@ if __name__ == '__main__':
     make_mv(ref)
     make_f2v()
     make_depth_head()
+    make_modules()

@@ -113,7 +113,39 @@ def install():
     mod('mmdet')
     mod('mmdet.models')
     mod('mmdet.models.builder', BACKBONES=reg, NECKS=reg, HEADS=reg, DETECTORS=reg)
+    # package skeleton so the reference files' absolute / relative imports resolve
+    mod('mmdet3d')
+    mod('mmdet3d.models')
+    mod('mmdet3d.models.builder', BACKBONES=reg, NECKS=reg, HEADS=reg, DETECTORS=reg, MODELS=reg)
+    mod('mmdet3d.models.necks')
+    mod('mmdet3d.models.backbones')
+    mod('mmdet3d.core')
+    geo = {'torch': torch}
+    import ast
+    tree = ast.parse(open(f'{REF_ROOT}/mmdet3d/core/bbox/structures/utils.py').read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ('points_cam2img', 'points_img2cam'):
+            node.decorator_list = []
+            exec(compile(ast.Module(body=[node], type_ignores=[]), 'utils.py', 'exec'), geo)
+    mod('mmdet3d.core.bbox', points_cam2img=geo['points_cam2img'],
+        points_img2cam=geo['points_img2cam'])
+    load_file('mmdet3d/models/utils/conv_modules.py', 'mmdet3d.models.utils')
     return reg
+
+
+def load_hot_path_modules():
+    """The reference's hot-path module files, executed unmodified."""
+    install()
+    out = {}
+    out['dfm_backbone'] = load_file('mmdet3d/models/backbones/dfm_backbone.py',
+                                    'mmdet3d.models.backbones.dfm_backbone')
+    out['imvoxel_neck'] = load_file('mmdet3d/models/necks/imvoxel_neck.py',
+                                    'mmdet3d.models.necks.imvoxel_neck')
+    out['dfm_neck'] = load_file('mmdet3d/models/necks/dfm_neck.py', 'mmdet3d.models.necks.dfm_neck')
+    out['feature_transformation'] = load_file('mmdet3d/models/necks/feature_transformation.py',
+                                              'mmdet3d.models.necks.feature_transformation')
+    out['depth_head'] = load_file('mmdet3d/models/dense_heads/depth_head.py', 'ref_depth_head')
+    return out
 
 
 def load_file(relpath, modname, extra_modules=None):

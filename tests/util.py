@@ -45,3 +45,28 @@ def host_inverse(P):
     if P.ndim == 2:
         return torch.inverse(torch.from_numpy(P.copy())).numpy()
     return np.stack([torch.inverse(torch.from_numpy(p.copy())).numpy() for p in P])
+
+
+def synthetic_state_dict(module, seed):
+    """Deterministic weights for a module (shared by the golden generator and the
+    tests so no checkpoint has to be stored): keys in state_dict order, values from a
+    seeded CPU generator; norm scales near 1, running_var positive."""
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in module.state_dict().items():
+        if k.endswith('num_batches_tracked'):
+            out[k] = torch.zeros_like(v)
+        elif k.endswith('running_var'):
+            out[k] = torch.rand(v.shape, generator=gen) + 0.5
+        elif k.endswith('running_mean'):
+            out[k] = torch.randn(v.shape, generator=gen) * 0.1
+        elif (k.endswith('gn.weight') or k.endswith('bn.weight') or
+              (v.dim() == 1 and k.endswith('.weight'))):
+            out[k] = 1.0 + 0.1 * torch.randn(v.shape, generator=gen)
+        elif v.dim() == 1:
+            out[k] = 0.1 * torch.randn(v.shape, generator=gen)
+        else:
+            fan_in = v[0].numel()
+            out[k] = torch.randn(v.shape, generator=gen) * (2.0 / fan_in) ** 0.5
+    return out
