@@ -46,7 +46,9 @@ def test_registry_builds_the_config_dicts(pkg):
     ft = reg.build_neck(dict(type='FrustumToVoxel', sem_atten_feat=True, stereo_atten_feat=False,
                              num_3dconvs=1, cv_channels=32, out_channels=32,
                              norm_cfg=dict(type='GN', num_groups=32, requires_grad=True)))
-    assert sum(p.numel() for p in ft.parameters()) == 55392
+    # 27*64*32 + 2*32; the reference module under the mmcv stub has the same count
+    # (SURVEY 8a quotes 55 392, which does not match the three state_dict tensors)
+    assert sum(p.numel() for p in ft.parameters()) == 55360
     assert ft.cat_img_feature and ft.in_sem_channels == 32
     n1 = reg.build_neck(dict(type='OutdoorImVoxelNeck', in_channels=64, out_channels=256))
     assert sum(p.numel() for p in n1.parameters()) == 7523328
