@@ -36,6 +36,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791],
                      [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
 
+# secondary workloads (other rows of SURVEY.md 8a), reported with the same JSON shape
+SECONDARY = ('waymo', 'depth_head', 'f2v')
+
 WORKLOADS = {
     # name: B, C, H, W, D, fsf, csf, crop, dtype
     'nstar': dict(B=8, C=256, H=94, W=311, D=112, fsf=4, csf=1, crop=(0, 0), dtype='bf16',
@@ -106,12 +109,87 @@ def cpu_baseline(w, budget_s=15.0):
     }
 
 
+def secondary(args, pkg, dev, rank, world):
+    """Other hot-path rows on their config shapes; `value` = passes/s of the op over
+    one sample batch, roofline from HIP-event step time (one fused kernel per step)."""
+    gen = torch.Generator().manual_seed(rank)
+    if args.workload == 'waymo':
+        # config W: 5 views x 2 frames, 64 ch, 208x312 level-0 maps, 220x300x12 voxels, concat
+        from tests.golden.make_golden import waymo_like_cameras
+        B, nv, nf, C, hf, wf, nvox = 2, 5, 2, 64, 208, 312, (220, 300, 12)
+        feats = torch.randn(B, nv * nf, C, hf, wf, generator=gen).to(dev)
+        cams = waymo_like_cameras(nv, nf, 5)
+        cams[:, 0, :] *= 1248 / 156.0
+        cams[:, 1, :] *= 832 / 104.0
+        meta = {'ori_lidar2img': [m for m in cams], 'input_shape': (832, 1248),
+                'img_shape': [(832, 1248, 3)] * (nv * nf)}
+        pts = pkg.voxel_centers([-35.0, -75.0, -2.0, 75.0, 75.0, 4.0], nvox).to(dev)
+
+        def step():
+            return pkg.mv_feature_transformation(feats, [meta] * B, nv, nf, None, nvox, 'concat',
+                                                 points=pts)
+        nbytes = B * 4 * (nv * nf * C * hf * wf + C * nf * nvox[0] * nvox[1] * nvox[2])
+        name, unit = 'multi-view voxel lifting (5 views x 2 frames -> 128x220x300x12, fp32)', 'voxel-volumes/s'
+    elif args.workload == 'depth_head':
+        B = 8
+        x = (torch.randn(B, 1, 72, 80, 320, generator=gen) * 4).to(dev)
+        ds = torch.tensor([(k + 0.5) * (57.6 / 288) + 2 for k in range(288)])
+
+        def step():
+            return pkg.depth_head_forward(x, ds)
+        nbytes = B * 4 * (72 * 80 * 320 + 2 * 288 * 320 * 1280 + 320 * 1280)
+        name, unit = 'DepthHead.forward (1,72,80,320)->2x(288,320,1280)+map, fp32', 'depth-volumes/s'
+    else:
+        B, C, D, H, W = 8, 32, 72, 80, 320
+        stereo = torch.randn(B, C, D, H, W, generator=gen).to(dev)
+        soft = torch.softmax(torch.randn(B, 1, 4 * D, 4 * H, 4 * W, device=dev), dim=2)
+        sem = torch.randn(B, C, H, W, generator=gen).to(dev)
+        zz, yy, xx = torch.meshgrid(torch.linspace(-2.9, 0.9, 20), torch.linspace(-30.3, 30.3, 304),
+                                    torch.linspace(2.1, 59.5, 288), indexing='ij')
+        coords = torch.stack([xx, yy, zz], -1).to(dev)
+        K = KITTI_P2.copy()
+        K[1, 2] -= 55.0
+        metas = [{'cam2img': K.tolist(), 'pad_shape': (320, 1280, 3)}] * B
+        cfg = dict(depth_min=2, depth_max=59.6)
+
+        def step():
+            return pkg.frustum_to_voxel_sample(stereo, soft, metas, sem, coords, cfg)
+        nbytes = B * 4 * (C * D * H * W + 288 * 320 * 1280 + C * H * W + 2 * C * 20 * 304 * 288)
+        name, unit = 'FrustumToVoxel sampling (32x72x80x320 + 288x320x1280 + 32x80x320 -> 64x20x304x288, fp32)', 'voxel-volumes/s'
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = elapsed * 1e3 / args.steps
+    dev_ms = e0.elapsed_time(e1) / args.steps
+    achieved = nbytes / (dev_ms * 1e-3) / 1e9
+    if rank == 0:
+        print(json.dumps({
+            'metric': unit.replace('/s', '/sec'), 'value': round(B * world / (ms / 1e3), 2),
+            'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: {name}', 'global_batch': B * world,
+                       'parallelism': f'dp{world}'},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4),
+                         'traffic': None, 'kernel_ms': round(dev_ms, 4),
+                         'algorithmic_bytes_per_launch': nbytes}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='nstar', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='nstar', choices=sorted(WORKLOADS) + list(SECONDARY))
     ap.add_argument('--kernel', type=int, default=0, help='0 auto, 1 gather, 2 LDS tiles, 3 direct tiles (A/B)')
     ap.add_argument('--lanes', type=int, default=0, help='LDS kernel lanes/workgroup (128|256)')
     ap.add_argument('--lds-kib', type=int, default=0, help='LDS kernel KiB/workgroup')
@@ -142,6 +220,8 @@ def main():
         pkg._capi.check(lib.dfm_plane_sweep_tune(args.lanes or 256, args.lds_kib or 52,
                                                  args.bpg or (1 << 20), args.planes or 2))
 
+    if args.workload in SECONDARY:
+        return secondary(args, pkg, dev, rank, world)
     w = WORKLOADS[args.workload]
     tdtype = torch.bfloat16 if w['dtype'] == 'bf16' else torch.float32
     elem = 2 if w['dtype'] == 'bf16' else 4
