@@ -33,6 +33,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+# HBM bytes per launch of the N* tile kernel from the separate rocprofv3 --pmc passes
+# (profiles/r01_final_pmc_traffic.txt): WRITE_SIZE 26 105 476 KB + 2 x FETCH_SIZE 222 537 KB
+# (the guide's gfx950 correction for wide coalesced reads); algorithmic = 27.06 GB.
+NSTAR_TRAFFIC_BYTES = (26105475.5 + 2 * 222536.8) * 1024
+
 KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791],
                      [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
 
@@ -69,7 +74,7 @@ def algorithmic_bytes(w, elem):
     return elem * (2 * w['C'] * w['H'] * w['W'] + 2 * w['C'] * w['D'] * h_out * w_out)
 
 
-def cpu_baseline(w, budget_s=15.0):
+def cpu_baseline(w, budget_s=12.0):
     """The oracle (a C port of the reference algorithm, OpenMP over rows) timed
     on this host's cores on a BOUNDED sample: one sample's volume restricted
     to a channel subset, extrapolated linearly in C (the work is exactly
@@ -95,9 +100,14 @@ def cpu_baseline(w, budget_s=15.0):
                                       orc._vp(prev), ctypes.c_int(c_sub), orc._vp(out))
         return time.perf_counter() - t0
 
-    t1 = run(2)  # calibration
-    c_sub = int(max(2, min(w['C'], budget_s / max(t1 / 2, 1e-6))))
-    t = run(c_sub)
+    run(2)  # warm the thread pool / page in the library
+    t1 = run(4)
+    c_sub = int(max(4, min(w['C'], round(4 * 3.0 / max(t1, 1e-6)))))  # ~3 s per repetition
+    reps, total = 0, 0.0
+    while total < budget_s and reps < 16:
+        total += run(c_sub)
+        reps += 1
+    t = total / reps
     sec_per_volume = t * (w['C'] / c_sub)
     return {
         'value': 1.0 / sec_per_volume,
@@ -105,7 +115,8 @@ def cpu_baseline(w, budget_s=15.0):
         'cores': cores,
         'kind': 'port',
         'sample': f'1 sample, {c_sub} of {w["C"]} channels x all D={w["D"]} planes x '
-                  f'{prm.h_out}x{prm.w_out}, fp32, {t:.1f} s measured, scaled by C',
+                  f'{prm.h_out}x{prm.w_out}, fp32, {reps} repetitions, {total:.1f} s of wall time on '
+                  f'{cores} threads, scaled by C',
     }
 
 
@@ -299,7 +310,9 @@ def main():
                 'peak': HBM_PEAK_GBPS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBPS, 4),
-                'traffic': args.traffic_bytes,
+                'traffic': args.traffic_bytes if args.traffic_bytes is not None else (
+                    NSTAR_TRAFFIC_BYTES if args.workload == 'nstar' and
+                    lib.dfm_plane_sweep_last_kernel() == 2 else None),
                 'kernel_ms': round(avg_kernel_ms, 4),
                 'algorithmic_bytes_per_launch': bytes_per_launch,
             },

@@ -261,13 +261,14 @@ struct TileGrid {
 // LDS == true : the staged kernel described above.
 // LDS == false: same lane/point/store structure, taps straight from the blocked
 //               map in global memory; runs only the tiles flagged by the LDS
-//               kernel (spill_flags) -- or every tile when flags == nullptr.
+//               kernel (spill list) -- or, as sweep_tile_kernel<.., false>, every tile.
 template <typename T, int NT, bool LDS>
-__global__ __launch_bounds__(NT) void sweep_tile_kernel(
-    SweepGeom g, SweepFast fast, TileGrid tg, int lds_slots, const uint4 *__restrict__ cur_blk,
-    const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
-    const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
-    T *__restrict__ out, unsigned char *__restrict__ spill_flags)
+__device__ __forceinline__ void tile_body(
+    const int bid, const SweepGeom &g, const SweepFast &fast, const TileGrid &tg, int lds_slots,
+    const uint4 *__restrict__ cur_blk, const uint4 *__restrict__ prev_blk,
+    const float *__restrict__ depths, const float *__restrict__ P,
+    const float *__restrict__ Pinv, const float *__restrict__ Tm, T *__restrict__ out,
+    int *__restrict__ spill_list)
 {
     constexpr int CB = elem<T>::CB;
     constexpr int V = CB;  // points per lane (one 16-byte store per channel)
@@ -275,8 +276,6 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
     constexpr int SLAB = 8;  // slab starts at a multiple of 8 so the swizzle stays inside it
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     int *bb = (int *)lds;  // slot 0: {ymin, ymax}
-
-    if (!LDS && spill_flags && !spill_flags[blockIdx.x]) return;
 
     const int tid = threadIdx.x;
     // Tiles: every depth plane (hw points) is cut into `bands` pieces of
@@ -293,8 +292,8 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
     // so one staged slab serves `planes` times as many volume bytes (the cur
     // rows are identical for every plane, the prev rows shift slowly with depth).
     const int batch = tg.batch;
-    const int b = blockIdx.x % batch;
-    int th = blockIdx.x / batch;
+    const int b = bid % batch;
+    int th = bid / batch;
     const int dgroup = th % tg.dgroups;
     th /= tg.dgroups;
     const int half = th & 1;
@@ -339,7 +338,12 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
             if (half) sweep_point_map<1>(g, fast, Pb, Pib, Tb, depths[d], hi, wi, sx, sy);
             else sweep_point_map<0>(g, fast, Pb, Pib, Tb, depths[d], hi, wi, sx, sy);
             int rN, rS, ix;
-            const uint32_t ok = footprint(sx, sy, H, W, rN, rS, ix, fw[j], fn[j]);
+            uint32_t ok = footprint(sx, sy, H, W, rN, rS, ix, fw[j], fn[j]);
+            // A tile starts at a multiple of 8 in the flat index, so its first vector can
+            // hold up to 7 points of the PREVIOUS depth plane (last image row) next to
+            // points of the first rows of this one: staging both would take the whole
+            // map.  The LDS pass writes zeros there; sweep_patch_kernel fills them in.
+            if (LDS && d != d_tile) ok = 0;
             qN[j] = rN * W + ix;
             qS[j] = rS * W + ix;
             okbits |= ok << (4 * j);
@@ -367,7 +371,6 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
         const int y0 = bb[0], y1 = bb[1];
         if (y1 < y0) {
             // no point of this tile lands inside the map: the volume is zero here
-            if (tid == 0) spill_flags[blockIdx.x] = 0;
             if (active) {
                 const u32x4_t z = {0u, 0u, 0u, 0u};
                 for (int c = blk_lo * CB; c < min(blk_hi * CB, g.C); ++c)
@@ -378,8 +381,11 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
         cnt = (y1 - y0 + 1) * W;  // pixels (16-B slots) to stage per block
         nslots = (PAD + cnt + 1 + 7) & ~7;
         const bool fits = SLAB + nslots <= lds_slots;
-        if (tid == 0) spill_flags[blockIdx.x] = fits ? 0 : 1;
-        if (!fits) return;
+        if (!fits) {
+            // rows beyond the LDS budget: queue the tile for the direct-tap pass
+            if (tid == 0) spill_list[1 + atomicAdd(&spill_list[0], 1)] = bid;
+            return;
+        }
         // LDS byte address of each corner: swizzled slot of pixel q (= index in
         // the staged rows + PAD), or the zero slot for an out-of-bounds corner.
         // Nothing in the channel loop depends on the in-bounds bits any more.
@@ -412,8 +418,8 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
     }
     const int wave = tid >> 6, lane = tid & 63;
     // debug trace: wave 0 of every 509th workgroup stamps its phases
-    unsigned long long *tr = (tg.trace && (blockIdx.x % 509) == 0 && tid == 0)
-                                 ? tg.trace + (size_t)(blockIdx.x / 509) * 64 : nullptr;
+    unsigned long long *tr = (LDS && tg.trace && (bid % 509) == 0 && tid == 0)
+                                 ? tg.trace + (size_t)(bid / 509) * 64 : nullptr;
     int tri = 0;
 #define TRACE_STAMP()                                                                       \
     do {                                                                                    \
@@ -547,6 +553,75 @@ __global__ __launch_bounds__(NT) void sweep_tile_kernel(
     }
 }
 
+#ifndef DFM_TILE_WAVES
+#define DFM_TILE_WAVES 1  // min waves/SIMD the LDS tile kernel is compiled for (1 = compiler's choice)
+#endif
+// one workgroup per tile; LDS == false is the "direct taps for every tile" mode
+template <typename T, int NT, bool LDS>
+__global__ __launch_bounds__(NT, (LDS ? DFM_TILE_WAVES : 1)) void sweep_tile_kernel(
+    SweepGeom g, SweepFast fast, TileGrid tg, int lds_slots, const uint4 *__restrict__ cur_blk,
+    const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
+    const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
+    T *__restrict__ out, int *__restrict__ spill_list)
+{
+    tile_body<T, NT, LDS>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk, depths, P, Pinv, Tm,
+                          out, spill_list);
+}
+
+// the tiles the LDS pass queued (spill_list[0] = count), a fixed small grid strides over them:
+// launching one mostly-empty workgroup per tile would cost ~0.5 ms for 26 k tiles
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void sweep_spill_kernel(
+    SweepGeom g, SweepFast fast, TileGrid tg, const uint4 *__restrict__ cur_blk,
+    const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
+    const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
+    T *__restrict__ out, int *__restrict__ spill_list)
+{
+    const int count = spill_list[0];
+    for (int i = blockIdx.x; i < count; i += gridDim.x)
+        tile_body<T, NT, false>(spill_list[1 + i], g, fast, tg, 0, cur_blk, prev_blk, depths, P,
+                                Pinv, Tm, out, nullptr);
+}
+
+// The <= 7 lattice points in front of every depth-plane boundary that the LDS pass
+// masked (see sweep_tile_kernel): direct taps, scalar stores.  grid = (D-1, 2, B),
+// block = 8 points x 32 channel-block lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void sweep_patch_kernel(
+    SweepGeom g, SweepFast fast, const uint4 *__restrict__ cur_blk,
+    const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
+    const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
+    T *__restrict__ out)
+{
+    constexpr int CB = elem<T>::CB;
+    const int d_next = blockIdx.x + 1;  // boundary in front of plane d_next
+    const int half = blockIdx.y, b = blockIdx.z;
+    const long long hw = (long long)g.h_out * g.w_out;
+    const long long edge = d_next * hw;
+    const long long n = (edge & ~7ll) + (threadIdx.x >> 5);
+    if (n >= edge) return;  // this boundary has fewer foreign points
+    const int d = d_next - 1;
+    const int rem = (int)(n - (long long)d * hw);
+    const int hi = rem / g.w_out, wi = rem - hi * g.w_out;
+    float sx, sy;
+    if (half) sweep_point_map<1>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, sx, sy);
+    else sweep_point_map<0>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, sx, sy);
+    const Tap t = make_tap(sx, sy, g.h_in, g.w_in);
+    const int HW = g.h_in * g.w_in;
+    const int i00 = t.iy * g.w_in + t.ix, i01 = i00 + t.dx;
+    const int i10 = i00 + t.dy * g.w_in, i11 = i10 + t.dx;
+    const uint4 *mb = (half ? prev_blk : cur_blk) + (size_t)b * g.nblk * HW;
+    T *o = out + ((size_t)b * 2 * g.C + (size_t)half * g.C) * g.N + n;
+    for (int blk = threadIdx.x & 31; blk < g.nblk; blk += 32) {
+        const uint4 *q = mb + (size_t)blk * HW;
+        float r[CB];
+        blend<CB>(t, q[i00], q[i01], q[i10], q[i11], r);
+#pragma unroll
+        for (int k = 0; k < CB; ++k)
+            if (blk * CB + k < g.C) o[(size_t)(blk * CB + k) * g.N] = elem<T>::store(r[k]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // backward: grad feats += scatter(grad_out * weights); grid (ceil(N/256), B)
 // ---------------------------------------------------------------------------
@@ -674,7 +749,8 @@ size_t flag_bytes(const dfm_sweep_desc *d)
     const long long hw = (long long)d->h_out * d->w_out;
     const long long bands = (hw + 7 + 64ll * V - 1) / (64ll * V);  // smallest tile (one wave per plane)
     const long long nblk = (d->channels + V - 1) / V;  // worst case: one block per group
-    return ((size_t)(bands * d->num_depths * 2 * d->batch * nblk) + 255) & ~(size_t)255;
+    // int32 counter + one int32 tile id per (worst-case) tile
+    return ((size_t)(1 + bands * d->num_depths * 2 * d->batch * nblk) * 4 + 255) & ~(size_t)255;
 }
 
 template <typename T>
@@ -731,8 +807,8 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
         }
         const long long nb = (long long)tg.bands * tg.dgroups * 2 * d->batch * groups;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
-        if ((size_t)nb > flag_bytes(d)) return fail(DFM_ERR_WORKSPACE, "flag area too small%s");
-        unsigned char *flags = (unsigned char *)ws + 2 * blocked_bytes(d);
+        if ((size_t)(nb + 1) * 4 > flag_bytes(d)) return fail(DFM_ERR_WORKSPACE, "spill list too small%s");
+        int *spill_list = (int *)((char *)ws + 2 * blocked_bytes(d));
         SweepFast fast;
         fast.scale_is_one = d->img_scale_factor == 1.0f;
         {
@@ -741,18 +817,32 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
             fast.fsf_pow2 = (m == 0.5f) && e > -60 && e < 60;
             fast.inv_fsf = 1.0f / d->feat_sample_factor;
         }
-        auto kern = nt == 128 ? sweep_tile_kernel<T, 128, true> : sweep_tile_kernel<T, 256, true>;
-        auto spill = nt == 128 ? sweep_tile_kernel<T, 128, false> : sweep_tile_kernel<T, 256, false>;
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    lds_bytes));
-        if (which == 2)
+        if (which == 2) {
+            auto kern = nt == 128   ? sweep_tile_kernel<T, 128, true>
+                        : nt == 256 ? sweep_tile_kernel<T, 256, true>
+                                    : sweep_tile_kernel<T, 512, true>;
+            auto spill = nt == 128   ? sweep_spill_kernel<T, 128>
+                         : nt == 256 ? sweep_spill_kernel<T, 256>
+                                     : sweep_spill_kernel<T, 512>;
+            HIP_TRY(hipFuncSetAttribute((const void *)kern,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            HIP_TRY(hipMemsetAsync(spill_list, 0, 4, st));
             hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nt), lds_bytes, st, g, fast, tg,
                                lds_bytes / 16, cur_blk, prev_blk, depths, P, Pinv, Tm, (T *)out,
-                               flags);
-        // flagged tiles (rows beyond the LDS budget), or all tiles for which == 3
-        hipLaunchKernelGGL(spill, dim3((unsigned)nb), dim3(nt), 16, st, g, fast, tg, 0, cur_blk,
-                           prev_blk, depths, P, Pinv, Tm, (T *)out,
-                           which == 2 ? flags : (unsigned char *)nullptr);
+                               spill_list);
+            // tiles whose rows exceeded the LDS budget (typically < 1 %)
+            hipLaunchKernelGGL(spill, dim3(512), dim3(nt), 16, st, g, fast, tg, cur_blk, prev_blk,
+                               depths, P, Pinv, Tm, (T *)out, spill_list);
+        } else {
+            auto direct = nt == 128   ? sweep_tile_kernel<T, 128, false>
+                          : nt == 256 ? sweep_tile_kernel<T, 256, false>
+                                      : sweep_tile_kernel<T, 512, false>;
+            hipLaunchKernelGGL(direct, dim3((unsigned)nb), dim3(nt), 16, st, g, fast, tg, 0, cur_blk,
+                               prev_blk, depths, P, Pinv, Tm, (T *)out, (int *)nullptr);
+        }
+        if (which == 2 && g.D > 1 && hw % 8 != 0)
+            hipLaunchKernelGGL(sweep_patch_kernel<T>, dim3(g.D - 1, 2, d->batch), dim3(256), 0, st,
+                               g, fast, cur_blk, prev_blk, depths, P, Pinv, Tm, (T *)out);
     }
     if (timed) {
         (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
@@ -777,10 +867,11 @@ DFM_API void dfm_debug_set_trace(void *buf) { g_trace = (unsigned long long *)bu
 DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int blocks_per_group,
                                  int planes_per_workgroup)
 {
-    if ((lanes_per_workgroup != 128 && lanes_per_workgroup != 256) || lds_kib < 4 ||
+    if ((lanes_per_workgroup != 128 && lanes_per_workgroup != 256 && lanes_per_workgroup != 512) ||
+        lds_kib < 4 ||
         lds_kib > 160 || blocks_per_group < 1 || planes_per_workgroup < 1)
         return fail(DFM_ERR_INVALID_ARG,
-                    "tune: lanes in {128,256}, 4 <= lds_kib <= 160, blocks_per_group >= 1, "
+                    "tune: lanes in {128,256,512}, 4 <= lds_kib <= 160, blocks_per_group >= 1, "
                     "planes_per_workgroup >= 1%s");
     g_lds_nt = lanes_per_workgroup;
     g_lds_kb = lds_kib;
