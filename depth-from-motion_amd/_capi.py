@@ -29,6 +29,9 @@ EXPORTS = (
     'dfm_point_sample_mv_fwd',
     'dfm_frustum_to_voxel_fwd',
     'dfm_depth_head_fwd',
+    'dfm_frustum_to_voxel_bwd',
+    'dfm_point_sample_mv_bwd',
+    'dfm_depth_head_bwd',
 )
 
 
@@ -135,6 +138,12 @@ def lib():
     h.dfm_frustum_to_voxel_fwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, vp, fp, fp, vp, vp]
     h.dfm_depth_head_fwd.restype = ctypes.c_int
     h.dfm_depth_head_fwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, vp]
+    h.dfm_frustum_to_voxel_bwd.restype = ctypes.c_int
+    h.dfm_frustum_to_voxel_bwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, fp, fp, fp, fp, vp]
+    h.dfm_point_sample_mv_bwd.restype = ctypes.c_int
+    h.dfm_point_sample_mv_bwd.argtypes = [mp, vp, fp, fp, fp, fp, vp]
+    h.dfm_depth_head_bwd.restype = ctypes.c_int
+    h.dfm_depth_head_bwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, fp, vp]
     _lib = h
     return h
 

@@ -129,3 +129,102 @@ DFM_API int dfm_depth_head_fwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// backward: gradients arriving on depth_volumes, softmax and depth_preds are
+// folded into one logit gradient per column
+//   gl[d] = g_vol[d] + p[d] * (s[d] - sum_k p[k] s[k]),  s[d] = g_soft[d] + g_pred * depth[d]
+// and scattered through the trilinear weights (fp32 atomics, zero-initialised).
+// Any of the three incoming gradients may be NULL.
+// ---------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void depth_head_bwd_kernel(
+    const T *__restrict__ in, int D, int H, int W, int s, const float *__restrict__ depth_samples,
+    const T *__restrict__ gvol, const T *__restrict__ gsoft, const T *__restrict__ gpred,
+    float *__restrict__ gin)
+{
+    const int Do = D * s, Ho = H * s, Wo = W * s;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (pix >= Ho * Wo) return;
+    const int h = pix / Wo, w = pix - h * Wo;
+    const UpIdx uh = up_index(h, H, Ho), uw = up_index(w, W, Wo);
+    const T *x = in + (size_t)b * D * H * W;
+    float *gx = gin + (size_t)b * D * H * W;
+    const int o00 = uh.i0 * W + uw.i0, o01 = uh.i0 * W + uw.i1;
+    const int o10 = uh.i1 * W + uw.i0, o11 = uh.i1 * W + uw.i1;
+    const size_t plane_o = (size_t)Ho * Wo;
+    const size_t col = (size_t)b * Do * plane_o + pix;
+    auto logit = [&](int d) {
+        const UpIdx ud = up_index(d, D, Do);
+        const T *p0 = x + (size_t)ud.i0 * H * W, *p1 = x + (size_t)ud.i1 * H * W;
+        const float a0 = lerp_fma(uw.w0, elem<T>::load(p0[o00]), uw.w1, elem<T>::load(p0[o01]));
+        const float b0 = lerp_fma(uw.w0, elem<T>::load(p0[o10]), uw.w1, elem<T>::load(p0[o11]));
+        const float a1 = lerp_fma(uw.w0, elem<T>::load(p1[o00]), uw.w1, elem<T>::load(p1[o01]));
+        const float b1 = lerp_fma(uw.w0, elem<T>::load(p1[o10]), uw.w1, elem<T>::load(p1[o11]));
+        return lerp_fma(ud.w0, lerp_fma(uh.w0, a0, uh.w1, b0), ud.w1, lerp_fma(uh.w0, a1, uh.w1, b1));
+    };
+    const bool soft_path = gsoft || gpred;
+    float mx = -INFINITY, sum = 0.0f, dotps = 0.0f;
+    const float gp = gpred ? elem<T>::load(gpred[(size_t)b * plane_o + pix]) : 0.0f;
+    if (soft_path) {
+        for (int d = 0; d < Do; ++d) mx = fmaxf(mx, logit(d));
+        for (int d = 0; d < Do; ++d) sum += expf(logit(d) - mx);
+        for (int d = 0; d < Do; ++d) {
+            const float p = expf(logit(d) - mx) / sum;
+            const float sd = (gsoft ? elem<T>::load(gsoft[col + (size_t)d * plane_o]) : 0.0f) +
+                             gp * depth_samples[d];
+            dotps += p * sd;
+        }
+    }
+    for (int d = 0; d < Do; ++d) {
+        float gl = gvol ? elem<T>::load(gvol[col + (size_t)d * plane_o]) : 0.0f;
+        if (soft_path) {
+            const float p = expf(logit(d) - mx) / sum;
+            const float sd = (gsoft ? elem<T>::load(gsoft[col + (size_t)d * plane_o]) : 0.0f) +
+                             gp * depth_samples[d];
+            gl += p * (sd - dotps);
+        }
+        if (gl == 0.0f) continue;
+        const UpIdx ud = up_index(d, D, Do);
+        float *g0 = gx + (size_t)ud.i0 * H * W, *g1 = gx + (size_t)ud.i1 * H * W;
+        const float c0 = gl * ud.w0, c1 = gl * ud.w1;
+        atomicAdd(g0 + o00, c0 * uh.w0 * uw.w0); atomicAdd(g0 + o01, c0 * uh.w0 * uw.w1);
+        atomicAdd(g0 + o10, c0 * uh.w1 * uw.w0); atomicAdd(g0 + o11, c0 * uh.w1 * uw.w1);
+        atomicAdd(g1 + o00, c1 * uh.w0 * uw.w0); atomicAdd(g1 + o01, c1 * uh.w0 * uw.w1);
+        atomicAdd(g1 + o10, c1 * uh.w1 * uw.w0); atomicAdd(g1 + o11, c1 * uh.w1 * uw.w1);
+    }
+}
+
+}  // namespace
+
+extern "C" DFM_API int dfm_depth_head_bwd(int32_t batch, int32_t d, int32_t h, int32_t w,
+                                          int32_t scale, int32_t dtype, const void *cost,
+                                          const float *depth_samples, const void *grad_volumes,
+                                          const void *grad_softmax, const void *grad_preds,
+                                          float *grad_cost, void *stream)
+{
+    if (batch <= 0 || d <= 0 || h <= 0 || w <= 0 || scale <= 0)
+        return set_error(DFM_ERR_INVALID_ARG, "non-positive size in dfm_depth_head_bwd");
+    if (dtype != DFM_F32 && dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!cost || !depth_samples || !grad_cost)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    const int npix = h * scale * w * scale;
+    dim3 grid((npix + 255) / 256, batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DFM_F32)
+        hipLaunchKernelGGL(depth_head_bwd_kernel<float>, grid, dim3(256), 0, st, (const float *)cost,
+                           d, h, w, scale, depth_samples, (const float *)grad_volumes,
+                           (const float *)grad_softmax, (const float *)grad_preds, grad_cost);
+    else
+        hipLaunchKernelGGL(depth_head_bwd_kernel<bf16_t>, grid, dim3(256), 0, st,
+                           (const bf16_t *)cost, d, h, w, scale, depth_samples,
+                           (const bf16_t *)grad_volumes, (const bf16_t *)grad_softmax,
+                           (const bf16_t *)grad_preds, grad_cost);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}

@@ -163,3 +163,93 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// backward of the sampling stage w.r.t. stereo_feat and cur_sem_feats (the depth
+// distribution is detached in the reference, feature_transformation.py:136).
+// One lane = one voxel; fp32 atomics into zero-initialised gradient tensors.
+// ---------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void f2v_bwd_kernel(F2vGeom g, const T *__restrict__ gout,
+                                                      const T *__restrict__ soft,
+                                                      const float *__restrict__ coords,
+                                                      const float *__restrict__ cam2img,
+                                                      float *__restrict__ gstereo,
+                                                      float *__restrict__ gsem)
+{
+    const long long N = (long long)g.Nz * g.Ny * g.Nx;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= N) return;
+    const float xs = coords[3 * i], ys = coords[3 * i + 1], zs = coords[3 * i + 2];
+    const float *P = cam2img + 16 * b;
+    const float a = dot4_chain(-ys, -zs, xs, 1.0f, P + 0);
+    const float bb = dot4_chain(-ys, -zs, xs, 1.0f, P + 4);
+    const float c = dot4_chain(-ys, -zs, xs, 1.0f, P + 8);
+    const float u = a / c, v = bb / c;
+    const bool valid2d = (u >= 0.0f) && (u <= g.pad_w) && (v >= 0.0f) && (v <= g.pad_h);
+    float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
+    float gz = (xs - g.depth_min) / g.depth_span;
+    gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
+    const bool valid = valid2d && gz >= -1.0f && gz <= 1.0f;
+    const T *go = gout + (size_t)b * (g.C + g.Cs) * N + i;
+    const size_t vol = (size_t)g.D * g.H * g.W;
+    if (valid) {
+        const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
+        float *gs = gstereo + (size_t)b * g.C * vol;
+        for (int ch = 0; ch < g.C; ++ch) {
+            const float gv = elem<T>::load(go[(size_t)ch * N]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (t.ok & (1u << k)) atomicAdd(gs + (size_t)ch * vol + t.o[k], gv * t.w[k]);
+        }
+    }
+    if (g.Cs > 0 && valid) {  // Voxel_2D = sample(sem) * valid2d * (disp * valid)
+        const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+        const float disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
+        const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
+        const size_t plane = (size_t)g.Hsem * g.Wsem;
+        float *gm = gsem + (size_t)b * g.Cs * plane;
+        for (int ch = 0; ch < g.Cs; ++ch) {
+            const float gv = elem<T>::load(go[(size_t)(g.C + ch) * N]) * disp;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t2.ok & (1u << k)) atomicAdd(gm + (size_t)ch * plane + t2.o[k], gv * t2.w[k]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const void *grad_out,
+                                                const void *softmax, const float *coords,
+                                                const float *cam2img, float *grad_stereo,
+                                                float *grad_sem, void *stream)
+{
+    if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
+    if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!grad_out || !coords || !cam2img || !grad_stereo || (d->sem_channels > 0 && (!grad_sem || !softmax)))
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    F2vGeom g;
+    g.C = d->channels; g.D = d->d; g.H = d->h; g.W = d->w;
+    g.Ds = d->ds; g.Hs = d->hs; g.Ws = d->ws;
+    g.Cs = d->sem_channels; g.Hsem = d->hsem; g.Wsem = d->wsem;
+    g.Nz = d->nz; g.Ny = d->ny; g.Nx = d->nx;
+    g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.depth_min = d->depth_min; g.depth_span = d->depth_span;
+    const long long N = (long long)d->nz * d->ny * d->nx;
+    dim3 grid((unsigned)((N + 255) / 256), d->batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == DFM_F32)
+        hipLaunchKernelGGL(f2v_bwd_kernel<float>, grid, dim3(256), 0, st, g, (const float *)grad_out,
+                           (const float *)softmax, coords, cam2img, grad_stereo, grad_sem);
+    else
+        hipLaunchKernelGGL(f2v_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, g,
+                           (const bf16_t *)grad_out, (const bf16_t *)softmax, coords, cam2img,
+                           grad_stereo, grad_sem);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}

@@ -72,14 +72,19 @@ namespace {
 // NCHW -> [B][nblk][H][W][CB]
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__ src,
-                                                           uint4 *__restrict__ dst, int C, int HW,
-                                                           int nblk)
+__global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__ src0,
+                                                           const T *__restrict__ src1,
+                                                           uint4 *__restrict__ dst0,
+                                                           uint4 *__restrict__ dst1, int batch,
+                                                           int C, int HW, int nblk)
 {
     constexpr int CB = elem<T>::CB;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     const int blk = blockIdx.y;
-    const int b = blockIdx.z;
+    const bool second = (int)blockIdx.z >= batch;  // z = [cur samples | prev samples]
+    const int b = second ? blockIdx.z - batch : blockIdx.z;
+    const T *__restrict__ src = second ? src1 : src0;
+    uint4 *__restrict__ dst = second ? dst1 : dst0;
     if (pix >= HW) return;
     T v[CB];
 #pragma unroll
@@ -708,7 +713,7 @@ int check_desc(const dfm_sweep_desc *d)
         return fail(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16%s");
     if ((long long)d->h_in * d->w_in >= (1ll << 31) / 64)
         return fail(DFM_ERR_UNSUPPORTED, "feature map too large for 32-bit tap offsets%s");
-    if (d->batch > 65535) return fail(DFM_ERR_UNSUPPORTED, "batch > 65535%s");
+    if (d->batch > 32767) return fail(DFM_ERR_UNSUPPORTED, "batch > 32767%s");
     return DFM_OK;
 }
 
@@ -762,11 +767,9 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
     const int HW = d->h_in * d->w_in;
     uint4 *cur_blk = (uint4 *)ws;
     uint4 *prev_blk = (uint4 *)((char *)ws + blocked_bytes(d));
-    dim3 pg((HW + 255) / 256, g.nblk, d->batch);
-    hipLaunchKernelGGL(pack_blocked_kernel<T>, pg, dim3(256), 0, st, (const T *)cur, cur_blk, g.C,
-                       HW, g.nblk);
-    hipLaunchKernelGGL(pack_blocked_kernel<T>, pg, dim3(256), 0, st, (const T *)prev, prev_blk,
-                       g.C, HW, g.nblk);
+    dim3 pg((HW + 255) / 256, g.nblk, 2 * d->batch);
+    hipLaunchKernelGGL(pack_blocked_kernel<T>, pg, dim3(256), 0, st, (const T *)cur, (const T *)prev,
+                       cur_blk, prev_blk, d->batch, g.C, HW, g.nblk);
     const bool timed = g_prof.on && g_prof.used + 2 <= (int)g_prof.ev.size();
     constexpr int V = elem<T>::CB;
     // the LDS kernel stores one aligned 16-byte vector of V points per channel:

@@ -253,3 +253,109 @@ DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *d, const void *feats, con
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// backward of the multi-view lifting w.r.t. the view features: every valid
+// (frame, view) tap receives grad_out / (number of valid views), fp32 atomics
+// into a zero-initialised (F*Nv, C, Hf, Wf) tensor.
+// ---------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void mv_sample_bwd_kernel(
+    MvGeom g, const T *__restrict__ gout, const float *__restrict__ points,
+    const float *__restrict__ proj, const float *__restrict__ ori_w, float *__restrict__ gfeats)
+{
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= g.N) return;
+    long long pidx = o;
+    if (g.nz > 0) {
+        const int z = (int)(o % g.nz);
+        const long long t = o / g.nz;
+        const int y = (int)(t % g.ny);
+        const int x = (int)(t / g.ny);
+        pidx = ((long long)z * g.ny + y) * g.nx + x;
+    }
+    const float px = points[3 * pidx], py = points[3 * pidx + 1], pz = points[3 * pidx + 2];
+    const int HW = g.Hf * g.Wf;
+    const size_t chan_stride = g.nz > 0 ? (size_t)g.N : 1;
+    const T *gbase = g.nz > 0 ? gout + o : gout + (size_t)o * g.C * (g.aggregate ? g.num_frames : 1);
+    int tot_cnt = 0;
+    for (int i = 0; i < g.num_views * g.num_frames; ++i) {
+        float nx, ny;
+        tot_cnt += project_view(g, proj + 16 * i, ori_w[i], px, py, pz, nx, ny) ? 1 : 0;
+    }
+    for (int f = 0; f < g.num_frames; ++f) {
+        int cnt = 0;
+        for (int v = 0; v < g.num_views; ++v) {
+            float nx, ny;
+            cnt += project_view(g, proj + 16 * (f * g.num_views + v), ori_w[f * g.num_views + v], px,
+                                py, pz, nx, ny) ? 1 : 0;
+        }
+        const float den = g.valid_sample ? (float)max(g.aggregate ? cnt : tot_cnt, 1) : 1.0f;
+        for (int v = 0; v < g.num_views; ++v) {
+            const int i = f * g.num_views + v;
+            float nx, ny;
+            const bool ok = project_view(g, proj + 16 * i, ori_w[i], px, py, pz, nx, ny);
+            if (g.valid_sample && !ok) continue;
+            const float x = ((nx + 1.0f) * 0.5f) * (float)(g.Wf - 1);
+            const float y = ((ny + 1.0f) * 0.5f) * (float)(g.Hf - 1);
+            float *gf = gfeats + (size_t)i * g.C * HW;
+            int idx[4];
+            float wt[4];
+            int ntap = 0;
+            if (g.mode == 0) {
+                const float xr = rintf(x), yr = rintf(y);
+                if ((fabsf(x) <= 3.0e38f) && (fabsf(y) <= 3.0e38f) && xr >= 0.0f &&
+                    xr <= (float)(g.Wf - 1) && yr >= 0.0f && yr <= (float)(g.Hf - 1)) {
+                    idx[0] = (int)yr * g.Wf + (int)xr; wt[0] = 1.0f; ntap = 1;
+                }
+            } else {
+                const Tap t = make_tap(x, y, g.Hf, g.Wf);
+                const int i00 = t.iy * g.Wf + t.ix, i01 = i00 + t.dx;
+                const int i10 = i00 + t.dy * g.Wf, i11 = i10 + t.dx;
+                if (t.ok & 1u) { idx[ntap] = i00; wt[ntap++] = t.nw; }
+                if (t.ok & 2u) { idx[ntap] = i01; wt[ntap++] = t.ne; }
+                if (t.ok & 4u) { idx[ntap] = i10; wt[ntap++] = t.sw; }
+                if (t.ok & 8u) { idx[ntap] = i11; wt[ntap++] = t.se; }
+            }
+            if (!ntap) continue;
+            for (int c = 0; c < g.C; ++c) {
+                const int co = g.aggregate ? f * g.C + c : c;
+                const float gv = elem<T>::load(gbase[(size_t)co * chan_stride]) / den;
+                for (int k = 0; k < ntap; ++k) atomicAdd(gf + (size_t)c * HW + idx[k], gv * wt[k]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" DFM_API int dfm_point_sample_mv_bwd(const dfm_mv_desc *d, const void *grad_out,
+                                               const float *points, const float *proj,
+                                               const float *ori_w, float *grad_feats, void *stream)
+{
+    if (!d) return fail_ps(DFM_ERR_INVALID_ARG, "desc is NULL");
+    if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
+        return fail_ps(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!grad_out || !points || !proj || !ori_w || !grad_feats)
+        return fail_ps(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    MvGeom g;
+    g.num_views = d->num_views; g.num_frames = d->num_frames; g.C = d->channels;
+    g.Hf = d->feat_h; g.Wf = d->feat_w; g.nblk = 0;
+    g.nx = d->nx; g.ny = d->ny; g.nz = d->nz; g.N = d->num_points;
+    g.scale_x = d->scale_x; g.scale_y = d->scale_y; g.crop_x = d->crop_x; g.crop_y = d->crop_y;
+    g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.flip = d->flip; g.mode = d->mode;
+    g.aggregate = d->aggregate; g.valid_sample = d->valid_sample;
+    const long long nb = (g.N + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == DFM_F32)
+        hipLaunchKernelGGL(mv_sample_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, g,
+                           (const float *)grad_out, points, proj, ori_w, grad_feats);
+    else
+        hipLaunchKernelGGL(mv_sample_bwd_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, g,
+                           (const bf16_t *)grad_out, points, proj, ori_w, grad_feats);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_ps(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}

@@ -11,6 +11,47 @@ from . import _capi
 from .plane_sweep import _DTYPES, _ptr, _require_gpu, _stream_ptr
 
 
+class _F2vFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, stereo, sem, soft, coords, cam4, desc):
+        lib = _capi.lib()
+        device = stereo.device
+        out = torch.empty((desc.batch, desc.channels + desc.sem_channels, desc.nz, desc.ny, desc.nx),
+                          dtype=stereo.dtype, device=device)
+        with torch.cuda.device(device):
+            _capi.check(
+                lib.dfm_frustum_to_voxel_fwd(ctypes.byref(desc), _ptr(stereo),
+                                             _ptr(soft) if soft is not None else None,
+                                             _ptr(sem) if sem is not None else None, _ptr(coords),
+                                             _ptr(cam4), _ptr(out), _stream_ptr(device)))
+        ctx.desc = desc
+        ctx.has_sem = sem is not None
+        ctx.shapes = (stereo.shape, None if sem is None else sem.shape, stereo.dtype)
+        ctx.save_for_backward(coords, cam4, *(() if soft is None else (soft,)))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        coords, cam4, *rest = ctx.saved_tensors
+        soft = rest[0] if rest else None
+        lib = _capi.lib()
+        desc = ctx.desc
+        st_shape, sem_shape, dtype = ctx.shapes
+        device = grad_out.device
+        go = grad_out.contiguous().to(dtype)
+        g_st = torch.zeros(st_shape, dtype=torch.float32, device=device)
+        g_sem = torch.zeros(sem_shape, dtype=torch.float32, device=device) if ctx.has_sem else None
+        with torch.cuda.device(device):
+            _capi.check(
+                lib.dfm_frustum_to_voxel_bwd(ctypes.byref(desc), _ptr(go),
+                                             _ptr(soft) if soft is not None else None, _ptr(coords),
+                                             _ptr(cam4), _ptr(g_st),
+                                             _ptr(g_sem) if g_sem is not None else None,
+                                             _stream_ptr(device)))
+        return g_st.to(dtype), (g_sem.to(dtype) if g_sem is not None else None), None, None, None, None
+
+
 def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem_feats,
                             coordinates_3d, depth_cfg):
     """
@@ -51,12 +92,4 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     cam4 = torch.eye(4).repeat(B, 1, 1)
     cam4[:, :cam.shape[1], :cam.shape[2]] = cam
     cam4 = cam4.reshape(B, 16).to(device)
-    out = torch.empty((B, C + desc.sem_channels, desc.nz, desc.ny, desc.nx), dtype=stereo.dtype,
-                      device=device)
-    with torch.cuda.device(device):
-        _capi.check(
-            lib.dfm_frustum_to_voxel_fwd(ctypes.byref(desc), _ptr(stereo),
-                                         _ptr(soft) if soft is not None else None,
-                                         _ptr(sem) if sem is not None else None, _ptr(coords),
-                                         _ptr(cam4), _ptr(out), _stream_ptr(device)))
-    return out
+    return _F2vFn.apply(stereo, sem, soft, coords, cam4, desc)

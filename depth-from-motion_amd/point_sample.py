@@ -68,20 +68,49 @@ def _launch(feats, points, proj, ori_w, nxyz, num_views, num_frames, scale, crop
     desc.aggregate = 1 if aggregate == 'concat' else 0
     desc.valid_sample = 1 if valid_sample else 0
     desc.dtype = _DTYPES[feats.dtype]
-    c_out = C * (num_frames if aggregate == 'concat' else 1)
-    if nxyz is not None:
-        out = torch.empty((c_out,) + tuple(nxyz), dtype=feats.dtype, device=device)
-    else:
-        out = torch.empty((points.shape[0], c_out), dtype=feats.dtype, device=device)
-    valid = torch.empty(points.shape[0], dtype=torch.uint8, device=device) if want_valid else None
-    nbytes = lib.dfm_point_sample_mv_workspace_bytes(ctypes.byref(desc))
-    ws = _Workspace.get(device, nbytes)
-    with torch.cuda.device(device):
-        _capi.check(
-            lib.dfm_point_sample_mv_fwd(ctypes.byref(desc), _ptr(feats), _ptr(points), _ptr(proj),
-                                        _ptr(ori_w), _ptr(out), _ptr(valid) if want_valid else None,
-                                        _ptr(ws), nbytes, _stream_ptr(device)))
-    return out, valid
+    return _MvFn.apply(feats, points, proj, ori_w, desc, nxyz, want_valid)
+
+
+class _MvFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, feats, points, proj, ori_w, desc, nxyz, want_valid):
+        lib = _capi.lib()
+        device = feats.device
+        c_out = desc.channels * (desc.num_frames if desc.aggregate else 1)
+        if nxyz is not None:
+            out = torch.empty((c_out,) + tuple(nxyz), dtype=feats.dtype, device=device)
+        else:
+            out = torch.empty((points.shape[0], c_out), dtype=feats.dtype, device=device)
+        valid = torch.empty(points.shape[0], dtype=torch.uint8, device=device) if want_valid else None
+        nbytes = lib.dfm_point_sample_mv_workspace_bytes(ctypes.byref(desc))
+        ws = _Workspace.get(device, nbytes)
+        with torch.cuda.device(device):
+            _capi.check(
+                lib.dfm_point_sample_mv_fwd(ctypes.byref(desc), _ptr(feats), _ptr(points), _ptr(proj),
+                                            _ptr(ori_w), _ptr(out),
+                                            _ptr(valid) if want_valid else None, _ptr(ws), nbytes,
+                                            _stream_ptr(device)))
+        ctx.desc = desc
+        ctx.meta = (feats.shape, feats.dtype)
+        ctx.save_for_backward(points, proj, ori_w)
+        if want_valid:
+            ctx.mark_non_differentiable(valid)
+        return out, valid
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_valid):
+        points, proj, ori_w = ctx.saved_tensors
+        lib = _capi.lib()
+        shape, dtype = ctx.meta
+        device = grad_out.device
+        go = grad_out.contiguous().to(dtype)
+        gf = torch.zeros(shape, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            _capi.check(
+                lib.dfm_point_sample_mv_bwd(ctypes.byref(ctx.desc), _ptr(go), _ptr(points), _ptr(proj),
+                                            _ptr(ori_w), _ptr(gf), _stream_ptr(device)))
+        return gf.to(dtype), None, None, None, None, None, None
 
 
 def point_sample(img_meta,

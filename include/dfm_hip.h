@@ -195,6 +195,11 @@ DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *desc, const void *feats,
                                     const float *points, const float *proj, const float *ori_w,
                                     void *out, unsigned char *valid, void *workspace,
                                     size_t workspace_bytes, void *stream);
+/* Backward w.r.t. the view features.  grad_out has the layout of `out`;
+ * grad_feats (F*Nv, C, feat_h, feat_w) is FP32, zero-filled by the caller. */
+DFM_API int dfm_point_sample_mv_bwd(const dfm_mv_desc *desc, const void *grad_out,
+                                    const float *points, const float *proj, const float *ori_w,
+                                    float *grad_feats, void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* FrustumToVoxel sampling stage                                           */
@@ -228,6 +233,14 @@ typedef struct dfm_f2v_desc {
 DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *desc, const void *stereo,
                                      const void *softmax, const void *sem, const float *coords,
                                      const float *cam2img, void *out, void *stream);
+/* Backward w.r.t. stereo_feat and cur_sem_feats (the depth distribution is
+ * detached in the reference, :136).  grad_out: (B, C+Cs, nz, ny, nx) dtype;
+ * grad_stereo (B,C,d,h,w) and grad_sem (B,Cs,hsem,wsem): FP32, zero-filled by
+ * the caller, accumulated with atomics. */
+DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *desc, const void *grad_out,
+                                     const void *softmax, const float *coords,
+                                     const float *cam2img, float *grad_stereo, float *grad_sem,
+                                     void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* DepthHead.forward (with_convs=False), dense_heads/depth_head.py:205-210  */
@@ -244,6 +257,12 @@ DFM_API int dfm_depth_head_fwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
                                int32_t dtype, const void *cost, const float *depth_samples,
                                void *depth_volumes, void *softmax, void *depth_preds,
                                void *stream);
+/* Backward: any of the three incoming gradients may be NULL; grad_cost
+ * (B,1,d,h,w) is FP32, zero-filled by the caller. */
+DFM_API int dfm_depth_head_bwd(int32_t batch, int32_t d, int32_t h, int32_t w, int32_t scale,
+                               int32_t dtype, const void *cost, const float *depth_samples,
+                               const void *grad_volumes, const void *grad_softmax,
+                               const void *grad_preds, float *grad_cost, void *stream);
 
 #ifdef __cplusplus
 }
