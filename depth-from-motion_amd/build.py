@@ -33,17 +33,23 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force=False, verbose=False):
-    """Compile every csrc/*.hip into lib/libdfm_hip.so. Returns the path."""
-    if not force and not _stale():
+def build_hip(force=False, verbose=False, debug_hooks=False, out=None):
+    """Compile every csrc/*.hip into lib/libdfm_hip.so. Returns the path.
+
+    debug_hooks=True adds -DDFM_DEBUG_HOOKS: the DFM_ABLATE switches and the
+    per-phase s_memtime trace of the tile kernel (tools/trace_phases.py).  They
+    are compiled out by default -- even never-taken runtime branches in the
+    blend loop changed hipcc's schedule by up to 25 % (profiles/r01_v8_*)."""
+    out = out or LIB
+    if not force and out == LIB and not _stale():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + sources() + \
-        ['-o', LIB]
+    cmd = [HIPCC] + FLAGS + (['-DDFM_DEBUG_HOOKS'] if debug_hooks else []) + \
+        ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + sources() + ['-o', out]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == '__main__':

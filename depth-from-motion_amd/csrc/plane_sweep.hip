@@ -423,9 +423,16 @@ __device__ __forceinline__ void tile_body(
     }
     const int wave = tid >> 6, lane = tid & 63;
     // debug trace: wave 0 of every 509th workgroup stamps its phases
+#ifdef DFM_DEBUG_HOOKS
     unsigned long long *tr = (LDS && tg.trace && (bid % 509) == 0 && tid == 0)
                                  ? tg.trace + (size_t)(bid / 509) * 64 : nullptr;
     int tri = 0;
+#endif
+#ifndef DFM_DEBUG_HOOKS
+#define TRACE_STAMP() do {} while (0)
+#define ABLATE(bit) false
+#else
+#define ABLATE(bit) ((tg.ablate & (bit)) != 0)
 #define TRACE_STAMP()                                                                       \
     do {                                                                                    \
         if (tr && tri < 64) {                                                               \
@@ -434,13 +441,14 @@ __device__ __forceinline__ void tile_body(
             tr[tri++] = t_;                                                                 \
         }                                                                                   \
     } while (0)
+#endif
     TRACE_STAMP();
 
     // blend the V points x CB channels of one channel block and store them
     auto compute_store = [&](int blk, const uint4 *gsrc) {
         const int cbase = blk * CB;
         uint32_t pk[CB][4];  // per channel: one 16-byte vector of V points
-        if (tg.ablate & 4) {
+        if (ABLATE(4)) {
 #pragma unroll
             for (int k = 0; k < CB; ++k)
 #pragma unroll
@@ -514,7 +522,7 @@ __device__ __forceinline__ void tile_body(
         TRACE_STAMP();
 #pragma unroll
         for (int k = 0; k < CB; ++k) {
-            if (cbase + k < g.C && (!(tg.ablate & 2) || pk[k][0] == 0x12345u)) {
+            if (cbase + k < g.C && (!ABLATE(2) || pk[k][0] == 0x12345u)) {
                 u32x4_t v = {pk[k][0], pk[k][1], pk[k][2], pk[k][3]};
                 __builtin_nontemporal_store(v, (u32x4_t *)(o + (size_t)(cbase + k) * g.N));
             }
@@ -532,7 +540,7 @@ __device__ __forceinline__ void tile_body(
         // so the swizzle goes on the SOURCE pixel).  A global_load -> ds_write
         // variant measured 2x slower and cost 20 VGPRs (r01 profiles).
         auto stage = [&](int buf_slot0, const uint4 *gsrc) {
-            if (tg.ablate & 1) return;
+            if (ABLATE(1)) return;
             for (int s0 = wave * 64; s0 < nslots; s0 += NT) {
                 const int p = swz(s0 + lane) - PAD;
                 if (p >= 0 && p < cnt)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Per-phase s_memtime trace of the tile kernel (debug hook dfm_debug_set_trace).
-usage: python tools/trace_phases.py [lanes lds_kib planes]   (N* workload, B=8)"""
+usage: python tools/trace_phases.py [lanes lds_kib planes]   (N* workload, B=8)
+Needs a debug build:  python -c "import importlib; b=importlib.import_module('depth-from-motion_amd.build'); b.build_hip(force=True, debug_hooks=True, out='/tmp/libdfm_dbg.so')"
+and DFM_HIP_LIB=/tmp/libdfm_dbg.so."""
 import ctypes, importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
