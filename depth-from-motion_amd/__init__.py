@@ -16,8 +16,9 @@ from .plane_sweep import build_dfm_cost, plane_sweep_grid  # noqa: F401
 from .depth_head import depth_head_forward  # noqa: F401
 from .geometry import prepare_coordinates_3d, prepare_depth  # noqa: F401
 from .frustum_to_voxel import frustum_to_voxel_sample  # noqa: F401
-from .point_sample import mv_feature_transformation, point_sample, voxel_centers  # noqa: F401
+from .point_sample import (mv_feature_transformation, point_sample, voxel_centers,  # noqa: F401
+                           voxel_sample)
 
 __all__ = ['build_dfm_cost', 'plane_sweep_grid', 'point_sample', 'mv_feature_transformation',
-           'voxel_centers', 'frustum_to_voxel_sample', 'depth_head_forward', 'prepare_depth',
+           'voxel_centers', 'voxel_sample', 'frustum_to_voxel_sample', 'depth_head_forward', 'prepare_depth',
            'prepare_coordinates_3d']

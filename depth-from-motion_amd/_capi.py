@@ -32,6 +32,7 @@ EXPORTS = (
     'dfm_frustum_to_voxel_bwd',
     'dfm_point_sample_mv_bwd',
     'dfm_depth_head_bwd',
+    'dfm_voxel_sample_fwd',
 )
 
 
@@ -90,6 +91,18 @@ class F2vDesc(ctypes.Structure):
                         ] + [('dtype', ctypes.c_int32)]
 
 
+class VsDesc(ctypes.Structure):
+    """struct dfm_vs_desc"""
+    _fields_ = [('channels', ctypes.c_int32), ('nx', ctypes.c_int32), ('ny', ctypes.c_int32),
+                ('nz', ctypes.c_int32), ('num_depths', ctypes.c_int32), ('h_out', ctypes.c_int32),
+                ('w_out', ctypes.c_int32), ('downsample_factor', ctypes.c_float),
+                ('scale_x', ctypes.c_float), ('scale_y', ctypes.c_float), ('crop_x', ctypes.c_float),
+                ('crop_y', ctypes.c_float), ('flip', ctypes.c_int32), ('ori_w', ctypes.c_float),
+                ('voxel_range', ctypes.c_float * 6), ('voxel_size', ctypes.c_float * 3),
+                ('proj_inv', ctypes.c_float * 16), ('mode', ctypes.c_int32),
+                ('dtype', ctypes.c_int32)]
+
+
 class DfmHipError(RuntimeError):
     pass
 
@@ -144,6 +157,8 @@ def lib():
     h.dfm_point_sample_mv_bwd.argtypes = [mp, vp, fp, fp, fp, fp, vp]
     h.dfm_depth_head_bwd.restype = ctypes.c_int
     h.dfm_depth_head_bwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, fp, vp]
+    h.dfm_voxel_sample_fwd.restype = ctypes.c_int
+    h.dfm_voxel_sample_fwd.argtypes = [ctypes.POINTER(VsDesc), vp, fp, vp, vp]
     _lib = h
     return h
 

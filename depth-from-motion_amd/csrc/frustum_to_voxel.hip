@@ -253,3 +253,95 @@ extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const voi
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
 }
+
+// ---------------------------------------------------------------------------
+// voxel_sample: the inverse op (voxel volume -> frustum), reference
+// mmdet3d/models/fusion_layers/point_fusion.py:324-410.  One lane = one lattice
+// point (w fastest); same trilinear arithmetic as above, or nearest.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct VsGeom {
+    int32_t C, Nx, Ny, Nz, D, h_out, w_out, flip, mode;
+    float ds, scale_x, scale_y, crop_x, crop_y, ori_w;
+    float range[6], vsize[3], Minv[16];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void voxel_sample_kernel(VsGeom g, const T *__restrict__ vox,
+                                                           const float *__restrict__ depths,
+                                                           T *__restrict__ out)
+{
+    const long long N = (long long)g.D * g.h_out * g.w_out;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int w = (int)(i % g.w_out), h = (int)((i / g.w_out) % g.h_out);
+    const int d = (int)(i / ((long long)g.w_out * g.h_out));
+    float x = (float)w * g.ds, y = (float)h * g.ds;
+    const float depth = depths[d];
+    if (g.flip) x = g.ori_w - x;
+    x = x + g.crop_x; y = y + g.crop_y;
+    x = x / g.scale_x; y = y / g.scale_y;
+    const float h0 = x * depth, h1 = y * depth;
+    float gr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float X = dot4_chain(h0, h1, depth, 1.0f, g.Minv + 4 * k);
+        const float gsz = (g.range[3 + k] - g.range[k]) / g.vsize[k];
+        const float v = (X - g.range[k]) / g.vsize[k] - 0.5f;
+        gr[k] = v / gsz * 2.0f - 1.0f;
+    }
+    const size_t vol = (size_t)g.Nx * g.Ny * g.Nz;
+    if (g.mode) {
+        const Tri t = make_tri(gr[2], gr[1], gr[0], g.Nx, g.Ny, g.Nz);
+        for (int c = 0; c < g.C; ++c)
+            out[(size_t)c * N + i] = elem<T>::store(tri_sample<T>(t, vox + c * vol));
+    } else {
+        const float ix = ((gr[2] + 1.0f) / 2.0f) * (float)(g.Nz - 1);
+        const float iy = ((gr[1] + 1.0f) / 2.0f) * (float)(g.Ny - 1);
+        const float iz = ((gr[0] + 1.0f) / 2.0f) * (float)(g.Nx - 1);
+        const float xr = rintf(ix), yr = rintf(iy), zr = rintf(iz);
+        const bool in = fabsf(ix) <= 1.0e9f && fabsf(iy) <= 1.0e9f && fabsf(iz) <= 1.0e9f &&
+                        xr >= 0.0f && xr <= (float)(g.Nz - 1) && yr >= 0.0f &&
+                        yr <= (float)(g.Ny - 1) && zr >= 0.0f && zr <= (float)(g.Nx - 1);
+        const int o = in ? ((int)zr * g.Ny + (int)yr) * g.Nz + (int)xr : 0;
+        for (int c = 0; c < g.C; ++c)
+            out[(size_t)c * N + i] = in ? vox[c * vol + o] : T(0);
+    }
+}
+
+}  // namespace
+
+extern "C" DFM_API int dfm_voxel_sample_fwd(const dfm_vs_desc *d, const void *voxel_features,
+                                            const float *depths, void *out, void *stream)
+{
+    if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
+    if (d->channels <= 0 || d->nx <= 0 || d->ny <= 0 || d->nz <= 0 || d->num_depths <= 0 ||
+        d->h_out <= 0 || d->w_out <= 0)
+        return set_error(DFM_ERR_INVALID_ARG, "non-positive size in dfm_vs_desc");
+    if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!voxel_features || !depths || !out) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if ((long long)d->nx * d->ny * d->nz >= (1ll << 31))
+        return set_error(DFM_ERR_UNSUPPORTED, "volume too large for 32-bit corner offsets");
+    VsGeom g;
+    g.C = d->channels; g.Nx = d->nx; g.Ny = d->ny; g.Nz = d->nz;
+    g.D = d->num_depths; g.h_out = d->h_out; g.w_out = d->w_out;
+    g.flip = d->flip; g.mode = d->mode; g.ds = d->downsample_factor;
+    g.scale_x = d->scale_x; g.scale_y = d->scale_y; g.crop_x = d->crop_x; g.crop_y = d->crop_y;
+    g.ori_w = d->ori_w;
+    for (int k = 0; k < 6; ++k) g.range[k] = d->voxel_range[k];
+    for (int k = 0; k < 3; ++k) g.vsize[k] = d->voxel_size[k];
+    for (int k = 0; k < 16; ++k) g.Minv[k] = d->proj_inv[k];
+    const long long N = (long long)d->num_depths * d->h_out * d->w_out;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == DFM_F32)
+        hipLaunchKernelGGL(voxel_sample_kernel<float>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+                           st, g, (const float *)voxel_features, depths, (float *)out);
+    else
+        hipLaunchKernelGGL(voxel_sample_kernel<bf16_t>, dim3((unsigned)((N + 255) / 256)), dim3(256),
+                           0, st, g, (const bf16_t *)voxel_features, depths, (bf16_t *)out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}

@@ -177,3 +177,62 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
                          True, False)
         vols.append(out)
     return torch.stack(vols)
+
+
+def voxel_sample(voxel_features,
+                 voxel_range,
+                 voxel_size,
+                 depth_samples,
+                 proj_mat,
+                 downsample_factor,
+                 img_scale_factor,
+                 img_crop_offset,
+                 img_flip,
+                 img_pad_shape,
+                 img_shape,
+                 aligned=True,
+                 padding_mode='zeros',
+                 align_corners=True,
+                 proj_inv=None):
+    """Drop-in for the reference ``voxel_sample`` (point_fusion.py:324-410):
+    (1, C, Nx, Ny, Nz) voxel features -> (1, C, D, H_out, W_out) frustum features.
+
+    ``proj_inv`` (extension): a precomputed fp32 inverse of ``proj_mat``.  By default
+    it is taken with torch.inverse on the host like the reference does
+    (utils.py:241); for a general 4x4 LAPACK's result can differ in the last bits
+    between CPU models, so bit-exact replays of a fixture pass the stored inverse."""
+    if padding_mode != 'zeros' or not align_corners:
+        raise NotImplementedError('only padding_mode="zeros", align_corners=True')
+    _require_gpu(voxel_features, 'voxel_features')
+    assert voxel_features.dim() == 5 and voxel_features.shape[0] == 1
+    lib = _capi.lib()
+    device = voxel_features.device
+    vox = voxel_features.contiguous()
+    depths = torch.as_tensor(depth_samples, dtype=torch.float32)[::downsample_factor]
+    depths = depths.to(device).contiguous()
+    desc = _capi.VsDesc()
+    desc.channels, desc.nx, desc.ny, desc.nz = vox.shape[1:]
+    desc.num_depths = depths.numel()
+    desc.h_out = round(img_pad_shape[0] / downsample_factor)
+    desc.w_out = round(img_pad_shape[1] / downsample_factor)
+    desc.downsample_factor = float(downsample_factor)
+    desc.scale_x, desc.scale_y = _scale_xy(img_scale_factor)
+    desc.crop_x, desc.crop_y = _crop_xy(img_crop_offset)
+    desc.flip, desc.ori_w = (1 if img_flip else 0), float(img_shape[1])
+    for i, v in enumerate(np.asarray(voxel_range, dtype=np.float32).reshape(6)):
+        desc.voxel_range[i] = float(v)
+    for i, v in enumerate(np.asarray(voxel_size, dtype=np.float32).reshape(3)):
+        desc.voxel_size[i] = float(v)
+    inv = torch.as_tensor(proj_inv, dtype=torch.float32) if proj_inv is not None else \
+        torch.inverse(torch.as_tensor(proj_mat, dtype=torch.float32).detach().cpu())  # utils.py:241
+    for i, v in enumerate(inv.reshape(16).tolist()):
+        desc.proj_inv[i] = v
+    desc.mode = 1 if aligned else 0
+    desc.dtype = _DTYPES[vox.dtype]
+    out = torch.empty((1, desc.channels, desc.num_depths, desc.h_out, desc.w_out), dtype=vox.dtype,
+                      device=device)
+    with torch.cuda.device(device):
+        _capi.check(
+            lib.dfm_voxel_sample_fwd(ctypes.byref(desc), _ptr(vox), _ptr(depths), _ptr(out),
+                                     _stream_ptr(device)))
+    return out

@@ -243,6 +243,29 @@ DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *desc, const void *grad_
                                      void *stream);
 
 /* ---------------------------------------------------------------------- */
+/* voxel_sample (voxel volume -> frustum), point_fusion.py:324-410          */
+/* ---------------------------------------------------------------------- */
+typedef struct dfm_vs_desc {
+    int32_t channels;        /* C of voxel_features (1, C, nx, ny, nz)           */
+    int32_t nx, ny, nz;
+    int32_t num_depths;      /* len(depth_samples[::downsample_factor])         */
+    int32_t h_out, w_out;    /* round(img_pad_shape / downsample_factor)        */
+    float downsample_factor;
+    float scale_x, scale_y, crop_x, crop_y;
+    int32_t flip;
+    float ori_w;             /* img_shape[1]                                    */
+    float voxel_range[6];
+    float voxel_size[3];
+    float proj_inv[16];      /* fp32 inverse of the 4x4 lidar2img (utils.py:241) */
+    int32_t mode;            /* 1 trilinear (aligned), 0 nearest                */
+    int32_t dtype;
+} dfm_vs_desc;
+
+/* voxel_features (1,C,nx,ny,nz), depths (num_depths) fp32 -> out (1,C,D,h_out,w_out) */
+DFM_API int dfm_voxel_sample_fwd(const dfm_vs_desc *desc, const void *voxel_features,
+                                 const float *depths, void *out, void *stream);
+
+/* ---------------------------------------------------------------------- */
 /* DepthHead.forward (with_convs=False), dense_heads/depth_head.py:205-210  */
 /* ---------------------------------------------------------------------- */
 /*

@@ -464,6 +464,69 @@ ORACLE_API void dfm_oracle_depth_head(const float *in, int D, int H, int W, int 
         }
 }
 
+/* ------------------------------------------------------------------------ */
+/* voxel_sample: mmdet3d/models/fusion_layers/point_fusion.py:324-410        */
+/* frustum lattice -> LiDAR (points_img2cam with the inverse of lidar2img)    */
+/* -> voxel index -> normalised (z,y,x) grid -> 3-D grid_sample of the        */
+/* (C, Nx, Ny, Nz) voxel volume.  mode 1 trilinear (aligned), 0 nearest.      */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t C, Nx, Ny, Nz;     /* voxel_features (1, C, Nx, Ny, Nz)            */
+    int32_t D, h_out, w_out;   /* output lattice                               */
+    float ds;                  /* downsample_factor                            */
+    float scale_x, scale_y, crop_x, crop_y;
+    int32_t flip;
+    float ori_w;
+    float range[6];            /* voxel_range                                  */
+    float vsize[3];            /* voxel_size                                   */
+    int32_t mode;
+    float Minv[16];            /* torch.inverse(proj_mat), row major           */
+} dfm_oracle_vs_params;
+
+static inline float nearest3(const float *vol, int D, int H, int W, float gx, float gy, float gz)
+{
+    const float ix = unnormalize_ac(gx, W), iy = unnormalize_ac(gy, H), iz = unnormalize_ac(gz, D);
+    if (!isfinite(ix) || !isfinite(iy) || !isfinite(iz)) return 0.0f;
+    if (fabsf(ix) > 1e9f || fabsf(iy) > 1e9f || fabsf(iz) > 1e9f) return 0.0f;
+    const int64_t x = (int64_t)nearbyintf(ix), y = (int64_t)nearbyintf(iy), z = (int64_t)nearbyintf(iz);
+    if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) return vol[((size_t)z * H + y) * W + x];
+    return 0.0f;
+}
+
+/* depths: the D plane depths actually used (depth_samples[::downsample_factor]) */
+ORACLE_API void dfm_oracle_voxel_sample(const dfm_oracle_vs_params *p, const float *vox,
+                                        const float *depths, float *out)
+{
+    const int64_t N = (int64_t)p->D * p->h_out * p->w_out;
+    const size_t vol = (size_t)p->Nx * p->Ny * p->Nz;
+    /* grid_size = (range[3:] - range[:3]) / voxel_size, fp32 tensor ops (:393) */
+    float gsz[3];
+    for (int k = 0; k < 3; ++k) gsz[k] = (p->range[3 + k] - p->range[k]) / p->vsize[k];
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        const int w = (int)(i % p->w_out), h = (int)((i / p->w_out) % p->h_out);
+        const int d = (int)(i / ((int64_t)p->w_out * p->h_out));
+        float x = (float)w * p->ds, y = (float)h * p->ds; /* :371-372 */
+        const float depth = depths[d];
+        if (p->flip) x = p->ori_w - x;                    /* :380-384 */
+        x = x + p->crop_x; y = y + p->crop_y;             /* :385 */
+        x = x / p->scale_x; y = y / p->scale_y;           /* :386 */
+        const float homo[4] = {x * depth, y * depth, depth, 1.0f};
+        float X[3];
+        for (int k = 0; k < 3; ++k) X[k] = dot4_chain(homo, p->Minv + 4 * k); /* points_img2cam */
+        float g[3];
+        for (int k = 0; k < 3; ++k) {
+            float v = (X[k] - p->range[k]) / p->vsize[k] - 0.5f; /* :392 */
+            g[k] = v / gsz[k] * 2.0f - 1.0f;                      /* :395 */
+        }
+        /* :397 (x,y,z) -> (z,y,x): grid x indexes Nz, grid z indexes Nx */
+        for (int c = 0; c < p->C; ++c)
+            out[(size_t)c * N + i] =
+                p->mode ? trilinear(vox + c * vol, p->Nx, p->Ny, p->Nz, g[2], g[1], g[0])
+                        : nearest3(vox + c * vol, p->Nx, p->Ny, p->Nz, g[2], g[1], g[0]);
+    }
+}
+
 ORACLE_API int dfm_oracle_version(void) { return 1; }
 
 #ifdef _OPENMP

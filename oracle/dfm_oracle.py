@@ -224,6 +224,45 @@ def depth_head(stereo_features, depth_samples, scale=4):
     return vol, soft, pred
 
 
+class VSParams(ctypes.Structure):
+    """struct dfm_oracle_vs_params"""
+    _fields_ = [('C', ctypes.c_int32), ('Nx', ctypes.c_int32), ('Ny', ctypes.c_int32),
+                ('Nz', ctypes.c_int32), ('D', ctypes.c_int32), ('h_out', ctypes.c_int32),
+                ('w_out', ctypes.c_int32), ('ds', ctypes.c_float), ('scale_x', ctypes.c_float),
+                ('scale_y', ctypes.c_float), ('crop_x', ctypes.c_float), ('crop_y', ctypes.c_float),
+                ('flip', ctypes.c_int32), ('ori_w', ctypes.c_float), ('range', ctypes.c_float * 6),
+                ('vsize', ctypes.c_float * 3), ('mode', ctypes.c_int32),
+                ('Minv', ctypes.c_float * 16)]
+
+
+def voxel_sample(voxel_features, voxel_range, voxel_size, depth_samples, proj_inv,
+                 downsample_factor, scale=(1.0, 1.0), crop=(0.0, 0.0), flip=False,
+                 img_pad_shape=(1, 1), img_shape=(1, 1), aligned=True):
+    """(1,C,Nx,Ny,Nz) -> (1,C,D,h_out,w_out); reference point_fusion.py:324-410.
+    proj_inv = torch.inverse(proj_mat) in fp32 (utils.py:241)."""
+    vox = _f32(voxel_features)[0]
+    p = VSParams()
+    p.C, p.Nx, p.Ny, p.Nz = vox.shape
+    depths = _f32(depth_samples)[::int(downsample_factor)].copy()
+    p.D = depths.size
+    p.h_out = round(img_pad_shape[0] / downsample_factor)
+    p.w_out = round(img_pad_shape[1] / downsample_factor)
+    p.ds = float(downsample_factor)
+    p.scale_x, p.scale_y = float(scale[0]), float(scale[1])
+    p.crop_x, p.crop_y = float(crop[0]), float(crop[1])
+    p.flip, p.ori_w = int(bool(flip)), float(img_shape[1])
+    for i, v in enumerate(_f32(voxel_range)):
+        p.range[i] = float(v)
+    for i, v in enumerate(_f32(voxel_size)):
+        p.vsize[i] = float(v)
+    p.mode = 1 if aligned else 0
+    for i, v in enumerate(_f32(proj_inv).reshape(16)):
+        p.Minv[i] = float(v)
+    out = np.empty((p.C, p.D, p.h_out, p.w_out), np.float32)
+    lib().dfm_oracle_voxel_sample(ctypes.byref(p), _vp(vox), _vp(depths), _vp(out))
+    return out[None]
+
+
 def bf16_round(a):
     """fp32 -> bf16 (round-to-nearest-even) -> fp32, numpy."""
     u = _f32(a).view(np.uint32)

@@ -63,7 +63,7 @@ def load_reference():
     extract(REF + 'core/bbox/structures/utils.py', ['points_cam2img', 'points_img2cam'], g)
     extract(REF + 'models/backbones/dfm_backbone.py', ['build_dfm_cost'], g)
     g['apply_3d_transformation'] = lambda pts, coord_type, img_meta, reverse=False: pts
-    extract(REF + 'models/fusion_layers/point_fusion.py', ['point_sample'], g)
+    extract(REF + 'models/fusion_layers/point_fusion.py', ['point_sample', 'voxel_sample'], g)
     extract_method(REF + 'models/detectors/multiview_dfm.py', 'MultiViewDfM',
                    'feature_transformation', g, rename='mv_feature_transformation')
     extract_method(REF + 'core/anchor/anchor_3d_generator.py', 'AlignedAnchor3DRangeGenerator',
@@ -379,6 +379,28 @@ def make_modules():
     print('modules:', {k: v.shape for k, v in out.items()})
 
 
+def make_voxel_sample(g):
+    gen = torch.Generator().manual_seed(600)
+    vox = torch.randn(1, 5, 22, 30, 4, generator=gen)
+    rng_, vsz = [-11.0, -15.0, -2.0, 11.0, 15.0, 2.0], [1.0, 1.0, 1.0]
+    cam = torch.from_numpy(waymo_like_cameras(1, 1, 7)[0])
+    depth_samples = torch.tensor([1.0 + 0.5 * k for k in range(24)])
+    out = {}
+    for tag, kw in (('plain', dict(img_scale_factor=torch.tensor([1.0, 1.0]),
+                                   img_crop_offset=torch.tensor([0.0, 0.0]), img_flip=False)),
+                    ('aug', dict(img_scale_factor=torch.tensor([0.95, 1.05]),
+                                 img_crop_offset=torch.tensor([3.0, 2.0]), img_flip=True))):
+        for aligned in (True, False):
+            o = g['voxel_sample'](vox, rng_, vsz, depth_samples, cam, 4, img_pad_shape=(104, 156),
+                                  img_shape=(100, 150), aligned=aligned, **kw)
+            out[f'out_{tag}_{"tri" if aligned else "near"}'] = o.numpy()
+    np.savez_compressed(os.path.join(HERE, 'voxel_sample.npz'), vox=vox.numpy(),
+                        voxel_range=np.asarray(rng_, np.float32), voxel_size=np.asarray(vsz, np.float32),
+                        depth_samples=depth_samples.numpy(), proj=cam.numpy(),
+                        proj_inv=torch.inverse(cam).numpy(), **out)
+    print('voxel_sample', {k: (v.shape, float((v != 0).mean())) for k, v in out.items()})
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference not mounted; fixtures are committed, nothing to do')
@@ -387,6 +409,7 @@ if __name__ == '__main__':
     make_sweep(ref)
     make_helpers(ref)
     make_mv(ref)
+    make_voxel_sample(ref)
     make_f2v()
     make_depth_head()
     make_modules()

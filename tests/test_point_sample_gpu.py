@@ -113,3 +113,28 @@ def test_waymo_shape_sub_volume_vs_oracle(pkg):
     assert got.shape == ref.shape
     assert np.array_equal(util.bits(got), util.bits(ref))
     assert (ref != 0).mean() > 0.2
+
+
+@pytest.mark.parametrize('aligned', [True, False])
+@pytest.mark.parametrize('tag,kw', [('plain', dict(scale=(1.0, 1.0), crop=(0.0, 0.0), flip=False)),
+                                    ('aug', dict(scale=(0.95, 1.05), crop=(3.0, 2.0), flip=True))])
+def test_voxel_sample_bitexact_vs_reference_fixture(pkg, tag, kw, aligned):
+    z = np.load(os.path.join(util.GOLDEN, 'voxel_sample.npz'))
+    out = pkg.voxel_sample(torch.from_numpy(z['vox']).cuda(), z['voxel_range'], z['voxel_size'],
+                           torch.from_numpy(z['depth_samples']), torch.from_numpy(z['proj']), 4,
+                           torch.tensor(kw['scale']), torch.tensor(kw['crop']), kw['flip'],
+                           (104, 156), (100, 150), aligned=aligned,
+                           proj_inv=torch.from_numpy(z['proj_inv']))  # inverse taken where the fixture was made
+    ref = z[f'out_{tag}_{"tri" if aligned else "near"}']
+    assert np.array_equal(util.bits(out.cpu().numpy()), util.bits(ref))
+
+
+def test_voxel_sample_with_host_inverse_is_close(pkg):
+    """default path: the inverse is recomputed on this host (LAPACK may differ in the last
+    bits from the machine that made the fixture) -> rtol 1e-4 like the reference's own tests"""
+    z = np.load(os.path.join(util.GOLDEN, 'voxel_sample.npz'))
+    out = pkg.voxel_sample(torch.from_numpy(z['vox']).cuda(), z['voxel_range'], z['voxel_size'],
+                           torch.from_numpy(z['depth_samples']), torch.from_numpy(z['proj']), 4,
+                           torch.tensor([1.0, 1.0]), torch.tensor([0.0, 0.0]), False, (104, 156),
+                           (100, 150), aligned=True)
+    np.testing.assert_allclose(out.cpu().numpy(), z['out_plain_tri'], rtol=1e-4, atol=1e-5)

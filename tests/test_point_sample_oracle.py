@@ -65,3 +65,18 @@ def test_helper_golden_vectors_of_the_reference_tests():
             rows.append(acc)
         out[i] = [rows[0] / rows[2], rows[1] / rows[2]]
     assert np.array_equal(util.bits(out), util.bits(z['cam2img_out']))
+
+
+VS_CASES = [('plain', dict(scale=(1.0, 1.0), crop=(0.0, 0.0), flip=False)),
+            ('aug', dict(scale=(0.95, 1.05), crop=(3.0, 2.0), flip=True))]
+
+
+@pytest.mark.parametrize('aligned', [True, False])
+@pytest.mark.parametrize('tag,kw', VS_CASES)
+def test_voxel_sample_oracle_bitexact_vs_reference(tag, kw, aligned):
+    z = np.load(os.path.join(util.GOLDEN, 'voxel_sample.npz'))
+    out = orc.voxel_sample(z['vox'], z['voxel_range'], z['voxel_size'], z['depth_samples'],
+                           z['proj_inv'], 4, img_pad_shape=(104, 156), img_shape=(100, 150),
+                           aligned=aligned, **kw)
+    ref = z[f'out_{tag}_{"tri" if aligned else "near"}']
+    assert np.array_equal(util.bits(out), util.bits(ref))
