@@ -33,6 +33,9 @@ EXPORTS = (
     'dfm_point_sample_mv_bwd',
     'dfm_depth_head_bwd',
     'dfm_voxel_sample_fwd',
+    'dfm_group_norm_workspace_bytes',
+    'dfm_group_norm_fwd',
+    'dfm_group_norm_bwd',
 )
 
 
@@ -159,6 +162,14 @@ def lib():
     h.dfm_depth_head_bwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, fp, vp]
     h.dfm_voxel_sample_fwd.restype = ctypes.c_int
     h.dfm_voxel_sample_fwd.argtypes = [ctypes.POINTER(VsDesc), vp, fp, vp, vp]
+    i64, f32 = ctypes.c_int64, ctypes.c_float
+    h.dfm_group_norm_workspace_bytes.restype = sz
+    h.dfm_group_norm_workspace_bytes.argtypes = [i32, i32, i64, i32]
+    h.dfm_group_norm_fwd.restype = ctypes.c_int
+    h.dfm_group_norm_fwd.argtypes = [i32, i32, i64, i32, f32, i32, i32, vp, fp, fp, vp, fp, fp, vp, sz, vp]
+    h.dfm_group_norm_bwd.restype = ctypes.c_int
+    h.dfm_group_norm_bwd.argtypes = [i32, i32, i64, i32, i32, i32, vp, vp, vp, fp, fp, fp, vp, fp, fp, vp, sz,
+                                     vp]
     _lib = h
     return h
 

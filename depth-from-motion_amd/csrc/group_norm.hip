@@ -1,0 +1,383 @@
+// group_norm.hip -- fused GroupNorm (+ReLU) for the cost-volume aggregation
+// stacks (gfx950).
+//
+// Reference: every Conv3d of DfMBackbone / hourglass / FrustumToVoxel is
+// followed by GroupNorm(32, C) [+ ReLU] (dfm_backbone.py:50-66,118-128,
+// utils/conv_modules.py:27-43, feature_transformation.py:55-62 via mmcv's
+// ConvModule).  With C = 32 that is a per-channel normalisation over the whole
+// (D,H,W) volume.  torch's kernel runs it at ~0.26 TB/s
+// (1.8 ms at 72x80x320, more than the bf16 convolution in front of it:
+// profiles/r01_miopen_conv3d_baseline.txt); it is a pure HBM-bound
+// reduction + elementwise op.
+//
+// Layout: NC(D)HW contiguous: the elements of group g of sample n are ONE
+// contiguous range of L = (C/G)*S elements.
+//   gn_stats_kernel : grid (splits, N*G); each block reduces a slice with
+//                     16-byte loads to (count, mean, M2) -- Welford/Chan
+//                     merges, no E[x^2]-E[x]^2 cancellation -- and writes a
+//                     partial.
+//   gn_apply_kernel : grid (splits, N*G); merges the partials of its group
+//                     (tiny), then y = (x-mean)*rstd*gamma[c]+beta[c], ReLU
+//                     optional, 16-byte loads/stores.  Saves mean / rstd.
+//   backward        : gn_bwd_stats (sums of dy*gamma and dy*gamma*xhat per
+//                     group, dgamma/dbeta per channel) + gn_bwd_apply.
+// Traffic: 2 reads + 1 write of the tensor (the stats read is L2/MALL-warm
+// right after the convolution).  Bound: HBM.
+#include "dfm_common.h"
+
+using namespace dfm;
+
+namespace {
+
+struct Moments {
+    float n, mean, m2;
+};
+
+__device__ __forceinline__ Moments merge(const Moments &a, const Moments &b)
+{
+    if (b.n == 0.0f) return a;
+    if (a.n == 0.0f) return b;
+    Moments r;
+    r.n = a.n + b.n;
+    const float delta = b.mean - a.mean;
+    const float f = b.n / r.n;
+    r.mean = a.mean + delta * f;
+    r.m2 = a.m2 + b.m2 + delta * delta * a.n * f;
+    return r;
+}
+
+__device__ __forceinline__ Moments wave_merge(Moments m)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Moments other;
+        other.n = __shfl_xor(m.n, o);
+        other.mean = __shfl_xor(m.mean, o);
+        other.m2 = __shfl_xor(m.m2, o);
+        m = merge(m, other);
+    }
+    return m;
+}
+
+template <typename T> struct vec16;
+template <> struct vec16<float> { static constexpr int N = 4; };
+template <> struct vec16<bf16_t> { static constexpr int N = 8; };
+
+template <typename T>
+__device__ __forceinline__ void load16(const T *p, float (&f)[vec16<T>::N])
+{
+    const uint4 q = *(const uint4 *)p;
+    unpack16(q, f);
+}
+
+template <typename T>
+__device__ __forceinline__ void store16(T *p, const float (&f)[vec16<T>::N])
+{
+    if constexpr (sizeof(T) == 4) {
+        *(uint4 *)p = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
+                                 __float_as_uint(f[3]));
+    } else {
+        *(uint4 *)p = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                                 pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+    }
+}
+
+// block-level merge of per-thread moments -> thread 0 holds the result
+__device__ __forceinline__ Moments block_merge(Moments m, Moments *sh)
+{
+    m = wave_merge(m);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Moments r = sh[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = merge(r, sh[w]);
+        sh[0] = r;
+    }
+    __syncthreads();
+    return sh[0];
+}
+
+// slice [lo, hi) of the group's L elements handled by split `s` (multiples of VEC)
+__device__ __forceinline__ void slice_of(long long L, int splits, int s, int vec, long long &lo,
+                                         long long &hi)
+{
+    const long long nvec = (L + vec - 1) / vec;
+    const long long per = (nvec + splits - 1) / splits;
+    lo = min((long long)s * per * vec, L);
+    hi = min(lo + per * vec, L);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T *__restrict__ x, long long L,
+                                                       int splits, float *__restrict__ partial)
+{
+    constexpr int VEC = vec16<T>::N;
+    __shared__ Moments sh[4];
+    const int grp = blockIdx.y, s = blockIdx.x;
+    const T *xg = x + (size_t)grp * L;
+    long long lo, hi;
+    slice_of(L, splits, s, VEC, lo, hi);
+    Moments m = {0.0f, 0.0f, 0.0f};
+    const bool aligned = (((uintptr_t)xg) & 15) == 0;
+    for (long long i = lo + (long long)threadIdx.x * VEC; i < hi; i += 256ll * VEC) {
+        float f[VEC];
+        int cnt = VEC;
+        if (aligned && i + VEC <= hi) {
+            load16<T>(xg + i, f);
+        } else {
+            cnt = (int)min((long long)VEC, hi - i);
+            for (int k = 0; k < VEC; ++k) f[k] = k < cnt ? elem<T>::load(xg[i + k]) : 0.0f;
+        }
+        // moments of the (<= VEC) values, merged into the running ones
+        float sm = 0.0f;
+        for (int k = 0; k < cnt; ++k) sm += f[k];
+        Moments v;
+        v.n = (float)cnt;
+        v.mean = sm / v.n;
+        v.m2 = 0.0f;
+        for (int k = 0; k < cnt; ++k) v.m2 += (f[k] - v.mean) * (f[k] - v.mean);
+        m = merge(m, v);
+    }
+    m = block_merge(m, sh);
+    if (threadIdx.x == 0) {
+        float *p = partial + ((size_t)grp * splits + s) * 3;
+        p[0] = m.n; p[1] = m.mean; p[2] = m.m2;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T *__restrict__ x, long long L,
+                                                       long long spatial, int cpg, int groups,
+                                                       int splits, float eps,
+                                                       const float *__restrict__ partial,
+                                                       const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, int relu,
+                                                       T *__restrict__ y, float *__restrict__ mean_out,
+                                                       float *__restrict__ rstd_out)
+{
+    constexpr int VEC = vec16<T>::N;
+    const int grp = blockIdx.y, s = blockIdx.x;
+    __shared__ float stat[2];
+    if (threadIdx.x == 0) {
+        Moments r = {0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < splits; ++k) {
+            const float *p = partial + ((size_t)grp * splits + k) * 3;
+            Moments v = {p[0], p[1], p[2]};
+            r = merge(r, v);
+        }
+        const float var = r.m2 / r.n;  // biased, like torch
+        stat[0] = r.mean;
+        stat[1] = 1.0f / sqrtf(var + eps);
+        if (s == 0) { mean_out[grp] = stat[0]; rstd_out[grp] = stat[1]; }
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    const int c0 = (grp % groups) * cpg;
+    const T *xg = x + (size_t)grp * L;
+    T *yg = y + (size_t)grp * L;
+    long long lo, hi;
+    slice_of(L, splits, s, VEC, lo, hi);
+    const bool aligned = ((((uintptr_t)xg) | ((uintptr_t)yg)) & 15) == 0 && spatial % VEC == 0;
+    for (long long i = lo + (long long)threadIdx.x * VEC; i < hi; i += 256ll * VEC) {
+        if (aligned && i + VEC <= hi) {
+            float f[VEC];
+            load16<T>(xg + i, f);
+            const int c = c0 + (int)(i / spatial);  // a vector never straddles channels
+            const float a = rstd * gamma[c], b = beta[c] - mean * a;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float v = f[k] * a + b;
+                f[k] = relu ? fmaxf(v, 0.0f) : v;
+            }
+            store16<T>(yg + i, f);
+        } else {
+            for (long long k = i; k < min(i + VEC, hi); ++k) {
+                const int c = c0 + (int)(k / spatial);
+                const float a = rstd * gamma[c], b = beta[c] - mean * a;
+                float v = elem<T>::load(xg[k]) * a + b;
+                yg[k] = elem<T>::store(relu ? fmaxf(v, 0.0f) : v);
+            }
+        }
+    }
+}
+
+// backward stats: per (n, channel) sums of dy' and dy'*xhat where dy' = dy (masked by y > 0
+// when relu); grid (splits, N*C); partial[(nc*splits + s)*2 + {0,1}]
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T *__restrict__ dy,
+                                                           const T *__restrict__ x,
+                                                           const T *__restrict__ y, long long spatial,
+                                                           int C, int cpg, int splits, int relu,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ rstd,
+                                                           float *__restrict__ partial)
+{
+    __shared__ float sh[2][4];
+    const int nc = blockIdx.y, s = blockIdx.x;
+    const int n = nc / C, c = nc % C, grp = n * (C / cpg) + c / cpg;
+    const float mu = mean[grp], rs = rstd[grp];
+    const size_t base = (size_t)nc * spatial;
+    const long long per = (spatial + splits - 1) / splits;
+    const long long lo = min((long long)s * per, spatial), hi = min(lo + per, spatial);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        float g = elem<T>::load(dy[base + i]);
+        if (relu && !(elem<T>::load(y[base + i]) > 0.0f)) g = 0.0f;
+        const float xh = (elem<T>::load(x[base + i]) - mu) * rs;
+        s1 += g;
+        s2 += g * xh;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wave] = s1; sh[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float *p = partial + ((size_t)nc * splits + s) * 2;
+        p[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        p[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
+}
+
+// dx = rstd * (gamma*dy' - (A + xhat*B)/L) with A = sum_group gamma*dy', B = sum_group gamma*dy'*xhat
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
+    const T *__restrict__ dy, const T *__restrict__ x, const T *__restrict__ y, long long spatial,
+    int C, int cpg, int splits, int relu, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gamma,
+    const float *__restrict__ partial, T *__restrict__ dx, float *__restrict__ dgamma,
+    float *__restrict__ dbeta)
+{
+    __shared__ float ab[2];
+    const int nc = blockIdx.y, s = blockIdx.x;
+    const int n = nc / C, c = nc % C, g0 = (c / cpg) * cpg, grp = n * (C / cpg) + c / cpg;
+    if (threadIdx.x == 0) {
+        float A = 0.0f, B = 0.0f;
+        for (int cc = g0; cc < g0 + cpg; ++cc) {
+            float a = 0.0f, b = 0.0f;
+            for (int k = 0; k < splits; ++k) {
+                const float *p = partial + ((size_t)(n * C + cc) * splits + k) * 2;
+                a += p[0]; b += p[1];
+            }
+            A += gamma[cc] * a; B += gamma[cc] * b;
+            if (cc == c && s == 0) { atomicAdd(dbeta + c, a); atomicAdd(dgamma + c, b); }
+        }
+        ab[0] = A; ab[1] = B;
+    }
+    __syncthreads();
+    const float mu = mean[grp], rs = rstd[grp], gm = gamma[c];
+    const float invL = 1.0f / ((float)cpg * (float)spatial);
+    const float A = ab[0] * invL, B = ab[1] * invL;
+    const size_t base = (size_t)nc * spatial;
+    const long long per = (spatial + splits - 1) / splits;
+    const long long lo = min((long long)s * per, spatial), hi = min(lo + per, spatial);
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        float g = elem<T>::load(dy[base + i]);
+        if (relu && !(elem<T>::load(y[base + i]) > 0.0f)) g = 0.0f;
+        const float xh = (elem<T>::load(x[base + i]) - mu) * rs;
+        dx[base + i] = elem<T>::store(rs * (gm * g - A - xh * B));
+    }
+}
+
+int pick_splits(long long L)
+{
+    long long s = L / (256 * 16 * 8);  // >= 8 vectors per thread
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" {
+
+DFM_API size_t dfm_group_norm_workspace_bytes(int32_t n, int32_t c, int64_t spatial, int32_t groups)
+{
+    if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups) return 0;
+    // forward partials (N*G*splits*3) and backward partials (N*C*splits*2), splits <= 256
+    const size_t fw = (size_t)n * groups * 256 * 3, bw = (size_t)n * c * 256 * 2;
+    return ((fw > bw ? fw : bw) * sizeof(float) + 255) & ~(size_t)255;
+}
+
+DFM_API int dfm_group_norm_fwd(int32_t n, int32_t c, int64_t spatial, int32_t groups, float eps,
+                               int32_t dtype, int32_t relu, const void *x, const float *gamma,
+                               const float *beta, void *y, float *mean, float *rstd,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups)
+        return set_error(DFM_ERR_INVALID_ARG, "bad sizes in dfm_group_norm_fwd");
+    if (dtype != DFM_F32 && dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!x || !gamma || !beta || !y || !mean || !rstd || !workspace)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (workspace_bytes < dfm_group_norm_workspace_bytes(n, c, spatial, groups))
+        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_group_norm_workspace_bytes");
+    if ((long long)n * groups > 65535) return set_error(DFM_ERR_UNSUPPORTED, "n*groups > 65535");
+    const int cpg = c / groups;
+    const long long L = (long long)cpg * spatial;
+    const int splits = pick_splits(L);
+    dim3 grid(splits, n * groups);
+    hipStream_t st = (hipStream_t)stream;
+    float *partial = (float *)workspace;
+    if (dtype == DFM_F32) {
+        hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, st, (const float *)x, L, splits,
+                           partial);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, st, (const float *)x, L,
+                           (long long)spatial, cpg, groups, splits, eps, partial, gamma, beta, relu,
+                           (float *)y, mean, rstd);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, L,
+                           splits, partial);
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, L,
+                           (long long)spatial, cpg, groups, splits, eps, partial, gamma, beta, relu,
+                           (bf16_t *)y, mean, rstd);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+DFM_API int dfm_group_norm_bwd(int32_t n, int32_t c, int64_t spatial, int32_t groups, int32_t dtype,
+                               int32_t relu, const void *grad_y, const void *x, const void *y,
+                               const float *mean, const float *rstd, const float *gamma,
+                               void *grad_x, float *grad_gamma, float *grad_beta, void *workspace,
+                               size_t workspace_bytes, void *stream)
+{
+    if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups)
+        return set_error(DFM_ERR_INVALID_ARG, "bad sizes in dfm_group_norm_bwd");
+    if (dtype != DFM_F32 && dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!grad_y || !x || (relu && !y) || !mean || !rstd || !gamma || !grad_x || !grad_gamma ||
+        !grad_beta || !workspace)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (workspace_bytes < dfm_group_norm_workspace_bytes(n, c, spatial, groups))
+        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_group_norm_workspace_bytes");
+    if ((long long)n * c > 65535) return set_error(DFM_ERR_UNSUPPORTED, "n*c > 65535");
+    const int cpg = c / groups;
+    const int splits = pick_splits(spatial);
+    dim3 grid(splits, n * c);
+    hipStream_t st = (hipStream_t)stream;
+    float *partial = (float *)workspace;
+    if (dtype == DFM_F32) {
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, grid, dim3(256), 0, st, (const float *)grad_y,
+                           (const float *)x, (const float *)y, (long long)spatial, c, cpg, splits, relu,
+                           mean, rstd, partial);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float *)grad_y,
+                           (const float *)x, (const float *)y, (long long)spatial, c, cpg, splits, relu,
+                           mean, rstd, gamma, partial, (float *)grad_x, grad_gamma, grad_beta);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, grid, dim3(256), 0, st,
+                           (const bf16_t *)grad_y, (const bf16_t *)x, (const bf16_t *)y,
+                           (long long)spatial, c, cpg, splits, relu, mean, rstd, partial);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st,
+                           (const bf16_t *)grad_y, (const bf16_t *)x, (const bf16_t *)y,
+                           (long long)spatial, c, cpg, splits, relu, mean, rstd, gamma, partial,
+                           (bf16_t *)grad_x, grad_gamma, grad_beta);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+}  // extern "C"

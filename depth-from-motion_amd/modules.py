@@ -21,6 +21,7 @@ from torch import nn
 
 from .depth_head import depth_head_forward
 from .frustum_to_voxel import frustum_to_voxel_sample
+from .group_norm import HipGroupNorm
 from .plane_sweep import build_dfm_cost
 from .registry import register_module
 
@@ -34,7 +35,7 @@ def _make_norm(norm_cfg, channels):
     kind = cfg.pop('type')
     trainable = cfg.pop('requires_grad', True)
     if kind == 'GN':
-        name, layer = 'gn', nn.GroupNorm(num_channels=channels, **cfg)
+        name, layer = 'gn', HipGroupNorm(num_channels=channels, **cfg)
     elif kind == 'BN3d':
         name, layer = 'bn', nn.BatchNorm3d(channels, **cfg)
     elif kind in ('BN', 'BN2d'):
@@ -68,7 +69,10 @@ class ConvModule(nn.Module):
     def forward(self, x):
         x = self.conv(x)
         if self.norm_name is not None:
-            x = getattr(self, self.norm_name)(x)
+            norm = getattr(self, self.norm_name)
+            if isinstance(norm, HipGroupNorm):
+                return norm(x, relu=self.activate is not None)  # GN and ReLU in one pass
+            x = norm(x)
         if self.activate is not None:
             x = self.activate(x)
         return x
@@ -84,7 +88,7 @@ def _conv3(cin, cout, norm_cfg, act=True, stride=1, padding=1):
 # --------------------------------------------------------------------------
 def _convgn3d(cin, cout, stride):
     return nn.Sequential(nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False),
-                         nn.GroupNorm(32, cout))
+                         HipGroupNorm(32, cout))
 
 
 class hourglass(nn.Module):  # noqa: N801  (reference class name)
@@ -100,10 +104,10 @@ class hourglass(nn.Module):  # noqa: N801  (reference class name)
         self.conv4 = nn.Sequential(_convgn3d(2 * c, 2 * c, 1), nn.ReLU(inplace=True))
         self.conv5 = nn.Sequential(
             nn.ConvTranspose3d(2 * c, 2 * c, 3, padding=1, output_padding=1, stride=2, bias=False),
-            nn.GroupNorm(32, 2 * c))
+            HipGroupNorm(32, 2 * c))
         self.conv6 = nn.Sequential(
             nn.ConvTranspose3d(2 * c, c, 3, padding=1, output_padding=1, stride=2, bias=False),
-            nn.GroupNorm(32, c))
+            HipGroupNorm(32, c))
 
     def forward(self, x, presqu, postsqu):
         down1 = self.conv1(x)

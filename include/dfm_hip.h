@@ -287,6 +287,33 @@ DFM_API int dfm_depth_head_bwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
                                const void *grad_volumes, const void *grad_softmax,
                                const void *grad_preds, float *grad_cost, void *stream);
 
+/* ---------------------------------------------------------------------- */
+/* fused GroupNorm (+ReLU) of the aggregation stacks                        */
+/* mmcv ConvModule(conv -> GN -> ReLU) at dfm_backbone.py:50-66,118-128,     */
+/* feature_transformation.py:55-62; convbn_3d at utils/conv_modules.py:27-43 */
+/* ---------------------------------------------------------------------- */
+DFM_API size_t dfm_group_norm_workspace_bytes(int32_t n, int32_t c, int64_t spatial,
+                                              int32_t groups);
+/*
+ * x, y      : (n, c, spatial) contiguous (NC(D)HW), dtype              [device]
+ * gamma,beta: (c) fp32 affine parameters                               [device]
+ * mean,rstd : (n*groups) fp32, written (saved for backward)            [device]
+ * y = (x - mean_g) * rstd_g * gamma_c + beta_c, then max(y, 0) if relu != 0;
+ * biased variance, rstd = 1/sqrt(var + eps) (torch.nn.GroupNorm semantics).
+ */
+DFM_API int dfm_group_norm_fwd(int32_t n, int32_t c, int64_t spatial, int32_t groups, float eps,
+                               int32_t dtype, int32_t relu, const void *x, const float *gamma,
+                               const float *beta, void *y, float *mean, float *rstd,
+                               void *workspace, size_t workspace_bytes, void *stream);
+/* grad_gamma / grad_beta: (c) fp32, zero-filled by the caller; `y` is only
+ * read when relu != 0 (mask y > 0). */
+DFM_API int dfm_group_norm_bwd(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                               int32_t dtype, int32_t relu, const void *grad_y, const void *x,
+                               const void *y, const float *mean, const float *rstd,
+                               const float *gamma, void *grad_x, float *grad_gamma,
+                               float *grad_beta, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

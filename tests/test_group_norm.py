@@ -1,0 +1,73 @@
+"""Fused GroupNorm(+ReLU): GPU forward/backward against torch's CPU GroupNorm
+(the op the reference modules run).  Tolerance rtol 1e-4 / atol 1e-5 (different
+reduction order; both fp32); bf16 storage: one bf16 ulp on top."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    return importlib.import_module('depth-from-motion_amd')
+
+
+def test_cpu_path_is_plain_groupnorm(pkg):
+    m = pkg.HipGroupNorm(4, 8)
+    x = torch.randn(2, 8, 3, 5, 7)
+    assert torch.equal(m(x), F.group_norm(x, 4, m.weight, m.bias, m.eps))
+    assert torch.equal(m(x, relu=True), F.relu(F.group_norm(x, 4, m.weight, m.bias, m.eps)))
+    assert list(m.state_dict()) == ['weight', 'bias']
+
+
+CASES = [(2, 32, (8, 12, 20), 32), (1, 32, (9, 7, 13), 32), (3, 16, (6, 10), 4), (1, 64, (18, 20, 40), 32),
+         (2, 8, (5, 3, 3), 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('n,c,sp,groups', CASES)
+def test_forward_backward_vs_torch_cpu(pkg, n, c, sp, groups, relu):
+    gen = torch.Generator().manual_seed(n * 100 + c)
+    x = torch.randn(n, c, *sp, generator=gen) * 2 + 0.7
+    w = 1 + 0.2 * torch.randn(c, generator=gen)
+    b = 0.3 * torch.randn(c, generator=gen)
+    gy = torch.randn(n, c, *sp, generator=gen)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.group_norm(xr, groups, wr, br, 1e-5)
+    ref = F.relu(ref) if relu else ref
+    (ref * gy).sum().backward()
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    out = pkg.group_norm(xg, groups, wg, bg, 1e-5, relu)
+    (out * gy.cuda()).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(wg.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_config_k_volume_and_large_mean(pkg):
+    """(1,32,72,80,320), per-channel groups, a large common offset (variance must not cancel)"""
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 32, 72, 80, 320, generator=gen) + 100.0
+    m = pkg.HipGroupNorm(32, 32).cuda()
+    y = m(x.cuda(), relu=False)
+    flat = y.float().reshape(32, -1)
+    assert float(flat.mean(1).abs().max()) < 1e-3
+    assert float((flat.var(1, unbiased=False) - 1).abs().max()) < 1e-3
+    ref = F.group_norm(x[:, :2], 2, None, None, 1e-5)
+    np.testing.assert_allclose(y[:, :2].detach().cpu().numpy(), ref.numpy(), rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_bf16_storage(pkg):
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 32, 6, 8, 16, generator=gen).bfloat16()
+    m = pkg.HipGroupNorm(32, 32).cuda()
+    y = m(x.cuda(), relu=True)
+    assert y.dtype == torch.bfloat16
+    ref = F.relu(F.group_norm(x.float(), 32, m.weight.cpu(), m.bias.cpu(), 1e-5))
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.detach().numpy(), rtol=1e-2, atol=1e-2)
