@@ -70,4 +70,4 @@ def test_bf16_storage(pkg):
     y = m(x.cuda(), relu=True)
     assert y.dtype == torch.bfloat16
     ref = F.relu(F.group_norm(x.float(), 32, m.weight.cpu(), m.bias.cpu(), 1e-5))
-    np.testing.assert_allclose(y.float().cpu().numpy(), ref.detach().numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.detach().numpy(), rtol=1e-2, atol=1e-2)
