@@ -42,7 +42,7 @@ KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0
                      [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
 
 # secondary workloads (other rows of SURVEY.md 8a), reported with the same JSON shape
-SECONDARY = ('waymo', 'depth_head', 'f2v')
+SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm')
 
 WORKLOADS = {
     # name: B, C, H, W, D, fsf, csf, crop, dtype
@@ -150,6 +150,16 @@ def secondary(args, pkg, dev, rank, world):
             return pkg.depth_head_forward(x, ds)
         nbytes = B * 4 * (72 * 80 * 320 + 2 * 288 * 320 * 1280 + 320 * 1280)
         name, unit = 'DepthHead.forward (1,72,80,320)->2x(288,320,1280)+map, fp32', 'depth-volumes/s'
+    elif args.workload == 'group_norm':
+        B = 8
+        x = (torch.randn(B, 32, 72, 80, 320, generator=gen) + 0.5).to(dev)
+        m = pkg.HipGroupNorm(32, 32).to(dev)
+
+        def step():
+            with torch.no_grad():
+                return m(x, relu=True)
+        nbytes = B * 4 * 2 * 32 * 72 * 80 * 320
+        name, unit = 'fused GroupNorm(32,32)+ReLU on (32,72,80,320) fp32 (in + out bytes)', 'volumes/s'
     else:
         B, C, D, H, W = 8, 32, 72, 80, 320
         stereo = torch.randn(B, C, D, H, W, generator=gen).to(dev)
