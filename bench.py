@@ -216,6 +216,8 @@ def main():
     ap.add_argument('--lds-kib', type=int, default=0, help='LDS kernel KiB/workgroup')
     ap.add_argument('--bpg', type=int, default=0, help='LDS kernel channel blocks per group')
     ap.add_argument('--planes', type=int, default=0, help='LDS kernel depth planes per workgroup')
+    ap.add_argument('--band-chunk', type=int, default=0,
+                    help='LDS kernel: adjacent bands scheduled back to back (default 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass')
@@ -240,6 +242,9 @@ def main():
     if args.lanes or args.lds_kib or args.bpg or args.planes:
         pkg._capi.check(lib.dfm_plane_sweep_tune(args.lanes or 256, args.lds_kib or 52,
                                                  args.bpg or (1 << 20), args.planes or 2))
+
+    if args.band_chunk:
+        pkg._capi.check(lib.dfm_plane_sweep_schedule(args.band_chunk))
 
     if args.workload in SECONDARY:
         return secondary(args, pkg, dev, rank, world)

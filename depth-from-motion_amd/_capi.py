@@ -25,6 +25,7 @@ EXPORTS = (
     'dfm_plane_sweep_last_kernel',
     'dfm_plane_sweep_force_kernel',
     'dfm_plane_sweep_tune',
+    'dfm_plane_sweep_schedule',
     'dfm_point_sample_mv_workspace_bytes',
     'dfm_point_sample_mv_fwd',
     'dfm_frustum_to_voxel_fwd',
@@ -145,6 +146,8 @@ def lib():
     h.dfm_plane_sweep_force_kernel.argtypes = [ctypes.c_int]
     h.dfm_plane_sweep_tune.restype = ctypes.c_int
     h.dfm_plane_sweep_tune.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    h.dfm_plane_sweep_schedule.restype = ctypes.c_int
+    h.dfm_plane_sweep_schedule.argtypes = [ctypes.c_int]
     mp = ctypes.POINTER(MvDesc)
     h.dfm_point_sample_mv_workspace_bytes.restype = sz
     h.dfm_point_sample_mv_workspace_bytes.argtypes = [mp]

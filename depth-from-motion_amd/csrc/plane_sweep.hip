@@ -38,6 +38,7 @@ int g_lds_kb = 52;   // dynamic LDS per workgroup, KiB
 unsigned long long *g_trace = nullptr;  // debug: see dfm_debug_set_trace
 int g_planes = 2;             // depth planes per workgroup of the LDS kernel (measured best)
 int g_blocks_per_group = 1 << 20;  // channel blocks per workgroup (default: all)
+int g_band_chunk = 1;              // adjacent bands scheduled back to back (store locality)
 
 // optional per-launch timing of the dominant (volume-writing) kernel with HIP
 // events on the caller's stream (bench.py's roofline leg)
@@ -258,6 +259,7 @@ struct TileGrid {
     int planes;            // depth planes per workgroup (divides NT/64)
     int dgroups;           // ceil(D / planes)
     int blocks_per_group;  // channel blocks one workgroup sweeps
+    int band_chunk;        // adjacent bands scheduled together (see the block id map)
     unsigned long long *trace;  // perf experiments only: per-phase s_memtime stamps
     int ablate;            // perf experiments only (DFM_ABLATE): 1 no staging,
                            // 2 no volume stores, 4 no taps/blend; results are wrong
@@ -286,7 +288,8 @@ __device__ __forceinline__ void tile_body(
     // Tiles: every depth plane (hw points) is cut into `bands` pieces of
     // `band_pts` points whose boundaries are multiples of 8 in the flat
     // (d,h,w) index, so every lane's V points form one aligned 16-byte store.
-    // block id = (((group*bands + band)*2 + half)*D + d)*batch + b
+    // block id = ((((group*chunks + chunk)*2 + half)*dgroups + dgroup)*band_chunk + band_in)*batch + b
+    //   band = chunk*band_chunk + band_in; band_chunk = 1 by default
     //   sample fastest -> id % 8 == XCD keeps one sample's maps in one L2 (batch 8)
     //   depth next     -> the workgroups resident on an XCD sweep the SAME band
     //                     of the SAME map over consecutive depth planes: they
@@ -299,12 +302,16 @@ __device__ __forceinline__ void tile_body(
     const int batch = tg.batch;
     const int b = bid % batch;
     int th = bid / batch;
+    const int band_in = th % tg.band_chunk;
+    th /= tg.band_chunk;
     const int dgroup = th % tg.dgroups;
     th /= tg.dgroups;
     const int half = th & 1;
     th >>= 1;
-    const int band = th % tg.bands;
-    const int group = th / tg.bands;
+    const int nchunks = (tg.bands + tg.band_chunk - 1) / tg.band_chunk;
+    const int band = (th % nchunks) * tg.band_chunk + band_in;
+    const int group = th / nchunks;
+    if (band >= tg.bands) return;
     const int blk_lo = group * tg.blocks_per_group;
     const int blk_hi = min(blk_lo + tg.blocks_per_group, g.nblk);
     const int lanes_per_plane = NT / tg.planes;
@@ -811,12 +818,14 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
         tg.bands = (int)((hw + 7 + per_plane - 1) / per_plane);
         tg.band_pts = (int)((((hw + 7 + tg.bands - 1) / tg.bands) + 7) & ~7ll);
         tg.blocks_per_group = bpg;
+        tg.band_chunk = std::max(1, std::min(g_band_chunk, tg.bands));
         tg.trace = g_trace;
         {
             const char *ab = getenv("DFM_ABLATE");  // perf experiments only
             tg.ablate = ab ? atoi(ab) : 0;
         }
-        const long long nb = (long long)tg.bands * tg.dgroups * 2 * d->batch * groups;
+        const long long nchunks = (tg.bands + tg.band_chunk - 1) / tg.band_chunk;
+        const long long nb = nchunks * tg.band_chunk * tg.dgroups * 2 * d->batch * groups;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
         if ((size_t)(nb + 1) * 4 > flag_bytes(d)) return fail(DFM_ERR_WORKSPACE, "spill list too small%s");
         int *spill_list = (int *)((char *)ws + 2 * blocked_bytes(d));
@@ -888,6 +897,14 @@ DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int block
     g_lds_kb = lds_kib;
     g_blocks_per_group = blocks_per_group;
     g_planes = planes_per_workgroup;
+    return DFM_OK;
+}
+
+DFM_API int dfm_plane_sweep_schedule(int bands_per_chunk)
+{
+    if (bands_per_chunk < 1)
+        return fail(DFM_ERR_INVALID_ARG, "schedule: bands_per_chunk >= 1%s");
+    g_band_chunk = bands_per_chunk;
     return DFM_OK;
 }
 

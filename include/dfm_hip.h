@@ -150,6 +150,13 @@ DFM_API void dfm_plane_sweep_force_kernel(int which);
  * LDS is redone with direct taps. */
 DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int blocks_per_group,
                                  int planes_per_workgroup);
+/* Workgroup order of the LDS-staged kernel (process-wide): how many adjacent
+ * bands of a depth plane are scheduled back to back before the next depth
+ * group.  1 (default) keeps all depth planes of one band resident together
+ * (best L2 reuse of the staged rows); larger values make the resident
+ * workgroups write longer contiguous runs of every channel plane (better HBM
+ * write locality, more L2 refetch) -- see profiles/r01_store_microbench3.txt. */
+DFM_API int dfm_plane_sweep_schedule(int bands_per_chunk);
 
 /* ---------------------------------------------------------------------- */
 /* multi-view voxel lifting (point_sample x views x frames + reduction)    */

@@ -33,22 +33,26 @@ def pkg():
 #   lds_spill : LDS budget too small for any tile -> every tile is flagged and
 #               redone by the direct-tap pass
 #   direct    : tile kernel with direct taps for every tile (strided sweeps)
-# (force_kernel, lanes, lds KiB, channel blocks per group, depth planes per workgroup)
-MODES = {'gather': (1, 256, 64, 4, 1), 'lds128_p1': (2, 128, 36, 1, 1),
-         'lds128_p2': (2, 128, 36, 1000, 2), 'lds256_p1': (2, 256, 64, 4, 1),
-         'lds256_p2': (2, 256, 52, 1000, 2), 'lds256_p4': (2, 256, 52, 1000, 4),
-         'lds_spill': (2, 128, 4, 2, 2), 'direct': (3, 256, 64, 4, 1)}
+#   lds256_chunk: shipped shape with 3 adjacent bands scheduled back to back
+# (force_kernel, lanes, lds KiB, channel blocks per group, depth planes per workgroup, bands per chunk)
+MODES = {'gather': (1, 256, 64, 4, 1, 1), 'lds128_p1': (2, 128, 36, 1, 1, 1),
+         'lds128_p2': (2, 128, 36, 1000, 2, 1), 'lds256_p1': (2, 256, 64, 4, 1, 1),
+         'lds256_p2': (2, 256, 52, 1000, 2, 1), 'lds256_p4': (2, 256, 52, 1000, 4, 1),
+         'lds256_chunk': (2, 256, 52, 1000, 2, 3),
+         'lds_spill': (2, 128, 4, 2, 2, 2), 'direct': (3, 256, 64, 4, 1, 1)}
 
 
 @pytest.fixture(params=sorted(MODES), autouse=True)
 def kernel_mode(request, pkg):
-    force, lanes, kib, bpg, planes = MODES[request.param]
+    force, lanes, kib, bpg, planes, chunk = MODES[request.param]
     lib = pkg._capi.lib()
     lib.dfm_plane_sweep_force_kernel(force)
     pkg._capi.check(lib.dfm_plane_sweep_tune(lanes, kib, bpg, planes))
+    pkg._capi.check(lib.dfm_plane_sweep_schedule(chunk))
     yield request.param
     lib.dfm_plane_sweep_force_kernel(0)
     pkg._capi.check(lib.dfm_plane_sweep_tune(256, 52, 1 << 20, 2))
+    pkg._capi.check(lib.dfm_plane_sweep_schedule(1))
 
 
 def run_hip(pkg, cur, prev, depths, fsf, csf, P, T, img_shape, flip, crop, scale, dtype=torch.float32):
