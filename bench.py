@@ -42,7 +42,7 @@ KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0
                      [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
 
 # secondary workloads (other rows of SURVEY.md 8a), reported with the same JSON shape
-SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm')
+SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd_kitti')
 
 WORKLOADS = {
     # name: B, C, H, W, D, fsf, csf, crop, dtype
@@ -150,6 +150,33 @@ def secondary(args, pkg, dev, rank, world):
             return pkg.depth_head_forward(x, ds)
         nbytes = B * 4 * (72 * 80 * 320 + 2 * 288 * 320 * 1280 + 320 * 1280)
         name, unit = 'DepthHead.forward (1,72,80,320)->2x(288,320,1280)+map, fp32', 'depth-volumes/s'
+    elif args.workload in ('sweep_bwd', 'sweep_bwd_kitti'):
+        # backward of the plane sweep on the N* / K shape: grad volume -> fp32 feature grads
+        sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+        w = WORKLOADS['nstar' if args.workload == 'sweep_bwd' else 'kitti']
+        B = w['B']
+        tdt = torch.bfloat16 if w['dtype'] == 'bf16' else torch.float32
+        esz = 2 if w['dtype'] == 'bf16' else 4
+        cur = torch.empty(B, w['C'], w['H'], w['W'], dtype=tdt, device=dev)
+        desc = sweep._make_desc(cur, w['D'], w['fsf'], w['csf'], (375, 1242), False, w['crop'], 1.0)
+        depths = torch.from_numpy(depth_planes(w['D'], w['dmin'], w['dmax'])).to(dev)
+        P, Pinv, T = sweep.camera_matrices(torch.from_numpy(np.stack([KITTI_P2] * B)),
+                                           torch.from_numpy(poses(B, 2 + rank)), B, dev)
+        gout = torch.randn(B, 2 * w['C'], w['D'], desc.h_out, desc.w_out, device=dev, dtype=tdt)
+        g_cur = torch.zeros(B, w['C'], w['H'], w['W'], device=dev)
+        g_prev = torch.zeros_like(g_cur)
+        lib = pkg._capi.lib()
+
+        def step():
+            g_cur.zero_()
+            g_prev.zero_()
+            pkg._capi.check(lib.dfm_plane_sweep_bwd(
+                ctypes.byref(desc), gout.data_ptr(), depths.data_ptr(), P.data_ptr(), Pinv.data_ptr(),
+                T.data_ptr(), g_cur.data_ptr(), g_prev.data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream))
+        nbytes = gout.numel() * esz + 2 * g_cur.numel() * 4
+        name = f'plane-sweep backward ({w["dtype"]} grad volume -> 2 fp32 feature grads)'
+        unit = 'cost-volume-grads/s'
     elif args.workload == 'group_norm':
         B = 8
         x = (torch.randn(B, 32, 72, 80, 320, generator=gen) + 0.5).to(dev)
@@ -196,7 +223,8 @@ def secondary(args, pkg, dev, rank, world):
             'metric': unit.replace('/s', '/sec'), 'value': round(B * world / (ms / 1e3), 2),
             'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'bf16' if args.workload == 'sweep_bwd' else 'f32',
+            'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {name}', 'global_batch': B * world,
                        'parallelism': f'dp{world}'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,

@@ -28,6 +28,7 @@ EXPORTS = (
     'dfm_plane_sweep_schedule',
     'dfm_point_sample_mv_workspace_bytes',
     'dfm_point_sample_mv_fwd',
+    'dfm_frustum_to_voxel_workspace_bytes',
     'dfm_frustum_to_voxel_fwd',
     'dfm_depth_head_fwd',
     'dfm_frustum_to_voxel_bwd',
@@ -154,7 +155,10 @@ def lib():
     h.dfm_point_sample_mv_fwd.restype = ctypes.c_int
     h.dfm_point_sample_mv_fwd.argtypes = [mp, vp, fp, fp, fp, vp, vp, vp, sz, vp]
     h.dfm_frustum_to_voxel_fwd.restype = ctypes.c_int
-    h.dfm_frustum_to_voxel_fwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, vp, fp, fp, vp, vp]
+    h.dfm_frustum_to_voxel_fwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, vp, fp, fp, vp, vp,
+                                           ctypes.c_size_t, vp]
+    h.dfm_frustum_to_voxel_workspace_bytes.restype = ctypes.c_size_t
+    h.dfm_frustum_to_voxel_workspace_bytes.argtypes = [ctypes.POINTER(F2vDesc)]
     h.dfm_depth_head_fwd.restype = ctypes.c_int
     h.dfm_depth_head_fwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, vp]
     h.dfm_frustum_to_voxel_bwd.restype = ctypes.c_int

@@ -45,55 +45,105 @@ __device__ __forceinline__ float lerp_fma(float w0, float a, float w1, float b)
     return __builtin_fmaf(w0, a, w1 * b);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void depth_head_kernel(const T *__restrict__ in, int D, int H,
+// V output pixels (consecutive along w) per lane: one V*sizeof(T)-byte store per depth.
+// The upsample is separable and ATen nests it W -> H -> D, so a lane first reduces
+// its 4 (W,H) taps of input plane i to one value col(i) and every output depth is a
+// single lerp of col(i0), col(i1); i0 advances once per `s` output depths, so each
+// pass over the column evaluates col() D times (not 4D times 2).
+template <typename T, int V>
+__global__ __launch_bounds__(128) void depth_head_kernel(const T *__restrict__ in, int D, int H,
                                                          int W, int s,
                                                          const float *__restrict__ depth_samples,
                                                          T *__restrict__ vol, T *__restrict__ soft,
                                                          T *__restrict__ pred)
 {
+    typedef T vec_t __attribute__((ext_vector_type(V)));
     const int Do = D * s, Ho = H * s, Wo = W * s;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int pix = (blockIdx.x * 128 + threadIdx.x) * V;
     const int b = blockIdx.y;
     if (pix >= Ho * Wo) return;
-    const int h = pix / Wo, w = pix - h * Wo;
-    const UpIdx uh = up_index(h, H, Ho), uw = up_index(w, W, Wo);
+    const int h = pix / Wo, w = pix - h * Wo;  // Wo % V == 0: the V pixels share the row
+    const UpIdx uh = up_index(h, H, Ho);
     const T *x = in + (size_t)b * D * H * W;
-    const int o00 = uh.i0 * W + uw.i0, o01 = uh.i0 * W + uw.i1;
-    const int o10 = uh.i1 * W + uw.i0, o11 = uh.i1 * W + uw.i1;
+    int o0[V], o1[V];
+    float ww0[V], ww1[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const UpIdx uw = up_index(w + j, W, Wo);
+        o0[j] = uw.i0;
+        o1[j] = uw.i1;
+        ww0[j] = uw.w0;
+        ww1[j] = uw.w1;
+    }
+    const int r0 = uh.i0 * W, r1 = uh.i1 * W;
     const size_t plane_o = (size_t)Ho * Wo;
     T *vcol = vol + (size_t)b * Do * plane_o + pix;
     T *scol = soft + (size_t)b * Do * plane_o + pix;
 
-    auto logit = [&](int d) {
+    auto column = [&](int i, float (&c)[V]) {
+        const T *p = x + (size_t)i * H * W;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float a = lerp_fma(ww0[j], elem<T>::load(p[r0 + o0[j]]), ww1[j],
+                                     elem<T>::load(p[r0 + o1[j]]));
+            const float bb = lerp_fma(ww0[j], elem<T>::load(p[r1 + o0[j]]), ww1[j],
+                                      elem<T>::load(p[r1 + o1[j]]));
+            c[j] = lerp_fma(uh.w0, a, uh.w1, bb);
+        }
+    };
+    // walks d = 0..Do-1 keeping col(i0), col(i1) of the current input interval
+    float c0[V], c1[V];
+    int have = -1;
+    auto logits = [&](int d, float (&v)[V]) {
         const UpIdx ud = up_index(d, D, Do);
-        const T *p0 = x + (size_t)ud.i0 * H * W, *p1 = x + (size_t)ud.i1 * H * W;
-        const float a0 = lerp_fma(uw.w0, elem<T>::load(p0[o00]), uw.w1, elem<T>::load(p0[o01]));
-        const float b0 = lerp_fma(uw.w0, elem<T>::load(p0[o10]), uw.w1, elem<T>::load(p0[o11]));
-        const float a1 = lerp_fma(uw.w0, elem<T>::load(p1[o00]), uw.w1, elem<T>::load(p1[o01]));
-        const float b1 = lerp_fma(uw.w0, elem<T>::load(p1[o10]), uw.w1, elem<T>::load(p1[o11]));
-        const float v = lerp_fma(ud.w0, lerp_fma(uh.w0, a0, uh.w1, b0), ud.w1,
-                                 lerp_fma(uh.w0, a1, uh.w1, b1));
-        // the reference's softmax reads depth_volumes in its storage type
-        return elem<T>::load(elem<T>::store(v));
+        if (ud.i0 != have) {
+            if (ud.i0 == have + 1 && have >= 0) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) c0[j] = c1[j];
+            } else {
+                column(ud.i0, c0);
+            }
+            column(ud.i1, c1);
+            have = ud.i0;
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+            // the reference's softmax reads depth_volumes in its storage type
+            v[j] = elem<T>::load(elem<T>::store(lerp_fma(ud.w0, c0[j], ud.w1, c1[j])));
     };
 
-    float mx = -INFINITY;
+    float mx[V], sum[V], acc[V], v[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { mx[j] = -INFINITY; sum[j] = 0.0f; acc[j] = 0.0f; }
     for (int d = 0; d < Do; ++d) {
-        const float v = logit(d);
-        vcol[(size_t)d * plane_o] = elem<T>::store(v);
-        mx = fmaxf(mx, v);
+        logits(d, v);
+        vec_t st;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { st[j] = elem<T>::store(v[j]); mx[j] = fmaxf(mx[j], v[j]); }
+        __builtin_nontemporal_store(st, (vec_t *)(vcol + (size_t)d * plane_o));
     }
-    float sum = 0.0f;
-    for (int d = 0; d < Do; ++d) sum = sum + expf(logit(d) - mx);
-    float acc = 0.0f;
+    have = -1;
     for (int d = 0; d < Do; ++d) {
-        const float pr = expf(logit(d) - mx) / sum;
-        const T st = elem<T>::store(pr);
-        scol[(size_t)d * plane_o] = st;
-        acc = acc + elem<T>::load(st) * depth_samples[d];
+        logits(d, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) sum[j] = sum[j] + expf(v[j] - mx[j]);
     }
-    pred[(size_t)b * plane_o + pix] = elem<T>::store(acc);
+    have = -1;
+    for (int d = 0; d < Do; ++d) {
+        logits(d, v);
+        const float ds = depth_samples[d];
+        vec_t st;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            st[j] = elem<T>::store(expf(v[j] - mx[j]) / sum[j]);
+            acc[j] = acc[j] + elem<T>::load(st[j]) * ds;
+        }
+        __builtin_nontemporal_store(st, (vec_t *)(scol + (size_t)d * plane_o));
+    }
+    vec_t pr;
+#pragma unroll
+    for (int j = 0; j < V; ++j) pr[j] = elem<T>::store(acc[j]);
+    *(vec_t *)(pred + (size_t)b * plane_o + pix) = pr;
 }
 
 }  // namespace
@@ -113,16 +163,24 @@ DFM_API int dfm_depth_head_fwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
     if (batch > 65535 || (long long)h * scale * w * scale >= (1ll << 31))
         return set_error(DFM_ERR_UNSUPPORTED, "shape too large");
     const int npix = h * scale * w * scale;
-    dim3 grid((npix + 255) / 256, batch);
+    // 4 pixels per lane (16-byte fp32 / 8-byte bf16 stores) when rows and the three
+    // output base pointers allow it, else one
+    const size_t esz = dtype == DFM_F32 ? 4 : 2;
+    const bool vec4 = (w * scale) % 4 == 0 &&
+                      (((uintptr_t)depth_volumes | (uintptr_t)softmax | (uintptr_t)depth_preds) %
+                       (4 * esz)) == 0;
+    const int v = vec4 ? 4 : 1;
+    dim3 grid((npix / v + 127) / 128, batch);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DFM_F32)
-        hipLaunchKernelGGL(depth_head_kernel<float>, grid, dim3(256), 0, st, (const float *)cost, d,
-                           h, w, scale, depth_samples, (float *)depth_volumes, (float *)softmax,
-                           (float *)depth_preds);
-    else
-        hipLaunchKernelGGL(depth_head_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)cost,
-                           d, h, w, scale, depth_samples, (bf16_t *)depth_volumes,
-                           (bf16_t *)softmax, (bf16_t *)depth_preds);
+#define DFM_DH_LAUNCH(T, V)                                                                       \
+    hipLaunchKernelGGL((depth_head_kernel<T, V>), grid, dim3(128), 0, st, (const T *)cost, d, h, \
+                       w, scale, depth_samples, (T *)depth_volumes, (T *)softmax, (T *)depth_preds)
+    if (dtype == DFM_F32) {
+        if (vec4) DFM_DH_LAUNCH(float, 4); else DFM_DH_LAUNCH(float, 1);
+    } else {
+        if (vec4) DFM_DH_LAUNCH(bf16_t, 4); else DFM_DH_LAUNCH(bf16_t, 1);
+    }
+#undef DFM_DH_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;

@@ -257,4 +257,40 @@ __device__ __forceinline__ Tap make_tap(float x, float y, int H, int W)
     return t;
 }
 
+// (n, C, P) planar -> (n, P, Cp) pixel-major, Cp = C rounded up to a whole number of
+// 16-byte channel blocks (zero padded): all channels of one sampled pixel / voxel are
+// one contiguous run, so a tap is Cp*sizeof(T)/16 adjacent 16-byte loads instead of
+// C scalar loads a whole plane apart.  64 pixels x 32 channels per workgroup through
+// an LDS tile: global reads run along pixels, global writes along channels.
+// grid = (ceil(P/64), ceil(Cp/32), n)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_pixel_major_kernel(const T *__restrict__ src,
+                                                               T *__restrict__ dst, int C, int Cp,
+                                                               long long P)
+{
+    __shared__ T tile[32][64 + 1];
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const size_t n = blockIdx.z;
+    {
+        const int p = threadIdx.x & 63, cc = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = cc + 4 * k;
+            T v = T(0);
+            if (c0 + c < C && p0 + p < P) v = src[(n * C + c0 + c) * (size_t)P + p0 + p];
+            tile[c][p] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const int c = threadIdx.x & 31, pp = threadIdx.x >> 5;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = pp + 8 * k;
+            if (c0 + c < Cp && p0 + p < P) dst[(n * (size_t)P + p0 + p) * Cp + c0 + c] = tile[c][p];
+        }
+    }
+}
+
 }  // namespace dfm

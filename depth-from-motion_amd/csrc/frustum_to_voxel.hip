@@ -11,9 +11,14 @@
 // (x1-ix)*(y1-iy)*(z1-iz) ..., out = 0; out += v*w over the in-bounds corners in
 // the order tnw,tne,tsw,tse,bnw,bne,bsw,bse, multiply and add unfused.
 //
-// Layout: everything in the caller's layouts (NCDHW / NCHW); lanes are adjacent
-// voxels along x, so the 8 corner loads of a wave fall in a few cache lines.
-// Bound: HBM write of the volume (the three sources are L2/MALL resident).
+// Layout: caller tensors are NCDHW / NCHW.  stereo_feat and cur_sem_feats are first
+// re-laid pixel-major into the workspace ([d][h][w][C], [h][w][Cs]: a corner is one
+// contiguous run of C*sizeof(T) bytes read with 16-byte loads -- in NCDHW the C scalar
+// loads of a corner sit a whole volume apart and neighbouring voxels along x walk
+// through depth planes, so every load touched its own cache line); the 1-channel
+// depth distribution is sampled where it lies.  Shapes whose channel counts are not a
+// whole number of 16-byte blocks take the scalar kernel on the caller's layout.
+// Bound: HBM write of the volume + one read of the sources.
 #include "dfm_common.h"
 
 using namespace dfm;
@@ -122,13 +127,134 @@ __global__ __launch_bounds__(256) void f2v_kernel(F2vGeom g, const T *__restrict
     }
 }
 
+// pixel-major sources: stereo_pm [b][d*h*w][C], sem_pm [b][hsem*wsem][Cs] (16-byte blocks)
+// 32 channels per pass; per channel the corners are added in ATen's order.
+template <typename T>
+__global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__restrict__ stereo_pm,
+                                                     const T *__restrict__ soft,
+                                                     const uint4 *__restrict__ sem_pm,
+                                                     const float *__restrict__ coords,
+                                                     const float *__restrict__ cam2img,
+                                                     T *__restrict__ out)
+{
+    constexpr int CB = elem<T>::CB;
+    constexpr int NB = 32 / CB;
+    const long long N = (long long)g.Nz * g.Ny * g.Nx;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= N) return;
+    const float xs = coords[3 * i], ys = coords[3 * i + 1], zs = coords[3 * i + 2];
+    const float *P = cam2img + 16 * b;  // rows 0..2 of the 4x4 == cam2img[:3]
+    const float a = dot4_chain(-ys, -zs, xs, 1.0f, P + 0);
+    const float bb = dot4_chain(-ys, -zs, xs, 1.0f, P + 4);
+    const float c = dot4_chain(-ys, -zs, xs, 1.0f, P + 8);
+    const float u = a / c, v = bb / c;
+    const bool valid2d = (u >= 0.0f) && (u <= g.pad_w) && (v >= 0.0f) && (v <= g.pad_h);
+    float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
+    float gz = (xs - g.depth_min) / g.depth_span;
+    gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
+    const float valid = (valid2d && gz >= -1.0f && gz <= 1.0f) ? 1.0f : 0.0f;
+
+    T *o = out + (size_t)b * (g.C + g.Cs) * N + i;
+    {
+        const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
+        const int nblk = g.C / CB;
+        const uint4 *sv = stereo_pm + (size_t)b * g.D * g.H * g.W * nblk;
+        for (int blk0 = 0; blk0 < nblk; blk0 += NB) {
+            float acc[NB][CB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int k = 0; k < CB; ++k) acc[j][k] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (!(t.ok & (1u << k))) continue;
+                const uint4 *p = sv + (size_t)t.o[k] * nblk + blk0;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (blk0 + j < nblk) {
+                        float r[CB];
+                        unpack16(p[j], r);
+#pragma unroll
+                        for (int e = 0; e < CB; ++e) acc[j][e] = acc[j][e] + r[e] * t.w[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < CB; ++e)
+                    if (blk0 + j < nblk)
+                        o[(size_t)((blk0 + j) * CB + e) * N] = elem<T>::store(acc[j][e] * valid);
+        }
+    }
+    if (g.Cs > 0) {
+        const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+        const float disp =
+            tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws) * valid;
+        const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
+        const float v2d = valid2d ? 1.0f : 0.0f;
+        const int nblk = g.Cs / CB;
+        const uint4 *sp = sem_pm + (size_t)b * g.Hsem * g.Wsem * nblk;
+        for (int blk0 = 0; blk0 < nblk; blk0 += NB) {
+            float acc[NB][CB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int k = 0; k < CB; ++k) acc[j][k] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // D == 1: the z1 corners are never in bounds
+                if (!(t2.ok & (1u << k))) continue;
+                const uint4 *p = sp + (size_t)t2.o[k] * nblk + blk0;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (blk0 + j < nblk) {
+                        float r[CB];
+                        unpack16(p[j], r);
+#pragma unroll
+                        for (int e = 0; e < CB; ++e) acc[j][e] = acc[j][e] + r[e] * t2.w[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < CB; ++e)
+                    if (blk0 + j < nblk) {
+                        float sval = acc[j][e] * v2d;
+                        o[(size_t)(g.C + (blk0 + j) * CB + e) * N] = elem<T>::store(sval * disp);
+                    }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
+// pixel-major staging is used when both channel counts are whole 16-byte blocks
+static bool f2v_pixel_major(const dfm_f2v_desc *d)
+{
+    const int CB = d->dtype == DFM_BF16 ? 8 : 4;
+    return d->channels % CB == 0 && d->sem_channels % CB == 0;
+}
+
+DFM_API size_t dfm_frustum_to_voxel_workspace_bytes(const dfm_f2v_desc *d)
+{
+    if (!d || d->batch <= 0 || d->channels <= 0 || d->d <= 0 || d->h <= 0 || d->w <= 0 ||
+        d->sem_channels < 0 || (d->dtype != DFM_F32 && d->dtype != DFM_BF16))
+        return 0;
+    if (!f2v_pixel_major(d)) return 256;
+    const size_t esz = d->dtype == DFM_BF16 ? 2 : 4;
+    const size_t a = (size_t)d->batch * d->channels * d->d * d->h * d->w * esz;
+    const size_t b = (size_t)d->batch * d->sem_channels * d->hsem * d->wsem * esz;
+    return ((a + 255) & ~(size_t)255) + ((b + 255) & ~(size_t)255) + 256;
+}
+
 DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, const void *softmax,
                                      const void *sem, const float *coords, const float *cam2img,
-                                     void *out, void *stream)
+                                     void *out, void *workspace, size_t workspace_bytes,
+                                     void *stream)
 {
     if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
     if (d->batch <= 0 || d->channels <= 0 || d->d <= 0 || d->h <= 0 || d->w <= 0 || d->nz <= 0 ||
@@ -150,7 +276,39 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, 
     const long long N = (long long)d->nz * d->ny * d->nx;
     dim3 grid((unsigned)((N + 255) / 256), d->batch);
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == DFM_F32)
+    if (f2v_pixel_major(d)) {
+        if (!workspace || workspace_bytes < dfm_frustum_to_voxel_workspace_bytes(d))
+            return set_error(DFM_ERR_WORKSPACE,
+                             "workspace smaller than dfm_frustum_to_voxel_workspace_bytes");
+        const size_t esz = d->dtype == DFM_BF16 ? 2 : 4;
+        const long long vox = (long long)d->d * d->h * d->w, pix = (long long)d->hsem * d->wsem;
+        const size_t a = ((size_t)d->batch * d->channels * vox * esz + 255) & ~(size_t)255;
+        void *stereo_pm = workspace, *sem_pm = (char *)workspace + a;
+        dim3 pg1((unsigned)((vox + 63) / 64), (d->channels + 31) / 32, d->batch);
+        dim3 pg2((unsigned)((pix + 63) / 64), (d->sem_channels + 31) / 32, d->batch);
+        if (d->dtype == DFM_F32) {
+            hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg1, dim3(256), 0, st,
+                               (const float *)stereo, (float *)stereo_pm, d->channels, d->channels, vox);
+            if (d->sem_channels > 0)
+                hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg2, dim3(256), 0, st,
+                                   (const float *)sem, (float *)sem_pm, d->sem_channels,
+                                   d->sem_channels, pix);
+            hipLaunchKernelGGL(f2v_pm_kernel<float>, grid, dim3(256), 0, st, g,
+                               (const uint4 *)stereo_pm, (const float *)softmax,
+                               (const uint4 *)sem_pm, coords, cam2img, (float *)out);
+        } else {
+            hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg1, dim3(256), 0, st,
+                               (const bf16_t *)stereo, (bf16_t *)stereo_pm, d->channels, d->channels,
+                               vox);
+            if (d->sem_channels > 0)
+                hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg2, dim3(256), 0, st,
+                                   (const bf16_t *)sem, (bf16_t *)sem_pm, d->sem_channels,
+                                   d->sem_channels, pix);
+            hipLaunchKernelGGL(f2v_pm_kernel<bf16_t>, grid, dim3(256), 0, st, g,
+                               (const uint4 *)stereo_pm, (const bf16_t *)softmax,
+                               (const uint4 *)sem_pm, coords, cam2img, (bf16_t *)out);
+        }
+    } else if (d->dtype == DFM_F32)
         hipLaunchKernelGGL(f2v_kernel<float>, grid, dim3(256), 0, st, g, (const float *)stereo,
                            (const float *)softmax, (const float *)sem, coords, cam2img, (float *)out);
     else

@@ -14,7 +14,8 @@
 //                         of the volume bytes).
 //   sweep_gather_kernel : one lane = one lattice point; loops channel blocks,
 //                         four 16-B taps per map straight from L2/L1.
-//   sweep_bwd_kernel    : scatter-add of grad_out into fp32 feature grads.
+//   sweep_bwd_tile_kernel: backward of dense sweeps, gradients accumulated in LDS rows.
+//   sweep_bwd_kernel    : backward fallback, lane-per-point scatter-add (global atomics).
 //   sweep_grid_kernel   : parity aid, dumps the normalised grids.
 #include "dfm_common.h"
 
@@ -690,6 +691,310 @@ __global__ __launch_bounds__(256) void sweep_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// backward, dense sweeps: LDS-accumulating tiles.
+// A workgroup owns one band of lattice points (same (h, w) range) of one map over a
+// chunk of depth planes.  Per pass of BWD_CW channels the taps' gradients are added
+// into an fp32 slab of feature rows in LDS ([channel][row][x]: lanes are consecutive
+// points, so a wave's adds land in consecutive banks) with ds_add_f32; the slab goes to
+// the global gradient with ONE coalesced atomic per touched pixel when the chunk is done
+// or when the footprint of the next plane has drifted out of the slab window (prev map,
+// near planes).  The cur map's footprint does not depend on depth, so its planes all
+// land in the same few rows: global atomics drop by about the chunk length.
+// The sampling positions are recomputed per (plane, channel pass) with the forward
+// kernel's own sweep_point_map/make_tap, i.e. the taps and weights ARE the forward's.
+// ---------------------------------------------------------------------------
+constexpr int BWD_CW = 8;     // channels accumulated per pass
+constexpr int BWD_PPL = 1;    // lattice points per lane and plane
+constexpr int BWD_MAXP = 32;  // depth planes per workgroup, at most
+
+struct BwdGrid {
+    int batch, bands, band_pts, planes, dchunks, rows;
+};
+
+template <typename T, int HALF>
+__device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFast &fast,
+                                              const BwdGrid &tg, int b, int band, int dchunk,
+                                              const T *__restrict__ gout,
+                                              const float *__restrict__ depths,
+                                              const float *__restrict__ P,
+                                              const float *__restrict__ Pinv,
+                                              const float *__restrict__ Tm,
+                                              float *__restrict__ gfeat, float *slab, int *yr)
+{
+    const int tid = threadIdx.x;
+    const int hw = g.h_out * g.w_out;
+    const int W = g.w_in, H = g.h_in, HW = H * W;
+    const int p_lo = band * tg.band_pts, p_hi = min(p_lo + tg.band_pts, hw);
+    const int d_lo = dchunk * tg.planes, d_hi = min(d_lo + tg.planes, g.D);
+    const int rows = tg.rows, slab_c = rows * W;
+    const float *Pb = P + b * 16, *Pib = Pinv + b * 16, *Tb = Tm + b * 16;
+
+    int idx[BWD_PPL], hi[BWD_PPL], wi[BWD_PPL];
+#pragma unroll
+    for (int k = 0; k < BWD_PPL; ++k) {
+        idx[k] = p_lo + k * 256 + tid;
+        hi[k] = idx[k] / g.w_out;
+        wi[k] = idx[k] - hi[k] * g.w_out;
+    }
+    for (int i = tid; i < 2 * BWD_MAXP; i += 256) yr[i] = (i & 1) ? -1 : 0x7fffffff;
+    for (int i = tid; i < BWD_CW * slab_c; i += 256) slab[i] = 0.0f;
+    __syncthreads();
+    // rows every plane of the chunk touches
+    for (int d = d_lo; d < d_hi; ++d) {
+        int ymin = 0x7fffffff, ymax = -1;
+        const float depth = depths[d];
+#pragma unroll
+        for (int k = 0; k < BWD_PPL; ++k) {
+            if (idx[k] >= p_hi) continue;
+            float sx, sy;
+            sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, hi[k], wi[k], sx, sy);
+            const Tap t = make_tap(sx, sy, H, W);
+            if (t.ok & 3u) { ymin = min(ymin, t.iy); ymax = max(ymax, t.iy); }
+            if (t.ok & 12u) { ymin = min(ymin, t.iy + t.dy); ymax = max(ymax, t.iy + t.dy); }
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            ymin = min(ymin, __shfl_xor(ymin, s));
+            ymax = max(ymax, __shfl_xor(ymax, s));
+        }
+        if ((tid & 63) == 0 && ymax >= 0) {
+            atomicMin(&yr[2 * (d - d_lo)], ymin);
+            atomicMax(&yr[2 * (d - d_lo) + 1], ymax);
+        }
+    }
+    __syncthreads();
+
+    const T *go = gout + ((size_t)b * 2 * g.C + (size_t)HALF * g.C) * g.N;
+    float *gf = gfeat + (size_t)b * g.C * HW;
+    for (int c0 = 0; c0 < g.C; c0 += BWD_CW) {
+        const int nc = min(BWD_CW, g.C - c0);
+        int y0 = -1, top = -1;
+        auto flush = [&]() {
+            const int cnt = (top - y0 + 1) * W;
+            for (int c = 0; c < nc; ++c) {
+                float *sl = slab + c * slab_c;
+                float *dst = gf + (size_t)(c0 + c) * HW + (size_t)y0 * W;
+                for (int r = tid; r < cnt; r += 256) {
+                    const float v = sl[r];
+                    if (v != 0.0f) {
+                        atomicAdd(dst + r, v);
+                        sl[r] = 0.0f;
+                    }
+                }
+            }
+        };
+        // Runs over depth.  ds_add_f32 retires about one lane per 3 clocks
+        // (profiles/r01_atomic_microbench.txt), so the kernel is bound by how many values it
+        // scatters.  A point's gradients are therefore summed in registers, over consecutive
+        // planes, into a 3x3 block of pixels whose corner (by, bx) follows the footprint: a
+        // 2x2 footprint whose corner is (by|by+1, bx|bx+1) fits, and while the block's last
+        // column / row is still unused the block may also move one pixel up or left.  The
+        // block is scattered when the footprint leaves it: once per depth chunk for the cur
+        // map (which samples AT the integers, x = w +- 1e-5: floor(x) flips between two
+        // neighbours, both inside the block), once per two pixels of drift for the prev map.
+        int run_key[BWD_PPL];  // (by + 2) | (bx + 2) << 13 : first row / column of the block; 0 = empty
+        uint32_t run_cells[BWD_PPL];
+        float acc[BWD_PPL][9][BWD_CW];
+#pragma unroll
+        for (int k = 0; k < BWD_PPL; ++k) { run_key[k] = 0; run_cells[k] = 0; }
+        auto scatter_run = [&](int k) {
+            const int key = run_key[k];
+            if (key) {
+                const int by = (key & 0x1fff) - 2, bx = (key >> 13) - 2;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int py = by + r;
+                    const int rr = py - y0;
+                    if (rr >= 0 && rr < rows) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            if (!(run_cells[k] & (1u << (3 * r + q)))) continue;  // in-bounds cells only
+                            float *l = slab + rr * W + (bx + q);
+#pragma unroll
+                            for (int c = 0; c < BWD_CW; ++c)
+                                if (c < nc && acc[k][3 * r + q][c] != 0.0f)
+                                    atomicAdd(l + c * slab_c, acc[k][3 * r + q][c]);
+                        }
+                    } else {  // row outside the slab window: rare, straight to memory
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            if (!(run_cells[k] & (1u << (3 * r + q)))) continue;
+                            float *gl = gf + (size_t)c0 * HW + (size_t)py * W + (bx + q);
+#pragma unroll
+                            for (int c = 0; c < BWD_CW; ++c)
+                                if (c < nc && acc[k][3 * r + q][c] != 0.0f)
+                                    atomicAdd(gl + (size_t)c * HW, acc[k][3 * r + q][c]);
+                        }
+                    }
+                }
+            }
+            run_key[k] = 0;
+            run_cells[k] = 0;
+        };
+        // gradient values are fetched one plane ahead of their use
+        T gv[2][BWD_PPL][BWD_CW];
+        auto fetch = [&](int d, T (&dst)[BWD_PPL][BWD_CW]) {
+#pragma unroll
+            for (int k = 0; k < BWD_PPL; ++k) {
+                // (lanes past the band end re-read the last point; their values are never used)
+                const T *gp = go + (size_t)c0 * g.N + (size_t)d * hw + min(idx[k], p_hi - 1);
+#pragma unroll
+                for (int c = 0; c < BWD_CW; ++c) dst[k][c] = gp[(size_t)min(c, nc - 1) * g.N];
+            }
+        };
+        int win_end = d_lo - 1;  // last plane covered by the current slab window
+        auto plane = [&](int d, const T (&src)[BWD_PPL][BWD_CW]) {
+            const int lo = __builtin_amdgcn_readfirstlane(yr[2 * (d - d_lo)]);
+            const int up = __builtin_amdgcn_readfirstlane(yr[2 * (d - d_lo) + 1]);
+            if (up < lo) return;  // nothing of this plane lands inside the map
+            if (d > win_end) {
+                // new slab window: the longest run of planes from here whose rows fit
+                int umin = lo, umax = up, e = d;
+                while (e + 1 < d_hi) {
+                    const int l2 = __builtin_amdgcn_readfirstlane(yr[2 * (e + 1 - d_lo)]);
+                    const int u2 = __builtin_amdgcn_readfirstlane(yr[2 * (e + 1 - d_lo) + 1]);
+                    if (u2 >= l2) {
+                        if (max(umax, u2) - min(umin, l2) + 1 > rows) break;
+                        umin = min(umin, l2);
+                        umax = max(umax, u2);
+                    }
+                    ++e;
+                }
+                if (y0 >= 0) {
+                    // runs do not outlive their window
+#pragma unroll
+                    for (int k = 0; k < BWD_PPL; ++k) scatter_run(k);
+                    __syncthreads();
+                    flush();
+                }
+                y0 = umin;
+                top = min(umax, umin + rows - 1);
+                win_end = e;
+                __syncthreads();
+            }
+            const float depth = depths[d];
+#pragma unroll
+            for (int k = 0; k < BWD_PPL; ++k) {
+                if (idx[k] >= p_hi) continue;
+                float sx, sy;
+                sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, hi[k], wi[k], sx, sy);
+                // make_tap's corner, fractions and in-bounds tests, kept separable
+                const bool fin = (fabsf(sx) <= 3.0e38f) && (fabsf(sy) <= 3.0e38f);
+                const float xw = floorf(sx), yn = floorf(sy);
+                const float fw = sx - xw, fe = 1.0f - fw, fn = sy - yn, fs = 1.0f - fn;
+                const bool wok = fin && xw >= 0.0f && xw <= (float)(W - 1);
+                const bool eok = fin && xw >= -1.0f && xw <= (float)(W - 2);
+                const bool nok = fin && yn >= 0.0f && yn <= (float)(H - 1);
+                const bool sok = fin && yn >= -1.0f && yn <= (float)(H - 2);
+                if (!((wok || eok) && (nok || sok))) continue;  // no tap inside the map
+                const int ixw = (int)xw, iyn = (int)yn;  // in [-1, W-1] x [-1, H-1] here
+                int by = (run_key[k] & 0x1fff) - 2, bx = (run_key[k] >> 13) - 2;
+                int ox = ixw - bx, oy = iyn - by;  // footprint corner inside the block: 0 or 1
+                const uint32_t cells = run_cells[k];
+                const bool fits = run_key[k] != 0 &&
+                                  (ox == 0 || ox == 1 || (ox == -1 && !(cells & 0444u))) &&
+                                  (oy == 0 || oy == 1 || (oy == -1 && !(cells & 0700u)));
+                if (!fits) {
+                    scatter_run(k);
+                    by = iyn; bx = ixw; ox = 0; oy = 0;
+#pragma unroll
+                    for (int cell = 0; cell < 9; ++cell)
+#pragma unroll
+                        for (int c = 0; c < BWD_CW; ++c) acc[k][cell][c] = 0.0f;
+                } else {
+                    if (ox < 0) {  // move the block one pixel left: its last column is empty
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < BWD_CW; ++c) {
+                                acc[k][3 * r + 2][c] = acc[k][3 * r + 1][c];
+                                acc[k][3 * r + 1][c] = acc[k][3 * r][c];
+                                acc[k][3 * r][c] = 0.0f;
+                            }
+                        run_cells[k] = (run_cells[k] << 1) & 0666u;
+                        bx -= 1; ox = 0;
+                    }
+                    if (oy < 0) {  // ... one pixel up: its last row is empty
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+#pragma unroll
+                            for (int c = 0; c < BWD_CW; ++c) {
+                                acc[k][6 + q][c] = acc[k][3 + q][c];
+                                acc[k][3 + q][c] = acc[k][q][c];
+                                acc[k][q][c] = 0.0f;
+                            }
+                        run_cells[k] = (run_cells[k] << 3) & 0770u;
+                        by -= 1; oy = 0;
+                    }
+                }
+                run_key[k] = (by + 2) | ((bx + 2) << 13);
+                // weights of the block's three rows / columns
+                const float cw = wok ? fe : 0.0f, ce = eok ? fw : 0.0f;
+                const float rn = nok ? fs : 0.0f, rs = sok ? fn : 0.0f;
+                const bool xlo = ox == 0, ylo = oy == 0;
+                const float cx[3] = {xlo ? cw : 0.0f, xlo ? ce : cw, xlo ? 0.0f : ce};
+                const float ry[3] = {ylo ? rn : 0.0f, ylo ? rs : rn, ylo ? 0.0f : rs};
+                const uint32_t mx = xlo ? ((wok ? 1u : 0u) | (eok ? 2u : 0u)) : ((wok ? 2u : 0u) | (eok ? 4u : 0u));
+                const uint32_t my = ylo ? ((nok ? 1u : 0u) | (sok ? 2u : 0u)) : ((nok ? 2u : 0u) | (sok ? 4u : 0u));
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    if (my & (1u << r)) run_cells[k] |= mx << (3 * r);
+                float gvf[BWD_CW];
+#pragma unroll
+                for (int c = 0; c < BWD_CW; ++c) gvf[c] = c < nc ? elem<T>::load(src[k][c]) : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const float wgt = ry[r] * cx[q];
+#pragma unroll
+                        for (int c = 0; c < BWD_CW; ++c)
+                            acc[k][3 * r + q][c] = __builtin_fmaf(gvf[c], wgt, acc[k][3 * r + q][c]);
+                    }
+            }
+        };
+        fetch(d_lo, gv[0]);
+        for (int d = d_lo; d < d_hi; d += 2) {
+            if (d + 1 < d_hi) fetch(d + 1, gv[1]);
+            plane(d, gv[0]);
+            if (d + 1 < d_hi) {
+                if (d + 2 < d_hi) fetch(d + 2, gv[0]);
+                plane(d + 1, gv[1]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BWD_PPL; ++k) scatter_run(k);
+        if (y0 >= 0) {
+            __syncthreads();
+            flush();
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void sweep_bwd_tile_kernel(
+    SweepGeom g, SweepFast fast, BwdGrid tg, const T *__restrict__ gout,
+    const float *__restrict__ depths, const float *__restrict__ P,
+    const float *__restrict__ Pinv, const float *__restrict__ Tm, float *__restrict__ gcur,
+    float *__restrict__ gprev)
+{
+    extern __shared__ __attribute__((aligned(16))) float bwd_slab[];
+    __shared__ int yr[2 * BWD_MAXP];
+    // block id = ((band*2 + half)*dchunks + dchunk)*batch + b
+    int th = blockIdx.x;
+    const int b = th % tg.batch;
+    th /= tg.batch;
+    const int dchunk = th % tg.dchunks;
+    th /= tg.dchunks;
+    const int half = th & 1;
+    const int band = th >> 1;
+    if (half)
+        bwd_tile_body<T, 1>(g, fast, tg, b, band, dchunk, gout, depths, P, Pinv, Tm, gprev, bwd_slab, yr);
+    else
+        bwd_tile_body<T, 0>(g, fast, tg, b, band, dchunk, gout, depths, P, Pinv, Tm, gcur, bwd_slab, yr);
+}
+
+// ---------------------------------------------------------------------------
 // parity aid: normalised grids of sample b
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sweep_grid_kernel(SweepGeom g, int b,
@@ -976,10 +1281,51 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
     if (!grad_out || !depths || !cam2img || !cam2img_inv || !cur2prev || !grad_cur || !grad_prev)
         return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
     const SweepGeom g = make_geom(desc);
+    hipStream_t st = (hipStream_t)stream;
+    // dense sweeps whose feature rows fit the LDS: accumulate there (see sweep_bwd_tile_kernel)
+    const int lds_budget = 80 * 1024;  // two workgroups per CU
+    const int rows = std::min((long long)desc->h_in,
+                              (long long)lds_budget / ((long long)BWD_CW * desc->w_in * 4));
+    const long long hw = (long long)g.h_out * g.w_out;
+    if (g_force_kernel != 1 && desc->cost_sample_factor < 1.5f && rows >= 4 && desc->h_in < 4096 &&
+        desc->w_in < 8192) {
+        BwdGrid tg;
+        tg.batch = desc->batch;
+        tg.band_pts = 256 * BWD_PPL;
+        tg.bands = (int)((hw + tg.band_pts - 1) / tg.band_pts);
+        tg.planes = std::max(1, std::min(BWD_MAXP, (g.D + 3) / 4));
+        tg.dchunks = (g.D + tg.planes - 1) / tg.planes;
+        tg.rows = rows;
+        const long long nb = (long long)tg.bands * 2 * tg.dchunks * desc->batch;
+        if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
+        const int lds_bytes = BWD_CW * rows * desc->w_in * 4;
+        SweepFast fast;
+        fast.scale_is_one = desc->img_scale_factor == 1.0f;
+        {
+            int e = 0;
+            const float m = frexpf(desc->feat_sample_factor, &e);
+            fast.fsf_pow2 = (m == 0.5f) && e > -60 && e < 60;
+            fast.inv_fsf = 1.0f / desc->feat_sample_factor;
+        }
+        if (desc->dtype == DFM_F32) {
+            HIP_TRY(hipFuncSetAttribute((const void *)sweep_bwd_tile_kernel<float>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            hipLaunchKernelGGL(sweep_bwd_tile_kernel<float>, dim3((unsigned)nb), dim3(256), lds_bytes,
+                               st, g, fast, tg, (const float *)grad_out, depths, cam2img, cam2img_inv,
+                               cur2prev, grad_cur, grad_prev);
+        } else {
+            HIP_TRY(hipFuncSetAttribute((const void *)sweep_bwd_tile_kernel<bf16_t>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            hipLaunchKernelGGL(sweep_bwd_tile_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), lds_bytes,
+                               st, g, fast, tg, (const bf16_t *)grad_out, depths, cam2img,
+                               cam2img_inv, cur2prev, grad_cur, grad_prev);
+        }
+        HIP_TRY(hipGetLastError());
+        return DFM_OK;
+    }
     const long long nb = (g.N + 255) / 256;
     if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
     dim3 grid((unsigned)nb, desc->batch);
-    hipStream_t st = (hipStream_t)stream;
     if (desc->dtype == DFM_F32)
         hipLaunchKernelGGL(sweep_bwd_kernel<float>, grid, dim3(256), 0, st, g,
                            (const float *)grad_out, depths, cam2img, cam2img_inv, cur2prev,

@@ -10,8 +10,10 @@
 //
 // Layout in HBM
 //   feats     : caller tensor (F*Nv, C, Hf, Wf), f32 or bf16
-//   workspace : the same re-blocked to [F*Nv][C/CB][Hf][Wf][CB], CB*sizeof(T)=16 B
-//               (one 16-byte load = CB channels of the sampled pixel)
+//   workspace : the same, pixel-major [F*Nv][Hf][Wf][Cp] (Cp = C rounded up to a whole
+//               16-byte channel block): the sampling is sparse (neighbouring voxels hit
+//               pixels several columns apart), so a tap should be ONE contiguous run
+//               of Cp*sizeof(T) bytes, not C/CB pieces a plane apart
 //   out       : volume (C*F', Nx, Ny, Nz) or flat (N, C)
 // Bound: HBM write of the volume + L2-resident gathers; no reuse to stage.
 #include "dfm_common.h"
@@ -31,27 +33,6 @@ struct MvGeom {
     float scale_x, scale_y, crop_x, crop_y, pad_h, pad_w;
     int32_t flip, mode, aggregate, valid_sample;
 };
-
-template <typename T>
-__global__ __launch_bounds__(256) void pack_views_kernel(const T *__restrict__ src,
-                                                         uint4 *__restrict__ dst, int C, int HW,
-                                                         int nblk)
-{
-    constexpr int CB = elem<T>::CB;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int blk = blockIdx.y;
-    const int b = blockIdx.z;
-    if (pix >= HW) return;
-    T v[CB];
-#pragma unroll
-    for (int j = 0; j < CB; ++j) {
-        const int c = blk * CB + j;
-        v[j] = (c < C) ? src[((size_t)b * C + c) * HW + pix] : T(0);
-    }
-    uint4 q;
-    memcpy(&q, v, 16);
-    dst[((size_t)b * nblk + blk) * HW + pix] = q;
-}
 
 // projection + image transform of one point into one view; returns validity
 // (point_fusion.py:61-84,99-101) and the normalised grid coordinates
@@ -73,7 +54,11 @@ __device__ __forceinline__ bool project_view(const MvGeom &g, const float *__res
     return (x < g.pad_w) && (x > 0.0f) && (y < g.pad_h) && (y > 0.0f) && (c > 0.0f);
 }
 
-// one thread = one voxel (output order) ; loops channel blocks, frames, views
+// one thread = one voxel (output order).  32 channels (NB 16-byte blocks) are
+// accumulated per pass so every (frame, view) is projected once per pass, and the NB
+// loads of a tap are adjacent.  Per channel the additions run in the reference's
+// order (views, then frames); a skipped out-of-image tap adds nothing, which equals
+// adding its zeros (the accumulators start at +0 and can never become -0).
 template <typename T>
 __global__ __launch_bounds__(256) void mv_sample_kernel(
     MvGeom g, const uint4 *__restrict__ feats, const float *__restrict__ points,
@@ -81,6 +66,7 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
     unsigned char *__restrict__ valid_out)
 {
     constexpr int CB = elem<T>::CB;
+    constexpr int NB = 32 / CB;
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
     if (o >= g.N) return;
     long long pidx = o;
@@ -93,82 +79,89 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
     }
     const float px = points[3 * pidx], py = points[3 * pidx + 1], pz = points[3 * pidx + 2];
     const int HW = g.Hf * g.Wf;
-    const int nvf = g.num_views * g.num_frames;
     const size_t chan_stride = g.nz > 0 ? (size_t)g.N : 1;  // volume: (C, N) ; flat: (N, C)
     T *obase = g.nz > 0 ? out + o : out + (size_t)o * g.C * (g.aggregate ? g.num_frames : 1);
-    const int c_out = g.C * (g.aggregate ? g.num_frames : 1);
 
-    // valid counts do not depend on the channel block
-    int cnt_total = 0;
-    for (int i = 0; i < nvf; ++i) {
-        float nx, ny;
-        cnt_total += project_view(g, proj + 16 * i, ori_w[i], px, py, pz, nx, ny) ? 1 : 0;
-    }
-    if (valid_out) valid_out[o] = cnt_total > 0;
-
-    for (int blk = 0; blk < g.nblk; ++blk) {
-        float tot[CB];
+    for (int blk0 = 0; blk0 < g.nblk; blk0 += NB) {
+        float tot[NB][CB];
 #pragma unroll
-        for (int k = 0; k < CB; ++k) tot[k] = 0.0f;
-        int tot_cnt = 0;
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int k = 0; k < CB; ++k) tot[j][k] = 0.0f;
+        int tot_cnt = 0, nvalid = 0;
         for (int f = 0; f < g.num_frames; ++f) {
-            float acc[CB];
+            float acc[NB][CB];
 #pragma unroll
-            for (int k = 0; k < CB; ++k) acc[k] = 0.0f;
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int k = 0; k < CB; ++k) acc[j][k] = 0.0f;
             int cnt = 0;
             for (int v = 0; v < g.num_views; ++v) {
                 const int i = f * g.num_views + v;
                 float nx, ny;
                 const bool ok = project_view(g, proj + 16 * i, ori_w[i], px, py, pz, nx, ny);
+                nvalid += ok ? 1 : 0;
                 if (g.valid_sample && !ok) continue;  // valid_features[~valid] = 0
                 ++cnt;
                 const float x = ((nx + 1.0f) * 0.5f) * (float)(g.Wf - 1);
                 const float y = ((ny + 1.0f) * 0.5f) * (float)(g.Hf - 1);
-                const uint4 *fb = feats + ((size_t)i * g.nblk + blk) * HW;
-                float r[CB];
+                const uint4 *fb = feats + (size_t)i * HW * g.nblk + blk0;
                 if (g.mode == 0) {
                     // nearest: nearbyint (round half to even), zeros outside
                     const float xr = rintf(x), yr = rintf(y);
                     const bool in = (fabsf(x) <= 3.0e38f) && (fabsf(y) <= 3.0e38f) && xr >= 0.0f &&
                                     xr <= (float)(g.Wf - 1) && yr >= 0.0f && yr <= (float)(g.Hf - 1);
-                    if (in) {
-                        unpack16(fb[(int)yr * g.Wf + (int)xr], r);
-                    } else {
+                    if (!in) continue;
+                    const uint4 *p = fb + (size_t)((int)yr * g.Wf + (int)xr) * g.nblk;
 #pragma unroll
-                        for (int k = 0; k < CB; ++k) r[k] = 0.0f;
+                    for (int j = 0; j < NB; ++j) {
+                        if (blk0 + j < g.nblk) {
+                            float r[CB];
+                            unpack16(p[j], r);
+#pragma unroll
+                            for (int k = 0; k < CB; ++k) acc[j][k] = acc[j][k] + r[k];  // stack(views).sum(0)
+                        }
                     }
                 } else {
                     const Tap t = make_tap(x, y, g.Hf, g.Wf);
                     const int i00 = t.iy * g.Wf + t.ix, i01 = i00 + t.dx;
                     const int i10 = i00 + t.dy * g.Wf, i11 = i10 + t.dx;
-                    const uint4 q0 = fb[i00], q1 = fb[i01], q2 = fb[i10], q3 = fb[i11];
-                    float a[CB], b2[CB], c2[CB], d2[CB];
-                    unpack16(q0, a); unpack16(q1, b2); unpack16(q2, c2); unpack16(q3, d2);
 #pragma unroll
-                    for (int k = 0; k < CB; ++k) {
-                        const float vnw = (t.ok & 1u) ? a[k] : 0.0f, vne = (t.ok & 2u) ? b2[k] : 0.0f;
-                        const float vsw = (t.ok & 4u) ? c2[k] : 0.0f, vse = (t.ok & 8u) ? d2[k] : 0.0f;
-                        float s = vnw * t.nw;
-                        s = __builtin_fmaf(vne, t.ne, s);
-                        s = __builtin_fmaf(vsw, t.sw, s);
-                        s = __builtin_fmaf(vse, t.se, s);
-                        r[k] = s;
+                    for (int j = 0; j < NB; ++j) {
+                        if (blk0 + j >= g.nblk) continue;
+                        const uint4 q0 = fb[(size_t)i00 * g.nblk + j], q1 = fb[(size_t)i01 * g.nblk + j];
+                        const uint4 q2 = fb[(size_t)i10 * g.nblk + j], q3 = fb[(size_t)i11 * g.nblk + j];
+                        float a[CB], b2[CB], c2[CB], d2[CB];
+                        unpack16(q0, a); unpack16(q1, b2); unpack16(q2, c2); unpack16(q3, d2);
+#pragma unroll
+                        for (int k = 0; k < CB; ++k) {
+                            const float vnw = (t.ok & 1u) ? a[k] : 0.0f, vne = (t.ok & 2u) ? b2[k] : 0.0f;
+                            const float vsw = (t.ok & 4u) ? c2[k] : 0.0f, vse = (t.ok & 8u) ? d2[k] : 0.0f;
+                            float s = vnw * t.nw;
+                            s = __builtin_fmaf(vne, t.ne, s);
+                            s = __builtin_fmaf(vsw, t.sw, s);
+                            s = __builtin_fmaf(vse, t.se, s);
+                            acc[j][k] = acc[j][k] + s;
+                        }
                     }
                 }
-#pragma unroll
-                for (int k = 0; k < CB; ++k) acc[k] = acc[k] + r[k];  // stack(views).sum(0)
             }
             if (g.aggregate) {
                 // 'concat': per-frame mean over its valid views, multiview_dfm.py:196-203
                 const float den = (float)max(cnt, 1);
 #pragma unroll
-                for (int k = 0; k < CB; ++k) {
-                    const int c = blk * CB + k;
-                    if (c < g.C) obase[(size_t)(f * g.C + c) * chan_stride] = elem<T>::store(acc[k] / den);
-                }
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int k = 0; k < CB; ++k) {
+                        const int c = (blk0 + j) * CB + k;
+                        if (c < g.C)
+                            obase[(size_t)(f * g.C + c) * chan_stride] = elem<T>::store(acc[j][k] / den);
+                    }
             } else {
 #pragma unroll
-                for (int k = 0; k < CB; ++k) tot[k] = tot[k] + acc[k];  // stack(frames).sum(0)
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int k = 0; k < CB; ++k) tot[j][k] = tot[j][k] + acc[j][k];  // stack(frames).sum(0)
                 tot_cnt += cnt;
             }
         }
@@ -176,13 +169,15 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
             // 'mean': sum over frames / clamp(total valid, 1), multiview_dfm.py:188-195
             const float den = (float)max(tot_cnt, 1);
 #pragma unroll
-            for (int k = 0; k < CB; ++k) {
-                const int c = blk * CB + k;
-                if (c < g.C) obase[(size_t)c * chan_stride] = elem<T>::store(tot[k] / den);
-            }
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int k = 0; k < CB; ++k) {
+                    const int c = (blk0 + j) * CB + k;
+                    if (c < g.C) obase[(size_t)c * chan_stride] = elem<T>::store(tot[j][k] / den);
+                }
         }
+        if (valid_out && blk0 == 0) valid_out[o] = nvalid > 0;
     }
-    (void)c_out;
 }
 
 }  // namespace
@@ -233,17 +228,18 @@ DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *d, const void *feats, con
     hipStream_t st = (hipStream_t)stream;
     const int HW = d->feat_h * d->feat_w;
     const int nvf = d->num_views * d->num_frames;
-    dim3 pg((HW + 255) / 256, g.nblk, nvf);
+    const int Cp = g.nblk * CB;
+    dim3 pg((HW + 63) / 64, (Cp + 31) / 32, nvf);
     const long long nb = (g.N + 255) / 256;
     if (nb > 2147483647ll) return fail_ps(DFM_ERR_UNSUPPORTED, "too many points");
     if (d->dtype == DFM_F32) {
-        hipLaunchKernelGGL(pack_views_kernel<float>, pg, dim3(256), 0, st, (const float *)feats,
-                           (uint4 *)workspace, g.C, HW, g.nblk);
+        hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg, dim3(256), 0, st,
+                           (const float *)feats, (float *)workspace, g.C, Cp, (long long)HW);
         hipLaunchKernelGGL(mv_sample_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, g,
                            (const uint4 *)workspace, points, proj, ori_w, (float *)out, valid_out);
     } else {
-        hipLaunchKernelGGL(pack_views_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t *)feats,
-                           (uint4 *)workspace, g.C, HW, g.nblk);
+        hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg, dim3(256), 0, st,
+                           (const bf16_t *)feats, (bf16_t *)workspace, g.C, Cp, (long long)HW);
         hipLaunchKernelGGL(mv_sample_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, g,
                            (const uint4 *)workspace, points, proj, ori_w, (bf16_t *)out, valid_out);
     }

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .plane_sweep import _DTYPES, _ptr, _require_gpu, _stream_ptr
+from .plane_sweep import _DTYPES, _Workspace, _ptr, _require_gpu, _stream_ptr
 
 
 class _F2vFn(torch.autograd.Function):
@@ -19,12 +19,15 @@ class _F2vFn(torch.autograd.Function):
         device = stereo.device
         out = torch.empty((desc.batch, desc.channels + desc.sem_channels, desc.nz, desc.ny, desc.nx),
                           dtype=stereo.dtype, device=device)
+        nbytes = lib.dfm_frustum_to_voxel_workspace_bytes(ctypes.byref(desc))
+        ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
             _capi.check(
                 lib.dfm_frustum_to_voxel_fwd(ctypes.byref(desc), _ptr(stereo),
                                              _ptr(soft) if soft is not None else None,
                                              _ptr(sem) if sem is not None else None, _ptr(coords),
-                                             _ptr(cam4), _ptr(out), _stream_ptr(device)))
+                                             _ptr(cam4), _ptr(out), _ptr(ws), nbytes,
+                                             _stream_ptr(device)))
         ctx.desc = desc
         ctx.has_sem = sem is not None
         ctx.shapes = (stereo.shape, None if sem is None else sem.shape, stereo.dtype)

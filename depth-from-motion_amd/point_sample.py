@@ -49,17 +49,15 @@ def _crop_xy(img_crop_offset):
     return float(img_crop_offset), float(img_crop_offset)
 
 
-def _launch(feats, points, proj, ori_w, nxyz, num_views, num_frames, scale, crop, flip, pad_shape,
-            aligned, aggregate, valid_sample, want_valid):
-    lib = _capi.lib()
-    device = feats.device
-    nvf, C, Hf, Wf = feats.shape
+def _make_desc(feats, npoints, nxyz, num_views, num_frames, scale, crop, flip, pad_shape, aligned,
+               aggregate, valid_sample):
+    nvf, C, Hf, Wf = feats.shape[-4:]
     assert nvf == num_views * num_frames
     desc = _capi.MvDesc()
     desc.num_views, desc.num_frames, desc.channels = num_views, num_frames, C
     desc.feat_h, desc.feat_w = Hf, Wf
     desc.nx, desc.ny, desc.nz = nxyz if nxyz is not None else (0, 0, 0)
-    desc.num_points = points.shape[0]
+    desc.num_points = npoints
     desc.scale_x, desc.scale_y = scale
     desc.crop_x, desc.crop_y = crop
     desc.flip = 1 if flip else 0
@@ -68,30 +66,35 @@ def _launch(feats, points, proj, ori_w, nxyz, num_views, num_frames, scale, crop
     desc.aggregate = 1 if aggregate == 'concat' else 0
     desc.valid_sample = 1 if valid_sample else 0
     desc.dtype = _DTYPES[feats.dtype]
-    return _MvFn.apply(feats, points, proj, ori_w, desc, nxyz, want_valid)
+    return desc
 
 
 class _MvFn(torch.autograd.Function):
+    """feats (B, F*Nv, C, Hf, Wf); one launch per sample (its own image transform in
+    ``descs[b]``) straight into one (B, ...) output; proj (B, F*Nv, 16), ori_w (B, F*Nv)."""
 
     @staticmethod
-    def forward(ctx, feats, points, proj, ori_w, desc, nxyz, want_valid):
+    def forward(ctx, feats, points, proj, ori_w, descs, nxyz, want_valid):
         lib = _capi.lib()
         device = feats.device
-        c_out = desc.channels * (desc.num_frames if desc.aggregate else 1)
+        B = feats.shape[0]
+        d0 = descs[0]
+        c_out = d0.channels * (d0.num_frames if d0.aggregate else 1)
         if nxyz is not None:
-            out = torch.empty((c_out,) + tuple(nxyz), dtype=feats.dtype, device=device)
+            out = torch.empty((B, c_out) + tuple(nxyz), dtype=feats.dtype, device=device)
         else:
-            out = torch.empty((points.shape[0], c_out), dtype=feats.dtype, device=device)
-        valid = torch.empty(points.shape[0], dtype=torch.uint8, device=device) if want_valid else None
-        nbytes = lib.dfm_point_sample_mv_workspace_bytes(ctypes.byref(desc))
+            out = torch.empty((B, points.shape[0], c_out), dtype=feats.dtype, device=device)
+        valid = torch.empty((B, points.shape[0]), dtype=torch.uint8, device=device) if want_valid else None
+        nbytes = lib.dfm_point_sample_mv_workspace_bytes(ctypes.byref(d0))
         ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
-            _capi.check(
-                lib.dfm_point_sample_mv_fwd(ctypes.byref(desc), _ptr(feats), _ptr(points), _ptr(proj),
-                                            _ptr(ori_w), _ptr(out),
-                                            _ptr(valid) if want_valid else None, _ptr(ws), nbytes,
-                                            _stream_ptr(device)))
-        ctx.desc = desc
+            for b in range(B):
+                _capi.check(
+                    lib.dfm_point_sample_mv_fwd(ctypes.byref(descs[b]), _ptr(feats[b]), _ptr(points),
+                                                _ptr(proj[b]), _ptr(ori_w[b]), _ptr(out[b]),
+                                                _ptr(valid[b]) if want_valid else None, _ptr(ws),
+                                                nbytes, _stream_ptr(device)))
+        ctx.descs = descs
         ctx.meta = (feats.shape, feats.dtype)
         ctx.save_for_backward(points, proj, ori_w)
         if want_valid:
@@ -107,9 +110,11 @@ class _MvFn(torch.autograd.Function):
         go = grad_out.contiguous().to(dtype)
         gf = torch.zeros(shape, dtype=torch.float32, device=device)
         with torch.cuda.device(device):
-            _capi.check(
-                lib.dfm_point_sample_mv_bwd(ctypes.byref(ctx.desc), _ptr(go), _ptr(points), _ptr(proj),
-                                            _ptr(ori_w), _ptr(gf), _stream_ptr(device)))
+            for b in range(shape[0]):
+                _capi.check(
+                    lib.dfm_point_sample_mv_bwd(ctypes.byref(ctx.descs[b]), _ptr(go[b]), _ptr(points),
+                                                _ptr(proj[b]), _ptr(ori_w[b]), _ptr(gf[b]),
+                                                _stream_ptr(device)))
         return gf.to(dtype), None, None, None, None, None, None
 
 
@@ -140,12 +145,12 @@ def point_sample(img_meta,
     pts = torch.as_tensor(points, dtype=torch.float32).to(device).contiguous()
     proj = torch.as_tensor(proj_mat, dtype=torch.float32).reshape(1, 16).to(device).contiguous()
     ori_w = torch.tensor([float(img_shape[1])], dtype=torch.float32, device=device)
-    out, valid = _launch(feats, pts, proj, ori_w, None, 1, 1, _scale_xy(img_scale_factor),
-                         _crop_xy(img_crop_offset), img_flip, img_pad_shape, aligned, 'mean',
-                         valid_flag, valid_flag)
+    desc = _make_desc(feats, pts.shape[0], None, 1, 1, _scale_xy(img_scale_factor),
+                      _crop_xy(img_crop_offset), img_flip, img_pad_shape, aligned, 'mean', valid_flag)
+    out, valid = _MvFn.apply(feats[None], pts, proj[None], ori_w[None], [desc], None, valid_flag)
     if valid_flag:
-        return out, valid.bool()
-    return out
+        return out[0], valid[0].bool()
+    return out[0]
 
 
 def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, voxel_range, n_voxels,
@@ -158,8 +163,10 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
         points = voxel_centers(voxel_range, n_voxels)
     points = torch.as_tensor(points, dtype=torch.float32).to(device).contiguous()
     nxyz = tuple(int(v) for v in n_voxels)
-    vols = []
-    for feature, img_meta in zip(batch_feats, img_metas):
+    nvf = num_views * num_frames
+    feats = batch_feats.contiguous()
+    descs, proj, ori_w = [], [], []
+    for img_meta in img_metas:
         if 'scale_factor' in img_meta:
             sf = img_meta['scale_factor']
             scale = _scale_xy(sf[:2] if isinstance(sf, np.ndarray) and len(sf) >= 2 else sf)
@@ -167,16 +174,15 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
             scale = (1.0, 1.0)
         flip = img_meta.get('flip', False)
         crop = _crop_xy(img_meta['img_crop_offset']) if 'img_crop_offset' in img_meta else (0.0, 0.0)
-        nvf = num_views * num_frames
-        proj = torch.as_tensor(np.asarray(img_meta['ori_lidar2img'][:nvf], dtype=np.float32)
-                               ).reshape(nvf, 16).to(device)
-        ori_w = torch.tensor([float(img_meta['img_shape'][i][1]) for i in range(nvf)],
-                             dtype=torch.float32, device=device)
-        out, _ = _launch(feature.contiguous(), points, proj, ori_w, nxyz, num_views, num_frames,
-                         scale, crop, flip, img_meta['input_shape'], False, temporal_aggregate,
-                         True, False)
-        vols.append(out)
-    return torch.stack(vols)
+        proj.append(np.asarray(img_meta['ori_lidar2img'][:nvf], dtype=np.float32).reshape(nvf, 16))
+        ori_w.append([float(img_meta['img_shape'][i][1]) for i in range(nvf)])
+        descs.append(_make_desc(feats, points.shape[0], nxyz, num_views, num_frames, scale, crop,
+                                flip, img_meta['input_shape'], False, temporal_aggregate, True))
+    # one upload for the whole batch's matrices
+    proj = torch.from_numpy(np.stack(proj)).to(device)
+    ori_w = torch.tensor(ori_w, dtype=torch.float32).to(device)
+    out, _ = _MvFn.apply(feats, points, proj, ori_w, descs, nxyz, False)
+    return out
 
 
 def voxel_sample(voxel_features,

@@ -236,10 +236,15 @@ typedef struct dfm_f2v_desc {
  * out      : (B, C + Cs, nz, ny, nx) = cat(Voxel, Voxel_2D) of the reference,
  *            the input of voxel_convs (sem_atten_feat=True,
  *            stereo_atten_feat=False: the shipped config)
+ * workspace: >= dfm_frustum_to_voxel_workspace_bytes(desc) bytes, 256-byte
+ *            aligned; holds stereo_feat and cur_sem_feats re-laid pixel-major
+ *            ([d][h][w][C], [h][w][Cs]) for this call                  [device]
  */
+DFM_API size_t dfm_frustum_to_voxel_workspace_bytes(const dfm_f2v_desc *desc);
 DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *desc, const void *stereo,
                                      const void *softmax, const void *sem, const float *coords,
-                                     const float *cam2img, void *out, void *stream);
+                                     const float *cam2img, void *out, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 /* Backward w.r.t. stereo_feat and cur_sem_feats (the depth distribution is
  * detached in the reference, :136).  grad_out: (B, C+Cs, nz, ny, nx) dtype;
  * grad_stereo (B,C,d,h,w) and grad_sem (B,Cs,hsem,wsem): FP32, zero-filled by

@@ -85,3 +85,18 @@ def test_hip_bf16_storage():
     np.testing.assert_allclose(got_soft, orc.bf16_round(p), rtol=8e-3, atol=1e-9)  # <= 2 bf16 ulp
     exp_pred = (got_soft * z['depth_samples'][None, None, :, None, None]).sum(2)
     np.testing.assert_allclose(pred.float().cpu().numpy(), exp_pred, rtol=5e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('scale,shape', [(2, (1, 1, 5, 4, 7)), (3, (2, 1, 4, 3, 5)), (1, (1, 1, 6, 5, 9))])
+def test_hip_one_pixel_per_lane_path_vs_oracle(scale, shape):
+    """row lengths that are not a multiple of 4 take the scalar-store instantiation"""
+    pkg = importlib.import_module('depth-from-motion_amd')
+    rng = np.random.RandomState(scale)
+    x = (rng.randn(*shape) * 3).astype(np.float32)
+    ds = np.linspace(2.0, 59.6, scale * shape[2]).astype(np.float32)
+    vol, soft, pred = pkg.depth_head_forward(torch.from_numpy(x).cuda(), torch.from_numpy(ds), scale)
+    ovol, osoft, opred = orc.depth_head(x, ds, scale)
+    assert np.array_equal(util.bits(vol.cpu().numpy()), util.bits(ovol))
+    np.testing.assert_allclose(soft.cpu().numpy(), osoft, **SOFT_TOL)
+    np.testing.assert_allclose(pred.cpu().numpy(), opred, **PRED_TOL)

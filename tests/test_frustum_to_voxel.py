@@ -120,3 +120,31 @@ def test_geometry_tables_match_the_reference_generators():
     zd = np.load(os.path.join(util.GOLDEN, 'depth_head_wide.npz'))
     _, full72 = pkg.prepare_depth(dict(num_bins=72, depth_min=2, depth_max=59.6, downsample_factor=4))
     assert np.array_equal(util.bits(full72.numpy()), util.bits(zd['depth_samples']))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('C,Cs', [(8, 16), (40, 8), (16, 0)])
+def test_hip_pixel_major_path_vs_oracle(dtype, C, Cs):
+    """channel counts that are whole 16-byte blocks (fp32: 4, bf16: 8) take the
+    pixel-major staged kernel, also with more than one 32-channel pass (C=40)"""
+    rng = np.random.RandomState(C + Cs)
+    D, H, W = 6, 10, 32
+    base = np.load(os.path.join(util.GOLDEN, 'f2v_small.npz'))
+    z = dict(stereo=rng.randn(2, C, D, H, W).astype(np.float32),
+             softmax=torch.softmax(torch.from_numpy(rng.randn(2, 1, 4 * D, 4 * H, 4 * W).astype(np.float32)),
+                                   dim=2).numpy(),
+             sem=rng.randn(2, max(Cs, 1), H, W).astype(np.float32),
+             coordinates_3d=base['coordinates_3d'], cam2img=np.repeat(base['cam2img'], 2, 0),
+             pad_shape=base['pad_shape'], depth_min=base['depth_min'], depth_max=base['depth_max'])
+    z['cam2img'][1, 0, 2] += 3.0
+    if dtype == torch.bfloat16:
+        for k in ('stereo', 'softmax', 'sem'):
+            z[k] = orc.bf16_round(z[k])
+    ref = oracle_run(z, sem=Cs > 0)
+    out = hip_run(z, dtype, sem=Cs > 0).float().cpu().numpy()
+    if dtype == torch.bfloat16:
+        ref = orc.bf16_round(ref)
+    assert out.shape[1] == C + Cs
+    assert np.array_equal(util.bits(out), util.bits(ref))
+    assert 0.05 < (ref != 0).mean()

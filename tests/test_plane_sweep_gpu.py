@@ -180,26 +180,31 @@ def test_north_star_shape_slices_and_properties(pkg):
     assert torch.equal(outi[:, :C], outi[:, C:])
 
 
-def test_backward_matches_torch_cpu_autograd(pkg):
-    rng = np.random.RandomState(5)
-    B, C, H, W, D = 2, 6, 20, 64, 3
+def _check_backward(pkg, B, C, H, W, D, fsf, csf, crop, seed, img_shape, dtype=torch.float32,
+                    tol=dict(rtol=1e-4, atol=1e-5), t_z=None):
+    rng = np.random.RandomState(seed)
     cur = rng.randn(B, C, H, W).astype(np.float32)
     prev = rng.randn(B, C, H, W).astype(np.float32)
     P = np.stack([util.KITTI_P2] * B)
-    T = util.random_poses(B, seed=9)
+    T = util.random_poses(B, seed=seed + 4)
+    if t_z is not None:
+        T[:, 2, 3] = t_z  # strong forward motion: the prev footprint drifts across rows with depth
     Pinv = util.host_inverse(P)
     depths = util.depth_planes(D)
-    gout = rng.randn(B, 2 * C, D, H // 2, W // 2).astype(np.float32)
+    ho, wo = round(H / csf), round(W / csf)
+    gout = rng.randn(B, 2 * C, D, ho, wo).astype(np.float32)
+    if dtype == torch.bfloat16:
+        gout = orc.bf16_round(gout)
     dev = torch.device('cuda:0')
-    c = torch.from_numpy(cur).to(dev).requires_grad_(True)
-    p = torch.from_numpy(prev).to(dev).requires_grad_(True)
-    out = pkg.build_dfm_cost(c, p, torch.from_numpy(depths).to(dev), 8, 2, torch.from_numpy(P),
-                             torch.from_numpy(T), (375, 1242), False, (3, 5), 1.0)
-    out.backward(torch.from_numpy(gout).to(dev))
+    c = torch.from_numpy(cur).to(dev).to(dtype).requires_grad_(True)
+    p = torch.from_numpy(prev).to(dev).to(dtype).requires_grad_(True)
+    out = pkg.build_dfm_cost(c, p, torch.from_numpy(depths).to(dev), fsf, csf, torch.from_numpy(P),
+                             torch.from_numpy(T), img_shape, False, crop, 1.0)
+    out.backward(torch.from_numpy(gout).to(dev).to(dtype))
     torch.cuda.synchronize()
     # reference gradient: torch CPU autograd through grid_sample on the oracle's grids
     for b in range(B):
-        prm = orc.sweep_params(H, W, D, 8, 2, P[b], Pinv[b], T[b], (375, 1242), False, (3, 5), 1.0)
+        prm = orc.sweep_params(H, W, D, fsf, csf, P[b], Pinv[b], T[b], img_shape, False, crop, 1.0)
         cg, pg = orc.plane_sweep_grid(prm, depths)
         for feats, grid, got, sl in ((cur, cg, c.grad, slice(0, C)), (prev, pg, p.grad, slice(C, 2 * C))):
             f = torch.from_numpy(feats[b:b + 1]).requires_grad_(True)
@@ -207,8 +212,33 @@ def test_backward_matches_torch_cpu_autograd(pkg):
                                                 mode='bilinear', padding_mode='zeros',
                                                 align_corners=True)
             o.backward(torch.from_numpy(gout[b:b + 1, sl]).reshape(o.shape))
-            np.testing.assert_allclose(got[b].cpu().numpy(), f.grad[0].numpy(), rtol=1e-4,
-                                       atol=1e-5)
+            ref = f.grad[0].numpy()
+            assert np.abs(ref).max() > 0.1
+            np.testing.assert_allclose(got[b].float().cpu().numpy(), ref, **tol)
+
+
+def test_backward_matches_torch_cpu_autograd(pkg):
+    """strided sweep (cost_sample_factor 2): lane-per-point scatter kernel"""
+    _check_backward(pkg, 2, 6, 20, 64, 3, 8, 2, (3, 5), 5, (375, 1242))
+
+
+@pytest.mark.parametrize('case', [
+    # dense sweeps: LDS-accumulating tile kernel (unless the mode forces the scatter kernel)
+    dict(B=2, C=11, H=24, W=96, D=9, fsf=4, csf=1, crop=(0, 0), seed=1, img_shape=(96, 384)),
+    # 4-row slab window (wide rows) + strong forward motion: window rebasing and taps
+    # outside the window
+    dict(B=1, C=8, H=14, W=640, D=7, fsf=2, csf=1, crop=(2, 1), seed=2, img_shape=(28, 1280),
+         t_z=-1.9),
+    # more than one depth chunk, partial last band
+    dict(B=1, C=3, H=37, W=53, D=41, fsf=4, csf=1, crop=(0, 0), seed=3, img_shape=(148, 212)),
+], ids=['small', 'wide_rows', 'deep'])
+def test_backward_dense_sweep_matches_torch_cpu_autograd(pkg, case):
+    _check_backward(pkg, **case)
+
+
+def test_backward_bf16_gradients(pkg):
+    _check_backward(pkg, 1, 8, 24, 96, 9, 4, 1, (0, 0), 7, (96, 384), dtype=torch.bfloat16,
+                    tol=dict(rtol=2e-2, atol=2e-2))
 
 
 def test_type_and_shape_errors(pkg):
