@@ -246,6 +246,8 @@ def main():
     ap.add_argument('--planes', type=int, default=0, help='LDS kernel depth planes per workgroup')
     ap.add_argument('--band-chunk', type=int, default=0,
                     help='LDS kernel: adjacent bands scheduled back to back (default 1)')
+    ap.add_argument('--channels-last', action='store_true',
+                    help='write the volume (B,D,H,W,2C) (memory_format channels_last_3d)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass')
@@ -289,10 +291,16 @@ def main():
     desc = sweep._make_desc(cur, w['D'], w['fsf'], w['csf'], (375, 1242), False, w['crop'], 1.0)
     P, Pinv, T = sweep.camera_matrices(torch.from_numpy(np.stack([KITTI_P2] * B)),
                                        torch.from_numpy(poses(B, 2 + rank)), B, dev)
-    out = torch.empty((B, 2 * w['C'], w['D'], desc.h_out, desc.w_out), dtype=tdtype, device=dev)
+    if args.channels_last:
+        # same values, volume laid out (B, D, H, W, 2C): torch memory_format channels_last_3d
+        out = torch.empty((B, w['D'], desc.h_out, desc.w_out, 2 * w['C']), dtype=tdtype,
+                          device=dev).permute(0, 4, 1, 2, 3)
+    else:
+        out = torch.empty((B, 2 * w['C'], w['D'], desc.h_out, desc.w_out), dtype=tdtype, device=dev)
 
     def step():
-        sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T, out=out)
+        sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T, out=out,
+                                  channels_last=args.channels_last)
 
     def barrier():
         if world > 1:
@@ -344,8 +352,11 @@ def main():
                             f'csf={w["csf"]}',
                 'global_batch': B * world,
                 'parallelism': f'dp{world}',
-                'kernel': {1: 'sweep_gather_kernel', 2: 'sweep_tile_kernel<LDS>', 3: 'sweep_tile_kernel<direct>'}.get(
+                'kernel': 'sweep_cl_kernel' if args.channels_last else
+                {1: 'sweep_gather_kernel', 2: 'sweep_tile_kernel<LDS>', 3: 'sweep_tile_kernel<direct>'}.get(
                     lib.dfm_plane_sweep_last_kernel(), 'none'),
+                'volume_layout': '(B,D,H,W,2C) channels_last_3d' if args.channels_last
+                else '(B,2C,D,H,W) contiguous (the reference layout)',
             },
             'roofline': {
                 'bound': 'hbm',
@@ -354,7 +365,7 @@ def main():
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBPS, 4),
                 'traffic': args.traffic_bytes if args.traffic_bytes is not None else (
-                    NSTAR_TRAFFIC_BYTES if args.workload == 'nstar' and
+                    NSTAR_TRAFFIC_BYTES if args.workload == 'nstar' and not args.channels_last and
                     lib.dfm_plane_sweep_last_kernel() == 2 else None),
                 'kernel_ms': round(avg_kernel_ms, 4),
                 'algorithmic_bytes_per_launch': bytes_per_launch,

@@ -20,6 +20,8 @@ EXPORTS = (
     'dfm_profile_end',
     'dfm_plane_sweep_workspace_bytes',
     'dfm_plane_sweep_fwd',
+    'dfm_plane_sweep_cl_workspace_bytes',
+    'dfm_plane_sweep_fwd_channels_last',
     'dfm_plane_sweep_bwd',
     'dfm_plane_sweep_grid',
     'dfm_plane_sweep_last_kernel',
@@ -138,6 +140,10 @@ def lib():
     h.dfm_plane_sweep_workspace_bytes.argtypes = [dp]
     h.dfm_plane_sweep_fwd.restype = ctypes.c_int
     h.dfm_plane_sweep_fwd.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp]
+    h.dfm_plane_sweep_cl_workspace_bytes.restype = sz
+    h.dfm_plane_sweep_cl_workspace_bytes.argtypes = [dp]
+    h.dfm_plane_sweep_fwd_channels_last.restype = ctypes.c_int
+    h.dfm_plane_sweep_fwd_channels_last.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp]
     h.dfm_plane_sweep_bwd.restype = ctypes.c_int
     h.dfm_plane_sweep_bwd.argtypes = [dp, vp, fp, fp, fp, fp, fp, fp, vp]
     h.dfm_plane_sweep_grid.restype = ctypes.c_int

@@ -16,6 +16,13 @@ namespace dfm {
 // records the thread-local message dfm_last_error() returns; defined in
 // plane_sweep.hip, shared by every translation unit of the library
 int set_error(int code, const char *msg);
+struct SweepGeom;
+// defined in plane_sweep.hip, used by the other plane-sweep translation units
+int sweep_check_desc(const dfm_sweep_desc *d);
+SweepGeom sweep_make_geom(const dfm_sweep_desc *d);
+// records the start (stop=false) / stop event of a timed launch when dfm_profile_begin
+// is active; the start call returns whether this launch is being timed
+bool profile_mark(void *stream, bool stop);
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 

@@ -1244,6 +1244,26 @@ DFM_API int dfm_profile_end(double *total_ms, int *launches)
     return DFM_OK;
 }
 
+}  // extern "C"
+
+// shared with plane_sweep_cl.hip
+int dfm::sweep_check_desc(const dfm_sweep_desc *d) { return check_desc(d); }
+dfm::SweepGeom dfm::sweep_make_geom(const dfm_sweep_desc *d) { return make_geom(d); }
+bool dfm::profile_mark(void *stream, bool stop)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!stop) {
+        if (!(g_prof.on && g_prof.used + 2 <= (int)g_prof.ev.size())) return false;
+        (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+        return true;
+    }
+    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+    g_prof.used += 2;
+    return true;
+}
+
+extern "C" {
+
 DFM_API size_t dfm_plane_sweep_workspace_bytes(const dfm_sweep_desc *desc)
 {
     if (check_desc(desc) != DFM_OK) return 0;

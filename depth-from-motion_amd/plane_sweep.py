@@ -92,10 +92,25 @@ class _Workspace:
         return buf
 
 
-def plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T, out=None):
-    """Raw launch: everything already on the device."""
+def plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T, out=None,
+                        channels_last=False):
+    """Raw launch: everything already on the device.  ``channels_last``: write the volume
+    as (B, D, H, W, 2C) and return it as a (B, 2C, D, H, W) channels_last_3d tensor."""
     lib = _capi.lib()
     device = cur_feats.device
+    if channels_last:
+        if out is None:
+            out = torch.empty((desc.batch, desc.num_depths, desc.h_out, desc.w_out, 2 * desc.channels),
+                              dtype=cur_feats.dtype, device=device).permute(0, 4, 1, 2, 3)
+        assert out.is_contiguous(memory_format=torch.channels_last_3d)
+        nbytes = lib.dfm_plane_sweep_cl_workspace_bytes(ctypes.byref(desc))
+        ws = _Workspace.get(device, nbytes)
+        with torch.cuda.device(device):
+            _capi.check(
+                lib.dfm_plane_sweep_fwd_channels_last(
+                    ctypes.byref(desc), _ptr(cur_feats), _ptr(prev_feats), _ptr(depths), _ptr(P),
+                    _ptr(Pinv), _ptr(T), _ptr(out), _ptr(ws), nbytes, _stream_ptr(device)))
+        return out
     if out is None:
         out = torch.empty((desc.batch, 2 * desc.channels, desc.num_depths, desc.h_out, desc.w_out),
                           dtype=cur_feats.dtype, device=device)
@@ -112,11 +127,12 @@ def plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T, out=Non
 class _PlaneSweepFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, cur_feats, prev_feats, depths, P, Pinv, T, desc):
+    def forward(ctx, cur_feats, prev_feats, depths, P, Pinv, T, desc, channels_last=False):
         ctx.desc = desc
         ctx.save_for_backward(depths, P, Pinv, T)
         ctx.in_dtype = cur_feats.dtype
-        return plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T)
+        return plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T,
+                                   channels_last=channels_last)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -133,7 +149,7 @@ class _PlaneSweepFn(torch.autograd.Function):
                 lib.dfm_plane_sweep_bwd(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P),
                                         _ptr(Pinv), _ptr(T), _ptr(g_cur), _ptr(g_prev),
                                         _stream_ptr(device)))
-        return g_cur.to(ctx.in_dtype), g_prev.to(ctx.in_dtype), None, None, None, None, None
+        return g_cur.to(ctx.in_dtype), g_prev.to(ctx.in_dtype), None, None, None, None, None, None
 
 
 def build_dfm_cost(cur_feats,
@@ -146,8 +162,14 @@ def build_dfm_cost(cur_feats,
                    img_shape,
                    flip=False,
                    img_crop_offset=(0, 0),
-                   img_scale_factor=1.0):
+                   img_scale_factor=1.0,
+                   memory_format=torch.contiguous_format):
     """Plane-sweep cost volume, drop-in for the reference function.
+
+    ``memory_format`` (extension): ``torch.channels_last_3d`` returns the same tensor
+    (same shape, same values bit for bit) laid out (B, D, H, W, 2C) in memory -- the
+    layout MIOpen's bf16 Conv3d runs in and the faster one to write (one contiguous run
+    per lattice point).  Needs C to be a multiple of 16 bytes.
 
     Args:
         cur_feats/prev_feats: [B, C, H, W] fp32 or bf16, on the GPU
@@ -173,7 +195,10 @@ def build_dfm_cost(cur_feats,
     desc = _make_desc(cur_feats, depths.numel(), feat_sample_factor, cost_sample_factor, img_shape,
                       flip, img_crop_offset, img_scale_factor)
     P, Pinv, T = camera_matrices(cam2imgs, cur2prevs, batch_size, device)
-    return _PlaneSweepFn.apply(cur_feats, prev_feats, depths, P, Pinv, T, desc)
+    if memory_format not in (torch.contiguous_format, torch.channels_last_3d):
+        raise ValueError('memory_format must be contiguous_format or channels_last_3d')
+    return _PlaneSweepFn.apply(cur_feats, prev_feats, depths, P, Pinv, T, desc,
+                               memory_format == torch.channels_last_3d)
 
 
 def plane_sweep_grid(cur_feats, depths, feat_sample_factor, cost_sample_factor, cam2imgs, cur2prevs,

@@ -115,6 +115,22 @@ DFM_API int dfm_plane_sweep_fwd(const dfm_sweep_desc *desc, const void *cur, con
                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Same call, same values bit for bit, result written channels-last:
+ *   out : (B, D, h_out, w_out, 2C) contiguous, i.e. a torch tensor of shape
+ *         (B, 2C, D, h_out, w_out) in memory_format channels_last_3d -- what an
+ *         NDHWC / implicit-GEMM Conv3d consumes, and one contiguous run of 2C values
+ *         per lattice point for the HBM.  Needs channels % (16 / sizeof(T)) == 0.
+ *   workspace : >= dfm_plane_sweep_cl_workspace_bytes(desc) (pixel-major copies of the
+ *         two maps + one zero pixel), 256-B aligned.
+ */
+DFM_API size_t dfm_plane_sweep_cl_workspace_bytes(const dfm_sweep_desc *desc);
+DFM_API int dfm_plane_sweep_fwd_channels_last(const dfm_sweep_desc *desc, const void *cur,
+                                              const void *prev, const float *depths,
+                                              const float *cam2img, const float *cam2img_inv,
+                                              const float *cur2prev, void *out, void *workspace,
+                                              size_t workspace_bytes, void *stream);
+
+/*
  * Backward of the two bilinear samplings w.r.t. the feature maps.
  * grad_out : (B, 2C, D, h_out, w_out) desc->dtype
  * grad_cur, grad_prev : (B, C, h_in, w_in) FP32, must be zero-filled by the

@@ -241,6 +241,60 @@ def test_backward_bf16_gradients(pkg):
                     tol=dict(rtol=2e-2, atol=2e-2))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('case', [
+    dict(B=2, C=8, H=20, W=64, D=5, fsf=8, csf=2, crop=(3, 5), flip=False, scale=1.0),
+    dict(B=1, C=40, H=24, W=96, D=4, fsf=4, csf=1, crop=(0, 0), flip=True, scale=1.03),
+    dict(B=3, C=256, H=9, W=31, D=3, fsf=4, csf=1, crop=(0, 0), flip=False, scale=1.0),
+    dict(B=1, C=16, H=37, W=53, D=7, fsf=4, csf=1, crop=(11, 55), flip=False, scale=0.97),
+], ids=['strided_c8', 'c40_flip_scale', 'c256', 'partial_tiles'])
+def test_channels_last_volume_equals_reference_layout(pkg, case, dtype, kernel_mode):
+    """memory_format=channels_last_3d: same shape, same values bit for bit as the
+    (B,2C,D,H,W)-contiguous volume (itself checked against the oracle / fixtures above)"""
+    if kernel_mode != 'lds256_p2':
+        pytest.skip('layout check runs once, against the shipped kernel configuration')
+    rng = np.random.RandomState(case['C'])
+    B, C, H, W, D = (case[k] for k in 'BCHWD')
+    cur = rng.randn(B, C, H, W).astype(np.float32)
+    prev = rng.randn(B, C, H, W).astype(np.float32)
+    P = np.stack([util.KITTI_P2] * B)
+    T = util.random_poses(B, seed=3)
+    T[0, 2, 3] = 4.0  # one sample with planes behind the prev camera (z <= 0 -> zeros / NaN coords)
+    dev = torch.device('cuda:0')
+    c = torch.from_numpy(cur).to(dev).to(dtype)
+    p = torch.from_numpy(prev).to(dev).to(dtype)
+    args = (torch.from_numpy(util.depth_planes(D)).to(dev), case['fsf'], case['csf'], torch.from_numpy(P),
+            torch.from_numpy(T), (375, 1242), case['flip'], case['crop'], case['scale'])
+    ref = pkg.build_dfm_cost(c, p, *args)
+    out = pkg.build_dfm_cost(c, p, *args, memory_format=torch.channels_last_3d)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last_3d)
+    assert out.stride(1) == 1
+    ob, rb = out.contiguous().view(-1), ref.view(-1)
+    bits = torch.int32 if dtype == torch.float32 else torch.int16
+    assert torch.equal(ob.view(bits), rb.view(bits))
+
+
+def test_channels_last_backward_and_errors(pkg, kernel_mode):
+    if kernel_mode != 'lds256_p2':
+        pytest.skip('runs once')
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(0)
+    c = torch.from_numpy(rng.randn(1, 8, 12, 40).astype(np.float32)).to(dev).requires_grad_(True)
+    p = torch.from_numpy(rng.randn(1, 8, 12, 40).astype(np.float32)).to(dev).requires_grad_(True)
+    args = (torch.from_numpy(util.depth_planes(3)).to(dev), 4, 1, torch.from_numpy(util.KITTI_P2[None]),
+            torch.from_numpy(util.random_poses(1, seed=1)), (48, 160))
+    g = torch.from_numpy(rng.randn(1, 16, 3, 12, 40).astype(np.float32)).to(dev)
+    out = pkg.build_dfm_cost(c, p, *args, memory_format=torch.channels_last_3d)
+    out.backward(g.contiguous(memory_format=torch.channels_last_3d))
+    gc, gp = c.grad.clone(), p.grad.clone()
+    c.grad = p.grad = None
+    pkg.build_dfm_cost(c, p, *args).backward(g)
+    assert torch.allclose(gc, c.grad, rtol=1e-5, atol=1e-6) and torch.allclose(gp, p.grad, rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):  # 6 channels are not a whole 16-byte block
+        pkg.build_dfm_cost(c[:, :6].detach(), p[:, :6].detach(), *args, memory_format=torch.channels_last_3d)
+
+
 def test_type_and_shape_errors(pkg):
     dev = torch.device('cuda:0')
     x = torch.zeros(1, 4, 8, 8, device=dev)
