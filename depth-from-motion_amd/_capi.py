@@ -39,6 +39,7 @@ EXPORTS = (
     'dfm_voxel_sample_fwd',
     'dfm_group_norm_workspace_bytes',
     'dfm_group_norm_fwd',
+    'dfm_group_norm_fwd_channels_last',
     'dfm_group_norm_bwd',
 )
 
@@ -95,7 +96,7 @@ class F2vDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         'batch', 'channels', 'd', 'h', 'w', 'ds', 'hs', 'ws', 'sem_channels', 'hsem', 'wsem', 'nz',
         'ny', 'nx')] + [(n, ctypes.c_float) for n in ('pad_h', 'pad_w', 'depth_min', 'depth_span')
-                        ] + [('dtype', ctypes.c_int32)]
+                        ] + [('dtype', ctypes.c_int32), ('stereo_channels_last', ctypes.c_int32)]
 
 
 class VsDesc(ctypes.Structure):
@@ -180,6 +181,8 @@ def lib():
     h.dfm_group_norm_workspace_bytes.argtypes = [i32, i32, i64, i32]
     h.dfm_group_norm_fwd.restype = ctypes.c_int
     h.dfm_group_norm_fwd.argtypes = [i32, i32, i64, i32, f32, i32, i32, vp, fp, fp, vp, fp, fp, vp, sz, vp]
+    h.dfm_group_norm_fwd_channels_last.restype = ctypes.c_int
+    h.dfm_group_norm_fwd_channels_last.argtypes = h.dfm_group_norm_fwd.argtypes
     h.dfm_group_norm_bwd.restype = ctypes.c_int
     h.dfm_group_norm_bwd.argtypes = [i32, i32, i64, i32, i32, i32, vp, vp, vp, fp, fp, fp, vp, fp, fp, vp, sz,
                                      vp]

@@ -276,6 +276,9 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, 
     const long long N = (long long)d->nz * d->ny * d->nx;
     dim3 grid((unsigned)((N + 255) / 256), d->batch);
     hipStream_t st = (hipStream_t)stream;
+    if (d->stereo_channels_last && (!f2v_pixel_major(d) || ((uintptr_t)stereo & 15)))
+        return set_error(DFM_ERR_UNSUPPORTED,
+                         "channels-last stereo_feat needs channel counts of whole 16-byte blocks");
     if (f2v_pixel_major(d)) {
         if (!workspace || workspace_bytes < dfm_frustum_to_voxel_workspace_bytes(d))
             return set_error(DFM_ERR_WORKSPACE,
@@ -283,12 +286,16 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, 
         const size_t esz = d->dtype == DFM_BF16 ? 2 : 4;
         const long long vox = (long long)d->d * d->h * d->w, pix = (long long)d->hsem * d->wsem;
         const size_t a = ((size_t)d->batch * d->channels * vox * esz + 255) & ~(size_t)255;
-        void *stereo_pm = workspace, *sem_pm = (char *)workspace + a;
+        const bool in_place = d->stereo_channels_last != 0;
+        void *stereo_pm = in_place ? const_cast<void *>(stereo) : workspace;
+        void *sem_pm = (char *)workspace + a;
         dim3 pg1((unsigned)((vox + 63) / 64), (d->channels + 31) / 32, d->batch);
         dim3 pg2((unsigned)((pix + 63) / 64), (d->sem_channels + 31) / 32, d->batch);
         if (d->dtype == DFM_F32) {
-            hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg1, dim3(256), 0, st,
-                               (const float *)stereo, (float *)stereo_pm, d->channels, d->channels, vox);
+            if (!in_place)
+                hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg1, dim3(256), 0, st,
+                                   (const float *)stereo, (float *)stereo_pm, d->channels,
+                                   d->channels, vox);
             if (d->sem_channels > 0)
                 hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg2, dim3(256), 0, st,
                                    (const float *)sem, (float *)sem_pm, d->sem_channels,
@@ -297,9 +304,10 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, 
                                (const uint4 *)stereo_pm, (const float *)softmax,
                                (const uint4 *)sem_pm, coords, cam2img, (float *)out);
         } else {
-            hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg1, dim3(256), 0, st,
-                               (const bf16_t *)stereo, (bf16_t *)stereo_pm, d->channels, d->channels,
-                               vox);
+            if (!in_place)
+                hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg1, dim3(256), 0, st,
+                                   (const bf16_t *)stereo, (bf16_t *)stereo_pm, d->channels,
+                                   d->channels, vox);
             if (d->sem_channels > 0)
                 hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg2, dim3(256), 0, st,
                                    (const bf16_t *)sem, (bf16_t *)sem_pm, d->sem_channels,

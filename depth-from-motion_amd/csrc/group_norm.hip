@@ -288,6 +288,113 @@ int pick_splits(long long L)
     return (int)s;
 }
 
+// ---------------------------------------------------------------------------
+// channels-last variant: x, y are (N, spatial, C) contiguous (torch channels_last_3d),
+// what the NDHWC convolutions produce and consume.  A lane owns one 16-byte channel
+// vector (VEC channels) of every (256 / nvb)-th voxel, nvb = C / VEC (a power of two),
+// so its VEC running moments / affine coefficients live in registers.
+//   gn_stats_cl : grid (splits, N): per-channel Welford over the slice, lanes holding the
+//                 same channels merged through LDS, channels of a group merged -> partial
+//   gn_apply_cl : grid (splits, N): merges the group's partials, y = x*a[c] + b[c] (+ReLU)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_cl_kernel(const T *__restrict__ x, long long spatial,
+                                                          int C, int groups, int splits,
+                                                          float *__restrict__ partial)
+{
+    constexpr int VEC = vec16<T>::N;
+    __shared__ Moments sh[256][VEC + 1];
+    __shared__ Moments chm[256];
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int nvb = C / VEC, vpi = 256 / nvb;  // voxels per iteration
+    const int vb = threadIdx.x % nvb, v0 = threadIdx.x / nvb;
+    const long long per = (spatial + splits - 1) / splits;
+    const long long lo = min((long long)s * per, spatial), hi = min(lo + per, spatial);
+    const T *xs = x + (size_t)n * spatial * C + (size_t)vb * VEC;
+    float cnt = 0.0f, mean[VEC], m2[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { mean[k] = 0.0f; m2[k] = 0.0f; }
+    for (long long v = lo + v0; v < hi; v += vpi) {
+        float f[VEC];
+        load16<T>(xs + (size_t)v * C, f);
+        cnt += 1.0f;
+        const float inv = 1.0f / cnt;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float d = f[k] - mean[k];
+            mean[k] += d * inv;
+            m2[k] += d * (f[k] - mean[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) sh[threadIdx.x][k] = Moments{cnt, mean[k], m2[k]};
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        // channel c = vb*VEC + k is held by the lanes with tid % nvb == vb
+        const int c = threadIdx.x, cvb = c / VEC, k = c % VEC;
+        Moments r = {0.0f, 0.0f, 0.0f};
+        for (int t = cvb; t < 256; t += nvb) r = merge(r, sh[t][k]);
+        chm[c] = r;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+        const int cpg = C / groups, g = threadIdx.x;
+        Moments r = {0.0f, 0.0f, 0.0f};
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) r = merge(r, chm[c]);
+        float *p = partial + (((size_t)n * groups + g) * splits + s) * 3;
+        p[0] = r.n; p[1] = r.mean; p[2] = r.m2;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ x, long long spatial,
+                                                          int C, int groups, int splits, float eps,
+                                                          const float *__restrict__ partial,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, int relu,
+                                                          T *__restrict__ y, float *__restrict__ mean_out,
+                                                          float *__restrict__ rstd_out)
+{
+    constexpr int VEC = vec16<T>::N;
+    __shared__ float ca[256], cb[256];
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int cpg = C / groups;
+    if ((int)threadIdx.x < groups) {
+        const int g = threadIdx.x;
+        Moments r = {0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < splits; ++k) {
+            const float *p = partial + (((size_t)n * groups + g) * splits + k) * 3;
+            r = merge(r, Moments{p[0], p[1], p[2]});
+        }
+        const float mean = r.mean, rstd = 1.0f / sqrtf(r.m2 / r.n + eps);  // biased, like torch
+        if (s == 0) { mean_out[n * groups + g] = mean; rstd_out[n * groups + g] = rstd; }
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const float a = rstd * gamma[c];
+            ca[c] = a;
+            cb[c] = beta[c] - mean * a;
+        }
+    }
+    __syncthreads();
+    const int nvb = C / VEC, vpi = 256 / nvb;
+    const int vb = threadIdx.x % nvb, v0 = threadIdx.x / nvb;
+    float a[VEC], b[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { a[k] = ca[vb * VEC + k]; b[k] = cb[vb * VEC + k]; }
+    const long long per = (spatial + splits - 1) / splits;
+    const long long lo = min((long long)s * per, spatial), hi = min(lo + per, spatial);
+    const size_t base = (size_t)n * spatial * C + (size_t)vb * VEC;
+    for (long long v = lo + v0; v < hi; v += vpi) {
+        float f[VEC];
+        load16<T>(x + base + (size_t)v * C, f);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float r = f[k] * a[k] + b[k];
+            f[k] = relu ? fmaxf(r, 0.0f) : r;
+        }
+        store16<T>(y + base + (size_t)v * C, f);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -331,6 +438,48 @@ DFM_API int dfm_group_norm_fwd(int32_t n, int32_t c, int64_t spatial, int32_t gr
                            splits, partial);
         hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, L,
                            (long long)spatial, cpg, groups, splits, eps, partial, gamma, beta, relu,
+                           (bf16_t *)y, mean, rstd);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+DFM_API int dfm_group_norm_fwd_channels_last(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                             float eps, int32_t dtype, int32_t relu, const void *x,
+                                             const float *gamma, const float *beta, void *y,
+                                             float *mean, float *rstd, void *workspace,
+                                             size_t workspace_bytes, void *stream)
+{
+    if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups)
+        return set_error(DFM_ERR_INVALID_ARG, "bad sizes in dfm_group_norm_fwd_channels_last");
+    if (dtype != DFM_F32 && dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!x || !gamma || !beta || !y || !mean || !rstd || !workspace)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (workspace_bytes < dfm_group_norm_workspace_bytes(n, c, spatial, groups))
+        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_group_norm_workspace_bytes");
+    const int vec = dtype == DFM_BF16 ? 8 : 4;
+    const int nvb = c / vec;
+    if (c % vec || c > 256 || (nvb & (nvb - 1)) || n > 65535 ||
+        ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
+        return set_error(DFM_ERR_UNSUPPORTED,
+                         "channels-last GroupNorm needs C = 16-byte vectors x a power of two, C <= 256");
+    const int splits = pick_splits((long long)spatial * c);
+    dim3 grid(splits, n);
+    hipStream_t st = (hipStream_t)stream;
+    float *partial = (float *)workspace;
+    if (dtype == DFM_F32) {
+        hipLaunchKernelGGL(gn_stats_cl_kernel<float>, grid, dim3(256), 0, st, (const float *)x,
+                           (long long)spatial, c, groups, splits, partial);
+        hipLaunchKernelGGL(gn_apply_cl_kernel<float>, grid, dim3(256), 0, st, (const float *)x,
+                           (long long)spatial, c, groups, splits, eps, partial, gamma, beta, relu,
+                           (float *)y, mean, rstd);
+    } else {
+        hipLaunchKernelGGL(gn_stats_cl_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x,
+                           (long long)spatial, c, groups, splits, partial);
+        hipLaunchKernelGGL(gn_apply_cl_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x,
+                           (long long)spatial, c, groups, splits, eps, partial, gamma, beta, relu,
                            (bf16_t *)y, mean, rstd);
     }
     hipError_t e = hipGetLastError();

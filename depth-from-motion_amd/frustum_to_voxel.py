@@ -74,10 +74,17 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     device = stereo_feat.device
     if stereo_feat.dtype not in _DTYPES:
         raise TypeError('stereo_feat must be float32 or bfloat16')
-    stereo = stereo_feat.contiguous()
+    # a channels_last_3d cost volume (NDHWC conv stack) is sampled where it lies: it IS the
+    # pixel-major layout the kernel stages an NCDHW volume into
+    vec = 16 // stereo_feat.element_size()
+    cs = 0 if cur_sem_feats is None else cur_sem_feats.shape[1]
+    in_place = (not stereo_feat.is_contiguous() and stereo_feat.shape[1] % vec == 0 and cs % vec == 0
+                and stereo_feat.is_contiguous(memory_format=torch.channels_last_3d))
+    stereo = stereo_feat if in_place else stereo_feat.contiguous()
     B, C, D, H, W = stereo.shape
     desc = _capi.F2vDesc()
     desc.batch, desc.channels, desc.d, desc.h, desc.w = B, C, D, H, W
+    desc.stereo_channels_last = 1 if in_place else 0
     sem = soft = None
     if cur_sem_feats is not None:
         sem = cur_sem_feats.to(stereo.dtype).contiguous()

@@ -21,29 +21,38 @@ class _GroupNormFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, groups, eps, relu):
         lib = _capi.lib()
         device = x.device
-        x = x.contiguous()
         n, c = x.shape[:2]
+        # channels-last input (what the NDHWC convolutions hand over) stays channels-last
+        vec = 16 // x.element_size()
+        cl = (x.dim() in (4, 5) and c % vec == 0 and c <= 256 and ((c // vec) & (c // vec - 1)) == 0
+              and not x.is_contiguous()
+              and x.is_contiguous(memory_format=torch.channels_last_3d if x.dim() == 5
+                                  else torch.channels_last))
+        if not cl:
+            x = x.contiguous()
         spatial = x.numel() // (n * c)
-        y = torch.empty_like(x)
+        y = torch.empty_like(x)  # preserves the memory format
         mean = torch.empty(n * groups, dtype=torch.float32, device=device)
         rstd = torch.empty_like(mean)
         w32 = weight.detach().float().contiguous()
         b32 = bias.detach().float().contiguous()
         nbytes = lib.dfm_group_norm_workspace_bytes(n, c, spatial, groups)
         ws = _Workspace.get(device, nbytes)
+        fn = lib.dfm_group_norm_fwd_channels_last if cl else lib.dfm_group_norm_fwd
         with torch.cuda.device(device):
-            _capi.check(
-                lib.dfm_group_norm_fwd(n, c, spatial, groups, eps, _DTYPES[x.dtype], int(relu),
-                                       _ptr(x), _ptr(w32), _ptr(b32), _ptr(y), _ptr(mean),
-                                       _ptr(rstd), _ptr(ws), nbytes, _stream_ptr(device)))
+            _capi.check(fn(n, c, spatial, groups, eps, _DTYPES[x.dtype], int(relu), _ptr(x), _ptr(w32),
+                           _ptr(b32), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), nbytes,
+                           _stream_ptr(device)))
         ctx.save_for_backward(x, y if relu else x, mean, rstd, w32)
-        ctx.cfg = (groups, bool(relu), weight.dtype, bias.dtype)
+        ctx.cfg = (groups, bool(relu), weight.dtype, bias.dtype, cl)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, y, mean, rstd, w32 = ctx.saved_tensors
-        groups, relu, wdt, bdt = ctx.cfg
+        groups, relu, wdt, bdt, cl = ctx.cfg
+        if cl:  # the backward kernels are NC(D)HW: convert (training through channels-last
+            x, y = x.contiguous(), y.contiguous()  # stacks pays two extra copies here)
         lib = _capi.lib()
         device = x.device
         n, c = x.shape[:2]

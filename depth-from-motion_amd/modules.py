@@ -159,6 +159,10 @@ class DfMBackbone(nn.Module):
         self.aggregate_cost = nn.Conv2d(2 * planes, planes, kernel_size=1, bias=False)
         # injected by the detector (dfm.py:88-89); a tensor of plane depths
         self.downsampled_depth = None
+        # extension: torch.channels_last_3d builds the cost volume (B, D, H, W, 2C) so the
+        # Conv3d / GroupNorm stack runs NDHWC end to end (convert the module as well:
+        # backbone.to(memory_format=torch.channels_last_3d)); values are unchanged
+        self.volume_memory_format = torch.contiguous_format
 
     def init_weights(self):
         pass
@@ -184,7 +188,8 @@ class DfMBackbone(nn.Module):
             cur_stereo_feats, prev_stereo_feats, self.downsampled_depth, self.feat_sample_factor,
             self.cost_sample_factor, ori_cam2imgs, cur2prevs[:, 0], meta0['ori_shape'][:2],
             meta0.get('flip', False), meta0['crop_offset'],
-            img_scale_factor=meta0.get('scale_factor', [1.0])[0])
+            img_scale_factor=meta0.get('scale_factor', [1.0])[0],
+            memory_format=self.volume_memory_format)
         stereo = self._aggregate(self.dres0, self.dres1, self.hg_stereo, cost_raw)
         mono = self._aggregate(self.dres0_mono, self.dres1_mono, self.hg_mono,
                                cost_raw[:, :self.in_channels])

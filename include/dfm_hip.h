@@ -243,6 +243,9 @@ typedef struct dfm_f2v_desc {
     float pad_h, pad_w;
     float depth_min, depth_span;
     int32_t dtype;         /* dfm_dtype of the three sources and of out       */
+    int32_t stereo_channels_last; /* 1: stereo is (B, d, h, w, C) in memory (torch
+                            * channels_last_3d, what an NDHWC Conv3d stack hands over):
+                            * it is sampled in place, no pixel-major copy is made   */
 } dfm_f2v_desc;
 
 /*
@@ -333,6 +336,14 @@ DFM_API int dfm_group_norm_fwd(int32_t n, int32_t c, int64_t spatial, int32_t gr
                                int32_t dtype, int32_t relu, const void *x, const float *gamma,
                                const float *beta, void *y, float *mean, float *rstd,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* Same op on channels-last data: x, y are (n, spatial, c) contiguous (a torch tensor in
+ * memory_format channels_last_3d), the layout of the NDHWC convolutions around it.
+ * Needs c = (16-byte vectors) x (a power of two), c <= 256. */
+DFM_API int dfm_group_norm_fwd_channels_last(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                             float eps, int32_t dtype, int32_t relu, const void *x,
+                                             const float *gamma, const float *beta, void *y,
+                                             float *mean, float *rstd, void *workspace,
+                                             size_t workspace_bytes, void *stream);
 /* grad_gamma / grad_beta: (c) fp32, zero-filled by the caller; `y` is only
  * read when relu != 0 (mask y > 0). */
 DFM_API int dfm_group_norm_bwd(int32_t n, int32_t c, int64_t spatial, int32_t groups,

@@ -33,13 +33,14 @@ def test_oracle_bitexact_vs_reference_module(path):
     assert 0.05 < (z['ref_out'][:, :C] == 0).mean() < 0.95
 
 
-def hip_run(z, dtype=torch.float32, sem=True):
+def hip_run(z, dtype=torch.float32, sem=True, stereo_format=torch.contiguous_format):
     pkg = importlib.import_module('depth-from-motion_amd')
     dev = torch.device('cuda:0')
     metas = [{'cam2img': c.tolist(), 'pad_shape': tuple(int(v) for v in z['pad_shape']) + (3,)}
              for c in z['cam2img']]
     out = pkg.frustum_to_voxel_sample(
-        torch.from_numpy(z['stereo']).to(dev).to(dtype), torch.from_numpy(z['softmax']).to(dev).to(dtype),
+        torch.from_numpy(z['stereo']).to(dev).to(dtype).contiguous(memory_format=stereo_format),
+        torch.from_numpy(z['softmax']).to(dev).to(dtype),
         metas, torch.from_numpy(z['sem']).to(dev).to(dtype) if sem else None,
         torch.from_numpy(z['coordinates_3d']),
         dict(depth_min=float(z['depth_min']), depth_max=float(z['depth_max'])))
@@ -148,3 +149,6 @@ def test_hip_pixel_major_path_vs_oracle(dtype, C, Cs):
     assert out.shape[1] == C + Cs
     assert np.array_equal(util.bits(out), util.bits(ref))
     assert 0.05 < (ref != 0).mean()
+    # a channels_last_3d cost volume is sampled in place (no pixel-major copy): same bits
+    out_cl = hip_run(z, dtype, sem=Cs > 0, stereo_format=torch.channels_last_3d).float().cpu().numpy()
+    assert np.array_equal(util.bits(out_cl), util.bits(ref))

@@ -71,3 +71,34 @@ def test_bf16_storage(pkg):
     assert y.dtype == torch.bfloat16
     ref = F.relu(F.group_norm(x.float(), 32, m.weight.cpu(), m.bias.cpu(), 1e-5))
     np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.detach().numpy(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('n,c,sp,groups', [(2, 32, (8, 12, 20), 32), (1, 64, (9, 7, 13), 32),
+                                           (3, 16, (6, 10), 4), (1, 32, (18, 20, 41), 8)])
+def test_channels_last_forward_backward_vs_torch_cpu(pkg, n, c, sp, groups, relu, dtype):
+    """channels_last(_3d) input takes the channels-last kernels and stays channels-last"""
+    gen = torch.Generator().manual_seed(n * 10 + c)
+    x = torch.randn(n, c, *sp, generator=gen) * 2 + 0.7
+    w = 1 + 0.2 * torch.randn(c, generator=gen)
+    b = 0.3 * torch.randn(c, generator=gen)
+    gy = torch.randn(n, c, *sp, generator=gen)
+    if dtype == torch.bfloat16:
+        x, gy = x.bfloat16().float(), gy.bfloat16().float()
+    fmt = torch.channels_last_3d if len(sp) == 3 else torch.channels_last
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.group_norm(xr, groups, wr, br, 1e-5)
+    ref = F.relu(ref) if relu else ref
+    (ref * gy).sum().backward()
+    xg = x.cuda().to(dtype).contiguous(memory_format=fmt).requires_grad_(True)
+    wg, bg = (t.cuda().requires_grad_(True) for t in (w, b))
+    out = pkg.group_norm(xg, groups, wg, bg, 1e-5, relu)
+    assert out.is_contiguous(memory_format=fmt) and out.shape == ref.shape
+    (out.float() * gy.cuda()).sum().backward()
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=2e-2)
+    np.testing.assert_allclose(out.detach().float().cpu().numpy(), ref.detach().numpy(), **tol)
+    gtol = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose(xg.grad.float().cpu().numpy(), xr.grad.numpy(), **gtol)
+    np.testing.assert_allclose(wg.grad.cpu().numpy(), wr.grad.numpy(), rtol=2e-2, atol=2e-2 * float(wr.grad.abs().max()))
