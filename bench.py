@@ -371,6 +371,33 @@ def main():
                 'algorithmic_bytes_per_launch': bytes_per_launch,
             },
         }
+        if world == 1 and not args.channels_last and w['C'] % (16 // elem) == 0:
+            # the same volume written channels-last (opt-in layout, identical values): reported
+            # beside the headline, never instead of it
+            del out
+            out_cl = torch.empty((B, w['D'], desc.h_out, desc.w_out, 2 * w['C']), dtype=tdtype,
+                                 device=dev).permute(0, 4, 1, 2, 3)
+            for _ in range(args.warmup):
+                sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T, out=out_cl,
+                                          channels_last=True)
+            torch.cuda.synchronize()
+            pkg._capi.check(lib.dfm_profile_begin(args.steps))
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T, out=out_cl,
+                                          channels_last=True)
+            torch.cuda.synchronize()
+            ms_cl = (time.perf_counter() - t0) * 1e3 / args.steps
+            pkg._capi.check(lib.dfm_profile_end(ctypes.byref(kms), ctypes.byref(klaunches)))
+            k_cl = kms.value / max(klaunches.value, 1)
+            line['channels_last_variant'] = {
+                'value': round(B / (ms_cl / 1e3), 2), 'unit': 'cost-volumes/s',
+                'ms_per_step': round(ms_cl, 4), 'kernel': 'sweep_cl_kernel',
+                'volume_layout': '(B,D,H,W,2C) channels_last_3d, bit-identical values',
+                'roofline': {'achieved': round(bytes_per_launch / (k_cl * 1e-3) / 1e9, 1),
+                             'frac': round(bytes_per_launch / (k_cl * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             'kernel_ms': round(k_cl, 4)}}
+            del out_cl
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(w)
         print(json.dumps(line), flush=True)
