@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 using namespace dfm;
@@ -703,7 +704,6 @@ __global__ __launch_bounds__(256) void sweep_bwd_kernel(
 // The sampling positions are recomputed per (plane, channel pass) with the forward
 // kernel's own sweep_point_map/make_tap, i.e. the taps and weights ARE the forward's.
 // ---------------------------------------------------------------------------
-constexpr int BWD_CW = 8;     // channels accumulated per pass
 constexpr int BWD_PPL = 1;    // lattice points per lane and plane
 constexpr int BWD_MAXP = 32;  // depth planes per workgroup, at most
 
@@ -711,7 +711,7 @@ struct BwdGrid {
     int batch, bands, band_pts, planes, dchunks, rows;
 };
 
-template <typename T, int HALF>
+template <typename T, int HALF, int BWD_CW>
 __device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFast &fast,
                                               const BwdGrid &tg, int b, int band, int dchunk,
                                               const T *__restrict__ gout,
@@ -719,7 +719,9 @@ __device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFas
                                               const float *__restrict__ P,
                                               const float *__restrict__ Pinv,
                                               const float *__restrict__ Tm,
-                                              float *__restrict__ gfeat, float *slab, int *yr)
+                                              float *__restrict__ gfeat,
+                                              unsigned long long *slab, int *yr, float fx_scale,
+                                              float fx_inv)
 {
     const int tid = threadIdx.x;
     const int hw = g.h_out * g.w_out;
@@ -737,7 +739,7 @@ __device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFas
         wi[k] = idx[k] - hi[k] * g.w_out;
     }
     for (int i = tid; i < 2 * BWD_MAXP; i += 256) yr[i] = (i & 1) ? -1 : 0x7fffffff;
-    for (int i = tid; i < BWD_CW * slab_c; i += 256) slab[i] = 0.0f;
+    for (int i = tid; i < BWD_CW * slab_c; i += 256) slab[i] = 0ull;
     __syncthreads();
     // rows every plane of the chunk touches
     for (int d = d_lo; d < d_hi; ++d) {
@@ -772,13 +774,16 @@ __device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFas
         auto flush = [&]() {
             const int cnt = (top - y0 + 1) * W;
             for (int c = 0; c < nc; ++c) {
-                float *sl = slab + c * slab_c;
+                unsigned long long *sl = slab + c * slab_c;
                 float *dst = gf + (size_t)(c0 + c) * HW + (size_t)y0 * W;
                 for (int r = tid; r < cnt; r += 256) {
-                    const float v = sl[r];
-                    if (v != 0.0f) {
-                        atomicAdd(dst + r, v);
-                        sl[r] = 0.0f;
+                    const unsigned long long v = sl[r];
+                    if (v != 0ull) {
+                        // two's-complement fixed point -> float
+                        const float f = __builtin_fmaf((float)(int)(v >> 32), 4294967296.0f,
+                                                       (float)(unsigned)v);
+                        atomicAdd(dst + r, f * fx_inv);
+                        sl[r] = 0ull;
                     }
                 }
             }
@@ -809,11 +814,19 @@ __device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFas
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
                             if (!(run_cells[k] & (1u << (3 * r + q)))) continue;  // in-bounds cells only
-                            float *l = slab + rr * W + (bx + q);
+                            unsigned long long *l = slab + rr * W + (bx + q);
 #pragma unroll
                             for (int c = 0; c < BWD_CW; ++c)
-                                if (c < nc && acc[k][3 * r + q][c] != 0.0f)
-                                    atomicAdd(l + c * slab_c, acc[k][3 * r + q][c]);
+                                if (c < nc && acc[k][3 * r + q][c] != 0.0f) {
+                                    // float -> 64-bit two's-complement fixed point (exact split:
+                                    // x has 24 significant bits, |x| < 2^56)
+                                    const float x = acc[k][3 * r + q][c] * fx_scale;
+                                    const float hif = floorf(x * 2.3283064365386963e-10f);
+                                    const float lof = __builtin_fmaf(hif, -4294967296.0f, x);
+                                    const unsigned long long fx =
+                                        ((unsigned long long)(unsigned)(int)hif << 32) | (unsigned)lof;
+                                    atomicAdd(l + c * slab_c, fx);
+                                }
                         }
                     } else {  // row outside the slab window: rare, straight to memory
 #pragma unroll
@@ -971,15 +984,64 @@ __device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFas
     }
 }
 
+// |x| maximum of the gradient volume as raw bits (|bits| are ordered like the values; a
+// NaN sorts above Inf), one atomicMax per workgroup
 template <typename T>
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const T *__restrict__ x, size_t n,
+                                                          unsigned *__restrict__ out)
+{
+    constexpr int V = 16 / sizeof(T);
+    unsigned m = 0;
+    const size_t nvec = (((uintptr_t)x & 15) == 0) ? n / V : 0;  // 16-byte loads when aligned
+    const uint4 *xv = (const uint4 *)x;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const uint4 q = xv[i];
+        if constexpr (sizeof(T) == 4) {
+            m = max(max(m, q.x & 0x7fffffffu), max(q.y & 0x7fffffffu, max(q.z & 0x7fffffffu, q.w & 0x7fffffffu)));
+        } else {
+            // two bf16 per dword: compare the high halves and the (shifted up) low halves
+            const unsigned hi = max(max(q.x & 0x7fff0000u, q.y & 0x7fff0000u), max(q.z & 0x7fff0000u, q.w & 0x7fff0000u));
+            const unsigned lo = max(max(q.x & 0x7fffu, q.y & 0x7fffu), max(q.z & 0x7fffu, q.w & 0x7fffu));
+            m = max(m, max(hi, lo << 16));
+        }
+    }
+    for (size_t i = nvec * V + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if constexpr (sizeof(T) == 4) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+        else m = max(m, ((unsigned)x[i] & 0x7fffu) << 16);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+template <typename T, int CW>
 __global__ __launch_bounds__(256, 2) void sweep_bwd_tile_kernel(
     SweepGeom g, SweepFast fast, BwdGrid tg, const T *__restrict__ gout,
-    const float *__restrict__ depths, const float *__restrict__ P,
-    const float *__restrict__ Pinv, const float *__restrict__ Tm, float *__restrict__ gcur,
-    float *__restrict__ gprev)
+    const unsigned *__restrict__ gmax_bits, const float *__restrict__ depths,
+    const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
+    float *__restrict__ gcur, float *__restrict__ gprev)
 {
-    extern __shared__ __attribute__((aligned(16))) float bwd_slab[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long bwd_slab[];
     __shared__ int yr[2 * BWD_MAXP];
+    // Fixed-point scale of the LDS accumulators: integer LDS atomics run at 10-14 lanes per
+    // clock, ds_add_f32 at 0.33 (profiles/r01_atomic_microbench.txt).  With M = max|grad_out|,
+    // a pixel of the slab receives < 2^11 * M in total (<= 32 planes x the <= 44 points whose
+    // footprint can cover it), so x * 2^(50 - exponent(M) - 1) stays below 2^61 and keeps 50
+    // bits below M -- finer than any fp32 accumulation.
+    const unsigned mb = *gmax_bits;
+    if (mb == 0) return;  // an all-zero gradient volume
+    if ((mb >> 23) == 0xffu) {
+        // Inf / NaN in the incoming gradients: they cannot be scaled; poison the result
+        const size_t total = (size_t)tg.batch * g.C * g.h_in * g.w_in;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            gcur[i] = __uint_as_float(0x7fc00000u);
+            gprev[i] = __uint_as_float(0x7fc00000u);
+        }
+        return;
+    }
+    const int sh = min(120, max(-100, 50 - ((int)(mb >> 23) - 127 + 1)));
+    const float fx_scale = __uint_as_float((unsigned)(sh + 127) << 23);
+    const float fx_inv = __uint_as_float((unsigned)(127 - sh) << 23);
     // block id = ((band*2 + half)*dchunks + dchunk)*batch + b
     int th = blockIdx.x;
     const int b = th % tg.batch;
@@ -989,9 +1051,11 @@ __global__ __launch_bounds__(256, 2) void sweep_bwd_tile_kernel(
     const int half = th & 1;
     const int band = th >> 1;
     if (half)
-        bwd_tile_body<T, 1>(g, fast, tg, b, band, dchunk, gout, depths, P, Pinv, Tm, gprev, bwd_slab, yr);
+        bwd_tile_body<T, 1, CW>(g, fast, tg, b, band, dchunk, gout, depths, P, Pinv, Tm, gprev,
+                                bwd_slab, yr, fx_scale, fx_inv);
     else
-        bwd_tile_body<T, 0>(g, fast, tg, b, band, dchunk, gout, depths, P, Pinv, Tm, gcur, bwd_slab, yr);
+        bwd_tile_body<T, 0, CW>(g, fast, tg, b, band, dchunk, gout, depths, P, Pinv, Tm, gcur,
+                                bwd_slab, yr, fx_scale, fx_inv);
 }
 
 // ---------------------------------------------------------------------------
@@ -1304,8 +1368,11 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
     hipStream_t st = (hipStream_t)stream;
     // dense sweeps whose feature rows fit the LDS: accumulate there (see sweep_bwd_tile_kernel)
     const int lds_budget = 80 * 1024;  // two workgroups per CU
-    const int rows = std::min((long long)desc->h_in,
-                              (long long)lds_budget / ((long long)BWD_CW * desc->w_in * 4));
+    // channels per pass: as many as leave >= 4 rows of 64-bit accumulators in the budget
+    int cw = 8;
+    while (cw > 2 && (long long)lds_budget / ((long long)cw * desc->w_in * 8) < 4) cw >>= 1;
+    const int rows = (int)std::min((long long)desc->h_in,
+                                   (long long)lds_budget / ((long long)cw * desc->w_in * 8));
     const long long hw = (long long)g.h_out * g.w_out;
     if (g_force_kernel != 1 && desc->cost_sample_factor < 1.5f && rows >= 4 && desc->h_in < 4096 &&
         desc->w_in < 8192) {
@@ -1318,7 +1385,7 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
         tg.rows = rows;
         const long long nb = (long long)tg.bands * 2 * tg.dchunks * desc->batch;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
-        const int lds_bytes = BWD_CW * rows * desc->w_in * 4;
+        const int lds_bytes = cw * rows * desc->w_in * 8;
         SweepFast fast;
         fast.scale_is_one = desc->img_scale_factor == 1.0f;
         {
@@ -1327,19 +1394,41 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
             fast.fsf_pow2 = (m == 0.5f) && e > -60 && e < 60;
             fast.inv_fsf = 1.0f / desc->feat_sample_factor;
         }
-        if (desc->dtype == DFM_F32) {
-            HIP_TRY(hipFuncSetAttribute((const void *)sweep_bwd_tile_kernel<float>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-            hipLaunchKernelGGL(sweep_bwd_tile_kernel<float>, dim3((unsigned)nb), dim3(256), lds_bytes,
-                               st, g, fast, tg, (const float *)grad_out, depths, cam2img, cam2img_inv,
-                               cur2prev, grad_cur, grad_prev);
-        } else {
-            HIP_TRY(hipFuncSetAttribute((const void *)sweep_bwd_tile_kernel<bf16_t>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-            hipLaunchKernelGGL(sweep_bwd_tile_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), lds_bytes,
-                               st, g, fast, tg, (const bf16_t *)grad_out, depths, cam2img,
-                               cam2img_inv, cur2prev, grad_cur, grad_prev);
+        // max |grad_out| of this call -> fixed-point scale (a 4-byte slot of a per-device ring)
+        unsigned *gmax = nullptr;
+        {
+            static std::mutex mu;
+            static unsigned *ring[64] = {};
+            static unsigned next[64] = {};
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64) return fail(DFM_ERR_UNSUPPORTED, "device index >= 64%s");
+            std::lock_guard<std::mutex> lk(mu);
+            if (!ring[dev]) HIP_TRY(hipMalloc((void **)&ring[dev], 16384 * sizeof(unsigned)));
+            gmax = ring[dev] + (next[dev]++ % 16384);
         }
+        HIP_TRY(hipMemsetAsync(gmax, 0, sizeof(unsigned), st));
+        const size_t nel = (size_t)desc->batch * 2 * g.C * g.N;
+#define DFM_BWD_LAUNCH(T, CW)                                                                        \
+    do {                                                                                             \
+        hipLaunchKernelGGL(absmax_bits_kernel<T>, dim3(4096), dim3(256), 0, st, (const T *)grad_out, \
+                           nel, gmax);                                                               \
+        HIP_TRY(hipFuncSetAttribute((const void *)sweep_bwd_tile_kernel<T, CW>,                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));         \
+        hipLaunchKernelGGL((sweep_bwd_tile_kernel<T, CW>), dim3((unsigned)nb), dim3(256), lds_bytes, \
+                           st, g, fast, tg, (const T *)grad_out, gmax, depths, cam2img, cam2img_inv, \
+                           cur2prev, grad_cur, grad_prev);                                           \
+    } while (0)
+        if (desc->dtype == DFM_F32) {
+            if (cw == 8) DFM_BWD_LAUNCH(float, 8);
+            else if (cw == 4) DFM_BWD_LAUNCH(float, 4);
+            else DFM_BWD_LAUNCH(float, 2);
+        } else {
+            if (cw == 8) DFM_BWD_LAUNCH(bf16_t, 8);
+            else if (cw == 4) DFM_BWD_LAUNCH(bf16_t, 4);
+            else DFM_BWD_LAUNCH(bf16_t, 2);
+        }
+#undef DFM_BWD_LAUNCH
         HIP_TRY(hipGetLastError());
         return DFM_OK;
     }

@@ -236,6 +236,38 @@ def test_backward_dense_sweep_matches_torch_cpu_autograd(pkg, case):
     _check_backward(pkg, **case)
 
 
+def test_backward_zero_and_nonfinite_gradients(pkg, kernel_mode):
+    """the dense-sweep backward scales the incoming gradients by their maximum: an all-zero
+    volume gives zero gradients, a NaN/Inf in it poisons the result instead of being scaled"""
+    if kernel_mode != 'lds256_p2':
+        pytest.skip('runs once')
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(0)
+    args = (torch.from_numpy(util.depth_planes(3)).to(dev), 4, 1, torch.from_numpy(util.KITTI_P2[None]),
+            torch.from_numpy(util.random_poses(1, seed=1)), (48, 160))
+    for poison in (None, float('nan'), float('inf')):
+        c = torch.from_numpy(rng.randn(1, 8, 12, 40).astype(np.float32)).to(dev).requires_grad_(True)
+        p = torch.from_numpy(rng.randn(1, 8, 12, 40).astype(np.float32)).to(dev).requires_grad_(True)
+        g = torch.zeros(1, 16, 3, 12, 40, device=dev)
+        if poison is not None:
+            g[0, 3, 1, 5, 7] = poison
+        pkg.build_dfm_cost(c, p, *args).backward(g)
+        if poison is None:
+            assert float(c.grad.abs().max()) == 0.0 and float(p.grad.abs().max()) == 0.0
+        else:
+            assert bool(torch.isnan(c.grad).any()) and not bool(torch.isfinite(c.grad[0, 3]).all())
+    # tiny and huge gradient scales keep their relative accuracy (the scale follows max |grad|)
+    for scale in (1e-20, 1e15):
+        c = torch.from_numpy(rng.randn(1, 8, 12, 40).astype(np.float32)).to(dev).requires_grad_(True)
+        p = torch.from_numpy(rng.randn(1, 8, 12, 40).astype(np.float32)).to(dev).requires_grad_(True)
+        g = torch.from_numpy(rng.randn(1, 16, 3, 12, 40).astype(np.float32)).to(dev)
+        pkg.build_dfm_cost(c, p, *args).backward(g)
+        g1 = c.grad.clone()
+        c.grad = p.grad = None
+        pkg.build_dfm_cost(c, p, *args).backward(g * scale)
+        assert torch.allclose(c.grad / scale, g1, rtol=1e-5, atol=1e-6)
+
+
 def test_backward_bf16_gradients(pkg):
     _check_backward(pkg, 1, 8, 24, 96, 9, 4, 1, (0, 0), 7, (96, 384), dtype=torch.bfloat16,
                     tol=dict(rtol=2e-2, atol=2e-2))

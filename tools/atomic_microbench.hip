@@ -27,6 +27,23 @@ __global__ __launch_bounds__(256) void lds_kernel(float *out, int iters) {
     __syncthreads();
     if (s[t] == 123.456f) out[0] = s[t];
 }
+template <typename I>
+__global__ __launch_bounds__(256) void lds_int_kernel(float *out, int iters) {
+    __shared__ I s[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) s[i] = 0;
+    __syncthreads();
+    const int t = threadIdx.x;
+    I v = (I)(1 + t);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int a = (it * 37 + j * 257 + t) & 4095;
+            atomicAdd(&s[a], v);
+        }
+    }
+    __syncthreads();
+    if (s[t] == (I)123456) out[0] = 1.0f;
+}
 template <int STRIDE>
 __global__ __launch_bounds__(256) void glob_kernel(float *buf, size_t n, int iters) {
     size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * STRIDE;
@@ -56,6 +73,10 @@ int main() {
     printf("lds atomic add f32, 16/64 lanes on  %8.3f ms  %8.1f G wave-instr/s (%.1f clk/instr/CU)\n", ms, ops / 64 / ms / 1e6, 256 * 2.4e9 / (ops / 64 / ms * 1e3));
     ms = timeit([&] { lds_kernel<0><<<blocks, 256>>>(out, iters); });
     printf("lds atomic add f32, 64/64 lanes on  %8.3f ms  %8.1f G wave-instr/s (%.1f clk/instr/CU)\n", ms, ops / 64 / ms / 1e6, 256 * 2.4e9 / (ops / 64 / ms * 1e3));
+    ms = timeit([&] { lds_int_kernel<unsigned int><<<blocks, 256>>>(out, iters); });
+    printf("lds atomic add u32, conflict-free   %8.3f ms  %8.1f G lane-ops/s  (%.2f lanes/clk/CU)\n", ms, ops / ms / 1e6, ops / ms / 1e6 / 256 / 2.4);
+    ms = timeit([&] { lds_int_kernel<unsigned long long><<<blocks, 256>>>(out, iters); });
+    printf("lds atomic add u64, conflict-free   %8.3f ms  %8.1f G lane-ops/s  (%.2f lanes/clk/CU)\n", ms, ops / ms / 1e6, ops / ms / 1e6 / 256 / 2.4);
     const int gi = 64;
     const double gops = 4096.0 * 256 * gi;
     ms = timeit([&] { glob_kernel<1><<<4096, 256>>>(buf, n, gi); });
