@@ -901,6 +901,43 @@ __device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFas
                 const bool sok = fin && yn >= -1.0f && yn <= (float)(H - 2);
                 if (!((wok || eok) && (nok || sok))) continue;  // no tap inside the map
                 const int ixw = (int)xw, iyn = (int)yn;  // in [-1, W-1] x [-1, H-1] here
+                if constexpr (HALF == 1) {
+                    // prev map: the footprint drifts with depth, a register run would end
+                    // (and scatter 9 cells) about every second plane -- more values than the
+                    // 4 taps per plane.  Scatter the taps directly; the atomics are cheap, the
+                    // float->fixed conversions are what this path costs.
+                    float gvf[BWD_CW];
+#pragma unroll
+                    for (int c = 0; c < BWD_CW; ++c) gvf[c] = c < nc ? elem<T>::load(src[k][c]) : 0.0f;
+                    const float cwt = wok ? fe : 0.0f, cet = eok ? fw : 0.0f;
+                    const float rnt = nok ? fs : 0.0f, rst = sok ? fn : 0.0f;
+                    const float wq[4] = {rnt * cwt, rnt * cet, rst * cwt, rst * cet};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (wq[q] == 0.0f) continue;  // out-of-bounds (or weightless) tap
+                        const int py = iyn + (q >> 1), px = ixw + (q & 1);
+                        const int rr = py - y0;  // >= 0: y0 <= the plane's first row
+                        const float ws = wq[q] * fx_scale;
+                        if (rr < rows) {
+                            unsigned long long *l = slab + rr * W + px;
+#pragma unroll
+                            for (int c = 0; c < BWD_CW; ++c) {
+                                if (c >= nc) continue;
+                                const float x = gvf[c] * ws;
+                                const float hif = floorf(x * 2.3283064365386963e-10f);
+                                const float lof = __builtin_fmaf(hif, -4294967296.0f, x);
+                                atomicAdd(l + c * slab_c,
+                                          ((unsigned long long)(unsigned)(int)hif << 32) | (unsigned)lof);
+                            }
+                        } else {  // plane taller than the slab window: rare, straight to memory
+                            float *gl = gf + (size_t)c0 * HW + (size_t)py * W + px;
+#pragma unroll
+                            for (int c = 0; c < BWD_CW; ++c)
+                                if (c < nc) atomicAdd(gl + (size_t)c * HW, gvf[c] * wq[q]);
+                        }
+                    }
+                    continue;
+                }
                 int by = (run_key[k] & 0x1fff) - 2, bx = (run_key[k] >> 13) - 2;
                 int ox = ixw - bx, oy = iyn - by;  // footprint corner inside the block: 0 or 1
                 const uint32_t cells = run_cells[k];
@@ -1014,7 +1051,9 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(const T *__restrict__ 
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
-template <typename T, int CW>
+// HALF = 0: gradient of the cur map (register runs), 1: of the prev map (direct scatter; it
+// needs a third of the registers, so it is its own kernel and launch)
+template <typename T, int CW, int HALF>
 __global__ __launch_bounds__(256, 2) void sweep_bwd_tile_kernel(
     SweepGeom g, SweepFast fast, BwdGrid tg, const T *__restrict__ gout,
     const unsigned *__restrict__ gmax_bits, const float *__restrict__ depths,
@@ -1042,20 +1081,14 @@ __global__ __launch_bounds__(256, 2) void sweep_bwd_tile_kernel(
     const int sh = min(120, max(-100, 50 - ((int)(mb >> 23) - 127 + 1)));
     const float fx_scale = __uint_as_float((unsigned)(sh + 127) << 23);
     const float fx_inv = __uint_as_float((unsigned)(127 - sh) << 23);
-    // block id = ((band*2 + half)*dchunks + dchunk)*batch + b
+    // block id = (band*dchunks + dchunk)*batch + b
     int th = blockIdx.x;
     const int b = th % tg.batch;
     th /= tg.batch;
     const int dchunk = th % tg.dchunks;
-    th /= tg.dchunks;
-    const int half = th & 1;
-    const int band = th >> 1;
-    if (half)
-        bwd_tile_body<T, 1, CW>(g, fast, tg, b, band, dchunk, gout, depths, P, Pinv, Tm, gprev,
-                                bwd_slab, yr, fx_scale, fx_inv);
-    else
-        bwd_tile_body<T, 0, CW>(g, fast, tg, b, band, dchunk, gout, depths, P, Pinv, Tm, gcur,
-                                bwd_slab, yr, fx_scale, fx_inv);
+    const int band = th / tg.dchunks;
+    bwd_tile_body<T, HALF, CW>(g, fast, tg, b, band, dchunk, gout, depths, P, Pinv, Tm,
+                               HALF ? gprev : gcur, bwd_slab, yr, fx_scale, fx_inv);
 }
 
 // ---------------------------------------------------------------------------
@@ -1369,23 +1402,29 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
     // dense sweeps whose feature rows fit the LDS: accumulate there (see sweep_bwd_tile_kernel)
     const int lds_budget = 80 * 1024;  // two workgroups per CU
     // channels per pass: as many as leave >= 4 rows of 64-bit accumulators in the budget
-    int cw = 8;
-    while (cw > 2 && (long long)lds_budget / ((long long)cw * desc->w_in * 8) < 4) cw >>= 1;
-    const int rows = (int)std::min((long long)desc->h_in,
-                                   (long long)lds_budget / ((long long)cw * desc->w_in * 8));
+    auto pick_cw = [&](int budget, int cw) {
+        while (cw > 2 && (long long)budget / ((long long)cw * desc->w_in * 8) < 4) cw >>= 1;
+        return cw;
+    };
+    auto rows_for = [&](int budget, int cw) {
+        return (int)std::min((long long)desc->h_in, (long long)budget / ((long long)cw * desc->w_in * 8));
+    };
+    // 4 channels per pass in half the LDS budget (four workgroups per CU) for both maps.
+    // Measured at N* (rocprofv3): prev map 8 ch / 80 KiB 24.7 ms, 4 ch / 40 KiB 19.1 ms (the
+    // direct scatter is latency-bound at two workgroups per CU); cur map 15.2 vs 14.8 ms.
+    const int cw_cur = pick_cw(lds_budget / 2, 4), cw_prev = pick_cw(lds_budget / 2, 4);
+    const int rows_cur = rows_for(lds_budget / 2, cw_cur), rows_prev = rows_for(lds_budget / 2, cw_prev);
     const long long hw = (long long)g.h_out * g.w_out;
-    if (g_force_kernel != 1 && desc->cost_sample_factor < 1.5f && rows >= 4 && desc->h_in < 4096 &&
-        desc->w_in < 8192) {
+    if (g_force_kernel != 1 && desc->cost_sample_factor < 1.5f && rows_cur >= 4 && rows_prev >= 4 &&
+        desc->h_in < 4096 && desc->w_in < 8192) {
         BwdGrid tg;
         tg.batch = desc->batch;
         tg.band_pts = 256 * BWD_PPL;
         tg.bands = (int)((hw + tg.band_pts - 1) / tg.band_pts);
         tg.planes = std::max(1, std::min(BWD_MAXP, (g.D + 3) / 4));
         tg.dchunks = (g.D + tg.planes - 1) / tg.planes;
-        tg.rows = rows;
-        const long long nb = (long long)tg.bands * 2 * tg.dchunks * desc->batch;
+        const long long nb = (long long)tg.bands * tg.dchunks * desc->batch;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
-        const int lds_bytes = cw * rows * desc->w_in * 8;
         SweepFast fast;
         fast.scale_is_one = desc->img_scale_factor == 1.0f;
         {
@@ -1409,25 +1448,34 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
         }
         HIP_TRY(hipMemsetAsync(gmax, 0, sizeof(unsigned), st));
         const size_t nel = (size_t)desc->batch * 2 * g.C * g.N;
-#define DFM_BWD_LAUNCH(T, CW)                                                                        \
+#define DFM_BWD_LAUNCH(T, CW, HALF, ROWS)                                                            \
     do {                                                                                             \
-        hipLaunchKernelGGL(absmax_bits_kernel<T>, dim3(4096), dim3(256), 0, st, (const T *)grad_out, \
-                           nel, gmax);                                                               \
-        HIP_TRY(hipFuncSetAttribute((const void *)sweep_bwd_tile_kernel<T, CW>,                      \
+        tg.rows = (ROWS);                                                                            \
+        const int lds_bytes = (CW) * (ROWS) * desc->w_in * 8;                                        \
+        HIP_TRY(hipFuncSetAttribute((const void *)sweep_bwd_tile_kernel<T, CW, HALF>,                \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));         \
-        hipLaunchKernelGGL((sweep_bwd_tile_kernel<T, CW>), dim3((unsigned)nb), dim3(256), lds_bytes, \
-                           st, g, fast, tg, (const T *)grad_out, gmax, depths, cam2img, cam2img_inv, \
-                           cur2prev, grad_cur, grad_prev);                                           \
+        hipLaunchKernelGGL((sweep_bwd_tile_kernel<T, CW, HALF>), dim3((unsigned)nb), dim3(256),      \
+                           lds_bytes, st, g, fast, tg, (const T *)grad_out, gmax, depths, cam2img,   \
+                           cam2img_inv, cur2prev, grad_cur, grad_prev);                              \
+    } while (0)
+#define DFM_BWD_HALF(T, HALF, CWV, ROWS)                                                             \
+    do {                                                                                             \
+        if ((CWV) == 8) DFM_BWD_LAUNCH(T, 8, HALF, ROWS);                                            \
+        else if ((CWV) == 4) DFM_BWD_LAUNCH(T, 4, HALF, ROWS);                                       \
+        else DFM_BWD_LAUNCH(T, 2, HALF, ROWS);                                                       \
     } while (0)
         if (desc->dtype == DFM_F32) {
-            if (cw == 8) DFM_BWD_LAUNCH(float, 8);
-            else if (cw == 4) DFM_BWD_LAUNCH(float, 4);
-            else DFM_BWD_LAUNCH(float, 2);
+            hipLaunchKernelGGL(absmax_bits_kernel<float>, dim3(4096), dim3(256), 0, st,
+                               (const float *)grad_out, nel, gmax);
+            DFM_BWD_HALF(float, 0, cw_cur, rows_cur);
+            DFM_BWD_HALF(float, 1, cw_prev, rows_prev);
         } else {
-            if (cw == 8) DFM_BWD_LAUNCH(bf16_t, 8);
-            else if (cw == 4) DFM_BWD_LAUNCH(bf16_t, 4);
-            else DFM_BWD_LAUNCH(bf16_t, 2);
+            hipLaunchKernelGGL(absmax_bits_kernel<bf16_t>, dim3(4096), dim3(256), 0, st,
+                               (const bf16_t *)grad_out, nel, gmax);
+            DFM_BWD_HALF(bf16_t, 0, cw_cur, rows_cur);
+            DFM_BWD_HALF(bf16_t, 1, cw_prev, rows_prev);
         }
+#undef DFM_BWD_HALF
 #undef DFM_BWD_LAUNCH
         HIP_TRY(hipGetLastError());
         return DFM_OK;
