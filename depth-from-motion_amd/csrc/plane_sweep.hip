@@ -14,8 +14,9 @@
 //                         of the volume bytes).
 //   sweep_gather_kernel : one lane = one lattice point; loops channel blocks,
 //                         four 16-B taps per map straight from L2/L1.
-//   sweep_bwd_tile_kernel: backward of dense sweeps, gradients accumulated in LDS rows.
-//   sweep_bwd_kernel    : backward fallback, lane-per-point scatter-add (global atomics).
+//   sweep_bwd_tile_kernel: backward, gradients accumulated in fixed-point LDS rows.
+//   sweep_bwd_kernel    : backward fallback (maps wider than the LDS rows), lane-per-point
+//                         scatter-add with global atomics.
 //   sweep_grid_kernel   : parity aid, dumps the normalised grids.
 #include "dfm_common.h"
 
@@ -709,6 +710,10 @@ constexpr int BWD_MAXP = 32;  // depth planes per workgroup, at most
 
 struct BwdGrid {
     int batch, bands, band_pts, planes, dchunks, rows;
+    int row_tiles;  // 0: bands are runs of band_pts points of the flat (h, w) index;
+                    // > 0 (strided sweeps): that many bands per lattice row, none crossing rows --
+                    // consecutive lattice rows sample feature rows `cost_sample_factor` apart,
+                    // which one slab window cannot hold
 };
 
 template <typename T, int HALF, int BWD_CW>
@@ -726,7 +731,12 @@ __device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFas
     const int tid = threadIdx.x;
     const int hw = g.h_out * g.w_out;
     const int W = g.w_in, H = g.h_in, HW = H * W;
-    const int p_lo = band * tg.band_pts, p_hi = min(p_lo + tg.band_pts, hw);
+    int p_lo = band * tg.band_pts, p_hi = min(p_lo + tg.band_pts, hw);
+    if (tg.row_tiles > 0) {
+        const int row = band / tg.row_tiles, t = band - row * tg.row_tiles;
+        p_lo = row * g.w_out + t * tg.band_pts;
+        p_hi = min(p_lo + tg.band_pts, (row + 1) * g.w_out);
+    }
     const int d_lo = dchunk * tg.planes, d_hi = min(d_lo + tg.planes, g.D);
     const int rows = tg.rows, slab_c = rows * W;
     const float *Pb = P + b * 16, *Pib = Pinv + b * 16, *Tb = Tm + b * 16;
@@ -1412,15 +1422,18 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
     // 4 channels per pass in half the LDS budget (four workgroups per CU) for both maps.
     // Measured at N* (rocprofv3): prev map 8 ch / 80 KiB 24.7 ms, 4 ch / 40 KiB 19.1 ms (the
     // direct scatter is latency-bound at two workgroups per CU); cur map 15.2 vs 14.8 ms.
-    const int cw_cur = pick_cw(lds_budget / 2, 4), cw_prev = pick_cw(lds_budget / 2, 4);
-    const int rows_cur = rows_for(lds_budget / 2, cw_cur), rows_prev = rows_for(lds_budget / 2, cw_prev);
+    // (wide maps that leave fewer than 4 rows in 40 KiB take the whole budget)
+    int budget = lds_budget / 2;
+    if (rows_for(budget, pick_cw(budget, 4)) < 4) budget = lds_budget;
+    const int cw_cur = pick_cw(budget, 4), cw_prev = cw_cur;
+    const int rows_cur = rows_for(budget, cw_cur), rows_prev = rows_cur;
     const long long hw = (long long)g.h_out * g.w_out;
-    if (g_force_kernel != 1 && desc->cost_sample_factor < 1.5f && rows_cur >= 4 && rows_prev >= 4 &&
-        desc->h_in < 4096 && desc->w_in < 8192) {
+    if (g_force_kernel != 1 && rows_cur >= 4 && desc->h_in < 4096 && desc->w_in < 8192) {
         BwdGrid tg;
         tg.batch = desc->batch;
         tg.band_pts = 256 * BWD_PPL;
-        tg.bands = (int)((hw + tg.band_pts - 1) / tg.band_pts);
+        tg.row_tiles = desc->cost_sample_factor < 1.5f ? 0 : (g.w_out + tg.band_pts - 1) / tg.band_pts;
+        tg.bands = tg.row_tiles ? g.h_out * tg.row_tiles : (int)((hw + tg.band_pts - 1) / tg.band_pts);
         tg.planes = std::max(1, std::min(BWD_MAXP, (g.D + 3) / 4));
         tg.dchunks = (g.D + tg.planes - 1) / tg.planes;
         const long long nb = (long long)tg.bands * tg.dchunks * desc->batch;
