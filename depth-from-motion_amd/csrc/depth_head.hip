@@ -15,6 +15,8 @@
 // Bound: HBM write (2 volumes), ~8 cached loads + 1 exp per element.
 #include "dfm_common.h"
 
+#include <algorithm>
+
 using namespace dfm;
 
 namespace {
@@ -256,6 +258,118 @@ __global__ __launch_bounds__(256) void depth_head_bwd_kernel(
     }
 }
 
+// Tiled backward: a workgroup owns 4 output rows x 64 output columns (lane = one output
+// pixel column, all 4D depths) and the few input pixels under them.  The logit gradients of
+// a column are first reduced along depth in registers (the ~s outputs that share an input
+// depth interval), then added into an LDS tile [D][rows][cols] of the input -- 4 LDS atomics
+// per input depth and lane instead of 8 global atomics per OUTPUT element -- and the tile goes
+// to memory with one atomic per input element.  The logits are recomputed with the forward's
+// rolling columns.  (The scatter-per-output kernel above stays as the fallback for tiles
+// that do not fit the LDS: scale 1, very deep volumes.)
+template <typename T>
+__global__ __launch_bounds__(256) void depth_head_bwd_tile_kernel(
+    const T *__restrict__ in, int D, int H, int W, int s, const float *__restrict__ depth_samples,
+    const T *__restrict__ gvol, const T *__restrict__ gsoft, const T *__restrict__ gpred,
+    float *__restrict__ gin, int nr, int ncol)
+{
+    extern __shared__ float dh_tile[];  // [D][nr][ncol]
+    const int Do = D * s, Ho = H * s, Wo = W * s;
+    const int b = blockIdx.z;
+    const int h0 = blockIdx.y * 4, w0 = blockIdx.x * 64;
+    const int h = h0 + (threadIdx.x >> 6), w = w0 + (threadIdx.x & 63);
+    const bool live = h < Ho && w < Wo;
+    // input window under the tile
+    const int ih_lo = up_index(h0, H, Ho).i0, iw_lo = up_index(w0, W, Wo).i0;
+    const int tile_n = D * nr * ncol;
+    for (int i = threadIdx.x; i < tile_n; i += 256) dh_tile[i] = 0.0f;
+    __syncthreads();
+    const T *x = in + (size_t)b * D * H * W;
+    if (live) {
+        const UpIdx uh = up_index(h, H, Ho), uw = up_index(w, W, Wo);
+        const int r0 = uh.i0 * W, r1 = uh.i1 * W;
+        auto column = [&](int i) {
+            const T *p = x + (size_t)i * H * W;
+            const float a = lerp_fma(uw.w0, elem<T>::load(p[r0 + uw.i0]), uw.w1, elem<T>::load(p[r0 + uw.i1]));
+            const float bb = lerp_fma(uw.w0, elem<T>::load(p[r1 + uw.i0]), uw.w1, elem<T>::load(p[r1 + uw.i1]));
+            return lerp_fma(uh.w0, a, uh.w1, bb);
+        };
+        float c0 = 0.0f, c1 = 0.0f;
+        int have = -1;
+        auto logit = [&](int d) {
+            const UpIdx ud = up_index(d, D, Do);
+            if (ud.i0 != have) {
+                c0 = (ud.i0 == have + 1 && have >= 0) ? c1 : column(ud.i0);
+                c1 = column(ud.i1);
+                have = ud.i0;
+            }
+            return lerp_fma(ud.w0, c0, ud.w1, c1);
+        };
+        const size_t plane_o = (size_t)Ho * Wo;
+        const size_t pix = (size_t)h * Wo + w;
+        const size_t col = (size_t)b * Do * plane_o + pix;
+        const bool soft_path = gsoft || gpred;
+        float mx = -INFINITY, sum = 0.0f, dotps = 0.0f;
+        const float gp = gpred ? elem<T>::load(gpred[(size_t)b * plane_o + pix]) : 0.0f;
+        if (soft_path) {
+            for (int d = 0; d < Do; ++d) mx = fmaxf(mx, logit(d));
+            have = -1;
+            for (int d = 0; d < Do; ++d) sum += expf(logit(d) - mx);
+            have = -1;
+            for (int d = 0; d < Do; ++d) {
+                const float p = expf(logit(d) - mx) / sum;
+                const float sd = (gsoft ? elem<T>::load(gsoft[col + (size_t)d * plane_o]) : 0.0f) +
+                                 gp * depth_samples[d];
+                dotps += p * sd;
+            }
+            have = -1;
+        }
+        // the four (h, w) taps of this column inside the tile
+        const int t00 = (uh.i0 - ih_lo) * ncol + (uw.i0 - iw_lo), t01 = (uh.i0 - ih_lo) * ncol + (uw.i1 - iw_lo);
+        const int t10 = (uh.i1 - ih_lo) * ncol + (uw.i0 - iw_lo), t11 = (uh.i1 - ih_lo) * ncol + (uw.i1 - iw_lo);
+        const float w00 = uh.w0 * uw.w0, w01 = uh.w0 * uw.w1, w10 = uh.w1 * uw.w0, w11 = uh.w1 * uw.w1;
+        const int dstride = nr * ncol;
+        auto put = [&](int i, float a) {  // input depth i receives a (already weighted along depth)
+            if (a == 0.0f) return;
+            float *t = dh_tile + i * dstride;
+            atomicAdd(t + t00, a * w00); atomicAdd(t + t01, a * w01);
+            atomicAdd(t + t10, a * w10); atomicAdd(t + t11, a * w11);
+        };
+        float a_lo = 0.0f, a_hi = 0.0f;  // pending sums for input depths cur and cur + 1
+        int cur = 0;
+        for (int d = 0; d < Do; ++d) {
+            float gl = gvol ? elem<T>::load(gvol[col + (size_t)d * plane_o]) : 0.0f;
+            if (soft_path) {
+                const float p = expf(logit(d) - mx) / sum;
+                const float sd = (gsoft ? elem<T>::load(gsoft[col + (size_t)d * plane_o]) : 0.0f) +
+                                 gp * depth_samples[d];
+                gl += p * (sd - dotps);
+            }
+            const UpIdx ud = up_index(d, D, Do);
+            while (cur < ud.i0) {  // the interval moved on: the lower depth is complete
+                put(cur, a_lo);
+                a_lo = a_hi;
+                a_hi = 0.0f;
+                ++cur;
+            }
+            a_lo += gl * ud.w0;
+            if (ud.i1 != ud.i0) a_hi += gl * ud.w1;
+            else a_lo += gl * ud.w1;  // last plane: i1 == i0
+        }
+        put(cur, a_lo);
+        if (cur + 1 < D) put(cur + 1, a_hi);
+    }
+    __syncthreads();
+    float *gx = gin + (size_t)b * D * H * W;
+    for (int i = threadIdx.x; i < tile_n; i += 256) {
+        const float v = dh_tile[i];
+        if (v == 0.0f) continue;
+        const int di = i / (nr * ncol), rem = i - di * (nr * ncol);
+        const int r = rem / ncol, c = rem - r * ncol;
+        const int ih = ih_lo + r, iw = iw_lo + c;
+        if (ih < H && iw < W) atomicAdd(gx + ((size_t)di * H + ih) * W + iw, v);
+    }
+}
+
 }  // namespace
 
 extern "C" DFM_API int dfm_depth_head_bwd(int32_t batch, int32_t d, int32_t h, int32_t w,
@@ -270,9 +384,32 @@ extern "C" DFM_API int dfm_depth_head_bwd(int32_t batch, int32_t d, int32_t h, i
         return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
     if (!cost || !depth_samples || !grad_cost)
         return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        // tiled kernel when the input window of a 4 x 64 output tile fits 64 KiB of LDS
+        const int Ho = h * scale, Wo = w * scale;
+        const double sh = Ho > 1 ? (double)(h - 1) / (Ho - 1) : 0.0, sw = Wo > 1 ? (double)(w - 1) / (Wo - 1) : 0.0;
+        const int nr = std::min(h, (int)(3 * sh) + 3), ncol = std::min(w, (int)(63 * sw) + 3);
+        const size_t lds = (size_t)d * nr * ncol * sizeof(float);
+        if (lds <= 64 * 1024 && batch <= 65535 && (Ho + 3) / 4 <= 65535) {
+            dim3 tg((Wo + 63) / 64, (Ho + 3) / 4, batch);
+            if (dtype == DFM_F32)
+                hipLaunchKernelGGL(depth_head_bwd_tile_kernel<float>, tg, dim3(256), lds, st,
+                                   (const float *)cost, d, h, w, scale, depth_samples,
+                                   (const float *)grad_volumes, (const float *)grad_softmax,
+                                   (const float *)grad_preds, grad_cost, nr, ncol);
+            else
+                hipLaunchKernelGGL(depth_head_bwd_tile_kernel<bf16_t>, tg, dim3(256), lds, st,
+                                   (const bf16_t *)cost, d, h, w, scale, depth_samples,
+                                   (const bf16_t *)grad_volumes, (const bf16_t *)grad_softmax,
+                                   (const bf16_t *)grad_preds, grad_cost, nr, ncol);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+            return DFM_OK;
+        }
+    }
     const int npix = h * scale * w * scale;
     dim3 grid((npix + 255) / 256, batch);
-    hipStream_t st = (hipStream_t)stream;
     if (dtype == DFM_F32)
         hipLaunchKernelGGL(depth_head_bwd_kernel<float>, grid, dim3(256), 0, st, (const float *)cost,
                            d, h, w, scale, depth_samples, (const float *)grad_volumes,

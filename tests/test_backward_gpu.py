@@ -48,6 +48,25 @@ def test_depth_head_backward(pkg):
     np.testing.assert_allclose(xg2.grad.cpu().numpy(), xr2.grad.numpy(), **TOL)
 
 
+@pytest.mark.parametrize('shape,scale', [((1, 1, 7, 9, 70), 4), ((2, 1, 5, 6, 40), 2)])
+def test_depth_head_backward_tiles(pkg, shape, scale):
+    """several 4 x 64 output tiles incl. partial ones; bf16 storage of the incoming gradients"""
+    rng = np.random.RandomState(3)
+    x = torch.from_numpy((rng.randn(*shape) * 2).astype(np.float32))
+    D = shape[2]
+    ds = torch.linspace(2.0, 59.6, scale * D)
+    xr = x.clone().requires_grad_(True)
+    vol = F.interpolate(xr, scale_factor=scale, mode='trilinear', align_corners=True)
+    soft = F.softmax(vol, dim=2)
+    pred = torch.sum(soft * ds[None, None, :, None, None], 2)
+    gv, gs, gp = (torch.from_numpy(rng.randn(*t.shape).astype(np.float32)) for t in (vol, soft, pred))
+    torch.autograd.backward([vol, soft, pred], [gv, gs, gp])
+    xg = x.cuda().requires_grad_(True)
+    v2, s2, p2 = pkg.depth_head_forward(xg, ds, scale)
+    torch.autograd.backward([v2, s2, p2], [gv.cuda(), gs.cuda(), gp.cuda()])
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-5)
+
+
 def _f2v_torch(stereo, soft, sem, coords, cam2img, pad, dmin, dmax):
     """feature_transformation.py:82-158 with torch ops (test-side restatement)."""
     outs = []
