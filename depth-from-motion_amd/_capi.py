@@ -33,6 +33,7 @@ EXPORTS = (
     'dfm_frustum_to_voxel_workspace_bytes',
     'dfm_frustum_to_voxel_fwd',
     'dfm_depth_head_fwd',
+    'dfm_frustum_to_voxel_bwd_workspace_bytes',
     'dfm_frustum_to_voxel_bwd',
     'dfm_point_sample_mv_bwd',
     'dfm_depth_head_bwd',
@@ -169,7 +170,10 @@ def lib():
     h.dfm_depth_head_fwd.restype = ctypes.c_int
     h.dfm_depth_head_fwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, vp]
     h.dfm_frustum_to_voxel_bwd.restype = ctypes.c_int
-    h.dfm_frustum_to_voxel_bwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, fp, fp, fp, fp, vp]
+    h.dfm_frustum_to_voxel_bwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, fp, fp, fp, fp, vp,
+                                           ctypes.c_size_t, vp]
+    h.dfm_frustum_to_voxel_bwd_workspace_bytes.restype = ctypes.c_size_t
+    h.dfm_frustum_to_voxel_bwd_workspace_bytes.argtypes = [ctypes.POINTER(F2vDesc)]
     h.dfm_point_sample_mv_bwd.restype = ctypes.c_int
     h.dfm_point_sample_mv_bwd.argtypes = [mp, vp, fp, fp, fp, fp, vp]
     h.dfm_depth_head_bwd.restype = ctypes.c_int

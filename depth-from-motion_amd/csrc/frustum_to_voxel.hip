@@ -387,12 +387,155 @@ __global__ __launch_bounds__(256) void f2v_bwd_kernel(F2vGeom g, const T *__rest
     }
 }
 
+// Pixel-major backward.  Scattered global fp32 atomics run at ~20 G/s, a wave whose 64
+// addresses are consecutive at ~320 G/s (profiles/r01_atomic_microbench.txt).  So the gradients
+// are accumulated in pixel-major scratch ([d*h*w][C] and [h*w][Cs], fp32): the lanes of a wave
+// are the CHANNELS of a voxel, a tap is one contiguous run of C atomics.  A workgroup takes 64
+// voxels: their grad_out rows come in through an LDS tile (read along voxels, used along
+// channels), their footprints are computed once per voxel; a transpose pass adds the scratch into
+// the caller's NC(D)HW gradients.
+constexpr int F2V_VT = 64;  // voxels per workgroup
+
+struct BwdFoot {
+    int st[8];     // stereo pixel index per corner, -1 = no contribution
+    float sw[8];
+    int sm[4];     // semantic-map pixel index per corner, -1 = none
+    float mw[4];   // corner weight * depth probability
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void f2v_bwd_pm_kernel(F2vGeom g, const T *__restrict__ gout,
+                                                         const T *__restrict__ soft,
+                                                         const float *__restrict__ coords,
+                                                         const float *__restrict__ cam2img,
+                                                         float *__restrict__ gst_pm,
+                                                         float *__restrict__ gsem_pm)
+{
+    extern __shared__ float f2v_lds[];
+    const int CT = g.C + g.Cs;
+    float *gt = f2v_lds;                                   // [CT][F2V_VT + 1]
+    BwdFoot *foot = (BwdFoot *)(gt + CT * (F2V_VT + 1));   // [F2V_VT]
+    const long long N = (long long)g.Nz * g.Ny * g.Nx;
+    const long long v0 = (long long)blockIdx.x * F2V_VT;
+    const int b = blockIdx.y;
+    const int nv = (int)min((long long)F2V_VT, N - v0);
+    const int tid = threadIdx.x;
+    // grad_out rows of the tile: one channel per wave pass, 64 consecutive voxels per load
+    const T *go = gout + (size_t)b * CT * N + v0;
+    for (int i = tid; i < CT * F2V_VT; i += 256) {
+        const int c = i / F2V_VT, v = i - c * F2V_VT;
+        gt[c * (F2V_VT + 1) + v] = v < nv ? elem<T>::load(go[(size_t)c * N + v]) : 0.0f;
+    }
+    if (tid < F2V_VT) {
+        BwdFoot f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { f.st[k] = -1; f.sw[k] = 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f.sm[k] = -1; f.mw[k] = 0.0f; }
+        if (tid < nv) {
+            const long long i = v0 + tid;
+            const float xs = coords[3 * i], ys = coords[3 * i + 1], zs = coords[3 * i + 2];
+            const float *P = cam2img + 16 * b;
+            const float a = dot4_chain(-ys, -zs, xs, 1.0f, P + 0);
+            const float bb = dot4_chain(-ys, -zs, xs, 1.0f, P + 4);
+            const float c = dot4_chain(-ys, -zs, xs, 1.0f, P + 8);
+            const float u = a / c, v = bb / c;
+            const bool valid2d = (u >= 0.0f) && (u <= g.pad_w) && (v >= 0.0f) && (v <= g.pad_h);
+            float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
+            float gz = (xs - g.depth_min) / g.depth_span;
+            gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
+            if (valid2d && gz >= -1.0f && gz <= 1.0f) {
+                const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (t.ok & (1u << k)) { f.st[k] = t.o[k]; f.sw[k] = t.w[k]; }
+                if (g.Cs > 0) {  // Voxel_2D = sample(sem) * valid2d * (disp * valid)
+                    const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+                    const float disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
+                    const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (t2.ok & (1u << k)) { f.sm[k] = t2.o[k]; f.mw[k] = t2.w[k] * disp; }
+                }
+            }
+        }
+        foot[tid] = f;
+    }
+    __syncthreads();
+    // lanes = channels of a voxel: [voxel in iteration][channel]
+    const int wave = tid >> 6, lane = tid & 63;
+    int lpv = 1;
+    while (lpv < min(max(g.C, g.Cs), 64)) lpv <<= 1;  // lanes per voxel
+    const int ch = lane & (lpv - 1), vin = lane / lpv, vpi = 64 / lpv;
+    float *gs = gst_pm + (size_t)b * g.D * g.H * g.W * g.C;
+    float *gm = gsem_pm + (size_t)b * g.Hsem * g.Wsem * g.Cs;
+    for (int it = 0; it < F2V_VT / 4; it += vpi) {
+        const int v = wave * (F2V_VT / 4) + it + vin;
+        if (v >= nv) continue;
+        const BwdFoot &f = foot[v];
+        for (int c = ch; c < g.C; c += lpv) {
+            const float gv = gt[c * (F2V_VT + 1) + v];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (f.st[k] >= 0) atomicAdd(gs + (size_t)f.st[k] * g.C + c, gv * f.sw[k]);
+        }
+        for (int c = ch; c < g.Cs; c += lpv) {
+            const float gv = gt[(g.C + c) * (F2V_VT + 1) + v];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (f.sm[k] >= 0) atomicAdd(gm + (size_t)f.sm[k] * g.Cs + c, gv * f.mw[k]);
+        }
+    }
+}
+
+// dst (n, C, P) += src (n, P, C): 64 pixels x 32 channels per workgroup through LDS
+__global__ __launch_bounds__(256) void add_from_pixel_major_kernel(const float *__restrict__ src,
+                                                                   float *__restrict__ dst, int C,
+                                                                   long long P)
+{
+    __shared__ float tile[64][32 + 1];
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const size_t n = blockIdx.z;
+    {
+        const int c = threadIdx.x & 31, pp = threadIdx.x >> 5;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = pp + 8 * k;
+            tile[p][c] = (c0 + c < C && p0 + p < P) ? src[(n * (size_t)P + p0 + p) * C + c0 + c] : 0.0f;
+        }
+    }
+    __syncthreads();
+    {
+        const int p = threadIdx.x & 63, cc = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = cc + 4 * k;
+            if (c0 + c < C && p0 + p < P) {
+                float *q = dst + (n * C + c0 + c) * (size_t)P + p0 + p;
+                *q = *q + tile[p][c];
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" DFM_API size_t dfm_frustum_to_voxel_bwd_workspace_bytes(const dfm_f2v_desc *d)
+{
+    if (!d || d->batch <= 0 || d->channels <= 0 || d->d <= 0 || d->h <= 0 || d->w <= 0 ||
+        d->sem_channels < 0)
+        return 0;
+    const size_t a = (size_t)d->batch * d->channels * d->d * d->h * d->w * sizeof(float);
+    const size_t b = (size_t)d->batch * d->sem_channels * d->hsem * d->wsem * sizeof(float);
+    return ((a + 255) & ~(size_t)255) + ((b + 255) & ~(size_t)255) + 256;
+}
 
 extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const void *grad_out,
                                                 const void *softmax, const float *coords,
                                                 const float *cam2img, float *grad_stereo,
-                                                float *grad_sem, void *stream)
+                                                float *grad_sem, void *workspace,
+                                                size_t workspace_bytes, void *stream)
 {
     if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
     if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
@@ -406,8 +549,43 @@ extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const voi
     g.Nz = d->nz; g.Ny = d->ny; g.Nx = d->nx;
     g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.depth_min = d->depth_min; g.depth_span = d->depth_span;
     const long long N = (long long)d->nz * d->ny * d->nx;
-    dim3 grid((unsigned)((N + 255) / 256), d->batch);
     hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(d->channels + d->sem_channels) * (F2V_VT + 1) * sizeof(float) +
+                       F2V_VT * sizeof(BwdFoot);
+    if (workspace && lds <= 64 * 1024 && d->batch <= 65535) {
+        // pixel-major accumulation (see f2v_bwd_pm_kernel)
+        if (workspace_bytes < dfm_frustum_to_voxel_bwd_workspace_bytes(d))
+            return set_error(DFM_ERR_WORKSPACE,
+                             "workspace smaller than dfm_frustum_to_voxel_bwd_workspace_bytes");
+        const long long vox = (long long)d->d * d->h * d->w, pix = (long long)d->hsem * d->wsem;
+        const size_t a = ((size_t)d->batch * d->channels * vox * sizeof(float) + 255) & ~(size_t)255;
+        const size_t bsz = (size_t)d->batch * d->sem_channels * pix * sizeof(float);
+        float *gst_pm = (float *)workspace, *gsem_pm = (float *)((char *)workspace + a);
+        hipError_t e = hipMemsetAsync(workspace, 0, a + bsz, st);
+        if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+        dim3 grid((unsigned)((N + F2V_VT - 1) / F2V_VT), d->batch);
+        if (d->dtype == DFM_F32)
+            hipLaunchKernelGGL(f2v_bwd_pm_kernel<float>, grid, dim3(256), lds, st, g,
+                               (const float *)grad_out, (const float *)softmax, coords, cam2img,
+                               gst_pm, gsem_pm);
+        else
+            hipLaunchKernelGGL(f2v_bwd_pm_kernel<bf16_t>, grid, dim3(256), lds, st, g,
+                               (const bf16_t *)grad_out, (const bf16_t *)softmax, coords, cam2img,
+                               gst_pm, gsem_pm);
+        dim3 t1((unsigned)((vox + 63) / 64), (d->channels + 31) / 32, d->batch);
+        hipLaunchKernelGGL(add_from_pixel_major_kernel, t1, dim3(256), 0, st, gst_pm, grad_stereo,
+                           d->channels, vox);
+        if (d->sem_channels > 0) {
+            dim3 t2((unsigned)((pix + 63) / 64), (d->sem_channels + 31) / 32, d->batch);
+            hipLaunchKernelGGL(add_from_pixel_major_kernel, t2, dim3(256), 0, st, gsem_pm, grad_sem,
+                               d->sem_channels, pix);
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+        return DFM_OK;
+    }
+    // no workspace (or more channels than the LDS tile holds): lane-per-voxel scatter
+    dim3 grid((unsigned)((N + 255) / 256), d->batch);
     if (d->dtype == DFM_F32)
         hipLaunchKernelGGL(f2v_bwd_kernel<float>, grid, dim3(256), 0, st, g, (const float *)grad_out,
                            (const float *)softmax, coords, cam2img, grad_stereo, grad_sem);

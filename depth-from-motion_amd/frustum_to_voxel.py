@@ -45,13 +45,15 @@ class _F2vFn(torch.autograd.Function):
         go = grad_out.contiguous().to(dtype)
         g_st = torch.zeros(st_shape, dtype=torch.float32, device=device)
         g_sem = torch.zeros(sem_shape, dtype=torch.float32, device=device) if ctx.has_sem else None
+        nbytes = lib.dfm_frustum_to_voxel_bwd_workspace_bytes(ctypes.byref(desc))
+        ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
             _capi.check(
                 lib.dfm_frustum_to_voxel_bwd(ctypes.byref(desc), _ptr(go),
                                              _ptr(soft) if soft is not None else None, _ptr(coords),
                                              _ptr(cam4), _ptr(g_st),
-                                             _ptr(g_sem) if g_sem is not None else None,
-                                             _stream_ptr(device)))
+                                             _ptr(g_sem) if g_sem is not None else None, _ptr(ws),
+                                             nbytes, _stream_ptr(device)))
         return g_st.to(dtype), (g_sem.to(dtype) if g_sem is not None else None), None, None, None, None
 
 

@@ -268,10 +268,14 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *desc, const void *stere
  * detached in the reference, :136).  grad_out: (B, C+Cs, nz, ny, nx) dtype;
  * grad_stereo (B,C,d,h,w) and grad_sem (B,Cs,hsem,wsem): FP32, zero-filled by
  * the caller, accumulated with atomics. */
+/* workspace (optional): >= dfm_frustum_to_voxel_bwd_workspace_bytes(desc) bytes of
+ * scratch for the pixel-major gradient accumulators ((B, d*h*w, C) and
+ * (B, hsem*wsem, Cs) fp32); NULL selects the slower lane-per-voxel scatter. */
+DFM_API size_t dfm_frustum_to_voxel_bwd_workspace_bytes(const dfm_f2v_desc *desc);
 DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *desc, const void *grad_out,
                                      const void *softmax, const float *coords,
                                      const float *cam2img, float *grad_stereo, float *grad_sem,
-                                     void *stream);
+                                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* voxel_sample (voxel volume -> frustum), point_fusion.py:324-410          */
