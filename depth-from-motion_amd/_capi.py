@@ -35,6 +35,7 @@ EXPORTS = (
     'dfm_depth_head_fwd',
     'dfm_frustum_to_voxel_bwd_workspace_bytes',
     'dfm_frustum_to_voxel_bwd',
+    'dfm_point_sample_mv_bwd_workspace_bytes',
     'dfm_point_sample_mv_bwd',
     'dfm_depth_head_bwd',
     'dfm_voxel_sample_fwd',
@@ -175,7 +176,9 @@ def lib():
     h.dfm_frustum_to_voxel_bwd_workspace_bytes.restype = ctypes.c_size_t
     h.dfm_frustum_to_voxel_bwd_workspace_bytes.argtypes = [ctypes.POINTER(F2vDesc)]
     h.dfm_point_sample_mv_bwd.restype = ctypes.c_int
-    h.dfm_point_sample_mv_bwd.argtypes = [mp, vp, fp, fp, fp, fp, vp]
+    h.dfm_point_sample_mv_bwd.argtypes = [mp, vp, fp, fp, fp, fp, vp, sz, vp]
+    h.dfm_point_sample_mv_bwd_workspace_bytes.restype = sz
+    h.dfm_point_sample_mv_bwd_workspace_bytes.argtypes = [mp]
     h.dfm_depth_head_bwd.restype = ctypes.c_int
     h.dfm_depth_head_bwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, fp, vp]
     h.dfm_voxel_sample_fwd.restype = ctypes.c_int

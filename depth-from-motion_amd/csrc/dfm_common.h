@@ -300,4 +300,37 @@ __global__ __launch_bounds__(256) void pack_pixel_major_kernel(const T *__restri
     }
 }
 
+// the way back for gradients accumulated pixel-major (coalesced atomics):
+// dst (n, C, P) += src (n, P, C): 64 pixels x 32 channels per workgroup through LDS
+template <typename F = float>
+__global__ __launch_bounds__(256) void add_from_pixel_major_kernel(const float *__restrict__ src,
+                                                                   float *__restrict__ dst, int C,
+                                                                   long long P)
+{
+    __shared__ float tile[64][32 + 1];
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const size_t n = blockIdx.z;
+    {
+        const int c = threadIdx.x & 31, pp = threadIdx.x >> 5;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = pp + 8 * k;
+            tile[p][c] = (c0 + c < C && p0 + p < P) ? src[(n * (size_t)P + p0 + p) * C + c0 + c] : 0.0f;
+        }
+    }
+    __syncthreads();
+    {
+        const int p = threadIdx.x & 63, cc = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = cc + 4 * k;
+            if (c0 + c < C && p0 + p < P) {
+                float *q = dst + (n * C + c0 + c) * (size_t)P + p0 + p;
+                *q = *q + tile[p][c];
+            }
+        }
+    }
+}
+
 }  // namespace dfm

@@ -488,37 +488,6 @@ __global__ __launch_bounds__(256) void f2v_bwd_pm_kernel(F2vGeom g, const T *__r
     }
 }
 
-// dst (n, C, P) += src (n, P, C): 64 pixels x 32 channels per workgroup through LDS
-__global__ __launch_bounds__(256) void add_from_pixel_major_kernel(const float *__restrict__ src,
-                                                                   float *__restrict__ dst, int C,
-                                                                   long long P)
-{
-    __shared__ float tile[64][32 + 1];
-    const long long p0 = (long long)blockIdx.x * 64;
-    const int c0 = blockIdx.y * 32;
-    const size_t n = blockIdx.z;
-    {
-        const int c = threadIdx.x & 31, pp = threadIdx.x >> 5;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int p = pp + 8 * k;
-            tile[p][c] = (c0 + c < C && p0 + p < P) ? src[(n * (size_t)P + p0 + p) * C + c0 + c] : 0.0f;
-        }
-    }
-    __syncthreads();
-    {
-        const int p = threadIdx.x & 63, cc = threadIdx.x >> 6;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int c = cc + 4 * k;
-            if (c0 + c < C && p0 + p < P) {
-                float *q = dst + (n * C + c0 + c) * (size_t)P + p0 + p;
-                *q = *q + tile[p][c];
-            }
-        }
-    }
-}
-
 }  // namespace
 
 extern "C" DFM_API size_t dfm_frustum_to_voxel_bwd_workspace_bytes(const dfm_f2v_desc *d)
@@ -573,11 +542,11 @@ extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const voi
                                (const bf16_t *)grad_out, (const bf16_t *)softmax, coords, cam2img,
                                gst_pm, gsem_pm);
         dim3 t1((unsigned)((vox + 63) / 64), (d->channels + 31) / 32, d->batch);
-        hipLaunchKernelGGL(add_from_pixel_major_kernel, t1, dim3(256), 0, st, gst_pm, grad_stereo,
+        hipLaunchKernelGGL(add_from_pixel_major_kernel<float>, t1, dim3(256), 0, st, gst_pm, grad_stereo,
                            d->channels, vox);
         if (d->sem_channels > 0) {
             dim3 t2((unsigned)((pix + 63) / 64), (d->sem_channels + 31) / 32, d->batch);
-            hipLaunchKernelGGL(add_from_pixel_major_kernel, t2, dim3(256), 0, st, gsem_pm, grad_sem,
+            hipLaunchKernelGGL(add_from_pixel_major_kernel<float>, t2, dim3(256), 0, st, gsem_pm, grad_sem,
                                d->sem_channels, pix);
         }
         e = hipGetLastError();

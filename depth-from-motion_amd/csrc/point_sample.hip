@@ -325,11 +325,129 @@ __global__ __launch_bounds__(256) void mv_sample_bwd_kernel(
     }
 }
 
+// Pixel-major backward (same idea as f2v_bwd_pm_kernel): the lanes of a wave are the channels
+// of one voxel, so the C atomics of a tap are one contiguous run of the pixel-major scratch
+// [frame*view][Hf*Wf][C]; a transpose pass adds the scratch into grad_feats.
+constexpr int MV_VT = 64;  // voxels per workgroup
+
+struct MvFoot {
+    int idx[4];   // pixel per tap, -1 = none
+    float w[4];   // tap weight / number of valid views
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void mv_sample_bwd_pm_kernel(
+    MvGeom g, const T *__restrict__ gout, const float *__restrict__ points,
+    const float *__restrict__ proj, const float *__restrict__ ori_w, float *__restrict__ gf_pm)
+{
+    extern __shared__ float mv_lds[];
+    const int nvf = g.num_views * g.num_frames;
+    const int c_out = g.C * (g.aggregate ? g.num_frames : 1);
+    float *gt = mv_lds;                                  // [c_out][MV_VT + 1]
+    MvFoot *foot = (MvFoot *)(gt + c_out * (MV_VT + 1));  // [MV_VT][nvf]
+    const long long v0 = (long long)blockIdx.x * MV_VT;
+    const int nv = (int)min((long long)MV_VT, g.N - v0);
+    const int tid = threadIdx.x;
+    const size_t cstride = g.nz > 0 ? (size_t)g.N : 1, vstride = g.nz > 0 ? 1 : (size_t)c_out;
+    for (int i = tid; i < c_out * MV_VT; i += 256) {
+        const int c = i / MV_VT, v = i - c * MV_VT;
+        gt[c * (MV_VT + 1) + v] = v < nv ? elem<T>::load(gout[(size_t)(v0 + v) * vstride + c * cstride]) : 0.0f;
+    }
+    if (tid < MV_VT) {
+        for (int i = 0; i < nvf; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { foot[tid * nvf + i].idx[k] = -1; foot[tid * nvf + i].w[k] = 0.0f; }
+        if (tid < nv) {
+            const long long o = v0 + tid;
+            long long pidx = o;
+            if (g.nz > 0) {
+                const int z = (int)(o % g.nz);
+                const long long t = o / g.nz;
+                const int y = (int)(t % g.ny);
+                const int x = (int)(t / g.ny);
+                pidx = ((long long)z * g.ny + y) * g.nx + x;
+            }
+            const float px = points[3 * pidx], py = points[3 * pidx + 1], pz = points[3 * pidx + 2];
+            int tot_cnt = 0;
+            for (int i = 0; i < nvf; ++i) {
+                float nx, ny;
+                tot_cnt += project_view(g, proj + 16 * i, ori_w[i], px, py, pz, nx, ny) ? 1 : 0;
+            }
+            for (int f = 0; f < g.num_frames; ++f) {
+                int cnt = 0;
+                for (int v = 0; v < g.num_views; ++v) {
+                    float nx, ny;
+                    cnt += project_view(g, proj + 16 * (f * g.num_views + v), ori_w[f * g.num_views + v],
+                                        px, py, pz, nx, ny) ? 1 : 0;
+                }
+                const float den = g.valid_sample ? (float)max(g.aggregate ? cnt : tot_cnt, 1) : 1.0f;
+                for (int v = 0; v < g.num_views; ++v) {
+                    const int i = f * g.num_views + v;
+                    float nx, ny;
+                    const bool ok = project_view(g, proj + 16 * i, ori_w[i], px, py, pz, nx, ny);
+                    if (g.valid_sample && !ok) continue;
+                    const float x = ((nx + 1.0f) * 0.5f) * (float)(g.Wf - 1);
+                    const float y = ((ny + 1.0f) * 0.5f) * (float)(g.Hf - 1);
+                    MvFoot &ft = foot[tid * nvf + i];
+                    if (g.mode == 0) {
+                        const float xr = rintf(x), yr = rintf(y);
+                        if ((fabsf(x) <= 3.0e38f) && (fabsf(y) <= 3.0e38f) && xr >= 0.0f &&
+                            xr <= (float)(g.Wf - 1) && yr >= 0.0f && yr <= (float)(g.Hf - 1)) {
+                            ft.idx[0] = (int)yr * g.Wf + (int)xr;
+                            ft.w[0] = 1.0f / den;
+                        }
+                    } else {
+                        const Tap t = make_tap(x, y, g.Hf, g.Wf);
+                        const int i00 = t.iy * g.Wf + t.ix, i01 = i00 + t.dx;
+                        const int i10 = i00 + t.dy * g.Wf, i11 = i10 + t.dx;
+                        if (t.ok & 1u) { ft.idx[0] = i00; ft.w[0] = t.nw / den; }
+                        if (t.ok & 2u) { ft.idx[1] = i01; ft.w[1] = t.ne / den; }
+                        if (t.ok & 4u) { ft.idx[2] = i10; ft.w[2] = t.sw / den; }
+                        if (t.ok & 8u) { ft.idx[3] = i11; ft.w[3] = t.se / den; }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    int lpv = 1;
+    while (lpv < min(g.C, 64)) lpv <<= 1;  // lanes per voxel
+    const int ch = lane & (lpv - 1), vin = lane / lpv, vpi = 64 / lpv;
+    const size_t HW = (size_t)g.Hf * g.Wf;
+    for (int it = 0; it < MV_VT / 4; it += vpi) {
+        const int v = wave * (MV_VT / 4) + it + vin;
+        if (v >= nv) continue;
+        for (int i = 0; i < nvf; ++i) {
+            const MvFoot &ft = foot[v * nvf + i];
+            if (ft.idx[0] < 0 && ft.idx[1] < 0 && ft.idx[2] < 0 && ft.idx[3] < 0) continue;
+            const int f = i / g.num_views;
+            float *dst = gf_pm + (size_t)i * HW * g.C;
+            for (int c = ch; c < g.C; c += lpv) {
+                const float gv = gt[(g.aggregate ? f * g.C + c : c) * (MV_VT + 1) + v];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (ft.idx[k] >= 0) atomicAdd(dst + (size_t)ft.idx[k] * g.C + c, gv * ft.w[k]);
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" DFM_API size_t dfm_point_sample_mv_bwd_workspace_bytes(const dfm_mv_desc *d)
+{
+    if (!d || d->num_views <= 0 || d->num_frames <= 0 || d->channels <= 0 || d->feat_h <= 0 ||
+        d->feat_w <= 0)
+        return 0;
+    return (((size_t)d->num_views * d->num_frames * d->channels * d->feat_h * d->feat_w * sizeof(float)) +
+            255) & ~(size_t)255;
+}
 
 extern "C" DFM_API int dfm_point_sample_mv_bwd(const dfm_mv_desc *d, const void *grad_out,
                                                const float *points, const float *proj,
-                                               const float *ori_w, float *grad_feats, void *stream)
+                                               const float *ori_w, float *grad_feats,
+                                               void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!d) return fail_ps(DFM_ERR_INVALID_ARG, "desc is NULL");
     if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
@@ -343,8 +461,33 @@ extern "C" DFM_API int dfm_point_sample_mv_bwd(const dfm_mv_desc *d, const void 
     g.scale_x = d->scale_x; g.scale_y = d->scale_y; g.crop_x = d->crop_x; g.crop_y = d->crop_y;
     g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.flip = d->flip; g.mode = d->mode;
     g.aggregate = d->aggregate; g.valid_sample = d->valid_sample;
-    const long long nb = (g.N + 255) / 256;
     hipStream_t st = (hipStream_t)stream;
+    const int nvf = d->num_views * d->num_frames;
+    const int c_out = d->channels * (d->aggregate ? d->num_frames : 1);
+    const size_t lds = (size_t)c_out * (MV_VT + 1) * sizeof(float) + (size_t)MV_VT * nvf * sizeof(MvFoot);
+    if (workspace && lds <= 64 * 1024) {
+        // pixel-major accumulation (see mv_sample_bwd_pm_kernel)
+        const size_t need = dfm_point_sample_mv_bwd_workspace_bytes(d);
+        if (workspace_bytes < need)
+            return fail_ps(DFM_ERR_WORKSPACE, "workspace smaller than dfm_point_sample_mv_bwd_workspace_bytes");
+        hipError_t e = hipMemsetAsync(workspace, 0, need, st);
+        if (e != hipSuccess) return fail_ps(DFM_ERR_HIP, hipGetErrorString(e));
+        const long long nb = (g.N + MV_VT - 1) / MV_VT;
+        if (d->dtype == DFM_F32)
+            hipLaunchKernelGGL(mv_sample_bwd_pm_kernel<float>, dim3((unsigned)nb), dim3(256), lds, st, g,
+                               (const float *)grad_out, points, proj, ori_w, (float *)workspace);
+        else
+            hipLaunchKernelGGL(mv_sample_bwd_pm_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), lds, st,
+                               g, (const bf16_t *)grad_out, points, proj, ori_w, (float *)workspace);
+        const long long HW = (long long)d->feat_h * d->feat_w;
+        dim3 tg((unsigned)((HW + 63) / 64), (d->channels + 31) / 32, nvf);
+        hipLaunchKernelGGL(add_from_pixel_major_kernel<float>, tg, dim3(256), 0, st,
+                           (const float *)workspace, grad_feats, d->channels, HW);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail_ps(DFM_ERR_HIP, hipGetErrorString(e));
+        return DFM_OK;
+    }
+    const long long nb = (g.N + 255) / 256;
     if (d->dtype == DFM_F32)
         hipLaunchKernelGGL(mv_sample_bwd_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, g,
                            (const float *)grad_out, points, proj, ori_w, grad_feats);

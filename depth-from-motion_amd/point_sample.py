@@ -109,12 +109,14 @@ class _MvFn(torch.autograd.Function):
         device = grad_out.device
         go = grad_out.contiguous().to(dtype)
         gf = torch.zeros(shape, dtype=torch.float32, device=device)
+        nbytes = lib.dfm_point_sample_mv_bwd_workspace_bytes(ctypes.byref(ctx.descs[0]))
+        ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
             for b in range(shape[0]):
                 _capi.check(
                     lib.dfm_point_sample_mv_bwd(ctypes.byref(ctx.descs[b]), _ptr(go[b]), _ptr(points),
-                                                _ptr(proj[b]), _ptr(ori_w[b]), _ptr(gf[b]),
-                                                _stream_ptr(device)))
+                                                _ptr(proj[b]), _ptr(ori_w[b]), _ptr(gf[b]), _ptr(ws),
+                                                nbytes, _stream_ptr(device)))
         return gf.to(dtype), None, None, None, None, None, None
 
 

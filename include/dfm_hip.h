@@ -220,9 +220,14 @@ DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *desc, const void *feats,
                                     size_t workspace_bytes, void *stream);
 /* Backward w.r.t. the view features.  grad_out has the layout of `out`;
  * grad_feats (F*Nv, C, feat_h, feat_w) is FP32, zero-filled by the caller. */
+/* workspace (optional): >= dfm_point_sample_mv_bwd_workspace_bytes(desc) bytes for the
+ * pixel-major gradient accumulator (F*Nv, feat_h*feat_w, C) fp32; NULL selects the
+ * slower lane-per-voxel scatter. */
+DFM_API size_t dfm_point_sample_mv_bwd_workspace_bytes(const dfm_mv_desc *desc);
 DFM_API int dfm_point_sample_mv_bwd(const dfm_mv_desc *desc, const void *grad_out,
                                     const float *points, const float *proj, const float *ori_w,
-                                    float *grad_feats, void *stream);
+                                    float *grad_feats, void *workspace, size_t workspace_bytes,
+                                    void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* FrustumToVoxel sampling stage                                           */
