@@ -693,17 +693,21 @@ __global__ __launch_bounds__(256) void sweep_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// backward, dense sweeps: LDS-accumulating tiles.
-// A workgroup owns one band of lattice points (same (h, w) range) of one map over a
-// chunk of depth planes.  Per pass of BWD_CW channels the taps' gradients are added
-// into an fp32 slab of feature rows in LDS ([channel][row][x]: lanes are consecutive
-// points, so a wave's adds land in consecutive banks) with ds_add_f32; the slab goes to
-// the global gradient with ONE coalesced atomic per touched pixel when the chunk is done
+// backward: LDS-accumulating tiles.
+// A workgroup owns one band of lattice points (same (h, w) range) of ONE map over a chunk
+// of depth planes.  Per pass of CW channels the taps' gradients are added into a slab of
+// feature rows in LDS ([channel][row][x], 64-bit fixed point: integer LDS atomics run at
+// 10-14 lanes per clock, ds_add_f32 at 0.33 -- profiles/r01_atomic_microbench.txt; lanes are
+// consecutive points, so a wave's adds land in consecutive banks); the slab goes to the
+// global gradient with ONE coalesced fp32 atomic per touched pixel when the chunk is done
 // or when the footprint of the next plane has drifted out of the slab window (prev map,
-// near planes).  The cur map's footprint does not depend on depth, so its planes all
-// land in the same few rows: global atomics drop by about the chunk length.
+// near planes).
+//   cur map : its footprint does not depend on depth (it samples AT the lattice points), so
+//             a lane first sums its gradients over the planes in registers ("runs") and
+//             scatters once per chunk;
+//   prev map: the footprint drifts with depth; the four taps are scattered per plane.
 // The sampling positions are recomputed per (plane, channel pass) with the forward
-// kernel's own sweep_point_map/make_tap, i.e. the taps and weights ARE the forward's.
+// kernel's own sweep_point_map and make_tap's arithmetic: taps and weights ARE the forward's.
 // ---------------------------------------------------------------------------
 constexpr int BWD_PPL = 1;    // lattice points per lane and plane
 constexpr int BWD_MAXP = 32;  // depth planes per workgroup, at most
@@ -798,9 +802,7 @@ __device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFas
                 }
             }
         };
-        // Runs over depth.  ds_add_f32 retires about one lane per 3 clocks
-        // (profiles/r01_atomic_microbench.txt), so the kernel is bound by how many values it
-        // scatters.  A point's gradients are therefore summed in registers, over consecutive
+        // Runs over depth (cur map).  A point's gradients are summed in registers, over consecutive
         // planes, into a 3x3 block of pixels whose corner (by, bx) follows the footprint: a
         // 2x2 footprint whose corner is (by|by+1, bx|bx+1) fits, and while the block's last
         // column / row is still unused the block may also move one pixel up or left.  The
@@ -1410,7 +1412,7 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
     const SweepGeom g = make_geom(desc);
     hipStream_t st = (hipStream_t)stream;
     // dense sweeps whose feature rows fit the LDS: accumulate there (see sweep_bwd_tile_kernel)
-    const int lds_budget = 80 * 1024;  // two workgroups per CU
+    const int lds_budget = 80 * 1024;  // two workgroups per CU at most (half of it by default)
     // channels per pass: as many as leave >= 4 rows of 64-bit accumulators in the budget
     auto pick_cw = [&](int budget, int cw) {
         while (cw > 2 && (long long)budget / ((long long)cw * desc->w_in * 8) < 4) cw >>= 1;
