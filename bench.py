@@ -248,6 +248,8 @@ def main():
                     help='LDS kernel: adjacent bands scheduled back to back (default 1)')
     ap.add_argument('--channels-last', action='store_true',
                     help='write the volume (B,D,H,W,2C) (memory_format channels_last_3d)')
+    ap.add_argument('--no-autotune', action='store_true',
+                    help='skip dfm_plane_sweep_autotune (workgroup schedule stays at its default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass')
@@ -309,6 +311,10 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    tuned = None
+    if not args.channels_last and not args.band_chunk and not args.no_autotune:
+        # untimed, like the warm-up: let the library pick its workgroup schedule on this part
+        tuned = sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
     pkg._capi.check(lib.dfm_profile_begin(args.steps))
     barrier()
     torch.cuda.synchronize()
@@ -355,6 +361,7 @@ def main():
                 'kernel': 'sweep_cl_kernel' if args.channels_last else
                 {1: 'sweep_gather_kernel', 2: 'sweep_tile_kernel<LDS>', 3: 'sweep_tile_kernel<direct>'}.get(
                     lib.dfm_plane_sweep_last_kernel(), 'none'),
+                'bands_per_chunk': tuned if tuned is not None else (args.band_chunk or 1),
                 'volume_layout': '(B,D,H,W,2C) channels_last_3d' if args.channels_last
                 else '(B,2C,D,H,W) contiguous (the reference layout)',
             },

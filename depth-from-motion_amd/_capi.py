@@ -28,6 +28,7 @@ EXPORTS = (
     'dfm_plane_sweep_force_kernel',
     'dfm_plane_sweep_tune',
     'dfm_plane_sweep_schedule',
+    'dfm_plane_sweep_autotune',
     'dfm_point_sample_mv_workspace_bytes',
     'dfm_point_sample_mv_fwd',
     'dfm_frustum_to_voxel_workspace_bytes',
@@ -156,6 +157,9 @@ def lib():
     h.dfm_plane_sweep_force_kernel.argtypes = [ctypes.c_int]
     h.dfm_plane_sweep_tune.restype = ctypes.c_int
     h.dfm_plane_sweep_tune.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    h.dfm_plane_sweep_autotune.restype = ctypes.c_int
+    h.dfm_plane_sweep_autotune.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp,
+                                           ctypes.POINTER(ctypes.c_int)]
     h.dfm_plane_sweep_schedule.restype = ctypes.c_int
     h.dfm_plane_sweep_schedule.argtypes = [ctypes.c_int]
     mp = ctypes.POINTER(MvDesc)

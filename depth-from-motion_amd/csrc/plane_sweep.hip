@@ -1400,6 +1400,44 @@ DFM_API int dfm_plane_sweep_fwd(const dfm_sweep_desc *desc, const void *cur, con
                               workspace, st);
 }
 
+DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur, const void *prev,
+                                     const float *depths, const float *cam2img,
+                                     const float *cam2img_inv, const float *cur2prev, void *out,
+                                     void *workspace, size_t workspace_bytes, void *stream,
+                                     int *bands_per_chunk)
+{
+    // The workgroup order trades HBM write locality against L2 reuse of the staged rows, and
+    // which side wins depends on the part the process landed on (profiles/r01_store_microbench3.txt):
+    // time the candidates on the caller's own tensors and keep the fastest.  Synchronous.
+    static const int cand[] = {1, 15, 29};
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const int saved = g_band_chunk;
+    int best = saved, rc = DFM_OK;
+    float best_ms = 3.0e38f;
+    for (int c : cand) {
+        g_band_chunk = c;
+        for (int rep = 0; rep < 4 && rc == DFM_OK; ++rep) {
+            if (rep == 1) (void)hipEventRecord(e0, st);  // rep 0 warms up
+            rc = dfm_plane_sweep_fwd(desc, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out,
+                                     workspace, workspace_bytes, stream);
+        }
+        if (rc != DFM_OK) break;
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(DFM_ERR_HIP, "autotune: event sync failed%s"); break; }
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    g_band_chunk = rc == DFM_OK ? best : saved;
+    if (bands_per_chunk) *bands_per_chunk = g_band_chunk;
+    return rc;
+}
+
 DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out,
                                 const float *depths, const float *cam2img,
                                 const float *cam2img_inv, const float *cur2prev, float *grad_cur,

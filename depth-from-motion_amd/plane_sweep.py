@@ -124,6 +124,22 @@ def plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T, out=Non
     return out
 
 
+def plane_sweep_autotune(desc, cur_feats, prev_feats, depths, P, Pinv, T, out):
+    """Times the workgroup schedules of the LDS-staged kernel on these tensors and keeps the
+    fastest for the process (``dfm_plane_sweep_autotune``; synchronous).  Returns the choice."""
+    lib = _capi.lib()
+    device = cur_feats.device
+    nbytes = lib.dfm_plane_sweep_workspace_bytes(ctypes.byref(desc))
+    ws = _Workspace.get(device, nbytes)
+    chosen = ctypes.c_int(0)
+    with torch.cuda.device(device):
+        _capi.check(
+            lib.dfm_plane_sweep_autotune(ctypes.byref(desc), _ptr(cur_feats), _ptr(prev_feats),
+                                         _ptr(depths), _ptr(P), _ptr(Pinv), _ptr(T), _ptr(out), _ptr(ws),
+                                         nbytes, _stream_ptr(device), ctypes.byref(chosen)))
+    return chosen.value
+
+
 class _PlaneSweepFn(torch.autograd.Function):
 
     @staticmethod

@@ -173,6 +173,15 @@ DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int block
  * workgroups write longer contiguous runs of every channel plane (better HBM
  * write locality, more L2 refetch) -- see profiles/r01_store_microbench3.txt. */
 DFM_API int dfm_plane_sweep_schedule(int bands_per_chunk);
+/* Picks bands_per_chunk for this process by timing dfm_plane_sweep_fwd with the caller's own
+ * arguments (a few launches per candidate; SYNCHRONOUS, `out` is overwritten with valid
+ * results).  The choice only matters for the LDS-staged kernel; *bands_per_chunk (may be NULL)
+ * receives it. */
+DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur, const void *prev,
+                                     const float *depths, const float *cam2img,
+                                     const float *cam2img_inv, const float *cur2prev, void *out,
+                                     void *workspace, size_t workspace_bytes, void *stream,
+                                     int *bands_per_chunk);
 
 /* ---------------------------------------------------------------------- */
 /* multi-view voxel lifting (point_sample x views x frames + reduction)    */
