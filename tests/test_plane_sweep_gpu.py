@@ -327,6 +327,28 @@ def test_channels_last_backward_and_errors(pkg, kernel_mode):
         pkg.build_dfm_cost(c[:, :6].detach(), p[:, :6].detach(), *args, memory_format=torch.channels_last_3d)
 
 
+def test_autotune_keeps_results_exact(pkg, kernel_mode):
+    if kernel_mode != 'lds256_p2':
+        pytest.skip('runs once')
+    sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(2)
+    B, C, H, W, D = 2, 16, 40, 120, 6
+    cur = torch.from_numpy(rng.randn(B, C, H, W).astype(np.float32)).to(dev).bfloat16()
+    prev = torch.from_numpy(rng.randn(B, C, H, W).astype(np.float32)).to(dev).bfloat16()
+    depths = torch.from_numpy(util.depth_planes(D)).to(dev)
+    desc = sweep._make_desc(cur, D, 4, 1, (160, 480), False, (0, 0), 1.0)
+    P, Pinv, T = sweep.camera_matrices(torch.from_numpy(np.stack([util.KITTI_P2] * B)),
+                                       torch.from_numpy(util.random_poses(B, seed=3)), B, dev)
+    ref = sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T).clone()
+    out = torch.empty_like(ref)
+    chosen = sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
+    assert chosen in (1, 15, 29)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    again = sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T)
+    assert torch.equal(again.view(torch.int16), ref.view(torch.int16))
+
+
 def test_type_and_shape_errors(pkg):
     dev = torch.device('cuda:0')
     x = torch.zeros(1, 4, 8, 8, device=dev)
