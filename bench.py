@@ -373,7 +373,8 @@ def main():
                 'frac': round(achieved / HBM_PEAK_GBPS, 4),
                 'traffic': args.traffic_bytes if args.traffic_bytes is not None else (
                     NSTAR_TRAFFIC_BYTES if args.workload == 'nstar' and not args.channels_last and
-                    lib.dfm_plane_sweep_last_kernel() == 2 else None),
+                    lib.dfm_plane_sweep_last_kernel() == 2 and (tuned or args.band_chunk or 1) == 1
+                    else None),  # the PMC pass was taken with the default schedule
                 'kernel_ms': round(avg_kernel_ms, 4),
                 'algorithmic_bytes_per_launch': bytes_per_launch,
             },
