@@ -13,6 +13,8 @@ over ranks with no data-path collective (weak scaling: B=8 per GPU).
 Workloads (``--workload``):
   nstar (default, the BASELINE.json metric): B=8, C=256, D=112, 94x311, bf16,
         feat_sample_factor=4, cost_sample_factor=1
+  nstar_aug : SURVEY.md 8d's second N* run: the same with flip=True, crop_offset=(11,55),
+        scale_factor=1.03 (the general-geometry code path of the same kernel)
   kitti : config K of configs/dfm/dfm_r34_1x8_kitti-3d-3class.py: B=8 (the
         config runs 1/GPU), C=32, 320x1280 fp32, csf=4, D=72 -> (64,72,80,320)
 """
@@ -33,10 +35,32 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
-# HBM bytes per launch of the N* tile kernel from the separate rocprofv3 --pmc passes
-# (profiles/r01_final_pmc_traffic.txt): WRITE_SIZE 26 105 476 KB + 2 x FETCH_SIZE 222 537 KB
-# (the guide's gfx950 correction for wide coalesced reads); algorithmic = 27.06 GB.
-NSTAR_TRAFFIC_BYTES = (26105475.5 + 2 * 222536.8) * 1024
+# HBM bytes per launch of the N* tile kernel from separate rocprofv3 --pmc passes (FETCH_SIZE and
+# WRITE_SIZE in their own runs; FETCH x2 = the guide's gfx950 correction for wide coalesced
+# reads), one entry per launch configuration the autotuner can pick:
+# profiles/r02_nstar_traffic.json, written by tools/pmc_traffic.py in the same gpurun lease as
+# a bench line.  Algorithmic = 27.06 GB.
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_nstar_traffic.json')
+# the reference's own build_dfm_cost on PyTorch-CPU, timed in the build container by
+# tools/ref_cpu_timing.py (/root/reference does not exist on the GPU box)
+REF_CPU_FILE = os.path.join(ROOT, 'profiles', 'r02_reference_cpu_timing.json')
+
+
+def schedule_key(opts):
+    """canonical name of a launch configuration (dict of dfm_sweep_opts fields)"""
+    o = opts or {}
+    return 'lanes{}_ppl{}_planes{}_chunk{}'.format(o.get('lanes_per_workgroup') or 256,
+                                                   o.get('points_per_lane') or 8,
+                                                   o.get('planes_per_workgroup') or 2,
+                                                   o.get('bands_per_chunk') or 1)
+
+
+def measured_traffic(workload, key):
+    try:
+        with open(TRAFFIC_FILE) as f:
+            return json.load(f).get(workload, {}).get(key, {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
 
 KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791],
                      [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
@@ -47,9 +71,11 @@ SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd
 WORKLOADS = {
     # name: B, C, H, W, D, fsf, csf, crop, dtype
     'nstar': dict(B=8, C=256, H=94, W=311, D=112, fsf=4, csf=1, crop=(0, 0), dtype='bf16',
-                  dmin=2.0, dmax=59.6),
+                  dmin=2.0, dmax=59.6, flip=False, scale=1.0),
+    'nstar_aug': dict(B=8, C=256, H=94, W=311, D=112, fsf=4, csf=1, crop=(11, 55), dtype='bf16',
+                      dmin=2.0, dmax=59.6, flip=True, scale=1.03),
     'kitti': dict(B=8, C=32, H=320, W=1280, D=72, fsf=1, csf=4, crop=(0, 55), dtype='f32',
-                  dmin=2.0, dmax=59.6),
+                  dmin=2.0, dmax=59.6, flip=False, scale=1.0),
 }
 
 
@@ -89,7 +115,7 @@ def cpu_baseline(w, budget_s=12.0):
     T = poses(1, 2)[0]
     depths = depth_planes(w['D'], w['dmin'], w['dmax'])
     prm = orc.sweep_params(w['H'], w['W'], w['D'], w['fsf'], w['csf'], P, Pinv, T, (375, 1242),
-                           False, w['crop'], 1.0)
+                           w['flip'], w['crop'], w['scale'])
 
     def run(c_sub):
         cur = rng.randn(c_sub, w['H'], w['W']).astype(np.float32)
@@ -109,7 +135,7 @@ def cpu_baseline(w, budget_s=12.0):
         reps += 1
     t = total / reps
     sec_per_volume = t * (w['C'] / c_sub)
-    return {
+    res = {
         'value': 1.0 / sec_per_volume,
         'unit': 'cost-volumes/s',
         'cores': cores,
@@ -118,6 +144,13 @@ def cpu_baseline(w, budget_s=12.0):
                   f'{prm.h_out}x{prm.w_out}, fp32, {reps} repetitions, {total:.1f} s of wall time on '
                   f'{cores} threads, scaled by C',
     }
+    try:
+        # the reference's own PyTorch-CPU build_dfm_cost (tools/ref_cpu_timing.py, build container)
+        with open(REF_CPU_FILE) as f:
+            res['reference_torch_cpu'] = json.load(f)
+    except (OSError, ValueError):
+        pass
+    return res
 
 
 def secondary(args, pkg, dev, rank, world):
@@ -246,6 +279,7 @@ def main():
     ap.add_argument('--planes', type=int, default=0, help='LDS kernel depth planes per workgroup')
     ap.add_argument('--band-chunk', type=int, default=0,
                     help='LDS kernel: adjacent bands scheduled back to back (default 1)')
+    ap.add_argument('--ppl', type=int, default=0, help='LDS kernel: lattice points per lane (4|8)')
     ap.add_argument('--channels-last', action='store_true',
                     help='write the volume (B,D,H,W,2C) (memory_format channels_last_3d)')
     ap.add_argument('--no-autotune', action='store_true',
@@ -270,13 +304,18 @@ def main():
     pkg = importlib.import_module('depth-from-motion_amd')
     sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
     lib = pkg._capi.lib()
-    lib.dfm_plane_sweep_force_kernel(args.kernel)
-    if args.lanes or args.lds_kib or args.bpg or args.planes:
-        pkg._capi.check(lib.dfm_plane_sweep_tune(args.lanes or 256, args.lds_kib or 52,
-                                                 args.bpg or (1 << 20), args.planes or 2))
+    # explicit launch options (A/B runs) travel with every call; none = tuned / default
+    explicit = {k: v for k, v in dict(kernel=args.kernel, lanes=args.lanes, lds_kib=args.lds_kib,
+                                      blocks_per_group=args.bpg, planes=args.planes,
+                                      bands_per_chunk=args.band_chunk,
+                                      points_per_lane=args.ppl).items() if v}
+    if args.no_autotune:
+        os.environ['DFM_AUTOTUNE'] = '0'
+    with sweep.launch_options(**explicit):
+        return run(args, pkg, sweep, lib, dev, rank, world, explicit)
 
-    if args.band_chunk:
-        pkg._capi.check(lib.dfm_plane_sweep_schedule(args.band_chunk))
+
+def run(args, pkg, sweep, lib, dev, rank, world, explicit):
 
     if args.workload in SECONDARY:
         return secondary(args, pkg, dev, rank, world)
@@ -290,9 +329,11 @@ def main():
     cur = torch.randn(B, w['C'], w['H'], w['W'], generator=gc).to(dev).to(tdtype)
     prev = torch.randn(B, w['C'], w['H'], w['W'], generator=gp).to(dev).to(tdtype)
     depths = torch.from_numpy(depth_planes(w['D'], w['dmin'], w['dmax'])).to(dev)
-    desc = sweep._make_desc(cur, w['D'], w['fsf'], w['csf'], (375, 1242), False, w['crop'], 1.0)
-    P, Pinv, T = sweep.camera_matrices(torch.from_numpy(np.stack([KITTI_P2] * B)),
-                                       torch.from_numpy(poses(B, 2 + rank)), B, dev)
+    desc = sweep._make_desc(cur, w['D'], w['fsf'], w['csf'], (375, 1242), w['flip'], w['crop'],
+                            w['scale'])
+    cam2imgs = torch.from_numpy(np.stack([KITTI_P2] * B))
+    cur2prevs = torch.from_numpy(poses(B, 2 + rank))
+    P, Pinv, T = sweep.camera_matrices(cam2imgs, cur2prevs, B, dev)
     if args.channels_last:
         # same values, volume laid out (B, D, H, W, 2C): torch memory_format channels_last_3d
         out = torch.empty((B, w['D'], desc.h_out, desc.w_out, 2 * w['C']), dtype=tdtype,
@@ -308,13 +349,15 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    tuned = None
+    if not args.channels_last and not explicit and not args.no_autotune:
+        # untimed, like the warm-up: the library times its candidate launch shapes / workgroup
+        # orders on this part once and caches the fastest for this shape (it would do so by
+        # itself on the first dfm_plane_sweep_fwd of a volume this size)
+        tuned = sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    tuned = None
-    if not args.channels_last and not args.band_chunk and not args.no_autotune:
-        # untimed, like the warm-up: let the library pick its workgroup schedule on this part
-        tuned = sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
     pkg._capi.check(lib.dfm_profile_begin(args.steps))
     barrier()
     torch.cuda.synchronize()
@@ -327,10 +370,10 @@ def main():
     kms, klaunches = ctypes.c_double(0), ctypes.c_int(0)
     pkg._capi.check(lib.dfm_profile_end(ctypes.byref(kms), ctypes.byref(klaunches)))
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # max over ranks is the job's time; every rank's own time is kept to expose stragglers
+    par = importlib.import_module('depth-from-motion_amd.parallel')
+    elapsed, every = par.gather_rank_times(elapsed, dev)
+    per_rank_ms = [round(v * 1e3 / args.steps, 4) for v in every]
     ms_per_step = elapsed * 1e3 / args.steps
     value = B * world / (ms_per_step / 1e3)
 
@@ -361,7 +404,10 @@ def main():
                 'kernel': 'sweep_cl_kernel' if args.channels_last else
                 {1: 'sweep_gather_kernel', 2: 'sweep_tile_kernel<LDS>', 3: 'sweep_tile_kernel<direct>'}.get(
                     lib.dfm_plane_sweep_last_kernel(), 'none'),
-                'bands_per_chunk': tuned if tuned is not None else (args.band_chunk or 1),
+                'launch': schedule_key(tuned if tuned is not None else
+                                       pkg._capi.SweepOpts(**{sweep._OPT_FIELDS[k]: v for k, v in
+                                                              explicit.items()}).as_dict()),
+                'autotuned': tuned is not None,
                 'volume_layout': '(B,D,H,W,2C) channels_last_3d' if args.channels_last
                 else '(B,2C,D,H,W) contiguous (the reference layout)',
             },
@@ -371,18 +417,50 @@ def main():
                 'peak': HBM_PEAK_GBPS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBPS, 4),
+                # the same bytes over the whole timed step (pack pass + launch gaps included)
+                'frac_step': round(bytes_per_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                # PMC traffic of the launch configuration that actually ran (None if that
+                # configuration has no committed counter pass)
                 'traffic': args.traffic_bytes if args.traffic_bytes is not None else (
-                    NSTAR_TRAFFIC_BYTES if args.workload == 'nstar' and not args.channels_last and
-                    lib.dfm_plane_sweep_last_kernel() == 2 and (tuned or args.band_chunk or 1) == 1
-                    else None),  # the PMC pass was taken with the default schedule
+                    None if args.channels_last or lib.dfm_plane_sweep_last_kernel() != 2 else
+                    measured_traffic(args.workload, schedule_key(
+                        tuned if tuned is not None else
+                        pkg._capi.SweepOpts(**{sweep._OPT_FIELDS[k]: v
+                                               for k, v in explicit.items()}).as_dict()))),
                 'kernel_ms': round(avg_kernel_ms, 4),
                 'algorithmic_bytes_per_launch': bytes_per_launch,
             },
+            'per_rank_ms_per_step': per_rank_ms,
         }
+        if world == 1 and not args.channels_last:
+            # the public API (what DfMBackbone.forward calls): build_dfm_cost with device-resident
+            # intrinsics / poses -- pads, inverts and packs them on the device, allocates the
+            # volume, launches.  Reported beside the raw launch, never as `value`.
+            k_dev, t_dev = cam2imgs.to(dev), cur2prevs.to(dev)
+            del out
+            torch.cuda.synchronize()
+
+            def api_step():
+                return pkg.build_dfm_cost(cur, prev, depths, w['fsf'], w['csf'], k_dev, t_dev,
+                                          (375, 1242), w['flip'], w['crop'], w['scale'])
+            for _ in range(args.warmup):
+                api_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                vol = api_step()
+            torch.cuda.synchronize()
+            ms_api = (time.perf_counter() - t0) * 1e3 / args.steps
+            del vol
+            line['api_build_dfm_cost'] = {
+                'value': round(B / (ms_api / 1e3), 2), 'unit': 'cost-volumes/s',
+                'ms_per_step': round(ms_api, 4),
+                'note': 'public build_dfm_cost(): device-side pad/inverse/pack of the camera '
+                        'matrices + output allocation (caching allocator) + the same launch'}
+            out = None
         if world == 1 and not args.channels_last and w['C'] % (16 // elem) == 0:
             # the same volume written channels-last (opt-in layout, identical values): reported
             # beside the headline, never instead of it
-            del out
             out_cl = torch.empty((B, w['D'], desc.h_out, desc.w_out, 2 * w['C']), dtype=tdtype,
                                  device=dev).permute(0, 4, 1, 2, 3)
             for _ in range(args.warmup):

@@ -25,10 +25,11 @@ EXPORTS = (
     'dfm_plane_sweep_bwd',
     'dfm_plane_sweep_grid',
     'dfm_plane_sweep_last_kernel',
-    'dfm_plane_sweep_force_kernel',
-    'dfm_plane_sweep_tune',
-    'dfm_plane_sweep_schedule',
+    'dfm_plane_sweep_fwd_opts',
+    'dfm_plane_sweep_bwd_opts',
     'dfm_plane_sweep_autotune',
+    'dfm_plane_sweep_tuning',
+    'dfm_plane_sweep_reset_tuning',
     'dfm_point_sample_mv_workspace_bytes',
     'dfm_point_sample_mv_fwd',
     'dfm_frustum_to_voxel_workspace_bytes',
@@ -66,6 +67,16 @@ class SweepDesc(ctypes.Structure):
         ('flip', ctypes.c_int32),
         ('dtype', ctypes.c_int32),
     ]
+
+
+class SweepOpts(ctypes.Structure):
+    """struct dfm_sweep_opts: launch options of ONE plane-sweep call (0 = library default)"""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        'kernel', 'lanes_per_workgroup', 'lds_kib', 'blocks_per_group', 'planes_per_workgroup',
+        'bands_per_chunk', 'points_per_lane', 'reserved')]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != 'reserved'}
 
 
 class MvDesc(ctypes.Structure):
@@ -153,15 +164,16 @@ def lib():
     h.dfm_plane_sweep_grid.restype = ctypes.c_int
     h.dfm_plane_sweep_grid.argtypes = [dp, i32, fp, fp, fp, fp, fp, fp, vp]
     h.dfm_plane_sweep_last_kernel.restype = ctypes.c_int
-    h.dfm_plane_sweep_force_kernel.restype = None
-    h.dfm_plane_sweep_force_kernel.argtypes = [ctypes.c_int]
-    h.dfm_plane_sweep_tune.restype = ctypes.c_int
-    h.dfm_plane_sweep_tune.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    op = ctypes.POINTER(SweepOpts)
+    h.dfm_plane_sweep_fwd_opts.restype = ctypes.c_int
+    h.dfm_plane_sweep_fwd_opts.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp, op]
+    h.dfm_plane_sweep_bwd_opts.restype = ctypes.c_int
+    h.dfm_plane_sweep_bwd_opts.argtypes = [dp, vp, fp, fp, fp, fp, fp, fp, vp, op]
     h.dfm_plane_sweep_autotune.restype = ctypes.c_int
-    h.dfm_plane_sweep_autotune.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp,
-                                           ctypes.POINTER(ctypes.c_int)]
-    h.dfm_plane_sweep_schedule.restype = ctypes.c_int
-    h.dfm_plane_sweep_schedule.argtypes = [ctypes.c_int]
+    h.dfm_plane_sweep_autotune.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp, op]
+    h.dfm_plane_sweep_tuning.restype = ctypes.c_int
+    h.dfm_plane_sweep_tuning.argtypes = [dp, op]
+    h.dfm_plane_sweep_reset_tuning.restype = None
     mp = ctypes.POINTER(MvDesc)
     h.dfm_point_sample_mv_workspace_bytes.restype = sz
     h.dfm_point_sample_mv_workspace_bytes.argtypes = [mp]

@@ -466,6 +466,9 @@ __global__ __launch_bounds__(256) void f2v_bwd_pm_kernel(F2vGeom g, const T *__r
     const int wave = tid >> 6, lane = tid & 63;
     int lpv = 1;
     while (lpv < min(max(g.C, g.Cs), 64)) lpv <<= 1;  // lanes per voxel
+    // a wave owns F2V_VT/4 voxels: never spread an iteration over more of them (1- and 2-channel
+    // maps would otherwise scatter their neighbours' voxels a second time)
+    lpv = max(lpv, 64 / (F2V_VT / 4));
     const int ch = lane & (lpv - 1), vin = lane / lpv, vpi = 64 / lpv;
     float *gs = gst_pm + (size_t)b * g.D * g.H * g.W * g.C;
     float *gm = gsem_pm + (size_t)b * g.Hsem * g.Wsem * g.Cs;

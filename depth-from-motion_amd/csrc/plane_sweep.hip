@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -34,18 +35,34 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local int g_last_kernel = 0;
-int g_force_kernel = 0;
-// LDS-kernel launch shape (tunable for A/B runs: dfm_plane_sweep_tune)
-int g_lds_nt = 256;  // lanes per workgroup: 128 or 256
-int g_lds_kb = 52;   // dynamic LDS per workgroup, KiB
-unsigned long long *g_trace = nullptr;  // debug: see dfm_debug_set_trace
-int g_planes = 2;             // depth planes per workgroup of the LDS kernel (measured best)
-int g_blocks_per_group = 1 << 20;  // channel blocks per workgroup (default: all)
-int g_band_chunk = 1;              // adjacent bands scheduled back to back (store locality)
+#ifdef DFM_DEBUG_HOOKS
+unsigned long long *g_trace = nullptr;  // debug builds only: see dfm_debug_set_trace
+#endif
+
+// The library keeps no mutable launch state: the shape of a forward launch comes from the
+// caller's dfm_sweep_opts (per call) or from the tuned-schedule cache below (per device and
+// problem shape, filled by dfm_plane_sweep_autotune, guarded by a mutex).
+struct Launch {
+    int kernel;      // 0 auto, 1 gather, 2 LDS tiles, 3 direct tiles
+    int lanes;       // lanes per workgroup of the tile kernels
+    int lds_kib;     // dynamic LDS per workgroup
+    int bpg;         // channel blocks per workgroup (all by default)
+    int planes;      // depth planes per workgroup
+    int band_chunk;  // adjacent bands scheduled back to back
+    int ppl;         // lattice points per lane
+};
+
+struct TuneKey {
+    int v[9];
+    bool operator<(const TuneKey &o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+std::mutex g_tune_mu;
+std::map<TuneKey, dfm_sweep_opts> g_tuned;
 
 // optional per-launch timing of the dominant (volume-writing) kernel with HIP
 // events on the caller's stream (bench.py's roofline leg)
 struct Profiler {
+    std::mutex mu;
     bool on = false;
     std::vector<hipEvent_t> ev;  // pairs
     int used = 0;
@@ -272,7 +289,7 @@ struct TileGrid {
 // LDS == false: same lane/point/store structure, taps straight from the blocked
 //               map in global memory; runs only the tiles flagged by the LDS
 //               kernel (spill list) -- or, as sweep_tile_kernel<.., false>, every tile.
-template <typename T, int NT, bool LDS>
+template <typename T, int NT, bool LDS, int V>
 __device__ __forceinline__ void tile_body(
     const int bid, const SweepGeom &g, const SweepFast &fast, const TileGrid &tg, int lds_slots,
     const uint4 *__restrict__ cur_blk, const uint4 *__restrict__ prev_blk,
@@ -281,7 +298,12 @@ __device__ __forceinline__ void tile_body(
     int *__restrict__ spill_list)
 {
     constexpr int CB = elem<T>::CB;
-    constexpr int V = CB;  // points per lane (one 16-byte store per channel)
+    // V = points per lane.  V == CB: one 16-byte store per channel (the default).  V == 4 with
+    // bf16: 8-byte stores, half the footprint / output registers per lane, so twice as many
+    // waves fit a CU for the same tile (the wave's run per channel is 512 B instead of 1 KiB).
+    static_assert(V == 4 || V == 8, "points per lane");
+    static_assert(V * sizeof(T) == 16 || V * sizeof(T) == 8, "8- or 16-byte stores");
+    constexpr int VW = V * (int)sizeof(T) / 4;  // dwords per channel vector
     constexpr int PAD = 8; // slots in front of the rows (keeps q = p + PAD >= 7)
     constexpr int SLAB = 8;  // slab starts at a multiple of 8 so the swizzle stays inside it
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
@@ -369,6 +391,7 @@ __device__ __forceinline__ void tile_body(
     }
     T *o = out + ((size_t)b * 2 * g.C + (size_t)half * g.C) * g.N + n0;
     const uint32_t full = (V == 8) ? 0xffffffffu : 0xffffu;
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     const bool all_in = __all(!active || okbits == full);
 
     int cnt = 0, nslots = 0;
@@ -387,9 +410,15 @@ __device__ __forceinline__ void tile_body(
         if (y1 < y0) {
             // no point of this tile lands inside the map: the volume is zero here
             if (active) {
-                const u32x4_t z = {0u, 0u, 0u, 0u};
-                for (int c = blk_lo * CB; c < min(blk_hi * CB, g.C); ++c)
-                    __builtin_nontemporal_store(z, (u32x4_t *)(o + (size_t)c * g.N));
+                for (int c = blk_lo * CB; c < min(blk_hi * CB, g.C); ++c) {
+                    if constexpr (VW == 4) {
+                        const u32x4_t z = {0u, 0u, 0u, 0u};
+                        __builtin_nontemporal_store(z, (u32x4_t *)(o + (size_t)c * g.N));
+                    } else {
+                        const u32x2_t z = {0u, 0u};
+                        __builtin_nontemporal_store(z, (u32x2_t *)(o + (size_t)c * g.N));
+                    }
+                }
             }
             return;
         }
@@ -457,12 +486,12 @@ __device__ __forceinline__ void tile_body(
     // blend the V points x CB channels of one channel block and store them
     auto compute_store = [&](int blk, const uint4 *gsrc) {
         const int cbase = blk * CB;
-        uint32_t pk[CB][4];  // per channel: one 16-byte vector of V points
+        uint32_t pk[CB][VW];  // per channel: one 16- (or 8-) byte vector of V points
         if (ABLATE(4)) {
 #pragma unroll
             for (int k = 0; k < CB; ++k)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pk[k][j] = (uint32_t)qN[j] + k + blk;
+                for (int j = 0; j < VW; ++j) pk[k][j] = (uint32_t)qN[j] + k + blk;
         } else if constexpr (LDS) {
             // Taps come from LDS through inline-asm ds_read_b128 (hipcc would put
             // a vmcnt(0) in front of the first LDS read after an LDS-DMA was
@@ -533,8 +562,13 @@ __device__ __forceinline__ void tile_body(
 #pragma unroll
         for (int k = 0; k < CB; ++k) {
             if (cbase + k < g.C && (!ABLATE(2) || pk[k][0] == 0x12345u)) {
-                u32x4_t v = {pk[k][0], pk[k][1], pk[k][2], pk[k][3]};
-                __builtin_nontemporal_store(v, (u32x4_t *)(o + (size_t)(cbase + k) * g.N));
+                if constexpr (VW == 4) {
+                    u32x4_t v = {pk[k][0], pk[k][1], pk[k][2], pk[k][3]};
+                    __builtin_nontemporal_store(v, (u32x4_t *)(o + (size_t)(cbase + k) * g.N));
+                } else {
+                    u32x2_t v = {pk[k][0], pk[k][1]};
+                    __builtin_nontemporal_store(v, (u32x2_t *)(o + (size_t)(cbase + k) * g.N));
+                }
             }
         }
     };
@@ -579,21 +613,23 @@ __device__ __forceinline__ void tile_body(
 #ifndef DFM_TILE_WAVES
 #define DFM_TILE_WAVES 1  // min waves/SIMD the LDS tile kernel is compiled for (1 = compiler's choice)
 #endif
-// one workgroup per tile; LDS == false is the "direct taps for every tile" mode
-template <typename T, int NT, bool LDS>
-__global__ __launch_bounds__(NT, (LDS ? DFM_TILE_WAVES : 1)) void sweep_tile_kernel(
+// one workgroup per tile; LDS == false is the "direct taps for every tile" mode.
+// V * sizeof(T) == 8 (bf16, 4 points per lane): compiled for 4 waves per SIMD (<= 128 VGPRs),
+// i.e. two 512-lane workgroups or one 1024-lane workgroup per CU.
+template <typename T, int NT, bool LDS, int V>
+__global__ __launch_bounds__(NT, (LDS ? (V * sizeof(T) == 8 ? 4 : DFM_TILE_WAVES) : 1)) void sweep_tile_kernel(
     SweepGeom g, SweepFast fast, TileGrid tg, int lds_slots, const uint4 *__restrict__ cur_blk,
     const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
     const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
     T *__restrict__ out, int *__restrict__ spill_list)
 {
-    tile_body<T, NT, LDS>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk, depths, P, Pinv, Tm,
-                          out, spill_list);
+    tile_body<T, NT, LDS, V>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk, depths, P, Pinv,
+                             Tm, out, spill_list);
 }
 
 // the tiles the LDS pass queued (spill_list[0] = count), a fixed small grid strides over them:
 // launching one mostly-empty workgroup per tile would cost ~0.5 ms for 26 k tiles
-template <typename T, int NT>
+template <typename T, int NT, int V>
 __global__ __launch_bounds__(NT) void sweep_spill_kernel(
     SweepGeom g, SweepFast fast, TileGrid tg, const uint4 *__restrict__ cur_blk,
     const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
@@ -602,8 +638,8 @@ __global__ __launch_bounds__(NT) void sweep_spill_kernel(
 {
     const int count = spill_list[0];
     for (int i = blockIdx.x; i < count; i += gridDim.x)
-        tile_body<T, NT, false>(spill_list[1 + i], g, fast, tg, 0, cur_blk, prev_blk, depths, P,
-                                Pinv, Tm, out, nullptr);
+        tile_body<T, NT, false, V>(spill_list[1 + i], g, fast, tg, 0, cur_blk, prev_blk, depths, P,
+                                   Pinv, Tm, out, nullptr);
 }
 
 // The <= 7 lattice points in front of every depth-plane boundary that the LDS pass
@@ -1187,10 +1223,118 @@ size_t flag_bytes(const dfm_sweep_desc *d)
     return ((size_t)(1 + bands * d->num_depths * 2 * d->batch * nblk) * 4 + 255) & ~(size_t)255;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of
+// on every launch
+int ensure_dynamic_lds(const void *kern, int lds_bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, int> seen;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    int &have = seen[std::make_pair(dev, kern)];
+    if (lds_bytes > have) {
+        HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        have = lds_bytes;
+    }
+    return DFM_OK;
+}
+
+SweepFast make_fast(const dfm_sweep_desc *d)
+{
+    SweepFast fast;
+    fast.scale_is_one = d->img_scale_factor == 1.0f;
+    int e = 0;
+    const float m = frexpf(d->feat_sample_factor, &e);
+    fast.fsf_pow2 = (m == 0.5f) && e > -60 && e < 60;
+    fast.inv_fsf = 1.0f / d->feat_sample_factor;
+    return fast;
+}
+
+// caller options (0 = default) -> a complete launch description
+int resolve(const dfm_sweep_desc *d, const dfm_sweep_opts *o, Launch &L)
+{
+    const int CB = d->dtype == DFM_BF16 ? 8 : 4;
+    L.kernel = o ? o->kernel : 0;
+    L.lanes = o && o->lanes_per_workgroup ? o->lanes_per_workgroup : 256;
+    L.lds_kib = o && o->lds_kib ? o->lds_kib : 52;
+    L.bpg = o && o->blocks_per_group ? o->blocks_per_group : (1 << 20);
+    L.planes = o && o->planes_per_workgroup ? o->planes_per_workgroup : 2;
+    L.band_chunk = o && o->bands_per_chunk ? o->bands_per_chunk : 1;
+    L.ppl = o && o->points_per_lane ? o->points_per_lane : CB;
+    if (L.kernel < 0 || L.kernel > 3) return fail(DFM_ERR_INVALID_ARG, "opts: kernel must be 0..3%s");
+    if (L.lanes != 128 && L.lanes != 256 && L.lanes != 512 && L.lanes != 1024)
+        return fail(DFM_ERR_INVALID_ARG, "opts: lanes_per_workgroup in {128,256,512,1024}%s");
+    if (L.lds_kib < 4 || L.lds_kib > 160 || L.bpg < 1 || L.planes < 1 || L.band_chunk < 1)
+        return fail(DFM_ERR_INVALID_ARG,
+                    "opts: 4 <= lds_kib <= 160, blocks_per_group / planes / bands_per_chunk >= 1%s");
+    if (L.ppl != CB && !(L.ppl == 4 && CB == 8 && (L.lanes == 512 || L.lanes == 1024)))
+        return fail(DFM_ERR_INVALID_ARG,
+                    "opts: points_per_lane is 16/sizeof(T), or 4 for bf16 with 512/1024 lanes%s");
+    if (L.lanes == 1024 && L.ppl != 4)
+        return fail(DFM_ERR_INVALID_ARG, "opts: 1024 lanes need points_per_lane = 4%s");
+    return DFM_OK;
+}
+
+template <typename T, int NT, int V>
+int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const Launch &L,
+                 const uint4 *cur_blk, const uint4 *prev_blk, const float *depths, const float *P,
+                 const float *Pinv, const float *Tm, T *out, int *spill_list, hipStream_t st)
+{
+    const int lds_bytes = L.lds_kib * 1024;
+    const int bpg = which == 2 ? std::min(L.bpg, g.nblk) : g.nblk;
+    const int groups = (g.nblk + bpg - 1) / bpg;
+    const long long hw = (long long)g.h_out * g.w_out;
+    TileGrid tg;
+    tg.batch = d->batch;
+    tg.planes = std::max(1, std::min(L.planes, NT / 64));
+    while ((NT / 64) % tg.planes) --tg.planes;  // whole waves per plane
+    tg.dgroups = (g.D + tg.planes - 1) / tg.planes;
+    const long long per_plane = (long long)(NT / tg.planes) * V;  // points per plane and tile
+    tg.bands = (int)((hw + 7 + per_plane - 1) / per_plane);
+    tg.band_pts = (int)((((hw + 7 + tg.bands - 1) / tg.bands) + 7) & ~7ll);
+    tg.blocks_per_group = bpg;
+    tg.band_chunk = std::max(1, std::min(L.band_chunk, tg.bands));
+    tg.trace = nullptr;
+    tg.ablate = 0;
+#ifdef DFM_DEBUG_HOOKS
+    tg.trace = g_trace;
+    {
+        const char *ab = getenv("DFM_ABLATE");  // perf experiments only
+        tg.ablate = ab ? atoi(ab) : 0;
+    }
+#endif
+    const long long nchunks = (tg.bands + tg.band_chunk - 1) / tg.band_chunk;
+    const long long nb = nchunks * tg.band_chunk * tg.dgroups * 2 * d->batch * groups;
+    if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
+    if ((size_t)(nb + 1) * 4 > flag_bytes(d)) return fail(DFM_ERR_WORKSPACE, "spill list too small%s");
+    const SweepFast fast = make_fast(d);
+    if (which == 2) {
+        const void *kern = (const void *)sweep_tile_kernel<T, NT, true, V>;
+        int rc = ensure_dynamic_lds(kern, lds_bytes);
+        if (rc != DFM_OK) return rc;
+        HIP_TRY(hipMemsetAsync(spill_list, 0, 4, st));
+        hipLaunchKernelGGL((sweep_tile_kernel<T, NT, true, V>), dim3((unsigned)nb), dim3(NT),
+                           lds_bytes, st, g, fast, tg, lds_bytes / 16, cur_blk, prev_blk, depths, P,
+                           Pinv, Tm, out, spill_list);
+        // tiles whose rows exceeded the LDS budget (typically < 1 %)
+        hipLaunchKernelGGL((sweep_spill_kernel<T, NT, V>), dim3(512), dim3(NT), 16, st, g, fast, tg,
+                           cur_blk, prev_blk, depths, P, Pinv, Tm, out, spill_list);
+        if (g.D > 1 && hw % 8 != 0)
+            hipLaunchKernelGGL(sweep_patch_kernel<T>, dim3(g.D - 1, 2, d->batch), dim3(256), 0, st,
+                               g, fast, cur_blk, prev_blk, depths, P, Pinv, Tm, out);
+    } else {
+        hipLaunchKernelGGL((sweep_tile_kernel<T, NT, false, V>), dim3((unsigned)nb), dim3(NT), 16,
+                           st, g, fast, tg, 0, cur_blk, prev_blk, depths, P, Pinv, Tm, out,
+                           (int *)nullptr);
+    }
+    return DFM_OK;
+}
+
 template <typename T>
-int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const float *depths,
-               const float *P, const float *Pinv, const float *Tm, void *out, void *ws,
-               hipStream_t st)
+int launch_fwd(const dfm_sweep_desc *d, const Launch &L, const void *cur, const void *prev,
+               const float *depths, const float *P, const float *Pinv, const float *Tm, void *out,
+               void *ws, hipStream_t st)
 {
     const SweepGeom g = make_geom(d);
     const int HW = d->h_in * d->w_in;
@@ -1199,18 +1343,18 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
     dim3 pg((HW + 255) / 256, g.nblk, 2 * d->batch);
     hipLaunchKernelGGL(pack_blocked_kernel<T>, pg, dim3(256), 0, st, (const T *)cur, (const T *)prev,
                        cur_blk, prev_blk, d->batch, g.C, HW, g.nblk);
-    const bool timed = g_prof.on && g_prof.used + 2 <= (int)g_prof.ev.size();
-    constexpr int V = elem<T>::CB;
-    // the LDS kernel stores one aligned 16-byte vector of V points per channel:
-    // it needs every channel plane (N elements) to start 16-byte aligned
+    constexpr int CB = elem<T>::CB;
+    // the tile kernels store one aligned vector of V points per channel: every channel
+    // plane (N elements) has to start 16-byte aligned.
     // Dense sampling (about one feature pixel per lattice step) reuses staged rows
     // well; a strided sweep (cost_sample_factor >= 2) would stage mostly unused
     // pixels, so it takes the same tile kernel with direct taps (3).
-    const bool vec_ok = g.N % V == 0 && ((uintptr_t)out & 15) == 0;
+    const bool vec_ok = g.N % CB == 0 && ((uintptr_t)out & 15) == 0;
     int which = !vec_ok ? 1 : (d->cost_sample_factor < 1.5f ? 2 : 3);
-    if (g_force_kernel == 1 || (g_force_kernel == 3 && vec_ok)) which = g_force_kernel;
-    if (g_force_kernel == 2 && vec_ok) which = 2;
-    if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+    if (L.kernel == 1 || (L.kernel == 3 && vec_ok)) which = L.kernel;
+    if (L.kernel == 2 && vec_ok) which = 2;
+    const bool timed = profile_mark(st, false);
+    int rc = DFM_OK;
     if (which == 1) {
         const long long nb = (g.N + 255) / 256;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
@@ -1218,114 +1362,91 @@ int launch_fwd(const dfm_sweep_desc *d, const void *cur, const void *prev, const
         hipLaunchKernelGGL(sweep_gather_kernel<T>, grid, dim3(256), 0, st, g, cur_blk, prev_blk,
                            depths, P, Pinv, Tm, (T *)out);
     } else {
-        const int nt = g_lds_nt;
-        const int lds_bytes = g_lds_kb * 1024;
-        const int bpg = which == 2 ? std::min(g_blocks_per_group, g.nblk) : g.nblk;
-        const int groups = (g.nblk + bpg - 1) / bpg;
-        const long long hw = (long long)g.h_out * g.w_out;
-        TileGrid tg;
-        tg.batch = d->batch;
-        tg.planes = std::max(1, std::min(g_planes, nt / 64));
-        while ((nt / 64) % tg.planes) --tg.planes;  // whole waves per plane
-        tg.dgroups = (g.D + tg.planes - 1) / tg.planes;
-        const long long per_plane = (long long)(nt / tg.planes) * V;  // points per plane and tile
-        tg.bands = (int)((hw + 7 + per_plane - 1) / per_plane);
-        tg.band_pts = (int)((((hw + 7 + tg.bands - 1) / tg.bands) + 7) & ~7ll);
-        tg.blocks_per_group = bpg;
-        tg.band_chunk = std::max(1, std::min(g_band_chunk, tg.bands));
-        tg.trace = g_trace;
-        {
-            const char *ab = getenv("DFM_ABLATE");  // perf experiments only
-            tg.ablate = ab ? atoi(ab) : 0;
-        }
-        const long long nchunks = (tg.bands + tg.band_chunk - 1) / tg.band_chunk;
-        const long long nb = nchunks * tg.band_chunk * tg.dgroups * 2 * d->batch * groups;
-        if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
-        if ((size_t)(nb + 1) * 4 > flag_bytes(d)) return fail(DFM_ERR_WORKSPACE, "spill list too small%s");
         int *spill_list = (int *)((char *)ws + 2 * blocked_bytes(d));
-        SweepFast fast;
-        fast.scale_is_one = d->img_scale_factor == 1.0f;
-        {
-            int e = 0;
-            const float m = frexpf(d->feat_sample_factor, &e);
-            fast.fsf_pow2 = (m == 0.5f) && e > -60 && e < 60;
-            fast.inv_fsf = 1.0f / d->feat_sample_factor;
-        }
-        if (which == 2) {
-            auto kern = nt == 128   ? sweep_tile_kernel<T, 128, true>
-                        : nt == 256 ? sweep_tile_kernel<T, 256, true>
-                                    : sweep_tile_kernel<T, 512, true>;
-            auto spill = nt == 128   ? sweep_spill_kernel<T, 128>
-                         : nt == 256 ? sweep_spill_kernel<T, 256>
-                                     : sweep_spill_kernel<T, 512>;
-            HIP_TRY(hipFuncSetAttribute((const void *)kern,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-            HIP_TRY(hipMemsetAsync(spill_list, 0, 4, st));
-            hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(nt), lds_bytes, st, g, fast, tg,
-                               lds_bytes / 16, cur_blk, prev_blk, depths, P, Pinv, Tm, (T *)out,
-                               spill_list);
-            // tiles whose rows exceeded the LDS budget (typically < 1 %)
-            hipLaunchKernelGGL(spill, dim3(512), dim3(nt), 16, st, g, fast, tg, cur_blk, prev_blk,
-                               depths, P, Pinv, Tm, (T *)out, spill_list);
+#define DFM_TILES(NT, V)                                                                            \
+    rc = launch_tiles<T, NT, V>(which, d, g, L, cur_blk, prev_blk, depths, P, Pinv, Tm, (T *)out,   \
+                                spill_list, st)
+        if (L.ppl == CB) {
+            if (L.lanes == 128) DFM_TILES(128, CB);
+            else if (L.lanes == 256) DFM_TILES(256, CB);
+            else if (L.lanes == 512) DFM_TILES(512, CB);
+            else if constexpr (CB == 4) DFM_TILES(1024, 4);
         } else {
-            auto direct = nt == 128   ? sweep_tile_kernel<T, 128, false>
-                          : nt == 256 ? sweep_tile_kernel<T, 256, false>
-                                      : sweep_tile_kernel<T, 512, false>;
-            hipLaunchKernelGGL(direct, dim3((unsigned)nb), dim3(nt), 16, st, g, fast, tg, 0, cur_blk,
-                               prev_blk, depths, P, Pinv, Tm, (T *)out, (int *)nullptr);
+            if constexpr (CB == 8) {
+                if (L.lanes == 512) DFM_TILES(512, 4);
+                else DFM_TILES(1024, 4);
+            }
         }
-        if (which == 2 && g.D > 1 && hw % 8 != 0)
-            hipLaunchKernelGGL(sweep_patch_kernel<T>, dim3(g.D - 1, 2, d->batch), dim3(256), 0, st,
-                               g, fast, cur_blk, prev_blk, depths, P, Pinv, Tm, (T *)out);
+#undef DFM_TILES
     }
-    if (timed) {
-        (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
-        g_prof.used += 2;
-    }
+    if (timed) profile_mark(st, true);
+    if (rc != DFM_OK) return rc;
     g_last_kernel = which;
     HIP_TRY(hipGetLastError());
     return DFM_OK;
+}
+
+int run_fwd(const dfm_sweep_desc *desc, const Launch &L, const void *cur, const void *prev,
+            const float *depths, const float *cam2img, const float *cam2img_inv,
+            const float *cur2prev, void *out, void *workspace, hipStream_t st)
+{
+    if (desc->dtype == DFM_F32)
+        return launch_fwd<float>(desc, L, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out,
+                                 workspace, st);
+    return launch_fwd<bf16_t>(desc, L, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out,
+                              workspace, st);
+}
+
+int check_fwd_args(const dfm_sweep_desc *desc, const void *cur, const void *prev,
+                   const float *depths, const float *cam2img, const float *cam2img_inv,
+                   const float *cur2prev, void *out, void *workspace, size_t workspace_bytes)
+{
+    int rc = check_desc(desc);
+    if (rc != DFM_OK) return rc;
+    if (!cur || !prev || !depths || !cam2img || !cam2img_inv || !cur2prev || !out)
+        return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
+    if (!workspace || workspace_bytes < 2 * blocked_bytes(desc) + flag_bytes(desc))
+        return fail(DFM_ERR_WORKSPACE, "workspace smaller than dfm_plane_sweep_workspace_bytes%s");
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)out & 1))
+        return fail(DFM_ERR_INVALID_ARG, "workspace must be 16-byte aligned%s");
+    return DFM_OK;
+}
+
+int tune_key(const dfm_sweep_desc *d, TuneKey &k)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const int v[9] = {dev, d->batch, d->channels, d->h_in, d->w_in, d->num_depths, d->h_out,
+                      d->w_out, d->dtype};
+    memcpy(k.v, v, sizeof(v));
+    return DFM_OK;
+}
+
+// would the default dispatch take the LDS tile kernel (the only one with schedules to tune)?
+bool takes_lds_tiles(const dfm_sweep_desc *d, const void *out)
+{
+    const int CB = d->dtype == DFM_BF16 ? 8 : 4;
+    const long long N = (long long)d->num_depths * d->h_out * d->w_out;
+    return N % CB == 0 && ((uintptr_t)out & 15) == 0 && d->cost_sample_factor < 1.5f;
 }
 
 }  // namespace
 
 extern "C" {
 
-DFM_API int dfm_version(void) { return 1; }
+DFM_API int dfm_version(void) { return 2; }
 DFM_API const char *dfm_last_error(void) { return g_err; }
 DFM_API int dfm_plane_sweep_last_kernel(void) { return g_last_kernel; }
-DFM_API void dfm_plane_sweep_force_kernel(int which) { g_force_kernel = which; }
-// internal (not in dfm_hip.h): device buffer of 64 x u64 per traced workgroup
+#ifdef DFM_DEBUG_HOOKS
+// debug builds only (not in dfm_hip.h): device buffer of 64 x u64 per traced workgroup
 DFM_API void dfm_debug_set_trace(void *buf) { g_trace = (unsigned long long *)buf; }
-
-DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int blocks_per_group,
-                                 int planes_per_workgroup)
-{
-    if ((lanes_per_workgroup != 128 && lanes_per_workgroup != 256 && lanes_per_workgroup != 512) ||
-        lds_kib < 4 ||
-        lds_kib > 160 || blocks_per_group < 1 || planes_per_workgroup < 1)
-        return fail(DFM_ERR_INVALID_ARG,
-                    "tune: lanes in {128,256,512}, 4 <= lds_kib <= 160, blocks_per_group >= 1, "
-                    "planes_per_workgroup >= 1%s");
-    g_lds_nt = lanes_per_workgroup;
-    g_lds_kb = lds_kib;
-    g_blocks_per_group = blocks_per_group;
-    g_planes = planes_per_workgroup;
-    return DFM_OK;
-}
-
-DFM_API int dfm_plane_sweep_schedule(int bands_per_chunk)
-{
-    if (bands_per_chunk < 1)
-        return fail(DFM_ERR_INVALID_ARG, "schedule: bands_per_chunk >= 1%s");
-    g_band_chunk = bands_per_chunk;
-    return DFM_OK;
-}
+#endif
 
 DFM_API int dfm_profile_begin(int max_launches)
 {
     if (max_launches <= 0 || max_launches > 65536)
         return fail(DFM_ERR_INVALID_ARG, "max_launches out of range%s");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
     g_prof.ev.assign(2 * (size_t)max_launches, nullptr);
     for (auto &e : g_prof.ev) HIP_TRY(hipEventCreate(&e));
@@ -1337,6 +1458,7 @@ DFM_API int dfm_profile_begin(int max_launches)
 DFM_API int dfm_profile_end(double *total_ms, int *launches)
 {
     if (!total_ms || !launches) return fail(DFM_ERR_INVALID_ARG, "NULL output%s");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = false;
     double sum = 0.0;
     for (int i = 0; i + 1 < g_prof.used; i += 2) {
@@ -1355,17 +1477,19 @@ DFM_API int dfm_profile_end(double *total_ms, int *launches)
 
 }  // extern "C"
 
-// shared with plane_sweep_cl.hip
+// shared with the other translation units
 int dfm::sweep_check_desc(const dfm_sweep_desc *d) { return check_desc(d); }
 dfm::SweepGeom dfm::sweep_make_geom(const dfm_sweep_desc *d) { return make_geom(d); }
 bool dfm::profile_mark(void *stream, bool stop)
 {
     hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     if (!stop) {
         if (!(g_prof.on && g_prof.used + 2 <= (int)g_prof.ev.size())) return false;
         (void)hipEventRecord(g_prof.ev[g_prof.used], st);
         return true;
     }
+    if (!(g_prof.on && g_prof.used + 2 <= (int)g_prof.ev.size())) return false;
     (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
     g_prof.used += 2;
     return true;
@@ -1379,63 +1503,157 @@ DFM_API size_t dfm_plane_sweep_workspace_bytes(const dfm_sweep_desc *desc)
     return 2 * blocked_bytes(desc) + flag_bytes(desc);
 }
 
+DFM_API int dfm_plane_sweep_fwd_opts(const dfm_sweep_desc *desc, const void *cur, const void *prev,
+                                     const float *depths, const float *cam2img,
+                                     const float *cam2img_inv, const float *cur2prev, void *out,
+                                     void *workspace, size_t workspace_bytes, void *stream,
+                                     const dfm_sweep_opts *opts)
+{
+    int rc = check_fwd_args(desc, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace,
+                            workspace_bytes);
+    if (rc != DFM_OK) return rc;
+    Launch L;
+    if (opts) {
+        rc = resolve(desc, opts, L);
+    } else {
+        // the schedule dfm_plane_sweep_autotune cached for this device and shape, else defaults
+        TuneKey k;
+        rc = tune_key(desc, k);
+        if (rc != DFM_OK) return rc;
+        dfm_sweep_opts tuned;
+        bool have = false;
+        {
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            auto it = g_tuned.find(k);
+            if (it != g_tuned.end()) { tuned = it->second; have = true; }
+        }
+        if (!have && takes_lds_tiles(desc, out)) {
+            // First launch of a large volume on this device: time the candidate schedules once
+            // (DFM_AUTOTUNE=0 disables; never inside a stream capture).  `out` ends up valid.
+            const int esz = desc->dtype == DFM_BF16 ? 2 : 4;
+            const double vol = 2.0 * desc->batch * desc->channels * (double)desc->num_depths *
+                               desc->h_out * desc->w_out * esz;
+            const char *env = getenv("DFM_AUTOTUNE");
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing((hipStream_t)stream, &cs);
+            if (vol >= 1.0e9 && !(env && env[0] == '0') && cs == hipStreamCaptureStatusNone)
+                return dfm_plane_sweep_autotune(desc, cur, prev, depths, cam2img, cam2img_inv,
+                                                cur2prev, out, workspace, workspace_bytes, stream,
+                                                nullptr);
+        }
+        rc = resolve(desc, have ? &tuned : nullptr, L);
+    }
+    if (rc != DFM_OK) return rc;
+    return run_fwd(desc, L, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace,
+                   (hipStream_t)stream);
+}
+
 DFM_API int dfm_plane_sweep_fwd(const dfm_sweep_desc *desc, const void *cur, const void *prev,
                                 const float *depths, const float *cam2img,
                                 const float *cam2img_inv, const float *cur2prev, void *out,
                                 void *workspace, size_t workspace_bytes, void *stream)
 {
-    int rc = check_desc(desc);
-    if (rc != DFM_OK) return rc;
-    if (!cur || !prev || !depths || !cam2img || !cam2img_inv || !cur2prev || !out)
-        return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
-    if (!workspace || workspace_bytes < 2 * blocked_bytes(desc) + flag_bytes(desc))
-        return fail(DFM_ERR_WORKSPACE, "workspace smaller than dfm_plane_sweep_workspace_bytes%s");
-    if (((uintptr_t)workspace & 15) || ((uintptr_t)out & 1))
-        return fail(DFM_ERR_INVALID_ARG, "workspace must be 16-byte aligned%s");
-    hipStream_t st = (hipStream_t)stream;
-    if (desc->dtype == DFM_F32)
-        return launch_fwd<float>(desc, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out,
-                                 workspace, st);
-    return launch_fwd<bf16_t>(desc, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out,
-                              workspace, st);
+    return dfm_plane_sweep_fwd_opts(desc, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out,
+                                    workspace, workspace_bytes, stream, nullptr);
 }
 
 DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur, const void *prev,
                                      const float *depths, const float *cam2img,
                                      const float *cam2img_inv, const float *cur2prev, void *out,
                                      void *workspace, size_t workspace_bytes, void *stream,
-                                     int *bands_per_chunk)
+                                     dfm_sweep_opts *chosen)
 {
-    // The workgroup order trades HBM write locality against L2 reuse of the staged rows, and
-    // which side wins depends on the part the process landed on (profiles/r01_store_microbench3.txt):
-    // time the candidates on the caller's own tensors and keep the fastest.  Synchronous.
-    static const int cand[] = {1, 15, 29};
-    hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    const int saved = g_band_chunk;
-    int best = saved, rc = DFM_OK;
-    float best_ms = 3.0e38f;
-    for (int c : cand) {
-        g_band_chunk = c;
-        for (int rep = 0; rep < 4 && rc == DFM_OK; ++rep) {
-            if (rep == 1) (void)hipEventRecord(e0, st);  // rep 0 warms up
-            rc = dfm_plane_sweep_fwd(desc, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out,
-                                     workspace, workspace_bytes, stream);
+    // The workgroup order trades HBM write locality against L2 reuse of the staged rows, and the
+    // tile shape trades waves per CU against registers per lane; which side wins depends on the
+    // part the process landed on (profiles/r01_store_microbench3.txt, r02_*): time the candidates
+    // on the caller's own tensors and remember the fastest for this (device, shape).  Synchronous.
+    int rc = check_fwd_args(desc, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace,
+                            workspace_bytes);
+    if (rc != DFM_OK) return rc;
+    TuneKey key;
+    rc = tune_key(desc, key);
+    if (rc != DFM_OK) return rc;
+    std::vector<dfm_sweep_opts> cand;
+    {
+        dfm_sweep_opts o;
+        memset(&o, 0, sizeof(o));
+        for (int chunk : {1, 15, 29}) {
+            o.bands_per_chunk = chunk;
+            cand.push_back(o);
         }
-        if (rc != DFM_OK) break;
-        (void)hipEventRecord(e1, st);
-        if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(DFM_ERR_HIP, "autotune: event sync failed%s"); break; }
-        float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best_ms) { best_ms = ms; best = c; }
+        if (desc->dtype == DFM_BF16) {
+            // 4 points per lane, twice the waves per CU (two 512-lane workgroups)
+            o.lanes_per_workgroup = 512;
+            o.points_per_lane = 4;
+            for (int chunk : {1, 15}) {
+                o.bands_per_chunk = chunk;
+                cand.push_back(o);
+            }
+        }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    g_band_chunk = rc == DFM_OK ? best : saved;
-    if (bands_per_chunk) *bands_per_chunk = g_band_chunk;
-    return rc;
+    hipStream_t st = (hipStream_t)stream;
+    dfm_sweep_opts best = cand[0];
+    if (takes_lds_tiles(desc, out)) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        float best_ms = 3.0e38f;
+        for (const dfm_sweep_opts &c : cand) {
+            Launch L;
+            rc = resolve(desc, &c, L);
+            for (int rep = 0; rep < 4 && rc == DFM_OK; ++rep) {
+                if (rep == 1) (void)hipEventRecord(e0, st);  // rep 0 warms up
+                rc = run_fwd(desc, L, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out,
+                             workspace, st);
+            }
+            if (rc != DFM_OK) break;
+            (void)hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) {
+                rc = fail(DFM_ERR_HIP, "autotune: event sync failed%s");
+                break;
+            }
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best_ms) { best_ms = ms; best = c; }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (rc != DFM_OK) return rc;
+    } else {
+        Launch L;
+        rc = resolve(desc, nullptr, L);
+        if (rc == DFM_OK)
+            rc = run_fwd(desc, L, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace, st);
+        if (rc != DFM_OK) return rc;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        g_tuned[key] = best;
+    }
+    if (chosen) *chosen = best;
+    return DFM_OK;
+}
+
+DFM_API int dfm_plane_sweep_tuning(const dfm_sweep_desc *desc, dfm_sweep_opts *opts)
+{
+    int rc = check_desc(desc);
+    if (rc != DFM_OK) return rc;
+    if (!opts) return fail(DFM_ERR_INVALID_ARG, "NULL output%s");
+    TuneKey k;
+    rc = tune_key(desc, k);
+    if (rc != DFM_OK) return rc;
+    memset(opts, 0, sizeof(*opts));
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(k);
+    if (it == g_tuned.end()) return 0;
+    *opts = it->second;
+    return 1;
+}
+
+DFM_API void dfm_plane_sweep_reset_tuning(void)
+{
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tuned.clear();
 }
 
 DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out,
@@ -1443,6 +1661,17 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
                                 const float *cam2img_inv, const float *cur2prev, float *grad_cur,
                                 float *grad_prev, void *stream)
 {
+    return dfm_plane_sweep_bwd_opts(desc, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_cur,
+                                    grad_prev, stream, nullptr);
+}
+
+DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *grad_out,
+                                     const float *depths, const float *cam2img,
+                                     const float *cam2img_inv, const float *cur2prev,
+                                     float *grad_cur, float *grad_prev, void *stream,
+                                     const dfm_sweep_opts *opts)
+{
+    const bool force_scatter = opts && opts->kernel == 1;
     int rc = check_desc(desc);
     if (rc != DFM_OK) return rc;
     if (!grad_out || !depths || !cam2img || !cam2img_inv || !cur2prev || !grad_cur || !grad_prev)
@@ -1468,7 +1697,7 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
     const int cw_cur = pick_cw(budget, 4), cw_prev = cw_cur;
     const int rows_cur = rows_for(budget, cw_cur), rows_prev = rows_cur;
     const long long hw = (long long)g.h_out * g.w_out;
-    if (g_force_kernel != 1 && rows_cur >= 4 && desc->h_in < 4096 && desc->w_in < 8192) {
+    if (!force_scatter && rows_cur >= 4 && desc->h_in < 4096 && desc->w_in < 8192) {
         BwdGrid tg;
         tg.batch = desc->batch;
         tg.band_pts = 256 * BWD_PPL;
@@ -1478,14 +1707,7 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
         tg.dchunks = (g.D + tg.planes - 1) / tg.planes;
         const long long nb = (long long)tg.bands * tg.dchunks * desc->batch;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
-        SweepFast fast;
-        fast.scale_is_one = desc->img_scale_factor == 1.0f;
-        {
-            int e = 0;
-            const float m = frexpf(desc->feat_sample_factor, &e);
-            fast.fsf_pow2 = (m == 0.5f) && e > -60 && e < 60;
-            fast.inv_fsf = 1.0f / desc->feat_sample_factor;
-        }
+        const SweepFast fast = make_fast(desc);
         // max |grad_out| of this call -> fixed-point scale (a 4-byte slot of a per-device ring)
         unsigned *gmax = nullptr;
         {
@@ -1505,8 +1727,8 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
     do {                                                                                             \
         tg.rows = (ROWS);                                                                            \
         const int lds_bytes = (CW) * (ROWS) * desc->w_in * 8;                                        \
-        HIP_TRY(hipFuncSetAttribute((const void *)sweep_bwd_tile_kernel<T, CW, HALF>,                \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));         \
+        rc = ensure_dynamic_lds((const void *)sweep_bwd_tile_kernel<T, CW, HALF>, lds_bytes);        \
+        if (rc != DFM_OK) return rc;                                                                 \
         hipLaunchKernelGGL((sweep_bwd_tile_kernel<T, CW, HALF>), dim3((unsigned)nb), dim3(256),      \
                            lds_bytes, st, g, fast, tg, (const T *)grad_out, gmax, depths, cam2img,   \
                            cam2img_inv, cur2prev, grad_cur, grad_prev);                              \

@@ -413,6 +413,9 @@ __global__ __launch_bounds__(256) void mv_sample_bwd_pm_kernel(
     const int wave = tid >> 6, lane = tid & 63;
     int lpv = 1;
     while (lpv < min(g.C, 64)) lpv <<= 1;  // lanes per voxel
+    // a wave owns MV_VT/4 voxels: never spread an iteration over more of them (1- and 2-channel
+    // maps would otherwise scatter their neighbours' voxels a second time)
+    lpv = max(lpv, 64 / (MV_VT / 4));
     const int ch = lane & (lpv - 1), vin = lane / lpv, vpi = 64 / lpv;
     const size_t HW = (size_t)g.Hf * g.Wf;
     for (int it = 0; it < MV_VT / 4; it += vpi) {

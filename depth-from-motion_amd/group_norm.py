@@ -79,13 +79,34 @@ def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
     return _GroupNormFn.apply(x, weight, bias, int(num_groups), float(eps), bool(relu))
 
 
+_cpu_reference = False
+
+
+def allow_cpu_reference(flag=True):
+    """TEST-ONLY switch: lets HipGroupNorm run torch's nn.GroupNorm on CPU tensors so that the
+    module wiring / the gloo data-parallel glue can be exercised on a box without a GPU
+    (tests/test_distributed_cpu.py, tests/test_modules.py).  Off by default: the product has no
+    CPU path and a CPU tensor raises.  Returns the previous setting."""
+    global _cpu_reference
+    prev, _cpu_reference = _cpu_reference, bool(flag)
+    return prev
+
+
 class HipGroupNorm(nn.GroupNorm):
-    """nn.GroupNorm whose GPU forward/backward run in the fused HIP kernels.
-    On CPU tensors (host-side unit tests of the module wiring, gloo data-parallel
-    tests) it is plain nn.GroupNorm."""
+    """nn.GroupNorm whose forward/backward run in the fused HIP kernels (float32 / bfloat16,
+    affine).  Anything else raises -- there is no silent eager fallback: a CPU tensor, or a GPU
+    tensor the kernels do not cover (fp16, affine=False), is an error.  (Tests that exercise
+    module wiring on a CPU-only box opt in with ``allow_cpu_reference(True)``.)"""
 
     def forward(self, x, relu=False):
-        if x.is_cuda and x.dtype in _DTYPES and self.affine:
+        if x.is_cuda:
+            if x.dtype not in _DTYPES or not self.affine:
+                raise RuntimeError(
+                    f'HipGroupNorm: unsupported GPU input (dtype {x.dtype}, affine={self.affine}); '
+                    'the fused kernels cover float32 / bfloat16 with affine parameters')
             return group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu)
+        if not _cpu_reference:
+            raise RuntimeError('HipGroupNorm got a CPU tensor: depth-from-motion_amd has no CPU path '
+                               '(tests opt in with group_norm.allow_cpu_reference(True))')
         y = super().forward(x)
         return torch.relu_(y) if relu else y

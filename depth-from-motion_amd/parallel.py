@@ -1,7 +1,13 @@
 """Data-parallel glue of the path: the batch shards by sample,
 one process per GPU, forward has NO collective; training adds one bucketed
 gradient all-reduce per step (what MMDistributedDataParallel does in the
-reference, apis/train.py:222-230) over RCCL (`backend='nccl'` on ROCm).
+reference, apis/train.py:222-230) over RCCL (`backend='nccl'` on ROCm),
+overlapped with the rest of backward.
+
+Two ways to get that step, both covered by tests/test_distributed_cpu.py on gloo:
+  * ``torch.nn.parallel.DistributedDataParallel`` wraps the registry modules unchanged (their
+    autograd Functions produce ordinary ``.grad`` tensors);
+  * ``GradientBucketReducer`` below: the same bucketing with bucket sizes chosen for xGMI.
 
 Only torch.distributed is used; the same code runs on gloo for the CPU tests.
 """
@@ -17,43 +23,167 @@ def shard_range(num_samples, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _active():
+    return dist.is_available() and dist.is_initialized()
+
+
 def max_over_ranks(value, device=None):
     """Slowest-rank time (bench.py's wall clock)."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def allreduce_gradients(parameters, bucket_bytes=64 << 20, average=True):
-    """Sum (then average) .grad over ranks in flat buckets.
+def gather_rank_times(value, device=None):
+    """(max over ranks, [every rank's value]): the job's time is the slowest rank's; the list
+    exposes stragglers (bench.py prints it as ``per_rank_ms_per_step``)."""
+    if not _active():
+        return float(value), [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, t)
+    vals = [float(v.item()) for v in every]
+    return max(vals), vals
 
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce
-    is per-link bound: few large buckets amortise the ring latency better than
-    DDP's 25 MB default; the KITTI student (~40 MB of grads) goes in one bucket.
-    Returns the number of buckets reduced."""
-    grads = [p.grad for p in parameters if p.grad is not None]
-    if not grads or not (dist.is_available() and dist.is_initialized()):
-        return 0
-    world = dist.get_world_size()
+
+def _buckets_of(params, bucket_bytes):
+    """Static bucket layout over ALL trainable parameters (not only those that happen to have a
+    gradient on this rank), in reverse registration order -- roughly the order backward
+    produces them -- split by size and dtype.  Identical on every rank by construction."""
     buckets, cur, cur_bytes = [], [], 0
-    for g in grads:
-        nbytes = g.numel() * g.element_size()
-        if cur and (cur_bytes + nbytes > bucket_bytes or g.dtype != cur[0].dtype):
+    for p in reversed([p for p in params if p.requires_grad]):
+        nbytes = p.numel() * p.element_size()
+        if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype):
             buckets.append(cur)
             cur, cur_bytes = [], 0
-        cur.append(g)
+        cur.append(p)
         cur_bytes += nbytes
     if cur:
         buckets.append(cur)
+    return buckets
+
+
+def allreduce_gradients(parameters, bucket_bytes=64 << 20, average=True):
+    """Sum (then average) .grad over ranks in flat buckets, after backward (no overlap).
+
+    The bucket layout covers every parameter with ``requires_grad`` -- a parameter that got no
+    gradient on this rank (unused branch, frozen-by-config norm, empty shard) contributes zeros
+    and receives the other ranks' sum -- so all ranks always reduce buffers of the same size in
+    the same order.  Returns the number of buckets reduced."""
+    params = list(parameters)
+    if not params or not _active():
+        return 0
+    world = dist.get_world_size()
+    buckets = _buckets_of(params, bucket_bytes)
     for bucket in buckets:
-        flat = torch.cat([g.reshape(-1) for g in bucket])
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                          for p in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if average:
             flat /= world
         off = 0
-        for g in bucket:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        for p in bucket:
+            piece = flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = piece.clone()
+            else:
+                p.grad.copy_(piece)
+            off += p.numel()
     return len(buckets)
+
+
+class GradientBucketReducer:
+    """Bucketed gradient all-reduce overlapped with backward (DDP semantics).
+
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is per-link
+    bound: few large buckets amortise the ring latency better than DDP's 25 MB default.  The
+    KITTI student (~40 MB of gradients) goes out in two 32 MB buckets: the first leaves while
+    the image backbone is still in backward.
+
+    ``reducer = GradientBucketReducer(model.parameters())`` once; every step:
+    ``loss.backward(); reducer.finalize()``.  A post-accumulate hook on each parameter copies
+    its finished gradient into the bucket's flat buffer; when a bucket is complete -- and all
+    earlier buckets have been launched, so every rank issues the collectives in the same order
+    even if their graphs differ -- its ``all_reduce`` starts asynchronously (on RCCL: on the
+    process group's own stream, next to the remaining backward kernels).  ``finalize`` launches
+    what is left (parameters without a gradient on this rank send zeros), waits, averages and
+    writes the results back into ``.grad``.
+    """
+
+    def __init__(self, parameters, bucket_bytes=32 << 20, average=True):
+        self.params = [p for p in parameters if p.requires_grad]
+        self.average = average
+        self.buckets = _buckets_of(self.params, bucket_bytes)
+        self._where = {}
+        for bi, bucket in enumerate(self.buckets):
+            off = 0
+            for p in bucket:
+                self._where[p] = (bi, off)
+                off += p.numel()
+        self._flat = [None] * len(self.buckets)
+        self._ready = [0] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._next = 0  # first bucket not launched yet
+        self._filled = set()
+        self.launched_during_backward = 0
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def _buffer(self, bi):
+        if self._flat[bi] is None:
+            b = self.buckets[bi]
+            self._flat[bi] = torch.zeros(sum(p.numel() for p in b), dtype=b[0].dtype,
+                                         device=b[0].device)
+        return self._flat[bi]
+
+    def _launch_ready(self, final=False):
+        while self._next < len(self.buckets) and (final or
+                                                  self._ready[self._next] == len(self.buckets[self._next])):
+            bi = self._next
+            buf = self._buffer(bi)
+            if _active():
+                self._work[bi] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+            if not final:
+                self.launched_during_backward += 1
+            self._next += 1
+
+    def _hook(self, p):
+        bi, off = self._where[p]
+        if p in self._filled:  # a second backward before finalize(): gradients accumulate
+            raise RuntimeError('GradientBucketReducer: call finalize() after every backward()')
+        self._filled.add(p)
+        self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        self._ready[bi] += 1
+        self._launch_ready()
+
+    def finalize(self):
+        """Launch the remaining buckets, wait for all, write the averaged sums back."""
+        self._launch_ready(final=True)
+        world = dist.get_world_size() if _active() else 1
+        for bi, bucket in enumerate(self.buckets):
+            if self._work[bi] is not None:
+                self._work[bi].wait()
+            buf = self._buffer(bi)
+            if self.average and world > 1:
+                buf /= world
+            off = 0
+            for p in bucket:
+                piece = buf[off:off + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = piece.clone()
+                else:
+                    p.grad.copy_(piece)
+                off += p.numel()
+            buf.zero_()
+        n = len(self.buckets)
+        self._ready = [0] * n
+        self._work = [None] * n
+        self._next = 0
+        self._filled.clear()
+        return n
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

@@ -8,8 +8,11 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
   * non-finite sampling coordinates (a plane exactly through the camera
     centre) give 0 like torch's GPU grid_sample; torch's CPU kernel gives NaN.
 """
+import contextlib
 import ctypes
+import threading
 
+import numpy as np
 import torch
 
 from . import _capi
@@ -24,28 +27,50 @@ def _require_gpu(t, name):
             '(the HIP kernels are the product; the CPU oracle is test-only)')
 
 
-def _pad4x4(m):
-    """pad (3,3)/(3,4)/(4,4) to the 4x4 the reference builds in
-    points_img2cam / points_cam2img (utils.py:199-203, 239-240)."""
-    out = torch.eye(4, dtype=torch.float32)
-    m = m[:3] if m.shape[0] == 4 else m
-    out[:m.shape[0], :m.shape[1]] = m
+def _pad4x4_batch(m, batch_size):
+    """(>=B, 3|4, 3|4) -> (B,4,4): the padding points_img2cam / points_cam2img apply
+    (utils.py:199-203, 239-240): rows :3 of a 4-row matrix, identity elsewhere."""
+    m = m[:batch_size]
+    rows = 3 if m.shape[-2] == 4 else m.shape[-2]
+    out = torch.eye(4, dtype=torch.float32, device=m.device).repeat(batch_size, 1, 1)
+    out[:, :rows, :m.shape[-1]] = m[:, :rows]
     return out
 
 
-def camera_matrices(cam2imgs, cur2prevs, batch_size, device):
+def camera_matrices(cam2imgs, cur2prevs, batch_size, device, cam2img_inv=None):
     """(B,16) fp32 device tensors: padded cam2img, its fp32 inverse, cur2prev.
 
-    The inverse is taken on the host with torch.inverse in fp32, exactly the
-    op the reference's PyTorch-CPU path runs (utils.py:241); it is 16 floats
-    per sample, not a hot path.
+    Inputs that already live on ``device`` (the reference pipeline hands device tensors,
+    dfm_backbone.py:151-154) never leave it: padding, ``torch.linalg.inv`` (batched, fp32) and
+    the packing run on the device, with no host round trip or stream synchronisation.  Host
+    inputs (lists / numpy / CPU tensors, what ``img_metas`` carries) are inverted on the host
+    with ``torch.inverse`` in fp32 -- exactly the op the reference's PyTorch-CPU path runs
+    (utils.py:241), which is what the bit-exact parity tests replay -- and uploaded once.
+    ``cam2img_inv``: a precomputed (B,4,4) inverse (bit-exact replay of another backend).
     """
-    cam2imgs = torch.as_tensor(cam2imgs, dtype=torch.float32).detach().cpu()
-    cur2prevs = torch.as_tensor(cur2prevs, dtype=torch.float32).detach().cpu()
-    P = torch.stack([_pad4x4(cam2imgs[i]) for i in range(batch_size)])
-    Pinv = torch.stack([torch.inverse(P[i]) for i in range(batch_size)])
-    T = torch.stack([cur2prevs[i] for i in range(batch_size)]).contiguous()
-    pack = torch.stack([P, Pinv, T]).reshape(3, batch_size, 16).contiguous()
+    def as_f32(x):
+        if isinstance(x, (list, tuple)):
+            if len(x) and torch.is_tensor(x[0]):
+                x = torch.stack(list(x))
+            else:
+                x = np.asarray(x, dtype=np.float32)
+        return torch.as_tensor(x).detach().to(torch.float32)
+
+    cam2imgs, cur2prevs = as_f32(cam2imgs), as_f32(cur2prevs)
+    on_device = cam2imgs.device == device
+    P = _pad4x4_batch(cam2imgs, batch_size)
+    if cam2img_inv is not None:
+        Pinv = as_f32(cam2img_inv)[:batch_size].to(P.device)
+    elif on_device:
+        Pinv = torch.linalg.inv(P)
+    else:
+        Pinv = torch.stack([torch.inverse(P[i]) for i in range(batch_size)])
+    T = cur2prevs[:batch_size]
+    if on_device:
+        T = T.to(device)
+        return (P.reshape(batch_size, 16).contiguous(), Pinv.reshape(batch_size, 16).contiguous(),
+                T.reshape(batch_size, 16).contiguous())
+    pack = torch.stack([P.cpu(), Pinv.cpu(), T.cpu()]).reshape(3, batch_size, 16).contiguous()
     pack = pack.to(device, non_blocking=True)
     return pack[0], pack[1], pack[2]
 
@@ -79,23 +104,68 @@ def _ptr(t):
 
 
 class _Workspace:
-    """Per-device scratch for the blocked feature copies, grown on demand and
-    kept so that the steady state allocates nothing."""
+    """Scratch (blocked feature copies, GroupNorm partials, pixel-major staging), grown on
+    demand and kept so that the steady state allocates nothing.  One buffer per (device,
+    stream): two ops issued on different streams never share scratch."""
     _bufs = {}
 
     @classmethod
     def get(cls, device, nbytes):
-        buf = cls._bufs.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        buf = cls._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            cls._bufs[device] = buf
+            cls._bufs[key] = buf
         return buf
 
 
+# ---------------------------------------------------------------------------
+# launch options: per call, never process state inside the library
+# ---------------------------------------------------------------------------
+_tls = threading.local()
+_OPT_FIELDS = {'kernel': 'kernel', 'lanes': 'lanes_per_workgroup', 'lds_kib': 'lds_kib',
+               'blocks_per_group': 'blocks_per_group', 'planes': 'planes_per_workgroup',
+               'bands_per_chunk': 'bands_per_chunk', 'points_per_lane': 'points_per_lane'}
+
+
+def make_opts(**kw):
+    """dfm_sweep_opts from keywords (kernel, lanes, lds_kib, blocks_per_group, planes,
+    bands_per_chunk, points_per_lane); unspecified fields = library default."""
+    o = _capi.SweepOpts()
+    for k, v in kw.items():
+        setattr(o, _OPT_FIELDS[k], int(v or 0))
+    return o
+
+
+@contextlib.contextmanager
+def launch_options(**kw):
+    """A/B runs and the kernel-mode parity matrix: every plane-sweep call made by THIS thread
+    inside the block (forward and backward, also through ``build_dfm_cost``) carries these
+    options to the C ABI.  Nothing is stored in the library."""
+    prev = getattr(_tls, 'opts', None)
+    _tls.opts = make_opts(**kw) if kw else None  # no keywords: back to tuned / default
+    try:
+        yield _tls.opts
+    finally:
+        _tls.opts = prev
+
+
+def _current_opts(schedule=None):
+    o = getattr(_tls, 'opts', None)
+    if schedule:
+        o2 = _capi.SweepOpts()
+        if o is not None:
+            ctypes.pointer(o2)[0] = o
+        o2.bands_per_chunk = int(schedule)
+        return o2
+    return o
+
+
 def plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T, out=None,
-                        channels_last=False):
+                        channels_last=False, schedule=None):
     """Raw launch: everything already on the device.  ``channels_last``: write the volume
-    as (B, D, H, W, 2C) and return it as a (B, 2C, D, H, W) channels_last_3d tensor."""
+    as (B, D, H, W, 2C) and return it as a (B, 2C, D, H, W) channels_last_3d tensor.
+    ``schedule``: bands_per_chunk of this call (None: tuned / default)."""
     lib = _capi.lib()
     device = cur_feats.device
     if channels_last:
@@ -116,28 +186,43 @@ def plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T, out=Non
                           dtype=cur_feats.dtype, device=device)
     nbytes = lib.dfm_plane_sweep_workspace_bytes(ctypes.byref(desc))
     ws = _Workspace.get(device, nbytes)
+    opts = _current_opts(schedule)
     with torch.cuda.device(device):
         _capi.check(
-            lib.dfm_plane_sweep_fwd(ctypes.byref(desc), _ptr(cur_feats), _ptr(prev_feats),
-                                    _ptr(depths), _ptr(P), _ptr(Pinv), _ptr(T), _ptr(out), _ptr(ws),
-                                    nbytes, _stream_ptr(device)))
+            lib.dfm_plane_sweep_fwd_opts(ctypes.byref(desc), _ptr(cur_feats), _ptr(prev_feats),
+                                         _ptr(depths), _ptr(P), _ptr(Pinv), _ptr(T), _ptr(out),
+                                         _ptr(ws), nbytes, _stream_ptr(device),
+                                         ctypes.byref(opts) if opts is not None else None))
     return out
 
 
 def plane_sweep_autotune(desc, cur_feats, prev_feats, depths, P, Pinv, T, out):
-    """Times the workgroup schedules of the LDS-staged kernel on these tensors and keeps the
-    fastest for the process (``dfm_plane_sweep_autotune``; synchronous).  Returns the choice."""
+    """Times the candidate launch shapes / workgroup schedules of the LDS-staged kernel on these
+    tensors and caches the fastest for this (device, shape) inside the library
+    (``dfm_plane_sweep_autotune``; synchronous; ``out`` holds valid results afterwards).
+    Returns the choice as a dict.  ``dfm_plane_sweep_fwd`` does this by itself on the first
+    launch of a volume >= 1 GB."""
     lib = _capi.lib()
     device = cur_feats.device
     nbytes = lib.dfm_plane_sweep_workspace_bytes(ctypes.byref(desc))
     ws = _Workspace.get(device, nbytes)
-    chosen = ctypes.c_int(0)
+    chosen = _capi.SweepOpts()
     with torch.cuda.device(device):
         _capi.check(
             lib.dfm_plane_sweep_autotune(ctypes.byref(desc), _ptr(cur_feats), _ptr(prev_feats),
                                          _ptr(depths), _ptr(P), _ptr(Pinv), _ptr(T), _ptr(out), _ptr(ws),
                                          nbytes, _stream_ptr(device), ctypes.byref(chosen)))
-    return chosen.value
+    return chosen.as_dict()
+
+
+def plane_sweep_tuning(desc):
+    """The cached launch options for this shape on the current device, or None."""
+    lib = _capi.lib()
+    o = _capi.SweepOpts()
+    rc = lib.dfm_plane_sweep_tuning(ctypes.byref(desc), ctypes.byref(o))
+    if rc < 0:
+        _capi.check(rc)
+    return o.as_dict() if rc == 1 else None
 
 
 class _PlaneSweepFn(torch.autograd.Function):
@@ -160,11 +245,13 @@ class _PlaneSweepFn(torch.autograd.Function):
         shape = (desc.batch, desc.channels, desc.h_in, desc.w_in)
         g_cur = torch.zeros(shape, dtype=torch.float32, device=device)
         g_prev = torch.zeros(shape, dtype=torch.float32, device=device)
+        opts = _current_opts()
         with torch.cuda.device(device):
             _capi.check(
-                lib.dfm_plane_sweep_bwd(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P),
-                                        _ptr(Pinv), _ptr(T), _ptr(g_cur), _ptr(g_prev),
-                                        _stream_ptr(device)))
+                lib.dfm_plane_sweep_bwd_opts(ctypes.byref(desc), _ptr(grad_out), _ptr(depths),
+                                             _ptr(P), _ptr(Pinv), _ptr(T), _ptr(g_cur), _ptr(g_prev),
+                                             _stream_ptr(device),
+                                             ctypes.byref(opts) if opts is not None else None))
         return g_cur.to(ctx.in_dtype), g_prev.to(ctx.in_dtype), None, None, None, None, None, None
 
 
@@ -179,7 +266,8 @@ def build_dfm_cost(cur_feats,
                    flip=False,
                    img_crop_offset=(0, 0),
                    img_scale_factor=1.0,
-                   memory_format=torch.contiguous_format):
+                   memory_format=torch.contiguous_format,
+                   cam2img_inv=None):
     """Plane-sweep cost volume, drop-in for the reference function.
 
     ``memory_format`` (extension): ``torch.channels_last_3d`` returns the same tensor
@@ -194,6 +282,9 @@ def build_dfm_cost(cur_feats,
         cur2prevs: [>=B, 4, 4]; indexed by the batch index like the reference
             (dfm_backbone.py:270)
         img_shape: (org_h, org_w) of the original image (flip only)
+        cam2img_inv (extension): precomputed fp32 inverse of the padded intrinsics, (B,4,4);
+            default: computed where ``cam2imgs`` lives (device: batched ``torch.linalg.inv``,
+            no host sync; host: ``torch.inverse`` like the reference's CPU path)
 
     Returns:
         cost_volume: [B, 2C, D, H_out, W_out], same dtype as the inputs
@@ -210,7 +301,7 @@ def build_dfm_cost(cur_feats,
     batch_size = cur_feats.shape[0]
     desc = _make_desc(cur_feats, depths.numel(), feat_sample_factor, cost_sample_factor, img_shape,
                       flip, img_crop_offset, img_scale_factor)
-    P, Pinv, T = camera_matrices(cam2imgs, cur2prevs, batch_size, device)
+    P, Pinv, T = camera_matrices(cam2imgs, cur2prevs, batch_size, device, cam2img_inv)
     if memory_format not in (torch.contiguous_format, torch.channels_last_3d):
         raise ValueError('memory_format must be contiguous_format or channels_last_3d')
     return _PlaneSweepFn.apply(cur_feats, prev_feats, depths, P, Pinv, T, desc,

@@ -24,7 +24,10 @@
  *   - plain C: device pointers are `void*` / `float*` (hipMalloc'ed or a torch
  *     tensor's data_ptr()), sizes are explicit, no torch types.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
- *     NULL = the null stream) and re-entrant per device.
+ *     NULL = the null stream) and re-entrant: the library keeps no mutable
+ *     launch state -- launch options travel with the call (dfm_sweep_opts),
+ *     the only shared state is the mutex-guarded tuned-schedule cache and
+ *     the bench-only dfm_profile_* event list.
  *   - return value: DFM_OK (0) or a negative dfm_status; never throws.
  *     dfm_last_error() returns a thread-local message for the last failure.
  *   - dtype: DFM_F32 or DFM_BF16 is the storage type of feature/volume
@@ -59,7 +62,7 @@ typedef enum dfm_dtype { DFM_F32 = 0, DFM_BF16 = 1 } dfm_dtype;
 /* ---------------------------------------------------------------------- */
 /* library                                                                 */
 /* ---------------------------------------------------------------------- */
-DFM_API int dfm_version(void);            /* ABI version, currently 1     */
+DFM_API int dfm_version(void);            /* ABI version, currently 2     */
 DFM_API const char *dfm_last_error(void); /* thread-local, never NULL     */
 
 /* Per-launch device timing of the volume-writing kernel, measured with HIP
@@ -152,36 +155,71 @@ DFM_API int dfm_plane_sweep_grid(const dfm_sweep_desc *desc, int32_t b, const fl
 
 /* Which kernel the last dfm_plane_sweep_fwd on this thread dispatched:
  * 0 = none yet, 1 = lane-per-point gather kernel, 2 = LDS-staged tile kernel
- * (+ direct-tap pass over flagged tiles), 3 = tile kernel with direct taps. */
+ * (+ direct-tap pass over flagged tiles), 3 = tile kernel with direct taps.
+ * Thread-local. */
 DFM_API int dfm_plane_sweep_last_kernel(void);
-/* A/B measurements: 0 = auto; 1/2/3 = force that kernel (2 and 3 need
- * D*h_out*w_out to be a multiple of 16/sizeof(T), else the call uses 1).
- * auto = 2 for dense sweeps (cost_sample_factor < 1.5), 3 for strided ones. */
-DFM_API void dfm_plane_sweep_force_kernel(int which);
-/* Launch shape of the LDS-staged kernel (process-wide): lanes per workgroup
- * (128 or 256), dynamic LDS per workgroup in KiB (4..160), how many 16-byte
- * channel blocks one workgroup sweeps before the next tile, and how many
- * consecutive depth planes share one workgroup's staged feature rows (rounded
- * down to a divisor of lanes/64).  A tile whose feature rows do not fit the
- * LDS is redone with direct taps. */
-DFM_API int dfm_plane_sweep_tune(int lanes_per_workgroup, int lds_kib, int blocks_per_group,
-                                 int planes_per_workgroup);
-/* Workgroup order of the LDS-staged kernel (process-wide): how many adjacent
- * bands of a depth plane are scheduled back to back before the next depth
- * group.  1 (default) keeps all depth planes of one band resident together
- * (best L2 reuse of the staged rows); larger values make the resident
- * workgroups write longer contiguous runs of every channel plane (better HBM
- * write locality, more L2 refetch) -- see profiles/r01_store_microbench3.txt. */
-DFM_API int dfm_plane_sweep_schedule(int bands_per_chunk);
-/* Picks bands_per_chunk for this process by timing dfm_plane_sweep_fwd with the caller's own
- * arguments (a few launches per candidate; SYNCHRONOUS, `out` is overwritten with valid
- * results).  The choice only matters for the LDS-staged kernel; *bands_per_chunk (may be NULL)
- * receives it. */
+
+/*
+ * Launch options of ONE call (the library keeps no process-wide launch state).  Every field:
+ * 0 = the library's default.
+ *   kernel               1/2/3 = force that kernel (2 and 3 need D*h_out*w_out to be a multiple
+ *                        of 16/sizeof(T), else the call uses 1).  default = 2 for dense sweeps
+ *                        (cost_sample_factor < 1.5), 3 for strided ones.  For the backward call:
+ *                        1 = the lane-per-point scatter fallback.
+ *   lanes_per_workgroup  128 | 256 | 512 | 1024 (tile kernels; default 256)
+ *   lds_kib              dynamic LDS per workgroup, 4..160 (default 52); a tile whose feature
+ *                        rows do not fit is redone with direct taps
+ *   blocks_per_group     16-byte channel blocks one workgroup sweeps (default: all)
+ *   planes_per_workgroup consecutive depth planes that share one workgroup's staged rows
+ *                        (default 2; rounded down to a divisor of lanes/64)
+ *   bands_per_chunk      workgroup order: adjacent bands of a depth plane scheduled back to
+ *                        back before the next depth group.  1 (default) keeps all depth planes
+ *                        of one band resident together (best L2 reuse of the staged rows);
+ *                        larger values make the resident workgroups write longer contiguous
+ *                        runs of every channel plane (profiles/r01_store_microbench3.txt)
+ *   points_per_lane      16/sizeof(T) (default: one 16-byte store per channel), or 4 with
+ *                        DFM_BF16 and 512/1024 lanes: 8-byte stores, half the registers per
+ *                        lane, twice the waves per CU for the same tile
+ */
+typedef struct dfm_sweep_opts {
+    int32_t kernel;
+    int32_t lanes_per_workgroup;
+    int32_t lds_kib;
+    int32_t blocks_per_group;
+    int32_t planes_per_workgroup;
+    int32_t bands_per_chunk;
+    int32_t points_per_lane;
+    int32_t reserved;
+} dfm_sweep_opts;
+
+/* dfm_plane_sweep_fwd with explicit launch options.  opts == NULL is dfm_plane_sweep_fwd: the
+ * schedule cached for this (device, shape) by dfm_plane_sweep_autotune if there is one; else,
+ * for a volume >= 1 GB that takes the LDS-staged kernel, the call runs the autotuner first
+ * (once per device and shape; synchronous; `out` is valid afterwards; DFM_AUTOTUNE=0 in the
+ * environment or an active stream capture disables it); else the defaults above. */
+DFM_API int dfm_plane_sweep_fwd_opts(const dfm_sweep_desc *desc, const void *cur, const void *prev,
+                                     const float *depths, const float *cam2img,
+                                     const float *cam2img_inv, const float *cur2prev, void *out,
+                                     void *workspace, size_t workspace_bytes, void *stream,
+                                     const dfm_sweep_opts *opts);
+DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *grad_out,
+                                     const float *depths, const float *cam2img,
+                                     const float *cam2img_inv, const float *cur2prev,
+                                     float *grad_cur, float *grad_prev, void *stream,
+                                     const dfm_sweep_opts *opts);
+/* Times the candidate launch shapes / workgroup orders of the LDS-staged kernel with the caller's
+ * own arguments (a few launches per candidate; SYNCHRONOUS, `out` is overwritten with valid
+ * results) and caches the fastest for this (device, problem shape); later dfm_plane_sweep_fwd
+ * calls of that shape use it.  *chosen (may be NULL) receives it.  Thread-safe. */
 DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur, const void *prev,
                                      const float *depths, const float *cam2img,
                                      const float *cam2img_inv, const float *cur2prev, void *out,
                                      void *workspace, size_t workspace_bytes, void *stream,
-                                     int *bands_per_chunk);
+                                     dfm_sweep_opts *chosen);
+/* The cached choice for desc's shape on the current device: returns 1 and fills *opts, or 0
+ * (nothing cached; *opts zeroed = defaults), or a negative dfm_status. */
+DFM_API int dfm_plane_sweep_tuning(const dfm_sweep_desc *desc, dfm_sweep_opts *opts);
+DFM_API void dfm_plane_sweep_reset_tuning(void);
 
 /* ---------------------------------------------------------------------- */
 /* multi-view voxel lifting (point_sample x views x frames + reduction)    */

@@ -110,6 +110,52 @@ def test_frustum_to_voxel_backward(pkg):
     np.testing.assert_allclose(mg.grad.cpu().numpy(), mr.grad.numpy(), **TOL)
 
 
+@pytest.mark.parametrize('channels', [1, 2, 3])
+def test_frustum_to_voxel_backward_few_channels(pkg, channels):
+    """1- and 2-channel maps: the pixel-major backward gives fewer than 4 lanes to a voxel; a
+    wave must still scatter only its own 16 voxels (round-1 advisor finding: 2-4x gradients)."""
+    z = np.load(os.path.join(util.GOLDEN, 'f2v_batch2.npz'))
+    stereo = torch.from_numpy(z['stereo'])[:, :channels].contiguous()
+    sem = torch.from_numpy(z['sem'])[:, :channels].contiguous()
+    soft = torch.from_numpy(z['softmax'])
+    coords, cam = torch.from_numpy(z['coordinates_3d']), torch.from_numpy(z['cam2img'])
+    pad = tuple(int(v) for v in z['pad_shape'])
+    sr, mr = stereo.clone().requires_grad_(True), sem.clone().requires_grad_(True)
+    ref = _f2v_torch(sr, soft, mr, coords, cam, pad, float(z['depth_min']), float(z['depth_max']))
+    go = torch.from_numpy(np.random.RandomState(3).randn(*ref.shape).astype(np.float32))
+    (ref * go).sum().backward()
+    sg, mg = stereo.cuda().requires_grad_(True), sem.cuda().requires_grad_(True)
+    metas = [{'cam2img': c.tolist(), 'pad_shape': pad + (3,)} for c in z['cam2img']]
+    out = pkg.frustum_to_voxel_sample(sg, soft.cuda(), metas, mg, coords,
+                                      dict(depth_min=float(z['depth_min']),
+                                           depth_max=float(z['depth_max'])))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    (out * go.cuda()).sum().backward()
+    np.testing.assert_allclose(sg.grad.cpu().numpy(), sr.grad.numpy(), **TOL)
+    np.testing.assert_allclose(mg.grad.cpu().numpy(), mr.grad.numpy(), **TOL)
+
+
+@pytest.mark.parametrize('channels', [1, 2])
+def test_mv_lifting_backward_few_channels(pkg, channels):
+    """Multi-view lifting with 1 / 2 channels against the full-channel run: the gradient of
+    channel c does not depend on how many channels ride along."""
+    from tests.test_point_sample_gpu import meta_from_fixture
+    z = np.load(os.path.join(util.GOLDEN, 'mv_mean_2frames.npz'))
+    nv, nf = int(z['num_views']), int(z['num_frames'])
+    feats = torch.from_numpy(z['feats'])
+    go = torch.from_numpy(np.random.RandomState(2).randn(*z['ref_out'].shape).astype(np.float32))
+
+    def grads(f, g):
+        fg = f.cuda().requires_grad_(True)
+        out = pkg.mv_feature_transformation(fg, [meta_from_fixture(z)], nv, nf, z['voxel_range'],
+                                            z['n_voxels'], 'mean')
+        (out * g.cuda()).sum().backward()
+        return fg.grad.cpu().numpy()
+    full = grads(feats, go)
+    few = grads(feats[:, :, :channels].contiguous(), go[:, :channels].contiguous())
+    np.testing.assert_allclose(few, full[:, :, :channels], **TOL)
+
+
 @pytest.mark.parametrize('case', ['mv_mean_2frames', 'mv_concat_2frames_aug'])
 def test_mv_lifting_backward(pkg, case):
     from oracle import dfm_oracle as orc

@@ -1,6 +1,8 @@
-"""CPU, gloo, world_size 2: the data-parallel glue of the path -- batch sharding
-by sample, max-over-ranks timing and the bucketed gradient all-reduce -- checked
-against the single-process result on the full batch."""
+"""CPU, gloo, world_size 2: the data-parallel glue of the path -- batch sharding by sample,
+max-over-ranks timing (bench.py's aggregation), the bucketed gradient all-reduce (post-backward
+and overlapped-with-backward forms, parameters unused on one rank included) and plain torch
+DDP around the registry modules -- checked against the single-process result on the full batch.
+(reference: MMDistributedDataParallel in apis/train.py:222-230)"""
 import importlib
 import os
 import socket
@@ -18,54 +20,135 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _neck(mods):
+    torch.manual_seed(0)
+    return mods.OutdoorImVoxelNeck(in_channels=4, out_channels=8,
+                                   norm_cfg=dict(type='GN', num_groups=2))  # per-sample norm
+
+
+def _worker(rank, world, port, q, mode):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     par = importlib.import_module('depth-from-motion_amd.parallel')
     mods = importlib.import_module('depth-from-motion_amd.modules')
-    torch.manual_seed(0)
-    neck = mods.OutdoorImVoxelNeck(in_channels=4, out_channels=8,
-                                   norm_cfg=dict(type='GN', num_groups=2))  # per-sample norm
+    importlib.import_module('depth-from-motion_amd.group_norm').allow_cpu_reference(True)
+    neck = _neck(mods)
     x = torch.randn(6, 4, 5, 4, 12, generator=torch.Generator().manual_seed(1))
     lo, hi = par.shard_range(6, rank, world)
-    out = neck(x[lo:hi])[0]
-    # DDP semantics: mean over the GLOBAL batch = average over ranks of per-rank means
-    # only if shards are equal; weight by shard size to be exact
-    loss = out.square().mean() * (hi - lo) * world / 6.0
-    loss.backward()
-    nb = par.allreduce_gradients(neck.parameters(), bucket_bytes=4096)
-    t = par.max_over_ranks(1.0 + rank)
-    flat = torch.cat([p.grad.reshape(-1) for p in neck.parameters()])
-    q.put((rank, (lo, hi), nb, t, flat))
+    extra = None
+    if mode == 'unused':
+        # a parameter only rank 0 uses: rank 1 has no gradient for it
+        extra = torch.nn.Parameter(torch.ones(3))
+    params = list(neck.parameters()) + ([extra] if extra is not None else [])
+    info = 0
+    if mode == 'ddp':
+        model = torch.nn.parallel.DistributedDataParallel(neck, broadcast_buffers=False)
+        out = model(x[lo:hi])[0]
+        out.square().mean().backward()  # equal shards: DDP's mean over ranks == global mean
+    else:
+        reducer = par.GradientBucketReducer(params, bucket_bytes=4096) if mode in ('overlap', 'unused') \
+            else None
+        out = neck(x[lo:hi])[0]
+        # DDP semantics: mean over the GLOBAL batch = average over ranks of per-rank means
+        # only if shards are equal; weight by shard size to be exact
+        loss = out.square().mean() * (hi - lo) * world / 6.0
+        if extra is not None and rank == 0:
+            loss = loss + (extra * torch.tensor([1.0, 2.0, 3.0])).sum()
+        loss.backward()
+        if reducer is not None:
+            info = reducer.launched_during_backward
+            nb = reducer.finalize()
+            # a second step through the same reducer gives the same result
+            for p in params:
+                p.grad = None
+            loss2 = neck(x[lo:hi])[0].square().mean() * (hi - lo) * world / 6.0
+            if extra is not None and rank == 0:
+                loss2 = loss2 + (extra * torch.tensor([1.0, 2.0, 3.0])).sum()
+            loss2.backward()
+            reducer.finalize()
+        else:
+            nb = par.allreduce_gradients(params, bucket_bytes=4096)
+        info = (info, nb)
+    t, every = par.gather_rank_times(1.0 + rank)
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    q.put((rank, (lo, hi), info, (t, every, par.max_over_ranks(1.0 + rank)), flat))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_matches_single_process():
+def _run(mode):
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert [r[1] for r in res] == [(0, 3), (3, 6)]
-    assert all(r[2] > 1 for r in res)              # several buckets were exercised
-    assert all(r[3] == 2.0 for r in res)           # max over ranks of (1.0, 2.0)
-    assert torch.equal(res[0][4], res[1][4])       # identical gradients on both ranks
-    # single-process reference on the full batch
+    return res
+
+
+def _reference():
     mods = importlib.import_module('depth-from-motion_amd.modules')
-    torch.manual_seed(0)
-    neck = mods.OutdoorImVoxelNeck(in_channels=4, out_channels=8,
-                                   norm_cfg=dict(type='GN', num_groups=2))
-    x = torch.randn(6, 4, 5, 4, 12, generator=torch.Generator().manual_seed(1))
-    neck(x)[0].square().mean().backward()
-    ref = torch.cat([p.grad.reshape(-1) for p in neck.parameters()])
-    torch.testing.assert_close(res[0][4], ref, rtol=1e-4, atol=1e-6)
+    gn = importlib.import_module('depth-from-motion_amd.group_norm')
+    prev = gn.allow_cpu_reference(True)
+    try:
+        neck = _neck(mods)
+        x = torch.randn(6, 4, 5, 4, 12, generator=torch.Generator().manual_seed(1))
+        neck(x)[0].square().mean().backward()
+    finally:
+        gn.allow_cpu_reference(prev)
+    return torch.cat([p.grad.reshape(-1) for p in neck.parameters()])
+
+
+def test_two_rank_gloo_matches_single_process():
+    res = _run('post')
+    assert [r[1] for r in res] == [(0, 3), (3, 6)]
+    assert all(r[2][1] > 1 for r in res)           # several buckets were exercised
+    # bench.py's aggregation: max over ranks is the job's time, every rank's time is kept
+    assert all(r[3] == (2.0, [1.0, 2.0], 2.0) for r in res)
+    assert torch.equal(res[0][4], res[1][4])       # identical gradients on both ranks
+    torch.testing.assert_close(res[0][4], _reference(), rtol=1e-4, atol=1e-6)
+
+
+def test_overlapped_bucket_reducer_matches_single_process():
+    res = _run('overlap')
+    assert all(r[2][1] > 1 for r in res)
+    # buckets were handed to the collective while backward was still running
+    assert all(r[2][0] >= 1 for r in res)
+    assert torch.equal(res[0][4], res[1][4])
+    torch.testing.assert_close(res[0][4], _reference(), rtol=1e-4, atol=1e-6)
+
+
+def test_parameter_unused_on_one_rank_does_not_desync():
+    """Round-1 advisor finding: buckets built from `p.grad is not None` differ between ranks
+    when a parameter is unused on one of them.  Both reducers bucket over requires_grad."""
+    res = _run('unused')
+    assert torch.equal(res[0][4], res[1][4])
+    ref = _reference()
+    torch.testing.assert_close(res[0][4][:-3], ref, rtol=1e-4, atol=1e-6)
+    # rank 0's gradient (1,2,3) averaged with rank 1's zeros
+    torch.testing.assert_close(res[0][4][-3:], torch.tensor([0.5, 1.0, 1.5]))
+
+
+def test_torch_ddp_wraps_the_modules_unchanged():
+    res = _run('ddp')
+    assert torch.equal(res[0][4], res[1][4])
+    torch.testing.assert_close(res[0][4], _reference(), rtol=1e-4, atol=1e-6)
+
+
+def test_hip_group_norm_refuses_cpu_tensors_by_default():
+    gn = importlib.import_module('depth-from-motion_amd.group_norm')
+    m = gn.HipGroupNorm(2, 4)
+    try:
+        m(torch.zeros(1, 4, 2, 2, 2))
+    except RuntimeError as e:
+        assert 'no CPU path' in str(e)
+    else:
+        raise AssertionError('HipGroupNorm ran on a CPU tensor without the test-only opt-in')
 
 
 def test_shard_range_covers_the_batch():

@@ -27,32 +27,34 @@ def pkg():
     return p
 
 
-# kernel variants every parity case runs through: (force_kernel, lanes, lds KiB)
+# kernel variants every parity case runs through (dfm_sweep_opts of every call in the test):
 #   gather    : lane-per-point kernel (also what non-vectorisable shapes take)
 #   lds128/256: LDS-staged tile kernel, 128- / 256-lane workgroups
 #   lds_spill : LDS budget too small for any tile -> every tile is flagged and
 #               redone by the direct-tap pass
 #   direct    : tile kernel with direct taps for every tile (strided sweeps)
 #   lds256_chunk: shipped shape with 3 adjacent bands scheduled back to back
-# (force_kernel, lanes, lds KiB, channel blocks per group, depth planes per workgroup, bands per chunk)
-MODES = {'gather': (1, 256, 64, 4, 1, 1), 'lds128_p1': (2, 128, 36, 1, 1, 1),
-         'lds128_p2': (2, 128, 36, 1000, 2, 1), 'lds256_p1': (2, 256, 64, 4, 1, 1),
-         'lds256_p2': (2, 256, 52, 1000, 2, 1), 'lds256_p4': (2, 256, 52, 1000, 4, 1),
-         'lds256_chunk': (2, 256, 52, 1000, 2, 3),
-         'lds_spill': (2, 128, 4, 2, 2, 2), 'direct': (3, 256, 64, 4, 1, 1)}
+#   lds512_v4 / lds1024_v4: 4 points per lane (bf16: 8-byte stores, 4 waves per SIMD)
+MODES = {'gather': dict(kernel=1, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
+         'lds128_p1': dict(kernel=2, lanes=128, lds_kib=36, blocks_per_group=1, planes=1),
+         'lds128_p2': dict(kernel=2, lanes=128, lds_kib=36, blocks_per_group=1000, planes=2),
+         'lds256_p1': dict(kernel=2, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
+         'lds256_p2': dict(kernel=2, lanes=256, lds_kib=52, blocks_per_group=1000, planes=2),
+         'lds256_p4': dict(kernel=2, lanes=256, lds_kib=52, blocks_per_group=1000, planes=4),
+         'lds256_chunk': dict(kernel=2, lanes=256, lds_kib=52, planes=2, bands_per_chunk=3),
+         'lds512_v4': dict(kernel=2, lanes=512, lds_kib=52, planes=2, points_per_lane=4),
+         'lds1024_v4': dict(kernel=2, lanes=1024, lds_kib=64, planes=4, points_per_lane=4,
+                            bands_per_chunk=2),
+         'lds_spill': dict(kernel=2, lanes=128, lds_kib=4, blocks_per_group=2, planes=2,
+                           bands_per_chunk=2),
+         'direct': dict(kernel=3, lanes=256, lds_kib=64, blocks_per_group=4, planes=1)}
 
 
 @pytest.fixture(params=sorted(MODES), autouse=True)
 def kernel_mode(request, pkg):
-    force, lanes, kib, bpg, planes, chunk = MODES[request.param]
-    lib = pkg._capi.lib()
-    lib.dfm_plane_sweep_force_kernel(force)
-    pkg._capi.check(lib.dfm_plane_sweep_tune(lanes, kib, bpg, planes))
-    pkg._capi.check(lib.dfm_plane_sweep_schedule(chunk))
-    yield request.param
-    lib.dfm_plane_sweep_force_kernel(0)
-    pkg._capi.check(lib.dfm_plane_sweep_tune(256, 52, 1 << 20, 2))
-    pkg._capi.check(lib.dfm_plane_sweep_schedule(1))
+    sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+    with sweep.launch_options(**MODES[request.param]):
+        yield request.param
 
 
 def run_hip(pkg, cur, prev, depths, fsf, csf, P, T, img_shape, flip, crop, scale, dtype=torch.float32):
@@ -342,11 +344,44 @@ def test_autotune_keeps_results_exact(pkg, kernel_mode):
                                        torch.from_numpy(util.random_poses(B, seed=3)), B, dev)
     ref = sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T).clone()
     out = torch.empty_like(ref)
-    chosen = sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
-    assert chosen in (1, 15, 29)
-    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
-    again = sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T)
-    assert torch.equal(again.view(torch.int16), ref.view(torch.int16))
+    pkg._capi.lib().dfm_plane_sweep_reset_tuning()
+    assert sweep.plane_sweep_tuning(desc) is None
+    with sweep.launch_options():  # no per-call options: the tuned cache is what the launch uses
+        chosen = sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
+        assert chosen['bands_per_chunk'] in (1, 15, 29)
+        assert sweep.plane_sweep_tuning(desc) == chosen
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+        again = sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T)
+        assert torch.equal(again.view(torch.int16), ref.view(torch.int16))
+    pkg._capi.lib().dfm_plane_sweep_reset_tuning()
+
+
+def test_camera_matrices_on_device_match_host(pkg, kernel_mode):
+    """Device-resident intrinsics / poses (what the reference pipeline passes,
+    dfm_backbone.py:151-154) are padded, inverted and packed on the device with no host round
+    trip; the result agrees with the host path to fp32 inverse rounding."""
+    if kernel_mode != 'lds256_p2':
+        pytest.skip('runs once')
+    sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+    dev = torch.device('cuda:0')
+    B = 3
+    K = torch.from_numpy(np.stack([util.KITTI_P2] * B))
+    T = torch.from_numpy(util.random_poses(B, seed=7))
+    Ph, Pih, Th = sweep.camera_matrices(K, T, B, dev)
+    Pd, Pid, Td = sweep.camera_matrices(K.to(dev), T.to(dev), B, dev)
+    assert Pd.is_cuda and Pid.is_cuda and Pd.shape == (B, 16)
+    assert torch.equal(Pd, Ph) and torch.equal(Td, Th)
+    assert torch.allclose(Pid, Pih, rtol=1e-5, atol=1e-7)
+    # 3x4 and 3x3 intrinsics are padded like points_img2cam does (utils.py:239-240)
+    P34, _, _ = sweep.camera_matrices(K[:, :3].to(dev), T.to(dev), B, dev)
+    assert torch.equal(P34, Ph)
+    P33, _, _ = sweep.camera_matrices(K[:, :3, :3], T, B, dev)
+    ref33 = Ph.clone().view(B, 4, 4)
+    ref33[:, :3, 3] = 0
+    assert torch.equal(P33.view(B, 4, 4), ref33)
+    # a precomputed inverse is passed through untouched
+    _, Pi2, _ = sweep.camera_matrices(K.to(dev), T.to(dev), B, dev, cam2img_inv=Pih.view(B, 4, 4).cpu())
+    assert torch.equal(Pi2.view(-1), Pih.view(-1))
 
 
 def test_type_and_shape_errors(pkg):
