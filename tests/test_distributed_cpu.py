@@ -72,7 +72,8 @@ def _worker(rank, world, port, q, mode):
         info = (info, nb)
     t, every = par.gather_rank_times(1.0 + rank)
     flat = torch.cat([p.grad.reshape(-1) for p in params])
-    q.put((rank, (lo, hi), info, (t, every, par.max_over_ranks(1.0 + rank)), flat))
+    # plain bytes through the queue (a shared-memory tensor handle dies with this process)
+    q.put((rank, (lo, hi), info, (t, every, par.max_over_ranks(1.0 + rank)), flat.detach().numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,6 +86,7 @@ def _run(mode):
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    res = [r[:4] + (torch.from_numpy(r[4]),) for r in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
