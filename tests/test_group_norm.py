@@ -14,12 +14,29 @@ def pkg():
     return importlib.import_module('depth-from-motion_amd')
 
 
-def test_cpu_path_is_plain_groupnorm(pkg):
+def test_cpu_tensors_raise_unless_the_test_opt_in_is_set(pkg):
+    import importlib
+    gn = importlib.import_module('depth-from-motion_amd.group_norm')
     m = pkg.HipGroupNorm(4, 8)
     x = torch.randn(2, 8, 3, 5, 7)
-    assert torch.equal(m(x), F.group_norm(x, 4, m.weight, m.bias, m.eps))
-    assert torch.equal(m(x, relu=True), F.relu(F.group_norm(x, 4, m.weight, m.bias, m.eps)))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        m(x)
+    prev = gn.allow_cpu_reference(True)  # test-only: module wiring on a CPU-only box
+    try:
+        assert torch.equal(m(x), F.group_norm(x, 4, m.weight, m.bias, m.eps))
+        assert torch.equal(m(x, relu=True), F.relu(F.group_norm(x, 4, m.weight, m.bias, m.eps)))
+    finally:
+        gn.allow_cpu_reference(prev)
     assert list(m.state_dict()) == ['weight', 'bias']
+
+
+@pytest.mark.gpu
+def test_unsupported_gpu_inputs_raise(pkg):
+    m = pkg.HipGroupNorm(4, 8).cuda()
+    with pytest.raises(RuntimeError, match='unsupported GPU input'):
+        m(torch.randn(2, 8, 3, 5, 7, device='cuda').half())
+    with pytest.raises(RuntimeError, match='unsupported GPU input'):
+        pkg.HipGroupNorm(4, 8, affine=False).cuda()(torch.randn(2, 8, 3, 5, 7, device='cuda'))
 
 
 CASES = [(2, 32, (8, 12, 20), 32), (1, 32, (9, 7, 13), 32), (3, 16, (6, 10), 4), (1, 64, (18, 20, 40), 32),
