@@ -17,9 +17,13 @@ from .depth_head import depth_head_forward  # noqa: F401
 from .group_norm import HipGroupNorm, group_norm  # noqa: F401
 from .geometry import prepare_coordinates_3d, prepare_depth  # noqa: F401
 from .frustum_to_voxel import frustum_to_voxel_sample  # noqa: F401
+from .integration import (DfMStereoPath, MultiViewDfMMixin, MultiViewVoxelPath,  # noqa: F401
+                          inject_detector_attributes, patch_reference)
+from .depth_head import depth_distribution_loss  # noqa: F401
 from .point_sample import (mv_feature_transformation, point_sample, voxel_centers,  # noqa: F401
                            voxel_sample)
 
 __all__ = ['build_dfm_cost', 'plane_sweep_grid', 'point_sample', 'mv_feature_transformation',
            'voxel_centers', 'voxel_sample', 'frustum_to_voxel_sample', 'depth_head_forward', 'prepare_depth',
-           'prepare_coordinates_3d', 'group_norm', 'HipGroupNorm']
+           'prepare_coordinates_3d', 'group_norm', 'HipGroupNorm', 'DfMStereoPath', 'MultiViewDfMMixin',
+           'MultiViewVoxelPath', 'inject_detector_attributes', 'patch_reference', 'depth_distribution_loss']

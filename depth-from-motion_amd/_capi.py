@@ -18,6 +18,7 @@ EXPORTS = (
     'dfm_last_error',
     'dfm_profile_begin',
     'dfm_profile_end',
+    'dfm_camera_prepare',
     'dfm_plane_sweep_workspace_bytes',
     'dfm_plane_sweep_fwd',
     'dfm_plane_sweep_cl_workspace_bytes',
@@ -40,6 +41,8 @@ EXPORTS = (
     'dfm_point_sample_mv_bwd_workspace_bytes',
     'dfm_point_sample_mv_bwd',
     'dfm_depth_head_bwd',
+    'dfm_depth_loss_fwd',
+    'dfm_depth_loss_bwd',
     'dfm_voxel_sample_fwd',
     'dfm_group_norm_workspace_bytes',
     'dfm_group_norm_fwd',
@@ -125,6 +128,16 @@ class VsDesc(ctypes.Structure):
                 ('dtype', ctypes.c_int32)]
 
 
+class DepthLossDesc(ctypes.Structure):
+    """struct dfm_depth_loss_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in ('batch', 'num_depths', 'h', 'w', 'target', 'focal')] + \
+        [(n, ctypes.c_float) for n in ('min_depth', 'max_depth', 'interval', 'sigma', 'alpha', 'gamma')] + \
+        [('dtype', ctypes.c_int32)]
+
+
+DL_LINEAR, DL_HARD, DL_GAUSSIAN, DL_LAPLACIAN = 0, 1, 2, 3
+
+
 class DfmHipError(RuntimeError):
     pass
 
@@ -151,6 +164,8 @@ def lib():
     h.dfm_profile_begin.argtypes = [ctypes.c_int]
     h.dfm_profile_end.restype = ctypes.c_int
     h.dfm_profile_end.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    h.dfm_camera_prepare.restype = ctypes.c_int
+    h.dfm_camera_prepare.argtypes = [fp, i32, i32, i32, fp, fp, vp]
     h.dfm_plane_sweep_workspace_bytes.restype = sz
     h.dfm_plane_sweep_workspace_bytes.argtypes = [dp]
     h.dfm_plane_sweep_fwd.restype = ctypes.c_int
@@ -197,6 +212,11 @@ def lib():
     h.dfm_point_sample_mv_bwd_workspace_bytes.argtypes = [mp]
     h.dfm_depth_head_bwd.restype = ctypes.c_int
     h.dfm_depth_head_bwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, fp, vp]
+    lp = ctypes.POINTER(DepthLossDesc)
+    h.dfm_depth_loss_fwd.restype = ctypes.c_int
+    h.dfm_depth_loss_fwd.argtypes = [lp, vp, fp, fp, fp, vp, vp]
+    h.dfm_depth_loss_bwd.restype = ctypes.c_int
+    h.dfm_depth_loss_bwd.argtypes = [lp, vp, fp, fp, fp, vp, vp]
     h.dfm_voxel_sample_fwd.restype = ctypes.c_int
     h.dfm_voxel_sample_fwd.argtypes = [ctypes.POINTER(VsDesc), vp, fp, vp, vp]
     i64, f32 = ctypes.c_int64, ctypes.c_float

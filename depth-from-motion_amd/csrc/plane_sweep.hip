@@ -92,6 +92,10 @@ namespace {
 // ---------------------------------------------------------------------------
 // NCHW -> [B][nblk][H][W][CB]
 // ---------------------------------------------------------------------------
+// Each lane re-blocks PACK_PPL pixels (256 apart) so that PACK_PPL * CB independent loads are in
+// flight per lane: the kernel is latency-bound otherwise (channel planes of an odd-sized map are
+// only element-aligned, so a lane cannot load several pixels of one channel at once).
+constexpr int PACK_PPL = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__ src0,
                                                            const T *__restrict__ src1,
@@ -100,22 +104,29 @@ __global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__
                                                            int C, int HW, int nblk)
 {
     constexpr int CB = elem<T>::CB;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int pix0 = blockIdx.x * (256 * PACK_PPL) + threadIdx.x;
     const int blk = blockIdx.y;
     const bool second = (int)blockIdx.z >= batch;  // z = [cur samples | prev samples]
     const int b = second ? blockIdx.z - batch : blockIdx.z;
-    const T *__restrict__ src = second ? src1 : src0;
-    uint4 *__restrict__ dst = second ? dst1 : dst0;
-    if (pix >= HW) return;
-    T v[CB];
+    const T *__restrict__ src = (second ? src1 : src0) + ((size_t)b * C + (size_t)blk * CB) * HW;
+    uint4 *__restrict__ dst = (second ? dst1 : dst0) + ((size_t)b * nblk + blk) * HW;
+    T v[PACK_PPL][CB];
 #pragma unroll
-    for (int j = 0; j < CB; ++j) {
-        const int c = blk * CB + j;
-        v[j] = (c < C) ? src[((size_t)b * C + c) * HW + pix] : T(0);
+    for (int i = 0; i < PACK_PPL; ++i) {
+        const int pix = pix0 + i * 256;
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+            v[i][j] = (blk * CB + j < C && pix < HW) ? src[(size_t)j * HW + pix] : T(0);
     }
-    uint4 q;
-    memcpy(&q, v, 16);
-    dst[((size_t)b * nblk + blk) * HW + pix] = q;
+#pragma unroll
+    for (int i = 0; i < PACK_PPL; ++i) {
+        const int pix = pix0 + i * 256;
+        if (pix < HW) {
+            uint4 q;
+            memcpy(&q, v[i], 16);
+            dst[pix] = q;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1166,6 +1177,60 @@ __global__ __launch_bounds__(256) void sweep_grid_kernel(SweepGeom g, int b,
 }
 
 // ---------------------------------------------------------------------------
+// camera matrices on the device: pad cam2img to the 4x4 points_img2cam / points_cam2img build
+// (utils.py:199-203, 239-240) and invert it in fp32 (Gauss-Jordan with partial pivoting), one
+// lane per sample.  Replaces a host round trip per build_dfm_cost call when the intrinsics are
+// device tensors (dfm_backbone.py:151-154).
+// ---------------------------------------------------------------------------
+__global__ void camera_prepare_kernel(const float *__restrict__ cam2img, int rows, int cols,
+                                      int batch, float *__restrict__ P, float *__restrict__ Pinv)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    float m[4][8];
+    const float *src = cam2img + (size_t)b * rows * cols;
+    const int use_rows = rows == 4 ? 3 : rows;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = i == j ? 1.0f : 0.0f;
+            if (i < use_rows && j < cols) v = src[i * cols + j];
+            m[i][j] = v;
+            m[i][j + 4] = i == j ? 1.0f : 0.0f;
+            P[b * 16 + i * 4 + j] = v;
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        float best = fabsf(m[c][c]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r > c && fabsf(m[r][c]) > best) { best = fabsf(m[r][c]); piv = r; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r == piv && r != c) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float t = m[c][j]; m[c][j] = m[r][j]; m[r][j] = t; }
+            }
+        const float inv = 1.0f / m[c][c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[c][j] *= inv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r != c) {
+                const float f = m[r][c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[r][j] = m[r][j] - f * m[c][j];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Pinv[b * 16 + i * 4 + j] = m[i][j + 4];
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 int check_desc(const dfm_sweep_desc *d)
@@ -1268,9 +1333,9 @@ int resolve(const dfm_sweep_desc *d, const dfm_sweep_opts *o, Launch &L)
     if (L.lds_kib < 4 || L.lds_kib > 160 || L.bpg < 1 || L.planes < 1 || L.band_chunk < 1)
         return fail(DFM_ERR_INVALID_ARG,
                     "opts: 4 <= lds_kib <= 160, blocks_per_group / planes / bands_per_chunk >= 1%s");
-    if (L.ppl != CB && !(L.ppl == 4 && CB == 8 && (L.lanes == 512 || L.lanes == 1024)))
+    if (L.ppl != CB && !(L.ppl == 4 && CB == 8 && L.lanes >= 256))
         return fail(DFM_ERR_INVALID_ARG,
-                    "opts: points_per_lane is 16/sizeof(T), or 4 for bf16 with 512/1024 lanes%s");
+                    "opts: points_per_lane is 16/sizeof(T), or 4 for bf16 with >= 256 lanes%s");
     if (L.lanes == 1024 && L.ppl != 4)
         return fail(DFM_ERR_INVALID_ARG, "opts: 1024 lanes need points_per_lane = 4%s");
     return DFM_OK;
@@ -1340,7 +1405,7 @@ int launch_fwd(const dfm_sweep_desc *d, const Launch &L, const void *cur, const 
     const int HW = d->h_in * d->w_in;
     uint4 *cur_blk = (uint4 *)ws;
     uint4 *prev_blk = (uint4 *)((char *)ws + blocked_bytes(d));
-    dim3 pg((HW + 255) / 256, g.nblk, 2 * d->batch);
+    dim3 pg((HW + 256 * PACK_PPL - 1) / (256 * PACK_PPL), g.nblk, 2 * d->batch);
     hipLaunchKernelGGL(pack_blocked_kernel<T>, pg, dim3(256), 0, st, (const T *)cur, (const T *)prev,
                        cur_blk, prev_blk, d->batch, g.C, HW, g.nblk);
     constexpr int CB = elem<T>::CB;
@@ -1373,7 +1438,8 @@ int launch_fwd(const dfm_sweep_desc *d, const Launch &L, const void *cur, const 
             else if constexpr (CB == 4) DFM_TILES(1024, 4);
         } else {
             if constexpr (CB == 8) {
-                if (L.lanes == 512) DFM_TILES(512, 4);
+                if (L.lanes == 256) DFM_TILES(256, 4);
+                else if (L.lanes == 512) DFM_TILES(512, 4);
                 else DFM_TILES(1024, 4);
             }
         }
@@ -1496,6 +1562,18 @@ bool dfm::profile_mark(void *stream, bool stop)
 }
 
 extern "C" {
+
+DFM_API int dfm_camera_prepare(const float *cam2img, int32_t rows, int32_t cols, int32_t batch,
+                               float *cam2img_4x4, float *cam2img_inv, void *stream)
+{
+    if (!cam2img || !cam2img_4x4 || !cam2img_inv) return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
+    if ((rows != 3 && rows != 4) || (cols != 3 && cols != 4) || batch <= 0)
+        return fail(DFM_ERR_INVALID_ARG, "cam2img must be (B,3|4,3|4) with B >= 1%s");
+    hipLaunchKernelGGL(camera_prepare_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       cam2img, rows, cols, batch, cam2img_4x4, cam2img_inv);
+    HIP_TRY(hipGetLastError());
+    return DFM_OK;
+}
 
 DFM_API size_t dfm_plane_sweep_workspace_bytes(const dfm_sweep_desc *desc)
 {

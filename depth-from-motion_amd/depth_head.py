@@ -56,3 +56,79 @@ def depth_head_forward(stereo_features, depth_samples, downsample_factor=4):
     ds = depth_samples.to(device=x.device, dtype=torch.float32).contiguous()
     assert ds.numel() == s * x.shape[2]
     return _DepthHeadFn.apply(x, ds, s)
+
+
+# ---------------------------------------------------------------------------
+# DepthHead.loss (mmdet3d/models/dense_heads/depth_head.py:75-188)
+# ---------------------------------------------------------------------------
+class _DepthLossFn(torch.autograd.Function):
+    """per-pixel -sum_d p_d f(log_softmax_d) over the valid pixels (dfm_depth_loss_fwd/bwd)"""
+
+    @staticmethod
+    def forward(ctx, volumes, depth_img, ds, desc):
+        lib = _capi.lib()
+        device = volumes.device
+        B, D, H, W = volumes.shape
+        loss = torch.empty((B, H, W), dtype=torch.float32, device=device)
+        valid = torch.empty((B, H, W), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _capi.check(lib.dfm_depth_loss_fwd(ctypes.byref(desc), _ptr(volumes), _ptr(depth_img),
+                                               _ptr(ds), _ptr(loss), _ptr(valid), _stream_ptr(device)))
+        ctx.save_for_backward(volumes, depth_img, ds)
+        ctx.desc = desc
+        ctx.mark_non_differentiable(valid)
+        return loss, valid
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_valid):
+        volumes, depth_img, ds = ctx.saved_tensors
+        lib = _capi.lib()
+        device = volumes.device
+        g = g_loss.contiguous().float()
+        gv = torch.empty_like(volumes)
+        with torch.cuda.device(device):
+            _capi.check(lib.dfm_depth_loss_bwd(ctypes.byref(ctx.desc), _ptr(volumes), _ptr(depth_img),
+                                               _ptr(ds), _ptr(g), _ptr(gv), _stream_ptr(device)))
+        return gv, None, None, None
+
+
+def depth_distribution_loss(depth_volumes, depth_img, depth_samples, loss_type, min_depth, max_depth,
+                            alpha=1.0, gamma=2.0):
+    """Unreduced depth-distribution loss per pixel and the validity mask.
+
+    depth_volumes [B*N, D, H, W] logits, depth_img [B*N, H, W]; returns (pixel_loss [B*N,H,W]
+    fp32 -- 0 at invalid pixels --, valid [B*N,H,W] bool).  ``loss_type`` as in the reference
+    config: ce | balanced_ce | focal | balanced_focal | hard_ce | gaussian_<s> | laplacian_<s>.
+    """
+    _require_gpu(depth_volumes, 'depth_volumes')
+    if depth_volumes.dtype not in _DTYPES:
+        raise TypeError('depth_volumes must be float32 or bfloat16')
+    vol = depth_volumes.contiguous()
+    B, D, H, W = vol.shape
+    img = depth_img.to(device=vol.device, dtype=torch.float32).contiguous()
+    assert img.shape == (B, H, W), (img.shape, vol.shape)
+    ds = depth_samples.to(device=vol.device, dtype=torch.float32).contiguous()
+    assert ds.numel() == D
+    d = _capi.DepthLossDesc()
+    d.batch, d.num_depths, d.h, d.w = B, D, H, W
+    d.focal = 1 if loss_type in ('focal', 'balanced_focal') else 0
+    d.alpha, d.gamma = float(alpha), float(gamma)
+    d.min_depth, d.max_depth = float(min_depth), float(max_depth)
+    d.sigma = 0.0
+    if loss_type in ('ce', 'balanced_ce', 'focal', 'balanced_focal'):
+        d.target = _capi.DL_LINEAR
+    elif loss_type == 'hard_ce':
+        d.target = _capi.DL_HARD
+    elif loss_type.startswith('gaussian'):
+        d.target, d.sigma = _capi.DL_GAUSSIAN, float(loss_type.split('_')[1])
+    elif loss_type.startswith('laplacian'):
+        d.target, d.sigma = _capi.DL_LAPLACIAN, float(loss_type.split('_')[1])
+    else:
+        raise NotImplementedError(loss_type)
+    # depth_interval = depth_samples[1] - depth_samples[0] in fp32 (depth_head.py:95); taken from
+    # the host copy of two scalars, not a device sync on the hot tensor
+    two = depth_samples[:2].detach().to('cpu', torch.float32)
+    d.interval = float(two[1] - two[0])
+    d.dtype = _DTYPES[vol.dtype]
+    loss, valid = _DepthLossFn.apply(vol, img, ds, d)
+    return loss, valid.bool()

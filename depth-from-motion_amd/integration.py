@@ -1,0 +1,226 @@
+"""Detector-level drop-in of the hot path.
+
+The reference's detectors wire the path's modules together and inject attributes into them:
+
+  DfM.__init__                mmdet3d/models/detectors/dfm.py:30-112 (attribute injection :82-100)
+  DfM.extract_feat / forward  dfm.py:268-356
+  MultiViewDfM.feature_transformation   mmdet3d/models/detectors/multiview_dfm.py:119-268
+
+Three ways to use this package from there, all routed to the HIP kernels:
+
+1. ``patch_reference()`` -- inside a real mmdet3d installation: re-registers the module
+   classes (``DfMBackbone``, ``FrustumToVoxel``, ``DepthHead``, ``OutdoorImVoxelNeck``,
+   ``DfMNeck``, ``BEVHourglass``, ``SPPUNetNeck``) under the same ``type`` names (force=True) so
+   ``configs/dfm/*`` build them unchanged, rebinds the functions the reference modules call
+   (``build_dfm_cost``, ``point_sample``, ``voxel_sample``) and replaces
+   ``MultiViewDfM.feature_transformation`` by ``MultiViewDfMMixin.feature_transformation``.
+2. ``DfMStereoPath`` -- the KITTI student's path (neck -> backbone_stereo -> depth_head ->
+   feature_transformation -> height compression -> backbone_3d) built from the ``model`` dict of
+   ``configs/dfm/dfm_r34_1x8_kitti-3d-3class.py`` with the detector's attribute injection;
+   usable without mmdet3d (this is what the tests and tools run).
+3. ``MultiViewDfMMixin`` -- for a subclass ``class MultiViewDfM(MultiViewDfMMixin, RefMultiViewDfM)``.
+"""
+import importlib
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import registry
+from .geometry import prepare_coordinates_3d, prepare_depth
+from .plane_sweep import build_dfm_cost
+from .point_sample import mv_feature_transformation, point_sample, voxel_centers, voxel_sample
+
+
+def inject_detector_attributes(detector, depth_cfg=None, voxel_cfg=None):
+    """What DfM.__init__ writes onto its sub-modules after building them (dfm.py:82-100):
+    ``backbone_stereo.downsampled_depth``, ``depth_head.depth_samples`` / ``.downsample_factor``,
+    ``feature_transformation.depth_cfg`` / ``.coordinates_3d``.  ``detector`` is any object with
+    those sub-modules as attributes (missing ones are skipped)."""
+    if depth_cfg is not None:
+        ds_factor = depth_cfg['downsample_factor']
+        downsampled, depth = prepare_depth(depth_cfg)
+        detector.downsampled_depth, detector.depth = downsampled, depth
+        detector.depth_downsample_factor = ds_factor
+        ft = getattr(detector, 'feature_transformation', None)
+        if ft is not None:
+            ft.depth_cfg = depth_cfg
+        if getattr(detector, 'depth_head', None) is not None:
+            detector.backbone_stereo.downsampled_depth = downsampled
+            detector.depth_head.depth_samples = depth
+            detector.depth_head.downsample_factor = ds_factor
+    if voxel_cfg is not None:
+        coords = prepare_coordinates_3d(voxel_cfg)
+        detector.coordinates_3d = coords
+        ft = getattr(detector, 'feature_transformation', None)
+        if ft is not None:
+            ft.coordinates_3d = coords
+    return detector
+
+
+class DfMStereoPath(nn.Module):
+    """The plane-sweep path of the ``DfM`` detector, built from its config ``model`` dict.
+
+    ``forward(cur_feats, prev_feats, img_metas)`` takes the two image pyramids
+    ``[img, *backbone(img)]`` (what dfm.py:281-284 hands to the neck) and returns what
+    ``DfM.forward_train`` computes up to the detection head (dfm.py:268-322):
+    ``dict(mono_stereo_costs, stereo_feats, mono_feats, upsample_costs, upsample_costs_softmax,
+    depth_preds, volume_feat, bev_feat_prehg, bev_feat)``.  ``loss_dense_depth(out, depth_img,
+    depth_fgmask_img)`` is dfm.py:348-356.
+    """
+
+    def __init__(self, model_cfg):
+        super().__init__()
+        cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in model_cfg.items()}
+        depth_cfg, voxel_cfg = cfg.get('depth_cfg'), cfg.get('voxel_cfg')
+        self.neck = registry.build_neck(cfg['neck'])
+        bs = cfg['backbone_stereo']
+        if depth_cfg is not None:
+            bs.update(depth_cfg=depth_cfg)                       # dfm.py:45-47
+        self.backbone_stereo = registry.build_backbone(bs)
+        ft = cfg.get('feature_transformation')
+        if ft is not None:
+            ft.update(cat_img_feature=self.neck.cat_img_feature,     # dfm.py:56-64
+                      in_sem_channels=self.neck.sem_channels[-1])
+            self.feature_transformation = registry.build_neck(ft)
+        self.depth_head = registry.build_head(cfg['depth_head']) if cfg.get('depth_head') else None
+        self.backbone_3d = registry.build_backbone(cfg['backbone_3d']) if cfg.get('backbone_3d') else None
+        inject_detector_attributes(self, depth_cfg, voxel_cfg)
+
+    def forward(self, cur_feats, prev_feats, img_metas):
+        cur_stereo, cur_sem = self.neck(cur_feats)
+        prev_stereo, _ = self.neck(prev_feats)
+        dev = cur_stereo.device
+        for meta in img_metas:  # dfm.py:288-293: (N-1,4,4) tensors on the device
+            meta['cur2prevs'] = torch.as_tensor(np.asarray(meta['cur2prevs'], dtype=np.float32)
+                                                if not torch.is_tensor(meta['cur2prevs'])
+                                                else meta['cur2prevs'], dtype=torch.float32).to(dev)
+        costs, stereo_feats, mono_feats = self.backbone_stereo(cur_stereo, prev_stereo, img_metas)
+        out = dict(mono_stereo_costs=costs, stereo_feats=stereo_feats, mono_feats=mono_feats,
+                   cur_sem_feat=cur_sem)
+        if self.depth_head is not None:
+            up, soft, preds = self.depth_head(costs)
+            out.update(upsample_costs=up, upsample_costs_softmax=soft, depth_preds=preds)
+            if hasattr(self, 'feature_transformation'):
+                vol = self.feature_transformation(stereo_feats, soft, img_metas, cur_sem)
+                out['volume_feat'] = vol
+                if self.backbone_3d is not None:
+                    _, cv, nz, ny, nx = vol.shape
+                    out['bev_feat_prehg'], out['bev_feat'] = self.backbone_3d(vol.view(-1, cv * nz, ny, nx))
+        return out
+
+    def loss_dense_depth(self, out, depth_img, depth_fgmask_img=None):
+        if depth_fgmask_img is not None:
+            depth_fgmask_img = depth_fgmask_img.flatten(start_dim=0, end_dim=1)
+        return self.depth_head.loss(out['depth_preds'].flatten(start_dim=0, end_dim=1),
+                                    out['upsample_costs'].flatten(start_dim=0, end_dim=1),
+                                    depth_img.flatten(start_dim=0, end_dim=1),
+                                    depth_fgmask_img=depth_fgmask_img)
+
+
+class MultiViewDfMMixin:
+    """``feature_transformation`` of ``MultiViewDfM`` (multiview_dfm.py:119-268) on the HIP path:
+    one launch per batch lifts all (frame, view) feature maps into the voxel volume (sampling,
+    valid-count reduction over views and frames, permute), then ``backbone_3d`` / ``neck_3d`` /
+    the optional ``voxel_sample`` for the depth head run as in the reference.  The host class
+    provides n_voxels, voxel_range, voxel_size, valid_sample, temporal_aggregate,
+    transform_depth and the usual with_* properties."""
+
+    def feature_transformation(self, batch_feats, img_metas, num_views, num_frames):
+        volume_feat = mv_feature_transformation(batch_feats, img_metas, num_views, num_frames,
+                                                self.voxel_range, self.n_voxels,
+                                                self.temporal_aggregate,
+                                                valid_sample=getattr(self, 'valid_sample', True))
+        if getattr(self, 'with_backbone_3d', False):
+            outputs = self.backbone_3d(volume_feat)
+            volume_feat = outputs[0]
+            if self.backbone_3d.output_bev:
+                bev_feat = outputs[-1]
+        batch_stereo_feats = None
+        if getattr(self, 'with_depth_head', False):
+            feats = []
+            for b, meta in enumerate(img_metas):
+                for v in range(num_views):
+                    td = self.transform_depth
+                    sf = meta.get('scale_factor', 1.0) if td else 1.0
+                    feats.append(voxel_sample(
+                        volume_feat[b][None], voxel_range=self.voxel_range, voxel_size=self.voxel_size,
+                        depth_samples=torch.as_tensor(self.depth_samples, dtype=torch.float32),
+                        proj_mat=torch.as_tensor(np.asarray(meta['ori_lidar2img'][v], np.float32)),
+                        downsample_factor=self.depth_head.downsample_factor, img_scale_factor=sf,
+                        img_crop_offset=meta.get('img_crop_offset', 0) if td else 0,
+                        img_flip=meta.get('flip', False) if td else False,
+                        img_pad_shape=meta['input_shape'] if td else meta['ori_shape'][:2],
+                        img_shape=meta['img_shape'][v][:2], aligned=True))
+            batch_stereo_feats = torch.cat(feats)
+        if getattr(self, 'with_neck_3d', False):
+            if getattr(self, 'with_backbone_3d', False) and self.backbone_3d.output_bev:
+                volume_feat = self.neck_3d(bev_feat)[1]
+            else:
+                volume_feat = self.neck_3d(volume_feat)[0]
+        out = (volume_feat, )
+        if batch_stereo_feats is not None:
+            out += (batch_stereo_feats, )
+        return out
+
+
+class MultiViewVoxelPath(MultiViewDfMMixin, nn.Module):
+    """The multi-view path of ``MultiViewDfM`` from its config ``model`` dict (neck_3d,
+    voxel_size, anchor_generator.ranges, temporal_aggregate), without mmdet3d: voxel lifting +
+    the 3-D neck.  ``forward(batch_feats (B, Nv*F, C, Hf, Wf), img_metas, num_views, num_frames)``
+    -> BEV feature (B, C_out, Ny, Nx)."""
+
+    def __init__(self, model_cfg):
+        super().__init__()
+        self.voxel_size = list(model_cfg['voxel_size'])
+        self.voxel_range = list(model_cfg['anchor_generator']['ranges'][0])
+        self.n_voxels = [round((self.voxel_range[3 + i] - self.voxel_range[i]) / self.voxel_size[i])
+                         for i in range(3)]                      # multiview_dfm.py:54-61
+        self.valid_sample = model_cfg.get('valid_sample', True)
+        self.temporal_aggregate = model_cfg.get('temporal_aggregate', 'mean')
+        self.transform_depth = model_cfg.get('transform_depth', True)
+        self.neck_3d = registry.build_neck(dict(model_cfg['neck_3d']))
+        self.with_neck_3d, self.with_backbone_3d, self.with_depth_head = True, False, False
+
+    def forward(self, batch_feats, img_metas, num_views, num_frames):
+        return self.feature_transformation(batch_feats, img_metas, num_views, num_frames)[0]
+
+
+# the functions the reference's modules look up by name, and the files that define them
+_FUNCTION_PATCHES = (
+    ('mmdet3d.models.backbones.dfm_backbone', 'build_dfm_cost', build_dfm_cost),
+    ('mmdet3d.models.fusion_layers.point_fusion', 'point_sample', point_sample),
+    ('mmdet3d.models.fusion_layers.point_fusion', 'voxel_sample', voxel_sample),
+    ('mmdet3d.models.fusion_layers', 'point_sample', point_sample),
+    ('mmdet3d.models.fusion_layers', 'voxel_sample', voxel_sample),
+    ('mmdet3d.models.detectors.multiview_dfm', 'point_sample', point_sample),
+    ('mmdet3d.models.detectors.multiview_dfm', 'voxel_sample', voxel_sample),
+    ('mmdet3d.models.detectors.imvoxelnet', 'point_sample', point_sample),
+)
+
+
+def patch_reference():
+    """Route a real mmdet3d (the reference fork) to the HIP path.  Call once after
+    ``import mmdet3d`` and before building the model from ``configs/dfm/*``.  Returns a report
+    dict {'modules': [...], 'functions': [...], 'methods': [...]}.  Raises ImportError when
+    mmdet3d is not importable (this package never needs it otherwise)."""
+    report = {'modules': registry.register_into_mmdet3d(), 'functions': [], 'methods': []}
+    for mod_name, attr, fn in _FUNCTION_PATCHES:
+        try:
+            mod = importlib.import_module(mod_name)
+        except ImportError:
+            continue
+        if hasattr(mod, attr):
+            setattr(mod, attr, fn)
+            report['functions'].append(f'{mod_name}.{attr}')
+    try:
+        det = importlib.import_module('mmdet3d.models.detectors.multiview_dfm')
+        det.MultiViewDfM.feature_transformation = MultiViewDfMMixin.feature_transformation
+        report['methods'].append('MultiViewDfM.feature_transformation')
+    except (ImportError, AttributeError):
+        pass
+    return report
+
+
+__all__ = ['inject_detector_attributes', 'DfMStereoPath', 'MultiViewDfMMixin', 'MultiViewVoxelPath',
+           'patch_reference', 'voxel_centers']

@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .depth_head import depth_head_forward
+from .depth_head import depth_distribution_loss, depth_head_forward
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .group_norm import HipGroupNorm
 from .plane_sweep import build_dfm_cost
@@ -218,6 +218,14 @@ class DepthHead(nn.Module):
         self.downsample_factor = downsample_factor
         self.num_views = num_views
         self.norm_cfg = norm_cfg
+        self.depth_loss_type = depth_loss['type']
+        if self.depth_loss_type in ('balanced_ce', 'balanced_focal'):
+            self.fg_weight = depth_loss['fg_weight']
+            self.bg_weight = depth_loss['bg_weight']
+        if self.depth_loss_type in ('focal', 'balanced_focal'):
+            self.alpha = depth_loss['alpha']
+            self.gamma = depth_loss['gamma']
+        self.loss_weight = depth_loss['loss_weight']
         self.min_depth = depth_cfg['min_depth']
         self.max_depth = depth_cfg['max_depth']
         if with_convs:
@@ -239,8 +247,37 @@ class DepthHead(nn.Module):
                     pred.view(B, V, s * H, s * W))
         return depth_head_forward(x, self.depth_samples, self.downsample_factor)
 
-    def loss(self, *args, **kwargs):
-        raise NotImplementedError('DepthHead.loss is outside the plane-sweep hot path (SURVEY 8a)')
+    def loss(self, depth_preds, depth_volumes, depth_img, depth_fgmask_img=None):
+        """depth_head.py:75-188.  depth_preds [B*N,H,W], depth_volumes [B*N,D,H,W],
+        depth_img [B*N,H,W]; depth_fgmask_img: fg mask with box ids (balanced_* losses).
+
+        The distribution losses run in one HIP kernel over the volume in place (no
+        (n_valid, D) gather copy, no log_softmax tensor); only the (B*N,H,W)-sized reductions
+        are torch ops.  Quirk kept: the result is scaled by loss_weight TWICE (:186)."""
+        loss_type = self.depth_loss_type
+        mask = (depth_img > self.min_depth) & (depth_img < self.max_depth)
+        n_valid = mask.sum()
+        if loss_type in ('l1', 'purel1'):
+            if int(n_valid) == 0:
+                print('no gt warning')
+                return depth_preds.mean() * 0.0
+            fn = F.smooth_l1_loss if loss_type == 'l1' else F.l1_loss
+            loss = fn(depth_preds[mask], depth_img[mask], reduction='none').mean()
+            return self.loss_weight * self.loss_weight * loss
+        pix, valid = depth_distribution_loss(
+            depth_volumes, depth_img, self.depth_samples, loss_type, self.min_depth, self.max_depth,
+            getattr(self, 'alpha', 1.0), getattr(self, 'gamma', 2.0))
+        n = valid.sum()
+        if int(n) == 0:
+            print('no gt warning')
+            return depth_preds.mean() * 0.0
+        if loss_type in ('balanced_ce', 'balanced_focal'):
+            fg = depth_fgmask_img.bool() & valid
+            bg = valid & ~fg
+            loss = (self.fg_weight * (pix * fg).sum() + self.bg_weight * (pix * bg).sum()) / n
+        else:
+            loss = pix.sum() / n
+        return self.loss_weight * self.loss_weight * loss
 
 
 # --------------------------------------------------------------------------
@@ -356,3 +393,150 @@ class DfMNeck(nn.Module):
 
     def init_weights(self):
         pass
+
+
+# --------------------------------------------------------------------------
+# producers / consumers either side of the path: ordinary 2-D conv
+# stacks with the reference's constructor arguments and state_dict keys.  GroupNorm runs in
+# the fused HIP kernel; the 2-D convolutions are MIOpen through torch.
+#   convbn / upconv_module   mmdet3d/models/utils/conv_modules.py:6-24,46-70
+#   hourglass2d, BEVHourglass mmdet3d/models/backbones/bev_hourglass.py
+#   SPPUNetNeck              mmdet3d/models/necks/spp_unet_neck.py
+# --------------------------------------------------------------------------
+def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation=1, gn=False, groups=32):
+    return nn.Sequential(
+        nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
+                  padding=dilation if dilation > 1 else pad, dilation=dilation, bias=False),
+        nn.SyncBatchNorm(out_planes) if not gn else HipGroupNorm(groups, out_planes))
+
+
+class upconv_module(nn.Module):  # noqa: N801  (reference class name)
+
+    def __init__(self, in_channels, up_channels):
+        super().__init__()
+        self.num_stage = len(in_channels) - 1
+        self.conv = nn.ModuleList(
+            convbn(in_channels[0] if i == 0 else up_channels[i - 1], up_channels[i], 3, 1, 1, 1)
+            for i in range(self.num_stage))
+        self.redir = nn.ModuleList(
+            convbn(in_channels[i + 1], up_channels[i], 3, 1, 1, 1) for i in range(self.num_stage))
+        self.up = nn.Upsample(scale_factor=2, mode='bilinear')
+
+    def forward(self, feats):
+        x = feats[0]
+        for i in range(self.num_stage):
+            x = F.relu(self.up(self.conv[i](x)) + self.redir[i](feats[i + 1]))
+        return x
+
+
+def _gn_relu(seq, x, relu):
+    """conv -> norm(+ReLU fused when the norm is the HIP GroupNorm)"""
+    x = seq[0](x)
+    if isinstance(seq[1], HipGroupNorm):
+        return seq[1](x, relu=relu)
+    x = seq[1](x)
+    return F.relu(x) if relu else x
+
+
+class hourglass2d(nn.Module):  # noqa: N801  (reference class name)
+
+    def __init__(self, inplanes, gn=False):
+        super().__init__()
+        c = inplanes
+        self.conv1 = nn.Sequential(convbn(c, 2 * c, 3, 2, 1, 1, gn=gn), nn.ReLU(inplace=True))
+        self.conv2 = convbn(2 * c, 2 * c, 3, 1, 1, 1, gn=gn)
+        self.conv3 = nn.Sequential(convbn(2 * c, 2 * c, 3, 2, 1, 1, gn=gn), nn.ReLU(inplace=True))
+        self.conv4 = nn.Sequential(convbn(2 * c, 2 * c, 3, 1, 1, 1, gn=gn), nn.ReLU(inplace=True))
+
+        def up(cin, cout):
+            return nn.Sequential(
+                nn.ConvTranspose2d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False),
+                nn.SyncBatchNorm(cout) if not gn else HipGroupNorm(32, cout))
+        self.conv5 = up(2 * c, 2 * c)
+        self.conv6 = up(2 * c, c)
+
+    def forward(self, x, presqu, postsqu):
+        out = _gn_relu(self.conv1[0], x, True)
+        pre = _gn_relu(self.conv2, out, False)
+        pre = F.relu(pre if postsqu is None else pre + postsqu)
+        out = _gn_relu(self.conv4[0], _gn_relu(self.conv3[0], pre, True), True)
+        post = F.relu(self.conv5(out) + (pre if presqu is None else presqu))
+        return self.conv6(post), pre, post
+
+
+@register_module
+class BEVHourglass(nn.Module):
+
+    def __init__(self, in_channels, out_channels, norm_cfg=None, output_prehg_feat=True,
+                 init_cfg=None):
+        super().__init__()
+        self.out_channels = out_channels
+        self.norm_cfg = norm_cfg
+        self.output_prehg_feat = output_prehg_feat
+        self.compress_conv = ConvModule(in_channels, out_channels, 3, stride=1, padding=1,
+                                        norm_cfg=norm_cfg)
+        self.bev_hourglass = hourglass2d(out_channels, gn=(norm_cfg['type'] == 'GN'))
+        self.num_bev_features = out_channels
+
+    def init_weights(self):
+        pass
+
+    def forward(self, spatial_features):
+        prehg = self.compress_conv(spatial_features)
+        x = self.bev_hourglass(prehg, None, None)[0]
+        return (prehg, x) if self.output_prehg_feat else x
+
+
+@register_module
+class SPPUNetNeck(nn.Module):
+
+    def __init__(self, in_channels, start_level, sem_channels=[128, 32], stereo_channels=[32, 32],
+                 spp_channel=32, with_upconv=True, cat_img_feature=True, norm_cfg=None,
+                 init_cfg=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.start_level = start_level
+        self.sem_channels = sem_channels
+        self.stereo_channels = stereo_channels
+        self.spp_channel = spp_channel
+        self.with_upconv = with_upconv
+        self.cat_img_feature = cat_img_feature
+        self.spp_branches = nn.ModuleList(
+            nn.Sequential(nn.AvgPool2d(s, stride=s),
+                          ConvModule(in_channels[-1], spp_channel, 1, stride=1, padding=0,
+                                     norm_cfg=norm_cfg))
+            for s in [(64, 64), (32, 32), (16, 16), (8, 8)])
+        concat_channel = spp_channel * len(self.spp_branches) + sum(in_channels[start_level:])
+        if with_upconv:
+            assert start_level == 2
+            self.upconv_module = upconv_module([concat_channel, in_channels[1], in_channels[0]],
+                                               [64, 32])
+            stereo_channel = 32
+        else:
+            stereo_channel = concat_channel
+            assert start_level >= 1
+        self.lastconv = nn.Sequential(
+            ConvModule(stereo_channel, stereo_channels[0], 3, stride=1, padding=1, norm_cfg=norm_cfg),
+            nn.Conv2d(stereo_channels[0], stereo_channels[1], kernel_size=1, padding=0, stride=1,
+                      bias=False))
+        if cat_img_feature:
+            self.rpnconv = nn.Sequential(
+                ConvModule(concat_channel, sem_channels[0], 3, stride=1, padding=1, norm_cfg=norm_cfg),
+                ConvModule(sem_channels[0], sem_channels[1], 3, stride=1, padding=1,
+                           norm_cfg=norm_cfg))
+
+    def init_weights(self):
+        pass
+
+    def forward(self, feats):
+        feat_shape = tuple(feats[self.start_level].shape[2:])
+        assert len(feats) == len(self.in_channels)
+        spp = [F.interpolate(branch(feats[-1]), feat_shape, mode='bilinear', align_corners=True)
+               for branch in self.spp_branches]
+        concat_feature = torch.cat((*feats[self.start_level:], *spp), 1)
+        stereo_feature = concat_feature
+        if self.with_upconv:
+            stereo_feature = self.upconv_module([stereo_feature, feats[1], feats[0]])
+        stereo_feature = self.lastconv(stereo_feature)
+        sem_feature = self.rpnconv(concat_feature) if self.cat_img_feature else None
+        return stereo_feature, sem_feature

@@ -41,8 +41,8 @@ def camera_matrices(cam2imgs, cur2prevs, batch_size, device, cam2img_inv=None):
     """(B,16) fp32 device tensors: padded cam2img, its fp32 inverse, cur2prev.
 
     Inputs that already live on ``device`` (the reference pipeline hands device tensors,
-    dfm_backbone.py:151-154) never leave it: padding, ``torch.linalg.inv`` (batched, fp32) and
-    the packing run on the device, with no host round trip or stream synchronisation.  Host
+    dfm_backbone.py:151-154) never leave it: ``dfm_camera_prepare`` pads and inverts them in one
+    small kernel on the current stream, with no host round trip or synchronisation.  Host
     inputs (lists / numpy / CPU tensors, what ``img_metas`` carries) are inverted on the host
     with ``torch.inverse`` in fp32 -- exactly the op the reference's PyTorch-CPU path runs
     (utils.py:241), which is what the bit-exact parity tests replay -- and uploaded once.
@@ -57,20 +57,26 @@ def camera_matrices(cam2imgs, cur2prevs, batch_size, device, cam2img_inv=None):
         return torch.as_tensor(x).detach().to(torch.float32)
 
     cam2imgs, cur2prevs = as_f32(cam2imgs), as_f32(cur2prevs)
-    on_device = cam2imgs.device == device
-    P = _pad4x4_batch(cam2imgs, batch_size)
+    if cam2imgs.device == device and device.type == 'cuda':
+        # device-resident: one small kernel pads + inverts, nothing touches the host
+        lib = _capi.lib()
+        k = cam2imgs[:batch_size].contiguous()
+        P = torch.empty((batch_size, 16), dtype=torch.float32, device=device)
+        Pinv = torch.empty_like(P)
+        with torch.cuda.device(device):
+            _capi.check(lib.dfm_camera_prepare(_ptr(k), k.shape[-2], k.shape[-1], batch_size, _ptr(P),
+                                               _ptr(Pinv), _stream_ptr(device)))
+        if cam2img_inv is not None:
+            Pinv = as_f32(cam2img_inv)[:batch_size].to(device).reshape(batch_size, 16).contiguous()
+        T = cur2prevs[:batch_size].to(device).reshape(batch_size, 16).contiguous()
+        return P, Pinv, T
+    P = _pad4x4_batch(cam2imgs.cpu(), batch_size)
     if cam2img_inv is not None:
-        Pinv = as_f32(cam2img_inv)[:batch_size].to(P.device)
-    elif on_device:
-        Pinv = torch.linalg.inv(P)
+        Pinv = as_f32(cam2img_inv)[:batch_size].cpu()
     else:
         Pinv = torch.stack([torch.inverse(P[i]) for i in range(batch_size)])
-    T = cur2prevs[:batch_size]
-    if on_device:
-        T = T.to(device)
-        return (P.reshape(batch_size, 16).contiguous(), Pinv.reshape(batch_size, 16).contiguous(),
-                T.reshape(batch_size, 16).contiguous())
-    pack = torch.stack([P.cpu(), Pinv.cpu(), T.cpu()]).reshape(3, batch_size, 16).contiguous()
+    T = cur2prevs[:batch_size].cpu()
+    pack = torch.stack([P, Pinv, T]).reshape(3, batch_size, 16).contiguous()
     pack = pack.to(device, non_blocking=True)
     return pack[0], pack[1], pack[2]
 

@@ -156,7 +156,7 @@ def point_sample(img_meta,
 
 
 def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, voxel_range, n_voxels,
-                              temporal_aggregate='mean', points=None):
+                              temporal_aggregate='mean', points=None, valid_sample=True):
     """(B, F*Nv, C, Hf, Wf) view features -> (B, C or C*F, Nx, Ny, Nz) voxel volume,
     the tensor the reference hands to ``neck_3d`` (multiview_dfm.py:206-209)."""
     _require_gpu(batch_feats, 'batch_feats')
@@ -179,7 +179,8 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
         proj.append(np.asarray(img_meta['ori_lidar2img'][:nvf], dtype=np.float32).reshape(nvf, 16))
         ori_w.append([float(img_meta['img_shape'][i][1]) for i in range(nvf)])
         descs.append(_make_desc(feats, points.shape[0], nxyz, num_views, num_frames, scale, crop,
-                                flip, img_meta['input_shape'], False, temporal_aggregate, True))
+                                flip, img_meta['input_shape'], False, temporal_aggregate,
+                                valid_sample))
     # one upload for the whole batch's matrices
     proj = torch.from_numpy(np.stack(proj)).to(device)
     ori_w = torch.tensor(ori_w, dtype=torch.float32).to(device)

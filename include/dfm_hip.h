@@ -93,6 +93,16 @@ typedef struct dfm_sweep_desc {
     int32_t dtype;        /* dfm_dtype of cur/prev/out                     */
 } dfm_sweep_desc;
 
+/* Camera matrices on the device (no host round trip when the intrinsics are device tensors,
+ * dfm_backbone.py:151-154): pads cam2img (B, rows, cols; rows, cols in {3,4}; row-major) to the
+ * 4x4 that points_img2cam / points_cam2img build (rows :3 of a 4-row matrix, identity elsewhere;
+ * utils.py:199-203, 239-240) and inverts it in fp32 (Gauss-Jordan, partial pivoting).
+ * cam2img_4x4, cam2img_inv : (B, 16) fp32 -- the cam2img / cam2img_inv arguments below.
+ * The inverse agrees with torch.inverse to fp32 rounding, not bit for bit (neither do two
+ * LAPACK builds); callers that replay the reference's CPU result bit-exactly pass that inverse. */
+DFM_API int dfm_camera_prepare(const float *cam2img, int32_t rows, int32_t cols, int32_t batch,
+                               float *cam2img_4x4, float *cam2img_inv, void *stream);
+
 /* Scratch the call needs (blocked copy of the two feature maps). */
 DFM_API size_t dfm_plane_sweep_workspace_bytes(const dfm_sweep_desc *desc);
 
@@ -373,6 +383,48 @@ DFM_API int dfm_depth_head_bwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
                                int32_t dtype, const void *cost, const float *depth_samples,
                                const void *grad_volumes, const void *grad_softmax,
                                const void *grad_preds, float *grad_cost, void *stream);
+
+/* ---------------------------------------------------------------------- */
+/* DepthHead.loss, dense_heads/depth_head.py:75-188 (called at dfm.py:348) */
+/* ---------------------------------------------------------------------- */
+typedef enum dfm_depth_loss_target {
+    DFM_DL_LINEAR = 0,    /* ce, balanced_ce, focal, balanced_focal: 1 - min(|ds-gt|/interval, 1) */
+    DFM_DL_HARD = 1,      /* hard_ce: the above thresholded at 0.5                               */
+    DFM_DL_GAUSSIAN = 2,  /* gaussian_<sigma>: exp(-0.5 dist^2/sigma^2) / max(sum, 1)             */
+    DFM_DL_LAPLACIAN = 3  /* laplacian_<sigma>: exp(-dist/sigma) / max(sum, 1)                    */
+} dfm_depth_loss_target;
+
+typedef struct dfm_depth_loss_desc {
+    int32_t batch;       /* B*N images                                          */
+    int32_t num_depths;  /* D bins of depth_volumes                             */
+    int32_t h, w;
+    int32_t target;      /* dfm_depth_loss_target                               */
+    int32_t focal;       /* != 0: weight every bin by alpha*(1-p)^gamma (depth_head.py:131-139) */
+    float min_depth, max_depth; /* valid gt: min_depth < gt < max_depth (:89)    */
+    float interval;      /* depth_samples[1] - depth_samples[0] (:95)            */
+    float sigma;         /* gaussian / laplacian                                 */
+    float alpha, gamma;  /* focal                                                */
+    int32_t dtype;       /* dfm_dtype of depth_volumes / grad_volumes            */
+} dfm_depth_loss_desc;
+
+/*
+ * depth_volumes : (B, D, h, w) logits, dtype                          [device]
+ * depth_img     : (B, h, w) fp32 ground-truth depth                   [device]
+ * depth_samples : (D) fp32 bin centres                                [device]
+ * pixel_loss    : (B, h, w) fp32: -sum_d p_d f(log_softmax_d) per valid pixel, 0 elsewhere --
+ *                 the reference's `loss` before `.mean()` / the fg-bg weighted sum
+ * valid         : (B, h, w) uint8: the reference's `mask`
+ * The caller reduces: mean over valid pixels (ce, focal, hard_ce, gaussian, laplacian) or
+ * (fg_weight*sum_fg + bg_weight*sum_bg)/n_valid (balanced_*), times loss_weight^2 (:186).
+ */
+DFM_API int dfm_depth_loss_fwd(const dfm_depth_loss_desc *desc, const void *depth_volumes,
+                               const float *depth_img, const float *depth_samples,
+                               float *pixel_loss, unsigned char *valid, void *stream);
+/* grad_volumes (B, D, h, w) dtype = grad_pixel_loss[b,h,w] * d pixel_loss / d depth_volumes;
+ * written for every element (zeros at invalid pixels). */
+DFM_API int dfm_depth_loss_bwd(const dfm_depth_loss_desc *desc, const void *depth_volumes,
+                               const float *depth_img, const float *depth_samples,
+                               const float *grad_pixel_loss, void *grad_volumes, void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* fused GroupNorm (+ReLU) of the aggregation stacks                        */

@@ -1,0 +1,238 @@
+"""Round-2 golden fixtures, produced by running the REFERENCE's own code on PyTorch-CPU.
+
+Build container only (needs /root/reference):   python tests/golden/make_golden_r02.py
+Same rules as make_golden.py: reference files are executed unmodified from where they lie (AST
+lift / ref_stubs); only inputs and the outputs the reference produced are stored.
+
+  depth_loss.npz       DepthHead.loss (dense_heads/depth_head.py:75-188) for every loss type the
+                       class implements: loss value and d loss / d (depth_volumes, depth_preds)
+                       from torch autograd.
+  configs_dfm.json     the model sub-dicts (backbone_stereo, feature_transformation, depth_head,
+                       neck_3d, backbone_3d, voxel / depth settings) of configs/dfm/*.py, obtained
+                       by exec'ing the config files (with their _base_ chain) -- what
+                       tests/test_config_build.py builds through the registry.
+  backbone_cfg1.npz    BASELINE.json configs[0] ("one synthetic KITTI pair 375x1242, D=4"):
+                       DfMBackbone forward (dfm_backbone.py:143-214) on seeded stereo features of
+                       the padded 384x1248 image, D=4 planes (num_bins=16, downsample_factor=4).
+                       Inputs are regenerated from the seeds by the test; stored are the cost
+                       volume and a strided sample of the two feature volumes.
+  bev_spp.npz          BEVHourglass (backbones/bev_hourglass.py) and SPPUNetNeck
+                       (necks/spp_unet_neck.py) forward on seeded inputs with synthetic weights.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+REF_ROOT = '/root/reference'
+
+LOSS_TYPES = ['ce', 'balanced_ce', 'focal', 'balanced_focal', 'hard_ce', 'gaussian_1.5',
+              'laplacian_2.0', 'l1', 'purel1']
+
+
+def depth_loss_inputs(seed=700, B=2, D=24, H=10, W=14):
+    """shared by the generator and tests/test_depth_loss.py"""
+    gen = torch.Generator().manual_seed(seed)
+    interval = (59.6 - 2) / D
+    ds = torch.tensor([(k + 0.5) * interval + 2 for k in range(D)], dtype=torch.float32)
+    vol = torch.randn(B, D, H, W, generator=gen) * 3
+    pred = torch.rand(B, H, W, generator=gen) * 57.6 + 2
+    img = torch.rand(B, H, W, generator=gen) * 70.0            # some beyond max_depth
+    img[torch.rand(B, H, W, generator=gen) < 0.45] = 0.0       # no LiDAR return
+    img.view(-1)[:3] = torch.tensor([2.0, 59.6, 30.0])         # the strict-inequality edges
+    fg = (torch.rand(B, H, W, generator=gen) * 3).floor()      # box ids 0 (bg), 1, 2
+    return ds, vol, pred, img, fg
+
+
+def make_depth_loss():
+    import ref_stubs
+    ref_stubs.install()
+    dh = ref_stubs.load_file('mmdet3d/models/dense_heads/depth_head.py', 'ref_depth_head_r02')
+    dh.dist = types.SimpleNamespace(get_rank=lambda: 1)  # gaussian/laplacian print on rank 0
+    ds, vol, pred, img, fg = depth_loss_inputs()
+    out = dict(depth_samples=ds.numpy(), volumes=vol.numpy(), preds=pred.numpy(), depth_img=img.numpy(),
+               fgmask=fg.numpy())
+    for t in LOSS_TYPES:
+        cfg = dict(type=t, loss_weight=0.7)
+        if 'balanced' in t:
+            cfg.update(fg_weight=5, bg_weight=1)
+        if 'focal' in t:
+            cfg.update(alpha=0.75, gamma=2)
+        m = dh.DepthHead(depth_cfg=dict(mode='UD', num_bins=len(ds), min_depth=2, max_depth=59.6),
+                         with_convs=False, depth_loss=cfg, downsample_factor=4, num_views=1)
+        m.depth_samples = ds
+        v, p = vol.clone().requires_grad_(True), pred.clone().requires_grad_(True)
+        loss = m.loss(p, v, img, depth_fgmask_img=fg)
+        loss.backward()
+        key = t.replace('.', 'p')
+        out[f'{key}_loss'] = loss.detach().numpy()
+        out[f'{key}_gvol'] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
+        out[f'{key}_gpred'] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+        print(f'depth loss {t:16s} {float(loss):.6f}')
+    # gamma = 3 (generic pow path) for the focal form
+    m = dh.DepthHead(depth_cfg=dict(mode='UD', num_bins=len(ds), min_depth=2, max_depth=59.6),
+                     with_convs=False, depth_loss=dict(type='focal', loss_weight=1.0, alpha=1, gamma=3),
+                     downsample_factor=4, num_views=1)
+    m.depth_samples = ds
+    v = vol.clone().requires_grad_(True)
+    loss = m.loss(pred, v, img)
+    loss.backward()
+    out['focal_g3_loss'], out['focal_g3_gvol'] = loss.detach().numpy(), v.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'depth_loss.npz'), **out)
+
+
+def _jsonable(x):
+    if isinstance(x, dict):
+        return {k: _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    if isinstance(x, (int, float, str, bool)) or x is None:
+        return x
+    return repr(x)
+
+
+def exec_config(path):
+    """mmcv.Config.fromfile for plain-Python configs: exec the _base_ chain, then the file
+    (later files override earlier keys; dicts are merged recursively like mmcv does)."""
+    def merge(base, new):
+        for k, v in new.items():
+            if isinstance(v, dict) and isinstance(base.get(k), dict) and not v.pop('_delete_', False):
+                merge(base[k], v)
+            else:
+                base[k] = v
+        return base
+
+    src = open(path).read()
+    glb = {}
+    exec(compile(src, path, 'exec'), glb)
+    cfg = {}
+    bases = glb.get('_base_', [])
+    for b in ([bases] if isinstance(bases, str) else bases):
+        merge(cfg, exec_config(os.path.normpath(os.path.join(os.path.dirname(path), b))))
+    merge(cfg, {k: v for k, v in glb.items() if not k.startswith('__') and k != '_base_' and
+                not isinstance(v, types.ModuleType)})
+    return cfg
+
+
+def make_configs():
+    names = ['dfm_r34_1x8_kitti-3d-3class.py']
+    cfg_dir = os.path.join(REF_ROOT, 'configs', 'dfm')
+    names += sorted(f for f in os.listdir(cfg_dir) if f.startswith('multiview-dfm_') and f.endswith('.py'))
+    keep = ('backbone_stereo', 'feature_transformation', 'depth_head', 'neck_3d', 'backbone_3d', 'neck',
+            'neck_stereo', 'neck_bev', 'depth_cfg', 'voxel_cfg', 'n_voxels', 'anchor_generator',
+            'depth_head', 'temporal_aggregate', 'num_ref_frames', 'type', 'voxel_size')
+    out = {}
+    for n in names:
+        cfg = exec_config(os.path.join(cfg_dir, n))
+        model = cfg['model']
+        out[n] = {'model': {k: _jsonable(v) for k, v in model.items() if k in keep},
+                  'file': f'configs/dfm/{n}'}
+        print(n, sorted(out[n]['model']))
+    with open(os.path.join(HERE, 'configs_dfm.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+CFG1 = dict(C=32, H=384, W=1248, D=4, csf=4, seed=41, wseed=42,
+            ori_shape=(375, 1242, 3), pad_shape=(384, 1248, 3))
+
+
+def cfg1_inputs():
+    """shared by the generator and tests/test_modules.py"""
+    c = CFG1
+    gen = torch.Generator().manual_seed(c['seed'])
+    cur = torch.randn(1, c['C'], c['H'], c['W'], generator=gen)
+    prev = torch.randn(1, c['C'], c['H'], c['W'], generator=gen)
+    interval = (59.6 - 2) / 16  # num_bins=16, downsample_factor=4 -> D=4
+    depths = torch.tensor([(i + 0.5) * 4 * interval + 2 for i in range(c['D'])])
+    from make_golden import KITTI_P2, pose
+    meta = dict(ori_cam2img=KITTI_P2, cur2prevs=torch.tensor(pose(-0.7, 0.03, 0.0, -1.1))[None],
+                ori_shape=c['ori_shape'], pad_shape=c['pad_shape'], crop_offset=[0, 0], flip=False,
+                scale_factor=[1.0])
+    return cur, prev, depths, meta
+
+
+def make_backbone_cfg1():
+    import ref_stubs
+    from tests import util
+    ref = ref_stubs.load_hot_path_modules()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    c = CFG1
+    depth_cfg = dict(mode='UD', num_bins=16, depth_min=2, depth_max=59.6, downsample_factor=4)
+    m = ref['dfm_backbone'].DfMBackbone(in_channels=c['C'], cv_channels=32, num_hg=1,
+                                        cost_sample_factor=c['csf'], depth_cfg=depth_cfg,
+                                        norm_cfg=dict(type='GN', num_groups=32, requires_grad=True)).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, c['wseed']))
+    cur, prev, depths, meta = cfg1_inputs()
+    m.downsampled_depth = depths
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        cost, sfeat, mfeat = m(cur, prev, [meta])
+    print('cfg1', tuple(cost.shape), tuple(sfeat.shape), float(cost.abs().mean()))
+    np.savez_compressed(os.path.join(HERE, 'backbone_cfg1.npz'), cost=cost.numpy(),
+                        stereo_s8=sfeat[..., ::8, ::8].numpy(), mono_s8=mfeat[..., ::8, ::8].numpy(),
+                        stereo_abs_mean=sfeat.abs().mean((0, 2, 3, 4)).numpy(),
+                        mono_abs_mean=mfeat.abs().mean((0, 2, 3, 4)).numpy(), depths=depths.numpy())
+
+
+def bev_spp_inputs():
+    """shared by the generator and tests/test_modules.py"""
+    gen = torch.Generator().manual_seed(51)
+    bev = torch.randn(2, 16, 24, 32, generator=gen)
+    # image + four backbone levels (1/2, 1/4, 1/4, 1/4) of a 256x256 crop: the 64x64 average
+    # pool of the SPP branch needs >= 64 pixels at 1/4 resolution
+    feats = [torch.randn(1, c, h, w, generator=gen) for c, h, w in
+             ((3, 256, 256), (8, 128, 128), (16, 64, 64), (32, 64, 64), (32, 64, 64))]
+    return bev, feats
+
+
+BEV_CFG = dict(in_channels=16, out_channels=32, norm_cfg=dict(type='GN', num_groups=32, requires_grad=True))
+SPP_CFG = dict(in_channels=[3, 8, 16, 32, 32], start_level=2, sem_channels=[16, 12],
+               stereo_channels=[32, 12], with_upconv=True, cat_img_feature=True,
+               norm_cfg=dict(type='GN', num_groups=4, requires_grad=True))
+
+
+def make_bev_spp():
+    import ref_stubs
+    from tests import util
+    ref_stubs.install()
+    bh = ref_stubs.load_file('mmdet3d/models/backbones/bev_hourglass.py', 'ref_bev_hourglass')
+    sp = ref_stubs.load_file('mmdet3d/models/necks/spp_unet_neck.py', 'ref_spp_unet')
+    bev, feats = bev_spp_inputs()
+    out = {}
+    m = bh.BEVHourglass(**BEV_CFG).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, 52))
+    with torch.no_grad():
+        pre, post = m(bev)
+    out['bev_prehg'], out['bev_out'] = pre.numpy(), post.numpy()
+    out['bev_keys'] = np.array(list(m.state_dict().keys()))
+    m = sp.SPPUNetNeck(**SPP_CFG).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, 53))
+    with torch.no_grad():
+        stereo, sem = m(feats)
+    out['spp_stereo_s4'], out['spp_sem'] = stereo[..., ::4, ::4].numpy(), sem.numpy()
+    out['spp_stereo_abs_mean'] = stereo.abs().mean((0, 2, 3)).numpy()
+    out['spp_keys'] = np.array(list(m.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, 'bev_spp.npz'), **out)
+    print('bev', out['bev_out'].shape, 'spp', tuple(stereo.shape), out['spp_sem'].shape)
+
+
+if __name__ == '__main__':
+    if not os.path.isdir(REF_ROOT):
+        sys.exit('reference not mounted; fixtures are committed, nothing to do')
+    which = sys.argv[1:] or ['depth_loss', 'configs', 'cfg1', 'bev_spp']
+    torch.set_num_threads(1)
+    if 'depth_loss' in which:
+        make_depth_loss()
+    if 'configs' in which:
+        make_configs()
+    if 'cfg1' in which:
+        make_backbone_cfg1()
+    if 'bev_spp' in which:
+        make_bev_spp()

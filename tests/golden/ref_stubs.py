@@ -111,7 +111,7 @@ def install():
     mod('mmcv.cnn', ConvModule=ConvModule)
     mod('mmcv.runner', BaseModule=BaseModule, force_fp32=lambda *a, **k: (lambda f: f))
     mod('mmdet')
-    mod('mmdet.models')
+    mod('mmdet.models', BACKBONES=reg, NECKS=reg, HEADS=reg, DETECTORS=reg)
     mod('mmdet.models.builder', BACKBONES=reg, NECKS=reg, HEADS=reg, DETECTORS=reg)
     # package skeleton so the reference files' absolute / relative imports resolve
     mod('mmdet3d')

@@ -145,3 +145,97 @@ def test_depth_head_module_matches_functional(mods, pkg):
     vol, soft, pred = m(torch.from_numpy(z['x']).cuda())
     assert np.array_equal(util.bits(vol.cpu().numpy()), util.bits(z['ref_vol']))
     np.testing.assert_allclose(pred.cpu().numpy(), z['ref_pred'], rtol=5e-6)
+
+
+@pytest.mark.gpu
+def test_baseline_config1_kitti_pair_d4_vs_reference_module(mods):
+    """BASELINE.json configs[0]: one synthetic KITTI pair (375x1242 -> padded 384x1248), D=4
+    planes, through DfMBackbone against the REFERENCE module's output on the same seeded features
+    and weights (tests/golden/make_golden_r02.py::make_backbone_cfg1)."""
+    import sys
+    sys.path.insert(0, util.GOLDEN)
+    from make_golden_r02 import CFG1, cfg1_inputs
+    z = np.load(os.path.join(util.GOLDEN, 'backbone_cfg1.npz'))
+    depth_cfg = dict(mode='UD', num_bins=16, depth_min=2, depth_max=59.6, downsample_factor=4)
+    m = _load(mods.DfMBackbone(in_channels=CFG1['C'], cv_channels=32, num_hg=1,
+                               cost_sample_factor=CFG1['csf'], depth_cfg=depth_cfg,
+                               norm_cfg=dict(type='GN', num_groups=32, requires_grad=True)),
+              CFG1['wseed'])
+    cur, prev, depths, meta = cfg1_inputs()
+    assert np.array_equal(depths.numpy(), z['depths'])
+    m.downsampled_depth = depths
+    with torch.no_grad():
+        cost, sfeat, mfeat = m(cur.cuda(), prev.cuda(), [meta])
+    assert cost.shape == (1, 1, 4, 96, 312) and sfeat.shape == (1, 32, 4, 96, 312)
+    np.testing.assert_allclose(cost.cpu().numpy(), z['cost'], **CONV_TOL)
+    np.testing.assert_allclose(sfeat[..., ::8, ::8].cpu().numpy(), z['stereo_s8'], **CONV_TOL)
+    np.testing.assert_allclose(mfeat[..., ::8, ::8].cpu().numpy(), z['mono_s8'], **CONV_TOL)
+    np.testing.assert_allclose(sfeat.abs().mean((0, 2, 3, 4)).cpu().numpy(), z['stereo_abs_mean'], rtol=1e-3)
+    np.testing.assert_allclose(mfeat.abs().mean((0, 2, 3, 4)).cpu().numpy(), z['mono_abs_mean'], rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_bev_hourglass_and_spp_unet_neck_vs_reference_modules(mods):
+    import sys
+    sys.path.insert(0, util.GOLDEN)
+    from make_golden_r02 import BEV_CFG, SPP_CFG, bev_spp_inputs
+    z = np.load(os.path.join(util.GOLDEN, 'bev_spp.npz'))
+    bev, feats = bev_spp_inputs()
+    b = mods.BEVHourglass(**BEV_CFG)
+    assert list(b.state_dict()) == list(z['bev_keys'])
+    b = _load(b, 52)
+    with torch.no_grad():
+        pre, post = b(bev.cuda())
+    np.testing.assert_allclose(pre.cpu().numpy(), z['bev_prehg'], **CONV_TOL)
+    np.testing.assert_allclose(post.cpu().numpy(), z['bev_out'], **CONV_TOL)
+    s = mods.SPPUNetNeck(**SPP_CFG)
+    assert list(s.state_dict()) == list(z['spp_keys'])
+    s = _load(s, 53)
+    with torch.no_grad():
+        stereo, sem = s([f.cuda() for f in feats])
+    assert stereo.shape == (1, 12, 256, 256) and sem.shape == (1, 12, 64, 64)
+    np.testing.assert_allclose(stereo[..., ::4, ::4].cpu().numpy(), z['spp_stereo_s4'], **CONV_TOL)
+    np.testing.assert_allclose(sem.cpu().numpy(), z['spp_sem'], **CONV_TOL)
+    np.testing.assert_allclose(stereo.abs().mean((0, 2, 3)).cpu().numpy(), z['spp_stereo_abs_mean'], rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_dfm_stereo_path_runs_the_training_config_end_to_end(pkg):
+    """configs/dfm/dfm_r34_1x8_kitti-3d-3class.py's model dict (as extracted from the file):
+    neck -> backbone_stereo -> depth_head -> feature_transformation -> BEVHourglass, plus the
+    dense depth loss (dfm.py:348-356) and a backward pass through every HIP kernel of the path.
+    Reduced image (128x256) and voxel range so the test stays small; channel widths, depth bins
+    and module wiring are the config's."""
+    import json
+    with open(os.path.join(util.GOLDEN, 'configs_dfm.json')) as f:
+        model = json.load(f)['dfm_r34_1x8_kitti-3d-3class.py']['model']
+    model = dict(model)
+    model['depth_cfg'] = dict(model['depth_cfg'], num_bins=32)          # D = 8 planes
+    model['depth_head'] = dict(model['depth_head'],
+                               depth_cfg=dict(model['depth_head']['depth_cfg'], num_bins=32))
+    model['voxel_cfg'] = dict(point_cloud_range=[2, -6.4, -3, 27.6, 6.4, 1], voxel_size=[0.2, 0.2, 0.2])
+    path = pkg.DfMStereoPath(model).cuda()
+    H, W = 256, 512
+    gen = torch.Generator().manual_seed(7)
+
+    def pyramid():
+        return [torch.randn(1, c, H // s, W // s, generator=gen).cuda()
+                for c, s in ((3, 1), (64, 2), (128, 4), (128, 4), (128, 4))]
+    K = util.KITTI_P2.copy()
+    meta = dict(ori_cam2img=K, cam2img=K.tolist(), cur2prevs=util.pose(0.5, 0.02, 0.0, -0.8)[None],
+                ori_shape=(H, W, 3), pad_shape=(H, W, 3), crop_offset=[0, 0], flip=False,
+                scale_factor=[1.0])
+    out = path(pyramid(), pyramid(), [meta])
+    assert out['mono_stereo_costs'].shape == (1, 1, 8, H // 4, W // 4)
+    assert out['upsample_costs'].shape == (1, 1, 32, H, W)
+    assert out['volume_feat'].shape == (1, 32, 5, 64, 128)
+    assert out['bev_feat'].shape == (1, 64, 64, 128)
+    depth_img = (torch.rand(1, 1, H, W, generator=gen) * 60).cuda()
+    depth_img[torch.rand(1, 1, H, W, generator=gen).cuda() < 0.8] = 0
+    fg = (torch.rand(1, 1, H, W, generator=gen) < 0.3).float().cuda()
+    loss = path.loss_dense_depth(out, depth_img, fg) + out['bev_feat'].square().mean()
+    loss.backward()
+    assert torch.isfinite(loss)
+    grads = [p.grad for p in path.parameters() if p.requires_grad]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads)
+    assert sum(float(g.abs().sum()) > 0 for g in grads) > 0.9 * len(grads)
