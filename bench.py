@@ -349,15 +349,18 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
         if world > 1:
             torch.distributed.barrier()
 
-    tuned = None
-    if not args.channels_last and not explicit and not args.no_autotune:
-        # untimed, like the warm-up: the library times its candidate launch shapes / workgroup
-        # orders on this part once and caches the fastest for this shape (it would do so by
-        # itself on the first dfm_plane_sweep_fwd of a volume this size)
-        tuned = sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
+    if explicit or args.channels_last or args.no_autotune:
+        os.environ['DFM_AUTOTUNE'] = '0'  # keep the first launch from tuning by itself
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    tuned = None
+    if not args.channels_last and not explicit and not args.no_autotune:
+        # untimed, like the warm-up: the library's choice among its candidate launch shapes /
+        # workgroup orders for this shape on this part (the first dfm_plane_sweep_fwd of a volume
+        # this size ran the autotuner; query what it cached, tune now if it did not)
+        tuned = sweep.plane_sweep_tuning(desc) or \
+            sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
     pkg._capi.check(lib.dfm_profile_begin(args.steps))
     barrier()
     torch.cuda.synchronize()

@@ -2,8 +2,9 @@
 
 BASELINE.json's metric is quoted on B=8, C=256, D=112, 94x311, bf16.  These tests run exactly
 that launch -- same inputs as bench.py (bench.WORKLOADS / bench.poses / KITTI P2), B=8, the LDS
-tile kernel in its default shape -- under every workgroup schedule the library's autotuner can
-pick (bands_per_chunk 1 / 15 / 29) and under the augmented geometry of SURVEY.md 8d's second run
+tile kernel -- under every launch configuration the library's autotuner can pick ({256 lanes x 8
+points, 512 lanes x 4 points} x bands_per_chunk {1, 15}; 29 as an extra) and under the augmented
+geometry of SURVEY.md 8d's second run
 (flip, crop offset (11,55), scale 1.03), and compare >= 8 whole depth planes x 16 channels of
 each half of every sample bit-for-bit with bf16(oracle(bf16 inputs)).  Whole planes include the
 first and last 16-byte vector of a plane, i.e. the points sweep_patch_kernel fills in.
@@ -50,7 +51,7 @@ def _oracle_planes(w, cur, prev, depths, T, b, flip, crop, scale):
                            T[b:b + 1], (375, 1242), flip, crop, scale))
 
 
-def _run(pkg, w, cur, prev, depths, T, flip, crop, scale, chunk):
+def _run(pkg, w, cur, prev, depths, T, flip, crop, scale, opts):
     sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
     dev = torch.device('cuda:0')
     B = w['B']
@@ -58,8 +59,8 @@ def _run(pkg, w, cur, prev, depths, T, flip, crop, scale, chunk):
     desc = sweep._make_desc(c, w['D'], w['fsf'], w['csf'], (375, 1242), flip, crop, scale)
     Pm, Pinv, Tm = sweep.camera_matrices(torch.from_numpy(np.stack([util.KITTI_P2] * B)),
                                          torch.from_numpy(T), B, dev)
-    out = sweep.plane_sweep_forward(desc, c, p, torch.from_numpy(depths).to(dev), Pm, Pinv, Tm,
-                                    schedule=chunk)
+    with sweep.launch_options(**opts):
+        out = sweep.plane_sweep_forward(desc, c, p, torch.from_numpy(depths).to(dev), Pm, Pinv, Tm)
     torch.cuda.synchronize()
     assert pkg._capi.lib().dfm_plane_sweep_last_kernel() == 2  # the LDS tile kernel
     return out
@@ -76,10 +77,16 @@ def _compare(out, w, cur, prev, depths, T, flip, crop, scale):
         assert not bad.any(), f'sample {b}: {int(bad.sum())} of {bad.size} values differ'
 
 
-@pytest.mark.parametrize('chunk', [1, 15, 29])
-def test_shipped_nstar_launch_bitexact(pkg, nstar_inputs, chunk):
+CANDIDATES = {'l256_p8_c1': dict(kernel=2), 'l256_p8_c15': dict(kernel=2, bands_per_chunk=15),
+              'l512_p4_c1': dict(kernel=2, lanes=512, points_per_lane=4),
+              'l512_p4_c15': dict(kernel=2, lanes=512, points_per_lane=4, bands_per_chunk=15),
+              'l256_p8_c29': dict(kernel=2, bands_per_chunk=29)}
+
+
+@pytest.mark.parametrize('cand', sorted(CANDIDATES))
+def test_shipped_nstar_launch_bitexact(pkg, nstar_inputs, cand):
     w, cur, prev, depths, T = nstar_inputs
-    out = _run(pkg, w, cur, prev, depths, T, False, (0, 0), 1.0, chunk)
+    out = _run(pkg, w, cur, prev, depths, T, False, (0, 0), 1.0, CANDIDATES[cand])
     assert out.shape == (8, 512, 112, 94, 311)
     _compare(out, w, cur, prev, depths, T, False, (0, 0), 1.0)
 
@@ -89,5 +96,7 @@ def test_nstar_augmented_run_bitexact(pkg, nstar_inputs):
     (bench.py --workload nstar_aug times the same launch)."""
     w, cur, prev, depths, T = nstar_inputs
     a = bench.WORKLOADS['nstar_aug']
-    out = _run(pkg, w, cur, prev, depths, T, a['flip'], a['crop'], a['scale'], 0)
-    _compare(out, w, cur, prev, depths, T, a['flip'], a['crop'], a['scale'])
+    for cand in ('l256_p8_c1', 'l512_p4_c1'):
+        out = _run(pkg, w, cur, prev, depths, T, a['flip'], a['crop'], a['scale'], CANDIDATES[cand])
+        _compare(out, w, cur, prev, depths, T, a['flip'], a['crop'], a['scale'])
+        del out

@@ -348,7 +348,7 @@ def test_autotune_keeps_results_exact(pkg, kernel_mode):
     assert sweep.plane_sweep_tuning(desc) is None
     with sweep.launch_options():  # no per-call options: the tuned cache is what the launch uses
         chosen = sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
-        assert chosen['bands_per_chunk'] in (1, 15, 29)
+        assert chosen['bands_per_chunk'] in (1, 15) and chosen['lanes_per_workgroup'] in (0, 512)
         assert sweep.plane_sweep_tuning(desc) == chosen
         assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
         again = sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T)

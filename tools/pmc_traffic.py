@@ -28,7 +28,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT_CFGS = ['chunk=1', 'chunk=15', 'chunk=29', 'lanes=512,ppl=4,chunk=1', 'lanes=512,ppl=4,chunk=15']
+DEFAULT_CFGS = ['chunk=1', 'chunk=15', 'lanes=512,ppl=4,chunk=1', 'lanes=512,ppl=4,chunk=15']
 
 
 def key_of(cfg):
@@ -77,8 +77,6 @@ def main():
             continue
         kernels = sorted(set(fetch) | set(write))
         total = sum(2 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in kernels) * 1024
-        tile = [k for k in kernels if 'sweep_tile_kernel' in k and 'Lb1' not in k] or \
-               [k for k in kernels if 'sweep_tile_kernel' in k]
         tile_bytes = sum(2 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in kernels
                          if 'sweep_tile_kernel' in k) * 1024
         res_w[key_of(cfg)] = {
