@@ -41,6 +41,9 @@ EXPORTS = (
     'dfm_point_sample_mv_bwd_workspace_bytes',
     'dfm_point_sample_mv_bwd',
     'dfm_depth_head_bwd',
+    'dfm_conv3d_k3_c32_weight_bytes',
+    'dfm_conv3d_k3_c32_pack_weights',
+    'dfm_conv3d_k3_c32_fwd',
     'dfm_depth_loss_fwd',
     'dfm_depth_loss_bwd',
     'dfm_voxel_sample_fwd',
@@ -212,6 +215,11 @@ def lib():
     h.dfm_point_sample_mv_bwd_workspace_bytes.argtypes = [mp]
     h.dfm_depth_head_bwd.restype = ctypes.c_int
     h.dfm_depth_head_bwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, fp, vp]
+    h.dfm_conv3d_k3_c32_weight_bytes.restype = sz
+    h.dfm_conv3d_k3_c32_pack_weights.restype = ctypes.c_int
+    h.dfm_conv3d_k3_c32_pack_weights.argtypes = [vp, i32, i32, i32, vp, vp]
+    h.dfm_conv3d_k3_c32_fwd.restype = ctypes.c_int
+    h.dfm_conv3d_k3_c32_fwd.argtypes = [i32, i32, i32, i32, vp, vp, fp, vp, i32, i32, i32, vp]
     lp = ctypes.POINTER(DepthLossDesc)
     h.dfm_depth_loss_fwd.restype = ctypes.c_int
     h.dfm_depth_loss_fwd.argtypes = [lp, vp, fp, fp, fp, vp, vp]

@@ -1,0 +1,308 @@
+// conv3d.hip -- hand-written MFMA implicit-GEMM Conv3d 3x3x3 (stride 1, pad 1) for the 3-D
+// aggregation stacks of the path:
+//   DfMBackbone dres0 / dres1 / pred convs   mmdet3d/models/backbones/dfm_backbone.py:50-128,175-201
+//   convbn_3d                                 mmdet3d/models/utils/conv_modules.py:27-43
+// Channels-last (NDHWC) bf16 activations, fp32 accumulation, C_in = C_out = 32 -- the width of
+// every full-resolution convolution of config K (a 64 -> 32 dres0 runs as two 32-channel halves:
+// conv(cat(cur, prev)) = conv_a(cur) + conv_b(prev), accumulated through the fp32 partial).
+//
+// Why not a generic implicit GEMM: with N = C_out = 32 every activation fragment feeds ONE MFMA,
+// so a tiling that stages an (M x K) operand per tap moves 27x the input through LDS-DMA and is
+// staging-bound at ~15 % of the MFMA peak (MIOpen: 350-370 TFLOP/s on these shapes,
+// profiles/r01_miopen_conv3d_baseline.txt).  This kernel instead:
+//   * keeps ALL weights (27 taps x 32 x 32 bf16 = 54 fragments = 216 registers per lane) in the
+//     register file of every wave for the whole launch (one wave per SIMD: 512 registers,
+//     MFMA A operands straight from them) -- no LDS or cache traffic for weights at all;
+//   * walks a workgroup (4 waves, 16 rows x 32 columns of output) along DEPTH with a ring of four
+//     input depth slabs (18 x 34 pixels x 64 B, halo included) in LDS: every input element is
+//     staged ONCE (x 1.2 for the halo) by LDS-DMA and used by all 27 taps; the slab of depth d+2
+//     streams in while depth d is computed;
+//   * orients the MFMA as D[cout][pixel] = W[cout][k] * X[k][pixel] (v_mfma_f32_32x32x16_bf16):
+//     a wave owns 4 output rows x 32 pixels, loads the 6 input rows they touch once per
+//     (kd, kw, 16-channel step) and reuses each row fragment for up to 3 kh taps
+//     -> 6 LDS fragment reads per 12 MFMAs (0.5 KiB per MFMA, a quarter of the LDS peak);
+//   * LDS image is XOR-swizzled at 16-byte granularity (slot ^= (pixel >> 2) & 3, applied to the
+//     DMA source and to the reads) so the 64-byte pixel stride is bank-conflict free;
+//   * epilogue: optional ReLU, bf16 (or fp32 partial) stores of 4 consecutive channels per lane;
+//     a wave writes 32 pixels x 64 B = 2 KiB contiguous.
+#include "dfm_common.h"
+
+using namespace dfm;
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int CV_C = 32;                  // C_in = C_out
+constexpr int CV_TH = 16, CV_TW = 32;     // output tile of a workgroup (rows x columns)
+constexpr int CV_SH = CV_TH + 2, CV_SW = CV_TW + 2;
+constexpr int CV_SLAB_PIX = CV_SH * CV_SW;           // 612
+constexpr int CV_SLAB_BYTES = CV_SLAB_PIX * CV_C * 2;  // 39168
+constexpr int CV_RING = 4;
+constexpr int CV_PIECES = CV_SLAB_PIX * 4;           // 16-byte pieces per slab
+constexpr int CV_ROUNDS = (CV_PIECES + 255) / 256;   // 10
+constexpr int CV_NFRAG = 27 * 2;
+
+struct ConvGeom {
+    int32_t N, D, H, W;
+    int32_t tiles_w, tiles_h, dchunk, relu;
+};
+
+// weights (C_out, C_in, 3, 3, 3) -> MFMA A-operand fragments [tap*2 + ks][lane][8]:
+// lane l holds W[cout = l & 31][cin = ks*16 + (l >> 5)*8 + j][tap], j = 0..7
+template <typename TW>
+__global__ void conv3d_pack_weights_kernel(const TW *__restrict__ w, int cin_total, int cin_off,
+                                           bf16_t *__restrict__ frag)
+{
+    const int f = blockIdx.x;  // fragment: tap*2 + ks
+    const int l = threadIdx.x;
+    const int tap = f >> 1, ks = f & 1;
+    const int cout = l & 31, cin0 = ks * 16 + (l >> 5) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = (float)w[((size_t)cout * cin_total + cin_off + cin0 + j) * 27 + tap];
+        frag[((size_t)f * 64 + l) * 8 + j] = f32_to_bf16(v);
+    }
+}
+template <>
+__global__ void conv3d_pack_weights_kernel<bf16_t>(const bf16_t *__restrict__ w, int cin_total,
+                                                   int cin_off, bf16_t *__restrict__ frag)
+{
+    const int f = blockIdx.x, l = threadIdx.x;
+    const int tap = f >> 1, ks = f & 1;
+    const int cout = l & 31, cin0 = ks * 16 + (l >> 5) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        frag[((size_t)f * 64 + l) * 8 + j] = w[((size_t)cout * cin_total + cin_off + cin0 + j) * 27 + tap];
+}
+
+// OUT_F32: write the fp32 partial (N,D,H,W,32) instead of bf16;  ACC_IN: start from a fp32 partial
+template <bool OUT_F32, bool ACC_IN>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
+    ConvGeom g, const bf16_t *__restrict__ x, const uint4 *__restrict__ wfrag,
+    const float *__restrict__ acc_in, void *__restrict__ yout, const uint4 *__restrict__ zero_page)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l32 = lane & 31, half = lane >> 5;
+    const int tile = blockIdx.x;
+    const int tw = tile % g.tiles_w, th = tile / g.tiles_w;
+    const int h0 = th * CV_TH, w0 = tw * CV_TW;
+    const int d0 = blockIdx.y * g.dchunk, d1 = min(d0 + g.dchunk, g.D);
+    const int n = blockIdx.z;
+    const size_t plane = (size_t)g.H * g.W * CV_C;  // elements per depth plane
+    const bf16_t *xn = x + (size_t)n * g.D * plane;
+
+    // ---- weights: 54 fragments, register resident for the whole launch ------------------
+    bf16x8_t wf[CV_NFRAG];
+#pragma unroll
+    for (int f = 0; f < CV_NFRAG; ++f) {
+        const uint4 q = wfrag[f * 64 + lane];
+        __builtin_memcpy(&wf[f], &q, 16);
+    }
+
+    // ---- per-lane DMA plan: byte offset inside a depth plane of each of its 16-byte pieces
+    int poff[CV_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < CV_ROUNDS; ++k) {
+        const int q = k * 256 + tid;
+        const int p = q >> 2, sl = (q & 3) ^ ((p >> 2) & 3);
+        const int j = p / CV_SW, i = p - j * CV_SW;
+        const int h = h0 - 1 + j, w = w0 - 1 + i;
+        const bool ok = q < CV_PIECES && h >= 0 && h < g.H && w >= 0 && w < g.W;
+        poff[k] = ok ? ((h * g.W + w) * CV_C + sl * 8) * 2 : -1;
+    }
+    auto stage = [&](int dz) {  // depth dz -> ring slot (dz - d0 + 1) & 3
+        const int slot = (dz - d0 + 1) & (CV_RING - 1);
+        const bool zok = dz >= 0 && dz < g.D;
+        const unsigned char *src = (const unsigned char *)(xn + (size_t)(zok ? dz : 0) * plane);
+        unsigned char *dst = ring + slot * CV_SLAB_BYTES + wave * 1024;
+#pragma unroll
+        for (int k = 0; k < CV_ROUNDS; ++k) {
+            if (k * 256 + tid < CV_PIECES) {
+                const unsigned char *s = (zok && poff[k] >= 0) ? src + poff[k] : (const unsigned char *)zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)s,
+                                                 (__attribute__((address_space(3))) void *)(dst + k * 4096),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    // LDS byte offset (inside a slab) of this lane's pixel in slab row (r0 + rr), before kw / ks
+    const int r0 = wave * 4;
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;  // LDS offset
+    auto frag_addr = [&](int slot, int rr, int kw, int ks) -> uint32_t {
+        const int pix = (r0 + rr) * CV_SW + l32 + kw;
+        return ring_base + slot * CV_SLAB_BYTES + pix * 64 + ((((2 * ks + half) ^ ((pix >> 2) & 3))) << 4);
+    };
+
+    // prologue: slabs d0-1, d0, d0+1
+    stage(d0 - 1);
+    stage(d0);
+    stage(d0 + 1);
+    __syncthreads();
+
+    const bool colok = w0 + l32 < g.W;
+    for (int d = d0; d < d1; ++d) {
+        if (d + 2 <= d1) stage(d + 2);  // needed by depth d+1 (<= d1-1) as its kd=2 slab
+        f32x16_t acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (ACC_IN) {
+                const int h = h0 + r0 + r;
+                const bool ok = colok && h < g.H;
+                const float *ap = acc_in + ((((size_t)n * g.D + d) * g.H + (ok ? h : 0)) * g.W + (ok ? w0 + l32 : 0)) * CV_C;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 v = ok ? *(const float4 *)(ap + 8 * gq + 4 * half) : make_float4(0, 0, 0, 0);
+                    acc[r][4 * gq + 0] = v.x; acc[r][4 * gq + 1] = v.y;
+                    acc[r][4 * gq + 2] = v.z; acc[r][4 * gq + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc[r][t] = 0.0f;
+            }
+        }
+        // 18 steps (kd, kw, ks); the 6 row fragments of step s+1 are in flight while the 12 MFMAs
+        // of step s run (inline-asm LDS reads: hipcc would otherwise drain the LDS-DMA of the
+        // next slab with vmcnt(0) before the first read)
+        u32x4_t q[2][6];
+        auto issue = [&](int step, u32x4_t (&dst)[6]) {
+            const int kd = step / 6, kw = (step / 2) % 3, ks = step & 1;
+            const int slot = (d - d0 + kd) & (CV_RING - 1);  // depth d-1+kd
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) {
+                const uint32_t a = frag_addr(slot, rr, kw, ks);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dst[rr]) : "v"(a));
+            }
+        };
+        issue(0, q[0]);
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            const int cb = step & 1, nb = cb ^ 1;
+            if (step + 1 < 18) {
+                issue(step + 1, q[nb]);
+                asm volatile("s_waitcnt lgkmcnt(6)"
+                             : "+v"(q[cb][0]), "+v"(q[cb][1]), "+v"(q[cb][2]), "+v"(q[cb][3]),
+                               "+v"(q[cb][4]), "+v"(q[cb][5]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(q[cb][0]), "+v"(q[cb][1]), "+v"(q[cb][2]), "+v"(q[cb][3]),
+                               "+v"(q[cb][4]), "+v"(q[cb][5]));
+            }
+            const int kd = step / 6, kw = (step / 2) % 3, ks = step & 1;
+            bf16x8_t xf[6];
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) __builtin_memcpy(&xf[rr], &q[cb][rr], 16);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int f = (((kd * 3 + kh) * 3 + kw) << 1) | ks;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[f], xf[r + kh], acc[r], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: lane = pixel (w0 + l32), 4 groups of 4 consecutive channels
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = h0 + r0 + r;
+            if (!(colok && h < g.H)) continue;
+            const size_t vox = (((size_t)n * g.D + d) * g.H + h) * g.W + w0 + l32;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                float v0 = acc[r][4 * gq], v1 = acc[r][4 * gq + 1], v2 = acc[r][4 * gq + 2], v3 = acc[r][4 * gq + 3];
+                if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                const int c = 8 * gq + 4 * half;
+                if constexpr (OUT_F32) {
+                    *(float4 *)((float *)yout + vox * CV_C + c) = make_float4(v0, v1, v2, v3);
+                } else {
+                    const u32x2_t pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                    *(u32x2_t *)((bf16_t *)yout + vox * CV_C + c) = pk;
+                }
+            }
+        }
+        __syncthreads();  // slab d+2 has landed (vmcnt drained) and slot (d-1) may be refilled
+    }
+}
+
+}  // namespace
+
+extern "C" DFM_API size_t dfm_conv3d_k3_c32_weight_bytes(void) { return (size_t)CV_NFRAG * 64 * 16 + 4096; }
+
+extern "C" DFM_API int dfm_conv3d_k3_c32_pack_weights(const void *weight, int32_t weight_dtype,
+                                                      int32_t cin_total, int32_t cin_offset,
+                                                      void *packed, void *stream)
+{
+    if (!weight || !packed) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (cin_total < 32 || cin_offset < 0 || cin_offset + 32 > cin_total)
+        return set_error(DFM_ERR_INVALID_ARG, "need a 32-channel slice of the input channels");
+    if (weight_dtype != DFM_F32 && weight_dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "weight dtype must be DFM_F32 or DFM_BF16");
+    hipStream_t st = (hipStream_t)stream;
+    // the zero page (out-of-bounds pixels read it) sits behind the fragments
+    hipError_t e = hipMemsetAsync((char *)packed + (size_t)CV_NFRAG * 64 * 16, 0, 4096, st);
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    if (weight_dtype == DFM_F32)
+        hipLaunchKernelGGL(conv3d_pack_weights_kernel<float>, dim3(CV_NFRAG), dim3(64), 0, st,
+                           (const float *)weight, cin_total, cin_offset, (bf16_t *)packed);
+    else
+        hipLaunchKernelGGL(conv3d_pack_weights_kernel<bf16_t>, dim3(CV_NFRAG), dim3(64), 0, st,
+                           (const bf16_t *)weight, cin_total, cin_offset, (bf16_t *)packed);
+    e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+extern "C" DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
+                                             const void *packed_weights, const float *acc_in,
+                                             void *out, int32_t out_f32, int32_t relu,
+                                             int32_t depth_chunk, void *stream)
+{
+    if (n <= 0 || d <= 0 || h <= 0 || w <= 0) return set_error(DFM_ERR_INVALID_ARG, "non-positive size");
+    if (!x || !packed_weights || !out) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if ((long long)h * w * 64 >= (1ll << 31)) return set_error(DFM_ERR_UNSUPPORTED, "depth plane too large");
+    if (n > 65535) return set_error(DFM_ERR_UNSUPPORTED, "batch > 65535");
+    ConvGeom g;
+    g.N = n; g.D = d; g.H = h; g.W = w;
+    g.tiles_w = (w + CV_TW - 1) / CV_TW;
+    g.tiles_h = (h + CV_TH - 1) / CV_TH;
+    g.relu = relu ? 1 : 0;
+    // depth chunk: enough workgroups for >= 4 rounds over the 256 CUs, at least 8 planes per
+    // chunk (each chunk re-stages 2 halo slabs)
+    int dc = depth_chunk;
+    if (dc <= 0) {
+        const long long cols = (long long)g.tiles_w * g.tiles_h * n;
+        long long chunks = (4 * 256 + cols - 1) / cols;
+        dc = (int)std::max<long long>(8, (d + chunks - 1) / chunks);
+    }
+    dc = std::min(dc, d);
+    g.dchunk = dc;
+    const int nchunks = (d + dc - 1) / dc;
+    if (nchunks > 65535) return set_error(DFM_ERR_UNSUPPORTED, "too many depth chunks");
+    const uint4 *wfrag = (const uint4 *)packed_weights;
+    const uint4 *zero = wfrag + CV_NFRAG * 64;
+    const int lds = CV_RING * CV_SLAB_BYTES;
+    dim3 grid(g.tiles_w * g.tiles_h, nchunks, n);
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done[4] = {false, false, false, false};
+#define CV_LAUNCH(F32, ACC, IDX)                                                                   \
+    do {                                                                                           \
+        if (!attr_done[IDX]) {                                                                     \
+            hipError_t e_ = hipFuncSetAttribute((const void *)conv3d_k3_c32_kernel<F32, ACC>,      \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
+            if (e_ != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e_));            \
+            attr_done[IDX] = true;                                                                 \
+        }                                                                                          \
+        hipLaunchKernelGGL((conv3d_k3_c32_kernel<F32, ACC>), grid, dim3(256), lds, st, g,          \
+                           (const bf16_t *)x, wfrag, acc_in, out, zero);                           \
+    } while (0)
+    if (out_f32) { if (acc_in) CV_LAUNCH(true, true, 3); else CV_LAUNCH(true, false, 2); }
+    else { if (acc_in) CV_LAUNCH(false, true, 1); else CV_LAUNCH(false, false, 0); }
+#undef CV_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}

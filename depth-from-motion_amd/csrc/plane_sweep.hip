@@ -92,10 +92,12 @@ namespace {
 // ---------------------------------------------------------------------------
 // NCHW -> [B][nblk][H][W][CB]
 // ---------------------------------------------------------------------------
-// Each lane re-blocks PACK_PPL pixels (256 apart) so that PACK_PPL * CB independent loads are in
-// flight per lane: the kernel is latency-bound otherwise (channel planes of an odd-sized map are
-// only element-aligned, so a lane cannot load several pixels of one channel at once).
-constexpr int PACK_PPL = 4;
+// Each lane re-blocks PACK_PPL pixels (256 apart).  One pixel per lane measured fastest in
+// isolation (0.083 ms for the N* maps, 5.8 TB/s read+write; 4 pixels per lane: 0.20 ms --
+// tools/pack_microbench.hip, profiles/r02_c3_pack_microbench.txt).  Inside the pipeline its
+// rocprofv3 duration is ~0.19 ms either way: it starts while the previous launch's 26.8 GB of
+// volume writes are still draining to HBM.
+constexpr int PACK_PPL = 1;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__ src0,
                                                            const T *__restrict__ src1,
@@ -306,7 +308,7 @@ __device__ __forceinline__ void tile_body(
     const uint4 *__restrict__ cur_blk, const uint4 *__restrict__ prev_blk,
     const float *__restrict__ depths, const float *__restrict__ P,
     const float *__restrict__ Pinv, const float *__restrict__ Tm, T *__restrict__ out,
-    int *__restrict__ spill_list)
+    int *__restrict__ spill_list, int blk_lo_ovr = -1, int blk_hi_ovr = -1)
 {
     constexpr int CB = elem<T>::CB;
     // V = points per lane.  V == CB: one 16-byte store per channel (the default).  V == 4 with
@@ -348,8 +350,10 @@ __device__ __forceinline__ void tile_body(
     const int band = (th % nchunks) * tg.band_chunk + band_in;
     const int group = th / nchunks;
     if (band >= tg.bands) return;
-    const int blk_lo = group * tg.blocks_per_group;
-    const int blk_hi = min(blk_lo + tg.blocks_per_group, g.nblk);
+    // (the second-chance pass hands a flagged tile to several workgroups, each with its own
+    // range of channel blocks)
+    const int blk_lo = blk_lo_ovr >= 0 ? blk_lo_ovr : group * tg.blocks_per_group;
+    const int blk_hi = blk_lo_ovr >= 0 ? min(blk_hi_ovr, g.nblk) : min(blk_lo + tg.blocks_per_group, g.nblk);
     const int lanes_per_plane = NT / tg.planes;
     const int d_tile = dgroup * tg.planes + tid / lanes_per_plane;
     const int tid_p = tid % lanes_per_plane;
@@ -437,8 +441,8 @@ __device__ __forceinline__ void tile_body(
         nslots = (PAD + cnt + 1 + 7) & ~7;
         const bool fits = SLAB + nslots <= lds_slots;
         if (!fits) {
-            // rows beyond the LDS budget: queue the tile for the direct-tap pass
-            if (tid == 0) spill_list[1 + atomicAdd(&spill_list[0], 1)] = bid;
+            // rows beyond the LDS budget: queue the tile for the next pass (once per tile)
+            if (tid == 0 && blk_lo_ovr <= 0) spill_list[1 + atomicAdd(&spill_list[0], 1)] = bid;
             return;
         }
         // LDS byte address of each corner: swizzled slot of pixel q (= index in
@@ -651,6 +655,29 @@ __global__ __launch_bounds__(NT) void sweep_spill_kernel(
     for (int i = blockIdx.x; i < count; i += gridDim.x)
         tile_body<T, NT, false, V>(spill_list[1 + i], g, fast, tg, 0, cur_blk, prev_blk, depths, P,
                                    Pinv, Tm, out, nullptr);
+}
+
+// Second chance for the flagged tiles (about 1 % at N*: the nearest planes of the prev map, whose
+// 3x zoom needs a few rows more than the budget that lets two workgroups share a CU): the same
+// LDS-staged body with (almost) the whole LDS of a CU, each tile split over `groups` workgroups
+// by channel block so the few hundred tiles still fill the chip.  What does not fit even then
+// goes to list_out and the direct-tap pass.  (The direct pass alone cost 0.12-0.17 ms per N* launch.)
+template <typename T, int NT, int V>
+__global__ __launch_bounds__(NT, (V * sizeof(T) == 8 ? 4 : DFM_TILE_WAVES)) void sweep_respill_kernel(
+    SweepGeom g, SweepFast fast, TileGrid tg, int lds_slots, int groups, int blocks_per_group,
+    const uint4 *__restrict__ cur_blk, const uint4 *__restrict__ prev_blk,
+    const float *__restrict__ depths, const float *__restrict__ P, const float *__restrict__ Pinv,
+    const float *__restrict__ Tm, T *__restrict__ out, const int *__restrict__ list_in,
+    int *__restrict__ list_out)
+{
+    const int count = list_in[0];
+    for (int i = blockIdx.x; i < count * groups; i += gridDim.x) {
+        const int grp = i % groups;
+        tile_body<T, NT, true, V>(list_in[1 + i / groups], g, fast, tg, lds_slots, cur_blk, prev_blk,
+                                  depths, P, Pinv, Tm, out, list_out, grp * blocks_per_group,
+                                  (grp + 1) * blocks_per_group);
+        __syncthreads();  // the next tile re-initialises the LDS scratch
+    }
 }
 
 // The <= 7 lattice points in front of every depth-plane boundary that the LDS pass
@@ -1373,18 +1400,34 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
     const long long nb = nchunks * tg.band_chunk * tg.dgroups * 2 * d->batch * groups;
     if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
     if ((size_t)(nb + 1) * 4 > flag_bytes(d)) return fail(DFM_ERR_WORKSPACE, "spill list too small%s");
+    int rc = DFM_OK;
     const SweepFast fast = make_fast(d);
     if (which == 2) {
         const void *kern = (const void *)sweep_tile_kernel<T, NT, true, V>;
-        int rc = ensure_dynamic_lds(kern, lds_bytes);
+        rc = ensure_dynamic_lds(kern, lds_bytes);
         if (rc != DFM_OK) return rc;
+        int *spill2 = (int *)((char *)spill_list + flag_bytes(d));
         HIP_TRY(hipMemsetAsync(spill_list, 0, 4, st));
+        HIP_TRY(hipMemsetAsync(spill2, 0, 4, st));
         hipLaunchKernelGGL((sweep_tile_kernel<T, NT, true, V>), dim3((unsigned)nb), dim3(NT),
                            lds_bytes, st, g, fast, tg, lds_bytes / 16, cur_blk, prev_blk, depths, P,
                            Pinv, Tm, out, spill_list);
-        // tiles whose rows exceeded the LDS budget (typically < 1 %)
+        // tiles whose rows exceeded the LDS budget (about 1 % at N*): once more with 144 KiB of
+        // LDS, split by channel block; then direct taps for what is left
+        {
+            // (a test-sized budget below 16 KiB keeps its size, so that the direct pass stays covered)
+            const int BIG = L.lds_kib < 16 ? lds_bytes : 144 * 1024;
+            const void *rk = (const void *)sweep_respill_kernel<T, NT, V>;
+            rc = ensure_dynamic_lds(rk, BIG);
+            if (rc != DFM_OK) return rc;
+            const int rgroups = std::min(8, g.nblk);
+            const int rbpg = (g.nblk + rgroups - 1) / rgroups;
+            hipLaunchKernelGGL((sweep_respill_kernel<T, NT, V>), dim3(1024), dim3(NT), BIG, st, g, fast,
+                               tg, BIG / 16, rgroups, rbpg, cur_blk, prev_blk, depths, P, Pinv, Tm, out,
+                               (const int *)spill_list, spill2);
+        }
         hipLaunchKernelGGL((sweep_spill_kernel<T, NT, V>), dim3(512), dim3(NT), 16, st, g, fast, tg,
-                           cur_blk, prev_blk, depths, P, Pinv, Tm, out, spill_list);
+                           cur_blk, prev_blk, depths, P, Pinv, Tm, out, spill2);
         if (g.D > 1 && hw % 8 != 0)
             hipLaunchKernelGGL(sweep_patch_kernel<T>, dim3(g.D - 1, 2, d->batch), dim3(256), 0, st,
                                g, fast, cur_blk, prev_blk, depths, P, Pinv, Tm, out);
@@ -1471,7 +1514,7 @@ int check_fwd_args(const dfm_sweep_desc *desc, const void *cur, const void *prev
     if (rc != DFM_OK) return rc;
     if (!cur || !prev || !depths || !cam2img || !cam2img_inv || !cur2prev || !out)
         return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
-    if (!workspace || workspace_bytes < 2 * blocked_bytes(desc) + flag_bytes(desc))
+    if (!workspace || workspace_bytes < 2 * blocked_bytes(desc) + 2 * flag_bytes(desc))
         return fail(DFM_ERR_WORKSPACE, "workspace smaller than dfm_plane_sweep_workspace_bytes%s");
     if (((uintptr_t)workspace & 15) || ((uintptr_t)out & 1))
         return fail(DFM_ERR_INVALID_ARG, "workspace must be 16-byte aligned%s");
@@ -1578,7 +1621,7 @@ DFM_API int dfm_camera_prepare(const float *cam2img, int32_t rows, int32_t cols,
 DFM_API size_t dfm_plane_sweep_workspace_bytes(const dfm_sweep_desc *desc)
 {
     if (check_desc(desc) != DFM_OK) return 0;
-    return 2 * blocked_bytes(desc) + flag_bytes(desc);
+    return 2 * blocked_bytes(desc) + 2 * flag_bytes(desc);
 }
 
 DFM_API int dfm_plane_sweep_fwd_opts(const dfm_sweep_desc *desc, const void *cur, const void *prev,

@@ -10,15 +10,19 @@ keys, so checkpoints and ``configs/dfm/*`` carry over:
   DfMNeck            mmdet3d/models/necks/dfm_neck.py
 
 The sampling stages call the HIP kernels (plane sweep, frustum-to-voxel,
-depth head).  The 3-D convolution / normalisation stacks are dense
-contractions that currently run on MIOpen through torch: a hand-written MFMA
-implicit-GEMM Conv3d is the "next" row of SURVEY.md 8f and is NOT built yet.
+depth head), GroupNorm(+ReLU) is the fused HIP kernel, and the full-resolution
+3x3x3 convolutions with 32 output channels (dres0 / dres1 / pred / voxel_convs)
+are ``MfmaConv3d``: the hand-written MFMA kernel of csrc/conv3d.hip when the
+stack runs bf16 channels_last_3d.  The remaining convolutions (stride-2 and
+transposed convolutions of the hourglass at 1/8 .. 1/64 of the volume, the
+32 -> 1 prediction conv, the 2-D convs, BN3d necks) are MIOpen through torch.
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .conv3d import MfmaConv3d
 from .depth_head import depth_distribution_loss, depth_head_forward
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .group_norm import HipGroupNorm
@@ -54,6 +58,11 @@ class ConvModule(nn.Module):
         super().__init__()
         conv_type = 'Conv2d' if conv_cfg is None else conv_cfg['type']
         conv_cls = {'Conv2d': nn.Conv2d, 'Conv3d': nn.Conv3d}[conv_type]
+        if (conv_type == 'Conv3d' and out_channels == 32 and in_channels % 32 == 0 and kernel_size == 3
+                and stride == 1 and padding == 1 and norm_cfg is not None):
+            # the full-resolution 3x3x3 convolutions of the aggregation stacks: nn.Conv3d whose
+            # bf16 / NDHWC forward is the hand-written MFMA kernel (csrc/conv3d.hip)
+            conv_cls = MfmaConv3d
         self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride,
                              padding=padding, bias=norm_cfg is None)
         self.norm_name = None

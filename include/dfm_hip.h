@@ -385,6 +385,31 @@ DFM_API int dfm_depth_head_bwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
                                const void *grad_preds, float *grad_cost, void *stream);
 
 /* ---------------------------------------------------------------------- */
+/* MFMA Conv3d 3x3x3, stride 1, pad 1, 32 -> 32 channels, NDHWC bf16         */
+/* (ConvModule / convbn_3d of the aggregation stacks: dfm_backbone.py:50-128, */
+/*  utils/conv_modules.py:27-43)                                              */
+/* ---------------------------------------------------------------------- */
+/* Bytes of the packed-weight buffer (54 MFMA fragments + a zero page). */
+DFM_API size_t dfm_conv3d_k3_c32_weight_bytes(void);
+/* weight : (32, cin_total, 3, 3, 3) contiguous, DFM_F32 or DFM_BF16 [device]; packs the 32 input
+ * channels [cin_offset, cin_offset + 32) into `packed` (register-fragment order, bf16). */
+DFM_API int dfm_conv3d_k3_c32_pack_weights(const void *weight, int32_t weight_dtype,
+                                           int32_t cin_total, int32_t cin_offset, void *packed,
+                                           void *stream);
+/*
+ * x       : (n, d, h, w, 32) bf16, channels-last                       [device]
+ * acc_in  : NULL, or a fp32 partial (n, d, h, w, 32) to start from (a 64-channel input runs as
+ *           two calls: the first with out_f32 = 1, the second with acc_in = that partial)
+ * out     : (n, d, h, w, 32) bf16 -- or fp32 when out_f32 != 0
+ * relu    : != 0 applies max(., 0) before the store
+ * depth_chunk : output planes one workgroup walks (0 = chosen from the shape)
+ * fp32 accumulation over the 27 x 32 products of a voxel (v_mfma_f32_32x32x16_bf16).
+ */
+DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
+                                  const void *packed_weights, const float *acc_in, void *out,
+                                  int32_t out_f32, int32_t relu, int32_t depth_chunk, void *stream);
+
+/* ---------------------------------------------------------------------- */
 /* DepthHead.loss, dense_heads/depth_head.py:75-188 (called at dfm.py:348) */
 /* ---------------------------------------------------------------------- */
 typedef enum dfm_depth_loss_target {

@@ -32,6 +32,8 @@ def pkg():
 #   lds128/256: LDS-staged tile kernel, 128- / 256-lane workgroups
 #   lds_spill : LDS budget too small for any tile -> every tile is flagged and
 #               redone by the direct-tap pass
+#   lds_respill: budget too small for most tiles -> flagged tiles take the second-chance LDS pass
+#               (144 KiB, split by channel block)
 #   direct    : tile kernel with direct taps for every tile (strided sweeps)
 #   lds256_chunk: shipped shape with 3 adjacent bands scheduled back to back
 #   lds512_v4 / lds1024_v4: 4 points per lane (bf16: 8-byte stores, 4 waves per SIMD)
@@ -47,6 +49,7 @@ MODES = {'gather': dict(kernel=1, lanes=256, lds_kib=64, blocks_per_group=4, pla
                             bands_per_chunk=2),
          'lds_spill': dict(kernel=2, lanes=128, lds_kib=4, blocks_per_group=2, planes=2,
                            bands_per_chunk=2),
+         'lds_respill': dict(kernel=2, lanes=256, lds_kib=16, planes=2),
          'direct': dict(kernel=3, lanes=256, lds_kib=64, blocks_per_group=4, planes=1)}
 
 

@@ -2,7 +2,9 @@
 """DfMBackbone forward at the config-K size (1 sample, 32-ch 320x1280 feats, D=72):
 plane sweep + 3-D aggregation; reference memory layout vs channels_last_3d end to end
 (cost volume written (B,D,H,W,2C), NDHWC Conv3d, channels-last fused GroupNorm).
-MIOpen autotuning (cudnn.benchmark) is OFF: it costs minutes of GPU time per process."""
+MIOpen autotuning (cudnn.benchmark) is OFF unless DFM_MIOPEN_FIND=1: it costs minutes of GPU
+time per process.  In bf16 + channels_last_3d the 32-channel 3x3x3 convolutions run in the
+hand-written MFMA kernel (DFM_NO_MFMA_CONV=1 sends them to MIOpen for an A/B)."""
 import importlib, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +12,9 @@ import bench
 pkg = importlib.import_module('depth-from-motion_amd')
 mods = importlib.import_module('depth-from-motion_amd.modules')
 dev = torch.device('cuda:0')
+torch.backends.cudnn.benchmark = os.environ.get('DFM_MIOPEN_FIND') == '1'
+if os.environ.get('DFM_NO_MFMA_CONV') == '1':
+    importlib.import_module('depth-from-motion_amd.conv3d').MfmaConv3d.eligible = lambda self, x: False
 outs = {}
 for dtype in (torch.float32, torch.bfloat16):
     for fmt in (torch.contiguous_format, torch.channels_last_3d):
