@@ -217,7 +217,7 @@ def lib():
     h.dfm_depth_head_bwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, fp, vp]
     h.dfm_conv3d_k3_c32_weight_bytes.restype = sz
     h.dfm_conv3d_k3_c32_pack_weights.restype = ctypes.c_int
-    h.dfm_conv3d_k3_c32_pack_weights.argtypes = [vp, i32, i32, i32, vp, vp]
+    h.dfm_conv3d_k3_c32_pack_weights.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     h.dfm_conv3d_k3_c32_fwd.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_fwd.argtypes = [i32, i32, i32, i32, vp, vp, fp, vp, i32, i32, i32, vp]
     lp = ctypes.POINTER(DepthLossDesc)

@@ -11,7 +11,8 @@ the MFMA kernel when the input is a bfloat16 ``channels_last_3d`` GPU tensor (wh
 converted with ``.to(torch.bfloat16, memory_format=torch.channels_last_3d)`` produces, fed by the
 channels-last cost volume); any other dtype / layout takes torch's convolution (MIOpen) exactly as
 before -- that is the module's other documented path, not a fallback of a failed launch.
-Backward: torch's convolution backward (MIOpen) on the saved tensors.
+Backward: the input gradient runs in the same MFMA kernel (transposed, mirrored weight
+fragments); the weight gradient is torch's convolution backward (MIOpen).
 """
 import ctypes
 
@@ -24,9 +25,10 @@ from .plane_sweep import _ptr, _stream_ptr
 _WDT = {torch.float32: _capi.DFM_F32, torch.bfloat16: _capi.DFM_BF16}
 
 
-def pack_conv3d_weights(weight, cin_offset=0):
+def pack_conv3d_weights(weight, cin_offset=0, transposed=False):
     """(32, C_in >= 32, 3, 3, 3) fp32/bf16 GPU weight -> MFMA A-operand fragments (+ zero page) for
-    the 32 input channels starting at ``cin_offset``."""
+    the 32 input channels starting at ``cin_offset``.  ``transposed``: fragments of the
+    backward-data convolution (grad_in[:, cin_offset:cin_offset+32] = conv(grad_out, W'))."""
     assert weight.is_cuda and weight.dim() == 5 and weight.shape[0] == 32 and tuple(weight.shape[2:]) == (3, 3, 3)
     w = weight.detach().contiguous()
     if w.dtype not in _WDT:
@@ -35,7 +37,8 @@ def pack_conv3d_weights(weight, cin_offset=0):
     packed = torch.empty(lib.dfm_conv3d_k3_c32_weight_bytes(), dtype=torch.uint8, device=w.device)
     with torch.cuda.device(w.device):
         _capi.check(lib.dfm_conv3d_k3_c32_pack_weights(_ptr(w), _WDT[w.dtype], w.shape[1], cin_offset,
-                                                       _ptr(packed), _stream_ptr(w.device)))
+                                                       1 if transposed else 0, _ptr(packed),
+                                                       _stream_ptr(w.device)))
     return packed
 
 
@@ -85,10 +88,21 @@ class _MfmaConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        gx, gw, _ = torch.ops.aten.convolution_backward(
-            gy.contiguous(memory_format=torch.channels_last_3d), x, weight.to(x.dtype), None,
-            [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1, [True, True, False])
-        return gx, gw.to(weight.dtype), None
+        gy = gy.contiguous(memory_format=torch.channels_last_3d)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # backward-data = the same MFMA kernel on the gradient with transposed, mirrored weights
+            halves = [conv3d_k3_c32(gy, pack_conv3d_weights(weight, 32 * i, transposed=True))
+                      for i in range(weight.shape[1] // 32)]
+            gx = halves[0] if len(halves) == 1 else \
+                torch.cat(halves, dim=1).contiguous(memory_format=torch.channels_last_3d)
+        gw = None
+        if ctx.needs_input_grad[1]:  # backward-weight: MIOpen through torch
+            _, gw, _ = torch.ops.aten.convolution_backward(
+                gy, x, weight.to(x.dtype), None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
+                [False, True, False])
+            gw = gw.to(weight.dtype)
+        return gx, gw, None
 
 
 class MfmaConv3d(nn.Conv3d):

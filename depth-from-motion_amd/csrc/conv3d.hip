@@ -52,31 +52,32 @@ struct ConvGeom {
 };
 
 // weights (C_out, C_in, 3, 3, 3) -> MFMA A-operand fragments [tap*2 + ks][lane][8]:
-// lane l holds W[cout = l & 31][cin = ks*16 + (l >> 5)*8 + j][tap], j = 0..7
+// lane l holds W[cout = l & 31][cin = ks*16 + (l >> 5)*8 + j][tap], j = 0..7.
+// transposed != 0: the fragments of the BACKWARD-DATA convolution (grad_in = conv(grad_out, W')
+// with W'[o][i][tap] = W[i][cin_off + o][26 - tap]: channels swapped, taps mirrored), so the
+// same kernel computes the input gradient.
+template <typename TW>
+__device__ __forceinline__ float conv3d_wload(const TW *w, size_t idx);
+template <>
+__device__ __forceinline__ float conv3d_wload<float>(const float *w, size_t idx) { return w[idx]; }
+template <>
+__device__ __forceinline__ float conv3d_wload<bf16_t>(const bf16_t *w, size_t idx) { return bf16_to_f32(w[idx]); }
+
 template <typename TW>
 __global__ void conv3d_pack_weights_kernel(const TW *__restrict__ w, int cin_total, int cin_off,
-                                           bf16_t *__restrict__ frag)
+                                           int transposed, bf16_t *__restrict__ frag)
 {
     const int f = blockIdx.x;  // fragment: tap*2 + ks
     const int l = threadIdx.x;
     const int tap = f >> 1, ks = f & 1;
-    const int cout = l & 31, cin0 = ks * 16 + (l >> 5) * 8;
+    const int row = l & 31, k0 = ks * 16 + (l >> 5) * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float v = (float)w[((size_t)cout * cin_total + cin_off + cin0 + j) * 27 + tap];
-        frag[((size_t)f * 64 + l) * 8 + j] = f32_to_bf16(v);
+        const size_t idx = transposed
+                               ? ((size_t)(k0 + j) * cin_total + cin_off + row) * 27 + (26 - tap)
+                               : ((size_t)row * cin_total + cin_off + k0 + j) * 27 + tap;
+        frag[((size_t)f * 64 + l) * 8 + j] = f32_to_bf16(conv3d_wload<TW>(w, idx));
     }
-}
-template <>
-__global__ void conv3d_pack_weights_kernel<bf16_t>(const bf16_t *__restrict__ w, int cin_total,
-                                                   int cin_off, bf16_t *__restrict__ frag)
-{
-    const int f = blockIdx.x, l = threadIdx.x;
-    const int tap = f >> 1, ks = f & 1;
-    const int cout = l & 31, cin0 = ks * 16 + (l >> 5) * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        frag[((size_t)f * 64 + l) * 8 + j] = w[((size_t)cout * cin_total + cin_off + cin0 + j) * 27 + tap];
 }
 
 // OUT_F32: write the fp32 partial (N,D,H,W,32) instead of bf16;  ACC_IN: start from a fp32 partial
@@ -234,7 +235,7 @@ extern "C" DFM_API size_t dfm_conv3d_k3_c32_weight_bytes(void) { return (size_t)
 
 extern "C" DFM_API int dfm_conv3d_k3_c32_pack_weights(const void *weight, int32_t weight_dtype,
                                                       int32_t cin_total, int32_t cin_offset,
-                                                      void *packed, void *stream)
+                                                      int32_t transposed, void *packed, void *stream)
 {
     if (!weight || !packed) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     if (cin_total < 32 || cin_offset < 0 || cin_offset + 32 > cin_total)
@@ -247,10 +248,10 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_pack_weights(const void *weight, int32_
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     if (weight_dtype == DFM_F32)
         hipLaunchKernelGGL(conv3d_pack_weights_kernel<float>, dim3(CV_NFRAG), dim3(64), 0, st,
-                           (const float *)weight, cin_total, cin_offset, (bf16_t *)packed);
+                           (const float *)weight, cin_total, cin_offset, transposed, (bf16_t *)packed);
     else
         hipLaunchKernelGGL(conv3d_pack_weights_kernel<bf16_t>, dim3(CV_NFRAG), dim3(64), 0, st,
-                           (const bf16_t *)weight, cin_total, cin_offset, (bf16_t *)packed);
+                           (const bf16_t *)weight, cin_total, cin_offset, transposed, (bf16_t *)packed);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;

@@ -392,10 +392,12 @@ DFM_API int dfm_depth_head_bwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
 /* Bytes of the packed-weight buffer (54 MFMA fragments + a zero page). */
 DFM_API size_t dfm_conv3d_k3_c32_weight_bytes(void);
 /* weight : (32, cin_total, 3, 3, 3) contiguous, DFM_F32 or DFM_BF16 [device]; packs the 32 input
- * channels [cin_offset, cin_offset + 32) into `packed` (register-fragment order, bf16). */
+ * channels [cin_offset, cin_offset + 32) into `packed` (register-fragment order, bf16).
+ * transposed != 0: the weights of the backward-data convolution instead (channels swapped, taps
+ * mirrored): dfm_conv3d_k3_c32_fwd(grad_out, packed) is then grad_in of those 32 channels. */
 DFM_API int dfm_conv3d_k3_c32_pack_weights(const void *weight, int32_t weight_dtype,
-                                           int32_t cin_total, int32_t cin_offset, void *packed,
-                                           void *stream);
+                                           int32_t cin_total, int32_t cin_offset,
+                                           int32_t transposed, void *packed, void *stream);
 /*
  * x       : (n, d, h, w, 32) bf16, channels-last                       [device]
  * acc_in  : NULL, or a fp32 partial (n, d, h, w, 32) to start from (a 64-channel input runs as

@@ -81,8 +81,15 @@ def test_module_is_a_conv3d_with_mfma_forward_and_torch_backward(cv):
     ref = F.conv3d(xb.detach().float(), m.weight.detach().bfloat16().float(), padding=1)
     np.testing.assert_allclose(yb.detach().float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
     np.testing.assert_allclose(y32.detach().cpu().numpy(), ref.cpu().numpy(), rtol=5e-2, atol=5e-2)
-    yb.float().square().mean().backward()
+    gy = torch.randn(yb.shape, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+    yb.backward(gy)
     assert xb.grad is not None and m.weight.grad is not None and torch.isfinite(m.weight.grad).all()
+    # input gradient (MFMA kernel, transposed weights) and weight gradient (MIOpen) vs torch fp32
+    xr = xb.detach().float().requires_grad_(True)
+    wr = m.weight.detach().bfloat16().float().requires_grad_(True)
+    F.conv3d(xr, wr, padding=1).backward(gy.float())
+    np.testing.assert_allclose(xb.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(m.weight.grad.cpu().numpy(), wr.grad.cpu().numpy(), rtol=3e-2, atol=0.5)
     # the packed fragments follow the parameter
     with torch.no_grad():
         m.weight.mul_(2.0)

@@ -16,7 +16,8 @@ torch.backends.cudnn.benchmark = os.environ.get('DFM_MIOPEN_FIND') == '1'
 if os.environ.get('DFM_NO_MFMA_CONV') == '1':
     importlib.import_module('depth-from-motion_amd.conv3d').MfmaConv3d.eligible = lambda self, x: False
 outs = {}
-for dtype in (torch.float32, torch.bfloat16):
+only = os.environ.get('DFM_ONLY', '')
+for dtype in ((torch.bfloat16,) if only == 'bf16' else (torch.float32, torch.bfloat16)):
     for fmt in (torch.contiguous_format, torch.channels_last_3d):
         torch.manual_seed(0)
         m = mods.DfMBackbone(in_channels=32).to(dev).to(dtype).eval()
