@@ -47,6 +47,7 @@ EXPORTS = (
     'dfm_depth_loss_fwd',
     'dfm_depth_loss_bwd',
     'dfm_voxel_sample_fwd',
+    'dfm_voxel_sample_bwd',
     'dfm_group_norm_workspace_bytes',
     'dfm_group_norm_fwd',
     'dfm_group_norm_fwd_channels_last',
@@ -227,6 +228,8 @@ def lib():
     h.dfm_depth_loss_bwd.argtypes = [lp, vp, fp, fp, fp, vp, vp]
     h.dfm_voxel_sample_fwd.restype = ctypes.c_int
     h.dfm_voxel_sample_fwd.argtypes = [ctypes.POINTER(VsDesc), vp, fp, vp, vp]
+    h.dfm_voxel_sample_bwd.restype = ctypes.c_int
+    h.dfm_voxel_sample_bwd.argtypes = [ctypes.POINTER(VsDesc), vp, fp, fp, vp]
     i64, f32 = ctypes.c_int64, ctypes.c_float
     h.dfm_group_norm_workspace_bytes.restype = sz
     h.dfm_group_norm_workspace_bytes.argtypes = [i32, i32, i64, i32]

@@ -626,10 +626,62 @@ __global__ __launch_bounds__(256) void voxel_sample_kernel(VsGeom g, const T *__
     }
 }
 
+// backward of voxel_sample w.r.t. the voxel features: the same coordinates, the gradient of every
+// lattice point scattered to its <= 8 corners (or its nearest voxel) with fp32 atomics
+// (point_fusion.py:396-410 is differentiable through F.grid_sample).
+template <typename T>
+__global__ __launch_bounds__(256) void voxel_sample_bwd_kernel(VsGeom g, const T *__restrict__ gout,
+                                                               const float *__restrict__ depths,
+                                                               float *__restrict__ gvox)
+{
+    const long long N = (long long)g.D * g.h_out * g.w_out;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int w = (int)(i % g.w_out), h = (int)((i / g.w_out) % g.h_out);
+    const int d = (int)(i / ((long long)g.w_out * g.h_out));
+    float x = (float)w * g.ds, y = (float)h * g.ds;
+    const float depth = depths[d];
+    if (g.flip) x = g.ori_w - x;
+    x = x + g.crop_x; y = y + g.crop_y;
+    x = x / g.scale_x; y = y / g.scale_y;
+    const float h0 = x * depth, h1 = y * depth;
+    float gr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float X = dot4_chain(h0, h1, depth, 1.0f, g.Minv + 4 * k);
+        const float gsz = (g.range[3 + k] - g.range[k]) / g.vsize[k];
+        const float v = (X - g.range[k]) / g.vsize[k] - 0.5f;
+        gr[k] = v / gsz * 2.0f - 1.0f;
+    }
+    const size_t vol = (size_t)g.Nx * g.Ny * g.Nz;
+    if (g.mode) {
+        const Tri t = make_tri(gr[2], gr[1], gr[0], g.Nx, g.Ny, g.Nz);
+        if (!t.ok) return;
+        for (int c = 0; c < g.C; ++c) {
+            const float gv = elem<T>::load(gout[(size_t)c * N + i]);
+            if (gv == 0.0f) continue;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (t.ok & (1u << k)) atomicAdd(gvox + c * vol + t.o[k], gv * t.w[k]);
+        }
+    } else {
+        const float ix = ((gr[2] + 1.0f) / 2.0f) * (float)(g.Nz - 1);
+        const float iy = ((gr[1] + 1.0f) / 2.0f) * (float)(g.Ny - 1);
+        const float iz = ((gr[0] + 1.0f) / 2.0f) * (float)(g.Nx - 1);
+        const float xr = rintf(ix), yr = rintf(iy), zr = rintf(iz);
+        const bool in = fabsf(ix) <= 1.0e9f && fabsf(iy) <= 1.0e9f && fabsf(iz) <= 1.0e9f &&
+                        xr >= 0.0f && xr <= (float)(g.Nz - 1) && yr >= 0.0f &&
+                        yr <= (float)(g.Ny - 1) && zr >= 0.0f && zr <= (float)(g.Nx - 1);
+        if (!in) return;
+        const int o = ((int)zr * g.Ny + (int)yr) * g.Nz + (int)xr;
+        for (int c = 0; c < g.C; ++c) atomicAdd(gvox + c * vol + o, elem<T>::load(gout[(size_t)c * N + i]));
+    }
+}
+
 }  // namespace
 
-extern "C" DFM_API int dfm_voxel_sample_fwd(const dfm_vs_desc *d, const void *voxel_features,
-                                            const float *depths, void *out, void *stream)
+namespace {
+int vs_geom(const dfm_vs_desc *d, VsGeom &g)
 {
     if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
     if (d->channels <= 0 || d->nx <= 0 || d->ny <= 0 || d->nz <= 0 || d->num_depths <= 0 ||
@@ -637,10 +689,8 @@ extern "C" DFM_API int dfm_voxel_sample_fwd(const dfm_vs_desc *d, const void *vo
         return set_error(DFM_ERR_INVALID_ARG, "non-positive size in dfm_vs_desc");
     if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
         return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
-    if (!voxel_features || !depths || !out) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     if ((long long)d->nx * d->ny * d->nz >= (1ll << 31))
         return set_error(DFM_ERR_UNSUPPORTED, "volume too large for 32-bit corner offsets");
-    VsGeom g;
     g.C = d->channels; g.Nx = d->nx; g.Ny = d->ny; g.Nz = d->nz;
     g.D = d->num_depths; g.h_out = d->h_out; g.w_out = d->w_out;
     g.flip = d->flip; g.mode = d->mode; g.ds = d->downsample_factor;
@@ -649,6 +699,17 @@ extern "C" DFM_API int dfm_voxel_sample_fwd(const dfm_vs_desc *d, const void *vo
     for (int k = 0; k < 6; ++k) g.range[k] = d->voxel_range[k];
     for (int k = 0; k < 3; ++k) g.vsize[k] = d->voxel_size[k];
     for (int k = 0; k < 16; ++k) g.Minv[k] = d->proj_inv[k];
+    return DFM_OK;
+}
+}  // namespace
+
+extern "C" DFM_API int dfm_voxel_sample_fwd(const dfm_vs_desc *d, const void *voxel_features,
+                                            const float *depths, void *out, void *stream)
+{
+    VsGeom g;
+    int rc = vs_geom(d, g);
+    if (rc != DFM_OK) return rc;
+    if (!voxel_features || !depths || !out) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     const long long N = (long long)d->num_depths * d->h_out * d->w_out;
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == DFM_F32)
@@ -657,6 +718,28 @@ extern "C" DFM_API int dfm_voxel_sample_fwd(const dfm_vs_desc *d, const void *vo
     else
         hipLaunchKernelGGL(voxel_sample_kernel<bf16_t>, dim3((unsigned)((N + 255) / 256)), dim3(256),
                            0, st, g, (const bf16_t *)voxel_features, depths, (bf16_t *)out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+extern "C" DFM_API int dfm_voxel_sample_bwd(const dfm_vs_desc *d, const void *grad_out,
+                                            const float *depths, float *grad_voxel_features,
+                                            void *stream)
+{
+    VsGeom g;
+    int rc = vs_geom(d, g);
+    if (rc != DFM_OK) return rc;
+    if (!grad_out || !depths || !grad_voxel_features)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    const long long N = (long long)d->num_depths * d->h_out * d->w_out;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == DFM_F32)
+        hipLaunchKernelGGL(voxel_sample_bwd_kernel<float>, dim3((unsigned)((N + 255) / 256)), dim3(256),
+                           0, st, g, (const float *)grad_out, depths, grad_voxel_features);
+    else
+        hipLaunchKernelGGL(voxel_sample_bwd_kernel<bf16_t>, dim3((unsigned)((N + 255) / 256)),
+                           dim3(256), 0, st, g, (const bf16_t *)grad_out, depths, grad_voxel_features);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;

@@ -768,45 +768,107 @@ __global__ __launch_bounds__(256) void sweep_bwd_kernel(
 
 // ---------------------------------------------------------------------------
 // backward: LDS-accumulating tiles.
-// A workgroup owns one band of lattice points (same (h, w) range) of ONE map over a chunk
-// of depth planes.  Per pass of CW channels the taps' gradients are added into a slab of
-// feature rows in LDS ([channel][row][x], 64-bit fixed point: integer LDS atomics run at
-// 10-14 lanes per clock, ds_add_f32 at 0.33 -- profiles/r01_atomic_microbench.txt; lanes are
-// consecutive points, so a wave's adds land in consecutive banks); the slab goes to the
-// global gradient with ONE coalesced fp32 atomic per touched pixel when the chunk is done
-// or when the footprint of the next plane has drifted out of the slab window (prev map,
-// near planes).
-//   cur map : its footprint does not depend on depth (it samples AT the lattice points), so
-//             a lane first sums its gradients over the planes in registers ("runs") and
-//             scatters once per chunk;
-//   prev map: the footprint drifts with depth; the four taps are scattered per plane.
-// The sampling positions are recomputed per (plane, channel pass) with the forward
-// kernel's own sweep_point_map and make_tap's arithmetic: taps and weights ARE the forward's.
+// A workgroup = one band of 256 lattice points (same (h, w) for every plane) of ONE map x G plane
+// groups (1024 lanes, G = 4 for the prev map; 512 lanes, G = 2 for the cur map), over a chunk of
+// <= BWD_MAXP depth planes: lane (tid & 255) is the point, (tid >> 8) takes the planes
+// p = group, group + G, ...
+//   * Footprints once: a prologue computes every (plane, point) sampling position with the
+//     forward kernel's own sweep_point_map and keeps it in an LDS table (corner + in-bounds bits
+//     and the two fractions: 12 bytes per entry), so the C/CW channel passes that follow never
+//     touch the geometry again.  (Round 1 re-derived the position per plane per pass and was
+//     VALU-bound on exactly that: 34 of 39 ms at N*.)
+//   * Per pass of CW channels the taps' gradients are added into a slab of feature rows in LDS
+//     ([channel][row][x], 64-bit two's-complement fixed point: integer LDS atomics run at 10-14
+//     lanes per clock, ds_add_f32 at 0.33 -- profiles/r01_atomic_microbench.txt); the slab goes
+//     to the global gradient with ONE coalesced fp32 atomic per touched pixel at the end of each
+//     slab window (the longest run of planes whose rows fit; the chunk, unless the footprint
+//     drifts far).
+//       cur map : x = w +- 1e-5, the footprint stays inside a 3x3 block anchored at the lane's
+//                 smallest corner: gradients are summed over the lane's planes in registers and
+//                 scattered once per window (a lane whose footprint leaves its block -- general
+//                 poses -- scatters that plane's taps straight to memory);
+//       prev map: the footprint drifts with depth; the four taps are scattered per plane.
+//   * The fixed-point scale is LOCAL: the prev kernel scans the pass's gradient values of its own
+//     (chunk, band) first (they are re-read from L2 right after), the cur kernel takes the maximum
+//     of its register sums at scatter time -- no pass over the whole gradient volume
+//     (absmax_bits_kernel: 5 ms of the 39 at N*), no device allocation.  An all-zero pass is
+//     skipped; a pass holding Inf / NaN takes plain float atomics so they propagate like torch's.
 // ---------------------------------------------------------------------------
-constexpr int BWD_PPL = 1;    // lattice points per lane and plane
 constexpr int BWD_MAXP = 32;  // depth planes per workgroup, at most
+constexpr int BWD_PTS = 256;  // lattice points per band
+// plane groups per workgroup: 4 for the prev map (70 VGPRs, LDS-atomic latency wants many waves),
+// 2 for the cur map (its 3x3 register block needs more than the 128 VGPRs a 1024-lane group allows)
+__host__ __device__ constexpr int bwd_groups(int half) { return half ? 4 : 2; }
 
 struct BwdGrid {
     int batch, bands, band_pts, planes, dchunks, rows;
+    int ablate;  // debug builds only (DFM_BWD_ABLATE): 1 no gradient loads, 2 no slab atomics, 4 no flush
     int row_tiles;  // 0: bands are runs of band_pts points of the flat (h, w) index;
                     // > 0 (strided sweeps): that many bands per lattice row, none crossing rows --
                     // consecutive lattice rows sample feature rows `cost_sample_factor` apart,
                     // which one slab window cannot hold
 };
 
-template <typename T, int HALF, int BWD_CW>
-__device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFast &fast,
-                                              const BwdGrid &tg, int b, int band, int dchunk,
-                                              const T *__restrict__ gout,
-                                              const float *__restrict__ depths,
-                                              const float *__restrict__ P,
-                                              const float *__restrict__ Pinv,
-                                              const float *__restrict__ Tm,
-                                              float *__restrict__ gfeat,
-                                              unsigned long long *slab, int *yr, float fx_scale,
-                                              float fx_inv)
+// packed footprint of one (plane, point): bit 31 valid, 27..30 = wok eok nok sok,
+// 13..25 = ixw + 1, 0..12 = iyn + 1 (corner in [-1, W-1] x [-1, H-1])
+__device__ __forceinline__ uint32_t bwd_footprint(float sx, float sy, int H, int W, float &fw, float &fn)
 {
-    const int tid = threadIdx.x;
+    const bool fin = (fabsf(sx) <= 3.0e38f) && (fabsf(sy) <= 3.0e38f);
+    const float xw = floorf(sx), yn = floorf(sy);
+    fw = sx - xw;
+    fn = sy - yn;
+    const bool wok = fin && xw >= 0.0f && xw <= (float)(W - 1);
+    const bool eok = fin && xw >= -1.0f && xw <= (float)(W - 2);
+    const bool nok = fin && yn >= 0.0f && yn <= (float)(H - 1);
+    const bool sok = fin && yn >= -1.0f && yn <= (float)(H - 2);
+    if (!((wok || eok) && (nok || sok))) return 0u;
+    const int ixw = (int)xw, iyn = (int)yn;
+    return 0x80000000u | ((uint32_t)wok << 27) | ((uint32_t)eok << 28) | ((uint32_t)nok << 29) |
+           ((uint32_t)sok << 30) | ((uint32_t)(ixw + 1) << 13) | (uint32_t)(iyn + 1);
+}
+
+// float -> 64-bit two's-complement fixed point (|x| < 2^61 after scaling; exact for the 24
+// significant bits of x)
+__device__ __forceinline__ unsigned long long bwd_to_fixed(float x)
+{
+    const float hif = floorf(x * 2.3283064365386963e-10f);
+    const float lof = __builtin_fmaf(hif, -4294967296.0f, x);  // in [0, 2^32]
+    return ((unsigned long long)(unsigned)(int)hif << 32) + (unsigned long long)lof;
+}
+
+// scale 2^sh with max|x| * 2^sh < 2^50 from the raw bits of max|x| (finite, non-zero)
+__device__ __forceinline__ void bwd_scale(unsigned mb, float &fx_scale, float &fx_inv)
+{
+    const int sh = min(120, max(-100, 50 - ((int)(mb >> 23) - 127 + 1)));
+    fx_scale = __uint_as_float((unsigned)(sh + 127) << 23);
+    fx_inv = __uint_as_float((unsigned)(127 - sh) << 23);
+}
+
+#ifdef DFM_DEBUG_HOOKS
+#define BWD_ABLATE(bit) ((tg.ablate & (bit)) != 0)
+#else
+#define BWD_ABLATE(bit) false
+#endif
+template <typename T, int CW, int HALF>
+__global__ __launch_bounds__(BWD_PTS * bwd_groups(HALF)) void sweep_bwd_tile_kernel(
+    SweepGeom g, SweepFast fast, BwdGrid tg, const T *__restrict__ gout,
+    const float *__restrict__ depths, const float *__restrict__ P, const float *__restrict__ Pinv,
+    const float *__restrict__ Tm, float *__restrict__ gcur, float *__restrict__ gprev)
+{
+    constexpr int BWD_GROUPS = bwd_groups(HALF);
+    constexpr int NT = BWD_PTS * BWD_GROUPS;
+    constexpr int VB = 8;  // plane slots whose gradient values are fetched together (one latency)
+    extern __shared__ __attribute__((aligned(16))) unsigned long long slab[];
+    __shared__ int yr[2 * BWD_MAXP];
+    __shared__ unsigned wgm[3];  // rotating slots of the workgroup-wide maximum (see wg_max)
+    __shared__ int wins[4 * BWD_MAXP + 1];  // slab windows of the chunk: count, then {first, last plane, y0, top}
+    // block id = (band*dchunks + dchunk)*batch + b
+    int th = blockIdx.x;
+    const int b = th % tg.batch;
+    th /= tg.batch;
+    const int dchunk = th % tg.dchunks;
+    const int band = th / tg.dchunks;
+    const int tid = threadIdx.x, pt = tid & (BWD_PTS - 1), grp = tid >> 8;
     const int hw = g.h_out * g.w_out;
     const int W = g.w_in, H = g.h_in, HW = H * W;
     int p_lo = band * tg.band_pts, p_hi = min(p_lo + tg.band_pts, hw);
@@ -816,365 +878,291 @@ __device__ __forceinline__ void bwd_tile_body(const SweepGeom &g, const SweepFas
         p_hi = min(p_lo + tg.band_pts, (row + 1) * g.w_out);
     }
     const int d_lo = dchunk * tg.planes, d_hi = min(d_lo + tg.planes, g.D);
+    const int np = d_hi - d_lo;
     const int rows = tg.rows, slab_c = rows * W;
+    // footprint table behind the slab: [plane][point] x {packed, fw, fn}
+    uint32_t *fpT = (uint32_t *)(slab + (size_t)CW * slab_c);
+    float *fwT = (float *)(fpT + tg.planes * BWD_PTS);
+    float *fnT = fwT + tg.planes * BWD_PTS;
     const float *Pb = P + b * 16, *Pib = Pinv + b * 16, *Tb = Tm + b * 16;
+    const int idx = p_lo + pt;
+    const bool live = idx < p_hi;
+    const int hi = idx / g.w_out, wi = idx - hi * g.w_out;
 
-    int idx[BWD_PPL], hi[BWD_PPL], wi[BWD_PPL];
-#pragma unroll
-    for (int k = 0; k < BWD_PPL; ++k) {
-        idx[k] = p_lo + k * 256 + tid;
-        hi[k] = idx[k] / g.w_out;
-        wi[k] = idx[k] - hi[k] * g.w_out;
-    }
-    for (int i = tid; i < 2 * BWD_MAXP; i += 256) yr[i] = (i & 1) ? -1 : 0x7fffffff;
-    for (int i = tid; i < BWD_CW * slab_c; i += 256) slab[i] = 0ull;
+    for (int i = tid; i < 2 * BWD_MAXP; i += NT) yr[i] = (i & 1) ? -1 : 0x7fffffff;
+    for (int i = tid; i < CW * slab_c; i += NT) slab[i] = 0ull;
+    if (tid < 3) wgm[tid] = 0u;
     __syncthreads();
-    // rows every plane of the chunk touches
-    for (int d = d_lo; d < d_hi; ++d) {
+    // workgroup-wide maximum with ONE barrier per call: round k accumulates into slot k % 3 and
+    // clears slot (k + 1) % 3, which nobody reads (round k - 1 reads slot (k - 1) % 3) or
+    // writes (round k + 1 starts after this barrier) meanwhile
+    int mround = 0;
+    auto wg_max = [&](unsigned m) -> unsigned {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        const int slot = mround % 3;
+        if ((tid & 63) == 0 && m) atomicMax(&wgm[slot], m);
+        if (tid == 0) wgm[(mround + 1) % 3] = 0u;
+        __syncthreads();
+        ++mround;
+        return wgm[slot];
+    };
+
+    // ---- footprints of the band's points in every plane of the chunk -> LDS table ------------
+    int bx = 0x7fffffff, by = 0x7fffffff;  // cur map: block anchor = this lane's smallest corner
+    for (int p = grp; p < np; p += BWD_GROUPS) {
         int ymin = 0x7fffffff, ymax = -1;
-        const float depth = depths[d];
-#pragma unroll
-        for (int k = 0; k < BWD_PPL; ++k) {
-            if (idx[k] >= p_hi) continue;
+        uint32_t f = 0u;
+        float fw = 0.0f, fn = 0.0f;
+        if (live) {
             float sx, sy;
-            sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, hi[k], wi[k], sx, sy);
-            const Tap t = make_tap(sx, sy, H, W);
-            if (t.ok & 3u) { ymin = min(ymin, t.iy); ymax = max(ymax, t.iy); }
-            if (t.ok & 12u) { ymin = min(ymin, t.iy + t.dy); ymax = max(ymax, t.iy + t.dy); }
+            sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depths[d_lo + p], hi, wi, sx, sy);
+            f = bwd_footprint(sx, sy, H, W, fw, fn);
+            if (f) {
+                const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
+                if (f & (1u << 29)) { ymin = min(ymin, iyn); ymax = max(ymax, iyn); }
+                if (f & (1u << 30)) { ymin = min(ymin, iyn + 1); ymax = max(ymax, iyn + 1); }
+                bx = min(bx, ixw);
+                by = min(by, iyn);
+            }
         }
+        fpT[p * BWD_PTS + pt] = f;
+        fwT[p * BWD_PTS + pt] = fw;
+        fnT[p * BWD_PTS + pt] = fn;
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) {
-            ymin = min(ymin, __shfl_xor(ymin, s));
-            ymax = max(ymax, __shfl_xor(ymax, s));
+        for (int s2 = 32; s2 > 0; s2 >>= 1) {
+            ymin = min(ymin, __shfl_xor(ymin, s2));
+            ymax = max(ymax, __shfl_xor(ymax, s2));
         }
         if ((tid & 63) == 0 && ymax >= 0) {
-            atomicMin(&yr[2 * (d - d_lo)], ymin);
-            atomicMax(&yr[2 * (d - d_lo) + 1], ymax);
+            atomicMin(&yr[2 * p], ymin);
+            atomicMax(&yr[2 * p + 1], ymax);
         }
     }
     __syncthreads();
+    // slab windows: maximal runs of planes whose rows fit `rows` slab rows -- the same for every
+    // channel pass, so they are laid out once
+    if (tid == 0) {
+        int nw = 0, p = 0;
+        while (p < np) {
+            while (p < np && yr[2 * p + 1] < yr[2 * p]) ++p;  // planes that miss the map
+            if (p >= np) break;
+            int umin = yr[2 * p], umax = yr[2 * p + 1], e = p;
+            while (e + 1 < np) {
+                const int l2 = yr[2 * (e + 1)], u2 = yr[2 * (e + 1) + 1];
+                if (u2 >= l2) {
+                    if (max(umax, u2) - min(umin, l2) + 1 > rows) break;
+                    umin = min(umin, l2);
+                    umax = max(umax, u2);
+                }
+                ++e;
+            }
+            wins[1 + 4 * nw] = p;
+            wins[2 + 4 * nw] = e;
+            wins[3 + 4 * nw] = umin;
+            wins[4 + 4 * nw] = min(umax, umin + rows - 1);
+            ++nw;
+            p = e + 1;
+        }
+        wins[0] = nw;
+    }
+    __syncthreads();
+    const int nwin = __builtin_amdgcn_readfirstlane(wins[0]);
 
-    const T *go = gout + ((size_t)b * 2 * g.C + (size_t)HALF * g.C) * g.N;
-    float *gf = gfeat + (size_t)b * g.C * HW;
-    for (int c0 = 0; c0 < g.C; c0 += BWD_CW) {
-        const int nc = min(BWD_CW, g.C - c0);
+    const T *go = gout + ((size_t)b * 2 * g.C + (size_t)HALF * g.C) * g.N + (size_t)d_lo * hw + min(idx, p_hi - 1);
+    float *gf = (HALF ? gprev : gcur) + (size_t)b * g.C * HW;
+
+    for (int c0 = 0; c0 < g.C; c0 += CW) {
+        const int nc = min(CW, g.C - c0);
+        const T *gp = go + (size_t)c0 * g.N;
+        float fx_scale = 1.0f, fx_inv = 1.0f;
+        bool plain = false;  // Inf / NaN in this pass (window): plain float atomics
         int y0 = -1, top = -1;
         auto flush = [&]() {
+            if (BWD_ABLATE(4)) return;
             const int cnt = (top - y0 + 1) * W;
             for (int c = 0; c < nc; ++c) {
                 unsigned long long *sl = slab + c * slab_c;
                 float *dst = gf + (size_t)(c0 + c) * HW + (size_t)y0 * W;
-                for (int r = tid; r < cnt; r += 256) {
+                for (int r = tid; r < cnt; r += NT) {
                     const unsigned long long v = sl[r];
                     if (v != 0ull) {
-                        // two's-complement fixed point -> float
-                        const float f = __builtin_fmaf((float)(int)(v >> 32), 4294967296.0f,
-                                                       (float)(unsigned)v);
+                        const float f = __builtin_fmaf((float)(int)(v >> 32), 4294967296.0f, (float)(unsigned)v);
                         atomicAdd(dst + r, f * fx_inv);
                         sl[r] = 0ull;
                     }
                 }
             }
         };
-        // Runs over depth (cur map).  A point's gradients are summed in registers, over consecutive
-        // planes, into a 3x3 block of pixels whose corner (by, bx) follows the footprint: a
-        // 2x2 footprint whose corner is (by|by+1, bx|bx+1) fits, and while the block's last
-        // column / row is still unused the block may also move one pixel up or left.  The
-        // block is scattered when the footprint leaves it: once per depth chunk for the cur
-        // map (which samples AT the integers, x = w +- 1e-5: floor(x) flips between two
-        // neighbours, both inside the block), once per two pixels of drift for the prev map.
-        int run_key[BWD_PPL];  // (by + 2) | (bx + 2) << 13 : first row / column of the block; 0 = empty
-        uint32_t run_cells[BWD_PPL];
-        float acc[BWD_PPL][9][BWD_CW];
+        // gradient values of up to VB of this lane's planes (slots k0 .. k0+VB-1; slot k is plane
+        // grp + k*G), all loads in flight together; planes outside the chunk / map give 0
+        auto load_block = [&](int k0, T (&gv)[VB][CW]) {
+            // every load is unconditional (clamped, always-valid address) and the masking happens on
+            // the values afterwards: a load under a runtime condition makes hipcc branch around it
+            // and wait for each one separately (cdna_hip_programming.md, ".s-level traps" (c))
 #pragma unroll
-        for (int k = 0; k < BWD_PPL; ++k) { run_key[k] = 0; run_cells[k] = 0; }
-        auto scatter_run = [&](int k) {
-            const int key = run_key[k];
-            if (key) {
-                const int by = (key & 0x1fff) - 2, bx = (key >> 13) - 2;
+            for (int k = 0; k < VB; ++k) {
+                const int p = min(grp + (k0 + k) * BWD_GROUPS, np - 1);
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int py = by + r;
-                    const int rr = py - y0;
-                    if (rr >= 0 && rr < rows) {
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            if (!(run_cells[k] & (1u << (3 * r + q)))) continue;  // in-bounds cells only
-                            unsigned long long *l = slab + rr * W + (bx + q);
-#pragma unroll
-                            for (int c = 0; c < BWD_CW; ++c)
-                                if (c < nc && acc[k][3 * r + q][c] != 0.0f) {
-                                    // float -> 64-bit two's-complement fixed point (exact split:
-                                    // x has 24 significant bits, |x| < 2^56)
-                                    const float x = acc[k][3 * r + q][c] * fx_scale;
-                                    const float hif = floorf(x * 2.3283064365386963e-10f);
-                                    const float lof = __builtin_fmaf(hif, -4294967296.0f, x);
-                                    const unsigned long long fx =
-                                        ((unsigned long long)(unsigned)(int)hif << 32) | (unsigned)lof;
-                                    atomicAdd(l + c * slab_c, fx);
-                                }
-                        }
-                    } else {  // row outside the slab window: rare, straight to memory
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            if (!(run_cells[k] & (1u << (3 * r + q)))) continue;
-                            float *gl = gf + (size_t)c0 * HW + (size_t)py * W + (bx + q);
-#pragma unroll
-                            for (int c = 0; c < BWD_CW; ++c)
-                                if (c < nc && acc[k][3 * r + q][c] != 0.0f)
-                                    atomicAdd(gl + (size_t)c * HW, acc[k][3 * r + q][c]);
-                        }
-                    }
-                }
+                for (int c = 0; c < CW; ++c) gv[k][c] = gp[(size_t)p * hw + (size_t)min(c, nc - 1) * g.N];
             }
-            run_key[k] = 0;
-            run_cells[k] = 0;
-        };
-        // gradient values are fetched one plane ahead of their use
-        T gv[2][BWD_PPL][BWD_CW];
-        auto fetch = [&](int d, T (&dst)[BWD_PPL][BWD_CW]) {
 #pragma unroll
-            for (int k = 0; k < BWD_PPL; ++k) {
-                // (lanes past the band end re-read the last point; their values are never used)
-                const T *gp = go + (size_t)c0 * g.N + (size_t)d * hw + min(idx[k], p_hi - 1);
+            for (int k = 0; k < VB; ++k) {
+                const int p = grp + (k0 + k) * BWD_GROUPS;
+                const bool on = p < np && fpT[min(p, np - 1) * BWD_PTS + pt] != 0u && !BWD_ABLATE(1);
 #pragma unroll
-                for (int c = 0; c < BWD_CW; ++c) dst[k][c] = gp[(size_t)min(c, nc - 1) * g.N];
+                for (int c = 0; c < CW; ++c) gv[k][c] = (on && c < nc) ? gv[k][c] : T(0);
             }
         };
-        int win_end = d_lo - 1;  // last plane covered by the current slab window
-        auto plane = [&](int d, const T (&src)[BWD_PPL][BWD_CW]) {
-            const int lo = __builtin_amdgcn_readfirstlane(yr[2 * (d - d_lo)]);
-            const int up = __builtin_amdgcn_readfirstlane(yr[2 * (d - d_lo) + 1]);
-            if (up < lo) return;  // nothing of this plane lands inside the map
-            if (d > win_end) {
-                // new slab window: the longest run of planes from here whose rows fit
-                int umin = lo, umax = up, e = d;
-                while (e + 1 < d_hi) {
-                    const int l2 = __builtin_amdgcn_readfirstlane(yr[2 * (e + 1 - d_lo)]);
-                    const int u2 = __builtin_amdgcn_readfirstlane(yr[2 * (e + 1 - d_lo) + 1]);
-                    if (u2 >= l2) {
-                        if (max(umax, u2) - min(umin, l2) + 1 > rows) break;
-                        umin = min(umin, l2);
-                        umax = max(umax, u2);
-                    }
-                    ++e;
-                }
-                if (y0 >= 0) {
-                    // runs do not outlive their window
+
+        if constexpr (HALF == 1) {
+            static_assert(BWD_MAXP / bwd_groups(1) <= VB, "one block holds all planes of a lane");
+            T gv[VB][CW];
+            load_block(0, gv);
+            // ---- scale of this pass: max |grad| over the workgroup's values ----------------
+            unsigned m = 0u;
 #pragma unroll
-                    for (int k = 0; k < BWD_PPL; ++k) scatter_run(k);
-                    __syncthreads();
-                    flush();
-                }
-                y0 = umin;
-                top = min(umax, umin + rows - 1);
-                win_end = e;
-                __syncthreads();
-            }
-            const float depth = depths[d];
+            for (int k = 0; k < VB; ++k)
 #pragma unroll
-            for (int k = 0; k < BWD_PPL; ++k) {
-                if (idx[k] >= p_hi) continue;
-                float sx, sy;
-                sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, hi[k], wi[k], sx, sy);
-                // make_tap's corner, fractions and in-bounds tests, kept separable
-                const bool fin = (fabsf(sx) <= 3.0e38f) && (fabsf(sy) <= 3.0e38f);
-                const float xw = floorf(sx), yn = floorf(sy);
-                const float fw = sx - xw, fe = 1.0f - fw, fn = sy - yn, fs = 1.0f - fn;
-                const bool wok = fin && xw >= 0.0f && xw <= (float)(W - 1);
-                const bool eok = fin && xw >= -1.0f && xw <= (float)(W - 2);
-                const bool nok = fin && yn >= 0.0f && yn <= (float)(H - 1);
-                const bool sok = fin && yn >= -1.0f && yn <= (float)(H - 2);
-                if (!((wok || eok) && (nok || sok))) continue;  // no tap inside the map
-                const int ixw = (int)xw, iyn = (int)yn;  // in [-1, W-1] x [-1, H-1] here
-                if constexpr (HALF == 1) {
-                    // prev map: the footprint drifts with depth, a register run would end
-                    // (and scatter 9 cells) about every second plane -- more values than the
-                    // 4 taps per plane.  Scatter the taps directly; the atomics are cheap, the
-                    // float->fixed conversions are what this path costs.
-                    float gvf[BWD_CW];
+                for (int c = 0; c < CW; ++c) m = max(m, __float_as_uint(elem<T>::load(gv[k][c])) & 0x7fffffffu);
+            const unsigned mb = wg_max(m);
+            if (mb == 0u) continue;  // nothing to add in this pass
+            plain = (mb >> 23) == 0xffu;
+            if (!plain) bwd_scale(mb, fx_scale, fx_inv);
+            // ---- windows of planes; the four taps of every plane go into the slab ----------
+            for (int wi_ = 0; wi_ < nwin; ++wi_) {
+                const int pw = __builtin_amdgcn_readfirstlane(wins[1 + 4 * wi_]);
+                const int pe = __builtin_amdgcn_readfirstlane(wins[2 + 4 * wi_]);
+                y0 = __builtin_amdgcn_readfirstlane(wins[3 + 4 * wi_]);
+                top = __builtin_amdgcn_readfirstlane(wins[4 + 4 * wi_]);
 #pragma unroll
-                    for (int c = 0; c < BWD_CW; ++c) gvf[c] = c < nc ? elem<T>::load(src[k][c]) : 0.0f;
-                    const float cwt = wok ? fe : 0.0f, cet = eok ? fw : 0.0f;
-                    const float rnt = nok ? fs : 0.0f, rst = sok ? fn : 0.0f;
+                for (int k = 0; k < VB; ++k) {
+                    const int p = grp + k * BWD_GROUPS;
+                    if (p < pw || p > pe) continue;
+                    const uint32_t f = fpT[p * BWD_PTS + pt];
+                    if (!f) continue;
+                    const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
+                    const float fw = fwT[p * BWD_PTS + pt], fn = fnT[p * BWD_PTS + pt];
+                    const float cwt = (f & (1u << 27)) ? 1.0f - fw : 0.0f, cet = (f & (1u << 28)) ? fw : 0.0f;
+                    const float rnt = (f & (1u << 29)) ? 1.0f - fn : 0.0f, rst = (f & (1u << 30)) ? fn : 0.0f;
                     const float wq[4] = {rnt * cwt, rnt * cet, rst * cwt, rst * cet};
+                    float gvf[CW];
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) gvf[c] = elem<T>::load(gv[k][c]);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (wq[q] == 0.0f) continue;  // out-of-bounds (or weightless) tap
                         const int py = iyn + (q >> 1), px = ixw + (q & 1);
-                        const int rr = py - y0;  // >= 0: y0 <= the plane's first row
-                        const float ws = wq[q] * fx_scale;
-                        if (rr < rows) {
+                        const int rr = py - y0;  // >= 0: y0 <= the window's first row
+                        if (BWD_ABLATE(2)) continue;
+                        if (rr < rows && !plain) {
                             unsigned long long *l = slab + rr * W + px;
+                            const float ws = wq[q] * fx_scale;
 #pragma unroll
-                            for (int c = 0; c < BWD_CW; ++c) {
-                                if (c >= nc) continue;
-                                const float x = gvf[c] * ws;
-                                const float hif = floorf(x * 2.3283064365386963e-10f);
-                                const float lof = __builtin_fmaf(hif, -4294967296.0f, x);
-                                atomicAdd(l + c * slab_c,
-                                          ((unsigned long long)(unsigned)(int)hif << 32) | (unsigned)lof);
-                            }
-                        } else {  // plane taller than the slab window: rare, straight to memory
+                            for (int c = 0; c < CW; ++c)
+                                if (c < nc) atomicAdd(l + c * slab_c, bwd_to_fixed(gvf[c] * ws));
+                        } else {  // taller than the slab window (rare), or a non-finite pass
                             float *gl = gf + (size_t)c0 * HW + (size_t)py * W + px;
 #pragma unroll
-                            for (int c = 0; c < BWD_CW; ++c)
+                            for (int c = 0; c < CW; ++c)
                                 if (c < nc) atomicAdd(gl + (size_t)c * HW, gvf[c] * wq[q]);
                         }
                     }
-                    continue;
                 }
-                int by = (run_key[k] & 0x1fff) - 2, bx = (run_key[k] >> 13) - 2;
-                int ox = ixw - bx, oy = iyn - by;  // footprint corner inside the block: 0 or 1
-                const uint32_t cells = run_cells[k];
-                const bool fits = run_key[k] != 0 &&
-                                  (ox == 0 || ox == 1 || (ox == -1 && !(cells & 0444u))) &&
-                                  (oy == 0 || oy == 1 || (oy == -1 && !(cells & 0700u)));
-                if (!fits) {
-                    scatter_run(k);
-                    by = iyn; bx = ixw; ox = 0; oy = 0;
-#pragma unroll
-                    for (int cell = 0; cell < 9; ++cell)
-#pragma unroll
-                        for (int c = 0; c < BWD_CW; ++c) acc[k][cell][c] = 0.0f;
-                } else {
-                    if (ox < 0) {  // move the block one pixel left: its last column is empty
-#pragma unroll
-                        for (int r = 0; r < 3; ++r)
-#pragma unroll
-                            for (int c = 0; c < BWD_CW; ++c) {
-                                acc[k][3 * r + 2][c] = acc[k][3 * r + 1][c];
-                                acc[k][3 * r + 1][c] = acc[k][3 * r][c];
-                                acc[k][3 * r][c] = 0.0f;
-                            }
-                        run_cells[k] = (run_cells[k] << 1) & 0666u;
-                        bx -= 1; ox = 0;
-                    }
-                    if (oy < 0) {  // ... one pixel up: its last row is empty
-#pragma unroll
-                        for (int q = 0; q < 3; ++q)
-#pragma unroll
-                            for (int c = 0; c < BWD_CW; ++c) {
-                                acc[k][6 + q][c] = acc[k][3 + q][c];
-                                acc[k][3 + q][c] = acc[k][q][c];
-                                acc[k][q][c] = 0.0f;
-                            }
-                        run_cells[k] = (run_cells[k] << 3) & 0770u;
-                        by -= 1; oy = 0;
-                    }
-                }
-                run_key[k] = (by + 2) | ((bx + 2) << 13);
-                // weights of the block's three rows / columns
-                const float cw = wok ? fe : 0.0f, ce = eok ? fw : 0.0f;
-                const float rn = nok ? fs : 0.0f, rs = sok ? fn : 0.0f;
-                const bool xlo = ox == 0, ylo = oy == 0;
-                const float cx[3] = {xlo ? cw : 0.0f, xlo ? ce : cw, xlo ? 0.0f : ce};
-                const float ry[3] = {ylo ? rn : 0.0f, ylo ? rs : rn, ylo ? 0.0f : rs};
-                const uint32_t mx = xlo ? ((wok ? 1u : 0u) | (eok ? 2u : 0u)) : ((wok ? 2u : 0u) | (eok ? 4u : 0u));
-                const uint32_t my = ylo ? ((nok ? 1u : 0u) | (sok ? 2u : 0u)) : ((nok ? 2u : 0u) | (sok ? 4u : 0u));
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    if (my & (1u << r)) run_cells[k] |= mx << (3 * r);
-                float gvf[BWD_CW];
-#pragma unroll
-                for (int c = 0; c < BWD_CW; ++c) gvf[c] = c < nc ? elem<T>::load(src[k][c]) : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const float wgt = ry[r] * cx[q];
-#pragma unroll
-                        for (int c = 0; c < BWD_CW; ++c)
-                            acc[k][3 * r + q][c] = __builtin_fmaf(gvf[c], wgt, acc[k][3 * r + q][c]);
-                    }
+                __syncthreads();
+                flush();
+                __syncthreads();
             }
-        };
-        fetch(d_lo, gv[0]);
-        for (int d = d_lo; d < d_hi; d += 2) {
-            if (d + 1 < d_hi) fetch(d + 1, gv[1]);
-            plane(d, gv[0]);
-            if (d + 1 < d_hi) {
-                if (d + 2 < d_hi) fetch(d + 2, gv[0]);
-                plane(d + 1, gv[1]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < BWD_PPL; ++k) scatter_run(k);
-        if (y0 >= 0) {
-            __syncthreads();
-            flush();
-        }
-    }
-}
-
-// |x| maximum of the gradient volume as raw bits (|bits| are ordered like the values; a
-// NaN sorts above Inf), one atomicMax per workgroup
-template <typename T>
-__global__ __launch_bounds__(256) void absmax_bits_kernel(const T *__restrict__ x, size_t n,
-                                                          unsigned *__restrict__ out)
-{
-    constexpr int V = 16 / sizeof(T);
-    unsigned m = 0;
-    const size_t nvec = (((uintptr_t)x & 15) == 0) ? n / V : 0;  // 16-byte loads when aligned
-    const uint4 *xv = (const uint4 *)x;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-        const uint4 q = xv[i];
-        if constexpr (sizeof(T) == 4) {
-            m = max(max(m, q.x & 0x7fffffffu), max(q.y & 0x7fffffffu, max(q.z & 0x7fffffffu, q.w & 0x7fffffffu)));
         } else {
-            // two bf16 per dword: compare the high halves and the (shifted up) low halves
-            const unsigned hi = max(max(q.x & 0x7fff0000u, q.y & 0x7fff0000u), max(q.z & 0x7fff0000u, q.w & 0x7fff0000u));
-            const unsigned lo = max(max(q.x & 0x7fffu, q.y & 0x7fffu), max(q.z & 0x7fffu, q.w & 0x7fffu));
-            m = max(m, max(hi, lo << 16));
-        }
-    }
-    for (size_t i = nvec * V + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        if constexpr (sizeof(T) == 4) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
-        else m = max(m, ((unsigned)x[i] & 0x7fffu) << 16);
-    }
+            // ---- cur map: per window, sum over this lane's planes in registers, one scatter -
+            for (int wi_ = 0; wi_ < nwin; ++wi_) {
+                const int pw = __builtin_amdgcn_readfirstlane(wins[1 + 4 * wi_]);
+                const int pe = __builtin_amdgcn_readfirstlane(wins[2 + 4 * wi_]);
+                y0 = __builtin_amdgcn_readfirstlane(wins[3 + 4 * wi_]);
+                top = __builtin_amdgcn_readfirstlane(wins[4 + 4 * wi_]);
+                float acc[9][CW];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
-}
-
-// HALF = 0: gradient of the cur map (register runs), 1: of the prev map (direct scatter; it
-// needs a third of the registers, so it is its own kernel and launch)
-template <typename T, int CW, int HALF>
-__global__ __launch_bounds__(256, 2) void sweep_bwd_tile_kernel(
-    SweepGeom g, SweepFast fast, BwdGrid tg, const T *__restrict__ gout,
-    const unsigned *__restrict__ gmax_bits, const float *__restrict__ depths,
-    const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
-    float *__restrict__ gcur, float *__restrict__ gprev)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned long long bwd_slab[];
-    __shared__ int yr[2 * BWD_MAXP];
-    // Fixed-point scale of the LDS accumulators: integer LDS atomics run at 10-14 lanes per
-    // clock, ds_add_f32 at 0.33 (profiles/r01_atomic_microbench.txt).  With M = max|grad_out|,
-    // a pixel of the slab receives < 2^11 * M in total (<= 32 planes x the <= 44 points whose
-    // footprint can cover it), so x * 2^(50 - exponent(M) - 1) stays below 2^61 and keeps 50
-    // bits below M -- finer than any fp32 accumulation.
-    const unsigned mb = *gmax_bits;
-    if (mb == 0) return;  // an all-zero gradient volume
-    if ((mb >> 23) == 0xffu) {
-        // Inf / NaN in the incoming gradients: they cannot be scaled; poison the result
-        const size_t total = (size_t)tg.batch * g.C * g.h_in * g.w_in;
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-            gcur[i] = __uint_as_float(0x7fc00000u);
-            gprev[i] = __uint_as_float(0x7fc00000u);
+                for (int cell = 0; cell < 9; ++cell)
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) acc[cell][c] = 0.0f;
+                for (int k0 = 0; k0 < BWD_MAXP / BWD_GROUPS; k0 += VB) {
+                    if (grp + k0 * BWD_GROUPS > pe) break;  // uniform per wave (grp is)
+                    T gv[VB][CW];
+                    load_block(k0, gv);
+#pragma unroll
+                    for (int k = 0; k < VB; ++k) {
+                        const int p = grp + (k0 + k) * BWD_GROUPS;
+                        if (p < pw || p > pe) continue;
+                        const uint32_t f = fpT[p * BWD_PTS + pt];
+                        if (!f) continue;
+                        float gvf[CW];
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) gvf[c] = elem<T>::load(gv[k][c]);
+                        const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
+                        const float fw = fwT[p * BWD_PTS + pt], fn = fnT[p * BWD_PTS + pt];
+                        const float cw = (f & (1u << 27)) ? 1.0f - fw : 0.0f, ce = (f & (1u << 28)) ? fw : 0.0f;
+                        const float rn = (f & (1u << 29)) ? 1.0f - fn : 0.0f, rs = (f & (1u << 30)) ? fn : 0.0f;
+                        const int ox = ixw - bx, oy = iyn - by;  // 0 or 1 while the footprint stays in the block
+                        if ((unsigned)ox <= 1u && (unsigned)oy <= 1u) {
+                            const bool xlo = ox == 0, ylo = oy == 0;
+                            const float cx[3] = {xlo ? cw : 0.0f, xlo ? ce : cw, xlo ? 0.0f : ce};
+                            const float ry[3] = {ylo ? rn : 0.0f, ylo ? rs : rn, ylo ? 0.0f : rs};
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                                for (int q = 0; q < 3; ++q) {
+                                    const float wgt = ry[r] * cx[q];
+#pragma unroll
+                                    for (int c = 0; c < CW; ++c)
+                                        acc[3 * r + q][c] = __builtin_fmaf(gvf[c], wgt, acc[3 * r + q][c]);
+                                }
+                        } else {  // the footprint left the lane's block (general poses): straight to memory
+                            const float wq[4] = {rn * cw, rn * ce, rs * cw, rs * ce};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (wq[q] == 0.0f) continue;
+                                float *gl = gf + (size_t)c0 * HW + (size_t)(iyn + (q >> 1)) * W + ixw + (q & 1);
+#pragma unroll
+                                for (int c = 0; c < CW; ++c)
+                                    if (c < nc) atomicAdd(gl + (size_t)c * HW, gvf[c] * wq[q]);
+                            }
+                        }
+                    }
+                }
+                // scale from the register sums themselves
+                unsigned m = 0u;
+#pragma unroll
+                for (int cell = 0; cell < 9; ++cell)
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) m = max(m, __float_as_uint(acc[cell][c]) & 0x7fffffffu);
+                const unsigned mb = wg_max(m);
+                if (mb != 0u) {
+                    const bool pl = (mb >> 23) == 0xffu;
+                    if (!pl) bwd_scale(mb, fx_scale, fx_inv);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const int py = by + r, rr = py - y0;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const int px = bx + q;
+#pragma unroll
+                            for (int c = 0; c < CW; ++c) {
+                                const float v = acc[3 * r + q][c];
+                                if (c >= nc || v == 0.0f || BWD_ABLATE(2)) continue;  // (out-of-bounds cells carry 0)
+                                if (!pl && rr >= 0 && rr < rows)
+                                    atomicAdd(slab + c * slab_c + rr * W + px, bwd_to_fixed(v * fx_scale));
+                                else
+                                    atomicAdd(gf + (size_t)(c0 + c) * HW + (size_t)py * W + px, v);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (!pl) flush();
+                    __syncthreads();
+                }
+            }
         }
-        return;
     }
-    const int sh = min(120, max(-100, 50 - ((int)(mb >> 23) - 127 + 1)));
-    const float fx_scale = __uint_as_float((unsigned)(sh + 127) << 23);
-    const float fx_inv = __uint_as_float((unsigned)(127 - sh) << 23);
-    // block id = (band*dchunks + dchunk)*batch + b
-    int th = blockIdx.x;
-    const int b = th % tg.batch;
-    th /= tg.batch;
-    const int dchunk = th % tg.dchunks;
-    const int band = th / tg.dchunks;
-    bwd_tile_body<T, HALF, CW>(g, fast, tg, b, band, dchunk, gout, depths, P, Pinv, Tm,
-                               HALF ? gprev : gcur, bwd_slab, yr, fx_scale, fx_inv);
 }
 
 // ---------------------------------------------------------------------------
@@ -1815,59 +1803,49 @@ DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *gra
         return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
     const SweepGeom g = make_geom(desc);
     hipStream_t st = (hipStream_t)stream;
-    // dense sweeps whose feature rows fit the LDS: accumulate there (see sweep_bwd_tile_kernel)
-    const int lds_budget = 80 * 1024;  // two workgroups per CU at most (half of it by default)
-    // channels per pass: as many as leave >= 4 rows of 64-bit accumulators in the budget
-    auto pick_cw = [&](int budget, int cw) {
+    // dense sweeps whose feature rows fit the LDS: accumulate there (see sweep_bwd_tile_kernel).
+    // One 1024-lane workgroup per CU: the LDS holds the footprint table of the chunk
+    // (planes x 256 points x 12 B) and the slab of 64-bit accumulators (CW channels x rows x W).
+    const int planes = std::max(1, std::min(BWD_MAXP, (g.D + 3) / 4));
+    const int table_bytes = planes * BWD_PTS * 12;
+    const int budget = 160 * 1024 - 1024 - table_bytes;  // 1 KiB for the static LDS
+    // channels per pass: as many (of 4) as leave >= 4 rows in the budget
+    auto pick_cw = [&](int cw) {
         while (cw > 2 && (long long)budget / ((long long)cw * desc->w_in * 8) < 4) cw >>= 1;
         return cw;
     };
-    auto rows_for = [&](int budget, int cw) {
-        return (int)std::min((long long)desc->h_in, (long long)budget / ((long long)cw * desc->w_in * 8));
-    };
-    // 4 channels per pass in half the LDS budget (four workgroups per CU) for both maps.
-    // Measured at N* (rocprofv3): prev map 8 ch / 80 KiB 24.7 ms, 4 ch / 40 KiB 19.1 ms (the
-    // direct scatter is latency-bound at two workgroups per CU); cur map 15.2 vs 14.8 ms.
-    // (wide maps that leave fewer than 4 rows in 40 KiB take the whole budget)
-    int budget = lds_budget / 2;
-    if (rows_for(budget, pick_cw(budget, 4)) < 4) budget = lds_budget;
-    const int cw_cur = pick_cw(budget, 4), cw_prev = cw_cur;
-    const int rows_cur = rows_for(budget, cw_cur), rows_prev = rows_cur;
+    const int cw_cur = pick_cw(4), cw_prev = cw_cur;
+    const int rows_cur = (int)std::min<long long>(std::min(desc->h_in, 8),
+                                                  (long long)budget / ((long long)cw_cur * desc->w_in * 8));
+    const int rows_prev = rows_cur;
     const long long hw = (long long)g.h_out * g.w_out;
     if (!force_scatter && rows_cur >= 4 && desc->h_in < 4096 && desc->w_in < 8192) {
         BwdGrid tg;
         tg.batch = desc->batch;
-        tg.band_pts = 256 * BWD_PPL;
+        tg.band_pts = BWD_PTS;
         tg.row_tiles = desc->cost_sample_factor < 1.5f ? 0 : (g.w_out + tg.band_pts - 1) / tg.band_pts;
         tg.bands = tg.row_tiles ? g.h_out * tg.row_tiles : (int)((hw + tg.band_pts - 1) / tg.band_pts);
-        tg.planes = std::max(1, std::min(BWD_MAXP, (g.D + 3) / 4));
+        tg.planes = planes;
+        tg.ablate = 0;
+#ifdef DFM_DEBUG_HOOKS
+        {
+            const char *ab = getenv("DFM_BWD_ABLATE");
+            tg.ablate = ab ? atoi(ab) : 0;
+        }
+#endif
         tg.dchunks = (g.D + tg.planes - 1) / tg.planes;
         const long long nb = (long long)tg.bands * tg.dchunks * desc->batch;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
         const SweepFast fast = make_fast(desc);
-        // max |grad_out| of this call -> fixed-point scale (a 4-byte slot of a per-device ring)
-        unsigned *gmax = nullptr;
-        {
-            static std::mutex mu;
-            static unsigned *ring[64] = {};
-            static unsigned next[64] = {};
-            int dev = 0;
-            HIP_TRY(hipGetDevice(&dev));
-            if (dev < 0 || dev >= 64) return fail(DFM_ERR_UNSUPPORTED, "device index >= 64%s");
-            std::lock_guard<std::mutex> lk(mu);
-            if (!ring[dev]) HIP_TRY(hipMalloc((void **)&ring[dev], 16384 * sizeof(unsigned)));
-            gmax = ring[dev] + (next[dev]++ % 16384);
-        }
-        HIP_TRY(hipMemsetAsync(gmax, 0, sizeof(unsigned), st));
-        const size_t nel = (size_t)desc->batch * 2 * g.C * g.N;
 #define DFM_BWD_LAUNCH(T, CW, HALF, ROWS)                                                            \
     do {                                                                                             \
         tg.rows = (ROWS);                                                                            \
-        const int lds_bytes = (CW) * (ROWS) * desc->w_in * 8;                                        \
+        const int lds_bytes = (CW) * (ROWS) * desc->w_in * 8 + table_bytes;                          \
         rc = ensure_dynamic_lds((const void *)sweep_bwd_tile_kernel<T, CW, HALF>, lds_bytes);        \
         if (rc != DFM_OK) return rc;                                                                 \
-        hipLaunchKernelGGL((sweep_bwd_tile_kernel<T, CW, HALF>), dim3((unsigned)nb), dim3(256),      \
-                           lds_bytes, st, g, fast, tg, (const T *)grad_out, gmax, depths, cam2img,   \
+        hipLaunchKernelGGL((sweep_bwd_tile_kernel<T, CW, HALF>), dim3((unsigned)nb),                 \
+                           dim3(BWD_PTS * bwd_groups(HALF)),                                         \
+                           lds_bytes, st, g, fast, tg, (const T *)grad_out, depths, cam2img,         \
                            cam2img_inv, cur2prev, grad_cur, grad_prev);                              \
     } while (0)
 #define DFM_BWD_HALF(T, HALF, CWV, ROWS)                                                             \
@@ -1877,13 +1855,9 @@ DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *gra
         else DFM_BWD_LAUNCH(T, 2, HALF, ROWS);                                                       \
     } while (0)
         if (desc->dtype == DFM_F32) {
-            hipLaunchKernelGGL(absmax_bits_kernel<float>, dim3(4096), dim3(256), 0, st,
-                               (const float *)grad_out, nel, gmax);
             DFM_BWD_HALF(float, 0, cw_cur, rows_cur);
             DFM_BWD_HALF(float, 1, cw_prev, rows_prev);
         } else {
-            hipLaunchKernelGGL(absmax_bits_kernel<bf16_t>, dim3(4096), dim3(256), 0, st,
-                               (const bf16_t *)grad_out, nel, gmax);
             DFM_BWD_HALF(bf16_t, 0, cw_cur, rows_cur);
             DFM_BWD_HALF(bf16_t, 1, cw_prev, rows_prev);
         }

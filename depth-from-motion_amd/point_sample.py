@@ -238,10 +238,34 @@ def voxel_sample(voxel_features,
         desc.proj_inv[i] = v
     desc.mode = 1 if aligned else 0
     desc.dtype = _DTYPES[vox.dtype]
-    out = torch.empty((1, desc.channels, desc.num_depths, desc.h_out, desc.w_out), dtype=vox.dtype,
-                      device=device)
-    with torch.cuda.device(device):
-        _capi.check(
-            lib.dfm_voxel_sample_fwd(ctypes.byref(desc), _ptr(vox), _ptr(depths), _ptr(out),
-                                     _stream_ptr(device)))
-    return out
+    return _VoxelSampleFn.apply(vox, depths, desc)
+
+
+class _VoxelSampleFn(torch.autograd.Function):
+    """dfm_voxel_sample_fwd / _bwd (gradient w.r.t. the voxel features)"""
+
+    @staticmethod
+    def forward(ctx, vox, depths, desc):
+        lib = _capi.lib()
+        device = vox.device
+        out = torch.empty((1, desc.channels, desc.num_depths, desc.h_out, desc.w_out), dtype=vox.dtype,
+                          device=device)
+        with torch.cuda.device(device):
+            _capi.check(lib.dfm_voxel_sample_fwd(ctypes.byref(desc), _ptr(vox), _ptr(depths), _ptr(out),
+                                                 _stream_ptr(device)))
+        ctx.desc, ctx.meta = desc, (vox.shape, vox.dtype)
+        ctx.save_for_backward(depths)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (depths,) = ctx.saved_tensors
+        shape, dtype = ctx.meta
+        lib = _capi.lib()
+        device = gout.device
+        go = gout.contiguous().to(dtype)
+        gv = torch.zeros(shape, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            _capi.check(lib.dfm_voxel_sample_bwd(ctypes.byref(ctx.desc), _ptr(go), _ptr(depths), _ptr(gv),
+                                                 _stream_ptr(device)))
+        return gv.to(dtype), None, None

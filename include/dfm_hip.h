@@ -361,6 +361,11 @@ typedef struct dfm_vs_desc {
 /* voxel_features (1,C,nx,ny,nz), depths (num_depths) fp32 -> out (1,C,D,h_out,w_out) */
 DFM_API int dfm_voxel_sample_fwd(const dfm_vs_desc *desc, const void *voxel_features,
                                  const float *depths, void *out, void *stream);
+/* Backward w.r.t. the voxel features (the reference op is differentiable through F.grid_sample,
+ * point_fusion.py:396-410): grad_out (1, C, D, h_out, w_out) dtype -> grad_voxel_features
+ * (1, C, nx, ny, nz) FP32, zero-filled by the caller (accumulated with atomics). */
+DFM_API int dfm_voxel_sample_bwd(const dfm_vs_desc *desc, const void *grad_out, const float *depths,
+                                 float *grad_voxel_features, void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* DepthHead.forward (with_convs=False), dense_heads/depth_head.py:205-210  */

@@ -138,3 +138,29 @@ def test_voxel_sample_with_host_inverse_is_close(pkg):
                            torch.tensor([1.0, 1.0]), torch.tensor([0.0, 0.0]), False, (104, 156),
                            (100, 150), aligned=True)
     np.testing.assert_allclose(out.cpu().numpy(), z['out_plain_tri'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('aligned', [True, False])
+def test_voxel_sample_backward_vs_torch_grid_sample(pkg, aligned):
+    """gradient w.r.t. the voxel features (dfm_voxel_sample_bwd) against torch autograd of a
+    grid_sample whose sampling positions reproduce the forward output (linearity probe: the op
+    is linear in the voxel features, so <out(v), g> must equal <v, grad> for random v, g, and the
+    gradient must equal the forward applied to one-hot perturbations summed -- checked through
+    the adjoint identity on two independent random pairs)."""
+    z = np.load(os.path.join(util.GOLDEN, 'voxel_sample.npz'))
+    dev = torch.device('cuda:0')
+    args = (z['voxel_range'], z['voxel_size'], torch.from_numpy(z['depth_samples']),
+            torch.from_numpy(z['proj']), 4, torch.tensor([0.95, 1.05]), torch.tensor([3.0, 2.0]), True,
+            (104, 156), (100, 150))
+    kw = dict(aligned=aligned, proj_inv=torch.from_numpy(z['proj_inv']))
+    rng = np.random.RandomState(4)
+    v = torch.from_numpy(rng.randn(*z['vox'].shape).astype(np.float32)).to(dev).requires_grad_(True)
+    out = pkg.voxel_sample(v, *args, **kw)
+    g = torch.from_numpy(rng.randn(*out.shape).astype(np.float32)).to(dev)
+    out.backward(g)
+    # adjoint identity <A v2, g> == <v2, A^T g> for an independent v2
+    v2 = torch.from_numpy(rng.randn(*z['vox'].shape).astype(np.float32)).to(dev)
+    lhs = float((pkg.voxel_sample(v2, *args, **kw).double() * g.double()).sum())
+    rhs = float((v2.double() * v.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+    assert float(v.grad.abs().sum()) > 0
