@@ -446,8 +446,9 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
             def api_step():
                 return pkg.build_dfm_cost(cur, prev, depths, w['fsf'], w['csf'], k_dev, t_dev,
                                           (375, 1242), w['flip'], w['crop'], w['scale'])
-            for _ in range(args.warmup):
-                api_step()
+            vol = None
+            for _ in range(max(args.warmup, 2)):
+                vol = api_step()  # (held like in the timed loop: both 26.8 GB blocks get cached now)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
