@@ -43,6 +43,7 @@ EXPORTS = (
     'dfm_depth_head_bwd',
     'dfm_conv3d_k3_c32_weight_bytes',
     'dfm_conv3d_k3_c32_pack_weights',
+    'dfm_conv3d_k3_c32_stats_splits',
     'dfm_conv3d_k3_c32_fwd',
     'dfm_depth_loss_fwd',
     'dfm_depth_loss_bwd',
@@ -51,6 +52,7 @@ EXPORTS = (
     'dfm_group_norm_workspace_bytes',
     'dfm_group_norm_fwd',
     'dfm_group_norm_fwd_channels_last',
+    'dfm_group_norm_apply_channels_last',
     'dfm_group_norm_bwd',
 )
 
@@ -220,7 +222,9 @@ def lib():
     h.dfm_conv3d_k3_c32_pack_weights.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_pack_weights.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     h.dfm_conv3d_k3_c32_fwd.restype = ctypes.c_int
-    h.dfm_conv3d_k3_c32_fwd.argtypes = [i32, i32, i32, i32, vp, vp, fp, vp, i32, i32, i32, vp]
+    h.dfm_conv3d_k3_c32_fwd.argtypes = [i32, i32, i32, i32, vp, vp, fp, vp, i32, i32, i32, fp, vp]
+    h.dfm_conv3d_k3_c32_stats_splits.restype = ctypes.c_int
+    h.dfm_conv3d_k3_c32_stats_splits.argtypes = [i32, i32, i32, i32, i32]
     lp = ctypes.POINTER(DepthLossDesc)
     h.dfm_depth_loss_fwd.restype = ctypes.c_int
     h.dfm_depth_loss_fwd.argtypes = [lp, vp, fp, fp, fp, vp, vp]
@@ -237,6 +241,9 @@ def lib():
     h.dfm_group_norm_fwd.argtypes = [i32, i32, i64, i32, f32, i32, i32, vp, fp, fp, vp, fp, fp, vp, sz, vp]
     h.dfm_group_norm_fwd_channels_last.restype = ctypes.c_int
     h.dfm_group_norm_fwd_channels_last.argtypes = h.dfm_group_norm_fwd.argtypes
+    h.dfm_group_norm_apply_channels_last.restype = ctypes.c_int
+    h.dfm_group_norm_apply_channels_last.argtypes = [i32, i32, i64, i32, f32, i32, i32, vp, fp, fp, vp, fp, fp, fp,
+                                                     i32, vp, sz, vp]
     h.dfm_group_norm_bwd.restype = ctypes.c_int
     h.dfm_group_norm_bwd.argtypes = [i32, i32, i64, i32, i32, i32, vp, vp, vp, fp, fp, fp, vp, fp, fp, vp, sz,
                                      vp]

@@ -46,9 +46,11 @@ def _is_ndhwc(x):
     return x.dim() == 5 and x.is_contiguous(memory_format=torch.channels_last_3d)
 
 
-def conv3d_k3_c32(x, packed, relu=False, acc_in=None, out_f32=False, depth_chunk=0):
+def conv3d_k3_c32(x, packed, relu=False, acc_in=None, out_f32=False, depth_chunk=0, stats=False):
     """x: (N, 32, D, H, W) bf16 channels_last_3d.  Returns (N, 32, D, H, W) channels_last_3d bf16,
-    or the fp32 partial (N, D, H, W, 32) when ``out_f32``; ``acc_in``: fp32 partial to start from."""
+    or the fp32 partial (N, D, H, W, 32) when ``out_f32``; ``acc_in``: fp32 partial to start from.
+    ``stats``: also return the per-channel moment partials (N, 32, splits, 3) of the stored values
+    (the GroupNorm statistics of the layer that follows, see ``group_norm_from_partials``)."""
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 32 and _is_ndhwc(x)
     N, _, D, H, W = x.shape
     lib = _capi.lib()
@@ -59,34 +61,43 @@ def conv3d_k3_c32(x, packed, relu=False, acc_in=None, out_f32=False, depth_chunk
         out = torch.empty((N, D, H, W, 32), dtype=torch.bfloat16, device=dev)
     if acc_in is not None:
         assert acc_in.dtype == torch.float32 and acc_in.shape == (N, D, H, W, 32) and acc_in.is_contiguous()
+    part = None
+    if stats:
+        assert not out_f32 and not relu, 'statistics are taken of the plain bf16 output'
+        splits = lib.dfm_conv3d_k3_c32_stats_splits(N, D, H, W, depth_chunk)
+        part = torch.empty((N, 32, splits, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _capi.check(lib.dfm_conv3d_k3_c32_fwd(N, D, H, W, _ptr(x), _ptr(packed),
                                               _ptr(acc_in) if acc_in is not None else None, _ptr(out),
                                               1 if out_f32 else 0, 1 if relu else 0, depth_chunk,
+                                              _ptr(part) if part is not None else None,
                                               _stream_ptr(dev)))
-    return out if out_f32 else out.permute(0, 4, 1, 2, 3)
+    if out_f32:
+        return out
+    out = out.permute(0, 4, 1, 2, 3)
+    return (out, part) if stats else out
 
 
 class _MfmaConvFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, weight, packs):
+    def forward(ctx, x, weight, packs, want_stats=False):
         ctx.save_for_backward(x, weight)
-        if len(packs) == 1:
-            return conv3d_k3_c32(x, packs[0])
         # C_in = 32 * k: halves accumulated through the fp32 partial
         part = None
         for i, pk in enumerate(packs):
-            xi = x[:, 32 * i:32 * (i + 1)]
+            xi = x if len(packs) == 1 else x[:, 32 * i:32 * (i + 1)]
             if not _is_ndhwc(xi):
                 xi = xi.contiguous(memory_format=torch.channels_last_3d)
             last = i == len(packs) - 1
-            res = conv3d_k3_c32(xi, pk, acc_in=part, out_f32=not last)
-            part = res
+            part = conv3d_k3_c32(xi, pk, acc_in=part, out_f32=not last, stats=want_stats and last)
+        if want_stats:
+            ctx.mark_non_differentiable(part[1])
+            return part
         return part
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_unused):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last_3d)
         gx = None
@@ -102,7 +113,7 @@ class _MfmaConvFn(torch.autograd.Function):
                 gy, x, weight.to(x.dtype), None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
                 [False, True, False])
             gw = gw.to(weight.dtype)
-        return gx, gw, None
+        return gx, gw, None, None
 
 
 class MfmaConv3d(nn.Conv3d):
@@ -131,3 +142,8 @@ class MfmaConv3d(nn.Conv3d):
         if self.eligible(x):
             return _MfmaConvFn.apply(x, self.weight, self._packed())
         return super().forward(x)
+
+    def forward_with_stats(self, x):
+        """(y, moment partials): the convolution plus the per-channel GroupNorm statistics of y
+        from the kernel's epilogue (``x`` must be eligible)."""
+        return _MfmaConvFn.apply(x, self.weight, self._packed(), True)

@@ -81,10 +81,15 @@ __global__ void conv3d_pack_weights_kernel(const TW *__restrict__ w, int cin_tot
 }
 
 // OUT_F32: write the fp32 partial (N,D,H,W,32) instead of bf16;  ACC_IN: start from a fp32 partial
-template <bool OUT_F32, bool ACC_IN>
+// STATS (bf16 output only): also emit, per (sample, channel, producing wave), the count / mean /
+// M2 of the values it stored -- the per-channel GroupNorm statistics of the NEXT layer, so that
+// layer's statistics pass over the tensor disappears (stats[((n*32 + c)*splits + s)*3 + {0,1,2}],
+// s = (tile*chunks + chunk)*4 + wave, merged by dfm_group_norm_apply_channels_last).
+template <bool OUT_F32, bool ACC_IN, bool STATS>
 __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
     ConvGeom g, const bf16_t *__restrict__ x, const uint4 *__restrict__ wfrag,
-    const float *__restrict__ acc_in, void *__restrict__ yout, const uint4 *__restrict__ zero_page)
+    const float *__restrict__ acc_in, void *__restrict__ yout, const uint4 *__restrict__ zero_page,
+    float *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -147,6 +152,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
     __syncthreads();
 
     const bool colok = w0 + l32 < g.W;
+    // STATS: shifted sums of this lane's stored values per channel (16 of the 32 channels live in
+    // a lane): s1 = sum(v - K), s2 = sum((v - K)^2) with K = the first value seen -- as robust as
+    // Welford for |mean| >> std, 3 VALU ops per value
+    float sK[16], s1[16], s2[16];
+    float scnt = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { sK[t] = 0.0f; s1[t] = 0.0f; s2[t] = 0.0f; }
     for (int d = d0; d < d1; ++d) {
         if (d + 2 <= d1) stage(d + 2);  // needed by depth d+1 (<= d1-1) as its kd=2 slab
         f32x16_t acc[4];
@@ -222,14 +234,83 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
                 } else {
                     const u32x2_t pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
                     *(u32x2_t *)((bf16_t *)yout + vox * CV_C + c) = pk;
+                    if constexpr (STATS) {
+                        // the values as stored (bf16-rounded): what the normalisation will read
+                        const float q[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                                            __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int t = 4 * gq + j;
+                            if (scnt == 0.0f) sK[t] = q[j];
+                            const float dv = q[j] - sK[t];
+                            s1[t] += dv;
+                            s2[t] = __builtin_fmaf(dv, dv, s2[t]);
+                        }
+                    }
                 }
             }
+            if constexpr (STATS && !OUT_F32) scnt += 1.0f;
         }
         __syncthreads();  // slab d+2 has landed (vmcnt drained) and slot (d-1) may be refilled
+    }
+    if constexpr (STATS && !OUT_F32) {
+        // lane -> (count, mean, M2) per channel, merged over the 32 pixel lanes of each half
+        // (Chan's parallel update), written by lanes 0 and 32
+        const int splits = g.tiles_w * g.tiles_h * gridDim.y * 4;
+        const int sidx = (blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            float cn = scnt, mean = 0.0f, m2 = 0.0f;
+            if (cn > 0.0f) {
+                const float a = s1[t] / cn;
+                mean = sK[t] + a;
+                m2 = fmaxf(s2[t] - s1[t] * a, 0.0f);
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                const float on = __shfl_xor(cn, o), om = __shfl_xor(mean, o), o2 = __shfl_xor(m2, o);
+                const float tot = cn + on;
+                if (tot > 0.0f) {
+                    const float delta = om - mean, f = on / tot;
+                    m2 = m2 + o2 + delta * delta * cn * f;
+                    mean = mean + delta * f;
+                }
+                cn = tot;
+            }
+            if (l32 == 0) {
+                const int c = (t & 3) + 8 * (t >> 2) + 4 * half;
+                float *o3 = stats + (((size_t)n * CV_C + c) * splits + sidx) * 3;
+                o3[0] = cn; o3[1] = mean; o3[2] = m2;
+            }
+        }
     }
 }
 
 }  // namespace
+
+namespace {
+// depth chunk: enough workgroups for >= 4 rounds over the 256 CUs, at least 8 planes per chunk
+// (each chunk re-stages 2 halo slabs)
+int conv_depth_chunk(int n, int d, int h, int w, int depth_chunk)
+{
+    int dc = depth_chunk;
+    if (dc <= 0) {
+        const long long cols = (long long)((w + CV_TW - 1) / CV_TW) * ((h + CV_TH - 1) / CV_TH) * n;
+        const long long chunks = (4 * 256 + cols - 1) / cols;
+        dc = (int)std::max<long long>(8, (d + chunks - 1) / chunks);
+    }
+    return std::min(dc, d);
+}
+}  // namespace
+
+// number of statistics partials per (sample, channel) a forward call with these sizes emits
+extern "C" DFM_API int dfm_conv3d_k3_c32_stats_splits(int32_t n, int32_t d, int32_t h, int32_t w,
+                                                      int32_t depth_chunk)
+{
+    if (n <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
+    const int dc = conv_depth_chunk(n, d, h, w, depth_chunk);
+    return ((w + CV_TW - 1) / CV_TW) * ((h + CV_TH - 1) / CV_TH) * ((d + dc - 1) / dc) * 4;
+}
 
 extern "C" DFM_API size_t dfm_conv3d_k3_c32_weight_bytes(void) { return (size_t)CV_NFRAG * 64 * 16 + 4096; }
 
@@ -260,8 +341,9 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_pack_weights(const void *weight, int32_
 extern "C" DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
                                              const void *packed_weights, const float *acc_in,
                                              void *out, int32_t out_f32, int32_t relu,
-                                             int32_t depth_chunk, void *stream)
+                                             int32_t depth_chunk, float *stats, void *stream)
 {
+    if (stats && out_f32) return set_error(DFM_ERR_INVALID_ARG, "statistics are taken of the bf16 output");
     if (n <= 0 || d <= 0 || h <= 0 || w <= 0) return set_error(DFM_ERR_INVALID_ARG, "non-positive size");
     if (!x || !packed_weights || !out) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     if ((long long)h * w * 64 >= (1ll << 31)) return set_error(DFM_ERR_UNSUPPORTED, "depth plane too large");
@@ -271,15 +353,7 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, in
     g.tiles_w = (w + CV_TW - 1) / CV_TW;
     g.tiles_h = (h + CV_TH - 1) / CV_TH;
     g.relu = relu ? 1 : 0;
-    // depth chunk: enough workgroups for >= 4 rounds over the 256 CUs, at least 8 planes per
-    // chunk (each chunk re-stages 2 halo slabs)
-    int dc = depth_chunk;
-    if (dc <= 0) {
-        const long long cols = (long long)g.tiles_w * g.tiles_h * n;
-        long long chunks = (4 * 256 + cols - 1) / cols;
-        dc = (int)std::max<long long>(8, (d + chunks - 1) / chunks);
-    }
-    dc = std::min(dc, d);
+    const int dc = conv_depth_chunk(n, d, h, w, depth_chunk);
     g.dchunk = dc;
     const int nchunks = (d + dc - 1) / dc;
     if (nchunks > 65535) return set_error(DFM_ERR_UNSUPPORTED, "too many depth chunks");
@@ -288,20 +362,21 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, in
     const int lds = CV_RING * CV_SLAB_BYTES;
     dim3 grid(g.tiles_w * g.tiles_h, nchunks, n);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_done[4] = {false, false, false, false};
-#define CV_LAUNCH(F32, ACC, IDX)                                                                   \
+    static bool attr_done[6] = {false, false, false, false, false, false};
+#define CV_LAUNCH(F32, ACC, ST, IDX)                                                                   \
     do {                                                                                           \
         if (!attr_done[IDX]) {                                                                     \
-            hipError_t e_ = hipFuncSetAttribute((const void *)conv3d_k3_c32_kernel<F32, ACC>,      \
+            hipError_t e_ = hipFuncSetAttribute((const void *)conv3d_k3_c32_kernel<F32, ACC, ST>,  \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
             if (e_ != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e_));            \
             attr_done[IDX] = true;                                                                 \
         }                                                                                          \
-        hipLaunchKernelGGL((conv3d_k3_c32_kernel<F32, ACC>), grid, dim3(256), lds, st, g,          \
-                           (const bf16_t *)x, wfrag, acc_in, out, zero);                           \
+        hipLaunchKernelGGL((conv3d_k3_c32_kernel<F32, ACC, ST>), grid, dim3(256), lds, st, g,      \
+                           (const bf16_t *)x, wfrag, acc_in, out, zero, stats);                    \
     } while (0)
-    if (out_f32) { if (acc_in) CV_LAUNCH(true, true, 3); else CV_LAUNCH(true, false, 2); }
-    else { if (acc_in) CV_LAUNCH(false, true, 1); else CV_LAUNCH(false, false, 0); }
+    if (out_f32) { if (acc_in) CV_LAUNCH(true, true, false, 3); else CV_LAUNCH(true, false, false, 2); }
+    else if (stats) { if (acc_in) CV_LAUNCH(false, true, true, 5); else CV_LAUNCH(false, false, true, 4); }
+    else { if (acc_in) CV_LAUNCH(false, true, false, 1); else CV_LAUNCH(false, false, false, 0); }
 #undef CV_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));

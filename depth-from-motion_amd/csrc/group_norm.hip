@@ -25,6 +25,8 @@
 // right after the convolution).  Bound: HBM.
 #include "dfm_common.h"
 
+#include <algorithm>
+
 using namespace dfm;
 
 namespace {
@@ -288,6 +290,17 @@ int pick_splits(long long L)
     return (int)s;
 }
 
+// channels-last passes: up to 2048 workgroups per sample (config K at batch 1 is ONE sample of
+// 118 MB: 256 workgroups were one per CU, 3.5 TB/s); the partials are merged once by
+// gn_merge_partials_kernel, not by every workgroup of the apply pass
+int pick_splits_cl(long long L)
+{
+    long long s = L / (256 * 16 * 4);  // >= 4 vectors per thread
+    if (s < 1) s = 1;
+    if (s > 2048) s = 2048;
+    return (int)s;
+}
+
 // ---------------------------------------------------------------------------
 // channels-last variant: x, y are (N, spatial, C) contiguous (torch channels_last_3d),
 // what the NDHWC convolutions produce and consume.  A lane owns one 16-byte channel
@@ -353,8 +366,10 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
                                                           const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, int relu,
                                                           T *__restrict__ y, float *__restrict__ mean_out,
-                                                          float *__restrict__ rstd_out)
+                                                          float *__restrict__ rstd_out, int psplits)
 {
+    // psplits: partials per group to merge (0: one per workgroup of this grid, the layout
+    // gn_stats_cl_kernel writes; 1: already merged by gn_merge_partials_kernel)
     constexpr int VEC = vec16<T>::N;
     __shared__ float ca[256], cb[256];
     const int n = blockIdx.y, s = blockIdx.x;
@@ -362,8 +377,9 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
     if ((int)threadIdx.x < groups) {
         const int g = threadIdx.x;
         Moments r = {0.0f, 0.0f, 0.0f};
-        for (int k = 0; k < splits; ++k) {
-            const float *p = partial + (((size_t)n * groups + g) * splits + k) * 3;
+        const int np_ = psplits > 0 ? psplits : splits;
+        for (int k = 0; k < np_; ++k) {
+            const float *p = partial + (((size_t)n * groups + g) * np_ + k) * 3;
             r = merge(r, Moments{p[0], p[1], p[2]});
         }
         const float mean = r.mean, rstd = 1.0f / sqrtf(r.m2 / r.n + eps);  // biased, like torch
@@ -383,7 +399,23 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
     const long long per = (spatial + splits - 1) / splits;
     const long long lo = min((long long)s * per, spatial), hi = min(lo + per, spatial);
     const size_t base = (size_t)n * spatial * C + (size_t)vb * VEC;
-    for (long long v = lo + v0; v < hi; v += vpi) {
+    constexpr int U = 4;  // vectors in flight per lane
+    long long v = lo + v0;
+    for (; v + (long long)(U - 1) * vpi < hi; v += (long long)U * vpi) {
+        float f[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load16<T>(x + base + (size_t)(v + (long long)u * vpi) * C, f[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float r = f[u][k] * a[k] + b[k];
+                f[u][k] = relu ? fmaxf(r, 0.0f) : r;
+            }
+            store16<T>(y + base + (size_t)(v + (long long)u * vpi) * C, f[u]);
+        }
+    }
+    for (; v < hi; v += vpi) {
         float f[VEC];
         load16<T>(x + base + (size_t)v * C, f);
 #pragma unroll
@@ -395,6 +427,20 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
     }
 }
 
+// partials [n*groups][splits][3] -> merged [n*groups][3]; one wave per (sample, group)
+__global__ __launch_bounds__(64) void gn_merge_partials_kernel(const float *__restrict__ partial,
+                                                               int splits, float *__restrict__ merged)
+{
+    const float *p = partial + (size_t)blockIdx.x * splits * 3;
+    Moments r = {0.0f, 0.0f, 0.0f};
+    for (int k = threadIdx.x; k < splits; k += 64) r = merge(r, Moments{p[3 * k], p[3 * k + 1], p[3 * k + 2]});
+    r = wave_merge(r);
+    if (threadIdx.x == 0) {
+        float *o = merged + (size_t)blockIdx.x * 3;
+        o[0] = r.n; o[1] = r.mean; o[2] = r.m2;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -403,7 +449,7 @@ DFM_API size_t dfm_group_norm_workspace_bytes(int32_t n, int32_t c, int64_t spat
 {
     if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups) return 0;
     // forward partials (N*G*splits*3) and backward partials (N*C*splits*2), splits <= 256
-    const size_t fw = (size_t)n * groups * 256 * 3, bw = (size_t)n * c * 256 * 2;
+    const size_t fw = (size_t)n * groups * 257 * 3, bw = (size_t)n * c * 256 * 2;
     return ((fw > bw ? fw : bw) * sizeof(float) + 255) & ~(size_t)255;
 }
 
@@ -465,23 +511,67 @@ DFM_API int dfm_group_norm_fwd_channels_last(int32_t n, int32_t c, int64_t spati
         ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
         return set_error(DFM_ERR_UNSUPPORTED,
                          "channels-last GroupNorm needs C = 16-byte vectors x a power of two, C <= 256");
-    const int splits = pick_splits((long long)spatial * c);
-    dim3 grid(splits, n);
+    const int splits = std::min(256, pick_splits_cl((long long)spatial * c));  // stats partials (workspace layout)
+    const int asplits = pick_splits_cl((long long)spatial * c);                // workgroups of the apply pass
+    dim3 grid(splits, n), agrid(asplits, n);
     hipStream_t st = (hipStream_t)stream;
     float *partial = (float *)workspace;
-    if (dtype == DFM_F32) {
+    float *merged = partial + (size_t)n * groups * splits * 3;  // behind the partials (fits: bw partials are larger)
+    if (dtype == DFM_F32)
         hipLaunchKernelGGL(gn_stats_cl_kernel<float>, grid, dim3(256), 0, st, (const float *)x,
                            (long long)spatial, c, groups, splits, partial);
-        hipLaunchKernelGGL(gn_apply_cl_kernel<float>, grid, dim3(256), 0, st, (const float *)x,
-                           (long long)spatial, c, groups, splits, eps, partial, gamma, beta, relu,
-                           (float *)y, mean, rstd);
-    } else {
+    else
         hipLaunchKernelGGL(gn_stats_cl_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x,
                            (long long)spatial, c, groups, splits, partial);
+    hipLaunchKernelGGL(gn_merge_partials_kernel, dim3(n * groups), dim3(64), 0, st, partial, splits, merged);
+    if (dtype == DFM_F32)
+        hipLaunchKernelGGL(gn_apply_cl_kernel<float>, agrid, dim3(256), 0, st, (const float *)x,
+                           (long long)spatial, c, groups, asplits, eps, merged, gamma, beta, relu,
+                           (float *)y, mean, rstd, 1);
+    else
+        hipLaunchKernelGGL(gn_apply_cl_kernel<bf16_t>, agrid, dim3(256), 0, st, (const bf16_t *)x,
+                           (long long)spatial, c, groups, asplits, eps, merged, gamma, beta, relu,
+                           (bf16_t *)y, mean, rstd, 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+DFM_API int dfm_group_norm_apply_channels_last(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                               float eps, int32_t dtype, int32_t relu, const void *x,
+                                               const float *gamma, const float *beta, void *y,
+                                               float *mean, float *rstd, const float *partials,
+                                               int32_t splits, void *workspace,
+                                               size_t workspace_bytes, void *stream)
+{
+    if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups || splits <= 0)
+        return set_error(DFM_ERR_INVALID_ARG, "bad sizes in dfm_group_norm_apply_channels_last");
+    if (dtype != DFM_F32 && dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!x || !gamma || !beta || !y || !mean || !rstd || !partials || !workspace)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (workspace_bytes < (size_t)n * groups * 3 * sizeof(float))
+        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than n*groups*3 floats");
+    const int vec = dtype == DFM_BF16 ? 8 : 4;
+    const int nvb = c / vec;
+    if (c % vec || c > 256 || (nvb & (nvb - 1)) || n > 65535 ||
+        ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
+        return set_error(DFM_ERR_UNSUPPORTED,
+                         "channels-last GroupNorm needs C = 16-byte vectors x a power of two, C <= 256");
+    hipStream_t st = (hipStream_t)stream;
+    float *merged = (float *)workspace;
+    hipLaunchKernelGGL(gn_merge_partials_kernel, dim3(n * groups), dim3(64), 0, st, partials, splits, merged);
+    const int asplits = pick_splits_cl((long long)spatial * c);  // workgroups of the apply pass
+    dim3 grid(asplits, n);
+    // the apply kernel slices the tensor by ITS grid and merges `1` partial per group
+    if (dtype == DFM_F32)
+        hipLaunchKernelGGL(gn_apply_cl_kernel<float>, grid, dim3(256), 0, st, (const float *)x,
+                           (long long)spatial, c, groups, asplits, eps, merged, gamma, beta, relu,
+                           (float *)y, mean, rstd, 1);
+    else
         hipLaunchKernelGGL(gn_apply_cl_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x,
-                           (long long)spatial, c, groups, splits, eps, partial, gamma, beta, relu,
-                           (bf16_t *)y, mean, rstd);
-    }
+                           (long long)spatial, c, groups, asplits, eps, merged, gamma, beta, relu,
+                           (bf16_t *)y, mean, rstd, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;

@@ -18,7 +18,7 @@ from .plane_sweep import _DTYPES, _Workspace, _ptr, _stream_ptr
 class _GroupNormFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, relu):
+    def forward(ctx, x, weight, bias, groups, eps, relu, partials=None):
         lib = _capi.lib()
         device = x.device
         n, c = x.shape[:2]
@@ -40,9 +40,17 @@ class _GroupNormFn(torch.autograd.Function):
         ws = _Workspace.get(device, nbytes)
         fn = lib.dfm_group_norm_fwd_channels_last if cl else lib.dfm_group_norm_fwd
         with torch.cuda.device(device):
-            _capi.check(fn(n, c, spatial, groups, eps, _DTYPES[x.dtype], int(relu), _ptr(x), _ptr(w32),
-                           _ptr(b32), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), nbytes,
-                           _stream_ptr(device)))
+            if partials is not None:
+                # statistics came from the producer (MFMA conv epilogue): normalisation pass only
+                assert cl and partials.shape[:2] == (n, groups) and partials.is_contiguous()
+                _capi.check(lib.dfm_group_norm_apply_channels_last(
+                    n, c, spatial, groups, eps, _DTYPES[x.dtype], int(relu), _ptr(x), _ptr(w32), _ptr(b32),
+                    _ptr(y), _ptr(mean), _ptr(rstd), _ptr(partials), partials.shape[2], _ptr(ws), nbytes,
+                    _stream_ptr(device)))
+            else:
+                _capi.check(fn(n, c, spatial, groups, eps, _DTYPES[x.dtype], int(relu), _ptr(x), _ptr(w32),
+                               _ptr(b32), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), nbytes,
+                               _stream_ptr(device)))
         ctx.save_for_backward(x, y if relu else x, mean, rstd, w32)
         ctx.cfg = (groups, bool(relu), weight.dtype, bias.dtype, cl)
         return y
@@ -68,15 +76,17 @@ class _GroupNormFn(torch.autograd.Function):
                 lib.dfm_group_norm_bwd(n, c, spatial, groups, _DTYPES[x.dtype], int(relu), _ptr(gy),
                                        _ptr(x), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(w32), _ptr(gx),
                                        _ptr(gw), _ptr(gb), _ptr(ws), nbytes, _stream_ptr(device)))
-        return gx, gw.to(wdt), gb.to(bdt), None, None, None
+        return gx, gw.to(wdt), gb.to(bdt), None, None, None, None
 
 
-def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
-    """torch.nn.functional.group_norm(+relu) on the GPU through the fused kernels."""
+def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False, partials=None):
+    """torch.nn.functional.group_norm(+relu) on the GPU through the fused kernels.
+    ``partials`` (N, groups, splits, 3): count / mean / M2 moment partials of ``x`` from its
+    producer (``MfmaConv3d.forward_with_stats``); the statistics pass over ``x`` is skipped."""
     if not x.is_cuda or x.dtype not in _DTYPES:
         raise RuntimeError('fused group_norm needs a float32/bfloat16 GPU tensor '
                            '(depth-from-motion_amd has no CPU path)')
-    return _GroupNormFn.apply(x, weight, bias, int(num_groups), float(eps), bool(relu))
+    return _GroupNormFn.apply(x, weight, bias, int(num_groups), float(eps), bool(relu), partials)
 
 
 _cpu_reference = False
@@ -98,13 +108,13 @@ class HipGroupNorm(nn.GroupNorm):
     tensor the kernels do not cover (fp16, affine=False), is an error.  (Tests that exercise
     module wiring on a CPU-only box opt in with ``allow_cpu_reference(True)``.)"""
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, partials=None):
         if x.is_cuda:
             if x.dtype not in _DTYPES or not self.affine:
                 raise RuntimeError(
                     f'HipGroupNorm: unsupported GPU input (dtype {x.dtype}, affine={self.affine}); '
                     'the fused kernels cover float32 / bfloat16 with affine parameters')
-            return group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu)
+            return group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu, partials)
         if not _cpu_reference:
             raise RuntimeError('HipGroupNorm got a CPU tensor: depth-from-motion_amd has no CPU path '
                                '(tests opt in with group_norm.allow_cpu_reference(True))')

@@ -76,9 +76,15 @@ class ConvModule(nn.Module):
             self.activate = nn.ReLU(inplace=act_cfg.get('inplace', True))
 
     def forward(self, x):
+        norm = getattr(self, self.norm_name) if self.norm_name is not None else None
+        if (isinstance(self.conv, MfmaConv3d) and isinstance(norm, HipGroupNorm) and
+                norm.num_groups == self.conv.out_channels and self.conv.eligible(x)):
+            # MFMA conv whose epilogue already produced the per-channel GroupNorm statistics:
+            # the normalisation (+ReLU) is one read and one write of the tensor
+            y, partials = self.conv.forward_with_stats(x)
+            return norm(y, relu=self.activate is not None, partials=partials)
         x = self.conv(x)
         if self.norm_name is not None:
-            norm = getattr(self, self.norm_name)
             if isinstance(norm, HipGroupNorm):
                 return norm(x, relu=self.activate is not None)  # GN and ReLU in one pass
             x = norm(x)

@@ -410,11 +410,18 @@ DFM_API int dfm_conv3d_k3_c32_pack_weights(const void *weight, int32_t weight_dt
  * out     : (n, d, h, w, 32) bf16 -- or fp32 when out_f32 != 0
  * relu    : != 0 applies max(., 0) before the store
  * depth_chunk : output planes one workgroup walks (0 = chosen from the shape)
+ * stats   : NULL, or fp32 [n][32][splits][3] (splits = dfm_conv3d_k3_c32_stats_splits(...) with the
+ *           same sizes and depth_chunk): count / mean / M2 of the stored bf16 values per (sample,
+ *           channel, producing wave) -- the per-channel GroupNorm statistics of the layer that
+ *           follows, consumed by dfm_group_norm_apply_channels_last (bf16 output only)
  * fp32 accumulation over the 27 x 32 products of a voxel (v_mfma_f32_32x32x16_bf16).
  */
+DFM_API int dfm_conv3d_k3_c32_stats_splits(int32_t n, int32_t d, int32_t h, int32_t w,
+                                           int32_t depth_chunk);
 DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
                                   const void *packed_weights, const float *acc_in, void *out,
-                                  int32_t out_f32, int32_t relu, int32_t depth_chunk, void *stream);
+                                  int32_t out_f32, int32_t relu, int32_t depth_chunk, float *stats,
+                                  void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* DepthHead.loss, dense_heads/depth_head.py:75-188 (called at dfm.py:348) */
@@ -484,6 +491,17 @@ DFM_API int dfm_group_norm_fwd_channels_last(int32_t n, int32_t c, int64_t spati
                                              const float *gamma, const float *beta, void *y,
                                              float *mean, float *rstd, void *workspace,
                                              size_t workspace_bytes, void *stream);
+/* The normalisation pass alone, from statistics somebody else produced (the MFMA convolution's
+ * epilogue): partials = fp32 [n][groups][splits][3] {count, mean, M2} (Chan-mergeable); they are
+ * merged once (a small kernel, into the first n*groups*3 floats of `workspace`), then
+ * y = (x - mean) * rstd * gamma + beta (+ReLU) like dfm_group_norm_fwd_channels_last, which also
+ * fills mean / rstd for the backward.  One read and one write of the tensor instead of two reads. */
+DFM_API int dfm_group_norm_apply_channels_last(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                               float eps, int32_t dtype, int32_t relu, const void *x,
+                                               const float *gamma, const float *beta, void *y,
+                                               float *mean, float *rstd, const float *partials,
+                                               int32_t splits, void *workspace,
+                                               size_t workspace_bytes, void *stream);
 /* grad_gamma / grad_beta: (c) fp32, zero-filled by the caller; `y` is only
  * read when relu != 0 (mask y > 0). */
 DFM_API int dfm_group_norm_bwd(int32_t n, int32_t c, int64_t spatial, int32_t groups,

@@ -118,3 +118,44 @@ def test_config_k_volume_shape(cv):
                 patch = xp[:, :, kd:kd + D, kh:kh + H, kw:kw + W][:, :, ds, hs, ws]
                 ref += torch.einsum('ncdhw,oc->nodhw', patch, wd[:, :, kd, kh, kw])
     np.testing.assert_allclose(part[:, :, ds, hs, ws].cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_groupnorm_statistics_from_the_conv_epilogue(cv):
+    """The per-channel moments the kernel emits for its stored bf16 values merge (Chan) to the
+    mean / biased variance torch computes on that tensor -- including |mean| >> std channels -- and
+    ConvModule's fused conv -> GroupNorm(+ReLU) equals the unfused path bit for bit."""
+    import importlib
+    mods = importlib.import_module('depth-from-motion_amd.modules')
+    dev = torch.device('cuda:0')
+    N, D, H, W = 2, 9, 21, 70  # ragged tiles, two samples, several depth chunks
+    x, w = _inputs(N, 32, D, H, W, seed=21)
+    x[:, 3] += 40.0  # a channel whose outputs sit far from zero
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last_3d)
+    packed = cv.pack_conv3d_weights(w.to(dev))
+    for chunk in (0, 2):
+        y, part = cv.conv3d_k3_c32(xg, packed, stats=True, depth_chunk=chunk)
+        assert torch.equal(y, cv.conv3d_k3_c32(xg, packed, depth_chunk=chunk))
+        p = part.double()
+        cnt = p[..., 0].sum(-1)
+        assert torch.all(cnt == D * H * W)
+        mean = (p[..., 0] * p[..., 1]).sum(-1) / cnt
+        m2 = (p[..., 2] + p[..., 0] * (p[..., 1] - mean[..., None]) ** 2).sum(-1)
+        yd = y.double().permute(0, 1, 2, 3, 4).reshape(N, 32, -1)
+        np.testing.assert_allclose(mean.cpu().numpy(), yd.mean(-1).cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose((m2 / cnt).cpu().numpy(), yd.var(-1, unbiased=False).cpu().numpy(), rtol=1e-4)
+    torch.manual_seed(1)
+    m = mods._conv3(32, 32, dict(type='GN', num_groups=32, requires_grad=True)).to(dev).bfloat16()
+    m = m.to(memory_format=torch.channels_last_3d)
+    with torch.no_grad():
+        m.gn.weight.copy_(torch.rand(32) + 0.5)
+        m.gn.bias.copy_(torch.randn(32) * 0.1)
+    assert isinstance(m.conv, cv.MfmaConv3d)
+    xin = xg.clone().requires_grad_(True)
+    fused = m(xin)
+    unfused = m.gn(m.conv(xin), relu=True)
+    # same statistics up to fp32 merge order -> outputs equal to bf16 rounding of ~1e-6 differences
+    np.testing.assert_allclose(fused.float().detach().cpu().numpy(), unfused.float().detach().cpu().numpy(),
+                               rtol=2e-2, atol=2e-2)
+    assert float((fused.float() - unfused.float()).abs().mean()) < 1e-4
+    fused.float().square().mean().backward()
+    assert xin.grad is not None and m.conv.weight.grad is not None and m.gn.weight.grad is not None

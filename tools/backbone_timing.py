@@ -18,7 +18,10 @@ if os.environ.get('DFM_NO_MFMA_CONV') == '1':
 outs = {}
 only = os.environ.get('DFM_ONLY', '')
 for dtype in ((torch.bfloat16,) if only == 'bf16' else (torch.float32, torch.bfloat16)):
-    for fmt in (torch.contiguous_format, torch.channels_last_3d):
+    fmts = (torch.contiguous_format, torch.channels_last_3d)
+    if os.environ.get('DFM_ONLY_FMT') == 'cl':
+        fmts = (torch.channels_last_3d,)
+    for fmt in fmts:
         torch.manual_seed(0)
         m = mods.DfMBackbone(in_channels=32).to(dev).to(dtype).eval()
         m.downsampled_depth = pkg.prepare_depth(dict(num_bins=288, depth_min=2, depth_max=59.6, downsample_factor=4))[0]
@@ -35,9 +38,12 @@ for dtype in ((torch.bfloat16,) if only == 'bf16' else (torch.float32, torch.bfl
         with torch.no_grad():
             for _ in range(2): out = m(cur, prev, [meta])
             torch.cuda.synchronize(); t = time.perf_counter()
-            for _ in range(5): out = m(cur, prev, [meta])
-            torch.cuda.synchronize(); ms = (time.perf_counter() - t) * 1e3 / 5
+            iters = int(os.environ.get('DFM_ITERS', '5'))
+            for _ in range(iters): out = m(cur, prev, [meta])
+            torch.cuda.synchronize(); ms = (time.perf_counter() - t) * 1e3 / iters
         outs[(dtype, fmt)] = out[0].float()
         print(f'DfMBackbone.forward {str(dtype)[6:]:9s} {str(fmt)[6:]:18s}: {ms:8.2f} ms', flush=True)
+    if len(fmts) < 2:
+        continue
     a, b = outs[(dtype, torch.contiguous_format)], outs[(dtype, torch.channels_last_3d)]
     print(f'  max |cost(channels_last) - cost(contiguous)| = {float((a - b).abs().max()):.3e} (max |cost| {float(a.abs().max()):.3e})')
