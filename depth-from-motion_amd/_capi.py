@@ -45,6 +45,10 @@ EXPORTS = (
     'dfm_conv3d_k3_c32_pack_weights',
     'dfm_conv3d_k3_c32_stats_splits',
     'dfm_conv3d_k3_c32_fwd',
+    'dfm_conv3d_g_weight_bytes',
+    'dfm_conv3d_g_pack_weights',
+    'dfm_conv3d_g_fwd',
+    'dfm_conv3d_g_plan',
     'dfm_depth_loss_fwd',
     'dfm_depth_loss_bwd',
     'dfm_voxel_sample_fwd',
@@ -141,6 +145,14 @@ class DepthLossDesc(ctypes.Structure):
         [('dtype', ctypes.c_int32)]
 
 
+class Conv3dDesc(ctypes.Structure):
+    """struct dfm_conv3d_desc"""
+    _fields_ = [('n', ctypes.c_int32), ('cin', ctypes.c_int32), ('cout', ctypes.c_int32),
+                ('in_size', ctypes.c_int32 * 3), ('out_size', ctypes.c_int32 * 3),
+                ('stride', ctypes.c_int32 * 3), ('padding', ctypes.c_int32 * 3),
+                ('transposed', ctypes.c_int32 * 3), ('relu', ctypes.c_int32)]
+
+
 DL_LINEAR, DL_HARD, DL_GAUSSIAN, DL_LAPLACIAN = 0, 1, 2, 3
 
 
@@ -225,6 +237,15 @@ def lib():
     h.dfm_conv3d_k3_c32_fwd.argtypes = [i32, i32, i32, i32, vp, vp, fp, vp, i32, i32, i32, fp, vp]
     h.dfm_conv3d_k3_c32_stats_splits.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_stats_splits.argtypes = [i32, i32, i32, i32, i32]
+    cp = ctypes.POINTER(Conv3dDesc)
+    h.dfm_conv3d_g_weight_bytes.restype = sz
+    h.dfm_conv3d_g_weight_bytes.argtypes = [i32, i32]
+    h.dfm_conv3d_g_pack_weights.restype = ctypes.c_int
+    h.dfm_conv3d_g_pack_weights.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+    h.dfm_conv3d_g_fwd.restype = ctypes.c_int
+    h.dfm_conv3d_g_fwd.argtypes = [cp, vp, vp, fp, fp, vp, vp, vp]
+    h.dfm_conv3d_g_plan.restype = ctypes.c_int
+    h.dfm_conv3d_g_plan.argtypes = [cp, ctypes.POINTER(ctypes.c_int64)]
     lp = ctypes.POINTER(DepthLossDesc)
     h.dfm_depth_loss_fwd.restype = ctypes.c_int
     h.dfm_depth_loss_fwd.argtypes = [lp, vp, fp, fp, fp, vp, vp]

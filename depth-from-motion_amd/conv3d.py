@@ -147,3 +147,209 @@ class MfmaConv3d(nn.Conv3d):
         """(y, moment partials): the convolution plus the per-channel GroupNorm statistics of y
         from the kernel's epilogue (``x`` must be eligible)."""
         return _MfmaConvFn.apply(x, self.weight, self._packed(), True)
+
+
+# ---------------------------------------------------------------------------------------------
+# General MFMA Conv3d / ConvTranspose3d 3x3x3 (csrc/conv3d_g.hip): channels = 32 k, stride 1 | 2,
+# padding 0..2, x2 transposed axes; epilogue scale/shift (+ residual) (+ ReLU).
+#   hourglass conv1..conv6            mmdet3d/models/utils/conv_modules.py:73-149
+#   ResModule / OutdoorImVoxelNeck    mmdet3d/models/necks/imvoxel_neck.py:26-55,85-117
+#   DfMNeck                           mmdet3d/models/necks/dfm_neck.py:29-95
+# ---------------------------------------------------------------------------------------------
+def _triple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+def pack_conv3d_g_weights(weight, cin, cout, swap=False, flip=0):
+    """torch weight (dim0, dim1, 3, 3, 3) fp32/bf16 on the GPU -> MFMA A-operand fragments (+ zero
+    page) for a convolution with ``cin`` input and ``cout`` output channels.  ``swap``: dim0 is the
+    input-channel axis of that convolution; ``flip``: bit mask (4 = d, 2 = h, 1 = w) of mirrored
+    kernel axes (see include/dfm_hip.h)."""
+    assert weight.is_cuda and weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3)
+    assert tuple(weight.shape[:2]) == ((cin, cout) if swap else (cout, cin))
+    w = weight.detach().contiguous()
+    if w.dtype not in _WDT:
+        w = w.float()
+    lib = _capi.lib()
+    packed = torch.empty(lib.dfm_conv3d_g_weight_bytes(cin, cout), dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        _capi.check(lib.dfm_conv3d_g_pack_weights(_ptr(w), _WDT[w.dtype], cin, cout, 1 if swap else 0,
+                                                  int(flip), _ptr(packed), _stream_ptr(w.device)))
+    return packed
+
+
+def _conv_desc(n, cin, cout, in_size, out_size, stride, padding, transposed, relu):
+    d = _capi.Conv3dDesc()
+    d.n, d.cin, d.cout, d.relu = n, cin, cout, 1 if relu else 0
+    for i in range(3):
+        d.in_size[i], d.out_size[i] = in_size[i], out_size[i]
+        d.stride[i], d.padding[i], d.transposed[i] = stride[i], padding[i], 1 if transposed[i] else 0
+    return d
+
+
+def conv3d_g_out_size(in_size, stride, padding, transposed):
+    return tuple(2 * s if t else (s + 2 * p - 3) // st + 1
+                 for s, st, p, t in zip(in_size, stride, padding, transposed))
+
+
+def conv3d_g_plan(n, cin, cout, in_size, stride=1, padding=1, transposed=False):
+    """The tiling the kernel picks: dict(pfw, cw, tile, block_px, lds, workgroups)."""
+    stride, padding = _triple(stride), _triple(padding)
+    transposed = _triple(transposed)
+    out_size = conv3d_g_out_size(in_size, stride, padding, transposed)
+    d = _conv_desc(n, cin, cout, in_size, out_size, stride, padding, transposed, False)
+    plan = (ctypes.c_int64 * 8)()
+    _capi.check(_capi.lib().dfm_conv3d_g_plan(ctypes.byref(d), plan))
+    return dict(pfw=plan[0], cw=plan[1], tile=(plan[2], plan[3], plan[4]), block_px=plan[5], lds=plan[6],
+                workgroups=plan[7])
+
+
+def conv3d_g(x, packed, cout, stride=1, padding=1, transposed=False, relu=False, scale=None, shift=None,
+             residual=None):
+    """x: (N, C_in, D, H, W) bf16 channels_last_3d.  Returns (N, cout, D', H', W') bf16
+    channels_last_3d = relu?(conv(x) * scale + shift + residual).  ``transposed``: per-axis flags of
+    the x2 transposed convolution (kernel 3, stride 2, padding 1, output_padding 1)."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and _is_ndhwc(x)
+    stride, padding, transposed = _triple(stride), _triple(padding), _triple(transposed)
+    N, cin = x.shape[:2]
+    in_size = tuple(x.shape[2:])
+    out_size = conv3d_g_out_size(in_size, stride, padding, transposed)
+    out = torch.empty((N, *out_size, cout), dtype=torch.bfloat16, device=x.device)
+    d = _conv_desc(N, cin, cout, in_size, out_size, stride, padding, transposed, relu)
+    if scale is not None:
+        scale, shift = scale.float().contiguous(), shift.float().contiguous()
+        assert scale.numel() == cout and shift.numel() == cout
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and tuple(residual.shape) == (N, cout, *out_size) and \
+            _is_ndhwc(residual)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().dfm_conv3d_g_fwd(
+            ctypes.byref(d), _ptr(x), _ptr(packed), _ptr(scale) if scale is not None else None,
+            _ptr(shift) if shift is not None else None, _ptr(residual) if residual is not None else None,
+            _ptr(out), _stream_ptr(x.device)))
+    return out.permute(0, 4, 1, 2, 3)
+
+
+def _bwd_data_supported(in_size, stride, padding):
+    """backward-data of an nn.Conv3d runs in the same kernel when every stride-2 axis has padding 1
+    and an even extent (it becomes a transposed axis)"""
+    return all(st == 1 or (st == 2 and p == 1 and s % 2 == 0) for s, st, p in zip(in_size, stride, padding))
+
+
+class _ConvGFn(torch.autograd.Function):
+    """nn.Conv3d (kind 'conv') / nn.ConvTranspose3d k3 s2 p1 op1 (kind 'convT') through the MFMA kernel.
+    Backward-data is another launch of the same kernel; backward-weight is torch's (MIOpen)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, packed, kind, stride, padding):
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (kind, stride, padding)
+        if kind == 'conv':
+            return conv3d_g(x, packed, weight.shape[0], stride, padding)
+        return conv3d_g(x, packed, weight.shape[1], transposed=True)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        kind, stride, padding = ctx.cfg
+        gy = gy.contiguous(memory_format=torch.channels_last_3d)
+        gx = gw = None
+        in_size = tuple(x.shape[2:])
+        if kind == 'conv':
+            cout, cin = weight.shape[:2]
+            if ctx.needs_input_grad[0]:
+                if _bwd_data_supported(in_size, stride, padding):
+                    up = tuple(st == 2 for st in stride)
+                    flip = sum(b for b, st in zip((4, 2, 1), stride) if st == 1)
+                    pk = pack_conv3d_g_weights(weight, cout, cin, swap=True, flip=flip)
+                    gx = conv3d_g(gy, pk, cin, stride=1, padding=tuple(2 - p for p in padding), transposed=up)
+                else:
+                    gx = torch.ops.aten.convolution_backward(
+                        gy, x, weight.to(x.dtype), None, list(stride), list(padding), [1, 1, 1], False,
+                        [0, 0, 0], 1, [True, False, False])[0]
+            if ctx.needs_input_grad[1]:
+                gw = torch.ops.aten.convolution_backward(
+                    gy, x, weight.to(x.dtype), None, list(stride), list(padding), [1, 1, 1], False, [0, 0, 0], 1,
+                    [False, True, False])[1].to(weight.dtype)
+        else:
+            cin, cout = weight.shape[:2]
+            if ctx.needs_input_grad[0]:
+                pk = pack_conv3d_g_weights(weight, cout, cin, swap=False, flip=0)
+                gx = conv3d_g(gy, pk, cin, stride=2, padding=1)
+            if ctx.needs_input_grad[1]:
+                gw = torch.ops.aten.convolution_backward(
+                    gy, x, weight.to(x.dtype), None, [2, 2, 2], [1, 1, 1], [1, 1, 1], True, [1, 1, 1], 1,
+                    [False, True, False])[1].to(weight.dtype)
+        return gx, gw, None, None, None, None
+
+
+class _PackCache:
+    """packed weight fragments of a module's parameter, rebuilt when the parameter changes"""
+
+    def __init__(self):
+        self._pack, self._key = None, None
+
+    def get(self, weight, make):
+        key = (weight._version, weight.data_ptr(), weight.device)
+        if self._key != key:
+            self._pack, self._key = make(), key
+        return self._pack
+
+
+class MfmaConv3dG(nn.Conv3d):
+    """nn.Conv3d(32 j, 32 k, 3, stride in {1, 2}, padding in {0, 1, 2}, bias=False) whose bf16 /
+    NDHWC forward is the general MFMA kernel; any other input takes torch's convolution (MIOpen),
+    the module's other documented path.  ``forward_fused`` folds a per-channel scale / shift (an
+    eval-mode BatchNorm3d), a residual and the ReLU into the epilogue (inference)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._cache = _PackCache()
+
+    def eligible(self, x):
+        return (x.is_cuda and x.dtype == torch.bfloat16 and _is_ndhwc(x) and self.in_channels % 32 == 0 and
+                self.out_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and
+                all(s in (1, 2) for s in self.stride) and all(0 <= p <= 2 for p in self.padding) and
+                self.dilation == (1, 1, 1) and self.groups == 1 and self.bias is None and
+                self.padding_mode == 'zeros' and
+                all(s + 2 * p >= 3 for s, p in zip(x.shape[2:], self.padding)))
+
+    def _packed(self):
+        return self._cache.get(self.weight, lambda: pack_conv3d_g_weights(
+            self.weight, self.in_channels, self.out_channels))
+
+    def forward(self, x):
+        if self.eligible(x):
+            return _ConvGFn.apply(x, self.weight, self._packed(), 'conv', self.stride, self.padding)
+        return super().forward(x)
+
+    def forward_fused(self, x, scale=None, shift=None, residual=None, relu=False):
+        """inference only (no autograd): relu?(conv(x) * scale + shift + residual)"""
+        assert self.eligible(x)
+        return conv3d_g(x, self._packed(), self.out_channels, self.stride, self.padding, relu=relu,
+                        scale=scale, shift=shift, residual=residual)
+
+
+class MfmaConvTranspose3d(nn.ConvTranspose3d):
+    """nn.ConvTranspose3d(32 j, 32 k, 3, stride=2, padding=1, output_padding=1, bias=False) of the
+    hourglass (conv_modules.py:101-117): evaluated per output parity class on the low-resolution
+    input by the general MFMA kernel when the input is bf16 / NDHWC."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._cache = _PackCache()
+
+    def eligible(self, x):
+        return (x.is_cuda and x.dtype == torch.bfloat16 and _is_ndhwc(x) and self.in_channels % 32 == 0 and
+                self.out_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and self.stride == (2, 2, 2) and
+                self.padding == (1, 1, 1) and self.output_padding == (1, 1, 1) and
+                self.dilation == (1, 1, 1) and self.groups == 1 and self.bias is None)
+
+    def _packed(self):
+        return self._cache.get(self.weight, lambda: pack_conv3d_g_weights(
+            self.weight, self.in_channels, self.out_channels, swap=True))
+
+    def forward(self, x, output_size=None):
+        if output_size is None and self.eligible(x):
+            return _ConvGFn.apply(x, self.weight, self._packed(), 'convT', self.stride, self.padding)
+        return super().forward(x, output_size)

@@ -1,0 +1,543 @@
+// conv3d_g.hip -- general hand-written MFMA Conv3d / ConvTranspose3d 3x3x3 for the 3-D aggregation
+// stacks of the path, NDHWC bf16 activations, fp32 accumulation:
+//   hourglass conv1..conv6 (stride-2, 64-channel, transposed)  mmdet3d/models/utils/conv_modules.py:73-149
+//   ResModule / OutdoorImVoxelNeck Conv3d+BN3d+ReLU stacks      mmdet3d/models/necks/imvoxel_neck.py:26-55,85-117
+//   DfMNeck mono / stereo stacks                                mmdet3d/models/necks/dfm_neck.py:29-95
+// (the 32 -> 32 full-resolution convolutions keep their register-resident-weight kernel, conv3d.hip).
+//
+// Per axis the operation is either a correlation (kernel 3, stride 1 or 2, padding 0..2) or the
+// x2 up-sampling transposed convolution (kernel 3, stride 2, padding 1, output_padding 1).  The
+// transposed axes are evaluated by OUTPUT PARITY CLASS: an even output touches one tap, an odd
+// output two, so a workgroup of class (cd, ch, cw) runs 1..8 dense taps on the low-resolution
+// input -- no zero insertion, exactly the useful FLOPs.  Backward-data of every variant is another
+// launch of the same kernel (stride-1: mirrored taps; stride-2 <-> transposed), only the weight
+// packing differs (dfm_conv3d_g_pack_weights: swap / flip).
+//
+// Tiling (one workgroup = 256 lanes = 4 waves, 2 workgroups per CU):
+//   * a workgroup owns a TD x TH x TW block of 128*PFW output positions and 32*CW output channels;
+//     per 32-channel input chunk it stages the input halo block it touches ONCE in LDS (LDS-DMA,
+//     16-byte pieces, XOR-swizzled so the 64-byte pixel stride is conflict-free for ds_read_b128)
+//     and all taps read their B fragments from it: the input crosses L2 -> LDS 1.5-2.5x, not 27x;
+//   * MFMA orientation D[cout][pixel] = W[cout][k] * X[k][pixel] (v_mfma_f32_32x32x16_bf16): a wave
+//     owns PFW pixel fragments x CW channel fragments (16*PFW*CW accumulator registers); weight
+//     fragments come pre-packed from global memory (L2-resident, one 16-byte load per lane and
+//     fragment, prefetched one tap ahead) and are reused by the wave's PFW pixel fragments, each
+//     activation fragment by its CW channel fragments -> 1/CW KiB of LDS and 1/PFW KiB of L2 per MFMA;
+//   * epilogue in registers: per-channel scale/shift (folded BatchNorm or bias), residual add, ReLU,
+//     8-byte bf16 stores of 4 consecutive channels.
+#include <algorithm>
+#include <type_traits>
+
+#include "dfm_common.h"
+
+using namespace dfm;
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int G_MAXR = 24;  // LDS-DMA rounds of 256 x 16 B: block <= 1536 pixels = 96 KiB
+constexpr int G_MAX_BLOCK_PX = G_MAXR * 64;
+
+struct GAxis {
+    int32_t in, out;   // extent of the input / output along this axis
+    int32_t tile;      // tile extent in "tile space" (output positions; input positions when up)
+    int32_t block;     // staged input extent
+    int32_t stride;    // 1 | 2 (correlation axes)
+    int32_t pad;       // 0..2 (correlation axes)
+    int32_t up;        // 1: x2 transposed-convolution axis
+    int32_t tiles;
+};
+
+struct GGeom {
+    GAxis d, h, w;
+    int32_t cin, cout, nchunk, cout_tiles, relu, nrounds, block_px;
+    float r_bw, r_bhw;  // 1 / block.w, 1 / (block.h * block.w)
+};
+
+// generic weight packing: A-operand fragments [cout_tile][chunk][tap][ks][cw][lane][8]:
+// lane l holds A[row = cw*32 + (l & 31)][k = chunk*32 + ks*16 + (l >> 5)*8 + j] of tap t, with
+//   A[row][k] = swap ? W[k][row][t'] : W[row][k][t'],   t' = t with the kernel index mirrored (k -> 2 - k)
+//   on the axes whose bit is set in `flip` (bit 2 = d, bit 1 = h, bit 0 = w)
+// (W: the torch weight tensor, dim0 x dim1 x 27)
+template <typename TW>
+__device__ __forceinline__ float g_wload(const TW *w, size_t idx);
+template <>
+__device__ __forceinline__ float g_wload<float>(const float *w, size_t idx) { return w[idx]; }
+template <>
+__device__ __forceinline__ float g_wload<bf16_t>(const bf16_t *w, size_t idx) { return bf16_to_f32(w[idx]); }
+
+template <typename TW>
+__global__ void conv3d_g_pack_kernel(const TW *__restrict__ w, int rows, int kk, int cw_n, int swap,
+                                     int flip, bf16_t *__restrict__ frag)
+{
+    // blockIdx.x = ((ct*nchunk + chunk)*27 + tap)*2 + ks, blockIdx.y = cw
+    const int nchunk = kk / 32;
+    int f = blockIdx.x;
+    const int ks = f & 1; f >>= 1;
+    const int tap = f % 27; f /= 27;
+    const int chunk = f % nchunk, ct = f / nchunk;
+    const int cw = blockIdx.y, l = threadIdx.x;
+    const int row = (ct * cw_n + cw) * 32 + (l & 31);
+    const int k0 = chunk * 32 + ks * 16 + (l >> 5) * 8;
+    int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    if (flip & 4) kd = 2 - kd;
+    if (flip & 2) kh = 2 - kh;
+    if (flip & 1) kw = 2 - kw;
+    const int t = (kd * 3 + kh) * 3 + kw;
+    const size_t o = (((size_t)blockIdx.x * cw_n + cw) * 64 + l) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const size_t idx = swap ? ((size_t)(k0 + j) * rows + row) * 27 + t
+                                : ((size_t)row * kk + k0 + j) * 27 + t;
+        frag[o + j] = f32_to_bf16(g_wload<TW>(w, idx));
+    }
+}
+
+template <int CW, int PFW>
+__global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
+    GGeom g, const bf16_t *__restrict__ x, const uint4 *__restrict__ wfrag,
+    const float *__restrict__ scale, const float *__restrict__ shift,
+    const bf16_t *__restrict__ residual, bf16_t *__restrict__ out,
+    const uint4 *__restrict__ zero_page)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char blk[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l32 = lane & 31, half = lane >> 5;
+
+    // ---- which tile / channel tile / parity class -------------------------------------------
+    int t = blockIdx.x;
+    const int tiw = t % g.w.tiles; t /= g.w.tiles;
+    const int tih = t % g.h.tiles;
+    const int tid_ = t / g.h.tiles;
+    int yy = blockIdx.y;
+    const int ct = yy % g.cout_tiles; yy /= g.cout_tiles;
+    const int ncw = g.w.up ? 2 : 1, nch = g.h.up ? 2 : 1;
+    const int pcw = yy % ncw; yy /= ncw;
+    const int pch = yy % nch;
+    const int pcd = yy / nch;
+    const int n = blockIdx.z;
+
+    const int od0 = tid_ * g.d.tile, oh0 = tih * g.h.tile, ow0 = tiw * g.w.tile;  // tile space
+    const int bd0 = g.d.up ? od0 : od0 * g.d.stride - g.d.pad;                     // block origin (input)
+    const int bh0 = g.h.up ? oh0 : oh0 * g.h.stride - g.h.pad;
+    const int bw0 = g.w.up ? ow0 : ow0 * g.w.stride - g.w.pad;
+    const int BH = g.h.block, BW = g.w.block;
+
+    const int pix_bytes = g.cin * 2;
+    const int BHW = BH * BW;
+    const unsigned char *xs = (const unsigned char *)(x + (size_t)n * g.d.in * g.h.in * g.w.in * g.cin);
+
+    // ---- this lane's pixels: PFW fragments of 32 consecutive tile positions per wave -----------
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)blk;
+    int base_bp[PFW];
+    int opix[PFW];  // output voxel index inside the sample, -1: outside the volume
+    {
+        const int sd = g.d.up ? 1 : g.d.stride, sh = g.h.up ? 1 : g.h.stride, sw = g.w.up ? 1 : g.w.stride;
+#pragma unroll
+        for (int f = 0; f < PFW; ++f) {
+            const int i = (wave * PFW + f) * 32 + l32;
+            const int tw = i % g.w.tile, i2 = i / g.w.tile;
+            const int th = i2 % g.h.tile, td = i2 / g.h.tile;
+            base_bp[f] = (td * sd * BH + th * sh) * BW + tw * sw;
+            const int od = g.d.up ? 2 * (od0 + td) + pcd : od0 + td;
+            const int oh = g.h.up ? 2 * (oh0 + th) + pch : oh0 + th;
+            const int ow = g.w.up ? 2 * (ow0 + tw) + pcw : ow0 + tw;
+            const bool ok = od < g.d.out && oh < g.h.out && ow < g.w.out;
+            opix[f] = ok ? (od * g.h.out + oh) * g.w.out + ow : -1;
+        }
+    }
+
+    // ---- taps of this class: counters (jd, jh, jw) -> (weight tap index, block offset in pixels) ----
+    const int ntw = g.w.up ? 1 + pcw : 3, nth = g.h.up ? 1 + pch : 3, ntd = g.d.up ? 1 + pcd : 3;
+    const int ntaps = ntd * nth * ntw;
+    int jd = 0, jh = 0, jw = 0;
+    auto tap_cur = [&](int &wt, int &off) {
+        // correlation axis: k = j at offset j; up axis: even class -> k 1 @ +0; odd -> k 2 @ +0, k 0 @ +1
+        const int kw = g.w.up ? (pcw ? (jw ? 0 : 2) : 1) : jw;
+        const int kh = g.h.up ? (pch ? (jh ? 0 : 2) : 1) : jh;
+        const int kd = g.d.up ? (pcd ? (jd ? 0 : 2) : 1) : jd;
+        wt = (kd * 3 + kh) * 3 + kw;
+        off = (jd * BH + jh) * BW + jw;
+    };
+    auto tap_adv = [&]() {
+        if (++jw == ntw) {
+            jw = 0;
+            if (++jh == nth) { jh = 0; ++jd; }
+        }
+    };
+
+    f32x16_t acc[PFW][CW];
+#pragma unroll
+    for (int f = 0; f < PFW; ++f)
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[f][c][i] = 0.0f;
+
+    // one round of ds_read_b128: the PFW B fragments of (tap offset `off`, k-step ks)
+    auto issue = [&](int off, int ks, u32x4_t (&dst)[PFW]) {
+#pragma unroll
+        for (int f = 0; f < PFW; ++f) {
+            const int bp = base_bp[f] + off;
+            const uint32_t a = lds0 + (uint32_t)bp * 64u + ((((uint32_t)(2 * ks + half)) ^ (((uint32_t)bp >> 2) & 3u)) << 4);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst[f]) : "v"(a));
+        }
+    };
+
+    for (int chunk = 0; chunk < g.nchunk; ++chunk) {
+        if (chunk > 0) __syncthreads();  // every wave is done reading the previous chunk's block
+        {
+            // stage the halo block of this 32-channel chunk: piece q = 16 bytes, LDS position q * 16
+            // holds slot (q & 3) ^ swizzle of block pixel q >> 2 (zero page outside the volume)
+            const unsigned char *src = xs + chunk * 64;
+            unsigned char *dst = blk + wave * 1024;
+            for (int r = 0; r < g.nrounds; ++r) {
+                const int q = r * 256 + tid;
+                const int p = q >> 2, sl = (q & 3) ^ ((p >> 2) & 3);
+                const int bd = (int)(((float)p + 0.5f) * g.r_bhw);
+                const int rem = p - bd * BHW;
+                const int bh = (int)(((float)rem + 0.5f) * g.r_bw);
+                const int bw = rem - bh * BW;
+                const int d = bd0 + bd, h = bh0 + bh, w = bw0 + bw;
+                const bool ok = p < g.block_px && (unsigned)d < (unsigned)g.d.in && (unsigned)h < (unsigned)g.h.in &&
+                                (unsigned)w < (unsigned)g.w.in;
+                const unsigned char *s_ = ok ? src + (((d * g.h.in + h) * g.w.in + w) * pix_bytes + sl * 16)
+                                             : (const unsigned char *)zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)s_,
+                                                 (__attribute__((address_space(3))) void *)(dst + r * 4096),
+                                                 16, 0, 0);
+            }
+        }
+        // weights of the first tap travel while the block lands
+        const uint4 *wp = wfrag + ((size_t)(ct * g.nchunk + chunk) * 27 * 2 * CW) * 64 + lane;
+        auto wload = [&](int wt, bf16x8_t (&dst)[2][CW]) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    const uint4 q = wp[((wt * 2 + ks) * CW + c) * 64];
+                    __builtin_memcpy(&dst[ks][c], &q, 16);
+                }
+        };
+        bf16x8_t wc[2][CW], wn[2][CW];
+        int wt, off, offn;
+        jd = jh = jw = 0;
+        tap_cur(wt, off);
+        wload(wt, wn);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the block has landed
+
+        u32x4_t q0[PFW], q1[PFW];
+        issue(off, 0, q0);
+        // q (issued one round earlier) is complete when at most PFW newer reads are outstanding
+#define G_WAIT(Q, N)                                                                                         \
+        do {                                                                                                 \
+            if constexpr (PFW == 1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]));                   \
+            if constexpr (PFW == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]));      \
+            if constexpr (PFW == 3) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2])); \
+            if constexpr (PFW == 4) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3])); \
+        } while (0)
+#define G_WAIT_PFW(Q)                                                                                        \
+        do {                                                                                                 \
+            if constexpr (PFW == 1) G_WAIT(Q, 1);                                                            \
+            if constexpr (PFW == 2) G_WAIT(Q, 2);                                                            \
+            if constexpr (PFW == 3) G_WAIT(Q, 3);                                                            \
+            if constexpr (PFW == 4) G_WAIT(Q, 4);                                                            \
+        } while (0)
+        auto mfmas = [&](bf16x8_t (&wk)[CW], u32x4_t (&q)[PFW]) {
+#pragma unroll
+            for (int f = 0; f < PFW; ++f) {
+                bf16x8_t xf;
+                __builtin_memcpy(&xf, &q[f], 16);
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[c], xf, acc[f][c], 0, 0, 0);
+            }
+        };
+        for (int j = 0; j + 1 < ntaps; ++j) {
+            // the weights of this tap were requested one tap ago; request the next tap's
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int c = 0; c < CW; ++c) wc[ks][c] = wn[ks][c];
+            tap_adv();
+            tap_cur(wt, offn);
+            wload(wt, wn);
+            issue(off, 1, q1);
+            G_WAIT_PFW(q0);
+            mfmas(wc[0], q0);
+            issue(offn, 0, q0);
+            G_WAIT_PFW(q1);
+            mfmas(wc[1], q1);
+            off = offn;
+        }
+        // last tap
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int c = 0; c < CW; ++c) wc[ks][c] = wn[ks][c];
+        issue(off, 1, q1);
+        G_WAIT_PFW(q0);
+        mfmas(wc[0], q0);
+        G_WAIT(q1, 0);
+        mfmas(wc[1], q1);
+#undef G_WAIT
+#undef G_WAIT_PFW
+    }
+
+    // ---- epilogue: lane = pixel (l32) x 4 groups of 4 consecutive channels per channel fragment ----
+    const size_t osample = (size_t)n * g.d.out * g.h.out * g.w.out;
+    auto epilogue = [&](auto has_scale, auto has_res) {
+#pragma unroll
+        for (int f = 0; f < PFW; ++f) {
+            if (opix[f] < 0) continue;
+            const size_t vox = osample + (size_t)opix[f];
+            u32x2_t rr[CW][4];
+            if constexpr (decltype(has_res)::value) {
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        rr[c][gq] = *(const u32x2_t *)(residual + vox * g.cout + (ct * CW + c) * 32 + 8 * gq + 4 * half);
+            }
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int ch = (ct * CW + c) * 32 + 8 * gq + 4 * half;
+                    float v0 = acc[f][c][4 * gq], v1 = acc[f][c][4 * gq + 1], v2 = acc[f][c][4 * gq + 2],
+                          v3 = acc[f][c][4 * gq + 3];
+                    if constexpr (decltype(has_scale)::value) {
+                        const float4 s4 = *(const float4 *)(scale + ch), b4 = *(const float4 *)(shift + ch);
+                        v0 = __builtin_fmaf(v0, s4.x, b4.x); v1 = __builtin_fmaf(v1, s4.y, b4.y);
+                        v2 = __builtin_fmaf(v2, s4.z, b4.z); v3 = __builtin_fmaf(v3, s4.w, b4.w);
+                    }
+                    if constexpr (decltype(has_res)::value) {
+                        v0 += __uint_as_float(rr[c][gq].x << 16); v1 += __uint_as_float(rr[c][gq].x & 0xffff0000u);
+                        v2 += __uint_as_float(rr[c][gq].y << 16); v3 += __uint_as_float(rr[c][gq].y & 0xffff0000u);
+                    }
+                    if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    const u32x2_t pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                    *(u32x2_t *)(out + vox * g.cout + ch) = pk;
+                }
+            }
+        }
+    };
+    if (scale) {
+        if (residual) epilogue(std::true_type{}, std::true_type{});
+        else epilogue(std::true_type{}, std::false_type{});
+    } else {
+        if (residual) epilogue(std::false_type{}, std::true_type{});
+        else epilogue(std::false_type{}, std::false_type{});
+    }
+}
+
+// ---- host: tile selection ------------------------------------------------------------------------
+struct GPlan {
+    GGeom g;
+    int pfw, cw, classes;
+    size_t lds;
+};
+
+void axis_fill(GAxis &a, int tile)
+{
+    a.tile = tile;
+    const int space = a.up ? a.in : a.out;
+    a.tiles = (space + tile - 1) / tile;
+    a.block = a.up ? tile + 1 : (tile - 1) * a.stride + 3;
+}
+
+// picks (PFW, TD, TH, TW): minimum estimated time = rounds of workgroups over the chip x per-workgroup
+// cost (MFMA work ~ positions, staging ~ block pixels)
+bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
+{
+    GGeom g{};
+    GAxis *ax[3] = {&g.d, &g.h, &g.w};
+    int classes = 1;
+    for (int i = 0; i < 3; ++i) {
+        ax[i]->in = d->in_size[i]; ax[i]->out = d->out_size[i];
+        ax[i]->stride = d->stride[i]; ax[i]->pad = d->padding[i]; ax[i]->up = d->transposed[i] ? 1 : 0;
+        if (ax[i]->up) classes *= 2;
+    }
+    g.cin = d->cin; g.cout = d->cout; g.nchunk = d->cin / 32;
+    const int cw = d->cout % 64 == 0 ? 2 : 1;
+    g.cout_tiles = d->cout / (32 * cw);
+    g.relu = d->relu ? 1 : 0;
+    double best = 1e300;
+    bool found = false;
+    const int sp[3] = {g.d.up ? g.d.in : g.d.out, g.h.up ? g.h.in : g.h.out, g.w.up ? g.w.in : g.w.out};
+    // pass 0 keeps tiles inside (twice) the volume; pass 1 (tiny volumes) takes any factorisation
+    for (int pass = 0; pass < 2 && !found; ++pass)
+    for (int pfw = 4; pfw >= 1; --pfw) {
+        const int P = 128 * pfw;
+        for (int td = 1; td <= P; ++td) {
+            if (P % td) continue;
+            if (pass == 0 && td > sp[0] && td > 1) continue;
+            for (int th = 1; th <= P / td; ++th) {
+                if ((P / td) % th) continue;
+                const int tw = P / td / th;
+                if (pass == 0 && ((th > 2 * sp[1] && th > 1) || (tw > 2 * sp[2] && tw > 1))) continue;
+                GGeom c = g;
+                axis_fill(c.d, td); axis_fill(c.h, th); axis_fill(c.w, tw);
+                const long long bpx = (long long)c.d.block * c.h.block * c.w.block;
+                if (bpx > G_MAX_BLOCK_PX) continue;
+                const int rounds = (int)((bpx * 4 + 255) / 256);
+                const size_t lds = (size_t)rounds * 4096;
+                const long long wgs = (long long)c.d.tiles * c.h.tiles * c.w.tiles * c.cout_tiles * classes * d->n;
+                // workgroups that actually share a CU: at most 2 (registers), what the LDS allows,
+                // and no more than there are workgroups per CU
+                const int wg_per_cu = (int)std::max<long long>(
+                    1, std::min<long long>(std::min(2, (int)(160 * 1024 / lds)), (wgs + 255) / 256));
+                const long long waves = (wgs + 256 * wg_per_cu - 1) / (256 * wg_per_cu);
+                // per-workgroup cost in clocks.  One tap = 2 k-steps: 2*pfw*cw MFMAs of 32 clocks per
+                // wave, against 4 waves x 2*cw KiB of weight fragments from L2 (~40 B/clk/CU); resident
+                // workgroups share both the MFMA pipes and the L2 port.  Staging ~ 0.1 clk/B.
+                const double taps = 27.0 / classes;
+                const double mf_tap = (double)pfw * cw * 64.0 * wg_per_cu;
+                const double wt_tap = 8192.0 * cw / 40.0 * wg_per_cu;
+                const double mf = std::max(mf_tap, wt_tap) * taps * g.nchunk;
+                const double st = ((double)bpx * 64 * 0.1 + 1500.0) * g.nchunk;
+                const double cost = (double)waves * (mf + st);
+                if (cost < best) {
+                    best = cost; found = true;
+                    c.block_px = (int)bpx; c.nrounds = rounds;
+                    c.r_bw = 1.0f / (float)c.w.block; c.r_bhw = 1.0f / (float)(c.h.block * c.w.block);
+                    pl.g = c; pl.pfw = pfw; pl.cw = cw; pl.classes = classes; pl.lds = lds;
+                }
+            }
+        }
+    }
+    return found;
+}
+
+int g_check(const dfm_conv3d_desc *d)
+{
+    if (!d) return set_error(DFM_ERR_INVALID_ARG, "NULL conv descriptor");
+    if (d->n <= 0 || d->n > 65535) return set_error(DFM_ERR_INVALID_ARG, "batch must be 1..65535");
+    if (d->cin <= 0 || d->cin % 32 || d->cout <= 0 || d->cout % 32)
+        return set_error(DFM_ERR_UNSUPPORTED, "channel counts must be multiples of 32");
+    long long in_px = 1, out_px = 1;
+    for (int i = 0; i < 3; ++i) {
+        if (d->in_size[i] <= 0 || d->out_size[i] <= 0) return set_error(DFM_ERR_INVALID_ARG, "non-positive size");
+        if (d->transposed[i]) {
+            if (d->out_size[i] != 2 * d->in_size[i])
+                return set_error(DFM_ERR_UNSUPPORTED, "transposed axes are kernel 3, stride 2, padding 1, output_padding 1 (out = 2 in)");
+        } else {
+            if (d->stride[i] < 1 || d->stride[i] > 2 || d->padding[i] < 0 || d->padding[i] > 2)
+                return set_error(DFM_ERR_UNSUPPORTED, "stride must be 1 or 2, padding 0..2");
+            const int o = (d->in_size[i] + 2 * d->padding[i] - 3) / d->stride[i] + 1;
+            if (d->in_size[i] + 2 * d->padding[i] < 3 || o != d->out_size[i])
+                return set_error(DFM_ERR_INVALID_ARG, "out_size does not match in_size / stride / padding");
+        }
+        in_px *= d->in_size[i]; out_px *= d->out_size[i];
+    }
+    if (in_px * d->cin * 2 >= (1ll << 31) || out_px >= (1ll << 31))
+        return set_error(DFM_ERR_UNSUPPORTED, "sample too large for 32-bit offsets");
+    return DFM_OK;
+}
+
+}  // namespace
+
+extern "C" DFM_API size_t dfm_conv3d_g_weight_bytes(int32_t cin, int32_t cout)
+{
+    if (cin <= 0 || cout <= 0 || cin % 32 || cout % 32) return 0;
+    return (size_t)cin * cout * 27 * 2 + 4096;  // fragments + the zero page
+}
+
+extern "C" DFM_API int dfm_conv3d_g_pack_weights(const void *weight, int32_t weight_dtype, int32_t cin,
+                                                 int32_t cout, int32_t swap, int32_t flip, void *packed,
+                                                 void *stream)
+{
+    if (!weight || !packed) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (cin <= 0 || cout <= 0 || cin % 32 || cout % 32)
+        return set_error(DFM_ERR_UNSUPPORTED, "channel counts must be multiples of 32");
+    if (weight_dtype != DFM_F32 && weight_dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "weight dtype must be DFM_F32 or DFM_BF16");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t fb = (size_t)cin * cout * 27 * 2;
+    hipError_t e = hipMemsetAsync((char *)packed + fb, 0, 4096, st);
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    const int cw = cout % 64 == 0 ? 2 : 1;
+    const int cts = cout / (32 * cw), nchunk = cin / 32;
+    dim3 grid(cts * nchunk * 27 * 2, cw);
+    if (weight_dtype == DFM_F32)
+        hipLaunchKernelGGL(conv3d_g_pack_kernel<float>, grid, dim3(64), 0, st, (const float *)weight, cout, cin,
+                           cw, swap, flip, (bf16_t *)packed);
+    else
+        hipLaunchKernelGGL(conv3d_g_pack_kernel<bf16_t>, grid, dim3(64), 0, st, (const bf16_t *)weight, cout,
+                           cin, cw, swap, flip, (bf16_t *)packed);
+    e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+extern "C" DFM_API int dfm_conv3d_g_fwd(const dfm_conv3d_desc *desc, const void *x, const void *packed_weights,
+                                        const float *scale, const float *shift, const void *residual,
+                                        void *out, void *stream)
+{
+    const int rc = g_check(desc);
+    if (rc != DFM_OK) return rc;
+    if (!x || !packed_weights || !out) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if ((scale == nullptr) != (shift == nullptr))
+        return set_error(DFM_ERR_INVALID_ARG, "scale and shift come together");
+    GPlan pl;
+    if (!g_plan(desc, pl)) return set_error(DFM_ERR_UNSUPPORTED, "no tiling fits the LDS budget");
+    const long long tiles = (long long)pl.g.d.tiles * pl.g.h.tiles * pl.g.w.tiles;
+    if (tiles >= (1ll << 31) || pl.g.cout_tiles * pl.classes > 65535)
+        return set_error(DFM_ERR_UNSUPPORTED, "grid too large");
+    const uint4 *wfrag = (const uint4 *)packed_weights;
+    const uint4 *zero = (const uint4 *)((const char *)packed_weights + (size_t)desc->cin * desc->cout * 27 * 2);
+    dim3 grid((unsigned)tiles, pl.g.cout_tiles * pl.classes, desc->n);
+    hipStream_t st = (hipStream_t)stream;
+    const int lds = (int)pl.lds;
+    static bool attr_done[2][4] = {{false, false, false, false}, {false, false, false, false}};
+#define G_LAUNCH(CW_, PFW_)                                                                              \
+    do {                                                                                             \
+        if (!attr_done[CW_ - 1][PFW_ - 1]) {                                                         \
+            hipError_t e_ = hipFuncSetAttribute((const void *)conv3d_g_kernel<CW_, PFW_>,            \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304);  \
+            if (e_ != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e_));              \
+            attr_done[CW_ - 1][PFW_ - 1] = true;                                                     \
+        }                                                                                            \
+        hipLaunchKernelGGL((conv3d_g_kernel<CW_, PFW_>), grid, dim3(256), lds, st, pl.g,             \
+                           (const bf16_t *)x, wfrag, scale, shift, (const bf16_t *)residual,         \
+                           (bf16_t *)out, zero);                                                     \
+    } while (0)
+    if (pl.cw == 2) {
+        switch (pl.pfw) {
+        case 1: G_LAUNCH(2, 1); break;
+        case 2: G_LAUNCH(2, 2); break;
+        case 3: G_LAUNCH(2, 3); break;
+        default: G_LAUNCH(2, 4); break;
+        }
+    } else {
+        switch (pl.pfw) {
+        case 1: G_LAUNCH(1, 1); break;
+        case 2: G_LAUNCH(1, 2); break;
+        case 3: G_LAUNCH(1, 3); break;
+        default: G_LAUNCH(1, 4); break;
+        }
+    }
+#undef G_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+// the tiling the launch will use: {PFW, CW, TD, TH, TW, block pixels, LDS bytes, workgroups}
+extern "C" DFM_API int dfm_conv3d_g_plan(const dfm_conv3d_desc *desc, int64_t *plan8)
+{
+    const int rc = g_check(desc);
+    if (rc != DFM_OK) return rc;
+    if (!plan8) return set_error(DFM_ERR_INVALID_ARG, "NULL plan");
+    GPlan pl;
+    if (!g_plan(desc, pl)) return set_error(DFM_ERR_UNSUPPORTED, "no tiling fits the LDS budget");
+    plan8[0] = pl.pfw; plan8[1] = pl.cw; plan8[2] = pl.g.d.tile; plan8[3] = pl.g.h.tile; plan8[4] = pl.g.w.tile;
+    plan8[5] = pl.g.block_px; plan8[6] = (int64_t)pl.lds;
+    plan8[7] = (int64_t)pl.g.d.tiles * pl.g.h.tiles * pl.g.w.tiles * pl.g.cout_tiles * pl.classes * desc->n;
+    return DFM_OK;
+}

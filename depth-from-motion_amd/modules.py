@@ -13,16 +13,19 @@ The sampling stages call the HIP kernels (plane sweep, frustum-to-voxel,
 depth head), GroupNorm(+ReLU) is the fused HIP kernel, and the full-resolution
 3x3x3 convolutions with 32 output channels (dres0 / dres1 / pred / voxel_convs)
 are ``MfmaConv3d``: the hand-written MFMA kernel of csrc/conv3d.hip when the
-stack runs bf16 channels_last_3d.  The remaining convolutions (stride-2 and
-transposed convolutions of the hourglass at 1/8 .. 1/64 of the volume, the
-32 -> 1 prediction conv, the 2-D convs, BN3d necks) are MIOpen through torch.
+stack runs bf16 channels_last_3d.  The stride-2 / 64-channel / transposed
+convolutions of the hourglass and the Conv3d+BN3d(+ReLU) blocks of the voxel necks
+(64 .. 256 channels, stride (1,1,2), padding (1,1,0)) are ``MfmaConv3dG`` /
+``MfmaConvTranspose3d``: the general MFMA kernel of csrc/conv3d_g.hip (in eval mode the
+BatchNorm folds into its epilogue together with the residual add and the ReLU).
+The 32 -> 1 prediction conv and the 2-D convs are MIOpen through torch.
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import MfmaConv3d
+from .conv3d import MfmaConv3d, MfmaConv3dG, MfmaConvTranspose3d
 from .depth_head import depth_distribution_loss, depth_head_forward
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .group_norm import HipGroupNorm
@@ -63,6 +66,11 @@ class ConvModule(nn.Module):
             # the full-resolution 3x3x3 convolutions of the aggregation stacks: nn.Conv3d whose
             # bf16 / NDHWC forward is the hand-written MFMA kernel (csrc/conv3d.hip)
             conv_cls = MfmaConv3d
+        elif (conv_type == 'Conv3d' and out_channels % 32 == 0 and in_channels % 32 == 0 and kernel_size == 3
+              and norm_cfg is not None):
+            # every other 3x3x3 convolution of the path (64 .. 256 channels, stride (1,1,2), padding
+            # (1,1,0): the BN3d stacks of the voxel necks): the general MFMA kernel (csrc/conv3d_g.hip)
+            conv_cls = MfmaConv3dG
         self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride,
                              padding=padding, bias=norm_cfg is None)
         self.norm_name = None
@@ -83,6 +91,8 @@ class ConvModule(nn.Module):
             # the normalisation (+ReLU) is one read and one write of the tensor
             y, partials = self.conv.forward_with_stats(x)
             return norm(y, relu=self.activate is not None, partials=partials)
+        if self.fusable(x):
+            return self.forward_fused(x)
         x = self.conv(x)
         if self.norm_name is not None:
             if isinstance(norm, HipGroupNorm):
@@ -91,6 +101,27 @@ class ConvModule(nn.Module):
         if self.activate is not None:
             x = self.activate(x)
         return x
+
+
+    # -- inference path of the Conv3d + BatchNorm3d (+ReLU) blocks of the voxel necks: the running
+    # statistics fold into a per-channel scale / shift applied to the fp32 accumulator in the
+    # convolution's epilogue, together with the residual add and the ReLU (one kernel per block)
+    def fusable(self, x):
+        norm = getattr(self, self.norm_name) if self.norm_name is not None else None
+        return (isinstance(self.conv, MfmaConv3dG) and isinstance(norm, nn.BatchNorm3d) and
+                not norm.training and norm.track_running_stats and not torch.is_grad_enabled() and
+                self.conv.eligible(x))
+
+    def forward_fused(self, x, residual=None, relu=None):
+        norm = getattr(self, self.norm_name)
+        scale = torch.rsqrt(norm.running_var.float() + norm.eps)
+        if norm.affine:
+            scale = scale * norm.weight.float()
+        shift = -norm.running_mean.float() * scale
+        if norm.affine:
+            shift = shift + norm.bias.float()
+        relu = (self.activate is not None) if relu is None else relu
+        return self.conv.forward_fused(x, scale, shift, residual, relu)
 
 
 def _conv3(cin, cout, norm_cfg, act=True, stride=1, padding=1):
@@ -102,7 +133,7 @@ def _conv3(cin, cout, norm_cfg, act=True, stride=1, padding=1):
 # hourglass (conv_modules.py:73-149): keys conv1.0.0, conv2.0, ..., conv5.0/1
 # --------------------------------------------------------------------------
 def _convgn3d(cin, cout, stride):
-    return nn.Sequential(nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False),
+    return nn.Sequential(MfmaConv3dG(cin, cout, 3, stride=stride, padding=1, bias=False),
                          HipGroupNorm(32, cout))
 
 
@@ -118,17 +149,20 @@ class hourglass(nn.Module):  # noqa: N801  (reference class name)
         self.conv3 = nn.Sequential(_convgn3d(2 * c, 2 * c, 2), nn.ReLU(inplace=True))
         self.conv4 = nn.Sequential(_convgn3d(2 * c, 2 * c, 1), nn.ReLU(inplace=True))
         self.conv5 = nn.Sequential(
-            nn.ConvTranspose3d(2 * c, 2 * c, 3, padding=1, output_padding=1, stride=2, bias=False),
+            MfmaConvTranspose3d(2 * c, 2 * c, 3, padding=1, output_padding=1, stride=2, bias=False),
             HipGroupNorm(32, 2 * c))
         self.conv6 = nn.Sequential(
-            nn.ConvTranspose3d(2 * c, c, 3, padding=1, output_padding=1, stride=2, bias=False),
+            MfmaConvTranspose3d(2 * c, c, 3, padding=1, output_padding=1, stride=2, bias=False),
             HipGroupNorm(32, c))
 
     def forward(self, x, presqu, postsqu):
-        down1 = self.conv1(x)
-        pre = self.conv2(down1)
-        pre = F.relu(pre if postsqu is None else pre + postsqu)
-        bottom = self.conv4(self.conv3(pre))
+        # GroupNorm and the ReLU that follows it are one pass of the fused kernel
+        down1 = _gn_relu(self.conv1[0], x, True)
+        if postsqu is None:
+            pre = _gn_relu(self.conv2, down1, True)
+        else:
+            pre = F.relu(_gn_relu(self.conv2, down1, False) + postsqu)
+        bottom = _gn_relu(self.conv4[0], _gn_relu(self.conv3[0], pre, True), True)
         skip = pre if presqu is None else presqu
         post = F.relu(self.conv5(bottom) + skip)
         return self.conv6(post), pre, post
@@ -347,6 +381,9 @@ class ResModule(nn.Module):
         self.activation = nn.ReLU(inplace=True)
 
     def forward(self, x):
+        if self.conv0.fusable(x) and self.conv1.fusable(x):
+            # inference: conv-bn-relu and conv-bn + identity + relu are one MFMA kernel each
+            return self.conv1.forward_fused(self.conv0.forward_fused(x), residual=x, relu=True)
         return self.activation(x + self.conv1(self.conv0(x)))
 
 

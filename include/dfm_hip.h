@@ -424,6 +424,53 @@ DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, int32_t w, co
                                   void *stream);
 
 /* ---------------------------------------------------------------------- */
+/* General MFMA Conv3d / ConvTranspose3d 3x3x3, NDHWC bf16, channels = 32 k    */
+/* (hourglass conv1..conv6: utils/conv_modules.py:73-149; Conv3d+BN3d+ReLU     */
+/*  stacks of the voxel necks: necks/imvoxel_neck.py:26-55,85-117,             */
+/*  necks/dfm_neck.py:29-95)                                                   */
+/* ---------------------------------------------------------------------- */
+typedef struct dfm_conv3d_desc {
+    int32_t n;              /* batch                                                         */
+    int32_t cin, cout;      /* multiples of 32                                               */
+    int32_t in_size[3];     /* (d, h, w) of the input                                        */
+    int32_t out_size[3];    /* (d, h, w) of the output (checked against stride / padding)    */
+    int32_t stride[3];      /* 1 | 2 per axis (ignored on transposed axes)                   */
+    int32_t padding[3];     /* 0..2 per axis (ignored on transposed axes)                    */
+    int32_t transposed[3];  /* != 0: this axis is the x2 transposed convolution (kernel 3,   */
+                            /* stride 2, padding 1, output_padding 1: out = 2 in)            */
+    int32_t relu;           /* != 0: max(., 0) before the store                              */
+} dfm_conv3d_desc;
+/* Bytes of the packed-weight buffer (27 * cin * cout bf16 in fragment order + a zero page). */
+DFM_API size_t dfm_conv3d_g_weight_bytes(int32_t cin, int32_t cout);
+/* weight : dim0 x dim1 x 27 contiguous, DFM_F32 or DFM_BF16 [device].  The kernel multiplies
+ * A[row][k] (row = output channel, k = input channel) per tap t = (kd, kh, kw); this packs
+ *   A[row][k](t) = swap ? weight[k][row][t'] : weight[row][k][t'],
+ *   t' = t with the kernel index mirrored (k -> 2 - k) on the axes in the bit mask `flip`
+ *   (bit 2 = d, bit 1 = h, bit 0 = w).
+ *   nn.Conv3d forward            (weight (cout, cin, 27)):  swap 0, flip 0
+ *   nn.ConvTranspose3d forward   (weight (cin, cout, 27)):  swap 1, flip 0, all axes transposed
+ *   backward-data of nn.Conv3d   : swap 1; a stride-1 axis becomes a correlation axis with
+ *                                  padding 2 - p and its flip bit set, a stride-2 axis (padding 1,
+ *                                  even extent) a transposed axis without flip
+ *   backward-data of nn.ConvTranspose3d: swap 0, flip 0, stride 2 / padding 1 on every axis */
+DFM_API int dfm_conv3d_g_pack_weights(const void *weight, int32_t weight_dtype, int32_t cin,
+                                      int32_t cout, int32_t swap, int32_t flip, void *packed,
+                                      void *stream);
+/*
+ * x        : (n, d, h, w, cin) bf16, channels-last                              [device]
+ * scale / shift : NULL, or fp32 [cout]: y = conv * scale[c] + shift[c] (a folded BatchNorm3d in
+ *            eval mode, or a bias) applied to the fp32 accumulator
+ * residual : NULL, or (n, od, oh, ow, cout) bf16 added after scale / shift (ResModule identity)
+ * out      : (n, od, oh, ow, cout) bf16; order: scale/shift -> + residual -> ReLU -> round to bf16
+ */
+DFM_API int dfm_conv3d_g_fwd(const dfm_conv3d_desc *desc, const void *x, const void *packed_weights,
+                             const float *scale, const float *shift, const void *residual,
+                             void *out, void *stream);
+/* The tiling dfm_conv3d_g_fwd uses for desc: {pixel fragments per wave, channel fragments per
+ * wave, tile d, tile h, tile w, staged pixels, LDS bytes, workgroups}. */
+DFM_API int dfm_conv3d_g_plan(const dfm_conv3d_desc *desc, int64_t *plan8);
+
+/* ---------------------------------------------------------------------- */
 /* DepthHead.loss, dense_heads/depth_head.py:75-188 (called at dfm.py:348) */
 /* ---------------------------------------------------------------------- */
 typedef enum dfm_depth_loss_target {

@@ -1,0 +1,191 @@
+"""General MFMA Conv3d / ConvTranspose3d (csrc/conv3d_g.hip) against torch's fp32 convolution of
+the same bf16-rounded inputs and weights (reference call sites: hourglass,
+mmdet3d/models/utils/conv_modules.py:73-149; ResModule / OutdoorImVoxelNeck,
+mmdet3d/models/necks/imvoxel_neck.py:26-55,85-117; DfMNeck, mmdet3d/models/necks/dfm_neck.py:29-95).
+
+Tolerance: the kernel accumulates 27 * C_in bf16 products in fp32 (order differs from torch's) and
+rounds ONCE to bf16: |got - ref| <= 2^-8 |ref| (half a bf16 ulp, doubled for the rounding of the
+reference itself) + 2e-3 absolute (summation-order noise of O(1) sums)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 2.0 ** -7, 2e-3
+
+
+@pytest.fixture(scope='module')
+def cv():
+    assert torch.cuda.is_available()
+    return importlib.import_module('depth-from-motion_amd.conv3d')
+
+
+def _x(N, C, size, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(N, C, *size, generator=g).bfloat16()
+
+
+def _w(d0, d1, fan_in, seed):
+    g = torch.Generator().manual_seed(seed + 1000)
+    return (torch.randn(d0, d1, 3, 3, 3, generator=g) * (2.0 / (27 * fan_in)) ** 0.5).bfloat16().float()
+
+
+def _cl(t, dev):
+    return t.to(dev).contiguous(memory_format=torch.channels_last_3d)
+
+
+# (cin, cout, in_size, stride, padding): ragged tiles, every stride / padding combination of the path
+CONV_CASES = [
+    (32, 32, (5, 7, 9), 1, 1),
+    (64, 64, (6, 10, 12), 1, 1),
+    (32, 64, (8, 12, 16), 2, 1),          # hourglass conv1
+    (64, 64, (8, 12, 20), 2, 1),          # hourglass conv3
+    (64, 64, (7, 9, 11), 2, 1),           # odd extents under stride 2
+    (64, 128, (5, 9, 12), (1, 1, 2), 1),  # neck down-sampling along z
+    (128, 128, (4, 6, 6), 1, 1),
+    (128, 256, (3, 5, 6), (1, 1, 2), 1),
+    (256, 256, (3, 5, 3), 1, (1, 1, 0)),  # neck last conv: Nz 3 -> 1
+    (64, 32, (4, 20, 40), 1, 1),
+    (32, 32, (3, 4, 5), 1, (2, 2, 2)),    # padding 2 (backward-data of padding 0)
+    (64, 64, (9, 17, 33), 1, 1),
+]
+
+
+@pytest.mark.parametrize('cin,cout,size,stride,padding', CONV_CASES)
+@pytest.mark.parametrize('N', [1, 2])
+def test_conv_matches_torch(cv, cin, cout, size, stride, padding, N):
+    dev = torch.device('cuda:0')
+    x, w = _x(N, cin, size, seed=cin + cout + size[2]), _w(cout, cin, cin, seed=cin * 3 + cout)
+    ref = F.conv3d(x.float(), w, stride=stride, padding=padding)
+    pk = cv.pack_conv3d_g_weights(w.to(dev), cin, cout)
+    out = cv.conv3d_g(_cl(x, dev), pk, cout, stride, padding)
+    assert out.shape == ref.shape and out.dtype == torch.bfloat16
+    assert out.is_contiguous(memory_format=torch.channels_last_3d)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+
+
+TRANSPOSED_CASES = [(64, 64, (4, 5, 6)), (64, 32, (5, 6, 9)), (32, 32, (3, 3, 17)), (128, 64, (2, 9, 8))]
+
+
+@pytest.mark.parametrize('cin,cout,size', TRANSPOSED_CASES)
+def test_transposed_conv_matches_torch(cv, cin, cout, size):
+    """hourglass conv5 / conv6: ConvTranspose3d(k 3, s 2, p 1, output_padding 1)"""
+    dev = torch.device('cuda:0')
+    x, w = _x(2, cin, size, seed=cin + size[0]), _w(cin, cout, cin, seed=cout)
+    ref = F.conv_transpose3d(x.float(), w, stride=2, padding=1, output_padding=1)
+    pk = cv.pack_conv3d_g_weights(w.to(dev), cin, cout, swap=True)
+    out = cv.conv3d_g(_cl(x, dev), pk, cout, transposed=True)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_mixed_transposed_axis(cv):
+    """backward-data of a stride-(1,1,2) convolution: z is a transposed axis, x / y are mirrored
+    correlations -- checked against torch's conv_transpose3d with the same per-axis strides"""
+    dev = torch.device('cuda:0')
+    cin, cout, size = 64, 32, (4, 6, 5)   # gy channels 64 -> gx channels 32
+    gy, w = _x(1, cin, size, seed=3), _w(cin, cout, cin, seed=4)   # w: conv weight (Cout=64, Cin=32)
+    ref = F.conv_transpose3d(gy.float(), w, stride=(1, 1, 2), padding=1, output_padding=(0, 0, 1))
+    pk = cv.pack_conv3d_g_weights(w.to(dev), cin, cout, swap=True, flip=4 | 2)
+    out = cv.conv3d_g(_cl(gy, dev), pk, cout, stride=1, padding=1, transposed=(False, False, True))
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_epilogue_scale_shift_residual_relu(cv):
+    """folded BatchNorm3d (eval) + identity + ReLU of ResModule (imvoxel_neck.py:102-117)"""
+    dev = torch.device('cuda:0')
+    cin = cout = 64
+    size = (5, 9, 12)
+    x, w = _x(2, cin, size, seed=11), _w(cout, cin, cin, seed=12)
+    g = torch.Generator().manual_seed(13)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = _x(2, cout, size, seed=14)
+    conv = F.conv3d(x.float(), w, padding=1)
+    sc, sh = scale.view(1, -1, 1, 1, 1), shift.view(1, -1, 1, 1, 1)
+    pk = cv.pack_conv3d_g_weights(w.to(dev), cin, cout)
+    xg, rg = _cl(x, dev), _cl(res, dev)
+    for use_res in (False, True):
+        for relu in (False, True):
+            ref = conv * sc + sh
+            if use_res:
+                ref = ref + res.float()
+            if relu:
+                ref = torch.relu(ref)
+            out = cv.conv3d_g(xg, pk, cout, relu=relu, scale=scale.to(dev), shift=shift.to(dev),
+                              residual=rg if use_res else None)
+            np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=RTOL, atol=3e-3)
+    out = cv.conv3d_g(xg, pk, cout, relu=True, residual=rg)   # residual without scale
+    np.testing.assert_allclose(out.float().cpu().numpy(), torch.relu(conv + res.float()).numpy(), rtol=RTOL,
+                               atol=3e-3)
+
+
+MODULE_CASES = [
+    ('conv', 32, 64, (8, 12, 16), 2, 1),
+    ('conv', 64, 64, (6, 10, 12), 1, 1),
+    ('conv', 64, 128, (4, 8, 12), (1, 1, 2), 1),
+    ('conv', 128, 64, (4, 6, 3), 1, (1, 1, 0)),
+    ('convT', 64, 64, (4, 5, 6), 2, 1),
+    ('convT', 64, 32, (3, 6, 8), 2, 1),
+]
+
+
+@pytest.mark.parametrize('kind,cin,cout,size,stride,padding', MODULE_CASES)
+def test_modules_forward_backward_vs_torch_autograd(cv, kind, cin, cout, size, stride, padding):
+    """MfmaConv3dG / MfmaConvTranspose3d: same state_dict as the torch module, forward and both
+    gradients against torch fp32 autograd on the bf16-rounded operands"""
+    dev = torch.device('cuda:0')
+    torch.manual_seed(cin + cout)
+    if kind == 'conv':
+        m = cv.MfmaConv3dG(cin, cout, 3, stride=stride, padding=padding, bias=False).to(dev)
+    else:
+        m = cv.MfmaConvTranspose3d(cin, cout, 3, stride=2, padding=1, output_padding=1, bias=False).to(dev)
+    assert list(m.state_dict()) == ['weight']
+    with torch.no_grad():
+        m.weight.copy_(m.weight.bfloat16().float())
+    x = _x(2, cin, size, seed=7)
+    xb = _cl(x, dev).requires_grad_(True)
+    assert m.eligible(xb) and not m.eligible(x.float().to(dev))
+    y = m(xb)
+    xr = x.float().requires_grad_(True)
+    wr = m.weight.detach().cpu().clone().requires_grad_(True)
+    if kind == 'conv':
+        yr = F.conv3d(xr, wr, stride=stride, padding=padding)
+    else:
+        yr = F.conv_transpose3d(xr, wr, stride=2, padding=1, output_padding=1)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), yr.detach().numpy(), rtol=RTOL, atol=ATOL)
+    gy = _x(2, cout, tuple(yr.shape[2:]), seed=8)
+    y.backward(_cl(gy, dev))
+    yr.backward(gy.float())
+    np.testing.assert_allclose(xb.grad.float().cpu().numpy(), xr.grad.numpy(), rtol=RTOL, atol=5e-3)
+    # weight gradient: torch's convolution backward in bf16 (MIOpen) -> loose
+    np.testing.assert_allclose(m.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=5e-2,
+                               atol=0.02 * float(wr.grad.abs().max()))
+    # the fp32 NCDHW path is torch's convolution, unchanged
+    y32 = m(x.float().to(dev))
+    np.testing.assert_allclose(y32.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_hourglass_shapes_full_size_against_fp64_subset(cv):
+    """conv2 of the hourglass at config-K size (64 -> 64 at 36 x 40 x 160) and conv1 (32 -> 64,
+    stride 2 from 72 x 80 x 320): a strided voxel subset against an fp64 evaluation on the GPU"""
+    dev = torch.device('cuda:0')
+    for cin, cout, size, stride in ((64, 64, (36, 40, 160), 1), (32, 64, (72, 80, 320), 2)):
+        x, w = _x(1, cin, size, seed=21), _w(cout, cin, cin, seed=22)
+        xg = _cl(x, dev)
+        out = cv.conv3d_g(xg, cv.pack_conv3d_g_weights(w.to(dev), cin, cout), cout, stride, 1)
+        D, H, W = out.shape[2:]
+        xp = F.pad(xg.double(), (1, 1, 1, 1, 1, 1))
+        wd = w.to(dev).double()
+        sd, sh, sw = range(0, D, 5), range(0, H, 7), range(0, W, 9)
+        ref = torch.zeros(1, cout, len(sd), len(sh), len(sw), dtype=torch.float64, device=dev)
+        for kd in range(3):
+            for kh in range(3):
+                for kw in range(3):
+                    patch = xp[:, :, kd::stride, kh::stride, kw::stride][:, :, :D, :H, :W][:, :, ::5, ::7, ::9]
+                    ref += torch.einsum('ncdhw,oc->nodhw', patch, wd[:, :, kd, kh, kw])
+        np.testing.assert_allclose(out[:, :, ::5, ::7, ::9].double().cpu().numpy(), ref.cpu().numpy(), rtol=RTOL,
+                                   atol=ATOL)
