@@ -45,6 +45,8 @@ EXPORTS = (
     'dfm_conv3d_k3_c32_pack_weights',
     'dfm_conv3d_k3_c32_stats_splits',
     'dfm_conv3d_k3_c32_fwd',
+    'dfm_conv3d_k3_c32_fwd_strided',
+    'dfm_conv3d_k3_c32_to1_fwd',
     'dfm_conv3d_g_weight_bytes',
     'dfm_conv3d_g_pack_weights',
     'dfm_conv3d_g_fwd',
@@ -57,6 +59,8 @@ EXPORTS = (
     'dfm_group_norm_fwd',
     'dfm_group_norm_fwd_channels_last',
     'dfm_group_norm_apply_channels_last',
+    'dfm_group_norm_fwd_channels_last_res',
+    'dfm_group_norm_apply_channels_last_res',
     'dfm_group_norm_bwd',
 )
 
@@ -150,7 +154,8 @@ class Conv3dDesc(ctypes.Structure):
     _fields_ = [('n', ctypes.c_int32), ('cin', ctypes.c_int32), ('cout', ctypes.c_int32),
                 ('in_size', ctypes.c_int32 * 3), ('out_size', ctypes.c_int32 * 3),
                 ('stride', ctypes.c_int32 * 3), ('padding', ctypes.c_int32 * 3),
-                ('transposed', ctypes.c_int32 * 3), ('relu', ctypes.c_int32)]
+                ('transposed', ctypes.c_int32 * 3), ('relu', ctypes.c_int32),
+                ('in_channel_stride', ctypes.c_int32)]
 
 
 DL_LINEAR, DL_HARD, DL_GAUSSIAN, DL_LAPLACIAN = 0, 1, 2, 3
@@ -235,6 +240,10 @@ def lib():
     h.dfm_conv3d_k3_c32_pack_weights.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     h.dfm_conv3d_k3_c32_fwd.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_fwd.argtypes = [i32, i32, i32, i32, vp, vp, fp, vp, i32, i32, i32, fp, vp]
+    h.dfm_conv3d_k3_c32_fwd_strided.restype = ctypes.c_int
+    h.dfm_conv3d_k3_c32_fwd_strided.argtypes = [i32, i32, i32, i32, vp, i32, vp, fp, vp, i32, i32, i32, fp, vp]
+    h.dfm_conv3d_k3_c32_to1_fwd.restype = ctypes.c_int
+    h.dfm_conv3d_k3_c32_to1_fwd.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, i32, vp]
     h.dfm_conv3d_k3_c32_stats_splits.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_stats_splits.argtypes = [i32, i32, i32, i32, i32]
     cp = ctypes.POINTER(Conv3dDesc)
@@ -265,6 +274,12 @@ def lib():
     h.dfm_group_norm_apply_channels_last.restype = ctypes.c_int
     h.dfm_group_norm_apply_channels_last.argtypes = [i32, i32, i64, i32, f32, i32, i32, vp, fp, fp, vp, fp, fp, fp,
                                                      i32, vp, sz, vp]
+    h.dfm_group_norm_fwd_channels_last_res.restype = ctypes.c_int
+    h.dfm_group_norm_fwd_channels_last_res.argtypes = [i32, i32, i64, i32, f32, i32, i32, vp, fp, fp, vp, vp, fp, fp,
+                                                       vp, sz, vp]
+    h.dfm_group_norm_apply_channels_last_res.restype = ctypes.c_int
+    h.dfm_group_norm_apply_channels_last_res.argtypes = [i32, i32, i64, i32, f32, i32, i32, vp, fp, fp, vp, vp, fp,
+                                                         fp, fp, i32, vp, sz, vp]
     h.dfm_group_norm_bwd.restype = ctypes.c_int
     h.dfm_group_norm_bwd.argtypes = [i32, i32, i64, i32, i32, i32, vp, vp, vp, fp, fp, fp, vp, fp, fp, vp, sz,
                                      vp]

@@ -51,7 +51,9 @@ def conv3d_k3_c32(x, packed, relu=False, acc_in=None, out_f32=False, depth_chunk
     or the fp32 partial (N, D, H, W, 32) when ``out_f32``; ``acc_in``: fp32 partial to start from.
     ``stats``: also return the per-channel moment partials (N, 32, splits, 3) of the stored values
     (the GroupNorm statistics of the layer that follows, see ``group_norm_from_partials``)."""
-    assert x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 32 and _is_ndhwc(x)
+    cstride = _ndhwc_channel_stride(x)
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 32 and cstride, \
+        'bf16 channels_last_3d with 32 channels (or a 32-channel slice of a wider NDHWC tensor)'
     N, _, D, H, W = x.shape
     lib = _capi.lib()
     dev = x.device
@@ -67,11 +69,10 @@ def conv3d_k3_c32(x, packed, relu=False, acc_in=None, out_f32=False, depth_chunk
         splits = lib.dfm_conv3d_k3_c32_stats_splits(N, D, H, W, depth_chunk)
         part = torch.empty((N, 32, splits, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _capi.check(lib.dfm_conv3d_k3_c32_fwd(N, D, H, W, _ptr(x), _ptr(packed),
-                                              _ptr(acc_in) if acc_in is not None else None, _ptr(out),
-                                              1 if out_f32 else 0, 1 if relu else 0, depth_chunk,
-                                              _ptr(part) if part is not None else None,
-                                              _stream_ptr(dev)))
+        _capi.check(lib.dfm_conv3d_k3_c32_fwd_strided(
+            N, D, H, W, _ptr(x), cstride, _ptr(packed), _ptr(acc_in) if acc_in is not None else None,
+            _ptr(out), 1 if out_f32 else 0, 1 if relu else 0, depth_chunk,
+            _ptr(part) if part is not None else None, _stream_ptr(dev)))
     if out_f32:
         return out
     out = out.permute(0, 4, 1, 2, 3)
@@ -86,8 +87,8 @@ class _MfmaConvFn(torch.autograd.Function):
         # C_in = 32 * k: halves accumulated through the fp32 partial
         part = None
         for i, pk in enumerate(packs):
-            xi = x if len(packs) == 1 else x[:, 32 * i:32 * (i + 1)]
-            if not _is_ndhwc(xi):
+            xi = x if len(packs) == 1 else x[:, 32 * i:32 * (i + 1)]  # read in place (pixel stride)
+            if not _ndhwc_channel_stride(xi):
                 xi = xi.contiguous(memory_format=torch.channels_last_3d)
             last = i == len(packs) - 1
             part = conv3d_k3_c32(xi, pk, acc_in=part, out_f32=not last, stats=want_stats and last)
@@ -126,8 +127,8 @@ class MfmaConv3d(nn.Conv3d):
         self._packs, self._pack_key = None, None
 
     def eligible(self, x):
-        return (x.is_cuda and x.dtype == torch.bfloat16 and _is_ndhwc(x) and self.out_channels == 32 and
-                self.in_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and self.stride == (1, 1, 1) and
+        return (x.is_cuda and x.dtype == torch.bfloat16 and _ndhwc_channel_stride(x) > 0 and
+                self.out_channels == 32 and self.in_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and self.stride == (1, 1, 1) and
                 self.padding == (1, 1, 1) and self.dilation == (1, 1, 1) and self.groups == 1 and
                 self.bias is None)
 
@@ -147,6 +148,71 @@ class MfmaConv3d(nn.Conv3d):
         """(y, moment partials): the convolution plus the per-channel GroupNorm statistics of y
         from the kernel's epilogue (``x`` must be eligible)."""
         return _MfmaConvFn.apply(x, self.weight, self._packed(), True)
+
+
+class _PackCache:
+    """packed weight fragments of a module's parameter, rebuilt when the parameter changes"""
+
+    def __init__(self):
+        self._pack, self._key = None, None
+
+    def get(self, weight, make):
+        key = (weight._version, weight.data_ptr(), weight.device)
+        if self._key != key:
+            self._pack, self._key = make(), key
+        return self._pack
+
+
+class _MfmaConvTo1Fn(torch.autograd.Function):
+    """Conv3d(32, 1, 3, 1, 1) through the MFMA kernel (weight rows 1..31 zero, channel 0 stored);
+    backward is torch's convolution backward (MIOpen) -- the op is memory-bound either way."""
+
+    @staticmethod
+    def forward(ctx, x, weight, packed):
+        ctx.save_for_backward(x, weight)
+        N, _, D, H, W = x.shape
+        out = torch.empty((N, 1, D, H, W), dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            _capi.check(_capi.lib().dfm_conv3d_k3_c32_to1_fwd(N, D, H, W, _ptr(x), _ptr(packed), _ptr(out), 0, 0,
+                                                              _stream_ptr(x.device)))
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx, gw, _ = torch.ops.aten.convolution_backward(
+            gy.contiguous(), x, weight.to(x.dtype), None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return gx, gw.to(weight.dtype) if gw is not None else None, None
+
+
+class MfmaConv3dTo1(nn.Conv3d):
+    """nn.Conv3d(32, 1, 3, 1, 1, bias=False): the prediction convolutions of DfMBackbone
+    (dfm_backbone.py:120-127).  bf16 / NDHWC input: the 32 -> 32 MFMA kernel with a zero-padded
+    weight, storing channel 0 only (MIOpen's untuned kernel for this shape takes 3.4 ms at config K,
+    this one 0.12 ms)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._cache = _PackCache()
+
+    def eligible(self, x):
+        return (x.is_cuda and x.dtype == torch.bfloat16 and _is_ndhwc(x) and self.in_channels == 32 and
+                self.out_channels == 1 and self.kernel_size == (3, 3, 3) and self.stride == (1, 1, 1) and
+                self.padding == (1, 1, 1) and self.dilation == (1, 1, 1) and self.groups == 1 and
+                self.bias is None)
+
+    def _packed(self):
+        def make():
+            w = torch.zeros((32, 32, 3, 3, 3), dtype=torch.float32, device=self.weight.device)
+            w[0] = self.weight.detach().float()[0]
+            return pack_conv3d_weights(w)
+        return self._cache.get(self.weight, make)
+
+    def forward(self, x):
+        if self.eligible(x):
+            return _MfmaConvTo1Fn.apply(x, self.weight, self._packed())
+        return super().forward(x)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -178,9 +244,32 @@ def pack_conv3d_g_weights(weight, cin, cout, swap=False, flip=0):
     return packed
 
 
-def _conv_desc(n, cin, cout, in_size, out_size, stride, padding, transposed, relu):
+def _ndhwc_channel_stride(x):
+    """x: (N, C, D, H, W).  The pixel stride (elements) when x is a channels-last tensor or a channel
+    slice of one (x[:, a:b] of an NDHWC tensor: dense pixels of C_total channels), else 0."""
+    if x.dim() != 5 or x.stride(1) != 1 or x.storage_offset() % 8:
+        return 0
+    C = x.shape[1]
+    ps, inner = 0, 1  # pixel stride, pixels spanned by the dimensions further in
+    for size, st in zip((x.shape[4], x.shape[3], x.shape[2], x.shape[0]),
+                        (x.stride(4), x.stride(3), x.stride(2), x.stride(0))):
+        if size == 1:
+            continue  # the stride of a singleton dimension is arbitrary
+        if ps == 0:
+            if st % inner:
+                return 0
+            ps = st // inner
+        elif st != ps * inner:
+            return 0
+        inner *= size
+    ps = ps or C
+    return ps if ps >= C and ps % 8 == 0 else 0
+
+
+def _conv_desc(n, cin, cout, in_size, out_size, stride, padding, transposed, relu, in_channel_stride=0):
     d = _capi.Conv3dDesc()
     d.n, d.cin, d.cout, d.relu = n, cin, cout, 1 if relu else 0
+    d.in_channel_stride = 0 if in_channel_stride == cin else in_channel_stride
     for i in range(3):
         d.in_size[i], d.out_size[i] = in_size[i], out_size[i]
         d.stride[i], d.padding[i], d.transposed[i] = stride[i], padding[i], 1 if transposed[i] else 0
@@ -209,13 +298,14 @@ def conv3d_g(x, packed, cout, stride=1, padding=1, transposed=False, relu=False,
     """x: (N, C_in, D, H, W) bf16 channels_last_3d.  Returns (N, cout, D', H', W') bf16
     channels_last_3d = relu?(conv(x) * scale + shift + residual).  ``transposed``: per-axis flags of
     the x2 transposed convolution (kernel 3, stride 2, padding 1, output_padding 1)."""
-    assert x.is_cuda and x.dtype == torch.bfloat16 and _is_ndhwc(x)
+    cstride = _ndhwc_channel_stride(x)
+    assert x.is_cuda and x.dtype == torch.bfloat16 and cstride, 'bf16 channels_last_3d (or a channel slice of it)'
     stride, padding, transposed = _triple(stride), _triple(padding), _triple(transposed)
     N, cin = x.shape[:2]
     in_size = tuple(x.shape[2:])
     out_size = conv3d_g_out_size(in_size, stride, padding, transposed)
     out = torch.empty((N, *out_size, cout), dtype=torch.bfloat16, device=x.device)
-    d = _conv_desc(N, cin, cout, in_size, out_size, stride, padding, transposed, relu)
+    d = _conv_desc(N, cin, cout, in_size, out_size, stride, padding, transposed, relu, cstride)
     if scale is not None:
         scale, shift = scale.float().contiguous(), shift.float().contiguous()
         assert scale.numel() == cout and shift.numel() == cout
@@ -283,19 +373,6 @@ class _ConvGFn(torch.autograd.Function):
         return gx, gw, None, None, None, None
 
 
-class _PackCache:
-    """packed weight fragments of a module's parameter, rebuilt when the parameter changes"""
-
-    def __init__(self):
-        self._pack, self._key = None, None
-
-    def get(self, weight, make):
-        key = (weight._version, weight.data_ptr(), weight.device)
-        if self._key != key:
-            self._pack, self._key = make(), key
-        return self._pack
-
-
 class MfmaConv3dG(nn.Conv3d):
     """nn.Conv3d(32 j, 32 k, 3, stride in {1, 2}, padding in {0, 1, 2}, bias=False) whose bf16 /
     NDHWC forward is the general MFMA kernel; any other input takes torch's convolution (MIOpen),
@@ -307,7 +384,8 @@ class MfmaConv3dG(nn.Conv3d):
         self._cache = _PackCache()
 
     def eligible(self, x):
-        return (x.is_cuda and x.dtype == torch.bfloat16 and _is_ndhwc(x) and self.in_channels % 32 == 0 and
+        return (x.is_cuda and x.dtype == torch.bfloat16 and _ndhwc_channel_stride(x) > 0 and
+                self.in_channels % 32 == 0 and
                 self.out_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and
                 all(s in (1, 2) for s in self.stride) and all(0 <= p <= 2 for p in self.padding) and
                 self.dilation == (1, 1, 1) and self.groups == 1 and self.bias is None and

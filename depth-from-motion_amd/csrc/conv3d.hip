@@ -49,6 +49,7 @@ constexpr int CV_NFRAG = 27 * 2;
 struct ConvGeom {
     int32_t N, D, H, W;
     int32_t tiles_w, tiles_h, dchunk, relu;
+    int32_t xcs;  // elements between consecutive input pixels (32, or more: a channel slice of a wider tensor)
 };
 
 // weights (C_out, C_in, 3, 3, 3) -> MFMA A-operand fragments [tap*2 + ks][lane][8]:
@@ -85,7 +86,9 @@ __global__ void conv3d_pack_weights_kernel(const TW *__restrict__ w, int cin_tot
 // M2 of the values it stored -- the per-channel GroupNorm statistics of the NEXT layer, so that
 // layer's statistics pass over the tensor disappears (stats[((n*32 + c)*splits + s)*3 + {0,1,2}],
 // s = (tile*chunks + chunk)*4 + wave, merged by dfm_group_norm_apply_channels_last).
-template <bool OUT_F32, bool ACC_IN, bool STATS>
+// OUT_C1: store output channel 0 only, as a (N, D, H, W) bf16 tensor -- the 32 -> 1 prediction
+// convolutions (dfm_backbone.py:120-127) run as a 32 -> 32 convolution whose weight rows 1..31 are zero
+template <bool OUT_F32, bool ACC_IN, bool STATS, bool OUT_C1 = false>
 __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
     ConvGeom g, const bf16_t *__restrict__ x, const uint4 *__restrict__ wfrag,
     const float *__restrict__ acc_in, void *__restrict__ yout, const uint4 *__restrict__ zero_page,
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
     const int h0 = th * CV_TH, w0 = tw * CV_TW;
     const int d0 = blockIdx.y * g.dchunk, d1 = min(d0 + g.dchunk, g.D);
     const int n = blockIdx.z;
-    const size_t plane = (size_t)g.H * g.W * CV_C;  // elements per depth plane
+    const size_t plane = (size_t)g.H * g.W * g.xcs;  // input elements per depth plane
     const bf16_t *xn = x + (size_t)n * g.D * plane;
 
     // ---- weights: 54 fragments, register resident for the whole launch ------------------
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
         const int j = p / CV_SW, i = p - j * CV_SW;
         const int h = h0 - 1 + j, w = w0 - 1 + i;
         const bool ok = q < CV_PIECES && h >= 0 && h < g.H && w >= 0 && w < g.W;
-        poff[k] = ok ? ((h * g.W + w) * CV_C + sl * 8) * 2 : -1;
+        poff[k] = ok ? ((h * g.W + w) * g.xcs + sl * 8) * 2 : -1;
     }
     auto stage = [&](int dz) {  // depth dz -> ring slot (dz - d0 + 1) & 3
         const int slot = (dz - d0 + 1) & (CV_RING - 1);
@@ -224,6 +227,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
             const int h = h0 + r0 + r;
             if (!(colok && h < g.H)) continue;
             const size_t vox = (((size_t)n * g.D + d) * g.H + h) * g.W + w0 + l32;
+            if constexpr (OUT_C1) {
+                if (half == 0) {  // channel 0 lives in element 0 of the lanes 0..31
+                    float v = acc[r][0];
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    ((bf16_t *)yout)[vox] = f32_to_bf16(v);
+                }
+                continue;
+            }
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 float v0 = acc[r][4 * gq], v1 = acc[r][4 * gq + 1], v2 = acc[r][4 * gq + 2], v3 = acc[r][4 * gq + 3];
@@ -338,18 +349,57 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_pack_weights(const void *weight, int32_
     return DFM_OK;
 }
 
-extern "C" DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
-                                             const void *packed_weights, const float *acc_in,
-                                             void *out, int32_t out_f32, int32_t relu,
-                                             int32_t depth_chunk, float *stats, void *stream)
+extern "C" DFM_API int dfm_conv3d_k3_c32_to1_fwd(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
+                                                 const void *packed_weights, void *out, int32_t relu,
+                                                 int32_t depth_chunk, void *stream)
 {
+    const int x_channel_stride = 32;
+    if (n <= 0 || d <= 0 || h <= 0 || w <= 0) return set_error(DFM_ERR_INVALID_ARG, "non-positive size");
+    if (!x || !packed_weights || !out) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if ((long long)h * w * x_channel_stride * 2 >= (1ll << 31)) return set_error(DFM_ERR_UNSUPPORTED, "depth plane too large");
+    if (n > 65535) return set_error(DFM_ERR_UNSUPPORTED, "batch > 65535");
+    ConvGeom g;
+    g.N = n; g.D = d; g.H = h; g.W = w; g.xcs = x_channel_stride;
+    g.tiles_w = (w + CV_TW - 1) / CV_TW;
+    g.tiles_h = (h + CV_TH - 1) / CV_TH;
+    g.relu = relu ? 1 : 0;
+    const int dc = conv_depth_chunk(n, d, h, w, depth_chunk);
+    g.dchunk = dc;
+    const int nchunks = (d + dc - 1) / dc;
+    if (nchunks > 65535) return set_error(DFM_ERR_UNSUPPORTED, "too many depth chunks");
+    const uint4 *wfrag = (const uint4 *)packed_weights;
+    const uint4 *zero = wfrag + CV_NFRAG * 64;
+    const int lds = CV_RING * CV_SLAB_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e_ = hipFuncSetAttribute((const void *)conv3d_k3_c32_kernel<false, false, false, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e_ != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e_));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3d_k3_c32_kernel<false, false, false, true>), dim3(g.tiles_w * g.tiles_h, nchunks, n),
+                       dim3(256), lds, (hipStream_t)stream, g, (const bf16_t *)x, wfrag, (const float *)nullptr,
+                       out, zero, (float *)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+extern "C" DFM_API int dfm_conv3d_k3_c32_fwd_strided(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
+                                                     int32_t x_channel_stride, const void *packed_weights,
+                                                     const float *acc_in, void *out, int32_t out_f32,
+                                                     int32_t relu, int32_t depth_chunk, float *stats,
+                                                     void *stream)
+{
+    if (x_channel_stride < 32 || x_channel_stride % 8)
+        return set_error(DFM_ERR_INVALID_ARG, "x_channel_stride must be >= 32 and a multiple of 8");
     if (stats && out_f32) return set_error(DFM_ERR_INVALID_ARG, "statistics are taken of the bf16 output");
     if (n <= 0 || d <= 0 || h <= 0 || w <= 0) return set_error(DFM_ERR_INVALID_ARG, "non-positive size");
     if (!x || !packed_weights || !out) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
-    if ((long long)h * w * 64 >= (1ll << 31)) return set_error(DFM_ERR_UNSUPPORTED, "depth plane too large");
+    if ((long long)h * w * x_channel_stride * 2 >= (1ll << 31)) return set_error(DFM_ERR_UNSUPPORTED, "depth plane too large");
     if (n > 65535) return set_error(DFM_ERR_UNSUPPORTED, "batch > 65535");
     ConvGeom g;
-    g.N = n; g.D = d; g.H = h; g.W = w;
+    g.N = n; g.D = d; g.H = h; g.W = w; g.xcs = x_channel_stride;
     g.tiles_w = (w + CV_TW - 1) / CV_TW;
     g.tiles_h = (h + CV_TH - 1) / CV_TH;
     g.relu = relu ? 1 : 0;
@@ -381,4 +431,13 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, in
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
+}
+
+extern "C" DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
+                                             const void *packed_weights, const float *acc_in,
+                                             void *out, int32_t out_f32, int32_t relu,
+                                             int32_t depth_chunk, float *stats, void *stream)
+{
+    return dfm_conv3d_k3_c32_fwd_strided(n, d, h, w, x, 32, packed_weights, acc_in, out, out_f32, relu,
+                                         depth_chunk, stats, stream);
 }

@@ -55,6 +55,8 @@ struct GAxis {
 struct GGeom {
     GAxis d, h, w;
     int32_t cin, cout, nchunk, cout_tiles, relu, nrounds, block_px;
+    int32_t resident, classes;  // resident != 0: all chunks in LDS, the workgroup loops the parity classes
+    int32_t cin_stride;  // elements between consecutive input pixels (>= cin: a channel slice of a wider tensor)
     float r_bw, r_bhw;  // 1 / block.w, 1 / (block.h * block.w)
 };
 
@@ -113,28 +115,54 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
     const int tiw = t % g.w.tiles; t /= g.w.tiles;
     const int tih = t % g.h.tiles;
     const int tid_ = t / g.h.tiles;
-    int yy = blockIdx.y;
-    const int ct = yy % g.cout_tiles; yy /= g.cout_tiles;
-    const int ncw = g.w.up ? 2 : 1, nch = g.h.up ? 2 : 1;
-    const int pcw = yy % ncw; yy /= ncw;
-    const int pch = yy % nch;
-    const int pcd = yy / nch;
+    const int ct = blockIdx.y % g.cout_tiles;
     const int n = blockIdx.z;
+    // resident mode (transposed convolutions): every input chunk of the block stays in LDS and the
+    // workgroup walks ALL parity classes over it -- the block is staged once, not once per class
+    const int cls0 = g.resident ? 0 : blockIdx.y / g.cout_tiles;
+    const int cls1 = g.resident ? g.classes : cls0 + 1;
 
     const int od0 = tid_ * g.d.tile, oh0 = tih * g.h.tile, ow0 = tiw * g.w.tile;  // tile space
     const int bd0 = g.d.up ? od0 : od0 * g.d.stride - g.d.pad;                     // block origin (input)
     const int bh0 = g.h.up ? oh0 : oh0 * g.h.stride - g.h.pad;
     const int bw0 = g.w.up ? ow0 : ow0 * g.w.stride - g.w.pad;
     const int BH = g.h.block, BW = g.w.block;
-
-    const int pix_bytes = g.cin * 2;
+    const int pix_bytes = g.cin_stride * 2;
     const int BHW = BH * BW;
-    const unsigned char *xs = (const unsigned char *)(x + (size_t)n * g.d.in * g.h.in * g.w.in * g.cin);
+    const unsigned char *xs = (const unsigned char *)(x + (size_t)n * g.d.in * g.h.in * g.w.in * g.cin_stride);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)blk;
+    const int chunk_bytes = g.nrounds * 4096;
+
+    // stage the halo block of one 32-channel chunk into LDS buffer `buf`: piece q = 16 bytes, LDS
+    // position q * 16 holds slot (q & 3) ^ swizzle of block pixel q >> 2 (zero page outside the volume)
+    auto stage = [&](int chunk, int buf) {
+        const unsigned char *src = xs + chunk * 64;
+        unsigned char *dst = blk + buf * chunk_bytes + wave * 1024;
+        for (int r = 0; r < g.nrounds; ++r) {
+            const int q = r * 256 + tid;
+            const int p = q >> 2, sl = (q & 3) ^ ((p >> 2) & 3);
+            const int bd = (int)(((float)p + 0.5f) * g.r_bhw);
+            const int rem = p - bd * BHW;
+            const int bh = (int)(((float)rem + 0.5f) * g.r_bw);
+            const int bw = rem - bh * BW;
+            const int d = bd0 + bd, h = bh0 + bh, w = bw0 + bw;
+            const bool ok = p < g.block_px && (unsigned)d < (unsigned)g.d.in && (unsigned)h < (unsigned)g.h.in &&
+                            (unsigned)w < (unsigned)g.w.in;
+            const unsigned char *s_ = ok ? src + (((d * g.h.in + h) * g.w.in + w) * pix_bytes + sl * 16)
+                                         : (const unsigned char *)zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)s_,
+                                             (__attribute__((address_space(3))) void *)(dst + r * 4096),
+                                             16, 0, 0);
+        }
+    };
+    if (g.resident) {
+        for (int chunk = 0; chunk < g.nchunk; ++chunk) stage(chunk, chunk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 
     // ---- this lane's pixels: PFW fragments of 32 consecutive tile positions per wave -----------
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)blk;
-    int base_bp[PFW];
-    int opix[PFW];  // output voxel index inside the sample, -1: outside the volume
+    int base_bp[PFW], tpos[PFW];  // block pixel of tap (0,0,0); packed tile coordinates
     {
         const int sd = g.d.up ? 1 : g.d.stride, sh = g.h.up ? 1 : g.h.stride, sw = g.w.up ? 1 : g.w.stride;
 #pragma unroll
@@ -143,196 +171,191 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
             const int tw = i % g.w.tile, i2 = i / g.w.tile;
             const int th = i2 % g.h.tile, td = i2 / g.h.tile;
             base_bp[f] = (td * sd * BH + th * sh) * BW + tw * sw;
+            tpos[f] = (td << 20) | (th << 10) | tw;  // tile extents <= 512
+        }
+    }
+    const size_t osample = (size_t)n * g.d.out * g.h.out * g.w.out;
+
+    for (int cls = cls0; cls < cls1; ++cls) {
+        const int ncw = g.w.up ? 2 : 1, nch = g.h.up ? 2 : 1;
+        const int pcw = cls % ncw, pch = (cls / ncw) % nch, pcd = cls / (ncw * nch);
+        int opix[PFW];  // output voxel index inside the sample, -1: outside the volume
+#pragma unroll
+        for (int f = 0; f < PFW; ++f) {
+            const int td = tpos[f] >> 20, th = (tpos[f] >> 10) & 1023, tw = tpos[f] & 1023;
             const int od = g.d.up ? 2 * (od0 + td) + pcd : od0 + td;
             const int oh = g.h.up ? 2 * (oh0 + th) + pch : oh0 + th;
             const int ow = g.w.up ? 2 * (ow0 + tw) + pcw : ow0 + tw;
             const bool ok = od < g.d.out && oh < g.h.out && ow < g.w.out;
             opix[f] = ok ? (od * g.h.out + oh) * g.w.out + ow : -1;
         }
-    }
 
-    // ---- taps of this class: counters (jd, jh, jw) -> (weight tap index, block offset in pixels) ----
-    const int ntw = g.w.up ? 1 + pcw : 3, nth = g.h.up ? 1 + pch : 3, ntd = g.d.up ? 1 + pcd : 3;
-    const int ntaps = ntd * nth * ntw;
-    int jd = 0, jh = 0, jw = 0;
-    auto tap_cur = [&](int &wt, int &off) {
-        // correlation axis: k = j at offset j; up axis: even class -> k 1 @ +0; odd -> k 2 @ +0, k 0 @ +1
-        const int kw = g.w.up ? (pcw ? (jw ? 0 : 2) : 1) : jw;
-        const int kh = g.h.up ? (pch ? (jh ? 0 : 2) : 1) : jh;
-        const int kd = g.d.up ? (pcd ? (jd ? 0 : 2) : 1) : jd;
-        wt = (kd * 3 + kh) * 3 + kw;
-        off = (jd * BH + jh) * BW + jw;
-    };
-    auto tap_adv = [&]() {
-        if (++jw == ntw) {
-            jw = 0;
-            if (++jh == nth) { jh = 0; ++jd; }
-        }
-    };
-
-    f32x16_t acc[PFW][CW];
-#pragma unroll
-    for (int f = 0; f < PFW; ++f)
-#pragma unroll
-        for (int c = 0; c < CW; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[f][c][i] = 0.0f;
-
-    // one round of ds_read_b128: the PFW B fragments of (tap offset `off`, k-step ks)
-    auto issue = [&](int off, int ks, u32x4_t (&dst)[PFW]) {
-#pragma unroll
-        for (int f = 0; f < PFW; ++f) {
-            const int bp = base_bp[f] + off;
-            const uint32_t a = lds0 + (uint32_t)bp * 64u + ((((uint32_t)(2 * ks + half)) ^ (((uint32_t)bp >> 2) & 3u)) << 4);
-            asm volatile("ds_read_b128 %0, %1" : "=v"(dst[f]) : "v"(a));
-        }
-    };
-
-    for (int chunk = 0; chunk < g.nchunk; ++chunk) {
-        if (chunk > 0) __syncthreads();  // every wave is done reading the previous chunk's block
-        {
-            // stage the halo block of this 32-channel chunk: piece q = 16 bytes, LDS position q * 16
-            // holds slot (q & 3) ^ swizzle of block pixel q >> 2 (zero page outside the volume)
-            const unsigned char *src = xs + chunk * 64;
-            unsigned char *dst = blk + wave * 1024;
-            for (int r = 0; r < g.nrounds; ++r) {
-                const int q = r * 256 + tid;
-                const int p = q >> 2, sl = (q & 3) ^ ((p >> 2) & 3);
-                const int bd = (int)(((float)p + 0.5f) * g.r_bhw);
-                const int rem = p - bd * BHW;
-                const int bh = (int)(((float)rem + 0.5f) * g.r_bw);
-                const int bw = rem - bh * BW;
-                const int d = bd0 + bd, h = bh0 + bh, w = bw0 + bw;
-                const bool ok = p < g.block_px && (unsigned)d < (unsigned)g.d.in && (unsigned)h < (unsigned)g.h.in &&
-                                (unsigned)w < (unsigned)g.w.in;
-                const unsigned char *s_ = ok ? src + (((d * g.h.in + h) * g.w.in + w) * pix_bytes + sl * 16)
-                                             : (const unsigned char *)zero_page;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)s_,
-                                                 (__attribute__((address_space(3))) void *)(dst + r * 4096),
-                                                 16, 0, 0);
+        // taps of this class: counters (jd, jh, jw) -> (weight tap index, block offset in pixels)
+        const int ntw = g.w.up ? 1 + pcw : 3, nth = g.h.up ? 1 + pch : 3, ntd = g.d.up ? 1 + pcd : 3;
+        const int ntaps = ntd * nth * ntw;
+        int jd = 0, jh = 0, jw = 0;
+        auto tap_cur = [&](int &wt, int &off) {
+            // correlation axis: k = j at offset j; up axis: even class -> k 1 @ +0; odd -> k 2 @ +0, k 0 @ +1
+            const int kw = g.w.up ? (pcw ? (jw ? 0 : 2) : 1) : jw;
+            const int kh = g.h.up ? (pch ? (jh ? 0 : 2) : 1) : jh;
+            const int kd = g.d.up ? (pcd ? (jd ? 0 : 2) : 1) : jd;
+            wt = (kd * 3 + kh) * 3 + kw;
+            off = (jd * BH + jh) * BW + jw;
+        };
+        auto tap_adv = [&]() {
+            if (++jw == ntw) {
+                jw = 0;
+                if (++jh == nth) { jh = 0; ++jd; }
             }
-        }
-        // weights of the first tap travel while the block lands
-        const uint4 *wp = wfrag + ((size_t)(ct * g.nchunk + chunk) * 27 * 2 * CW) * 64 + lane;
-        auto wload = [&](int wt, bf16x8_t (&dst)[2][CW]) {
+        };
+
+        f32x16_t acc[PFW][CW];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+        for (int f = 0; f < PFW; ++f)
 #pragma unroll
-                for (int c = 0; c < CW; ++c) {
-                    const uint4 q = wp[((wt * 2 + ks) * CW + c) * 64];
-                    __builtin_memcpy(&dst[ks][c], &q, 16);
+            for (int c = 0; c < CW; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[f][c][i] = 0.0f;
+
+        for (int chunk = 0; chunk < g.nchunk; ++chunk) {
+            const uint32_t ldsb = lds0 + (g.resident ? chunk * chunk_bytes : 0);
+            // one round of ds_read_b128: the PFW B fragments of (tap offset `off`, k-step ks)
+            auto issue = [&](int off, int ks, u32x4_t (&dst)[PFW]) {
+#pragma unroll
+                for (int f = 0; f < PFW; ++f) {
+                    const int bp = base_bp[f] + off;
+                    const uint32_t a = ldsb + (uint32_t)bp * 64u +
+                                       ((((uint32_t)(2 * ks + half)) ^ (((uint32_t)bp >> 2) & 3u)) << 4);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(dst[f]) : "v"(a));
                 }
-        };
-        bf16x8_t wc[2][CW], wn[2][CW];
-        int wt, off, offn;
-        jd = jh = jw = 0;
-        tap_cur(wt, off);
-        wload(wt, wn);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // the block has landed
-
-        u32x4_t q0[PFW], q1[PFW];
-        issue(off, 0, q0);
-        // q (issued one round earlier) is complete when at most PFW newer reads are outstanding
-#define G_WAIT(Q, N)                                                                                         \
-        do {                                                                                                 \
-            if constexpr (PFW == 1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]));                   \
-            if constexpr (PFW == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]));      \
-            if constexpr (PFW == 3) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2])); \
-            if constexpr (PFW == 4) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3])); \
-        } while (0)
-#define G_WAIT_PFW(Q)                                                                                        \
-        do {                                                                                                 \
-            if constexpr (PFW == 1) G_WAIT(Q, 1);                                                            \
-            if constexpr (PFW == 2) G_WAIT(Q, 2);                                                            \
-            if constexpr (PFW == 3) G_WAIT(Q, 3);                                                            \
-            if constexpr (PFW == 4) G_WAIT(Q, 4);                                                            \
-        } while (0)
-        auto mfmas = [&](bf16x8_t (&wk)[CW], u32x4_t (&q)[PFW]) {
-#pragma unroll
-            for (int f = 0; f < PFW; ++f) {
-                bf16x8_t xf;
-                __builtin_memcpy(&xf, &q[f], 16);
-#pragma unroll
-                for (int c = 0; c < CW; ++c)
-                    acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[c], xf, acc[f][c], 0, 0, 0);
+            };
+            if (!g.resident) {
+                if (chunk > 0) __syncthreads();  // every wave is done reading the previous chunk's block
+                stage(chunk, 0);
             }
-        };
-        for (int j = 0; j + 1 < ntaps; ++j) {
-            // the weights of this tap were requested one tap ago; request the next tap's
+            // weights of the first tap travel while the block lands
+            const uint4 *wp = wfrag + ((size_t)(ct * g.nchunk + chunk) * 27 * 2 * CW) * 64 + lane;
+            auto wload = [&](int wt, bf16x8_t (&dst)[2][CW]) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) {
+                        const uint4 q = wp[((wt * 2 + ks) * CW + c) * 64];
+                        __builtin_memcpy(&dst[ks][c], &q, 16);
+                    }
+            };
+            bf16x8_t wc[2][CW], wn[2][CW];
+            int wt, off, offn;
+            jd = jh = jw = 0;
+            tap_cur(wt, off);
+            wload(wt, wn);
+            if (!g.resident) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();  // the block has landed
+            }
+
+            u32x4_t q0[PFW], q1[PFW];
+            issue(off, 0, q0);
+            // q (issued one round earlier) is complete when at most PFW newer reads are outstanding
+#define G_WAIT(Q, N)                                                                                         \
+            do {                                                                                             \
+                if constexpr (PFW == 1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]));               \
+                if constexpr (PFW == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]));  \
+                if constexpr (PFW == 3) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2])); \
+                if constexpr (PFW == 4) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3])); \
+            } while (0)
+#define G_WAIT_PFW(Q)                                                                                        \
+            do {                                                                                             \
+                if constexpr (PFW == 1) G_WAIT(Q, 1);                                                        \
+                if constexpr (PFW == 2) G_WAIT(Q, 2);                                                        \
+                if constexpr (PFW == 3) G_WAIT(Q, 3);                                                        \
+                if constexpr (PFW == 4) G_WAIT(Q, 4);                                                        \
+            } while (0)
+            auto mfmas = [&](bf16x8_t (&wk)[CW], u32x4_t (&q)[PFW]) {
+#pragma unroll
+                for (int f = 0; f < PFW; ++f) {
+                    bf16x8_t xf;
+                    __builtin_memcpy(&xf, &q[f], 16);
+#pragma unroll
+                    for (int c = 0; c < CW; ++c)
+                        acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[c], xf, acc[f][c], 0, 0, 0);
+                }
+            };
+            for (int j = 0; j + 1 < ntaps; ++j) {
+                // the weights of this tap were requested one tap ago; request the next tap's
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) wc[ks][c] = wn[ks][c];
+                tap_adv();
+                tap_cur(wt, offn);
+                wload(wt, wn);
+                issue(off, 1, q1);
+                G_WAIT_PFW(q0);
+                mfmas(wc[0], q0);
+                issue(offn, 0, q0);
+                G_WAIT_PFW(q1);
+                mfmas(wc[1], q1);
+                off = offn;
+            }
+            // last tap
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int c = 0; c < CW; ++c) wc[ks][c] = wn[ks][c];
-            tap_adv();
-            tap_cur(wt, offn);
-            wload(wt, wn);
             issue(off, 1, q1);
             G_WAIT_PFW(q0);
             mfmas(wc[0], q0);
-            issue(offn, 0, q0);
-            G_WAIT_PFW(q1);
+            G_WAIT(q1, 0);
             mfmas(wc[1], q1);
-            off = offn;
-        }
-        // last tap
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int c = 0; c < CW; ++c) wc[ks][c] = wn[ks][c];
-        issue(off, 1, q1);
-        G_WAIT_PFW(q0);
-        mfmas(wc[0], q0);
-        G_WAIT(q1, 0);
-        mfmas(wc[1], q1);
 #undef G_WAIT
 #undef G_WAIT_PFW
-    }
+        }
 
-    // ---- epilogue: lane = pixel (l32) x 4 groups of 4 consecutive channels per channel fragment ----
-    const size_t osample = (size_t)n * g.d.out * g.h.out * g.w.out;
-    auto epilogue = [&](auto has_scale, auto has_res) {
+        // ---- epilogue: lane = pixel (l32) x 4 groups of 4 consecutive channels per channel fragment ----
+        auto epilogue = [&](auto has_scale, auto has_res) {
 #pragma unroll
-        for (int f = 0; f < PFW; ++f) {
-            if (opix[f] < 0) continue;
-            const size_t vox = osample + (size_t)opix[f];
-            u32x2_t rr[CW][4];
-            if constexpr (decltype(has_res)::value) {
+            for (int f = 0; f < PFW; ++f) {
+                if (opix[f] < 0) continue;
+                const size_t vox = osample + (size_t)opix[f];
+                u32x2_t rr[CW][4];
+                if constexpr (decltype(has_res)::value) {
 #pragma unroll
-                for (int c = 0; c < CW; ++c)
+                    for (int c = 0; c < CW; ++c)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-                        rr[c][gq] = *(const u32x2_t *)(residual + vox * g.cout + (ct * CW + c) * 32 + 8 * gq + 4 * half);
-            }
+                        for (int gq = 0; gq < 4; ++gq)
+                            rr[c][gq] = *(const u32x2_t *)(residual + vox * g.cout + (ct * CW + c) * 32 + 8 * gq + 4 * half);
+                }
 #pragma unroll
-            for (int c = 0; c < CW; ++c) {
+                for (int c = 0; c < CW; ++c) {
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int ch = (ct * CW + c) * 32 + 8 * gq + 4 * half;
-                    float v0 = acc[f][c][4 * gq], v1 = acc[f][c][4 * gq + 1], v2 = acc[f][c][4 * gq + 2],
-                          v3 = acc[f][c][4 * gq + 3];
-                    if constexpr (decltype(has_scale)::value) {
-                        const float4 s4 = *(const float4 *)(scale + ch), b4 = *(const float4 *)(shift + ch);
-                        v0 = __builtin_fmaf(v0, s4.x, b4.x); v1 = __builtin_fmaf(v1, s4.y, b4.y);
-                        v2 = __builtin_fmaf(v2, s4.z, b4.z); v3 = __builtin_fmaf(v3, s4.w, b4.w);
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int ch = (ct * CW + c) * 32 + 8 * gq + 4 * half;
+                        float v0 = acc[f][c][4 * gq], v1 = acc[f][c][4 * gq + 1], v2 = acc[f][c][4 * gq + 2],
+                              v3 = acc[f][c][4 * gq + 3];
+                        if constexpr (decltype(has_scale)::value) {
+                            const float4 s4 = *(const float4 *)(scale + ch), b4 = *(const float4 *)(shift + ch);
+                            v0 = __builtin_fmaf(v0, s4.x, b4.x); v1 = __builtin_fmaf(v1, s4.y, b4.y);
+                            v2 = __builtin_fmaf(v2, s4.z, b4.z); v3 = __builtin_fmaf(v3, s4.w, b4.w);
+                        }
+                        if constexpr (decltype(has_res)::value) {
+                            v0 += __uint_as_float(rr[c][gq].x << 16); v1 += __uint_as_float(rr[c][gq].x & 0xffff0000u);
+                            v2 += __uint_as_float(rr[c][gq].y << 16); v3 += __uint_as_float(rr[c][gq].y & 0xffff0000u);
+                        }
+                        if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        const u32x2_t pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                        *(u32x2_t *)(out + vox * g.cout + ch) = pk;
                     }
-                    if constexpr (decltype(has_res)::value) {
-                        v0 += __uint_as_float(rr[c][gq].x << 16); v1 += __uint_as_float(rr[c][gq].x & 0xffff0000u);
-                        v2 += __uint_as_float(rr[c][gq].y << 16); v3 += __uint_as_float(rr[c][gq].y & 0xffff0000u);
-                    }
-                    if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                    const u32x2_t pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-                    *(u32x2_t *)(out + vox * g.cout + ch) = pk;
                 }
             }
+        };
+        if (scale) {
+            if (residual) epilogue(std::true_type{}, std::true_type{});
+            else epilogue(std::true_type{}, std::false_type{});
+        } else {
+            if (residual) epilogue(std::false_type{}, std::true_type{});
+            else epilogue(std::false_type{}, std::false_type{});
         }
-    };
-    if (scale) {
-        if (residual) epilogue(std::true_type{}, std::true_type{});
-        else epilogue(std::true_type{}, std::false_type{});
-    } else {
-        if (residual) epilogue(std::false_type{}, std::true_type{});
-        else epilogue(std::false_type{}, std::false_type{});
     }
 }
 
@@ -364,6 +387,7 @@ bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
         if (ax[i]->up) classes *= 2;
     }
     g.cin = d->cin; g.cout = d->cout; g.nchunk = d->cin / 32;
+    g.cin_stride = d->in_channel_stride > 0 ? d->in_channel_stride : d->cin;
     const int cw = d->cout % 64 == 0 ? 2 : 1;
     g.cout_tiles = d->cout / (32 * cw);
     g.relu = d->relu ? 1 : 0;
@@ -386,8 +410,12 @@ bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
                 const long long bpx = (long long)c.d.block * c.h.block * c.w.block;
                 if (bpx > G_MAX_BLOCK_PX) continue;
                 const int rounds = (int)((bpx * 4 + 255) / 256);
-                const size_t lds = (size_t)rounds * 4096;
-                const long long wgs = (long long)c.d.tiles * c.h.tiles * c.w.tiles * c.cout_tiles * classes * d->n;
+                // transposed convolutions keep every chunk of the block in LDS and walk the parity
+                // classes inside the workgroup (staged once instead of once per class) when it fits
+                const bool resident = classes > 1 && (size_t)rounds * 4096 * g.nchunk <= 160 * 1024;
+                const size_t lds = (size_t)rounds * 4096 * (resident ? g.nchunk : 1);
+                const long long wgs = (long long)c.d.tiles * c.h.tiles * c.w.tiles * c.cout_tiles *
+                                      (resident ? 1 : classes) * d->n;
                 // workgroups that actually share a CU: at most 2 (registers), what the LDS allows,
                 // and no more than there are workgroups per CU
                 const int wg_per_cu = (int)std::max<long long>(
@@ -396,7 +424,7 @@ bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
                 // per-workgroup cost in clocks.  One tap = 2 k-steps: 2*pfw*cw MFMAs of 32 clocks per
                 // wave, against 4 waves x 2*cw KiB of weight fragments from L2 (~40 B/clk/CU); resident
                 // workgroups share both the MFMA pipes and the L2 port.  Staging ~ 0.1 clk/B.
-                const double taps = 27.0 / classes;
+                const double taps = resident ? 27.0 : 27.0 / classes;
                 const double mf_tap = (double)pfw * cw * 64.0 * wg_per_cu;
                 const double wt_tap = 8192.0 * cw / 40.0 * wg_per_cu;
                 const double mf = std::max(mf_tap, wt_tap) * taps * g.nchunk;
@@ -406,7 +434,8 @@ bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
                     best = cost; found = true;
                     c.block_px = (int)bpx; c.nrounds = rounds;
                     c.r_bw = 1.0f / (float)c.w.block; c.r_bhw = 1.0f / (float)(c.h.block * c.w.block);
-                    pl.g = c; pl.pfw = pfw; pl.cw = cw; pl.classes = classes; pl.lds = lds;
+                    c.resident = resident ? 1 : 0; c.classes = classes;
+                    pl.g = c; pl.pfw = pfw; pl.cw = cw; pl.classes = resident ? 1 : classes; pl.lds = lds;
                 }
             }
         }
@@ -435,7 +464,9 @@ int g_check(const dfm_conv3d_desc *d)
         }
         in_px *= d->in_size[i]; out_px *= d->out_size[i];
     }
-    if (in_px * d->cin * 2 >= (1ll << 31) || out_px >= (1ll << 31))
+    if (d->in_channel_stride != 0 && (d->in_channel_stride < d->cin || d->in_channel_stride % 8))
+        return set_error(DFM_ERR_INVALID_ARG, "in_channel_stride must be 0 or >= cin and a multiple of 8");
+    if (in_px * std::max(d->cin, d->in_channel_stride) * 2 >= (1ll << 31) || out_px >= (1ll << 31))
         return set_error(DFM_ERR_UNSUPPORTED, "sample too large for 32-bit offsets");
     return DFM_OK;
 }
@@ -499,7 +530,7 @@ extern "C" DFM_API int dfm_conv3d_g_fwd(const dfm_conv3d_desc *desc, const void 
     do {                                                                                             \
         if (!attr_done[CW_ - 1][PFW_ - 1]) {                                                         \
             hipError_t e_ = hipFuncSetAttribute((const void *)conv3d_g_kernel<CW_, PFW_>,            \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 98304);  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
             if (e_ != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e_));              \
             attr_done[CW_ - 1][PFW_ - 1] = true;                                                     \
         }                                                                                            \

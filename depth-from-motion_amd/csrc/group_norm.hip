@@ -366,8 +366,12 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
                                                           const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, int relu,
                                                           T *__restrict__ y, float *__restrict__ mean_out,
-                                                          float *__restrict__ rstd_out, int psplits)
+                                                          float *__restrict__ rstd_out, int psplits,
+                                                          const T *__restrict__ res)
 {
+    // res: NULL, or a tensor of x's shape added after the affine map and before the ReLU
+    // (the residual connections of the aggregation stacks: dfm_backbone.py:176,183,
+    //  conv_modules.py:124-139) -- one pass instead of a separate elementwise add
     // psplits: partials per group to merge (0: one per workgroup of this grid, the layout
     // gn_stats_cl_kernel writes; 1: already merged by gn_merge_partials_kernel)
     constexpr int VEC = vec16<T>::N;
@@ -402,25 +406,32 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
     constexpr int U = 4;  // vectors in flight per lane
     long long v = lo + v0;
     for (; v + (long long)(U - 1) * vpi < hi; v += (long long)U * vpi) {
-        float f[U][VEC];
+        float f[U][VEC], q[U][VEC];
 #pragma unroll
         for (int u = 0; u < U; ++u) load16<T>(x + base + (size_t)(v + (long long)u * vpi) * C, f[u]);
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) load16<T>(res + base + (size_t)(v + (long long)u * vpi) * C, q[u]);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float r = f[u][k] * a[k] + b[k];
+                float r = f[u][k] * a[k] + b[k];
+                if (res) r += q[u][k];
                 f[u][k] = relu ? fmaxf(r, 0.0f) : r;
             }
             store16<T>(y + base + (size_t)(v + (long long)u * vpi) * C, f[u]);
         }
     }
     for (; v < hi; v += vpi) {
-        float f[VEC];
+        float f[VEC], q[VEC];
         load16<T>(x + base + (size_t)v * C, f);
+        if (res) load16<T>(res + base + (size_t)v * C, q);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const float r = f[k] * a[k] + b[k];
+            float r = f[k] * a[k] + b[k];
+            if (res) r += q[k];
             f[k] = relu ? fmaxf(r, 0.0f) : r;
         }
         store16<T>(y + base + (size_t)v * C, f);
@@ -497,6 +508,16 @@ DFM_API int dfm_group_norm_fwd_channels_last(int32_t n, int32_t c, int64_t spati
                                              float *mean, float *rstd, void *workspace,
                                              size_t workspace_bytes, void *stream)
 {
+    return dfm_group_norm_fwd_channels_last_res(n, c, spatial, groups, eps, dtype, relu, x, gamma, beta, nullptr,
+                                                y, mean, rstd, workspace, workspace_bytes, stream);
+}
+
+DFM_API int dfm_group_norm_fwd_channels_last_res(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                                 float eps, int32_t dtype, int32_t relu, const void *x,
+                                                 const float *gamma, const float *beta,
+                                                 const void *residual, void *y, float *mean, float *rstd,
+                                                 void *workspace, size_t workspace_bytes, void *stream)
+{
     if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups)
         return set_error(DFM_ERR_INVALID_ARG, "bad sizes in dfm_group_norm_fwd_channels_last");
     if (dtype != DFM_F32 && dtype != DFM_BF16)
@@ -527,11 +548,11 @@ DFM_API int dfm_group_norm_fwd_channels_last(int32_t n, int32_t c, int64_t spati
     if (dtype == DFM_F32)
         hipLaunchKernelGGL(gn_apply_cl_kernel<float>, agrid, dim3(256), 0, st, (const float *)x,
                            (long long)spatial, c, groups, asplits, eps, merged, gamma, beta, relu,
-                           (float *)y, mean, rstd, 1);
+                           (float *)y, mean, rstd, 1, (const float *)residual);
     else
         hipLaunchKernelGGL(gn_apply_cl_kernel<bf16_t>, agrid, dim3(256), 0, st, (const bf16_t *)x,
                            (long long)spatial, c, groups, asplits, eps, merged, gamma, beta, relu,
-                           (bf16_t *)y, mean, rstd, 1);
+                           (bf16_t *)y, mean, rstd, 1, (const bf16_t *)residual);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
@@ -543,6 +564,18 @@ DFM_API int dfm_group_norm_apply_channels_last(int32_t n, int32_t c, int64_t spa
                                                float *mean, float *rstd, const float *partials,
                                                int32_t splits, void *workspace,
                                                size_t workspace_bytes, void *stream)
+{
+    return dfm_group_norm_apply_channels_last_res(n, c, spatial, groups, eps, dtype, relu, x, gamma, beta,
+                                                  nullptr, y, mean, rstd, partials, splits, workspace,
+                                                  workspace_bytes, stream);
+}
+
+DFM_API int dfm_group_norm_apply_channels_last_res(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                                   float eps, int32_t dtype, int32_t relu, const void *x,
+                                                   const float *gamma, const float *beta,
+                                                   const void *residual, void *y, float *mean, float *rstd,
+                                                   const float *partials, int32_t splits, void *workspace,
+                                                   size_t workspace_bytes, void *stream)
 {
     if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups || splits <= 0)
         return set_error(DFM_ERR_INVALID_ARG, "bad sizes in dfm_group_norm_apply_channels_last");
@@ -567,11 +600,11 @@ DFM_API int dfm_group_norm_apply_channels_last(int32_t n, int32_t c, int64_t spa
     if (dtype == DFM_F32)
         hipLaunchKernelGGL(gn_apply_cl_kernel<float>, grid, dim3(256), 0, st, (const float *)x,
                            (long long)spatial, c, groups, asplits, eps, merged, gamma, beta, relu,
-                           (float *)y, mean, rstd, 1);
+                           (float *)y, mean, rstd, 1, (const float *)residual);
     else
         hipLaunchKernelGGL(gn_apply_cl_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x,
                            (long long)spatial, c, groups, asplits, eps, merged, gamma, beta, relu,
-                           (bf16_t *)y, mean, rstd, 1);
+                           (bf16_t *)y, mean, rstd, 1, (const bf16_t *)residual);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;

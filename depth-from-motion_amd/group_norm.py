@@ -7,6 +7,7 @@ GroupNorm kernel followed by a separate ReLU.
 touching checkpoints.
 """
 import ctypes
+import weakref
 
 import torch
 from torch import nn
@@ -15,10 +16,31 @@ from . import _capi
 from .plane_sweep import _DTYPES, _Workspace, _ptr, _stream_ptr
 
 
+_F32_CACHE = {}
+
+
+def _f32_params(weight, bias):
+    """fp32 copies of the affine parameters the kernels read; bf16 modules would otherwise launch two
+    conversion kernels per call (36 per DfMBackbone forward).  Cached per parameter and version."""
+    if weight.dtype == torch.float32 and bias.dtype == torch.float32:
+        return weight.detach().contiguous(), bias.detach().contiguous()
+    key = (id(weight), id(bias))
+    ver = (weight._version, bias._version, weight.device, weight.data_ptr(), bias.data_ptr())
+    hit = _F32_CACHE.get(key)
+    # the entry holds weak references: an id() reused by a new tensor never matches a dead one
+    if hit is None or hit[0] != ver or hit[3]() is not weight or hit[4]() is not bias:
+        if len(_F32_CACHE) > 1024:
+            _F32_CACHE.clear()
+        hit = (ver, weight.detach().float().contiguous(), bias.detach().float().contiguous(),
+               weakref.ref(weight), weakref.ref(bias))
+        _F32_CACHE[key] = hit
+    return hit[1], hit[2]
+
+
 class _GroupNormFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, relu, partials=None):
+    def forward(ctx, x, weight, bias, groups, eps, relu, partials=None, residual=None):
         lib = _capi.lib()
         device = x.device
         n, c = x.shape[:2]
@@ -34,31 +56,47 @@ class _GroupNormFn(torch.autograd.Function):
         y = torch.empty_like(x)  # preserves the memory format
         mean = torch.empty(n * groups, dtype=torch.float32, device=device)
         rstd = torch.empty_like(mean)
-        w32 = weight.detach().float().contiguous()
-        b32 = bias.detach().float().contiguous()
+        w32, b32 = _f32_params(weight, bias)
         nbytes = lib.dfm_group_norm_workspace_bytes(n, c, spatial, groups)
         ws = _Workspace.get(device, nbytes)
         fn = lib.dfm_group_norm_fwd_channels_last if cl else lib.dfm_group_norm_fwd
+        fused_res = residual is not None and cl and residual.dtype == x.dtype and \
+            residual.shape == x.shape and residual.stride() == x.stride()
+        rp = _ptr(residual) if fused_res else None
         with torch.cuda.device(device):
             if partials is not None:
                 # statistics came from the producer (MFMA conv epilogue): normalisation pass only
                 assert cl and partials.shape[:2] == (n, groups) and partials.is_contiguous()
-                _capi.check(lib.dfm_group_norm_apply_channels_last(
-                    n, c, spatial, groups, eps, _DTYPES[x.dtype], int(relu), _ptr(x), _ptr(w32), _ptr(b32),
-                    _ptr(y), _ptr(mean), _ptr(rstd), _ptr(partials), partials.shape[2], _ptr(ws), nbytes,
+                _capi.check(lib.dfm_group_norm_apply_channels_last_res(
+                    n, c, spatial, groups, eps, _DTYPES[x.dtype], int(relu and (fused_res or residual is None)),
+                    _ptr(x), _ptr(w32), _ptr(b32), rp, _ptr(y), _ptr(mean), _ptr(rstd), _ptr(partials),
+                    partials.shape[2], _ptr(ws), nbytes, _stream_ptr(device)))
+            elif cl:
+                _capi.check(lib.dfm_group_norm_fwd_channels_last_res(
+                    n, c, spatial, groups, eps, _DTYPES[x.dtype], int(relu and (fused_res or residual is None)),
+                    _ptr(x), _ptr(w32), _ptr(b32), rp, _ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), nbytes,
                     _stream_ptr(device)))
             else:
-                _capi.check(fn(n, c, spatial, groups, eps, _DTYPES[x.dtype], int(relu), _ptr(x), _ptr(w32),
-                               _ptr(b32), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), nbytes,
+                _capi.check(fn(n, c, spatial, groups, eps, _DTYPES[x.dtype], int(relu and residual is None),
+                               _ptr(x), _ptr(w32), _ptr(b32), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), nbytes,
                                _stream_ptr(device)))
+        if residual is not None and not fused_res:
+            # a layout the kernel does not fuse (NCDHW, mismatched strides): plain torch ops
+            y = y + residual
+            if relu:
+                y = torch.relu_(y)
         ctx.save_for_backward(x, y if relu else x, mean, rstd, w32)
-        ctx.cfg = (groups, bool(relu), weight.dtype, bias.dtype, cl)
+        ctx.cfg = (groups, bool(relu), weight.dtype, bias.dtype, cl, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, y, mean, rstd, w32 = ctx.saved_tensors
-        groups, relu, wdt, bdt, cl = ctx.cfg
+        groups, relu, wdt, bdt, cl, has_res = ctx.cfg
+        # y = relu?(gn(x) + residual): the residual's gradient is the incoming one behind the ReLU mask
+        gres = None
+        if has_res and ctx.needs_input_grad[7]:
+            gres = gy * (y > 0).to(gy.dtype) if relu else gy
         if cl:  # the backward kernels are NC(D)HW: convert (training through channels-last
             x, y = x.contiguous(), y.contiguous()  # stacks pays two extra copies here)
         lib = _capi.lib()
@@ -76,17 +114,18 @@ class _GroupNormFn(torch.autograd.Function):
                 lib.dfm_group_norm_bwd(n, c, spatial, groups, _DTYPES[x.dtype], int(relu), _ptr(gy),
                                        _ptr(x), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(w32), _ptr(gx),
                                        _ptr(gw), _ptr(gb), _ptr(ws), nbytes, _stream_ptr(device)))
-        return gx, gw.to(wdt), gb.to(bdt), None, None, None, None
+        return gx, gw.to(wdt), gb.to(bdt), None, None, None, None, gres
 
 
-def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False, partials=None):
+def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False, partials=None, residual=None):
     """torch.nn.functional.group_norm(+relu) on the GPU through the fused kernels.
     ``partials`` (N, groups, splits, 3): count / mean / M2 moment partials of ``x`` from its
-    producer (``MfmaConv3d.forward_with_stats``); the statistics pass over ``x`` is skipped."""
+    producer (``MfmaConv3d.forward_with_stats``); the statistics pass over ``x`` is skipped.
+    ``residual``: added after the affine map, before the ReLU (fused into the channels-last pass)."""
     if not x.is_cuda or x.dtype not in _DTYPES:
         raise RuntimeError('fused group_norm needs a float32/bfloat16 GPU tensor '
                            '(depth-from-motion_amd has no CPU path)')
-    return _GroupNormFn.apply(x, weight, bias, int(num_groups), float(eps), bool(relu), partials)
+    return _GroupNormFn.apply(x, weight, bias, int(num_groups), float(eps), bool(relu), partials, residual)
 
 
 _cpu_reference = False
@@ -108,15 +147,17 @@ class HipGroupNorm(nn.GroupNorm):
     tensor the kernels do not cover (fp16, affine=False), is an error.  (Tests that exercise
     module wiring on a CPU-only box opt in with ``allow_cpu_reference(True)``.)"""
 
-    def forward(self, x, relu=False, partials=None):
+    def forward(self, x, relu=False, partials=None, residual=None):
         if x.is_cuda:
             if x.dtype not in _DTYPES or not self.affine:
                 raise RuntimeError(
                     f'HipGroupNorm: unsupported GPU input (dtype {x.dtype}, affine={self.affine}); '
                     'the fused kernels cover float32 / bfloat16 with affine parameters')
-            return group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu, partials)
+            return group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu, partials, residual)
         if not _cpu_reference:
             raise RuntimeError('HipGroupNorm got a CPU tensor: depth-from-motion_amd has no CPU path '
                                '(tests opt in with group_norm.allow_cpu_reference(True))')
         y = super().forward(x)
+        if residual is not None:
+            y = y + residual
         return torch.relu_(y) if relu else y

@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import MfmaConv3d, MfmaConv3dG, MfmaConvTranspose3d
+from .conv3d import MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose3d
 from .depth_head import depth_distribution_loss, depth_head_forward
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .group_norm import HipGroupNorm
@@ -83,25 +83,29 @@ class ConvModule(nn.Module):
                 raise NotImplementedError(act_cfg['type'])
             self.activate = nn.ReLU(inplace=act_cfg.get('inplace', True))
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual`` (extension, GroupNorm blocks): added after the norm, before the activation --
+        fused into the normalisation pass of the HIP GroupNorm."""
         norm = getattr(self, self.norm_name) if self.norm_name is not None else None
         if (isinstance(self.conv, MfmaConv3d) and isinstance(norm, HipGroupNorm) and
                 norm.num_groups == self.conv.out_channels and self.conv.eligible(x)):
             # MFMA conv whose epilogue already produced the per-channel GroupNorm statistics:
-            # the normalisation (+ReLU) is one read and one write of the tensor
+            # the normalisation (+residual, +ReLU) is one read and one write of the tensor
             y, partials = self.conv.forward_with_stats(x)
-            return norm(y, relu=self.activate is not None, partials=partials)
-        if self.fusable(x):
+            return norm(y, relu=self.activate is not None, partials=partials, residual=residual)
+        if residual is None and self.fusable(x):
             return self.forward_fused(x)
         x = self.conv(x)
         if self.norm_name is not None:
             if isinstance(norm, HipGroupNorm):
-                return norm(x, relu=self.activate is not None)  # GN and ReLU in one pass
+                # GN (+residual) and ReLU in one pass
+                return norm(x, relu=self.activate is not None, residual=residual)
             x = norm(x)
+        if residual is not None:
+            x = x + residual
         if self.activate is not None:
             x = self.activate(x)
         return x
-
 
     # -- inference path of the Conv3d + BatchNorm3d (+ReLU) blocks of the voxel necks: the running
     # statistics fold into a per-channel scale / shift applied to the fp32 accumulator in the
@@ -157,15 +161,17 @@ class hourglass(nn.Module):  # noqa: N801  (reference class name)
 
     def forward(self, x, presqu, postsqu):
         # GroupNorm and the ReLU that follows it are one pass of the fused kernel
+        return self.forward_add(x, presqu, postsqu, None)
+
+    def forward_add(self, x, presqu, postsqu, out_residual):
+        """forward with ``out_residual`` added to the first output (DfMBackbone's
+        ``cost = cost + hourglass(cost)[0]``, dfm_backbone.py:180-183).  GroupNorm, the residual adds
+        and the ReLUs that follow them are one pass of the fused kernel each."""
         down1 = _gn_relu(self.conv1[0], x, True)
-        if postsqu is None:
-            pre = _gn_relu(self.conv2, down1, True)
-        else:
-            pre = F.relu(_gn_relu(self.conv2, down1, False) + postsqu)
+        pre = _gn_relu(self.conv2, down1, True, postsqu)
         bottom = _gn_relu(self.conv4[0], _gn_relu(self.conv3[0], pre, True), True)
-        skip = pre if presqu is None else presqu
-        post = F.relu(self.conv5(bottom) + skip)
-        return self.conv6(post), pre, post
+        post = _gn_relu(self.conv5, bottom, True, pre if presqu is None else presqu)
+        return _gn_relu(self.conv6, post, False, out_residual), pre, post
 
 
 # --------------------------------------------------------------------------
@@ -199,7 +205,7 @@ class DfMBackbone(nn.Module):
                     nn.ModuleList(hourglass(cv, gn=True) for _ in range(num_hg)),
                     nn.ModuleList(
                         nn.Sequential(_conv3(cv, cv, norm_cfg),
-                                      nn.Conv3d(cv, 1, 3, 1, 1, bias=False))
+                                      (MfmaConv3dTo1 if cv == 32 else nn.Conv3d)(cv, 1, 3, 1, 1, bias=False))
                         for _ in range(num_hg)))
 
         self.dres0, self.dres1, self.hg_stereo, self.pred_stereo = branch(2 * in_channels)
@@ -219,11 +225,10 @@ class DfMBackbone(nn.Module):
     @staticmethod
     def _aggregate(first, second, hgs, x):
         cost = first(x)
-        cost = second(cost) + cost
+        cost = second(cost, residual=cost)
         outs = []
         for hg in hgs:
-            residual, _, _ = hg(cost, None, None)
-            cost = cost + residual
+            cost, _, _ = hg.forward_add(cost, None, None, cost)  # cost + hourglass(cost)[0]
             outs.append(cost)
         return outs if outs else [cost]
 
@@ -383,7 +388,9 @@ class ResModule(nn.Module):
     def forward(self, x):
         if self.conv0.fusable(x) and self.conv1.fusable(x):
             # inference: conv-bn-relu and conv-bn + identity + relu are one MFMA kernel each
-            return self.conv1.forward_fused(self.conv0.forward_fused(x), residual=x, relu=True)
+            res = x if x.is_contiguous(memory_format=torch.channels_last_3d) else \
+                x.contiguous(memory_format=torch.channels_last_3d)  # a channel slice (DfMNeck mono stack)
+            return self.conv1.forward_fused(self.conv0.forward_fused(x), residual=res, relu=True)
         return self.activation(x + self.conv1(self.conv0(x)))
 
 
@@ -481,12 +488,14 @@ class upconv_module(nn.Module):  # noqa: N801  (reference class name)
         return x
 
 
-def _gn_relu(seq, x, relu):
-    """conv -> norm(+ReLU fused when the norm is the HIP GroupNorm)"""
+def _gn_relu(seq, x, relu, residual=None):
+    """conv -> norm (+residual) (+ReLU), one pass when the norm is the HIP GroupNorm"""
     x = seq[0](x)
     if isinstance(seq[1], HipGroupNorm):
-        return seq[1](x, relu=relu)
+        return seq[1](x, relu=relu, residual=residual)
     x = seq[1](x)
+    if residual is not None:
+        x = x + residual
     return F.relu(x) if relu else x
 
 

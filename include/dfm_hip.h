@@ -423,6 +423,22 @@ DFM_API int dfm_conv3d_k3_c32_fwd(int32_t n, int32_t d, int32_t h, int32_t w, co
                                   int32_t out_f32, int32_t relu, int32_t depth_chunk, float *stats,
                                   void *stream);
 
+/* Same call on a 32-channel SLICE of a wider channels-last tensor: x points at the slice's first
+ * channel, x_channel_stride = channels of the wide tensor (elements between consecutive pixels,
+ * multiple of 8).  The stereo dres0 (64 -> 32) reads the two halves of the cost volume, the mono
+ * dres0 its first half (dfm_backbone.py:175,189), in place. */
+DFM_API int dfm_conv3d_k3_c32_fwd_strided(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
+                                          int32_t x_channel_stride, const void *packed_weights,
+                                          const float *acc_in, void *out, int32_t out_f32,
+                                          int32_t relu, int32_t depth_chunk, float *stats,
+                                          void *stream);
+/* The 32 -> 1 prediction convolutions (dfm_backbone.py:120-127, Conv3d(32, 1, 3, 1, 1)): the same
+ * kernel with packed weights whose output rows 1..31 are zero (pack a (32, 32, 3, 3, 3) tensor with
+ * the (1, 32, 3, 3, 3) weight in row 0); only channel 0 is stored: out = (n, d, h, w) bf16. */
+DFM_API int dfm_conv3d_k3_c32_to1_fwd(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
+                                      const void *packed_weights, void *out, int32_t relu,
+                                      int32_t depth_chunk, void *stream);
+
 /* ---------------------------------------------------------------------- */
 /* General MFMA Conv3d / ConvTranspose3d 3x3x3, NDHWC bf16, channels = 32 k    */
 /* (hourglass conv1..conv6: utils/conv_modules.py:73-149; Conv3d+BN3d+ReLU     */
@@ -439,6 +455,9 @@ typedef struct dfm_conv3d_desc {
     int32_t transposed[3];  /* != 0: this axis is the x2 transposed convolution (kernel 3,   */
                             /* stride 2, padding 1, output_padding 1: out = 2 in)            */
     int32_t relu;           /* != 0: max(., 0) before the store                              */
+    int32_t in_channel_stride; /* elements between consecutive input pixels; 0 = cin.  > cin: x  */
+                            /* is a channel slice of a wider channels-last tensor (pointer at   */
+                            /* its first channel; multiple of 8 so pieces stay 16-byte aligned) */
 } dfm_conv3d_desc;
 /* Bytes of the packed-weight buffer (27 * cin * cout bf16 in fragment order + a zero page). */
 DFM_API size_t dfm_conv3d_g_weight_bytes(int32_t cin, int32_t cout);
@@ -457,7 +476,7 @@ DFM_API int dfm_conv3d_g_pack_weights(const void *weight, int32_t weight_dtype, 
                                       int32_t cout, int32_t swap, int32_t flip, void *packed,
                                       void *stream);
 /*
- * x        : (n, d, h, w, cin) bf16, channels-last                              [device]
+ * x        : (n, d, h, w, cin) bf16, channels-last (pixel stride desc->in_channel_stride) [device]
  * scale / shift : NULL, or fp32 [cout]: y = conv * scale[c] + shift[c] (a folded BatchNorm3d in
  *            eval mode, or a bias) applied to the fp32 accumulator
  * residual : NULL, or (n, od, oh, ow, cout) bf16 added after scale / shift (ResModule identity)
@@ -549,6 +568,22 @@ DFM_API int dfm_group_norm_apply_channels_last(int32_t n, int32_t c, int64_t spa
                                                float *mean, float *rstd, const float *partials,
                                                int32_t splits, void *workspace,
                                                size_t workspace_bytes, void *stream);
+/* The two channels-last entry points with a fused residual: `residual` (NULL, or a tensor of x's
+ * shape / dtype) is added after the affine map and before the ReLU,
+ *   y = relu?((x - mean) * rstd * gamma + beta + residual)
+ * -- the residual connections of the aggregation stacks (dfm_backbone.py:176,183,
+ * utils/conv_modules.py:124-139) without a separate elementwise pass. */
+DFM_API int dfm_group_norm_fwd_channels_last_res(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                                 float eps, int32_t dtype, int32_t relu, const void *x,
+                                                 const float *gamma, const float *beta,
+                                                 const void *residual, void *y, float *mean, float *rstd,
+                                                 void *workspace, size_t workspace_bytes, void *stream);
+DFM_API int dfm_group_norm_apply_channels_last_res(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                                   float eps, int32_t dtype, int32_t relu, const void *x,
+                                                   const float *gamma, const float *beta,
+                                                   const void *residual, void *y, float *mean, float *rstd,
+                                                   const float *partials, int32_t splits, void *workspace,
+                                                   size_t workspace_bytes, void *stream);
 /* grad_gamma / grad_beta: (c) fp32, zero-filled by the caller; `y` is only
  * read when relu != 0 (mask y > 0). */
 DFM_API int dfm_group_norm_bwd(int32_t n, int32_t c, int64_t spatial, int32_t groups,

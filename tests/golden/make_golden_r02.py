@@ -16,6 +16,11 @@ lift / ref_stubs); only inputs and the outputs the reference produced are stored
                        the padded 384x1248 image, D=4 planes (num_bins=16, downsample_factor=4).
                        Inputs are regenerated from the seeds by the test; stored are the cost
                        volume and a strided sample of the two feature volumes.
+  modules_wide.npz     the 3-D aggregation modules at their REAL channel widths (what the MFMA
+                       convolution kernels cover): hourglass(32) (utils/conv_modules.py:73-149),
+                       OutdoorImVoxelNeck(64 -> 256) (necks/imvoxel_neck.py) and
+                       DfMNeck(64 -> 256, 2 frames) (necks/dfm_neck.py) in eval mode on small seeded
+                       volumes with synthetic weights; inputs are regenerated from the seeds.
   bev_spp.npz          BEVHourglass (backbones/bev_hourglass.py) and SPPUNetNeck
                        (necks/spp_unet_neck.py) forward on seeded inputs with synthetic weights.
 """
@@ -223,10 +228,44 @@ def make_bev_spp():
     print('bev', out['bev_out'].shape, 'spp', tuple(stereo.shape), out['spp_sem'].shape)
 
 
+def wide_inputs():
+    """shared by the generator and tests/test_modules.py"""
+    gen = torch.Generator().manual_seed(60)
+    return dict(hg=torch.randn(1, 32, 8, 12, 16, generator=gen),
+                neck=torch.randn(1, 64, 10, 12, 12, generator=gen),
+                dfmneck=torch.randn(1, 128, 10, 12, 12, generator=gen))
+
+
+def make_wide_modules():
+    import ref_stubs
+    from tests import util
+    ref = ref_stubs.load_hot_path_modules()
+    cm = sys.modules['mmdet3d.models.utils.conv_modules'] if 'mmdet3d.models.utils.conv_modules' in sys.modules \
+        else ref_stubs.load_file('mmdet3d/models/utils/conv_modules.py', 'ref_conv_modules')
+    x = wide_inputs()
+    out = {}
+    m = cm.hourglass(32, gn=True).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, 61))
+    with torch.no_grad():
+        y, pre, post = m(x['hg'], None, None)
+    out.update(hg_out=y.numpy(), hg_pre=pre.numpy(), hg_post=post.numpy(),
+               hg_keys=np.array(list(m.state_dict().keys())))
+    m = ref['imvoxel_neck'].OutdoorImVoxelNeck(in_channels=64, out_channels=256).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, 62))
+    with torch.no_grad():
+        out['imvoxel_out'] = m(x['neck'])[0].numpy()
+    m = ref['dfm_neck'].DfMNeck(in_channels=64, out_channels=256, num_frames=2).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, 63))
+    with torch.no_grad():
+        out['dfmneck_out'] = m(x['dfmneck'])[0].numpy()
+    np.savez_compressed(os.path.join(HERE, 'modules_wide.npz'), **out)
+    print('wide modules:', {k: v.shape for k, v in out.items() if k != 'hg_keys'})
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF_ROOT):
         sys.exit('reference not mounted; fixtures are committed, nothing to do')
-    which = sys.argv[1:] or ['depth_loss', 'configs', 'cfg1', 'bev_spp']
+    which = sys.argv[1:] or ['depth_loss', 'configs', 'cfg1', 'bev_spp', 'wide']
     torch.set_num_threads(1)
     if 'depth_loss' in which:
         make_depth_loss()
@@ -236,3 +275,5 @@ if __name__ == '__main__':
         make_backbone_cfg1()
     if 'bev_spp' in which:
         make_bev_spp()
+    if 'wide' in which:
+        make_wide_modules()

@@ -189,3 +189,21 @@ def test_hourglass_shapes_full_size_against_fp64_subset(cv):
                     ref += torch.einsum('ncdhw,oc->nodhw', patch, wd[:, :, kd, kh, kw])
         np.testing.assert_allclose(out[:, :, ::5, ::7, ::9].double().cpu().numpy(), ref.cpu().numpy(), rtol=RTOL,
                                    atol=ATOL)
+
+
+def test_channel_slice_of_a_wider_tensor_is_read_in_place(cv):
+    """DfMNeck's mono stack convolves x[:, :C] of the (N, C*F, ...) volume (dfm_neck.py:108): the
+    kernel reads the slice with the wide tensor's pixel stride, no copy"""
+    dev = torch.device('cuda:0')
+    size = (4, 6, 12)
+    x, w = _x(2, 128, size, seed=31), _w(64, 64, 64, seed=32)
+    xg = _cl(x, dev)
+    pk = cv.pack_conv3d_g_weights(w.to(dev), 64, 64)
+    for lo in (0, 64):
+        xs = xg[:, lo:lo + 64]
+        assert not xs.is_contiguous(memory_format=torch.channels_last_3d)
+        out = cv.conv3d_g(xs, pk, 64)
+        ref = F.conv3d(x[:, lo:lo + 64].float(), w, padding=1)
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+    m = cv.MfmaConv3dG(64, 64, 3, padding=1, bias=False).to(dev)
+    assert m.eligible(xg[:, :64]) and not m.eligible(xg[:, 4:68])

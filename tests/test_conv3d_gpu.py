@@ -159,3 +159,20 @@ def test_groupnorm_statistics_from_the_conv_epilogue(cv):
     assert float((fused.float() - unfused.float()).abs().mean()) < 1e-4
     fused.float().square().mean().backward()
     assert xin.grad is not None and m.conv.weight.grad is not None and m.gn.weight.grad is not None
+
+
+def test_prediction_conv_32_to_1(cv):
+    """Conv3d(32, 1, 3, 1, 1) of the pred stacks (dfm_backbone.py:120-127) through the MFMA kernel"""
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    m = cv.MfmaConv3dTo1(32, 1, 3, 1, 1, bias=False).to(dev)
+    assert list(m.state_dict()) == ['weight']
+    x, _ = _inputs(2, 32, 5, 19, 45, seed=3)
+    xb = x.to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    assert m.eligible(xb)
+    y = m(xb)
+    assert y.shape == (2, 1, 5, 19, 45) and y.dtype == torch.bfloat16
+    ref = F.conv3d(x.float(), m.weight.detach().cpu().bfloat16().float(), padding=1)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+    y.sum().backward()
+    assert xb.grad is not None and m.weight.grad is not None and torch.isfinite(m.weight.grad).all()

@@ -119,3 +119,33 @@ def test_channels_last_forward_backward_vs_torch_cpu(pkg, n, c, sp, groups, relu
     gtol = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)
     np.testing.assert_allclose(xg.grad.float().cpu().numpy(), xr.grad.numpy(), **gtol)
     np.testing.assert_allclose(wg.grad.cpu().numpy(), wr.grad.numpy(), rtol=2e-2, atol=2e-2 * float(wr.grad.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('layout', ['channels_last', 'contiguous'])
+@pytest.mark.parametrize('n,c,sp,groups', [(2, 32, (6, 10, 12), 32), (1, 64, (5, 9, 16), 32)])
+def test_fused_residual_forward_backward(pkg, n, c, sp, groups, relu, layout):
+    """y = relu?(GroupNorm(x) + residual): the residual connections of the aggregation stacks
+    (dfm_backbone.py:176,183; conv_modules.py:124-139) in the normalisation pass itself
+    (channels-last; other layouts take separate torch ops)"""
+    gen = torch.Generator().manual_seed(n * 7 + c)
+    x = torch.randn(n, c, *sp, generator=gen) * 2 + 0.7
+    res = torch.randn(n, c, *sp, generator=gen)
+    w = 1 + 0.2 * torch.randn(c, generator=gen)
+    b = 0.3 * torch.randn(c, generator=gen)
+    gy = torch.randn(n, c, *sp, generator=gen)
+    xr, rr, wr, br = (t.clone().requires_grad_(True) for t in (x, res, w, b))
+    ref = F.group_norm(xr, groups, wr, br, 1e-5) + rr
+    ref = F.relu(ref) if relu else ref
+    (ref * gy).sum().backward()
+    fmt = torch.channels_last_3d if layout == 'channels_last' else torch.contiguous_format
+    xg, rg = (t.cuda().contiguous(memory_format=fmt).requires_grad_(True) for t in (x, res))
+    wg, bg = (t.cuda().requires_grad_(True) for t in (w, b))
+    out = pkg.group_norm(xg, groups, wg, bg, 1e-5, relu, residual=rg)
+    (out * gy.cuda()).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(rg.grad.cpu().numpy(), rr.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(wg.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-3, atol=1e-3)

@@ -239,3 +239,85 @@ def test_dfm_stereo_path_runs_the_training_config_end_to_end(pkg):
     grads = [p.grad for p in path.parameters() if p.requires_grad]
     assert all(g is not None and torch.isfinite(g).all() for g in grads)
     assert sum(float(g.abs().sum()) > 0 for g in grads) > 0.9 * len(grads)
+
+
+def _wide_inputs():
+    gen = torch.Generator().manual_seed(60)   # tests/golden/make_golden_r02.py::wide_inputs
+    return dict(hg=torch.randn(1, 32, 8, 12, 16, generator=gen),
+                neck=torch.randn(1, 64, 10, 12, 12, generator=gen),
+                dfmneck=torch.randn(1, 128, 10, 12, 12, generator=gen))
+
+
+def _close_bf16(got, ref):
+    """bf16 activations through 6-8 convolution layers: 5 % relative + 3 % of the output range"""
+    np.testing.assert_allclose(got, ref, rtol=5e-2, atol=0.03 * float(np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+def test_wide_modules_mfma_path_vs_reference_modules(mods, monkeypatch):
+    """hourglass(32), OutdoorImVoxelNeck(64 -> 256), DfMNeck(64 -> 256, 2 frames) at their real
+    channel widths against the REFERENCE modules (tests/golden/modules_wide.npz):
+    fp32 NCDHW (torch convolutions) within CONV_TOL, and bf16 channels_last_3d -- every 3x3x3
+    convolution in the hand-written MFMA kernels, eval-mode BatchNorm folded into their epilogue --
+    within the bf16 tolerance."""
+    cv = importlib.import_module('depth-from-motion_amd.conv3d')
+    calls = {'g': 0}
+    real = cv.conv3d_g
+
+    def counted(*a, **k):
+        calls['g'] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(cv, 'conv3d_g', counted)
+    z = np.load(os.path.join(util.GOLDEN, 'modules_wide.npz'))
+    x = _wide_inputs()
+    cl = torch.channels_last_3d
+
+    hg = _load(mods.hourglass(32, gn=True), 61)
+    assert list(hg.state_dict().keys()) == list(z['hg_keys'])
+    with torch.no_grad():
+        y, pre, post = hg(x['hg'].cuda(), None, None)
+    for got, key in ((y, 'hg_out'), (pre, 'hg_pre'), (post, 'hg_post')):
+        np.testing.assert_allclose(got.cpu().numpy(), z[key], **CONV_TOL)
+    assert calls['g'] == 0
+    hgb = hg.to(torch.bfloat16)
+    with torch.no_grad():
+        y, pre, post = hgb(x['hg'].cuda().bfloat16().contiguous(memory_format=cl), None, None)
+    assert calls['g'] == 6, 'all six convolutions of the hourglass run in the general MFMA kernel'
+    for got, key in ((y, 'hg_out'), (pre, 'hg_pre'), (post, 'hg_post')):
+        _close_bf16(got.float().cpu().numpy(), z[key])
+
+    for cls, kw, seed, xin, key, nconv in (
+            (mods.OutdoorImVoxelNeck, dict(in_channels=64, out_channels=256), 62, 'neck', 'imvoxel_out', 9),
+            (mods.DfMNeck, dict(in_channels=64, out_channels=256, num_frames=2), 63, 'dfmneck', 'dfmneck_out', 18)):
+        m = _load(cls(**kw), seed)
+        with torch.no_grad():
+            a = m(x[xin].cuda())[0]
+        np.testing.assert_allclose(a.cpu().numpy(), z[key], **CONV_TOL)
+        calls['g'] = 0
+        mb = m.to(torch.bfloat16)
+        with torch.no_grad():
+            b = mb(x[xin].cuda().bfloat16().contiguous(memory_format=cl))[0]
+        assert calls['g'] == nconv, f'{cls.__name__}: {calls["g"]} MFMA launches, expected {nconv}'
+        _close_bf16(b.float().cpu().numpy(), z[key])
+
+
+@pytest.mark.gpu
+def test_res_module_trains_through_the_mfma_convolutions(mods):
+    """training mode (batch statistics: torch BatchNorm3d) with the convolutions and their input
+    gradients in the MFMA kernel; gradients against the same module in fp32 NCDHW"""
+    torch.manual_seed(3)
+    ref = mods.ResModule(64).cuda().train()
+    m = mods.ResModule(64).cuda().train()
+    m.load_state_dict(ref.state_dict())
+    m = m.to(torch.bfloat16)
+    x = torch.randn(2, 64, 6, 10, 12, device='cuda')
+    xr = x.clone().requires_grad_(True)
+    xb = x.bfloat16().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    yr, yb = ref(xr), m(xb)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    yb.backward(gy.bfloat16().contiguous(memory_format=torch.channels_last_3d))
+    _close_bf16(yb.detach().float().cpu().numpy(), yr.detach().cpu().numpy())
+    _close_bf16(xb.grad.float().cpu().numpy(), xr.grad.cpu().numpy())
+    gw, gwr = m.conv0.conv.weight.grad.float().cpu().numpy(), ref.conv0.conv.weight.grad.cpu().numpy()
+    np.testing.assert_allclose(gw, gwr, rtol=0.1, atol=0.05 * float(np.abs(gwr).max()))

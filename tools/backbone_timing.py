@@ -15,6 +15,10 @@ dev = torch.device('cuda:0')
 torch.backends.cudnn.benchmark = os.environ.get('DFM_MIOPEN_FIND') == '1'
 if os.environ.get('DFM_NO_MFMA_CONV') == '1':
     importlib.import_module('depth-from-motion_amd.conv3d').MfmaConv3d.eligible = lambda self, x: False
+if os.environ.get('DFM_NO_MFMA_CONV_G') == '1':  # hourglass convolutions back to MIOpen
+    _cv = importlib.import_module('depth-from-motion_amd.conv3d')
+    _cv.MfmaConv3dG.eligible = lambda self, x: False
+    _cv.MfmaConvTranspose3d.eligible = lambda self, x: False
 outs = {}
 only = os.environ.get('DFM_ONLY', '')
 for dtype in ((torch.bfloat16,) if only == 'bf16' else (torch.float32, torch.bfloat16)):
