@@ -66,7 +66,9 @@ KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0
                      [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
 
 # secondary workloads (other rows of SURVEY.md 8a), reported with the same JSON shape
-SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd_kitti')
+SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd_kitti',
+             'backbone', 'neck', 'dfm_neck')
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 
 WORKLOADS = {
     # name: B, C, H, W, D, fsf, csf, crop, dtype
@@ -157,7 +159,45 @@ def secondary(args, pkg, dev, rank, world):
     """Other hot-path rows on their config shapes; `value` = passes/s of the op over
     one sample batch, roofline from HIP-event step time (one fused kernel per step)."""
     gen = torch.Generator().manual_seed(rank)
-    if args.workload == 'waymo':
+    flops, dtype_name = None, None
+    if args.workload in ('backbone', 'neck', 'dfm_neck'):
+        # the MFMA-bound rows (SURVEY.md 8a a2 / a8 / a9): whole-module forward, bf16 channels_last_3d,
+        # every 3x3x3 convolution in the hand-written MFMA kernels (csrc/conv3d.hip, conv3d_g.hip)
+        mods = importlib.import_module('depth-from-motion_amd.modules')
+        torch.manual_seed(0)
+        B, nbytes, dtype_name = 1, None, 'bf16'
+        cl = torch.channels_last_3d
+        if args.workload == 'backbone':
+            m = mods.DfMBackbone(in_channels=32).to(dev).to(torch.bfloat16).eval()
+            m.downsampled_depth = pkg.prepare_depth(dict(num_bins=288, depth_min=2, depth_max=59.6,
+                                                         downsample_factor=4))[0]
+            m.volume_memory_format = cl
+            meta = dict(ori_cam2img=KITTI_P2, cur2prevs=torch.from_numpy(poses(1, 2 + rank)),
+                        ori_shape=(375, 1242, 3), pad_shape=(320, 1280, 3), crop_offset=[0, 55], flip=False,
+                        scale_factor=[1.0])
+            cur = torch.randn(1, 32, 320, 1280, generator=gen).to(dev).bfloat16()
+            prev = torch.randn(1, 32, 320, 1280, generator=gen).to(dev).bfloat16()
+
+            def step():
+                with torch.no_grad():
+                    return m(cur, prev, [meta])
+            flops = 0.96e12  # SURVEY 8a a2: stereo 532 G + mono 430 G per sample
+            name, unit = 'DfMBackbone.forward config K (plane sweep + 3-D aggregation, 72x80x320, bf16 NDHWC)', 'samples/s'
+        else:
+            big = args.workload == 'dfm_neck'
+            m = (mods.DfMNeck(in_channels=64, out_channels=256, num_frames=2) if big else
+                 mods.OutdoorImVoxelNeck(in_channels=64, out_channels=256)).to(dev).to(torch.bfloat16).eval()
+            x = torch.randn(1, 128 if big else 64, 220, 300, 12, generator=gen).to(dev).bfloat16() \
+                .contiguous(memory_format=cl)
+
+            def step():
+                with torch.no_grad():
+                    return m(x)
+            flops = 7.65e12 if big else 3.21e12  # SURVEY 8a a9 / a8
+            name = ('DfMNeck' if big else 'OutdoorImVoxelNeck') + \
+                '.forward config W (220x300x12 voxels, eval: BN folded into the MFMA conv epilogue, bf16 NDHWC)'
+            unit = 'voxel-volumes/s'
+    elif args.workload == 'waymo':
         # config W: 5 views x 2 frames, 64 ch, 208x312 level-0 maps, 220x300x12 voxels, concat
         from tests.golden.make_golden import waymo_like_cameras
         B, nv, nf, C, hf, wf, nvox = 2, 5, 2, 64, 208, 312, (220, 300, 12)
@@ -250,20 +290,28 @@ def secondary(args, pkg, dev, rank, world):
     elapsed = time.perf_counter() - t0
     ms = elapsed * 1e3 / args.steps
     dev_ms = e0.elapsed_time(e1) / args.steps
-    achieved = nbytes / (dev_ms * 1e-3) / 1e9
+    if flops is not None:
+        tf = flops / (dev_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(tf / MFMA_PEAK_TFLOPS, 4), 'traffic': None, 'kernel_ms': round(dev_ms, 4),
+                'algorithmic_flops_per_step': flops}
+    else:
+        achieved = nbytes / (dev_ms * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
+                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4),
+                'traffic': None, 'kernel_ms': round(dev_ms, 4),
+                'algorithmic_bytes_per_launch': nbytes}
     if rank == 0:
         print(json.dumps({
             'metric': unit.replace('/s', '/sec'), 'value': round(B * world / (ms / 1e3), 2),
             'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16' if args.workload == 'sweep_bwd' else 'f32',
+            'vs_baseline': None,
+            'dtype': dtype_name or ('bf16' if args.workload == 'sweep_bwd' else 'f32'),
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {name}', 'global_batch': B * world,
                        'parallelism': f'dp{world}'},
-            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4),
-                         'traffic': None, 'kernel_ms': round(dev_ms, 4),
-                         'algorithmic_bytes_per_launch': nbytes}}), flush=True)
+            'roofline': roof}), flush=True)
 
 
 def main():

@@ -26,6 +26,7 @@
 //   * epilogue in registers: per-channel scale/shift (folded BatchNorm or bias), residual add, ReLU,
 //     8-byte bf16 stores of 4 consecutive channels.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "dfm_common.h"
@@ -56,6 +57,9 @@ struct GGeom {
     GAxis d, h, w;
     int32_t cin, cout, nchunk, cout_tiles, relu, nrounds, block_px;
     int32_t resident, classes;  // resident != 0: all chunks in LDS, the workgroup loops the parity classes
+    int32_t ablate;      // perf experiments only (DFM_DEBUG_HOOKS builds, env DFM_CONV_ABLATE): bit 0 stage only
+                         // the first chunk, bit 1 load weights only for the first tap, bit 2 conflict-free
+                         // (wrong) LDS read addresses
     int32_t cin_stride;  // elements between consecutive input pixels (>= cin: a channel slice of a wider tensor)
     float r_bw, r_bhw;  // 1 / block.w, 1 / (block.h * block.w)
 };
@@ -224,13 +228,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
 #pragma unroll
                 for (int f = 0; f < PFW; ++f) {
                     const int bp = base_bp[f] + off;
-                    const uint32_t a = ldsb + (uint32_t)bp * 64u +
-                                       ((((uint32_t)(2 * ks + half)) ^ (((uint32_t)bp >> 2) & 3u)) << 4);
+                    uint32_t a = ldsb + (uint32_t)bp * 64u +
+                                 ((((uint32_t)(2 * ks + half)) ^ (((uint32_t)bp >> 2) & 3u)) << 4);
+#ifdef DFM_DEBUG_HOOKS
+                    if (g.ablate & 4) a = ldsb + ((uint32_t)(off & 15) << 10) + lane * 16;
+#endif
                     asm volatile("ds_read_b128 %0, %1" : "=v"(dst[f]) : "v"(a));
                 }
             };
             if (!g.resident) {
                 if (chunk > 0) __syncthreads();  // every wave is done reading the previous chunk's block
+#ifdef DFM_DEBUG_HOOKS
+                if (!(g.ablate & 1) || chunk == 0)
+#endif
                 stage(chunk, 0);
             }
             // weights of the first tap travel while the block lands
@@ -289,6 +299,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
                     for (int c = 0; c < CW; ++c) wc[ks][c] = wn[ks][c];
                 tap_adv();
                 tap_cur(wt, offn);
+#ifdef DFM_DEBUG_HOOKS
+                if (!(g.ablate & 2))
+#endif
                 wload(wt, wn);
                 issue(off, 1, q1);
                 G_WAIT_PFW(q0);
@@ -387,6 +400,12 @@ bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
         if (ax[i]->up) classes *= 2;
     }
     g.cin = d->cin; g.cout = d->cout; g.nchunk = d->cin / 32;
+#ifdef DFM_DEBUG_HOOKS
+    {
+        const char *ab = getenv("DFM_CONV_ABLATE");  // perf experiments only
+        g.ablate = ab ? atoi(ab) : 0;
+    }
+#endif
     g.cin_stride = d->in_channel_stride > 0 ? d->in_channel_stride : d->cin;
     const int cw = d->cout % 64 == 0 ? 2 : 1;
     g.cout_tiles = d->cout / (32 * cw);

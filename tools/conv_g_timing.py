@@ -50,9 +50,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')
     ap.add_argument('--no-miopen', action='store_true')
+    ap.add_argument('--case', default='', help='only the cases whose name contains this')
+    ap.add_argument('--iters', type=int, default=10)
     args = ap.parse_args()
     cases = (HG if args.only != 'neck' else []) + (NECK if args.only != 'hg' else [])
     for name, kind, cin, cout, size, stride, padding in cases:
+        if args.case and args.case not in name:
+            continue
         x = torch.randn(1, cin, *size, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
         if kind == 'conv':
             ref = torch.nn.Conv3d(cin, cout, 3, stride=stride, padding=padding, bias=False)
@@ -69,7 +73,7 @@ def main():
             y = cv.conv3d_g(x, pk, cout, st, pd, tr)
             vox = y.numel() // cout
             flops = 2 * 27 * cin * cout * vox / (8 if tr else 1)
-            t = timeit(lambda: cv.conv3d_g(x, pk, cout, st, pd, tr))
+            t = timeit(lambda: cv.conv3d_g(x, pk, cout, st, pd, tr), args.iters)
             line = (f'{name:30s} {str(size):16s} MFMA {t:7.3f} ms {flops / t / 1e9:7.1f} TFLOP/s '
                     f'({flops / t / 1e9 / 25:4.1f} %)  plan pfw={plan["pfw"]} tile={plan["tile"]} '
                     f'lds={plan["lds"] // 1024}K wgs={plan["workgroups"]}')
