@@ -304,20 +304,33 @@ def test_wide_modules_mfma_path_vs_reference_modules(mods, monkeypatch):
 @pytest.mark.gpu
 def test_res_module_trains_through_the_mfma_convolutions(mods):
     """training mode (batch statistics: torch BatchNorm3d) with the convolutions and their input
-    gradients in the MFMA kernel; gradients against the same module in fp32 NCDHW"""
+    gradients in the MFMA kernel, against the SAME bf16 module with torch's convolutions (MIOpen):
+    identical rounding points except inside the convolutions.  A ReLU whose input rounds to the
+    other side of zero flips a gradient entirely, so a small fraction of outliers is allowed."""
+    cv = importlib.import_module('depth-from-motion_amd.conv3d')
     torch.manual_seed(3)
-    ref = mods.ResModule(64).cuda().train()
-    m = mods.ResModule(64).cuda().train()
-    m.load_state_dict(ref.state_dict())
-    m = m.to(torch.bfloat16)
-    x = torch.randn(2, 64, 6, 10, 12, device='cuda')
-    xr = x.clone().requires_grad_(True)
-    xb = x.bfloat16().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
-    yr, yb = ref(xr), m(xb)
-    gy = torch.randn_like(yr)
-    yr.backward(gy)
-    yb.backward(gy.bfloat16().contiguous(memory_format=torch.channels_last_3d))
-    _close_bf16(yb.detach().float().cpu().numpy(), yr.detach().cpu().numpy())
-    _close_bf16(xb.grad.float().cpu().numpy(), xr.grad.cpu().numpy())
-    gw, gwr = m.conv0.conv.weight.grad.float().cpu().numpy(), ref.conv0.conv.weight.grad.cpu().numpy()
-    np.testing.assert_allclose(gw, gwr, rtol=0.1, atol=0.05 * float(np.abs(gwr).max()))
+    m = mods.ResModule(64).cuda().train().to(torch.bfloat16)
+    x = torch.randn(2, 64, 6, 10, 12, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last_3d)
+    gy = torch.randn(2, 64, 6, 10, 12, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last_3d)
+
+    def run():
+        m.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        y.backward(gy)
+        return (y.detach().float().cpu().numpy(), xi.grad.float().cpu().numpy(),
+                m.conv0.conv.weight.grad.float().cpu().numpy())
+    y, gx, gw = run()
+    elig = cv.MfmaConv3dG.eligible
+    cv.MfmaConv3dG.eligible = lambda self, t: False
+    try:
+        yr, gxr, gwr = run()
+    finally:
+        cv.MfmaConv3dG.eligible = elig
+
+    def mostly_close(got, ref, frac):
+        bad = np.abs(got - ref) > 5e-2 * np.abs(ref) + 0.03 * np.abs(ref).max()
+        assert bad.mean() <= frac, f'{bad.mean():.4f} of the elements differ'
+    mostly_close(y, yr, 0.0)
+    mostly_close(gx, gxr, 0.01)
+    mostly_close(gw, gwr, 0.01)
