@@ -13,7 +13,7 @@ ops raise.
 from . import _capi  # noqa: F401
 from . import modules, registry  # noqa: F401  (registers the module classes)
 from .plane_sweep import build_dfm_cost, plane_sweep_grid  # noqa: F401
-from .depth_head import depth_head_forward  # noqa: F401
+from .depth_head import LazyDepthDistribution, depth_head_forward, depth_head_statistics  # noqa: F401
 from .group_norm import HipGroupNorm, group_norm  # noqa: F401
 from .geometry import prepare_coordinates_3d, prepare_depth  # noqa: F401
 from .frustum_to_voxel import frustum_to_voxel_sample  # noqa: F401
@@ -26,4 +26,5 @@ from .point_sample import (mv_feature_transformation, point_sample, voxel_center
 __all__ = ['build_dfm_cost', 'plane_sweep_grid', 'point_sample', 'mv_feature_transformation',
            'voxel_centers', 'voxel_sample', 'frustum_to_voxel_sample', 'depth_head_forward', 'prepare_depth',
            'prepare_coordinates_3d', 'group_norm', 'HipGroupNorm', 'DfMStereoPath', 'MultiViewDfMMixin',
-           'MultiViewVoxelPath', 'inject_detector_attributes', 'patch_reference', 'depth_distribution_loss']
+           'MultiViewVoxelPath', 'inject_detector_attributes', 'patch_reference', 'depth_distribution_loss',
+           'depth_head_statistics', 'LazyDepthDistribution']

@@ -36,6 +36,8 @@ EXPORTS = (
     'dfm_frustum_to_voxel_workspace_bytes',
     'dfm_frustum_to_voxel_fwd',
     'dfm_depth_head_fwd',
+    'dfm_depth_head_stats_fwd',
+    'dfm_frustum_to_voxel_fused_fwd',
     'dfm_frustum_to_voxel_bwd_workspace_bytes',
     'dfm_frustum_to_voxel_bwd',
     'dfm_point_sample_mv_bwd_workspace_bytes',
@@ -224,6 +226,11 @@ def lib():
     h.dfm_frustum_to_voxel_workspace_bytes.argtypes = [ctypes.POINTER(F2vDesc)]
     h.dfm_depth_head_fwd.restype = ctypes.c_int
     h.dfm_depth_head_fwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, vp]
+    h.dfm_depth_head_stats_fwd.restype = ctypes.c_int
+    h.dfm_depth_head_stats_fwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, fp, fp, vp, vp]
+    h.dfm_frustum_to_voxel_fused_fwd.restype = ctypes.c_int
+    h.dfm_frustum_to_voxel_fused_fwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, fp, fp, i32, vp, fp, fp, vp, vp,
+                                                 ctypes.c_size_t, vp]
     h.dfm_frustum_to_voxel_bwd.restype = ctypes.c_int
     h.dfm_frustum_to_voxel_bwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, fp, fp, fp, fp, vp,
                                            ctypes.c_size_t, vp]

@@ -21,43 +21,23 @@ using namespace dfm;
 
 namespace {
 
-struct UpIdx {
-    int i0, i1;
-    float w0, w1;
-};
-
-__device__ __forceinline__ UpIdx up_index(int i, int in, int out)
-{
-    UpIdx u;
-    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f;
-    const float real = scale * (float)i;
-    int a = (int)floorf(real);
-    a = min(a, in - 1);
-    float l = real - (float)a;
-    l = fminf(fmaxf(l, 0.0f), 1.0f);
-    u.i0 = a;
-    u.i1 = min(a + 1, in - 1);
-    u.w1 = l;
-    u.w0 = 1.0f - l;
-    return u;
-}
-
-__device__ __forceinline__ float lerp_fma(float w0, float a, float w1, float b)
-{
-    return __builtin_fmaf(w0, a, w1 * b);
-}
-
 // V output pixels (consecutive along w) per lane: one V*sizeof(T)-byte store per depth.
 // The upsample is separable and ATen nests it W -> H -> D, so a lane first reduces
 // its 4 (W,H) taps of input plane i to one value col(i) and every output depth is a
 // single lerp of col(i0), col(i1); i0 advances once per `s` output depths, so each
 // pass over the column evaluates col() D times (not 4D times 2).
-template <typename T, int V>
+// STORE = false: the volumes are not written; instead the column maximum and the sum of
+// exp(logit - max) go to col_max / col_sum (fp32, (B, sH, sW)): everything the fused
+// FrustumToVoxel needs to evaluate softmax(upsample(cost)) at any lattice point on the fly
+// (dfm_frustum_to_voxel_fused_fwd) -- the three 472 MB tensors are never materialised.
+template <typename T, int V, bool STORE>
 __global__ __launch_bounds__(128) void depth_head_kernel(const T *__restrict__ in, int D, int H,
                                                          int W, int s,
                                                          const float *__restrict__ depth_samples,
                                                          T *__restrict__ vol, T *__restrict__ soft,
-                                                         T *__restrict__ pred)
+                                                         T *__restrict__ pred,
+                                                         float *__restrict__ col_max,
+                                                         float *__restrict__ col_sum)
 {
     typedef T vec_t __attribute__((ext_vector_type(V)));
     const int Do = D * s, Ho = H * s, Wo = W * s;
@@ -122,7 +102,7 @@ __global__ __launch_bounds__(128) void depth_head_kernel(const T *__restrict__ i
         vec_t st;
 #pragma unroll
         for (int j = 0; j < V; ++j) { st[j] = elem<T>::store(v[j]); mx[j] = fmaxf(mx[j], v[j]); }
-        __builtin_nontemporal_store(st, (vec_t *)(vcol + (size_t)d * plane_o));
+        if constexpr (STORE) __builtin_nontemporal_store(st, (vec_t *)(vcol + (size_t)d * plane_o));
     }
     have = -1;
     for (int d = 0; d < Do; ++d) {
@@ -131,6 +111,14 @@ __global__ __launch_bounds__(128) void depth_head_kernel(const T *__restrict__ i
         for (int j = 0; j < V; ++j) sum[j] = sum[j] + expf(v[j] - mx[j]);
     }
     have = -1;
+    if (!STORE && !pred) {  // statistics only: the expectation pass is not needed
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            col_max[(size_t)b * plane_o + pix + j] = mx[j];
+            col_sum[(size_t)b * plane_o + pix + j] = sum[j];
+        }
+        return;
+    }
     for (int d = 0; d < Do; ++d) {
         logits(d, v);
         const float ds = depth_samples[d];
@@ -140,12 +128,21 @@ __global__ __launch_bounds__(128) void depth_head_kernel(const T *__restrict__ i
             st[j] = elem<T>::store(expf(v[j] - mx[j]) / sum[j]);
             acc[j] = acc[j] + elem<T>::load(st[j]) * ds;
         }
-        __builtin_nontemporal_store(st, (vec_t *)(scol + (size_t)d * plane_o));
+        if constexpr (STORE) __builtin_nontemporal_store(st, (vec_t *)(scol + (size_t)d * plane_o));
     }
-    vec_t pr;
+    if constexpr (!STORE) {
 #pragma unroll
-    for (int j = 0; j < V; ++j) pr[j] = elem<T>::store(acc[j]);
-    *(vec_t *)(pred + (size_t)b * plane_o + pix) = pr;
+        for (int j = 0; j < V; ++j) {
+            col_max[(size_t)b * plane_o + pix + j] = mx[j];
+            col_sum[(size_t)b * plane_o + pix + j] = sum[j];
+        }
+    }
+    if (pred) {
+        vec_t pr;
+#pragma unroll
+        for (int j = 0; j < V; ++j) pr[j] = elem<T>::store(acc[j]);
+        *(vec_t *)(pred + (size_t)b * plane_o + pix) = pr;
+    }
 }
 
 }  // namespace
@@ -175,8 +172,42 @@ DFM_API int dfm_depth_head_fwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
     dim3 grid((npix / v + 127) / 128, batch);
     hipStream_t st = (hipStream_t)stream;
 #define DFM_DH_LAUNCH(T, V)                                                                       \
-    hipLaunchKernelGGL((depth_head_kernel<T, V>), grid, dim3(128), 0, st, (const T *)cost, d, h, \
-                       w, scale, depth_samples, (T *)depth_volumes, (T *)softmax, (T *)depth_preds)
+    hipLaunchKernelGGL((depth_head_kernel<T, V, true>), grid, dim3(128), 0, st, (const T *)cost, d, h, \
+                       w, scale, depth_samples, (T *)depth_volumes, (T *)softmax, (T *)depth_preds,   \
+                       (float *)nullptr, (float *)nullptr)
+    if (dtype == DFM_F32) {
+        if (vec4) DFM_DH_LAUNCH(float, 4); else DFM_DH_LAUNCH(float, 1);
+    } else {
+        if (vec4) DFM_DH_LAUNCH(bf16_t, 4); else DFM_DH_LAUNCH(bf16_t, 1);
+    }
+#undef DFM_DH_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+DFM_API int dfm_depth_head_stats_fwd(int32_t batch, int32_t d, int32_t h, int32_t w, int32_t scale,
+                                     int32_t dtype, const void *cost, const float *depth_samples,
+                                     float *col_max, float *col_sum, void *depth_preds, void *stream)
+{
+    if (batch <= 0 || d <= 0 || h <= 0 || w <= 0 || scale <= 0)
+        return set_error(DFM_ERR_INVALID_ARG, "non-positive size in dfm_depth_head_stats_fwd");
+    if (dtype != DFM_F32 && dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!cost || !depth_samples || !col_max || !col_sum)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (batch > 65535 || (long long)h * scale * w * scale >= (1ll << 31))
+        return set_error(DFM_ERR_UNSUPPORTED, "shape too large");
+    const int npix = h * scale * w * scale;
+    // one pixel per lane: there are no wide stores to feed, and 4x the waves hide the latency of the
+    // cached cost loads and of expf (a B = 1 launch with 4 pixels per lane has 1.5 waves per SIMD)
+    const bool vec4 = false;
+    dim3 grid((npix + 127) / 128, batch);
+    hipStream_t st = (hipStream_t)stream;
+#define DFM_DH_LAUNCH(T, V)                                                                            \
+    hipLaunchKernelGGL((depth_head_kernel<T, V, false>), grid, dim3(128), 0, st, (const T *)cost, d, h, \
+                       w, scale, depth_samples, (T *)nullptr, (T *)nullptr, (T *)depth_preds, col_max,  \
+                       col_sum)
     if (dtype == DFM_F32) {
         if (vec4) DFM_DH_LAUNCH(float, 4); else DFM_DH_LAUNCH(float, 1);
     } else {

@@ -85,6 +85,35 @@ __device__ __forceinline__ void unpack16(const uint4 &q, float (&f)[8])
     f[7] = __uint_as_float(q.w & 0xffff0000u);
 }
 
+// trilinear x-scale upsample with align_corners=True, ATen's index / weight arithmetic
+// (nn.Upsample in DepthHead.forward, dense_heads/depth_head.py:205; shared by the depth-head
+// kernels and the fused FrustumToVoxel, which must produce the same bits)
+struct UpIdx {
+    int i0, i1;
+    float w0, w1;
+};
+
+__device__ __forceinline__ UpIdx up_index(int i, int in, int out)
+{
+    UpIdx u;
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f;
+    const float real = scale * (float)i;
+    int a = (int)floorf(real);
+    a = min(a, in - 1);
+    float l = real - (float)a;
+    l = fminf(fmaxf(l, 0.0f), 1.0f);
+    u.i0 = a;
+    u.i1 = min(a + 1, in - 1);
+    u.w1 = l;
+    u.w0 = 1.0f - l;
+    return u;
+}
+
+__device__ __forceinline__ float lerp_fma(float w0, float a, float w1, float b)
+{
+    return __builtin_fmaf(w0, a, w1 * b);
+}
+
 // row of (v @ M^T): sum_k v[k]*M[k], k-ordered fma chain
 // (torch fp32 mm on CPU; reference call sites utils.py:208,246 and
 //  dfm_backbone.py:270)

@@ -28,7 +28,69 @@ namespace {
 struct F2vGeom {
     int32_t C, D, H, W, Ds, Hs, Ws, Cs, Hsem, Wsem, Nz, Ny, Nx;
     float pad_h, pad_w, depth_min, depth_span;
+    int32_t cd, ch, cw;  // fused depth head: size of the low-resolution cost volume (Ds = scale * cd ...)
 };
+
+// Fused DepthHead: the depth distribution the reference samples,
+//   softmax_d(Upsample_x4(cost))          dense_heads/depth_head.py:205-207
+// is evaluated at the (up to) 8 lattice corners of the voxel directly from the low-resolution
+// cost volume and the per-column softmax statistics (col_max, col_sum from
+// dfm_depth_head_stats_fwd), with the arithmetic of depth_head_kernel -- the value at a corner is
+// bit for bit what that kernel would have stored -- instead of reading a materialised
+// (B, 1, 4D, 4H, 4W) tensor (472 MB per sample at config K, written once and read once).
+struct FusedHead {
+    const void *cost;      // (B, 1, cd, ch, cw), T
+    const float *col_max;  // (B, Hs, Ws)
+    const float *col_sum;
+};
+
+template <typename T>
+__device__ __forceinline__ float fused_disp(const F2vGeom &g, const T *__restrict__ cost,
+                                            const float *__restrict__ cmax,
+                                            const float *__restrict__ csum, float gx, float gy, float gz)
+{
+    const int D = g.Ds, H = g.Hs, W = g.Ws;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    const float iz = ((gz + 1.0f) / 2.0f) * (float)(D - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
+    const bool fin = fabsf(ix) <= 1.0e9f && fabsf(iy) <= 1.0e9f && fabsf(iz) <= 1.0e9f;
+    float wgt[8];
+    wgt[0] = (x1 - ix) * (y1 - iy) * (z1 - iz);
+    wgt[1] = (ix - x0) * (y1 - iy) * (z1 - iz);
+    wgt[2] = (x1 - ix) * (iy - y0) * (z1 - iz);
+    wgt[3] = (ix - x0) * (iy - y0) * (z1 - iz);
+    wgt[4] = (x1 - ix) * (y1 - iy) * (iz - z0);
+    wgt[5] = (ix - x0) * (y1 - iy) * (iz - z0);
+    wgt[6] = (x1 - ix) * (iy - y0) * (iz - z0);
+    wgt[7] = (ix - x0) * (iy - y0) * (iz - z0);
+    float out = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float xf = (k & 1) ? x1 : x0, yf = (k & 2) ? y1 : y0, zf = (k & 4) ? z1 : z0;
+        const bool ok = fin && xf >= 0.0f && xf <= (float)(W - 1) && yf >= 0.0f && yf <= (float)(H - 1) &&
+                        zf >= 0.0f && zf <= (float)(D - 1);
+        if (!ok) continue;
+        const int xc = (int)xf, yc = (int)yf, zc = (int)zf;
+        const UpIdx uw = up_index(xc, g.cw, W), uh = up_index(yc, g.ch, H), ud = up_index(zc, g.cd, D);
+        const int r0 = uh.i0 * g.cw, r1 = uh.i1 * g.cw;
+        float col[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const T *p = cost + (size_t)(e ? ud.i1 : ud.i0) * g.ch * g.cw;
+            const float a = lerp_fma(uw.w0, elem<T>::load(p[r0 + uw.i0]), uw.w1, elem<T>::load(p[r0 + uw.i1]));
+            const float b = lerp_fma(uw.w0, elem<T>::load(p[r1 + uw.i0]), uw.w1, elem<T>::load(p[r1 + uw.i1]));
+            col[e] = lerp_fma(uh.w0, a, uh.w1, b);
+        }
+        // depth_volumes and its softmax are stored (and read back) in T by the unfused pipeline
+        const float logit = elem<T>::load(elem<T>::store(lerp_fma(ud.w0, col[0], ud.w1, col[1])));
+        const size_t pix = (size_t)yc * W + xc;
+        const float prob = elem<T>::load(elem<T>::store(expf(logit - cmax[pix]) / csum[pix]));
+        out = out + prob * wgt[k];
+    }
+    return out;
+}
 
 struct Tri {
     int o[8];     // element offsets of the 8 corners (valid only where ok bit set)
@@ -85,7 +147,7 @@ __global__ __launch_bounds__(256) void f2v_kernel(F2vGeom g, const T *__restrict
                                                   const T *__restrict__ sem,
                                                   const float *__restrict__ coords,
                                                   const float *__restrict__ cam2img,
-                                                  T *__restrict__ out)
+                                                  T *__restrict__ out, FusedHead fh)
 {
     const long long N = (long long)g.Nz * g.Ny * g.Nx;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -112,9 +174,18 @@ __global__ __launch_bounds__(256) void f2v_kernel(F2vGeom g, const T *__restrict
             o[(size_t)ch * N] = elem<T>::store(tri_sample<T>(t, sv + ch * vol) * valid);
     }
     if (g.Cs > 0) {
-        const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
-        const float disp =
-            tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws) * valid;
+        float disp;
+        if (fh.cost) {
+            // nothing to evaluate outside the frustum (the unfused product is +0 there as well)
+            disp = valid != 0.0f
+                       ? fused_disp<T>(g, (const T *)fh.cost + (size_t)b * g.cd * g.ch * g.cw,
+                                       fh.col_max + (size_t)b * g.Hs * g.Ws,
+                                       fh.col_sum + (size_t)b * g.Hs * g.Ws, gx, gy, gz) * valid
+                       : 0.0f;
+        } else {
+            const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+            disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws) * valid;
+        }
         const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
         const float v2d = valid2d ? 1.0f : 0.0f;
         const size_t plane = (size_t)g.Hsem * g.Wsem;
@@ -135,7 +206,7 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
                                                      const uint4 *__restrict__ sem_pm,
                                                      const float *__restrict__ coords,
                                                      const float *__restrict__ cam2img,
-                                                     T *__restrict__ out)
+                                                     T *__restrict__ out, FusedHead fh)
 {
     constexpr int CB = elem<T>::CB;
     constexpr int NB = 32 / CB;
@@ -189,9 +260,18 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
         }
     }
     if (g.Cs > 0) {
-        const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
-        const float disp =
-            tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws) * valid;
+        float disp;
+        if (fh.cost) {
+            // nothing to evaluate outside the frustum (the unfused product is +0 there as well)
+            disp = valid != 0.0f
+                       ? fused_disp<T>(g, (const T *)fh.cost + (size_t)b * g.cd * g.ch * g.cw,
+                                       fh.col_max + (size_t)b * g.Hs * g.Ws,
+                                       fh.col_sum + (size_t)b * g.Hs * g.Ws, gx, gy, gz) * valid
+                       : 0.0f;
+        } else {
+            const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+            disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws) * valid;
+        }
         const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
         const float v2d = valid2d ? 1.0f : 0.0f;
         const int nblk = g.Cs / CB;
@@ -251,10 +331,9 @@ DFM_API size_t dfm_frustum_to_voxel_workspace_bytes(const dfm_f2v_desc *d)
     return ((a + 255) & ~(size_t)255) + ((b + 255) & ~(size_t)255) + 256;
 }
 
-DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, const void *softmax,
-                                     const void *sem, const float *coords, const float *cam2img,
-                                     void *out, void *workspace, size_t workspace_bytes,
-                                     void *stream)
+static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *softmax, FusedHead fh,
+                        int32_t head_scale, const void *sem, const float *coords, const float *cam2img,
+                        void *out, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
     if (d->batch <= 0 || d->channels <= 0 || d->d <= 0 || d->h <= 0 || d->w <= 0 || d->nz <= 0 ||
@@ -262,7 +341,7 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, 
         return set_error(DFM_ERR_INVALID_ARG, "non-positive size in dfm_f2v_desc");
     if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
         return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
-    if (!stereo || !coords || !cam2img || !out || (d->sem_channels > 0 && (!sem || !softmax)))
+    if (!stereo || !coords || !cam2img || !out || (d->sem_channels > 0 && (!sem || (!softmax && !fh.cost))))
         return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     if ((long long)d->ds * d->hs * d->ws >= (1ll << 31) || (long long)d->d * d->h * d->w >= (1ll << 31))
         return set_error(DFM_ERR_UNSUPPORTED, "volume too large for 32-bit corner offsets");
@@ -273,6 +352,12 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, 
     g.Cs = d->sem_channels; g.Hsem = d->hsem; g.Wsem = d->wsem;
     g.Nz = d->nz; g.Ny = d->ny; g.Nx = d->nx;
     g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.depth_min = d->depth_min; g.depth_span = d->depth_span;
+    g.cd = g.ch = g.cw = 0;
+    if (fh.cost) {
+        if (head_scale <= 0 || d->ds % head_scale || d->hs % head_scale || d->ws % head_scale)
+            return set_error(DFM_ERR_INVALID_ARG, "ds, hs, ws must be multiples of the depth head's scale");
+        g.cd = d->ds / head_scale; g.ch = d->hs / head_scale; g.cw = d->ws / head_scale;
+    }
     const long long N = (long long)d->nz * d->ny * d->nx;
     dim3 grid((unsigned)((N + 255) / 256), d->batch);
     hipStream_t st = (hipStream_t)stream;
@@ -302,7 +387,7 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, 
                                    d->sem_channels, pix);
             hipLaunchKernelGGL(f2v_pm_kernel<float>, grid, dim3(256), 0, st, g,
                                (const uint4 *)stereo_pm, (const float *)softmax,
-                               (const uint4 *)sem_pm, coords, cam2img, (float *)out);
+                               (const uint4 *)sem_pm, coords, cam2img, (float *)out, fh);
         } else {
             if (!in_place)
                 hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg1, dim3(256), 0, st,
@@ -314,18 +399,38 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, 
                                    d->sem_channels, pix);
             hipLaunchKernelGGL(f2v_pm_kernel<bf16_t>, grid, dim3(256), 0, st, g,
                                (const uint4 *)stereo_pm, (const bf16_t *)softmax,
-                               (const uint4 *)sem_pm, coords, cam2img, (bf16_t *)out);
+                               (const uint4 *)sem_pm, coords, cam2img, (bf16_t *)out, fh);
         }
     } else if (d->dtype == DFM_F32)
         hipLaunchKernelGGL(f2v_kernel<float>, grid, dim3(256), 0, st, g, (const float *)stereo,
-                           (const float *)softmax, (const float *)sem, coords, cam2img, (float *)out);
+                           (const float *)softmax, (const float *)sem, coords, cam2img, (float *)out, fh);
     else
         hipLaunchKernelGGL(f2v_kernel<bf16_t>, grid, dim3(256), 0, st, g, (const bf16_t *)stereo,
                            (const bf16_t *)softmax, (const bf16_t *)sem, coords, cam2img,
-                           (bf16_t *)out);
+                           (bf16_t *)out, fh);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
+}
+
+DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *d, const void *stereo, const void *softmax,
+                                     const void *sem, const float *coords, const float *cam2img,
+                                     void *out, void *workspace, size_t workspace_bytes,
+                                     void *stream)
+{
+    return f2v_fwd_impl(d, stereo, softmax, FusedHead{nullptr, nullptr, nullptr}, 0, sem, coords, cam2img, out,
+                        workspace, workspace_bytes, stream);
+}
+
+DFM_API int dfm_frustum_to_voxel_fused_fwd(const dfm_f2v_desc *d, const void *stereo, const void *cost,
+                                           const float *col_max, const float *col_sum,
+                                           int32_t head_scale, const void *sem, const float *coords,
+                                           const float *cam2img, void *out, void *workspace,
+                                           size_t workspace_bytes, void *stream)
+{
+    if (!cost || !col_max || !col_sum) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    return f2v_fwd_impl(d, stereo, nullptr, FusedHead{cost, col_max, col_sum}, head_scale, sem, coords, cam2img,
+                        out, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -58,6 +58,53 @@ def depth_head_forward(stereo_features, depth_samples, downsample_factor=4):
     return _DepthHeadFn.apply(x, ds, s)
 
 
+class LazyDepthDistribution:
+    """softmax(Upsample_x4(cost), dim=depth) WITHOUT the tensor: the low-resolution cost and the
+    per-column softmax statistics (``depth_head_statistics``).  ``FrustumToVoxel`` /
+    ``frustum_to_voxel_sample`` accept it in place of ``stereo_feat_softmax`` and evaluate the
+    distribution at the voxels' corners on the fly -- bit-identical to sampling the materialised
+    tensor (inference; the reference detaches the distribution anyway, feature_transformation.py:136).
+    ``materialize()`` returns the (B, 1, sD, sH, sW) tensor if somebody needs it after all."""
+
+    def __init__(self, cost, col_max, col_sum, depth_samples, scale):
+        self.cost, self.col_max, self.col_sum = cost, col_max, col_sum
+        self.depth_samples, self.scale = depth_samples, scale
+        B, _, D, H, W = cost.shape
+        self.shape = (B, 1, scale * D, scale * H, scale * W)
+        self.dtype, self.device = cost.dtype, cost.device
+
+    def detach(self):
+        return self
+
+    def materialize(self):
+        return depth_head_forward(self.cost, self.depth_samples, self.scale)[1]
+
+
+def depth_head_statistics(stereo_features, depth_samples, downsample_factor=4, need_preds=True):
+    """The inference form of ``depth_head_forward``: (LazyDepthDistribution, depth_preds) from one
+    statistics pass over the low-resolution cost -- none of the three (B, 1, sD, sH, sW) tensors
+    (472 MB each per sample at config K) is written.  ``need_preds=False`` skips the expectation
+    pass (depth_preds is None): the detector's inference path does not read it."""
+    _require_gpu(stereo_features, 'stereo_features')
+    if stereo_features.dtype not in _DTYPES:
+        raise TypeError('stereo_features must be float32 or bfloat16')
+    assert stereo_features.dim() == 5 and stereo_features.shape[1] == 1
+    x = stereo_features.detach().contiguous()
+    s = int(downsample_factor)
+    ds = depth_samples.to(device=x.device, dtype=torch.float32).contiguous()
+    B, _, D, H, W = x.shape
+    assert ds.numel() == s * D
+    cmax = torch.empty((B, s * H, s * W), dtype=torch.float32, device=x.device)
+    csum = torch.empty_like(cmax)
+    pred = torch.empty((B, 1, s * H, s * W), dtype=x.dtype, device=x.device) if need_preds else None
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().dfm_depth_head_stats_fwd(B, D, H, W, s, _DTYPES[x.dtype], _ptr(x), _ptr(ds),
+                                                         _ptr(cmax), _ptr(csum),
+                                                         _ptr(pred) if need_preds else None,
+                                                         _stream_ptr(x.device)))
+    return LazyDepthDistribution(x, cmax, csum, ds, s), pred
+
+
 # ---------------------------------------------------------------------------
 # DepthHead.loss (mmdet3d/models/dense_heads/depth_head.py:75-188)
 # ---------------------------------------------------------------------------

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from . import _capi
+from .depth_head import LazyDepthDistribution
 from .plane_sweep import _DTYPES, _Workspace, _ptr, _require_gpu, _stream_ptr
 
 
@@ -63,7 +64,8 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     Args:
         stereo_feat: (B, C, D, H, W) cost-volume features
         stereo_feat_softmax: (B, 1, Ds, Hs, Ws) depth distribution (used detached,
-            like the reference, feature_transformation.py:136)
+            like the reference, feature_transformation.py:136), or a ``LazyDepthDistribution``
+            (``depth_head_statistics``): the DepthHead fused into this kernel, inference only
         img_metas: list of dicts with 'cam2img' (4x4) and 'pad_shape'
         cur_sem_feats: (B, Cs, H, W) or None (cat_img_feature=False)
         coordinates_3d: (Nz, Ny, Nx, 3) voxel centres in pseudo-LiDAR coordinates
@@ -87,11 +89,20 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     desc = _capi.F2vDesc()
     desc.batch, desc.channels, desc.d, desc.h, desc.w = B, C, D, H, W
     desc.stereo_channels_last = 1 if in_place else 0
-    sem = soft = None
+    sem = soft = lazy = None
     if cur_sem_feats is not None:
         sem = cur_sem_feats.to(stereo.dtype).contiguous()
-        soft = stereo_feat_softmax.detach().to(stereo.dtype).contiguous()
-        desc.ds, desc.hs, desc.ws = soft.shape[2:]
+        if isinstance(stereo_feat_softmax, LazyDepthDistribution):
+            lazy = stereo_feat_softmax
+            if lazy.dtype != stereo.dtype:
+                raise TypeError('the fused depth head needs cost and stereo_feat in the same dtype')
+            if torch.is_grad_enabled() and (stereo_feat.requires_grad or cur_sem_feats.requires_grad):
+                raise RuntimeError('the fused DepthHead -> FrustumToVoxel path is inference only '
+                                   '(training materialises the distribution for DepthHead.loss)')
+            desc.ds, desc.hs, desc.ws = lazy.shape[2:]
+        else:
+            soft = stereo_feat_softmax.detach().to(stereo.dtype).contiguous()
+            desc.ds, desc.hs, desc.ws = soft.shape[2:]
         desc.sem_channels, desc.hsem, desc.wsem = sem.shape[1:]
     coords = coordinates_3d.to(device=device, dtype=torch.float32).contiguous()
     desc.nz, desc.ny, desc.nx = coords.shape[:3]
@@ -104,4 +115,16 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     cam4 = torch.eye(4).repeat(B, 1, 1)
     cam4[:, :cam.shape[1], :cam.shape[2]] = cam
     cam4 = cam4.reshape(B, 16).to(device)
+    if lazy is not None:
+        lib = _capi.lib()
+        out = torch.empty((B, C + desc.sem_channels, desc.nz, desc.ny, desc.nx), dtype=stereo.dtype,
+                          device=device)
+        nbytes = lib.dfm_frustum_to_voxel_workspace_bytes(ctypes.byref(desc))
+        ws = _Workspace.get(device, nbytes)
+        with torch.cuda.device(device):
+            _capi.check(lib.dfm_frustum_to_voxel_fused_fwd(
+                ctypes.byref(desc), _ptr(stereo.detach()), _ptr(lazy.cost), _ptr(lazy.col_max),
+                _ptr(lazy.col_sum), lazy.scale, _ptr(sem.detach()), _ptr(coords), _ptr(cam4), _ptr(out),
+                _ptr(ws), nbytes, _stream_ptr(device)))
+        return out
     return _F2vFn.apply(stereo, sem, soft, coords, cam4, desc)

@@ -86,6 +86,9 @@ class DfMStereoPath(nn.Module):
         self.depth_head = registry.build_head(cfg['depth_head']) if cfg.get('depth_head') else None
         self.backbone_3d = registry.build_backbone(cfg['backbone_3d']) if cfg.get('backbone_3d') else None
         inject_detector_attributes(self, depth_cfg, voxel_cfg)
+        # inference-time DepthHead -> FrustumToVoxel fusion; set False to get
+        # the materialised upsample_costs / upsample_costs_softmax in eval mode as well
+        self.fuse_depth_head = True
 
     def forward(self, cur_feats, prev_feats, img_metas):
         cur_stereo, cur_sem = self.neck(cur_feats)
@@ -99,7 +102,13 @@ class DfMStereoPath(nn.Module):
         out = dict(mono_stereo_costs=costs, stereo_feats=stereo_feats, mono_feats=mono_feats,
                    cur_sem_feat=cur_sem)
         if self.depth_head is not None:
-            up, soft, preds = self.depth_head(costs)
+            # inference: the depth head is fused into FrustumToVoxel's sampling kernel (the
+            # distribution is never materialised; upsample_costs is None).  Training keeps the
+            # volumes: DepthHead.loss reads upsample_costs (dfm.py:348-356).
+            fuse = (self.fuse_depth_head and not torch.is_grad_enabled() and
+                    hasattr(self, 'feature_transformation') and not self.depth_head.with_convs)
+            up, preds, soft = self.depth_head(costs, lazy=True) if fuse else \
+                (lambda v, s, p: (v, p, s))(*self.depth_head(costs))
             out.update(upsample_costs=up, upsample_costs_softmax=soft, depth_preds=preds)
             if hasattr(self, 'feature_transformation'):
                 vol = self.feature_transformation(stereo_feats, soft, img_metas, cur_sem)

@@ -26,7 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .conv3d import MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose3d
-from .depth_head import depth_distribution_loss, depth_head_forward
+from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .group_norm import HipGroupNorm
 from .plane_sweep import build_dfm_cost
@@ -286,9 +286,15 @@ class DepthHead(nn.Module):
             self.conv_depth = nn.Conv3d(in_channels, 1, 3, 1, 1, bias=False)
         self.depth_samples = None  # injected by the detector (dfm.py:90)
 
-    def forward(self, stereo_features):
+    def forward(self, stereo_features, lazy=False):
+        """``lazy=True`` (extension, inference, single view): returns (None, depth_preds,
+        LazyDepthDistribution) -- the distribution is handed to FrustumToVoxel unmaterialised and
+        evaluated inside its sampling kernel (the DepthHead -> FrustumToVoxel fusion)."""
         _, _, D, H, W = stereo_features.shape
         x = stereo_features
+        if lazy and not self.with_convs and x.shape[1] == 1:
+            dist, pred = depth_head_statistics(x, self.depth_samples, self.downsample_factor)
+            return None, pred, dist
         if self.with_convs:
             x = self.conv_depth(x).view(-1, self.num_views, D, H, W)
         if x.shape[1] != 1:

@@ -326,6 +326,18 @@ DFM_API int dfm_frustum_to_voxel_fwd(const dfm_f2v_desc *desc, const void *stere
                                      const void *softmax, const void *sem, const float *coords,
                                      const float *cam2img, void *out, void *workspace,
                                      size_t workspace_bytes, void *stream);
+/* DepthHead fused into the sampling (inference): instead of the materialised
+ * stereo_feat_softmax = softmax(Upsample_x4(cost)) (dense_heads/depth_head.py:205-207) the kernel
+ * takes the low-resolution cost (B, 1, ds/scale, hs/scale, ws/scale) [desc->dtype] and the per-column
+ * softmax statistics col_max / col_sum (B, hs, ws) fp32 from dfm_depth_head_stats_fwd, and evaluates
+ * the distribution at the corners each voxel touches with the depth-head kernel's own arithmetic:
+ * out is bit-identical to dfm_depth_head_fwd followed by dfm_frustum_to_voxel_fwd, and none of the
+ * three (B, 1, ds, hs, ws) tensors exists.  desc->ds/hs/ws = the (virtual) distribution's size. */
+DFM_API int dfm_frustum_to_voxel_fused_fwd(const dfm_f2v_desc *desc, const void *stereo,
+                                           const void *cost, const float *col_max,
+                                           const float *col_sum, int32_t head_scale, const void *sem,
+                                           const float *coords, const float *cam2img, void *out,
+                                           void *workspace, size_t workspace_bytes, void *stream);
 /* Backward w.r.t. stereo_feat and cur_sem_feats (the depth distribution is
  * detached in the reference, :136).  grad_out: (B, C+Cs, nz, ny, nx) dtype;
  * grad_stereo (B,C,d,h,w) and grad_sem (B,Cs,hsem,wsem): FP32, zero-filled by
@@ -382,6 +394,14 @@ DFM_API int dfm_depth_head_fwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
                                int32_t dtype, const void *cost, const float *depth_samples,
                                void *depth_volumes, void *softmax, void *depth_preds,
                                void *stream);
+/* The statistics-only pass of the same kernel: no volume is written; col_max / col_sum
+ * (B, scale*h, scale*w) fp32 receive the maximum of each upsampled depth column and the sum of
+ * exp(logit - max) over it (what dfm_frustum_to_voxel_fused_fwd needs to evaluate the softmax at
+ * any lattice point); depth_preds (B, 1, scale*h, scale*w) as above, or NULL. */
+DFM_API int dfm_depth_head_stats_fwd(int32_t batch, int32_t d, int32_t h, int32_t w, int32_t scale,
+                                     int32_t dtype, const void *cost, const float *depth_samples,
+                                     float *col_max, float *col_sum, void *depth_preds,
+                                     void *stream);
 /* Backward: any of the three incoming gradients may be NULL; grad_cost
  * (B,1,d,h,w) is FP32, zero-filled by the caller. */
 DFM_API int dfm_depth_head_bwd(int32_t batch, int32_t d, int32_t h, int32_t w, int32_t scale,
