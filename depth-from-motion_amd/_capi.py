@@ -121,6 +121,7 @@ class MvDesc(ctypes.Structure):
         ('aggregate', ctypes.c_int32),
         ('valid_sample', ctypes.c_int32),
         ('dtype', ctypes.c_int32),
+        ('out_channels_last', ctypes.c_int32),
     ]
 
 
@@ -129,7 +130,8 @@ class F2vDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         'batch', 'channels', 'd', 'h', 'w', 'ds', 'hs', 'ws', 'sem_channels', 'hsem', 'wsem', 'nz',
         'ny', 'nx')] + [(n, ctypes.c_float) for n in ('pad_h', 'pad_w', 'depth_min', 'depth_span')
-                        ] + [('dtype', ctypes.c_int32), ('stereo_channels_last', ctypes.c_int32)]
+                        ] + [('dtype', ctypes.c_int32), ('stereo_channels_last', ctypes.c_int32),
+                           ('out_channels_last', ctypes.c_int32)]
 
 
 class VsDesc(ctypes.Structure):

@@ -85,6 +85,30 @@ __device__ __forceinline__ void unpack16(const uint4 &q, float (&f)[8])
     f[7] = __uint_as_float(q.w & 0xffff0000u);
 }
 
+// 16-byte vector of T <-> floats (4 fp32 / 8 bf16)
+template <typename T> struct vec16;
+template <> struct vec16<float> { static constexpr int N = 4; };
+template <> struct vec16<bf16_t> { static constexpr int N = 8; };
+
+template <typename T>
+__device__ __forceinline__ void load16(const T *p, float (&f)[vec16<T>::N])
+{
+    const uint4 q = *(const uint4 *)p;
+    unpack16(q, f);
+}
+
+template <typename T>
+__device__ __forceinline__ void store16(T *p, const float (&f)[vec16<T>::N])
+{
+    if constexpr (sizeof(T) == 4) {
+        *(uint4 *)p = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
+                                 __float_as_uint(f[3]));
+    } else {
+        *(uint4 *)p = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                                 pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+    }
+}
+
 // trilinear x-scale upsample with align_corners=True, ATen's index / weight arithmetic
 // (nn.Upsample in DepthHead.forward, dense_heads/depth_head.py:205; shared by the depth-head
 // kernels and the fused FrustumToVoxel, which must produce the same bits)

@@ -28,6 +28,7 @@ namespace {
 struct F2vGeom {
     int32_t C, D, H, W, Ds, Hs, Ws, Cs, Hsem, Wsem, Nz, Ny, Nx;
     float pad_h, pad_w, depth_min, depth_span;
+    int32_t out_cl;      // out stored (B, Nz, Ny, Nx, C + Cs): torch channels_last_3d
     int32_t cd, ch, cw;  // fused depth head: size of the low-resolution cost volume (Ds = scale * cd ...)
 };
 
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
     const float valid = (valid2d && gz >= -1.0f && gz <= 1.0f) ? 1.0f : 0.0f;
 
     T *o = out + (size_t)b * (g.C + g.Cs) * N + i;
+    T *ocl = out + ((size_t)b * N + i) * (g.C + g.Cs);  // channels-last: this voxel's C + Cs values
     {
         const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
         const int nblk = g.C / CB;
@@ -251,12 +253,23 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
                     }
                 }
             }
+            if (g.out_cl) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
+                for (int j = 0; j < NB; ++j)
+                    if (blk0 + j < nblk) {
+                        float r[CB];
 #pragma unroll
-                for (int e = 0; e < CB; ++e)
-                    if (blk0 + j < nblk)
-                        o[(size_t)((blk0 + j) * CB + e) * N] = elem<T>::store(acc[j][e] * valid);
+                        for (int e = 0; e < CB; ++e) r[e] = acc[j][e] * valid;
+                        store16<T>(ocl + (size_t)(blk0 + j) * CB, r);
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int e = 0; e < CB; ++e)
+                        if (blk0 + j < nblk)
+                            o[(size_t)((blk0 + j) * CB + e) * N] = elem<T>::store(acc[j][e] * valid);
+            }
         }
     }
     if (g.Cs > 0) {
@@ -296,14 +309,28 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
                     }
                 }
             }
+            if (g.out_cl) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int e = 0; e < CB; ++e)
+                for (int j = 0; j < NB; ++j)
                     if (blk0 + j < nblk) {
-                        float sval = acc[j][e] * v2d;
-                        o[(size_t)(g.C + (blk0 + j) * CB + e) * N] = elem<T>::store(sval * disp);
+                        float r[CB];
+#pragma unroll
+                        for (int e = 0; e < CB; ++e) {
+                            const float sval = acc[j][e] * v2d;
+                            r[e] = sval * disp;
+                        }
+                        store16<T>(ocl + g.C + (size_t)(blk0 + j) * CB, r);
                     }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int e = 0; e < CB; ++e)
+                        if (blk0 + j < nblk) {
+                            float sval = acc[j][e] * v2d;
+                            o[(size_t)(g.C + (blk0 + j) * CB + e) * N] = elem<T>::store(sval * disp);
+                        }
+            }
         }
     }
 }
@@ -353,6 +380,9 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
     g.Nz = d->nz; g.Ny = d->ny; g.Nx = d->nx;
     g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.depth_min = d->depth_min; g.depth_span = d->depth_span;
     g.cd = g.ch = g.cw = 0;
+    g.out_cl = d->out_channels_last ? 1 : 0;
+    if (g.out_cl && !f2v_pixel_major(d))
+        return set_error(DFM_ERR_UNSUPPORTED, "channels-last output needs channel counts of whole 16-byte blocks");
     if (fh.cost) {
         if (head_scale <= 0 || d->ds % head_scale || d->hs % head_scale || d->ws % head_scale)
             return set_error(DFM_ERR_INVALID_ARG, "ds, hs, ws must be multiples of the depth head's scale");

@@ -61,29 +61,6 @@ __device__ __forceinline__ Moments wave_merge(Moments m)
     return m;
 }
 
-template <typename T> struct vec16;
-template <> struct vec16<float> { static constexpr int N = 4; };
-template <> struct vec16<bf16_t> { static constexpr int N = 8; };
-
-template <typename T>
-__device__ __forceinline__ void load16(const T *p, float (&f)[vec16<T>::N])
-{
-    const uint4 q = *(const uint4 *)p;
-    unpack16(q, f);
-}
-
-template <typename T>
-__device__ __forceinline__ void store16(T *p, const float (&f)[vec16<T>::N])
-{
-    if constexpr (sizeof(T) == 4) {
-        *(uint4 *)p = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
-                                 __float_as_uint(f[3]));
-    } else {
-        *(uint4 *)p = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
-                                 pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
-    }
-}
-
 // block-level merge of per-thread moments -> thread 0 holds the result
 __device__ __forceinline__ Moments block_merge(Moments m, Moments *sh)
 {

@@ -32,6 +32,7 @@ struct MvGeom {
     long long N;
     float scale_x, scale_y, crop_x, crop_y, pad_h, pad_w;
     int32_t flip, mode, aggregate, valid_sample;
+    int32_t out_cl;  // volume stored channels-last: (nx, ny, nz, C*F') -- torch channels_last_3d
 };
 
 // projection + image transform of one point into one view; returns validity
@@ -79,8 +80,10 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
     }
     const float px = points[3 * pidx], py = points[3 * pidx + 1], pz = points[3 * pidx + 2];
     const int HW = g.Hf * g.Wf;
-    const size_t chan_stride = g.nz > 0 ? (size_t)g.N : 1;  // volume: (C, N) ; flat: (N, C)
-    T *obase = g.nz > 0 ? out + o : out + (size_t)o * g.C * (g.aggregate ? g.num_frames : 1);
+    // volume: (C, N); flat, and the channels-last volume (what the NDHWC neck convolutions read): (N, C)
+    const bool pm_out = g.nz == 0 || g.out_cl;
+    const size_t chan_stride = pm_out ? 1 : (size_t)g.N;
+    T *obase = pm_out ? out + (size_t)o * g.C * (g.aggregate ? g.num_frames : 1) : out + o;
 
     for (int blk0 = 0; blk0 < g.nblk; blk0 += NB) {
         float tot[NB][CB];
@@ -149,6 +152,16 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
             if (g.aggregate) {
                 // 'concat': per-frame mean over its valid views, multiview_dfm.py:196-203
                 const float den = (float)max(cnt, 1);
+                if (g.out_cl && g.C % CB == 0) {  // 16-byte stores of CB consecutive channels
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        if (blk0 + j < g.nblk) {
+                            float r[CB];
+#pragma unroll
+                            for (int k = 0; k < CB; ++k) r[k] = acc[j][k] / den;
+                            store16<T>(obase + (size_t)f * g.C + (size_t)(blk0 + j) * CB, r);
+                        }
+                } else {
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -157,6 +170,7 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
                         if (c < g.C)
                             obase[(size_t)(f * g.C + c) * chan_stride] = elem<T>::store(acc[j][k] / den);
                     }
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
@@ -168,6 +182,16 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
         if (!g.aggregate) {
             // 'mean': sum over frames / clamp(total valid, 1), multiview_dfm.py:188-195
             const float den = (float)max(tot_cnt, 1);
+            if (g.out_cl && g.C % CB == 0) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (blk0 + j < g.nblk) {
+                        float r[CB];
+#pragma unroll
+                        for (int k = 0; k < CB; ++k) r[k] = tot[j][k] / den;
+                        store16<T>(obase + (size_t)(blk0 + j) * CB, r);
+                    }
+            } else {
 #pragma unroll
             for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -175,6 +199,7 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
                     const int c = (blk0 + j) * CB + k;
                     if (c < g.C) obase[(size_t)c * chan_stride] = elem<T>::store(tot[j][k] / den);
                 }
+            }
         }
         if (valid_out && blk0 == 0) valid_out[o] = nvalid > 0;
     }
@@ -223,6 +248,7 @@ DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *d, const void *feats, con
     g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.flip = d->flip; g.mode = d->mode;
     g.aggregate = d->aggregate;
     g.valid_sample = d->valid_sample;
+    g.out_cl = d->out_channels_last && d->nz > 0 ? 1 : 0;
     if (!d->valid_sample && (d->num_views != 1 || d->num_frames != 1))
         return fail_ps(DFM_ERR_UNSUPPORTED, "valid_sample=0 is only supported for a single view");
     hipStream_t st = (hipStream_t)stream;
@@ -464,6 +490,7 @@ extern "C" DFM_API int dfm_point_sample_mv_bwd(const dfm_mv_desc *d, const void 
     g.scale_x = d->scale_x; g.scale_y = d->scale_y; g.crop_x = d->crop_x; g.crop_y = d->crop_y;
     g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.flip = d->flip; g.mode = d->mode;
     g.aggregate = d->aggregate; g.valid_sample = d->valid_sample;
+    g.out_cl = 0;  // the backward reads an (C, N) gradient volume
     hipStream_t st = (hipStream_t)stream;
     const int nvf = d->num_views * d->num_frames;
     const int c_out = d->channels * (d->aggregate ? d->num_frames : 1);

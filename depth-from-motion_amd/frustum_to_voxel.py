@@ -18,8 +18,7 @@ class _F2vFn(torch.autograd.Function):
     def forward(ctx, stereo, sem, soft, coords, cam4, desc):
         lib = _capi.lib()
         device = stereo.device
-        out = torch.empty((desc.batch, desc.channels + desc.sem_channels, desc.nz, desc.ny, desc.nx),
-                          dtype=stereo.dtype, device=device)
+        out = _alloc_out(desc, stereo)
         nbytes = lib.dfm_frustum_to_voxel_workspace_bytes(ctypes.byref(desc))
         ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
@@ -58,8 +57,16 @@ class _F2vFn(torch.autograd.Function):
         return g_st.to(dtype), (g_sem.to(dtype) if g_sem is not None else None), None, None, None, None
 
 
+def _alloc_out(desc, stereo):
+    ctot = desc.channels + desc.sem_channels
+    if desc.out_channels_last:  # (B, Nz, Ny, Nx, C) in memory = channels_last_3d
+        return torch.empty((desc.batch, desc.nz, desc.ny, desc.nx, ctot), dtype=stereo.dtype,
+                           device=stereo.device).permute(0, 4, 1, 2, 3)
+    return torch.empty((desc.batch, ctot, desc.nz, desc.ny, desc.nx), dtype=stereo.dtype, device=stereo.device)
+
+
 def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem_feats,
-                            coordinates_3d, depth_cfg):
+                            coordinates_3d, depth_cfg, memory_format=None):
     """
     Args:
         stereo_feat: (B, C, D, H, W) cost-volume features
@@ -70,6 +77,8 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
         cur_sem_feats: (B, Cs, H, W) or None (cat_img_feature=False)
         coordinates_3d: (Nz, Ny, Nx, 3) voxel centres in pseudo-LiDAR coordinates
         depth_cfg: dict with 'depth_min', 'depth_max'
+        memory_format: layout of the result; default: channels_last_3d when stereo_feat is (the
+            NDHWC stack: voxel_convs' MFMA convolution reads it in place), else contiguous
     Returns:
         (B, C + Cs, Nz, Ny, Nx), same dtype as stereo_feat
     """
@@ -89,6 +98,10 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     desc = _capi.F2vDesc()
     desc.batch, desc.channels, desc.d, desc.h, desc.w = B, C, D, H, W
     desc.stereo_channels_last = 1 if in_place else 0
+    if memory_format is None:
+        memory_format = torch.channels_last_3d if in_place else torch.contiguous_format
+    desc.out_channels_last = 1 if (memory_format == torch.channels_last_3d and C % vec == 0 and
+                                   cs % vec == 0) else 0
     sem = soft = lazy = None
     if cur_sem_feats is not None:
         sem = cur_sem_feats.to(stereo.dtype).contiguous()
@@ -117,8 +130,7 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     cam4 = cam4.reshape(B, 16).to(device)
     if lazy is not None:
         lib = _capi.lib()
-        out = torch.empty((B, C + desc.sem_channels, desc.nz, desc.ny, desc.nx), dtype=stereo.dtype,
-                          device=device)
+        out = _alloc_out(desc, stereo)
         nbytes = lib.dfm_frustum_to_voxel_workspace_bytes(ctypes.byref(desc))
         ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):

@@ -115,7 +115,7 @@ class DfMStereoPath(nn.Module):
                 out['volume_feat'] = vol
                 if self.backbone_3d is not None:
                     _, cv, nz, ny, nx = vol.shape
-                    out['bev_feat_prehg'], out['bev_feat'] = self.backbone_3d(vol.view(-1, cv * nz, ny, nx))
+                    out['bev_feat_prehg'], out['bev_feat'] = self.backbone_3d(vol.reshape(-1, cv * nz, ny, nx))
         return out
 
     def loss_dense_depth(self, out, depth_img, depth_fgmask_img=None):
@@ -136,10 +136,16 @@ class MultiViewDfMMixin:
     transform_depth and the usual with_* properties."""
 
     def feature_transformation(self, batch_feats, img_metas, num_views, num_frames):
+        # bf16 features: the volume is written channels-last, the layout the MFMA convolutions of
+        # neck_3d read (no conversion copy); ``volume_memory_format`` on the host class overrides
+        fmt = getattr(self, 'volume_memory_format', None)
+        if fmt is None:
+            fmt = torch.channels_last_3d if batch_feats.dtype == torch.bfloat16 else torch.contiguous_format
         volume_feat = mv_feature_transformation(batch_feats, img_metas, num_views, num_frames,
                                                 self.voxel_range, self.n_voxels,
                                                 self.temporal_aggregate,
-                                                valid_sample=getattr(self, 'valid_sample', True))
+                                                valid_sample=getattr(self, 'valid_sample', True),
+                                                memory_format=fmt)
         if getattr(self, 'with_backbone_3d', False):
             outputs = self.backbone_3d(volume_feat)
             volume_feat = outputs[0]

@@ -74,13 +74,18 @@ class _MvFn(torch.autograd.Function):
     ``descs[b]``) straight into one (B, ...) output; proj (B, F*Nv, 16), ori_w (B, F*Nv)."""
 
     @staticmethod
-    def forward(ctx, feats, points, proj, ori_w, descs, nxyz, want_valid):
+    def forward(ctx, feats, points, proj, ori_w, descs, nxyz, want_valid, channels_last=False):
         lib = _capi.lib()
         device = feats.device
         B = feats.shape[0]
         d0 = descs[0]
         c_out = d0.channels * (d0.num_frames if d0.aggregate else 1)
-        if nxyz is not None:
+        if nxyz is not None and channels_last:
+            # (B, Nx, Ny, Nz, C) in memory = (B, C, Nx, Ny, Nz) channels_last_3d
+            out = torch.empty((B,) + tuple(nxyz) + (c_out,), dtype=feats.dtype, device=device).permute(0, 4, 1, 2, 3)
+            for d in descs:
+                d.out_channels_last = 1
+        elif nxyz is not None:
             out = torch.empty((B, c_out) + tuple(nxyz), dtype=feats.dtype, device=device)
         else:
             out = torch.empty((B, points.shape[0], c_out), dtype=feats.dtype, device=device)
@@ -94,7 +99,7 @@ class _MvFn(torch.autograd.Function):
                                                 _ptr(proj[b]), _ptr(ori_w[b]), _ptr(out[b]),
                                                 _ptr(valid[b]) if want_valid else None, _ptr(ws),
                                                 nbytes, _stream_ptr(device)))
-        ctx.descs = descs
+        ctx.descs = descs  # (the backward reads a (C, N) gradient: grad_out.contiguous() below)
         ctx.meta = (feats.shape, feats.dtype)
         ctx.save_for_backward(points, proj, ori_w)
         if want_valid:
@@ -117,7 +122,7 @@ class _MvFn(torch.autograd.Function):
                     lib.dfm_point_sample_mv_bwd(ctypes.byref(ctx.descs[b]), _ptr(go[b]), _ptr(points),
                                                 _ptr(proj[b]), _ptr(ori_w[b]), _ptr(gf[b]), _ptr(ws),
                                                 nbytes, _stream_ptr(device)))
-        return gf.to(dtype), None, None, None, None, None, None
+        return gf.to(dtype), None, None, None, None, None, None, None
 
 
 def point_sample(img_meta,
@@ -156,9 +161,12 @@ def point_sample(img_meta,
 
 
 def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, voxel_range, n_voxels,
-                              temporal_aggregate='mean', points=None, valid_sample=True):
+                              temporal_aggregate='mean', points=None, valid_sample=True,
+                              memory_format=torch.contiguous_format):
     """(B, F*Nv, C, Hf, Wf) view features -> (B, C or C*F, Nx, Ny, Nz) voxel volume,
-    the tensor the reference hands to ``neck_3d`` (multiview_dfm.py:206-209)."""
+    the tensor the reference hands to ``neck_3d`` (multiview_dfm.py:206-209).
+    ``memory_format=torch.channels_last_3d`` (extension): the same tensor stored (B, Nx, Ny, Nz, C),
+    what the NDHWC / MFMA neck convolutions read -- written directly, no conversion copy."""
     _require_gpu(batch_feats, 'batch_feats')
     device = batch_feats.device
     if points is None:
@@ -184,7 +192,8 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
     # one upload for the whole batch's matrices
     proj = torch.from_numpy(np.stack(proj)).to(device)
     ori_w = torch.tensor(ori_w, dtype=torch.float32).to(device)
-    out, _ = _MvFn.apply(feats, points, proj, ori_w, descs, nxyz, False)
+    out, _ = _MvFn.apply(feats, points, proj, ori_w, descs, nxyz, False,
+                         memory_format == torch.channels_last_3d)
     return out
 
 

@@ -256,6 +256,9 @@ typedef struct dfm_mv_desc {
                              * 0: plain grid_sample output, single view only
                              * (point_sample(valid_flag=False))               */
     int32_t dtype;          /* dfm_dtype of feats and out                       */
+    int32_t out_channels_last; /* forward only, nz > 0: out is (nx, ny, nz, C*F') in memory, a torch
+                             * tensor (C*F', nx, ny, nz) in channels_last_3d -- the layout the
+                             * NDHWC / MFMA neck convolutions read, no conversion copy         */
 } dfm_mv_desc;
 
 DFM_API size_t dfm_point_sample_mv_workspace_bytes(const dfm_mv_desc *desc);
@@ -308,6 +311,9 @@ typedef struct dfm_f2v_desc {
     int32_t stereo_channels_last; /* 1: stereo is (B, d, h, w, C) in memory (torch
                             * channels_last_3d, what an NDHWC Conv3d stack hands over):
                             * it is sampled in place, no pixel-major copy is made   */
+    int32_t out_channels_last; /* forward only: out is (B, nz, ny, nx, C + Cs) in memory (torch
+                            * channels_last_3d), what voxel_convs' MFMA convolution reads;
+                            * needs channel counts of whole 16-byte blocks                   */
 } dfm_f2v_desc;
 
 /*

@@ -188,3 +188,21 @@ def test_fused_depth_head_is_bit_identical_to_the_materialised_pipeline(path, dt
     assert torch.equal(lazy.materialize(), soft)
     with pytest.raises(RuntimeError, match='inference only'):
         pkg.frustum_to_voxel_sample(stereo.clone().requires_grad_(True), lazy, metas, sem, coords, cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_channels_last_output_is_the_same_tensor(dtype):
+    """memory_format=channels_last_3d (the default when stereo_feat is channels-last): the layout
+    voxel_convs' MFMA convolution reads, written directly -- same values bit for bit"""
+    pkg = importlib.import_module('depth-from-motion_amd')
+    z = dict(np.load(os.path.join(util.GOLDEN, 'f2v_small.npz')))
+    rng = np.random.RandomState(3)   # channel counts of whole 16-byte blocks
+    z['stereo'] = rng.randn(1, 8, *z['stereo'].shape[2:]).astype(np.float32)
+    z['sem'] = rng.randn(1, 8, *z['sem'].shape[2:]).astype(np.float32)
+    ref = hip_run(z, dtype)
+    assert ref.is_contiguous()
+    cl = hip_run(z, dtype, stereo_format=torch.channels_last_3d)
+    assert cl.shape == ref.shape and cl.is_contiguous(memory_format=torch.channels_last_3d)
+    assert not cl.is_contiguous()
+    assert torch.equal(cl, ref)

@@ -241,6 +241,53 @@ def test_dfm_stereo_path_runs_the_training_config_end_to_end(pkg):
     assert sum(float(g.abs().sum()) > 0 for g in grads) > 0.9 * len(grads)
 
 
+@pytest.mark.gpu
+def test_dfm_stereo_path_inference_bf16_ndhwc_matches_fp32(pkg, monkeypatch):
+    """The same config path at inference in bf16 with the channels-last volume: every 3x3x3
+    convolution in the MFMA kernels, GroupNorm(+residual) fused, the depth head fused into
+    FrustumToVoxel (no upsample_costs tensor), against the fp32 / NCDHW run of the same weights."""
+    import json
+    cv = importlib.import_module('depth-from-motion_amd.conv3d')
+    with open(os.path.join(util.GOLDEN, 'configs_dfm.json')) as f:
+        model = json.load(f)['dfm_r34_1x8_kitti-3d-3class.py']['model']
+    model = dict(model)
+    model['depth_cfg'] = dict(model['depth_cfg'], num_bins=32)
+    model['depth_head'] = dict(model['depth_head'],
+                               depth_cfg=dict(model['depth_head']['depth_cfg'], num_bins=32))
+    model['voxel_cfg'] = dict(point_cloud_range=[2, -6.4, -3, 27.6, 6.4, 1], voxel_size=[0.2, 0.2, 0.2])
+    torch.manual_seed(5)
+    path = pkg.DfMStereoPath(model).cuda().eval()
+    H, W = 256, 512
+    gen = torch.Generator().manual_seed(7)
+    feats = [[torch.randn(1, c, H // s, W // s, generator=gen).cuda()
+              for c, s in ((3, 1), (64, 2), (128, 4), (128, 4), (128, 4))] for _ in range(2)]
+    K = util.KITTI_P2.copy()
+
+    def meta():
+        return dict(ori_cam2img=K, cam2img=K.tolist(), cur2prevs=util.pose(0.5, 0.02, 0.0, -0.8)[None],
+                    ori_shape=(H, W, 3), pad_shape=(H, W, 3), crop_offset=[0, 0], flip=False,
+                    scale_factor=[1.0])
+    with torch.no_grad():
+        ref = path(feats[0], feats[1], [meta()])
+    assert ref['upsample_costs'] is None and isinstance(ref['upsample_costs_softmax'], pkg.LazyDepthDistribution)
+    calls = {'g': 0, 'c32': 0}
+    real_g, real_c = cv.conv3d_g, cv.conv3d_k3_c32
+    monkeypatch.setattr(cv, 'conv3d_g', lambda *a, **k: (calls.__setitem__('g', calls['g'] + 1), real_g(*a, **k))[1])
+    monkeypatch.setattr(cv, 'conv3d_k3_c32',
+                        lambda *a, **k: (calls.__setitem__('c32', calls['c32'] + 1), real_c(*a, **k))[1])
+    pb = path.to(torch.bfloat16)
+    pb.backbone_stereo.volume_memory_format = torch.channels_last_3d
+    with torch.no_grad():
+        out = pb([t.bfloat16() for t in feats[0]], [t.bfloat16() for t in feats[1]], [meta()])
+    # 2 x 6 hourglass convolutions; dres0 (2 halves + mono), dres1 x 2, pred.0 x 2, voxel_convs (2 halves)
+    assert calls['g'] == 12 and calls['c32'] == 9, calls
+    assert out['volume_feat'].shape == (1, 32, 5, 64, 128) and out['bev_feat'].shape == (1, 64, 64, 128)
+    for key in ('mono_stereo_costs', 'volume_feat', 'bev_feat'):
+        a, b = out[key].float().cpu().numpy(), ref[key].float().cpu().numpy()
+        err = np.abs(a - b).mean() / (np.abs(b).mean() + 1e-6)
+        assert err < 0.06, f'{key}: mean relative error {err:.3f}'
+
+
 def _wide_inputs():
     gen = torch.Generator().manual_seed(60)   # tests/golden/make_golden_r02.py::wide_inputs
     return dict(hg=torch.randn(1, 32, 8, 12, 16, generator=gen),

@@ -164,3 +164,27 @@ def test_voxel_sample_backward_vs_torch_grid_sample(pkg, aligned):
     rhs = float((v2.double() * v.grad.double()).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
     assert float(v.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize('path', mv_cases(), ids=lambda p: os.path.basename(p)[:-4])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_mv_channels_last_volume_is_the_same_tensor(pkg, path, dtype):
+    """memory_format=channels_last_3d: the volume the NDHWC / MFMA neck convolutions read, written
+    directly by the lifting kernel -- same shape, same values bit for bit, different strides;
+    gradients flow through it like through the contiguous one"""
+    z = np.load(path)
+    feats = torch.from_numpy(z['feats']).cuda().to(dtype)
+    args = ([meta_from_fixture(z)], int(z['num_views']), int(z['num_frames']), z['voxel_range'],
+            z['n_voxels'], str(z['aggregate']))
+    ref = pkg.mv_feature_transformation(feats, *args)
+    f2 = feats.clone().requires_grad_(True)
+    out = pkg.mv_feature_transformation(f2, *args, memory_format=torch.channels_last_3d)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last_3d)
+    assert torch.equal(out, ref)
+    f1 = feats.clone().requires_grad_(True)
+    g = torch.randn(ref.shape, device='cuda').to(dtype)
+    pkg.mv_feature_transformation(f1, *args).backward(g)
+    out.backward(g.contiguous(memory_format=torch.channels_last_3d))
+    # fp32 atomics: the accumulation order differs from run to run
+    torch.testing.assert_close(f1.grad.float(), f2.grad.float(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-4,
+                               atol=2e-2 if dtype == torch.bfloat16 else 1e-5)
