@@ -9,7 +9,7 @@ import torch
 
 from . import _capi
 from .depth_head import LazyDepthDistribution
-from .plane_sweep import _DTYPES, _Workspace, _ptr, _require_gpu, _stream_ptr
+from .plane_sweep import _DTYPES, _Workspace, _ptr, _require_gpu, _stream_ptr, _upload
 
 
 class _F2vFn(torch.autograd.Function):
@@ -127,7 +127,7 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     cam = torch.as_tensor(np.asarray([m['cam2img'] for m in img_metas], dtype=np.float32))
     cam4 = torch.eye(4).repeat(B, 1, 1)
     cam4[:, :cam.shape[1], :cam.shape[2]] = cam
-    cam4 = cam4.reshape(B, 16).to(device)
+    cam4 = _upload(cam4.reshape(B, 16), device)
     if lazy is not None:
         lib = _capi.lib()
         out = _alloc_out(desc, stereo)

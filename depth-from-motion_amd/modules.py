@@ -33,6 +33,20 @@ from .plane_sweep import build_dfm_cost
 from .registry import register_module
 
 
+def _on_device(owner, name, device):
+    """device copy of a small tensor the detector injected on the host (depth planes, depth
+    samples): uploaded once per (tensor, device) instead of a blocking H2D copy every forward"""
+    t = getattr(owner, name)
+    if not torch.is_tensor(t) or t.device == device:
+        return t
+    key = (id(t), t._version, str(device))
+    cache = owner.__dict__.setdefault('_dev_cache', {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = cache[name] = (key, t.to(device=device, dtype=torch.float32).contiguous())
+    return hit[1]
+
+
 # --------------------------------------------------------------------------
 # conv -> norm -> act block with mmcv.cnn.ConvModule's sub-module names
 # (`conv`, `gn` / `bn`, `activate`) and bias rule (no conv bias under a norm)
@@ -116,14 +130,24 @@ class ConvModule(nn.Module):
                 not norm.training and norm.track_running_stats and not torch.is_grad_enabled() and
                 self.conv.eligible(x))
 
-    def forward_fused(self, x, residual=None, relu=None):
+    def _folded_norm(self):
+        """(scale, shift) of the eval-mode BatchNorm, cached until one of its tensors changes (eight
+        tiny kernels per block and forward otherwise: launch-bound on the 9-block necks)"""
         norm = getattr(self, self.norm_name)
-        scale = torch.rsqrt(norm.running_var.float() + norm.eps)
-        if norm.affine:
-            scale = scale * norm.weight.float()
-        shift = -norm.running_mean.float() * scale
-        if norm.affine:
-            shift = shift + norm.bias.float()
+        ts = [norm.running_mean, norm.running_var] + ([norm.weight, norm.bias] if norm.affine else [])
+        key = tuple((t._version, t.data_ptr()) for t in ts) + (norm.eps,)
+        if getattr(self, '_fold_key', None) != key:
+            scale = torch.rsqrt(norm.running_var.float() + norm.eps)
+            if norm.affine:
+                scale = scale * norm.weight.float()
+            shift = -norm.running_mean.float() * scale
+            if norm.affine:
+                shift = shift + norm.bias.float()
+            self._fold, self._fold_key = (scale.contiguous(), shift.contiguous()), key
+        return self._fold
+
+    def forward_fused(self, x, residual=None, relu=None):
+        scale, shift = self._folded_norm()
         relu = (self.activate is not None) if relu is None else relu
         return self.conv.forward_fused(x, scale, shift, residual, relu)
 
@@ -239,7 +263,8 @@ class DfMBackbone(nn.Module):
         meta0 = img_metas[0]
         # plane sweep: HIP kernel (reference: build_dfm_cost, batch semantics per sample)
         cost_raw = build_dfm_cost(
-            cur_stereo_feats, prev_stereo_feats, self.downsampled_depth, self.feat_sample_factor,
+            cur_stereo_feats, prev_stereo_feats,
+            _on_device(self, 'downsampled_depth', cur_stereo_feats.device), self.feat_sample_factor,
             self.cost_sample_factor, ori_cam2imgs, cur2prevs[:, 0], meta0['ori_shape'][:2],
             meta0.get('flip', False), meta0['crop_offset'],
             img_scale_factor=meta0.get('scale_factor', [1.0])[0],
@@ -293,7 +318,8 @@ class DepthHead(nn.Module):
         _, _, D, H, W = stereo_features.shape
         x = stereo_features
         if lazy and not self.with_convs and x.shape[1] == 1:
-            dist, pred = depth_head_statistics(x, self.depth_samples, self.downsample_factor)
+            dist, pred = depth_head_statistics(x, _on_device(self, 'depth_samples', x.device),
+                                               self.downsample_factor)
             return None, pred, dist
         if self.with_convs:
             x = self.conv_depth(x).view(-1, self.num_views, D, H, W)
@@ -305,7 +331,7 @@ class DepthHead(nn.Module):
             s = self.downsample_factor
             return (vol.view(B, V, s * D, s * H, s * W), soft.view(B, V, s * D, s * H, s * W),
                     pred.view(B, V, s * H, s * W))
-        return depth_head_forward(x, self.depth_samples, self.downsample_factor)
+        return depth_head_forward(x, _on_device(self, 'depth_samples', x.device), self.downsample_factor)
 
     def loss(self, depth_preds, depth_volumes, depth_img, depth_fgmask_img=None):
         """depth_head.py:75-188.  depth_preds [B*N,H,W], depth_volumes [B*N,D,H,W],
@@ -373,10 +399,19 @@ class FrustumToVoxel(nn.Module):
     def init_weights(self):
         pass
 
+    def _coords_on(self, device):
+        # the detector injects a host tensor (dfm.py:99-100) and the reference uploads it every
+        # forward (.cuda(), feature_transformation.py:82): 21 MB at config K; uploaded once here
+        c = self.coordinates_3d
+        key = (id(c), c._version, str(device))
+        if getattr(self, '_coords_key', None) != key:
+            self._coords_dev, self._coords_key = c.to(device=device, dtype=torch.float32).contiguous(), key
+        return self._coords_dev
+
     def forward(self, stereo_feat, stereo_feat_softmax, img_metas, cur_sem_feats=None):
         voxel = frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas,
                                         cur_sem_feats if self.cat_img_feature else None,
-                                        self.coordinates_3d, self.depth_cfg)
+                                        self._coords_on(stereo_feat.device), self.depth_cfg)
         return self.voxel_pool(self.voxel_convs(voxel))
 
 
@@ -453,7 +488,12 @@ class DfMNeck(nn.Module):
         assert x.shape[1] == self.in_channels[0] * self.num_frames
         mono = _to_bev(self.mono_layers(x[:, :self.in_channels[0]]))
         stereo = _to_bev(self.stereo_layers(x))
-        gate = self.aggregate_layer(torch.cat([mono, stereo], dim=1)).sigmoid()
+        # 1x1 Conv2d(2 C_out -> 1): MIOpen's kernel for this shape is a 58 ms naive convolution in
+        # bf16 (profiles/r02_c26_*); it is a weighted channel sum of the two maps
+        w = self.aggregate_layer.weight.view(2, -1, 1, 1).to(mono.dtype)
+        gate = ((mono * w[0]).sum(1, keepdim=True) + (stereo * w[1]).sum(1, keepdim=True)).sigmoid() \
+            if mono.is_cuda and mono.dtype == torch.bfloat16 else \
+            self.aggregate_layer(torch.cat([mono, stereo], dim=1)).sigmoid()
         return [gate * mono + (1 - gate) * stereo]
 
     def init_weights(self):

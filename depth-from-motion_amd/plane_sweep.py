@@ -75,9 +75,13 @@ def camera_matrices(cam2imgs, cur2prevs, batch_size, device, cam2img_inv=None):
         Pinv = as_f32(cam2img_inv)[:batch_size].cpu()
     else:
         Pinv = torch.stack([torch.inverse(P[i]) for i in range(batch_size)])
-    T = cur2prevs[:batch_size].cpu()
-    pack = torch.stack([P, Pinv, T]).reshape(3, batch_size, 16).contiguous()
-    pack = pack.to(device, non_blocking=True)
+    if cur2prevs.device.type == 'cuda':
+        # the detector moves cur2prevs to the device (dfm.py:288-293) while the intrinsics stay
+        # img_meta lists: no device -> host round trip for the poses, one pinned upload for P / Pinv
+        pack = _upload(torch.stack([P, Pinv]).reshape(2, batch_size, 16), device)
+        return pack[0], pack[1], cur2prevs[:batch_size].to(device).reshape(batch_size, 16).contiguous()
+    T = cur2prevs[:batch_size]
+    pack = _upload(torch.stack([P, Pinv, T]).reshape(3, batch_size, 16), device)
     return pack[0], pack[1], pack[2]
 
 
@@ -99,6 +103,15 @@ def _make_desc(cur_feats, num_depths, feat_sample_factor, cost_sample_factor, im
     desc.flip = 1 if flip else 0
     desc.dtype = _DTYPES[cur_feats.dtype]
     return desc
+
+
+def _upload(t, device):
+    """small host tensor -> device without blocking the host on the stream: a pageable H2D copy
+    waits for everything queued before it, which serialises the Python launch loop of the next
+    step with the GPU work of the previous one (profiles/r02_c26_*: 2x on the multi-view path)"""
+    if t.device.type != 'cpu':
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
 
 
 def _stream_ptr(device):

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .plane_sweep import _DTYPES, _Workspace, _ptr, _require_gpu, _stream_ptr
+from .plane_sweep import _DTYPES, _Workspace, _ptr, _require_gpu, _stream_ptr, _upload
 
 
 def voxel_centers(voxel_range, n_voxels):
@@ -33,6 +33,22 @@ def voxel_centers(voxel_range, n_voxels):
     x = x + (x[1] - x[0]) / 2
     zz, yy, xx = torch.meshgrid(z[:nz], y[:ny], x[:nx], indexing='ij')
     return torch.stack([xx, yy, zz], dim=-1).reshape(-1, 3).contiguous()
+
+
+_CENTERS = {}
+
+
+def _device_voxel_centers(voxel_range, n_voxels, device):
+    """voxel centres on the device, built and uploaded once per (range, grid, device): the
+    reference regenerates the anchor grid every forward (multiview_dfm.py:122-123); 9.5 MB per
+    call through a blocking H2D copy is a pipeline stall"""
+    key = (tuple(float(v) for v in voxel_range), tuple(int(v) for v in n_voxels), str(device))
+    pts = _CENTERS.get(key)
+    if pts is None:
+        if len(_CENTERS) > 16:
+            _CENTERS.clear()
+        pts = _CENTERS[key] = voxel_centers(voxel_range, n_voxels).to(device)
+    return pts
 
 
 def _scale_xy(img_scale_factor):
@@ -170,7 +186,7 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
     _require_gpu(batch_feats, 'batch_feats')
     device = batch_feats.device
     if points is None:
-        points = voxel_centers(voxel_range, n_voxels)
+        points = _device_voxel_centers(voxel_range, n_voxels, device)
     points = torch.as_tensor(points, dtype=torch.float32).to(device).contiguous()
     nxyz = tuple(int(v) for v in n_voxels)
     nvf = num_views * num_frames
@@ -190,8 +206,8 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
                                 flip, img_meta['input_shape'], False, temporal_aggregate,
                                 valid_sample))
     # one upload for the whole batch's matrices
-    proj = torch.from_numpy(np.stack(proj)).to(device)
-    ori_w = torch.tensor(ori_w, dtype=torch.float32).to(device)
+    proj = _upload(torch.from_numpy(np.stack(proj)), device)
+    ori_w = _upload(torch.tensor(ori_w, dtype=torch.float32), device)
     out, _ = _MvFn.apply(feats, points, proj, ori_w, descs, nxyz, False,
                          memory_format == torch.channels_last_3d)
     return out
