@@ -320,7 +320,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='nstar', choices=sorted(WORKLOADS) + list(SECONDARY))
-    ap.add_argument('--kernel', type=int, default=0, help='0 auto, 1 gather, 2 LDS tiles, 3 direct tiles (A/B)')
+    ap.add_argument('--kernel', type=int, default=0, help='0 auto, 1 gather, 2 LDS tiles, 3 direct tiles, 4 pixel-major taps + LDS transpose (A/B)')
     ap.add_argument('--lanes', type=int, default=0, help='LDS kernel lanes/workgroup (128|256)')
     ap.add_argument('--lds-kib', type=int, default=0, help='LDS kernel KiB/workgroup')
     ap.add_argument('--bpg', type=int, default=0, help='LDS kernel channel blocks per group')
@@ -453,7 +453,8 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
                 'global_batch': B * world,
                 'parallelism': f'dp{world}',
                 'kernel': 'sweep_cl_kernel' if args.channels_last else
-                {1: 'sweep_gather_kernel', 2: 'sweep_tile_kernel<LDS>', 3: 'sweep_tile_kernel<direct>'}.get(
+                {1: 'sweep_gather_kernel', 2: 'sweep_tile_kernel<LDS>', 3: 'sweep_tile_kernel<direct>',
+                 4: 'sweep_clt_kernel (pixel-major taps + LDS transpose)'}.get(
                     lib.dfm_plane_sweep_last_kernel(), 'none'),
                 'launch': schedule_key(tuned if tuned is not None else
                                        pkg._capi.SweepOpts(**{sweep._OPT_FIELDS[k]: v for k, v in

@@ -43,7 +43,7 @@ unsigned long long *g_trace = nullptr;  // debug builds only: see dfm_debug_set_
 // caller's dfm_sweep_opts (per call) or from the tuned-schedule cache below (per device and
 // problem shape, filled by dfm_plane_sweep_autotune, guarded by a mutex).
 struct Launch {
-    int kernel;      // 0 auto, 1 gather, 2 LDS tiles, 3 direct tiles
+    int kernel;      // 0 auto, 1 gather, 2 LDS tiles, 3 direct tiles, 4 pixel-major taps + LDS transpose
     int lanes;       // lanes per workgroup of the tile kernels
     int lds_kib;     // dynamic LDS per workgroup
     int bpg;         // channel blocks per workgroup (all by default)
@@ -1342,7 +1342,7 @@ int resolve(const dfm_sweep_desc *d, const dfm_sweep_opts *o, Launch &L)
     L.planes = o && o->planes_per_workgroup ? o->planes_per_workgroup : 2;
     L.band_chunk = o && o->bands_per_chunk ? o->bands_per_chunk : 1;
     L.ppl = o && o->points_per_lane ? o->points_per_lane : CB;
-    if (L.kernel < 0 || L.kernel > 3) return fail(DFM_ERR_INVALID_ARG, "opts: kernel must be 0..3%s");
+    if (L.kernel < 0 || L.kernel > 4) return fail(DFM_ERR_INVALID_ARG, "opts: kernel must be 0..4%s");
     if (L.lanes != 128 && L.lanes != 256 && L.lanes != 512 && L.lanes != 1024)
         return fail(DFM_ERR_INVALID_ARG, "opts: lanes_per_workgroup in {128,256,512,1024}%s");
     if (L.lds_kib < 4 || L.lds_kib > 160 || L.bpg < 1 || L.planes < 1 || L.band_chunk < 1)
@@ -1434,6 +1434,13 @@ int launch_fwd(const dfm_sweep_desc *d, const Launch &L, const void *cur, const 
 {
     const SweepGeom g = make_geom(d);
     const int HW = d->h_in * d->w_in;
+    // strided sweeps (cost_sample_factor >= 2: config K) in the reference layout: pixel-major taps
+    // + an LDS transpose (kernel 4, plane_sweep_cl.hip) instead of the direct tile kernel (3)
+    if ((L.kernel == 4 || (L.kernel == 0 && d->cost_sample_factor >= 1.5f)) && sweep_clt_supported(d, out)) {
+        const int rc4 = sweep_clt_launch(d, cur, prev, depths, P, Pinv, Tm, out, ws, (void *)st);
+        if (rc4 == DFM_OK) g_last_kernel = 4;
+        return rc4;
+    }
     uint4 *cur_blk = (uint4 *)ws;
     uint4 *prev_blk = (uint4 *)((char *)ws + blocked_bytes(d));
     dim3 pg((HW + 256 * PACK_PPL - 1) / (256 * PACK_PPL), g.nblk, 2 * d->batch);
@@ -1494,6 +1501,12 @@ int run_fwd(const dfm_sweep_desc *desc, const Launch &L, const void *cur, const 
                               workspace, st);
 }
 
+// blocked maps + spill lists (tile kernels), or the pixel-major maps of the strided-sweep kernel
+size_t fwd_workspace_bytes(const dfm_sweep_desc *desc)
+{
+    return std::max(2 * blocked_bytes(desc) + 2 * flag_bytes(desc), sweep_clt_workspace_bytes(desc));
+}
+
 int check_fwd_args(const dfm_sweep_desc *desc, const void *cur, const void *prev,
                    const float *depths, const float *cam2img, const float *cam2img_inv,
                    const float *cur2prev, void *out, void *workspace, size_t workspace_bytes)
@@ -1502,7 +1515,7 @@ int check_fwd_args(const dfm_sweep_desc *desc, const void *cur, const void *prev
     if (rc != DFM_OK) return rc;
     if (!cur || !prev || !depths || !cam2img || !cam2img_inv || !cur2prev || !out)
         return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
-    if (!workspace || workspace_bytes < 2 * blocked_bytes(desc) + 2 * flag_bytes(desc))
+    if (!workspace || workspace_bytes < fwd_workspace_bytes(desc))
         return fail(DFM_ERR_WORKSPACE, "workspace smaller than dfm_plane_sweep_workspace_bytes%s");
     if (((uintptr_t)workspace & 15) || ((uintptr_t)out & 1))
         return fail(DFM_ERR_INVALID_ARG, "workspace must be 16-byte aligned%s");
@@ -1609,7 +1622,7 @@ DFM_API int dfm_camera_prepare(const float *cam2img, int32_t rows, int32_t cols,
 DFM_API size_t dfm_plane_sweep_workspace_bytes(const dfm_sweep_desc *desc)
 {
     if (check_desc(desc) != DFM_OK) return 0;
-    return 2 * blocked_bytes(desc) + 2 * flag_bytes(desc);
+    return fwd_workspace_bytes(desc);
 }
 
 DFM_API int dfm_plane_sweep_fwd_opts(const dfm_sweep_desc *desc, const void *cur, const void *prev,

@@ -160,6 +160,100 @@ __global__ __launch_bounds__(256) void sweep_cl_kernel(
     }
 }
 
+// Same sampling (pixel-major maps, footprints once per point, coalesced 16-byte tap loads), result in
+// the REFERENCE layout (B, 2C, D, h, w): the workgroup's 256 points x CP channels are transposed
+// through an LDS tile and leave as 16-byte stores of consecutive points per channel plane (a wave
+// writes one contiguous 1 KiB run per channel).  For strided sweeps (cost_sample_factor >= 2,
+// config K) where staging whole feature rows would fetch mostly unused pixels and the direct tile
+// kernel pays a scattered 16-byte tap per channel block.
+template <typename T, int CP>
+__global__ __launch_bounds__(256) void sweep_clt_kernel(
+    SweepGeom g, ClGrid tg, const uint4 *__restrict__ ws, const float *__restrict__ depths,
+    const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
+    T *__restrict__ out)
+{
+    constexpr int CB = elem<T>::CB;
+    constexpr int BPP = CP / CB;          // 16-byte channel blocks per pass (8)
+    constexpr int VEC = 16 / sizeof(T);   // points per 16-byte store
+    constexpr int PITCH = 256 + VEC;      // elements per tile row (16-byte aligned rows)
+    constexpr int PPI = 64 / BPP;         // points per wave iteration
+    __shared__ Foot foot[256][2];
+    __shared__ __attribute__((aligned(16))) T tile[CP * PITCH];
+    const int tid = threadIdx.x;
+    int th = blockIdx.x;
+    const int b = th % tg.batch;
+    th /= tg.batch;
+    const int d = th % g.D;
+    const int tl = th / g.D;
+    const int hw = g.h_out * g.w_out;
+    const int p0 = tl * 256;
+    const int npts = min(256, hw - p0);
+    const int HW = g.h_in * g.w_in;
+
+    if (tid < npts) {
+        const int p = p0 + tid;
+        const int hi = p / g.w_out, wi = p - hi * g.w_out;
+        float cx, cy, px, py;
+        sweep_point(g, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, cx, cy, px, py,
+                    nullptr);
+        const Tap tc = make_tap(cx, cy, g.h_in, g.w_in);
+        const Tap tp = make_tap(px, py, g.h_in, g.w_in);
+        make_foot(tc, tg.cur_slot + (unsigned)b * HW * g.nblk, tg.zero_slot, g.w_in, g.nblk, foot[tid][0]);
+        make_foot(tp, tg.prev_slot + (unsigned)b * HW * g.nblk, tg.zero_slot, g.w_in, g.nblk, foot[tid][1]);
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int sub = lane & (BPP - 1), pin = lane / BPP;
+    const int qlast = npts - 1;
+    constexpr int U = 4;
+    const int npass = (g.nblk + BPP - 1) / BPP;
+    for (int map = 0; map < 2; ++map) {
+        for (int pass = 0; pass < npass; ++pass) {
+            const int blk = pass * BPP + sub;
+            if (blk < g.nblk) {
+                for (int it = 0; it < 64; it += U * PPI) {
+                    uint4 tap[U][4];
+                    float wgt[U][4];
+                    int qq[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        qq[u] = wave * 64 + it + u * PPI + pin;
+                        const Foot f = foot[min(qq[u], qlast)][map];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            tap[u][k] = ws[f.slot[k] + blk];
+                            wgt[u][k] = f.w[k];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        float r[CB];
+                        blend4<CB>(wgt[u], tap[u][0], tap[u][1], tap[u][2], tap[u][3], r);
+                        if (it + u * PPI < 64) {
+#pragma unroll
+                            for (int j = 0; j < CB; ++j) tile[(sub * CB + j) * PITCH + qq[u]] = elem<T>::store(r[j]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // flush: CP rows (channels) x 256 points, one 16-byte vector of VEC points per lane and step
+            const int crem = min(CP, g.C - pass * CP);
+            constexpr int VPR = 256 / VEC;  // vectors per row
+            for (int idx = tid; idx < crem * VPR; idx += 256) {
+                const int row = idx / VPR, v = idx - row * VPR;
+                if (v * VEC < npts) {
+                    const u32x4_t val = *(const u32x4_t *)(tile + row * PITCH + v * VEC);
+                    const size_t ch = (size_t)b * 2 * g.C + (size_t)map * g.C + pass * CP + row;
+                    __builtin_nontemporal_store(val, (u32x4_t *)(out + (ch * g.D + d) * hw + p0 + v * VEC));
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 size_t map_bytes(const dfm_sweep_desc *d)
 {
     return ((size_t)d->batch * d->channels * d->h_in * d->w_in * (d->dtype == DFM_BF16 ? 2 : 4) + 255) &
@@ -167,6 +261,76 @@ size_t map_bytes(const dfm_sweep_desc *d)
 }
 
 }  // namespace
+
+namespace dfm {
+
+// can the strided-sweep kernel above take this call? (16-byte alignment of every channel plane
+// and of every 256-point tile, whole 16-byte channel blocks, 32-bit tap slots)
+bool sweep_clt_supported(const dfm_sweep_desc *d, const void *out)
+{
+    const int CB = d->dtype == DFM_BF16 ? 8 : 4;
+    const size_t esz = d->dtype == DFM_BF16 ? 2 : 4;
+    const long long hw = (long long)d->h_out * d->w_out;
+    const size_t zero = ((size_t)d->channels * esz + 255) & ~(size_t)255;
+    return d->channels % CB == 0 && hw % CB == 0 && ((uintptr_t)out & 15) == 0 &&
+           (zero + 2 * map_bytes(d)) / 16 < (1ull << 32);
+}
+
+size_t sweep_clt_workspace_bytes(const dfm_sweep_desc *d)
+{
+    const size_t zero = ((size_t)d->channels * (d->dtype == DFM_BF16 ? 2 : 4) + 255) & ~(size_t)255;
+    return zero + 2 * map_bytes(d);
+}
+
+int sweep_clt_launch(const dfm_sweep_desc *d, const void *cur, const void *prev, const float *depths,
+                     const float *cam2img, const float *cam2img_inv, const float *cur2prev, void *out,
+                     void *workspace, void *stream)
+{
+    const SweepGeom g = sweep_make_geom(d);
+    const size_t esz = d->dtype == DFM_BF16 ? 2 : 4;
+    const size_t zero = ((size_t)d->channels * esz + 255) & ~(size_t)255;
+    const size_t mb = map_bytes(d);
+    hipStream_t st = (hipStream_t)stream;
+    char *w8 = (char *)workspace;
+    hipError_t e = hipMemsetAsync(w8, 0, zero, st);
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    const long long HW = (long long)d->h_in * d->w_in;
+    dim3 pg((unsigned)((HW + 63) / 64), (d->channels + 31) / 32, d->batch);
+    ClGrid tg;
+    tg.batch = d->batch;
+    const long long hw = (long long)g.h_out * g.w_out;
+    tg.tiles = (int)((hw + 255) / 256);
+    tg.lpi_shift = 3;
+    tg.zero_slot = 0;
+    tg.cur_slot = (unsigned)(zero / 16);
+    tg.prev_slot = (unsigned)((zero + mb) / 16);
+    const long long nb = (long long)tg.tiles * g.D * d->batch;
+    if (nb > 2147483647ll) return set_error(DFM_ERR_UNSUPPORTED, "too many lattice points");
+    if (d->dtype == DFM_F32) {
+        hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg, dim3(256), 0, st, (const float *)cur,
+                           (float *)(w8 + zero), d->channels, d->channels, HW);
+        hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg, dim3(256), 0, st, (const float *)prev,
+                           (float *)(w8 + zero + mb), d->channels, d->channels, HW);
+    } else {
+        hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t *)cur,
+                           (bf16_t *)(w8 + zero), d->channels, d->channels, HW);
+        hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t *)prev,
+                           (bf16_t *)(w8 + zero + mb), d->channels, d->channels, HW);
+    }
+    const bool timed = profile_mark(stream, false);
+    if (d->dtype == DFM_F32)
+        hipLaunchKernelGGL((sweep_clt_kernel<float, 32>), dim3((unsigned)nb), dim3(256), 0, st, g, tg,
+                           (const uint4 *)workspace, depths, cam2img, cam2img_inv, cur2prev, (float *)out);
+    else
+        hipLaunchKernelGGL((sweep_clt_kernel<bf16_t, 64>), dim3((unsigned)nb), dim3(256), 0, st, g, tg,
+                           (const uint4 *)workspace, depths, cam2img, cam2img_inv, cur2prev, (bf16_t *)out);
+    if (timed) profile_mark(stream, true);
+    e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+}  // namespace dfm
 
 extern "C" {
 

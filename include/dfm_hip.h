@@ -165,16 +165,21 @@ DFM_API int dfm_plane_sweep_grid(const dfm_sweep_desc *desc, int32_t b, const fl
 
 /* Which kernel the last dfm_plane_sweep_fwd on this thread dispatched:
  * 0 = none yet, 1 = lane-per-point gather kernel, 2 = LDS-staged tile kernel
- * (+ direct-tap pass over flagged tiles), 3 = tile kernel with direct taps.
- * Thread-local. */
+ * (+ direct-tap pass over flagged tiles), 3 = tile kernel with direct taps, 4 = pixel-major
+ * taps + LDS transpose (strided sweeps).  Thread-local. */
 DFM_API int dfm_plane_sweep_last_kernel(void);
 
 /*
  * Launch options of ONE call (the library keeps no process-wide launch state).  Every field:
  * 0 = the library's default.
- *   kernel               1/2/3 = force that kernel (2 and 3 need D*h_out*w_out to be a multiple
- *                        of 16/sizeof(T), else the call uses 1).  default = 2 for dense sweeps
- *                        (cost_sample_factor < 1.5), 3 for strided ones.  For the backward call:
+ *   kernel               1/2/3/4 = force that kernel (2 and 3 need D*h_out*w_out to be a multiple
+ *                        of 16/sizeof(T), else the call uses 1; 4 needs whole 16-byte channel
+ *                        blocks and h_out*w_out a multiple of 16/sizeof(T), else the default
+ *                        dispatch applies).  default = 2 for dense sweeps (cost_sample_factor
+ *                        < 1.5); strided ones (config K) take 4: taps from pixel-major maps
+ *                        (one contiguous run of channels per tap), the workgroup's 256 points x
+ *                        32/64 channels transposed through LDS and stored as 1 KiB runs per
+ *                        channel plane -- or 3 where 4 does not apply.  For the backward call:
  *                        1 = the lane-per-point scatter fallback.
  *   lanes_per_workgroup  128 | 256 | 512 | 1024 (tile kernels; default 256)
  *   lds_kib              dynamic LDS per workgroup, 4..160 (default 52); a tile whose feature

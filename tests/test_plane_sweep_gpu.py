@@ -35,6 +35,8 @@ def pkg():
 #   lds_respill: budget too small for most tiles -> flagged tiles take the second-chance LDS pass
 #               (144 KiB, split by channel block)
 #   direct    : tile kernel with direct taps for every tile (strided sweeps)
+#   clt       : pixel-major taps + LDS transpose to the reference layout (strided sweeps, config K);
+#               shapes it does not cover (odd channel counts / plane sizes) take the default dispatch
 #   lds256_chunk: shipped shape with 3 adjacent bands scheduled back to back
 #   lds512_v4 / lds1024_v4: 4 points per lane (bf16: 8-byte stores, 4 waves per SIMD)
 MODES = {'gather': dict(kernel=1, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
@@ -50,7 +52,8 @@ MODES = {'gather': dict(kernel=1, lanes=256, lds_kib=64, blocks_per_group=4, pla
          'lds_spill': dict(kernel=2, lanes=128, lds_kib=4, blocks_per_group=2, planes=2,
                            bands_per_chunk=2),
          'lds_respill': dict(kernel=2, lanes=256, lds_kib=16, planes=2),
-         'direct': dict(kernel=3, lanes=256, lds_kib=64, blocks_per_group=4, planes=1)}
+         'direct': dict(kernel=3, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
+         'clt': dict(kernel=4)}
 
 
 @pytest.fixture(params=sorted(MODES), autouse=True)
@@ -69,7 +72,7 @@ def run_hip(pkg, cur, prev, depths, fsf, csf, P, T, img_shape, flip, crop, scale
                              torch.from_numpy(np.asarray(T, np.float32)), img_shape, flip, crop,
                              scale)
     torch.cuda.synchronize()
-    assert pkg._capi.lib().dfm_plane_sweep_last_kernel() in (1, 2, 3)
+    assert pkg._capi.lib().dfm_plane_sweep_last_kernel() in (1, 2, 3, 4)
     return out
 
 
