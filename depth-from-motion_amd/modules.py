@@ -152,6 +152,36 @@ class ConvModule(nn.Module):
         return self.conv.forward_fused(x, scale, shift, residual, relu)
 
 
+class _WindowMean2d(nn.AvgPool2d):
+    """nn.AvgPool2d(k, stride=k) (SPP branches, spp_unet_neck.py:60-70) as a reshape + mean on the GPU:
+    torch's avg_pool2d kernel walks the 64 x 64 / 32 x 32 windows serially per output (0.44 ms per
+    branch at config K, 3.5 ms per forward of the two necks); the windows do not overlap, so the
+    pooled map is a mean over two reshaped axes (floor mode: trailing rows / columns dropped)."""
+
+    def forward(self, x):
+        kh, kw = self.kernel_size if isinstance(self.kernel_size, tuple) else (self.kernel_size,) * 2
+        st = self.stride if isinstance(self.stride, tuple) else (self.stride,) * 2
+        if not x.is_cuda or (kh, kw) != tuple(st) or self.padding not in (0, (0, 0)) or self.ceil_mode:
+            return super().forward(x)
+        B, C, H, W = x.shape
+        ho, wo = H // kh, W // kw
+        v = x[:, :, :ho * kh, :wo * kw].reshape(B, C, ho, kh, wo, kw)
+        return v.float().mean(dim=(3, 5)).to(x.dtype)
+
+
+def _depth_pool4(pool, x):
+    """AvgPool3d((4,1,1)) of FrustumToVoxel (feature_transformation.py:167).  torch's kernel makes a
+    channels_last_3d input contiguous first (a 224 MB copy at config K); on the NDHWC path the pooled
+    depth axis is a plain reshape + mean and the result stays channels-last."""
+    k = pool.kernel_size if isinstance(pool.kernel_size, tuple) else (pool.kernel_size,) * 3
+    if (x.is_cuda and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last_3d) and
+            k[1:] == (1, 1) and tuple(pool.stride) == tuple(k) and x.shape[2] % k[0] == 0):
+        B, C, D, H, W = x.shape
+        v = x.permute(0, 2, 3, 4, 1).reshape(B, D // k[0], k[0], H, W, C)
+        return v.float().mean(dim=2).to(x.dtype).permute(0, 4, 1, 2, 3)
+    return pool(x)
+
+
 def _conv3(cin, cout, norm_cfg, act=True, stride=1, padding=1):
     return ConvModule(cin, cout, 3, stride=stride, padding=padding, conv_cfg=dict(type='Conv3d'),
                       norm_cfg=norm_cfg, act_cfg=dict(type='ReLU', inplace=True) if act else None)
@@ -412,7 +442,7 @@ class FrustumToVoxel(nn.Module):
         voxel = frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas,
                                         cur_sem_feats if self.cat_img_feature else None,
                                         self._coords_on(stereo_feat.device), self.depth_cfg)
-        return self.voxel_pool(self.voxel_convs(voxel))
+        return _depth_pool4(self.voxel_pool, self.voxel_convs(voxel))
 
 
 # --------------------------------------------------------------------------
@@ -609,7 +639,7 @@ class SPPUNetNeck(nn.Module):
         self.with_upconv = with_upconv
         self.cat_img_feature = cat_img_feature
         self.spp_branches = nn.ModuleList(
-            nn.Sequential(nn.AvgPool2d(s, stride=s),
+            nn.Sequential(_WindowMean2d(s, stride=s),
                           ConvModule(in_channels[-1], spp_channel, 1, stride=1, padding=0,
                                      norm_cfg=norm_cfg))
             for s in [(64, 64), (32, 32), (16, 16), (8, 8)])
