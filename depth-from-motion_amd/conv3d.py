@@ -109,11 +109,8 @@ class _MfmaConvFn(torch.autograd.Function):
             gx = halves[0] if len(halves) == 1 else \
                 torch.cat(halves, dim=1).contiguous(memory_format=torch.channels_last_3d)
         gw = None
-        if ctx.needs_input_grad[1]:  # backward-weight: MIOpen through torch
-            _, gw, _ = torch.ops.aten.convolution_backward(
-                gy, x, weight.to(x.dtype), None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
-                [False, True, False])
-            gw = gw.to(weight.dtype)
+        if ctx.needs_input_grad[1]:  # backward-weight: chunked implicit-im2col GEMM (see above)
+            gw = conv3d_weight_grad(x, gy, 1, 1).to(weight.dtype)
         return gx, gw, None, None
 
 
@@ -150,6 +147,65 @@ class MfmaConv3d(nn.Conv3d):
         return _MfmaConvFn.apply(x, self.weight, self._packed(), True)
 
 
+# ---------------------------------------------------------------------------------------------
+# backward-weight: MIOpen's untuned bf16 NDHWC kernels for these shapes are 84 ms .. 1.26 s PER
+# CONVOLUTION (naive fallbacks; profiles/r02_c31_train_step_kernel_stats.txt: 2.1 s per training
+# step of DfMBackbone).  Until the MFMA weight-gradient kernel exists, the gradient is a chunked
+# implicit-im2col GEMM: a strided view of the padded input gives the (rows, 27 C_in) patch matrix of
+# a depth chunk, one library GEMM (hipBLASLt, fp32 accumulation over the chunk) contracts it with
+# the output gradient, chunks are summed in fp32.
+# ---------------------------------------------------------------------------------------------
+_MM_OUT_DTYPE = [None]  # does torch.mm(..., out_dtype=torch.float32) work on this build?
+
+
+def _mm_f32(a, b):
+    if _MM_OUT_DTYPE[0] is None:
+        try:
+            r = torch.mm(a, b, out_dtype=torch.float32)
+            _MM_OUT_DTYPE[0] = True
+            return r
+        except (RuntimeError, TypeError, NotImplementedError):
+            _MM_OUT_DTYPE[0] = False
+    if _MM_OUT_DTYPE[0]:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return torch.mm(a, b).float()
+
+
+def conv3d_weight_grad(x_in, g_out, stride, padding, chunk_bytes=256 << 20):
+    """out[a][b][kd][kh][kw] = sum_o g_out[:, a, o] * x_in[:, b, o * stride - padding + k]
+    for NDHWC bf16 tensors x_in (N, B, D, H, W) and g_out (N, A, Do, Ho, Wo); fp32 result (A, B, 3, 3, 3).
+    nn.Conv3d: x_in = input, g_out = grad_output -> grad_weight (C_out, C_in, 3, 3, 3);
+    nn.ConvTranspose3d (k 3, s 2, p 1, op 1): x_in = grad_output, g_out = input, stride 2, padding 1
+    -> grad_weight (C_in, C_out, 3, 3, 3)."""
+    stride, padding = _triple(stride), _triple(padding)
+    N, B = x_in.shape[:2]
+    A = g_out.shape[1]
+    Do, Ho, Wo = g_out.shape[2:]
+    xl = x_in.permute(0, 2, 3, 4, 1)   # (N, D, H, W, B): a view of the channels-last tensor
+    gl = g_out.permute(0, 2, 3, 4, 1)
+    if not xl.is_contiguous():
+        xl = xl.contiguous()
+    if not gl.is_contiguous():
+        gl = gl.contiguous()
+    # pad so that every tap of every output position is in bounds (high side: what the strides leave)
+    need = [(o - 1) * s - p + 3 for o, s, p in zip((Do, Ho, Wo), stride, padding)]
+    hi = [max(0, n - d) for n, d in zip(need, xl.shape[1:4])]
+    xp = torch.nn.functional.pad(xl, (0, 0, padding[2], hi[2], padding[1], hi[1], padding[0], hi[0]))
+    sN, sD, sH, sW, _ = xp.stride()
+    cols = xp.as_strided((N, Do, Ho, Wo, 3, 3, 3, B),
+                         (sN, sD * stride[0], sH * stride[1], sW * stride[2], sD, sH, sW, 1))
+    rows_per_plane = Ho * Wo
+    planes = max(1, int(chunk_bytes // (rows_per_plane * 27 * B * 2)))
+    acc = torch.zeros((A, 27 * B), dtype=torch.float32, device=x_in.device)
+    for n in range(N):
+        for d0 in range(0, Do, planes):
+            d1 = min(Do, d0 + planes)
+            c = cols[n, d0:d1].reshape(-1, 27 * B)            # the only materialised patch matrix
+            g = gl[n, d0:d1].reshape(-1, A)
+            acc += _mm_f32(g.t(), c)
+    return acc.view(A, 3, 3, 3, B).permute(0, 4, 1, 2, 3).contiguous()
+
+
 class _PackCache:
     """packed weight fragments of a module's parameter, rebuilt when the parameter changes"""
 
@@ -180,10 +236,21 @@ class _MfmaConvTo1Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        gx, gw, _ = torch.ops.aten.convolution_backward(
-            gy.contiguous(), x, weight.to(x.dtype), None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
-        return gx, gw.to(weight.dtype) if gw is not None else None, None
+        gx = gw = None
+        gy = gy.contiguous()
+        if ctx.needs_input_grad[0]:
+            # backward-data through the same MFMA kernel: the one gradient channel zero-padded to 32,
+            # transposed / mirrored fragments of the zero-padded weight (MIOpen's kernel for this
+            # 1 -> 32 shape is a 34 ms naive fallback)
+            N, _, D, H, W = gy.shape
+            g32 = torch.zeros((N, D, H, W, 32), dtype=gy.dtype, device=gy.device)
+            g32[..., 0] = gy[:, 0]
+            w32 = torch.zeros((32, 32, 3, 3, 3), dtype=torch.float32, device=weight.device)
+            w32[0] = weight.detach().float()[0]
+            gx = conv3d_k3_c32(g32.permute(0, 4, 1, 2, 3), pack_conv3d_weights(w32, 0, transposed=True))
+        if ctx.needs_input_grad[1]:
+            gw = conv3d_weight_grad(x, gy, 1, 1).to(weight.dtype)
+        return gx, gw, None
 
 
 class MfmaConv3dTo1(nn.Conv3d):
@@ -358,18 +425,14 @@ class _ConvGFn(torch.autograd.Function):
                         gy, x, weight.to(x.dtype), None, list(stride), list(padding), [1, 1, 1], False,
                         [0, 0, 0], 1, [True, False, False])[0]
             if ctx.needs_input_grad[1]:
-                gw = torch.ops.aten.convolution_backward(
-                    gy, x, weight.to(x.dtype), None, list(stride), list(padding), [1, 1, 1], False, [0, 0, 0], 1,
-                    [False, True, False])[1].to(weight.dtype)
+                gw = conv3d_weight_grad(x, gy, stride, padding).to(weight.dtype)
         else:
             cin, cout = weight.shape[:2]
             if ctx.needs_input_grad[0]:
                 pk = pack_conv3d_g_weights(weight, cout, cin, swap=False, flip=0)
                 gx = conv3d_g(gy, pk, cin, stride=2, padding=1)
             if ctx.needs_input_grad[1]:
-                gw = torch.ops.aten.convolution_backward(
-                    gy, x, weight.to(x.dtype), None, [2, 2, 2], [1, 1, 1], [1, 1, 1], True, [1, 1, 1], 1,
-                    [False, True, False])[1].to(weight.dtype)
+                gw = conv3d_weight_grad(gy, x, 2, 1).to(weight.dtype)
         return gx, gw, None, None, None, None
 
 
