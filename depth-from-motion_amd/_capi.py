@@ -53,6 +53,8 @@ EXPORTS = (
     'dfm_conv3d_g_pack_weights',
     'dfm_conv3d_g_fwd',
     'dfm_conv3d_g_plan',
+    'dfm_conv3d_wgrad_workspace_bytes',
+    'dfm_conv3d_wgrad',
     'dfm_depth_loss_fwd',
     'dfm_depth_loss_bwd',
     'dfm_voxel_sample_fwd',
@@ -162,6 +164,14 @@ class Conv3dDesc(ctypes.Structure):
                 ('in_channel_stride', ctypes.c_int32)]
 
 
+class Conv3dWgradDesc(ctypes.Structure):
+    """struct dfm_conv3d_wgrad_desc"""
+    _fields_ = [('n', ctypes.c_int32), ('a', ctypes.c_int32), ('b', ctypes.c_int32),
+                ('g_size', ctypes.c_int32 * 3), ('x_size', ctypes.c_int32 * 3),
+                ('stride', ctypes.c_int32 * 3), ('padding', ctypes.c_int32 * 3),
+                ('g_stride', ctypes.c_int64 * 4), ('x_stride', ctypes.c_int64 * 4)]
+
+
 DL_LINEAR, DL_HARD, DL_GAUSSIAN, DL_LAPLACIAN = 0, 1, 2, 3
 
 
@@ -264,6 +274,11 @@ def lib():
     h.dfm_conv3d_g_fwd.argtypes = [cp, vp, vp, fp, fp, vp, vp, vp]
     h.dfm_conv3d_g_plan.restype = ctypes.c_int
     h.dfm_conv3d_g_plan.argtypes = [cp, ctypes.POINTER(ctypes.c_int64)]
+    wp = ctypes.POINTER(Conv3dWgradDesc)
+    h.dfm_conv3d_wgrad_workspace_bytes.restype = sz
+    h.dfm_conv3d_wgrad_workspace_bytes.argtypes = [wp]
+    h.dfm_conv3d_wgrad.restype = ctypes.c_int
+    h.dfm_conv3d_wgrad.argtypes = [wp, vp, vp, fp, vp, sz, vp]
     lp = ctypes.POINTER(DepthLossDesc)
     h.dfm_depth_loss_fwd.restype = ctypes.c_int
     h.dfm_depth_loss_fwd.argtypes = [lp, vp, fp, fp, fp, vp, vp]

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import _capi
-from .plane_sweep import _ptr, _stream_ptr
+from .plane_sweep import _Workspace, _ptr, _stream_ptr
 
 _WDT = {torch.float32: _capi.DFM_F32, torch.bfloat16: _capi.DFM_BF16}
 
@@ -171,7 +171,48 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
-def conv3d_weight_grad(x_in, g_out, stride, padding, chunk_bytes=256 << 20):
+def _ndhwc_strides(t):
+    """(n, d, h, w) element strides of a (N, C, D, H, W) tensor whose channels are contiguous, or None"""
+    if t.dim() != 5 or t.stride(1) != 1 or t.storage_offset() % 8:
+        return None
+    st = (t.stride(0), t.stride(2), t.stride(3), t.stride(4))
+    # the stride of a singleton dimension is arbitrary: any multiple of 8 will do
+    st = tuple(s if t.shape[i] > 1 else 8 * max(1, s // 8) for s, i in zip(st, (0, 2, 3, 4)))
+    return st if all(s > 0 and s % 8 == 0 for s in st) else None
+
+
+def conv3d_weight_grad(x_in, g_out, stride, padding):
+    """Weight gradient of a 3x3x3 convolution,
+        out[a][b][kd][kh][kw] = sum_o g_out[:, a, o] * x_in[:, b, o * stride - padding + k],
+    for bf16 channels-last x_in (N, B, D, H, W) and g_out (N, A, Do, Ho, Wo); fp32 (A, B, 3, 3, 3).
+    The hand-written MFMA kernel (csrc/conv3d_wgrad.hip) when the channel counts are multiples of 32,
+    else the chunked implicit-im2col GEMM below."""
+    stride, padding = _triple(stride), _triple(padding)
+    A, B = g_out.shape[1], x_in.shape[1]
+    gs, xs = _ndhwc_strides(g_out), _ndhwc_strides(x_in)
+    if (x_in.is_cuda and x_in.dtype == torch.bfloat16 and g_out.dtype == torch.bfloat16 and A % 32 == 0 and
+            B % 32 == 0 and gs is not None and xs is not None and all(s in (1, 2) for s in stride) and
+            all(0 <= p <= 2 for p in padding)):
+        d = _capi.Conv3dWgradDesc()
+        d.n, d.a, d.b = x_in.shape[0], A, B
+        for i in range(3):
+            d.g_size[i], d.x_size[i] = g_out.shape[2 + i], x_in.shape[2 + i]
+            d.stride[i], d.padding[i] = stride[i], padding[i]
+        for i in range(4):
+            d.g_stride[i], d.x_stride[i] = gs[i], xs[i]
+        lib = _capi.lib()
+        nbytes = lib.dfm_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
+        if nbytes:
+            out = torch.empty((A, B, 3, 3, 3), dtype=torch.float32, device=x_in.device)
+            ws = _Workspace.get(x_in.device, nbytes)
+            with torch.cuda.device(x_in.device):
+                _capi.check(lib.dfm_conv3d_wgrad(ctypes.byref(d), _ptr(g_out), _ptr(x_in), _ptr(out), _ptr(ws),
+                                                 nbytes, _stream_ptr(x_in.device)))
+            return out
+    return _weight_grad_gemm(x_in, g_out, stride, padding)
+
+
+def _weight_grad_gemm(x_in, g_out, stride, padding, chunk_bytes=256 << 20):
     """out[a][b][kd][kh][kw] = sum_o g_out[:, a, o] * x_in[:, b, o * stride - padding + k]
     for NDHWC bf16 tensors x_in (N, B, D, H, W) and g_out (N, A, Do, Ho, Wo); fp32 result (A, B, 3, 3, 3).
     nn.Conv3d: x_in = input, g_out = grad_output -> grad_weight (C_out, C_in, 3, 3, 3);
@@ -236,7 +277,7 @@ class _MfmaConvTo1Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        gx = gw = None
+        gx = gw = g32 = None
         gy = gy.contiguous()
         if ctx.needs_input_grad[0]:
             # backward-data through the same MFMA kernel: the one gradient channel zero-padded to 32,
@@ -249,7 +290,12 @@ class _MfmaConvTo1Fn(torch.autograd.Function):
             w32[0] = weight.detach().float()[0]
             gx = conv3d_k3_c32(g32.permute(0, 4, 1, 2, 3), pack_conv3d_weights(w32, 0, transposed=True))
         if ctx.needs_input_grad[1]:
-            gw = conv3d_weight_grad(x, gy, 1, 1).to(weight.dtype)
+            if g32 is None:
+                N, _, D, H, W = gy.shape
+                g32 = torch.zeros((N, D, H, W, 32), dtype=gy.dtype, device=gy.device)
+                g32[..., 0] = gy[:, 0]
+            # rows 1..31 of the padded gradient are zero: row 0 is the (1, 32, 3, 3, 3) gradient
+            gw = conv3d_weight_grad(x, g32.permute(0, 4, 1, 2, 3), 1, 1)[:1].to(weight.dtype)
         return gx, gw, None
 
 

@@ -520,6 +520,31 @@ DFM_API int dfm_conv3d_g_fwd(const dfm_conv3d_desc *desc, const void *x, const v
  * wave, tile d, tile h, tile w, staged pixels, LDS bytes, workgroups}. */
 DFM_API int dfm_conv3d_g_plan(const dfm_conv3d_desc *desc, int64_t *plan8);
 
+/* Weight gradient of the same convolutions (backward-weight; MFMA, csrc/conv3d_wgrad.hip):
+ *   out[a][b][kd][kh][kw] = sum over output positions o of g[o][a] * x[o * stride - padding + k][b]
+ * g : (n, g_size, a) bf16, x : (n, x_size, b) bf16, both channels-last with explicit element strides
+ * (n, d, h, w; multiples of 8; channels contiguous -- a channel slice of a wider tensor is fine);
+ * out : (a, b, 27) fp32, overwritten.
+ *   nn.Conv3d          : g = grad_output, x = input, the convolution's stride / padding
+ *                        -> grad_weight (C_out, C_in, 3, 3, 3)
+ *   nn.ConvTranspose3d (kernel 3, stride 2, padding 1, output_padding 1): g = input, x = grad_output,
+ *                        stride 2, padding 1 -> grad_weight (C_in, C_out, 3, 3, 3)
+ * workspace: >= dfm_conv3d_wgrad_workspace_bytes(desc) (per-workgroup partial sums, summed by a second
+ * kernel: deterministic, no atomics). */
+typedef struct dfm_conv3d_wgrad_desc {
+    int32_t n;
+    int32_t a, b;           /* channels of g (rows of out) and x (columns of out), multiples of 32 */
+    int32_t g_size[3];      /* (d, h, w) of g                                                      */
+    int32_t x_size[3];      /* (d, h, w) of x                                                      */
+    int32_t stride[3];      /* 1 | 2 per axis                                                      */
+    int32_t padding[3];     /* 0..2 per axis                                                       */
+    int64_t g_stride[4];    /* element strides of g: n, d, h, w                                    */
+    int64_t x_stride[4];    /* element strides of x: n, d, h, w                                    */
+} dfm_conv3d_wgrad_desc;
+DFM_API size_t dfm_conv3d_wgrad_workspace_bytes(const dfm_conv3d_wgrad_desc *desc);
+DFM_API int dfm_conv3d_wgrad(const dfm_conv3d_wgrad_desc *desc, const void *g, const void *x, float *out,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------- */
 /* DepthHead.loss, dense_heads/depth_head.py:75-188 (called at dfm.py:348) */
 /* ---------------------------------------------------------------------- */

@@ -207,3 +207,59 @@ def test_channel_slice_of_a_wider_tensor_is_read_in_place(cv):
         np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
     m = cv.MfmaConv3dG(64, 64, 3, padding=1, bias=False).to(dev)
     assert m.eligible(xg[:, :64]) and not m.eligible(xg[:, 4:68])
+
+
+# (a = g channels, b = x channels, x size, stride, padding): both contraction axes (the kernel picks the
+# longer of H / W), ragged tiles, stride-2 rows (de-interleaved phases), padding 0 / 2
+WGRAD_CASES = [
+    (32, 32, (3, 5, 70), 1, 1),
+    (32, 32, (4, 37, 9), 1, 1),            # contracts along H
+    (64, 32, (5, 6, 40), 1, 1),
+    (32, 64, (8, 12, 40), 2, 1),           # hourglass conv1: stride-2 rows
+    (64, 64, (7, 9, 33), 2, 1),            # odd extents under stride 2
+    (64, 128, (4, 20, 12), (1, 1, 2), 1),  # neck down-sampling along z (w stays short: contracts along H)
+    (128, 64, (3, 24, 3), 1, (1, 1, 0)),   # neck last conv: Nz 3 -> 1
+    (32, 32, (3, 4, 18), 1, (2, 2, 2)),
+]
+
+
+@pytest.mark.parametrize('a,b,size,stride,padding', WGRAD_CASES)
+def test_weight_gradient_matches_torch_autograd(cv, a, b, size, stride, padding):
+    """dfm_conv3d_wgrad (MFMA) against torch's fp32 autograd of the same bf16-rounded tensors"""
+    dev = torch.device('cuda:0')
+    x = _x(2, b, size, seed=a + b + size[1])
+    w = torch.zeros(a, b, 3, 3, 3, requires_grad=True)
+    y = F.conv3d(x.float(), w, stride=stride, padding=padding)
+    gy = _x(2, a, tuple(y.shape[2:]), seed=77)
+    y.backward(gy.float())
+    got = cv.conv3d_weight_grad(_cl(x, dev), _cl(gy, dev), stride, padding)
+    assert got.dtype == torch.float32 and got.shape == w.shape
+    ref = w.grad.numpy()
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()))
+
+
+def test_weight_gradient_of_the_transposed_convolution_and_of_channel_slices(cv):
+    dev = torch.device('cuda:0')
+    x = _x(2, 64, (3, 5, 9), seed=1)
+    w = torch.zeros(64, 32, 3, 3, 3, requires_grad=True)
+    y = F.conv_transpose3d(x.float(), w, stride=2, padding=1, output_padding=1)
+    gy = _x(2, 32, tuple(y.shape[2:]), seed=2)
+    y.backward(gy.float())
+    got = cv.conv3d_weight_grad(_cl(gy, dev), _cl(x, dev), 2, 1)     # x_in = grad_output, g_out = input
+    ref = w.grad.numpy()
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()))
+    # a channel slice of a wider NDHWC tensor as the input (DfMNeck mono stack, dres0 halves)
+    xw = _x(1, 128, (4, 6, 20), seed=3)
+    w2 = torch.zeros(32, 64, 3, 3, 3, requires_grad=True)
+    y2 = F.conv3d(xw[:, 64:].float(), w2, padding=1)
+    g2 = _x(1, 32, tuple(y2.shape[2:]), seed=4)
+    y2.backward(g2.float())
+    got2 = cv.conv3d_weight_grad(_cl(xw, dev)[:, 64:], _cl(g2, dev), 1, 1)
+    ref2 = w2.grad.numpy()
+    np.testing.assert_allclose(got2.cpu().numpy(), ref2, rtol=2e-4, atol=2e-4 * float(np.abs(ref2).max()))
+    # channel counts the MFMA kernel does not take: the implicit-im2col GEMM
+    x3, g3 = _x(1, 8, (3, 4, 5), seed=5), _x(1, 4, (3, 4, 5), seed=6)
+    w3 = torch.zeros(4, 8, 3, 3, 3, requires_grad=True)
+    F.conv3d(x3.float(), w3, padding=1).backward(g3.float())
+    got3 = cv.conv3d_weight_grad(_cl(x3, dev), _cl(g3, dev), 1, 1)
+    np.testing.assert_allclose(got3.cpu().numpy(), w3.grad.numpy(), rtol=2e-2, atol=2e-2 * float(w3.grad.abs().max()))
