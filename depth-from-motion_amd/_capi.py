@@ -66,6 +66,7 @@ EXPORTS = (
     'dfm_group_norm_fwd_channels_last_res',
     'dfm_group_norm_apply_channels_last_res',
     'dfm_group_norm_bwd',
+    'dfm_group_norm_bwd_channels_last',
 )
 
 
@@ -307,6 +308,9 @@ def lib():
     h.dfm_group_norm_bwd.restype = ctypes.c_int
     h.dfm_group_norm_bwd.argtypes = [i32, i32, i64, i32, i32, i32, vp, vp, vp, fp, fp, fp, vp, fp, fp, vp, sz,
                                      vp]
+    h.dfm_group_norm_bwd_channels_last.restype = ctypes.c_int
+    h.dfm_group_norm_bwd_channels_last.argtypes = [i32, i32, i64, i32, i32, i32, vp, vp, vp, fp, fp, fp, vp, vp, fp,
+                                                   fp, vp, sz, vp]
     _lib = h
     return h
 

@@ -415,6 +415,127 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
     }
 }
 
+// ---- channels-last backward (the NDHWC stacks train without a layout round trip) ----------------
+// pass 1: per (sample, channel) partial sums of dy' and dy' * xhat over a spatial slice
+//         (dy' = dy behind the ReLU mask of y); same partial layout as gn_bwd_stats_kernel
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_stats_cl_kernel(
+    const T *__restrict__ dy, const T *__restrict__ x, const T *__restrict__ y, long long spatial, int C,
+    int groups, int splits, int relu, const float *__restrict__ mean, const float *__restrict__ rstd,
+    float *__restrict__ partial)
+{
+    constexpr int VEC = vec16<T>::N;
+    __shared__ float sh[256][2 * VEC + 1];
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int nvb = C / VEC, vpi = 256 / nvb, cpg = C / groups;
+    const int vb = threadIdx.x % nvb, v0 = threadIdx.x / nvb;
+    const long long per = (spatial + splits - 1) / splits;
+    const long long lo = min((long long)s * per, spatial), hi = min(lo + per, spatial);
+    const size_t base = (size_t)n * spatial * C + (size_t)vb * VEC;
+    float mu[VEC], rs[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const int grp = n * groups + (vb * VEC + k) / cpg;
+        mu[k] = mean[grp]; rs[k] = rstd[grp]; s1[k] = 0.0f; s2[k] = 0.0f;
+    }
+    for (long long v = lo + v0; v < hi; v += vpi) {
+        float g[VEC], xv[VEC], yv[VEC];
+        load16<T>(dy + base + (size_t)v * C, g);
+        load16<T>(x + base + (size_t)v * C, xv);
+        if (relu) load16<T>(y + base + (size_t)v * C, yv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float gk = (relu && !(yv[k] > 0.0f)) ? 0.0f : g[k];
+            s1[k] += gk;
+            s2[k] += gk * ((xv[k] - mu[k]) * rs[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { sh[threadIdx.x][2 * k] = s1[k]; sh[threadIdx.x][2 * k + 1] = s2[k]; }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        const int c = threadIdx.x, cvb = c / VEC, k = c % VEC;
+        float a = 0.0f, b = 0.0f;
+        for (int t = cvb; t < 256; t += nvb) { a += sh[t][2 * k]; b += sh[t][2 * k + 1]; }
+        float *p = partial + ((size_t)(n * C + c) * splits + s) * 2;
+        p[0] = a; p[1] = b;
+    }
+}
+
+// pass 2 (tiny): per (sample, channel) the coefficients of dx = k1 * dy' + k2 * x + k3 and the
+// parameter gradients: one workgroup per (sample, group)
+__global__ __launch_bounds__(64) void gn_bwd_coef_kernel(const float *__restrict__ partial, int C, int cpg,
+                                                        int splits, long long spatial,
+                                                        const float *__restrict__ mean,
+                                                        const float *__restrict__ rstd,
+                                                        const float *__restrict__ gamma,
+                                                        float *__restrict__ coef, float *__restrict__ dgamma,
+                                                        float *__restrict__ dbeta)
+{
+    const int groups = C / cpg;
+    const int n = blockIdx.x / groups, grp = blockIdx.x % groups;
+    __shared__ float ab[2];
+    float A = 0.0f, B = 0.0f;
+    for (int cc = grp * cpg; cc < (grp + 1) * cpg; ++cc) {
+        float a = 0.0f, b = 0.0f;
+        for (int k = threadIdx.x; k < splits; k += 64) {
+            const float *p = partial + ((size_t)(n * C + cc) * splits + k) * 2;
+            a += p[0]; b += p[1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (threadIdx.x == 0) { atomicAdd(dbeta + cc, a); atomicAdd(dgamma + cc, b); }
+        A += gamma[cc] * a; B += gamma[cc] * b;
+    }
+    if (threadIdx.x == 0) { ab[0] = A; ab[1] = B; }
+    __syncthreads();
+    const float invL = 1.0f / ((float)cpg * (float)spatial);
+    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+    const float Am = ab[0] * invL, Bm = ab[1] * invL;
+    // dx = rs * (gm * g - Am - xh * Bm), xh = (x - mu) * rs  ->  k1 g + k2 x + k3
+    for (int cc = grp * cpg + threadIdx.x; cc < (grp + 1) * cpg; cc += 64) {
+        float *o = coef + ((size_t)n * C + cc) * 3;
+        o[0] = rs * gamma[cc];
+        o[1] = -rs * rs * Bm;
+        o[2] = rs * (rs * mu * Bm - Am);
+    }
+}
+
+// pass 3: dx = k1[c] * dy' + k2[c] * x + k3[c]; optionally the masked dy' itself (the gradient of
+// a fused residual input)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_cl_kernel(
+    const T *__restrict__ dy, const T *__restrict__ x, const T *__restrict__ y, long long spatial, int C,
+    int splits, int relu, const float *__restrict__ coef, T *__restrict__ dx, T *__restrict__ dres)
+{
+    constexpr int VEC = vec16<T>::N;
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int nvb = C / VEC, vpi = 256 / nvb;
+    const int vb = threadIdx.x % nvb, v0 = threadIdx.x / nvb;
+    float k1[VEC], k2[VEC], k3[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const float *o = coef + ((size_t)n * C + vb * VEC + k) * 3;
+        k1[k] = o[0]; k2[k] = o[1]; k3[k] = o[2];
+    }
+    const long long per = (spatial + splits - 1) / splits;
+    const long long lo = min((long long)s * per, spatial), hi = min(lo + per, spatial);
+    const size_t base = (size_t)n * spatial * C + (size_t)vb * VEC;
+    for (long long v = lo + v0; v < hi; v += vpi) {
+        float g[VEC], xv[VEC], yv[VEC];
+        load16<T>(dy + base + (size_t)v * C, g);
+        load16<T>(x + base + (size_t)v * C, xv);
+        if (relu) load16<T>(y + base + (size_t)v * C, yv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            if (relu && !(yv[k] > 0.0f)) g[k] = 0.0f;
+            xv[k] = k1[k] * g[k] + k2[k] * xv[k] + k3[k];
+        }
+        store16<T>(dx + base + (size_t)v * C, xv);
+        if (dres) store16<T>(dres + base + (size_t)v * C, g);
+    }
+}
+
 // partials [n*groups][splits][3] -> merged [n*groups][3]; one wave per (sample, group)
 __global__ __launch_bounds__(64) void gn_merge_partials_kernel(const float *__restrict__ partial,
                                                                int splits, float *__restrict__ merged)
@@ -437,7 +558,8 @@ DFM_API size_t dfm_group_norm_workspace_bytes(int32_t n, int32_t c, int64_t spat
 {
     if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups) return 0;
     // forward partials (N*G*splits*3) and backward partials (N*C*splits*2), splits <= 256
-    const size_t fw = (size_t)n * groups * 257 * 3, bw = (size_t)n * c * 256 * 2;
+    // (+ n*c*4 floats: coefficients of the channels-last backward)
+    const size_t fw = (size_t)n * groups * 257 * 3, bw = (size_t)n * c * (256 * 2 + 4);
     return ((fw > bw ? fw : bw) * sizeof(float) + 255) & ~(size_t)255;
 }
 
@@ -624,6 +746,58 @@ DFM_API int dfm_group_norm_bwd(int32_t n, int32_t c, int64_t spatial, int32_t gr
                            (long long)spatial, c, cpg, splits, relu, mean, rstd, gamma, partial,
                            (bf16_t *)grad_x, grad_gamma, grad_beta);
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+DFM_API int dfm_group_norm_bwd_channels_last(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                             int32_t dtype, int32_t relu, const void *grad_y, const void *x,
+                                             const void *y, const float *mean, const float *rstd,
+                                             const float *gamma, void *grad_x, void *grad_residual,
+                                             float *grad_gamma, float *grad_beta, void *workspace,
+                                             size_t workspace_bytes, void *stream)
+{
+    if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups)
+        return set_error(DFM_ERR_INVALID_ARG, "bad sizes in dfm_group_norm_bwd_channels_last");
+    if (dtype != DFM_F32 && dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!grad_y || !x || (relu && !y) || !mean || !rstd || !gamma || !grad_x || !grad_gamma || !grad_beta ||
+        !workspace)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (workspace_bytes < dfm_group_norm_workspace_bytes(n, c, spatial, groups))
+        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_group_norm_workspace_bytes");
+    const int vec = dtype == DFM_BF16 ? 8 : 4;
+    const int nvb = c / vec;
+    if (c % vec || c > 256 || (nvb & (nvb - 1)) || n > 65535 || (long long)n * groups > 2147483647ll ||
+        ((uintptr_t)x & 15) || ((uintptr_t)grad_y & 15) || ((uintptr_t)grad_x & 15) || ((uintptr_t)y & 15) ||
+        ((uintptr_t)grad_residual & 15))
+        return set_error(DFM_ERR_UNSUPPORTED,
+                         "channels-last GroupNorm needs C = 16-byte vectors x a power of two, C <= 256");
+    const int splits = std::min(256, pick_splits_cl((long long)spatial * c));
+    const int asplits = pick_splits_cl((long long)spatial * c);
+    hipStream_t st = (hipStream_t)stream;
+    float *partial = (float *)workspace;
+    float *coef = partial + (size_t)n * c * 256 * 2;
+    dim3 grid(splits, n), agrid(asplits, n);
+    if (dtype == DFM_F32)
+        hipLaunchKernelGGL(gn_bwd_stats_cl_kernel<float>, grid, dim3(256), 0, st, (const float *)grad_y,
+                           (const float *)x, (const float *)y, (long long)spatial, c, groups, splits, relu, mean,
+                           rstd, partial);
+    else
+        hipLaunchKernelGGL(gn_bwd_stats_cl_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)grad_y,
+                           (const bf16_t *)x, (const bf16_t *)y, (long long)spatial, c, groups, splits, relu, mean,
+                           rstd, partial);
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(n * groups), dim3(64), 0, st, partial, c, c / groups, splits,
+                       (long long)spatial, mean, rstd, gamma, coef, grad_gamma, grad_beta);
+    if (dtype == DFM_F32)
+        hipLaunchKernelGGL(gn_bwd_apply_cl_kernel<float>, agrid, dim3(256), 0, st, (const float *)grad_y,
+                           (const float *)x, (const float *)y, (long long)spatial, c, asplits, relu, coef,
+                           (float *)grad_x, (float *)grad_residual);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_cl_kernel<bf16_t>, agrid, dim3(256), 0, st, (const bf16_t *)grad_y,
+                           (const bf16_t *)x, (const bf16_t *)y, (long long)spatial, c, asplits, relu, coef,
+                           (bf16_t *)grad_x, (bf16_t *)grad_residual);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;

@@ -93,22 +93,36 @@ class _GroupNormFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, y, mean, rstd, w32 = ctx.saved_tensors
         groups, relu, wdt, bdt, cl, has_res = ctx.cfg
-        # y = relu?(gn(x) + residual): the residual's gradient is the incoming one behind the ReLU mask
-        gres = None
-        if has_res and ctx.needs_input_grad[7]:
-            gres = gy * (y > 0).to(gy.dtype) if relu else gy
-        if cl:  # the backward kernels are NC(D)HW: convert (training through channels-last
-            x, y = x.contiguous(), y.contiguous()  # stacks pays two extra copies here)
         lib = _capi.lib()
         device = x.device
         n, c = x.shape[:2]
         spatial = x.numel() // (n * c)
-        gy = gy.contiguous().to(x.dtype)
-        gx = torch.empty_like(x)
+        want_res = has_res and ctx.needs_input_grad[7]
         gw = torch.zeros(c, dtype=torch.float32, device=device)
         gb = torch.zeros(c, dtype=torch.float32, device=device)
         nbytes = lib.dfm_group_norm_workspace_bytes(n, c, spatial, groups)
         ws = _Workspace.get(device, nbytes)
+        if cl:
+            # channels-last kernels: no layout round trip; the masked gradient of a fused residual
+            # input is a second output of the same pass
+            fmt = torch.channels_last_3d if x.dim() == 5 else torch.channels_last
+            gy = gy.to(x.dtype).contiguous(memory_format=fmt)
+            gx = torch.empty_like(x)
+            gres = torch.empty_like(x) if want_res and relu else None
+            with torch.cuda.device(device):
+                _capi.check(lib.dfm_group_norm_bwd_channels_last(
+                    n, c, spatial, groups, _DTYPES[x.dtype], int(relu), _ptr(gy), _ptr(x), _ptr(y), _ptr(mean),
+                    _ptr(rstd), _ptr(w32), _ptr(gx), _ptr(gres) if gres is not None else None, _ptr(gw),
+                    _ptr(gb), _ptr(ws), nbytes, _stream_ptr(device)))
+            if want_res and not relu:
+                gres = gy
+            return gx, gw.to(wdt), gb.to(bdt), None, None, None, None, gres
+        # y = relu?(gn(x) + residual): the residual's gradient is the incoming one behind the ReLU mask
+        gres = None
+        if want_res:
+            gres = gy * (y > 0).to(gy.dtype) if relu else gy
+        gy = gy.contiguous().to(x.dtype)
+        gx = torch.empty_like(x)
         with torch.cuda.device(device):
             _capi.check(
                 lib.dfm_group_norm_bwd(n, c, spatial, groups, _DTYPES[x.dtype], int(relu), _ptr(gy),

@@ -306,7 +306,14 @@ class DfMBackbone(nn.Module):
         s_cost = self.pred_stereo[0](stereo[0])
         m_cost = self.pred_mono[0](mono[0])
         both = torch.cat((s_cost, m_cost), dim=1).flatten(start_dim=1, end_dim=2)
-        gate = self.aggregate_cost(both).unsqueeze(dim=1).sigmoid()
+        if both.is_cuda:
+            # the 1x1 Conv2d(2D -> D) as a GEMM over the flattened image (hipBLASLt forward and
+            # backward): MIOpen's kernels for this shape are naive fallbacks in bf16 (1.2 ms backward-weight)
+            w2 = self.aggregate_cost.weight.flatten(1)
+            gate = torch.matmul(w2, both.flatten(2)).view(both.shape[0], -1, *both.shape[2:])
+            gate = gate.unsqueeze(dim=1).sigmoid()
+        else:
+            gate = self.aggregate_cost(both).unsqueeze(dim=1).sigmoid()
         return gate * s_cost + (1 - gate) * m_cost, stereo[0], mono[0]
 
 

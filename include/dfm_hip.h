@@ -648,6 +648,16 @@ DFM_API int dfm_group_norm_bwd(int32_t n, int32_t c, int64_t spatial, int32_t gr
                                const float *gamma, void *grad_x, float *grad_gamma,
                                float *grad_beta, void *workspace, size_t workspace_bytes,
                                void *stream);
+/* The same backward on channels-last data (x, y, grad_y, grad_x: (n, spatial, c) contiguous): the
+ * NDHWC stacks train without converting three tensors per layer to NC(D)HW and back.
+ * grad_residual: NULL, or a tensor of grad_y's shape receiving grad_y behind the ReLU mask -- the
+ * gradient of the residual input of dfm_group_norm_*_channels_last_res.  Same workspace size. */
+DFM_API int dfm_group_norm_bwd_channels_last(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                             int32_t dtype, int32_t relu, const void *grad_y,
+                                             const void *x, const void *y, const float *mean,
+                                             const float *rstd, const float *gamma, void *grad_x,
+                                             void *grad_residual, float *grad_gamma, float *grad_beta,
+                                             void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -149,3 +149,36 @@ def test_fused_residual_forward_backward(pkg, n, c, sp, groups, relu, layout):
     np.testing.assert_allclose(rg.grad.cpu().numpy(), rr.grad.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(wg.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(bg.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,c,sp,groups', [(2, 32, (6, 10, 12), 32), (1, 64, (5, 9, 16), 32), (2, 16, (7, 5), 4)])
+def test_channels_last_backward_matches_the_contiguous_one(pkg, n, c, sp, groups, relu, dtype):
+    """dfm_group_norm_bwd_channels_last (no layout round trip) against the NC(D)HW backward kernels on
+    the same values, and both against torch autograd in fp32"""
+    gen = torch.Generator().manual_seed(n * 11 + c)
+    x = (torch.randn(n, c, *sp, generator=gen) * 2 + 0.7).to(dtype)
+    gy = torch.randn(n, c, *sp, generator=gen).to(dtype)
+    w = 1 + 0.2 * torch.randn(c, generator=gen)
+    b = 0.3 * torch.randn(c, generator=gen)
+    fmt = torch.channels_last_3d if len(sp) == 3 else torch.channels_last
+    outs = []
+    for f in (torch.contiguous_format, fmt):
+        xg = x.cuda().contiguous(memory_format=f).requires_grad_(True)
+        wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        out = pkg.group_norm(xg, groups, wg, bg, 1e-5, relu)
+        out.backward(gy.cuda().contiguous(memory_format=f))
+        outs.append((out.detach().float().cpu(), xg.grad.float().cpu(), wg.grad.cpu(), bg.grad.cpu()))
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=2e-5)
+    for a, bb in zip(outs[0], outs[1]):
+        torch.testing.assert_close(a, bb, rtol=max(tol['rtol'], 1e-3), atol=max(tol['atol'], 1e-3) * float(bb.abs().max() + 1))
+    xr, wr, br = x.float().clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.group_norm(xr, groups, wr, br, 1e-5)
+    ref = F.relu(ref) if relu else ref
+    ref.backward(gy.float())
+    if dtype == torch.float32:
+        torch.testing.assert_close(outs[1][1], xr.grad, rtol=1e-3, atol=2e-5)
+        torch.testing.assert_close(outs[1][2], wr.grad, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(outs[1][3], br.grad, rtol=1e-3, atol=1e-3)
