@@ -67,7 +67,7 @@ KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0
 
 # secondary workloads (other rows of SURVEY.md 8a), reported with the same JSON shape
 SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd_kitti',
-             'backbone', 'neck', 'dfm_neck')
+             'backbone', 'backbone_train', 'neck', 'dfm_neck')
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 
 WORKLOADS = {
@@ -160,29 +160,37 @@ def secondary(args, pkg, dev, rank, world):
     one sample batch, roofline from HIP-event step time (one fused kernel per step)."""
     gen = torch.Generator().manual_seed(rank)
     flops, dtype_name = None, None
-    if args.workload in ('backbone', 'neck', 'dfm_neck'):
+    if args.workload in ('backbone', 'backbone_train', 'neck', 'dfm_neck'):
         # the MFMA-bound rows (SURVEY.md 8a a2 / a8 / a9): whole-module forward, bf16 channels_last_3d,
         # every 3x3x3 convolution in the hand-written MFMA kernels (csrc/conv3d.hip, conv3d_g.hip)
         mods = importlib.import_module('depth-from-motion_amd.modules')
         torch.manual_seed(0)
         B, nbytes, dtype_name = 1, None, 'bf16'
         cl = torch.channels_last_3d
-        if args.workload == 'backbone':
-            m = mods.DfMBackbone(in_channels=32).to(dev).to(torch.bfloat16).eval()
+        if args.workload in ('backbone', 'backbone_train'):
+            train = args.workload == 'backbone_train'
+            m = mods.DfMBackbone(in_channels=32).to(dev).to(torch.bfloat16).train(train)
             m.downsampled_depth = pkg.prepare_depth(dict(num_bins=288, depth_min=2, depth_max=59.6,
                                                          downsample_factor=4))[0]
             m.volume_memory_format = cl
             meta = dict(ori_cam2img=KITTI_P2, cur2prevs=torch.from_numpy(poses(1, 2 + rank)),
                         ori_shape=(375, 1242, 3), pad_shape=(320, 1280, 3), crop_offset=[0, 55], flip=False,
                         scale_factor=[1.0])
-            cur = torch.randn(1, 32, 320, 1280, generator=gen).to(dev).bfloat16()
-            prev = torch.randn(1, 32, 320, 1280, generator=gen).to(dev).bfloat16()
+            cur = torch.randn(1, 32, 320, 1280, generator=gen).to(dev).bfloat16().requires_grad_(train)
+            prev = torch.randn(1, 32, 320, 1280, generator=gen).to(dev).bfloat16().requires_grad_(train)
 
             def step():
+                if train:  # forward + backward (all gradients; no optimizer): 3x the forward FLOPs
+                    m.zero_grad(set_to_none=True)
+                    cost, sf, mf = m(cur, prev, [meta])
+                    return (cost.float().square().mean() + sf.float().square().mean() +
+                            mf.float().square().mean()).backward()
                 with torch.no_grad():
                     return m(cur, prev, [meta])
-            flops = 0.96e12  # SURVEY 8a a2: stereo 532 G + mono 430 G per sample
-            name, unit = 'DfMBackbone.forward config K (plane sweep + 3-D aggregation, 72x80x320, bf16 NDHWC)', 'samples/s'
+            flops = (3 if train else 1) * 0.96e12  # SURVEY 8a a2: stereo 532 G + mono 430 G per sample
+            name = ('DfMBackbone forward + backward' if train else 'DfMBackbone.forward') + \
+                ' config K (plane sweep + 3-D aggregation, 72x80x320, bf16 NDHWC)'
+            unit = 'samples/s'
         else:
             big = args.workload == 'dfm_neck'
             m = (mods.DfMNeck(in_channels=64, out_channels=256, num_frames=2) if big else

@@ -247,6 +247,33 @@ def _weight_grad_gemm(x_in, g_out, stride, padding, chunk_bytes=256 << 20):
     return acc.view(A, 3, 3, 3, B).permute(0, 4, 1, 2, 3).contiguous()
 
 
+class _ChannelSliceFn(torch.autograd.Function):
+    """x[:, lo:hi] of a channels-last tensor whose gradient comes back channels-last too (autograd's
+    own slice backward allocates a contiguous NCDHW zero tensor: the accumulation with the
+    channels-last gradients of x's other consumers then runs as a strided add, 1.1 ms at config K)"""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        ctx.cfg = (x.shape, lo, hi)
+        return x[:, lo:hi]
+
+    @staticmethod
+    def backward(ctx, gy):
+        shape, lo, hi = ctx.cfg
+        N, C, D, H, W = shape
+        g = torch.zeros((N, D, H, W, C), dtype=gy.dtype, device=gy.device).permute(0, 4, 1, 2, 3)
+        g[:, lo:hi] = gy
+        return g, None, None
+
+
+def channel_slice(x, lo, hi):
+    """x[:, lo:hi]; channels-last 5-D GPU tensors get a channels-last gradient (see _ChannelSliceFn)"""
+    if x.is_cuda and x.dim() == 5 and x.requires_grad and torch.is_grad_enabled() and \
+            x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous():
+        return _ChannelSliceFn.apply(x, lo, hi)
+    return x[:, lo:hi]
+
+
 class _PackCache:
     """packed weight fragments of a module's parameter, rebuilt when the parameter changes"""
 

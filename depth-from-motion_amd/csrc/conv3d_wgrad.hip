@@ -222,17 +222,25 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
         }
 }
 
-// out[(a0 + a) * B + b0 + b][tap'] = sum over the pair's workgroups; tap' undoes the h/w swap
-__global__ void conv3d_wgrad_reduce_kernel(const float *__restrict__ part, int wgs_per_pair, int b_tiles,
-                                           int B, int swap_hw, float *__restrict__ out)
+// out[(a0 + a) * B + b0 + b][tap'] = sum over the pair's workgroups; tap' undoes the h/w swap.
+// 64 consecutive elements per block, the workgroup partials split over 4 thread groups (the sum of
+// up to 512 partials per element is latency-bound when one thread walks them all)
+__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *__restrict__ part, int wgs_per_pair,
+                                                                  int b_tiles, int B, int swap_hw,
+                                                                  float *__restrict__ out)
 {
+    __shared__ float sh[4][64];
     const int pair = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;  // tap * 1024 + a * 32 + b
-    if (idx >= 27 * 1024) return;
-    const int tap = idx >> 10, a = (idx >> 5) & 31, b = idx & 31;
+    const int e = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + e;  // tap * 1024 + a * 32 + b  (27 * 1024 is a multiple of 64)
     const float *p = part + (size_t)pair * wgs_per_pair * (27 * 1024) + idx;
     float s = 0.0f;
-    for (int w = 0; w < wgs_per_pair; ++w) s += p[(size_t)w * (27 * 1024)];
+    for (int w = sub; w < wgs_per_pair; w += 4) s += p[(size_t)w * (27 * 1024)];
+    sh[sub][e] = s;
+    __syncthreads();
+    if (sub) return;
+    s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+    const int tap = idx >> 10, a = (idx >> 5) & 31, b = idx & 31;
     const int kd = tap / 9, k1 = (tap / 3) % 3, k2 = tap % 3;
     const int tp = swap_hw ? (kd * 3 + k2) * 3 + k1 : tap;
     const int a0 = (pair / b_tiles) * 32, b0 = (pair % b_tiles) * 32;
@@ -324,7 +332,7 @@ extern "C" DFM_API int dfm_conv3d_wgrad(const dfm_conv3d_wgrad_desc *desc, const
     else
         hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, grid, dim3(WG_THREADS), pl.lds, st, pl.g, (const bf16_t *)g,
                            (const bf16_t *)x, (float *)workspace);
-    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3((27 * 1024 + 255) / 256, pl.pairs), dim3(256), 0, st,
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(27 * 1024 / 64, pl.pairs), dim3(256), 0, st,
                        (const float *)workspace, pl.g.wgs_per_pair, pl.g.b_tiles, desc->b, pl.swap, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));

@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose3d
+from .conv3d import MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose3d, channel_slice
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .group_norm import HipGroupNorm
@@ -301,7 +301,7 @@ class DfMBackbone(nn.Module):
             memory_format=self.volume_memory_format)
         stereo = self._aggregate(self.dres0, self.dres1, self.hg_stereo, cost_raw)
         mono = self._aggregate(self.dres0_mono, self.dres1_mono, self.hg_mono,
-                               cost_raw[:, :self.in_channels])
+                               channel_slice(cost_raw, 0, self.in_channels))
         assert len(stereo) == 1 and len(mono) == 1, 'Only support num_hg=1 for now.'
         s_cost = self.pred_stereo[0](stereo[0])
         m_cost = self.pred_mono[0](mono[0])
@@ -523,7 +523,7 @@ class DfMNeck(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.in_channels[0] * self.num_frames
-        mono = _to_bev(self.mono_layers(x[:, :self.in_channels[0]]))
+        mono = _to_bev(self.mono_layers(channel_slice(x, 0, self.in_channels[0])))
         stereo = _to_bev(self.stereo_layers(x))
         # 1x1 Conv2d(2 C_out -> 1): MIOpen's kernel for this shape is a 58 ms naive convolution in
         # bf16 (profiles/r02_c26_*); it is a weighted channel sum of the two maps
