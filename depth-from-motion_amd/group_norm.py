@@ -40,7 +40,7 @@ def _f32_params(weight, bias):
 class _GroupNormFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, relu, partials=None, residual=None):
+    def forward(ctx, x, weight, bias, groups, eps, relu, partials=None, residual=None, stats_out=None):
         lib = _capi.lib()
         device = x.device
         n, c = x.shape[:2]
@@ -87,6 +87,8 @@ class _GroupNormFn(torch.autograd.Function):
                 y = torch.relu_(y)
         ctx.save_for_backward(x, y if relu else x, mean, rstd, w32)
         ctx.cfg = (groups, bool(relu), weight.dtype, bias.dtype, cl, residual is not None)
+        if stats_out is not None:  # (mean, rstd) per (sample, group): HipBatchNorm3d's running statistics
+            stats_out.append((mean, rstd))
         return y
 
     @staticmethod
@@ -116,7 +118,7 @@ class _GroupNormFn(torch.autograd.Function):
                     _ptr(gb), _ptr(ws), nbytes, _stream_ptr(device)))
             if want_res and not relu:
                 gres = gy
-            return gx, gw.to(wdt), gb.to(bdt), None, None, None, None, gres
+            return gx, gw.to(wdt), gb.to(bdt), None, None, None, None, gres, None
         # y = relu?(gn(x) + residual): the residual's gradient is the incoming one behind the ReLU mask
         gres = None
         if want_res:
@@ -128,7 +130,7 @@ class _GroupNormFn(torch.autograd.Function):
                 lib.dfm_group_norm_bwd(n, c, spatial, groups, _DTYPES[x.dtype], int(relu), _ptr(gy),
                                        _ptr(x), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(w32), _ptr(gx),
                                        _ptr(gw), _ptr(gb), _ptr(ws), nbytes, _stream_ptr(device)))
-        return gx, gw.to(wdt), gb.to(bdt), None, None, None, None, gres
+        return gx, gw.to(wdt), gb.to(bdt), None, None, None, None, gres, None
 
 
 def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False, partials=None, residual=None):
@@ -175,3 +177,51 @@ class HipGroupNorm(nn.GroupNorm):
         if residual is not None:
             y = y + residual
         return torch.relu_(y) if relu else y
+
+
+class HipBatchNorm3d(nn.BatchNorm3d):
+    """nn.BatchNorm3d (same parameters, buffers and ``state_dict`` keys) whose TRAINING forward /
+    backward on channels-last GPU tensors run in the fused HIP kernels: the batch statistics of a
+    channels-last (N, C, D, H, W) tensor are the per-channel GroupNorm statistics of the same memory
+    viewed as ONE sample (1, C, N*D, H, W), so normalisation (+ residual) (+ ReLU) is one statistics
+    pass and one apply pass, and the backward the channels-last GroupNorm backward (torch's
+    BatchNorm backward on this layout: 2.3 ms per layer of the voxel neck, 42 % of its training step).
+    Eval mode / other inputs: torch (the necks fold eval-mode BatchNorm into the conv epilogue anyway).
+    ``forward(x, relu=False, residual=None)``: y = relu?(bn(x) + residual)."""
+
+    def _fusable(self, x):
+        vec = 16 // x.element_size() if x.dtype in _DTYPES else 0
+        c = x.shape[1]
+        return (self.training and x.is_cuda and vec and x.dim() == 5 and self.affine and
+                self.track_running_stats and c % vec == 0 and c <= 256 and ((c // vec) & (c // vec - 1)) == 0 and
+                not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last_3d))
+
+    @staticmethod
+    def _as_one_sample(t):
+        N, C, D, H, W = t.shape
+        return t.permute(0, 2, 3, 4, 1).reshape(1, N * D, H, W, C).permute(0, 4, 1, 2, 3)
+
+    def forward(self, x, relu=False, residual=None):
+        if not self._fusable(x):
+            y = super().forward(x)
+            if residual is not None:
+                y = y + residual
+            return torch.relu_(y) if relu else y
+        N, C, D, H, W = x.shape
+        res = None
+        if residual is not None:
+            res = residual if residual.is_contiguous(memory_format=torch.channels_last_3d) else \
+                residual.contiguous(memory_format=torch.channels_last_3d)
+            res = self._as_one_sample(res)
+        stats = []
+        y = _GroupNormFn.apply(self._as_one_sample(x), self.weight, self.bias, C, float(self.eps), bool(relu), None,
+                               res, stats)
+        mean, rstd = stats[0]
+        with torch.no_grad():
+            m = N * D * H * W
+            var = (1.0 / (rstd * rstd) - self.eps).clamp_min_(0.0) * (m / max(m - 1, 1))  # unbiased
+            self.num_batches_tracked += 1
+            f = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+            self.running_mean.mul_(1 - f).add_(mean.to(self.running_mean.dtype), alpha=f)
+            self.running_var.mul_(1 - f).add_(var.to(self.running_var.dtype), alpha=f)
+        return y.permute(0, 2, 3, 4, 1).reshape(N, D, H, W, C).permute(0, 4, 1, 2, 3)

@@ -28,7 +28,7 @@ from torch import nn
 from .conv3d import MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose3d, channel_slice
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
-from .group_norm import HipGroupNorm
+from .group_norm import HipBatchNorm3d, HipGroupNorm
 from .plane_sweep import build_dfm_cost
 from .registry import register_module
 
@@ -58,7 +58,7 @@ def _make_norm(norm_cfg, channels):
     if kind == 'GN':
         name, layer = 'gn', HipGroupNorm(num_channels=channels, **cfg)
     elif kind == 'BN3d':
-        name, layer = 'bn', nn.BatchNorm3d(channels, **cfg)
+        name, layer = 'bn', HipBatchNorm3d(channels, **cfg)
     elif kind in ('BN', 'BN2d'):
         name, layer = 'bn', nn.BatchNorm2d(channels, **cfg)
     else:
@@ -97,28 +97,30 @@ class ConvModule(nn.Module):
                 raise NotImplementedError(act_cfg['type'])
             self.activate = nn.ReLU(inplace=act_cfg.get('inplace', True))
 
-    def forward(self, x, residual=None):
-        """``residual`` (extension, GroupNorm blocks): added after the norm, before the activation --
-        fused into the normalisation pass of the HIP GroupNorm."""
+    def forward(self, x, residual=None, relu=None):
+        """``residual`` (extension): added after the norm, before the activation -- fused into the
+        normalisation pass of the HIP GroupNorm / BatchNorm.  ``relu``: overrides the block's own
+        activation (ResModule applies its ReLU after the identity add)."""
         norm = getattr(self, self.norm_name) if self.norm_name is not None else None
+        act = (self.activate is not None) if relu is None else bool(relu)
         if (isinstance(self.conv, MfmaConv3d) and isinstance(norm, HipGroupNorm) and
                 norm.num_groups == self.conv.out_channels and self.conv.eligible(x)):
             # MFMA conv whose epilogue already produced the per-channel GroupNorm statistics:
             # the normalisation (+residual, +ReLU) is one read and one write of the tensor
             y, partials = self.conv.forward_with_stats(x)
-            return norm(y, relu=self.activate is not None, partials=partials, residual=residual)
-        if residual is None and self.fusable(x):
+            return norm(y, relu=act, partials=partials, residual=residual)
+        if residual is None and relu is None and self.fusable(x):
             return self.forward_fused(x)
         x = self.conv(x)
         if self.norm_name is not None:
-            if isinstance(norm, HipGroupNorm):
-                # GN (+residual) and ReLU in one pass
-                return norm(x, relu=self.activate is not None, residual=residual)
+            if isinstance(norm, (HipGroupNorm, HipBatchNorm3d)):
+                # norm (+residual) and ReLU in one pass
+                return norm(x, relu=act, residual=residual)
             x = norm(x)
         if residual is not None:
             x = x + residual
-        if self.activate is not None:
-            x = self.activate(x)
+        if act:
+            x = F.relu(x)
         return x
 
     # -- inference path of the Conv3d + BatchNorm3d (+ReLU) blocks of the voxel necks: the running
@@ -469,7 +471,8 @@ class ResModule(nn.Module):
             res = x if x.is_contiguous(memory_format=torch.channels_last_3d) else \
                 x.contiguous(memory_format=torch.channels_last_3d)  # a channel slice (DfMNeck mono stack)
             return self.conv1.forward_fused(self.conv0.forward_fused(x), residual=res, relu=True)
-        return self.activation(x + self.conv1(self.conv0(x)))
+        # training: BatchNorm (batch statistics) + identity + ReLU are one fused pass of HipBatchNorm3d
+        return self.conv1(self.conv0(x), residual=x, relu=True)
 
 
 def _bev_stack(c_in, widths, out_channels, norm_cfg):

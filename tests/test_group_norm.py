@@ -182,3 +182,61 @@ def test_channels_last_backward_matches_the_contiguous_one(pkg, n, c, sp, groups
         torch.testing.assert_close(outs[1][1], xr.grad, rtol=1e-3, atol=2e-5)
         torch.testing.assert_close(outs[1][2], wr.grad, rtol=1e-3, atol=1e-3)
         torch.testing.assert_close(outs[1][3], br.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('relu,with_res', [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_hip_batch_norm3d_training_matches_torch(pkg, relu, with_res, dtype):
+    """HipBatchNorm3d in training mode on a channels-last batch (the BN3d blocks of the voxel necks,
+    imvoxel_neck.py:28-55): output, running statistics and all gradients against nn.BatchNorm3d"""
+    import importlib
+    gn = importlib.import_module('depth-from-motion_amd.group_norm')
+    torch.manual_seed(4)
+    N, C, sp = 2, 64, (5, 9, 12)
+    ref = torch.nn.BatchNorm3d(C).cuda().train()
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.2 * torch.randn(C))
+        ref.bias.copy_(0.3 * torch.randn(C))
+    m = gn.HipBatchNorm3d(C).cuda().train()
+    m.load_state_dict(ref.state_dict())
+    assert list(m.state_dict()) == list(ref.state_dict())
+    x = (torch.randn(N, C, *sp, device='cuda') * 2 + 0.5).to(dtype)
+    res = torch.randn(N, C, *sp, device='cuda').to(dtype)
+    gy = torch.randn(N, C, *sp, device='cuda').to(dtype)
+    cl = torch.channels_last_3d
+    xr, rr = x.float().clone().requires_grad_(True), res.float().clone().requires_grad_(True)
+    yr = ref(xr)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(gy.float())
+    if dtype == torch.bfloat16:
+        m = m.to(torch.bfloat16)
+    xg = x.contiguous(memory_format=cl).requires_grad_(True)
+    rg = res.contiguous(memory_format=cl).requires_grad_(True)
+    y = m(xg, relu=relu, residual=rg if with_res else None)
+    assert y.shape == x.shape and y.is_contiguous(memory_format=cl)
+    y.backward(gy.contiguous(memory_format=cl))
+    tol = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+
+    def close(a, b):
+        if dtype == torch.float32:
+            return torch.testing.assert_close(a, b, **tol)
+        # bf16: a pre-activation that rounds to the other side of zero flips its gradient entirely
+        bad = (a - b).abs() > tol['atol'] + tol['rtol'] * b.abs()
+        assert float(bad.float().mean()) < 0.01, float(bad.float().mean())
+    close(y.float(), yr)
+    close(xg.grad.float(), xr.grad)
+    if with_res:
+        close(rg.grad.float(), rr.grad)
+    ptol = 6e-2 if dtype == torch.bfloat16 else 1e-3   # sums over 1080 elements per channel, ReLU flips in bf16
+    torch.testing.assert_close(m.weight.grad.float(), ref.weight.grad, rtol=ptol, atol=ptol * float(ref.weight.grad.abs().max()))
+    torch.testing.assert_close(m.bias.grad.float(), ref.bias.grad, rtol=ptol, atol=ptol * float(ref.bias.grad.abs().max()))
+    torch.testing.assert_close(m.running_mean.float(), ref.running_mean, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(m.running_var.float(), ref.running_var, rtol=1e-2, atol=1e-2)
+    assert int(m.num_batches_tracked) == 1
+    # eval mode is torch's BatchNorm (the necks fold it into the convolution epilogue instead)
+    m.eval(); ref.eval()
+    torch.testing.assert_close(m(xg.detach()).float(), ref(x.float()), **tol)
