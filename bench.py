@@ -417,15 +417,47 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
         # this size ran the autotuner; query what it cached, tune now if it did not)
         tuned = sweep.plane_sweep_tuning(desc) or \
             sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
-    pkg._capi.check(lib.dfm_profile_begin(args.steps))
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    verified = None
+    if tuned is not None and w['dtype'] == 'bf16':
+        # untimed, part of the tuning: the library's pick is checked against both tile shapes over as
+        # many launches as the timed region has -- its own timing window is a few launches at process
+        # start, and a wrong pick costs 3-6 % (it cost 20 % while re-fetching schedules were still
+        # candidates: profiles/r02_c43_bench_default_mispick.json).  The faster one is used.
+        shapes = {'lanes256_ppl8_planes2_chunk1': dict(kernel=2, lanes=256, points_per_lane=8, bands_per_chunk=1),
+                  'lanes512_ppl4_planes2_chunk1': dict(kernel=2, lanes=512, points_per_lane=4, bands_per_chunk=1)}
+        verified = {}
+        for key, kw in shapes.items():
+            with sweep.launch_options(**kw):
+                step()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.steps):
+                    step()
+                e1.record()
+                torch.cuda.synchronize()
+                verified[key] = round(e0.elapsed_time(e1) / args.steps, 4)
+        if world > 1:  # every rank must take the same launch shape
+            t = torch.tensor([verified[k] for k in shapes], device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            verified = {k: round(float(v), 4) for k, v in zip(shapes, t)}
+        best_key = min(verified, key=verified.get)
+        chosen_kw = shapes[best_key]
+        tuned = pkg._capi.SweepOpts(**{sweep._OPT_FIELDS[k]: v for k, v in chosen_kw.items()}).as_dict()
+    else:
+        chosen_kw = {}
+    import contextlib
+    with (sweep.launch_options(**chosen_kw) if chosen_kw else contextlib.nullcontext()):
         step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+        pkg._capi.check(lib.dfm_profile_begin(args.steps))
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
     kms, klaunches = ctypes.c_double(0), ctypes.c_int(0)
     pkg._capi.check(lib.dfm_profile_end(ctypes.byref(kms), ctypes.byref(klaunches)))
 
@@ -468,6 +500,7 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
                                        pkg._capi.SweepOpts(**{sweep._OPT_FIELDS[k]: v for k, v in
                                                               explicit.items()}).as_dict()),
                 'autotuned': tuned is not None,
+                'tuning_check_ms': verified,
                 'volume_layout': '(B,D,H,W,2C) channels_last_3d' if args.channels_last
                 else '(B,2C,D,H,W) contiguous (the reference layout)',
             },

@@ -1695,24 +1695,23 @@ DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur
     TuneKey key;
     rc = tune_key(desc, key);
     if (rc != DFM_OK) return rc;
-    // candidates: {8 points per lane x 256 lanes, 4 points per lane x 512 lanes (bf16)} x
-    // {bands_per_chunk 1, 15}.  (29 was dropped: 41 GB of HBM traffic per N* launch against 28 GB
-    // for 1, profiles/r02_nstar_traffic.json.)
+    // candidates: 8 points per lane x 256 lanes, 4 points per lane x 512 lanes (bf16), both with
+    // bands_per_chunk 1.  The re-fetching schedules are no longer candidates: bands_per_chunk 29 moved
+    // 41 GB and 15 moves 37 GB of HBM traffic per N* launch against 28 GB (profiles/r02_nstar_traffic.json);
+    // 15 gained 3 % on the slowest parts seen, but a short timing window picked it once on a part where
+    // it then ran 20 % SLOWER in steady state (profiles/r02_c43_bench_default_mispick.json: 6.75 ms
+    // against 5.46 ms for 512 x 4 in the same lease).  A wrong pick between the two remaining shapes
+    // costs at most the 3-6 % they differ by; bands_per_chunk stays available through dfm_sweep_opts.
     std::vector<dfm_sweep_opts> cand;
     {
         dfm_sweep_opts o;
         memset(&o, 0, sizeof(o));
-        for (int chunk : {1, 15}) {
-            o.bands_per_chunk = chunk;
-            cand.push_back(o);
-        }
+        o.bands_per_chunk = 1;
+        cand.push_back(o);
         if (desc->dtype == DFM_BF16) {
             o.lanes_per_workgroup = 512;
             o.points_per_lane = 4;
-            for (int chunk : {1, 15}) {
-                o.bands_per_chunk = chunk;
-                cand.push_back(o);
-            }
+            cand.push_back(o);
         }
     }
     hipStream_t st = (hipStream_t)stream;
@@ -1722,7 +1721,7 @@ DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur
         // start and picked a schedule 20 % slower than the best on one box): warm the part up
         // with the default shape, then ROUNDS round-robin passes over the candidates, two
         // launches per measurement, minimum per candidate.
-        constexpr int ROUNDS = 3, PER = 2;
+        constexpr int ROUNDS = 5, PER = 3;
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
