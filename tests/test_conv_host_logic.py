@@ -1,0 +1,124 @@
+"""Host-side logic of the MFMA convolution path that needs no GPU: the C-ABI planners / validators
+(dfm_conv3d_g_plan, dfm_conv3d_wgrad_workspace_bytes), the layout helpers and the CPU behaviour of
+the module classes (they fall through to torch, same state_dict keys)."""
+import ctypes
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+@pytest.fixture(scope='module')
+def cv():
+    importlib.import_module('depth-from-motion_amd.build').build_hip()
+    return importlib.import_module('depth-from-motion_amd.conv3d')
+
+
+def test_planner_covers_every_layer_shape_of_the_path(cv):
+    """hourglass (conv_modules.py:73-149) and voxel-neck (imvoxel_neck.py:26-55) layers: a tiling
+    exists, fits the LDS, tiles the volume, and fills the chip where the layer is big enough"""
+    cases = [(64, 64, (36, 40, 160), 1, 1, False), (32, 64, (72, 80, 320), 2, 1, False),
+             (64, 64, (18, 20, 80), 1, 1, True), (64, 32, (36, 40, 160), 1, 1, True),
+             (64, 64, (220, 300, 12), 1, 1, False), (64, 128, (220, 300, 12), (1, 1, 2), 1, False),
+             (128, 128, (220, 300, 6), 1, 1, False), (256, 256, (220, 300, 3), 1, (1, 1, 0), False),
+             (128, 256, (3, 5, 6), (1, 1, 2), 1, False)]
+    for cin, cout, size, stride, padding, tr in cases:
+        p = cv.conv3d_g_plan(1, cin, cout, size, stride, padding, tr)
+        assert p['pfw'] in (1, 2, 3, 4) and p['cw'] == (2 if cout % 64 == 0 else 1)
+        assert p['tile'][0] * p['tile'][1] * p['tile'][2] == 128 * p['pfw']
+        assert p['block_px'] <= 1536 and p['lds'] <= 160 * 1024 and p['workgroups'] >= 1
+        out = cv.conv3d_g_out_size(size, cv._triple(stride), cv._triple(padding), cv._triple(tr))
+        space = size if tr else out
+        tiles = 1
+        for s, t in zip(space, p['tile']):
+            tiles *= -(-s // t)
+        assert p['workgroups'] % tiles == 0
+    big = cv.conv3d_g_plan(1, 128, 128, (220, 300, 12))
+    assert big['workgroups'] >= 512
+
+
+def test_conv_descriptors_are_validated_without_a_gpu(cv):
+    lib = importlib.import_module('depth-from-motion_amd._capi').lib()
+    capi = importlib.import_module('depth-from-motion_amd._capi')
+    d = cv._conv_desc(1, 48, 64, (4, 4, 4), (4, 4, 4), (1, 1, 1), (1, 1, 1), (False,) * 3, False)
+    plan = (ctypes.c_int64 * 8)()
+    assert lib.dfm_conv3d_g_plan(ctypes.byref(d), plan) == -2 and b'multiples of 32' in lib.dfm_last_error()
+    d = cv._conv_desc(1, 32, 64, (4, 4, 4), (3, 4, 4), (1, 1, 1), (1, 1, 1), (False,) * 3, False)
+    assert lib.dfm_conv3d_g_plan(ctypes.byref(d), plan) == -1 and b'out_size' in lib.dfm_last_error()
+    d = cv._conv_desc(1, 32, 32, (4, 4, 4), (8, 8, 9), (1, 1, 1), (1, 1, 1), (True,) * 3, False)
+    assert lib.dfm_conv3d_g_plan(ctypes.byref(d), plan) == -2 and b'transposed' in lib.dfm_last_error()
+    assert lib.dfm_conv3d_g_fwd(ctypes.byref(d), None, None, None, None, None, None, None) != 0
+    assert lib.dfm_conv3d_g_weight_bytes(64, 128) == 27 * 64 * 128 * 2 + 4096
+    assert lib.dfm_conv3d_g_weight_bytes(48, 128) == 0
+    w = capi.Conv3dWgradDesc()
+    w.n, w.a, w.b = 1, 64, 32
+    for i, (g, x) in enumerate(zip((36, 40, 160), (72, 80, 320))):
+        w.g_size[i], w.x_size[i], w.stride[i], w.padding[i] = g, x, 2, 1
+    for i, (gs, xs) in enumerate(zip((36 * 40 * 160 * 64, 40 * 160 * 64, 160 * 64, 64),
+                                     (72 * 80 * 320 * 32, 80 * 320 * 32, 320 * 32, 32))):
+        w.g_stride[i], w.x_stride[i] = gs, xs
+    nbytes = lib.dfm_conv3d_wgrad_workspace_bytes(ctypes.byref(w))
+    assert nbytes > 0 and nbytes % (27 * 1024 * 4) == 0      # whole 27 x 32 x 32 fp32 partials
+    w.a = 40
+    assert lib.dfm_conv3d_wgrad_workspace_bytes(ctypes.byref(w)) == 0
+    w.a, w.x_stride[3] = 64, 36
+    assert lib.dfm_conv3d_wgrad_workspace_bytes(ctypes.byref(w)) == 0   # strides: multiples of 8
+
+
+def test_channel_stride_of_channels_last_views(cv):
+    x = torch.zeros(2, 128, 3, 4, 5).contiguous(memory_format=torch.channels_last_3d)
+    assert cv._ndhwc_channel_stride(x) == 128
+    assert cv._ndhwc_channel_stride(x[:, :64]) == 128 and cv._ndhwc_channel_stride(x[:, 64:]) == 128
+    assert cv._ndhwc_channel_stride(x[:, 4:68]) == 0          # not 16-byte aligned
+    assert cv._ndhwc_channel_stride(x.contiguous()) == 0      # NCDHW
+    assert cv._ndhwc_channel_stride(x[:, :, ::2]) == 0        # gaps between depth slices
+    y = torch.zeros(1, 64, 3, 4, 1).contiguous(memory_format=torch.channels_last_3d)
+    assert cv._ndhwc_channel_stride(y) == 64
+    assert cv._ndhwc_strides(x[:, :64]) == (128 * 60, 128 * 20, 128 * 5, 128)
+
+
+def test_weight_gradient_gemm_form_matches_autograd_on_the_cpu(cv):
+    """the chunked implicit-im2col GEMM (the form channel counts outside the MFMA kernel take)"""
+    torch.manual_seed(0)
+    for cin, cout, size, stride, pad in [(4, 6, (5, 6, 7), 1, 1), (4, 6, (6, 8, 8), 2, 1),
+                                         (3, 5, (4, 5, 6), (1, 1, 2), 1), (4, 4, (4, 5, 3), 1, (1, 1, 0))]:
+        x = torch.randn(2, cin, *size).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        w = torch.randn(cout, cin, 3, 3, 3, requires_grad=True)
+        y = F.conv3d(x, w, stride=stride, padding=pad)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        gw = cv.conv3d_weight_grad(x.detach(), gy.contiguous(memory_format=torch.channels_last_3d), stride, pad)
+        torch.testing.assert_close(gw, w.grad, rtol=1e-4, atol=1e-4)
+    x = torch.randn(2, 4, 3, 4, 5).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    w = torch.randn(4, 6, 3, 3, 3, requires_grad=True)
+    y = F.conv_transpose3d(x, w, stride=2, padding=1, output_padding=1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    gw = cv.conv3d_weight_grad(gy.contiguous(memory_format=torch.channels_last_3d), x.detach(), 2, 1)
+    torch.testing.assert_close(gw, w.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_module_classes_are_their_torch_parents_on_the_cpu(cv):
+    """same parameters / state_dict keys; CPU tensors take torch's implementation"""
+    gn = importlib.import_module('depth-from-motion_amd.group_norm')
+    mods = importlib.import_module('depth-from-motion_amd.modules')
+    torch.manual_seed(1)
+    for m, ref in ((cv.MfmaConv3dG(32, 64, 3, stride=2, padding=1, bias=False), torch.nn.Conv3d),
+                   (cv.MfmaConvTranspose3d(64, 32, 3, stride=2, padding=1, output_padding=1, bias=False),
+                    torch.nn.ConvTranspose3d),
+                   (cv.MfmaConv3dTo1(32, 1, 3, 1, 1, bias=False), torch.nn.Conv3d)):
+        assert isinstance(m, ref) and list(m.state_dict()) == ['weight']
+        x = torch.randn(1, m.in_channels, 4, 6, 6)
+        assert not m.eligible(x)
+        assert torch.equal(m(x), ref.forward(m, x))
+    bn = gn.HipBatchNorm3d(8).train()
+    ref = torch.nn.BatchNorm3d(8).train()
+    ref.load_state_dict(bn.state_dict())
+    x, r = torch.randn(2, 8, 3, 4, 5), torch.randn(2, 8, 3, 4, 5)
+    torch.testing.assert_close(bn(x, relu=True, residual=r), torch.relu(ref(x) + r))
+    torch.testing.assert_close(bn.running_var, ref.running_var)
+    pool = mods._WindowMean2d(4, stride=4)
+    xi = torch.randn(1, 3, 9, 13)
+    assert torch.equal(pool(xi), F.avg_pool2d(xi, 4, stride=4))
+    assert cv.channel_slice(torch.zeros(1, 8, 2, 2, 2), 0, 4).shape == (1, 4, 2, 2, 2)
