@@ -223,16 +223,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
 
         for (int chunk = 0; chunk < g.nchunk; ++chunk) {
             const uint32_t ldsb = lds0 + (g.resident ? chunk * chunk_bytes : 0);
-            // one round of ds_read_b128: the PFW B fragments of (tap offset `off`, k-step ks)
-            auto issue = [&](int off, int ks, u32x4_t (&dst)[PFW]) {
+            // one round of ds_read_b128: the PFW B fragments of a tap.  k-step 0 computes the swizzled
+            // addresses; k-step 1 is the same pixel's slot ^ 2, i.e. address ^ 32 (the dynamic LDS
+            // base and the chunk stride are multiples of 64: no static __shared__ in this kernel)
+            uint32_t addr[PFW];
+            auto issue0 = [&](int off, u32x4_t (&dst)[PFW]) {
 #pragma unroll
                 for (int f = 0; f < PFW; ++f) {
                     const int bp = base_bp[f] + off;
-                    uint32_t a = ldsb + (uint32_t)bp * 64u +
-                                 ((((uint32_t)(2 * ks + half)) ^ (((uint32_t)bp >> 2) & 3u)) << 4);
+                    uint32_t a = ldsb + (uint32_t)bp * 64u + ((((uint32_t)half) ^ (((uint32_t)bp >> 2) & 3u)) << 4);
 #ifdef DFM_DEBUG_HOOKS
                     if (g.ablate & 4) a = ldsb + ((uint32_t)(off & 15) << 10) + lane * 16;
 #endif
+                    addr[f] = a;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(dst[f]) : "v"(a));
+                }
+            };
+            auto issue1 = [&](u32x4_t (&dst)[PFW]) {
+#pragma unroll
+                for (int f = 0; f < PFW; ++f) {
+                    const uint32_t a = addr[f] ^ 32u;
                     asm volatile("ds_read_b128 %0, %1" : "=v"(dst[f]) : "v"(a));
                 }
             };
@@ -254,18 +264,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
                         __builtin_memcpy(&dst[ks][c], &q, 16);
                     }
             };
-            bf16x8_t wc[2][CW], wn[2][CW];
+            bf16x8_t wa[2][CW], wb[2][CW];  // weights of the current / next tap, ping-pong (no copies)
             int wt, off, offn;
             jd = jh = jw = 0;
             tap_cur(wt, off);
-            wload(wt, wn);
+            wload(wt, wa);
             if (!g.resident) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();  // the block has landed
             }
 
             u32x4_t q0[PFW], q1[PFW];
-            issue(off, 0, q0);
+            issue0(off, q0);
             // q (issued one round earlier) is complete when at most PFW newer reads are outstanding
 #define G_WAIT(Q, N)                                                                                         \
             do {                                                                                             \
@@ -291,36 +301,37 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
                         acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[c], xf, acc[f][c], 0, 0, 0);
                 }
             };
-            for (int j = 0; j + 1 < ntaps; ++j) {
-                // the weights of this tap were requested one tap ago; request the next tap's
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) wc[ks][c] = wn[ks][c];
+            // one tap: request the next tap's weights into `wnext`, run this tap's two k-steps from `wcur`
+            auto step = [&](bf16x8_t (&wcur)[2][CW], bf16x8_t (&wnext)[2][CW]) {
+                asm volatile("" ::: "memory");  // keep the next step's weight loads from being hoisted here
                 tap_adv();
                 tap_cur(wt, offn);
 #ifdef DFM_DEBUG_HOOKS
                 if (!(g.ablate & 2))
 #endif
-                wload(wt, wn);
-                issue(off, 1, q1);
+                wload(wt, wnext);
+                issue1(q1);
                 G_WAIT_PFW(q0);
-                mfmas(wc[0], q0);
-                issue(offn, 0, q0);
+                mfmas(wcur[0], q0);
+                issue0(offn, q0);
                 G_WAIT_PFW(q1);
-                mfmas(wc[1], q1);
-                off = offn;
+                mfmas(wcur[1], q1);
+            };
+            auto last = [&](bf16x8_t (&wcur)[2][CW]) {
+                issue1(q1);
+                G_WAIT_PFW(q0);
+                mfmas(wcur[0], q0);
+                G_WAIT(q1, 0);
+                mfmas(wcur[1], q1);
+            };
+            for (int j = 0; j + 1 < ntaps; ++j) {
+                step(wa, wb);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int cw = 0; cw < CW; ++cw) wa[ks][cw] = wb[ks][cw];
             }
-            // last tap
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int c = 0; c < CW; ++c) wc[ks][c] = wn[ks][c];
-            issue(off, 1, q1);
-            G_WAIT_PFW(q0);
-            mfmas(wc[0], q0);
-            G_WAIT(q1, 0);
-            mfmas(wc[1], q1);
+            last(wa);
 #undef G_WAIT
 #undef G_WAIT_PFW
         }
