@@ -827,13 +827,19 @@ __device__ __forceinline__ uint32_t bwd_footprint(float sx, float sy, int H, int
            ((uint32_t)sok << 30) | ((uint32_t)(ixw + 1) << 13) | (uint32_t)(iyn + 1);
 }
 
-// float -> 64-bit two's-complement fixed point (|x| < 2^61 after scaling; exact for the 24
-// significant bits of x)
+// float -> 64-bit two's-complement fixed point (|x| < 2^61 after scaling): high word =
+// floor(x / 2^32), low word = x - high * 2^32, which the fma delivers exactly except for a negative
+// x of tiny magnitude, whose 2^32 - |x| rounds to 2^32 and saturates the conversion -- one unit of
+// 2^-50 of the local maximum.  Five VALU operations; the pair is assembled from the two converted
+// words (the first version went through a float -> u64 conversion: 12 operations per add).
 __device__ __forceinline__ unsigned long long bwd_to_fixed(float x)
 {
     const float hif = floorf(x * 2.3283064365386963e-10f);
     const float lof = __builtin_fmaf(hif, -4294967296.0f, x);  // in [0, 2^32]
-    return ((unsigned long long)(unsigned)(int)hif << 32) + (unsigned long long)lof;
+    unsigned lo;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(lo) : "v"(lof));  // saturating
+    const unsigned hi = (unsigned)(int)hif;
+    return ((unsigned long long)hi << 32) | (unsigned long long)lo;
 }
 
 // scale 2^sh with max|x| * 2^sh < 2^50 from the raw bits of max|x| (finite, non-zero)
@@ -1049,6 +1055,23 @@ __global__ __launch_bounds__(BWD_PTS * bwd_groups(HALF)) void sweep_bwd_tile_ker
                     float gvf[CW];
 #pragma unroll
                     for (int c = 0; c < CW; ++c) gvf[c] = elem<T>::load(gv[k][c]);
+                    const int rr0 = iyn - y0;  // >= 0 for an in-bounds north row: y0 <= the window's first row
+                    if ((f & 0x78000000u) == 0x78000000u && rr0 + 1 < rows && !plain && !BWD_ABLATE(2)) {
+                        // interior footprint inside the slab window (nearly every point): four taps x CW
+                        // channels without a branch; channels past nc carry 0 into slab rows nobody flushes
+                        unsigned long long *l = slab + rr0 * W + ixw;
+                        const float w0 = wq[0] * fx_scale, w1 = wq[1] * fx_scale;
+                        const float w2 = wq[2] * fx_scale, w3 = wq[3] * fx_scale;
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) {
+                            unsigned long long *lc = l + c * slab_c;
+                            atomicAdd(lc, bwd_to_fixed(gvf[c] * w0));
+                            atomicAdd(lc + 1, bwd_to_fixed(gvf[c] * w1));
+                            atomicAdd(lc + W, bwd_to_fixed(gvf[c] * w2));
+                            atomicAdd(lc + W + 1, bwd_to_fixed(gvf[c] * w3));
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (wq[q] == 0.0f) continue;  // out-of-bounds (or weightless) tap
@@ -1059,8 +1082,7 @@ __global__ __launch_bounds__(BWD_PTS * bwd_groups(HALF)) void sweep_bwd_tile_ker
                             unsigned long long *l = slab + rr * W + px;
                             const float ws = wq[q] * fx_scale;
 #pragma unroll
-                            for (int c = 0; c < CW; ++c)
-                                if (c < nc) atomicAdd(l + c * slab_c, bwd_to_fixed(gvf[c] * ws));
+                            for (int c = 0; c < CW; ++c) atomicAdd(l + c * slab_c, bwd_to_fixed(gvf[c] * ws));
                         } else {  // taller than the slab window (rare), or a non-finite pass
                             float *gl = gf + (size_t)c0 * HW + (size_t)py * W + px;
 #pragma unroll
@@ -1818,7 +1840,12 @@ DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *gra
     // dense sweeps whose feature rows fit the LDS: accumulate there (see sweep_bwd_tile_kernel).
     // One 1024-lane workgroup per CU: the LDS holds the footprint table of the chunk
     // (planes x 256 points x 12 B) and the slab of 64-bit accumulators (CW channels x rows x W).
-    const int planes = std::max(1, std::min(BWD_MAXP, (g.D + 3) / 4));
+    int planes = std::max(1, std::min(BWD_MAXP, (g.D + 3) / 4));
+    int cw_max = 4;
+#ifdef DFM_DEBUG_HOOKS
+    if (const char *e = getenv("DFM_BWD_PLANES")) planes = std::max(1, std::min(BWD_MAXP, atoi(e)));
+    if (const char *e = getenv("DFM_BWD_CW")) cw_max = atoi(e);
+#endif
     const int table_bytes = planes * BWD_PTS * 12;
     const int budget = 160 * 1024 - 1024 - table_bytes;  // 1 KiB for the static LDS
     // channels per pass: as many (of 4) as leave >= 4 rows in the budget
@@ -1826,7 +1853,7 @@ DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *gra
         while (cw > 2 && (long long)budget / ((long long)cw * desc->w_in * 8) < 4) cw >>= 1;
         return cw;
     };
-    const int cw_cur = pick_cw(4), cw_prev = cw_cur;
+    const int cw_cur = pick_cw(cw_max), cw_prev = cw_cur;
     const int rows_cur = (int)std::min<long long>(std::min(desc->h_in, 8),
                                                   (long long)budget / ((long long)cw_cur * desc->w_in * 8));
     const int rows_prev = rows_cur;
