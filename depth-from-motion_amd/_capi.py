@@ -134,7 +134,8 @@ class F2vDesc(ctypes.Structure):
         'batch', 'channels', 'd', 'h', 'w', 'ds', 'hs', 'ws', 'sem_channels', 'hsem', 'wsem', 'nz',
         'ny', 'nx')] + [(n, ctypes.c_float) for n in ('pad_h', 'pad_w', 'depth_min', 'depth_span')
                         ] + [('dtype', ctypes.c_int32), ('stereo_channels_last', ctypes.c_int32),
-                           ('out_channels_last', ctypes.c_int32)]
+                           ('out_channels_last', ctypes.c_int32), ('stereo_atten', ctypes.c_int32),
+                           ('no_sem_atten', ctypes.c_int32)]
 
 
 class VsDesc(ctypes.Structure):

@@ -30,6 +30,8 @@ struct F2vGeom {
     float pad_h, pad_w, depth_min, depth_span;
     int32_t out_cl;      // out stored (B, Nz, Ny, Nx, C + Cs): torch channels_last_3d
     int32_t cd, ch, cw;  // fused depth head: size of the low-resolution cost volume (Ds = scale * cd ...)
+    int32_t st_att;      // stereo_atten_feat: Voxel *= pred_disp      (feature_transformation.py:141-142)
+    int32_t sem_att;     // sem_atten_feat:    Voxel_2D *= pred_disp   (feature_transformation.py:154-155)
 };
 
 // Fused DepthHead: the depth distribution the reference samples,
@@ -166,16 +168,10 @@ __global__ __launch_bounds__(256) void f2v_kernel(F2vGeom g, const T *__restrict
     gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
     const float valid = (valid2d && gz >= -1.0f && gz <= 1.0f) ? 1.0f : 0.0f;
 
-    const size_t vol = (size_t)g.D * g.H * g.W;
-    T *o = out + (size_t)b * (g.C + g.Cs) * N + i;
-    {
-        const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
-        const T *sv = stereo + (size_t)b * g.C * vol;
-        for (int ch = 0; ch < g.C; ++ch)
-            o[(size_t)ch * N] = elem<T>::store(tri_sample<T>(t, sv + ch * vol) * valid);
-    }
-    if (g.Cs > 0) {
-        float disp;
+    // pred_disp = grid_sample(stereo_feat_softmax) * valids, wanted when either attention is on
+    // (feature_transformation.py:133-139)
+    float disp = 1.0f;
+    if (g.st_att || (g.Cs > 0 && g.sem_att)) {
         if (fh.cost) {
             // nothing to evaluate outside the frustum (the unfused product is +0 there as well)
             disp = valid != 0.0f
@@ -187,6 +183,18 @@ __global__ __launch_bounds__(256) void f2v_kernel(F2vGeom g, const T *__restrict
             const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
             disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws) * valid;
         }
+    }
+    const float sdisp = g.st_att ? disp : 1.0f;   // x * 1.0f is exact: one code path
+    const float mdisp = g.sem_att ? disp : 1.0f;
+    const size_t vol = (size_t)g.D * g.H * g.W;
+    T *o = out + (size_t)b * (g.C + g.Cs) * N + i;
+    {
+        const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
+        const T *sv = stereo + (size_t)b * g.C * vol;
+        for (int ch = 0; ch < g.C; ++ch)
+            o[(size_t)ch * N] = elem<T>::store(tri_sample<T>(t, sv + ch * vol) * valid * sdisp);
+    }
+    if (g.Cs > 0) {
         const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
         const float v2d = valid2d ? 1.0f : 0.0f;
         const size_t plane = (size_t)g.Hsem * g.Wsem;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void f2v_kernel(F2vGeom g, const T *__restrict
         for (int ch = 0; ch < g.Cs; ++ch) {
             float s = tri_sample<T>(t2, sp + ch * plane);
             s = s * v2d;
-            o[(size_t)(g.C + ch) * N] = elem<T>::store(s * disp);
+            o[(size_t)(g.C + ch) * N] = elem<T>::store(s * mdisp);
         }
     }
 }
@@ -227,6 +235,24 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
     gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
     const float valid = (valid2d && gz >= -1.0f && gz <= 1.0f) ? 1.0f : 0.0f;
 
+    // pred_disp = grid_sample(stereo_feat_softmax) * valids, wanted when either attention is on
+    // (feature_transformation.py:133-139)
+    float disp = 1.0f;
+    if (g.st_att || (g.Cs > 0 && g.sem_att)) {
+        if (fh.cost) {
+            // nothing to evaluate outside the frustum (the unfused product is +0 there as well)
+            disp = valid != 0.0f
+                       ? fused_disp<T>(g, (const T *)fh.cost + (size_t)b * g.cd * g.ch * g.cw,
+                                       fh.col_max + (size_t)b * g.Hs * g.Ws,
+                                       fh.col_sum + (size_t)b * g.Hs * g.Ws, gx, gy, gz) * valid
+                       : 0.0f;
+        } else {
+            const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+            disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws) * valid;
+        }
+    }
+    const float sdisp = g.st_att ? disp : 1.0f;   // x * 1.0f is exact: one code path
+    const float mdisp = g.sem_att ? disp : 1.0f;
     T *o = out + (size_t)b * (g.C + g.Cs) * N + i;
     T *ocl = out + ((size_t)b * N + i) * (g.C + g.Cs);  // channels-last: this voxel's C + Cs values
     {
@@ -259,7 +285,7 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
                     if (blk0 + j < nblk) {
                         float r[CB];
 #pragma unroll
-                        for (int e = 0; e < CB; ++e) r[e] = acc[j][e] * valid;
+                        for (int e = 0; e < CB; ++e) r[e] = acc[j][e] * valid * sdisp;
                         store16<T>(ocl + (size_t)(blk0 + j) * CB, r);
                     }
             } else {
@@ -268,23 +294,11 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
 #pragma unroll
                     for (int e = 0; e < CB; ++e)
                         if (blk0 + j < nblk)
-                            o[(size_t)((blk0 + j) * CB + e) * N] = elem<T>::store(acc[j][e] * valid);
+                            o[(size_t)((blk0 + j) * CB + e) * N] = elem<T>::store(acc[j][e] * valid * sdisp);
             }
         }
     }
     if (g.Cs > 0) {
-        float disp;
-        if (fh.cost) {
-            // nothing to evaluate outside the frustum (the unfused product is +0 there as well)
-            disp = valid != 0.0f
-                       ? fused_disp<T>(g, (const T *)fh.cost + (size_t)b * g.cd * g.ch * g.cw,
-                                       fh.col_max + (size_t)b * g.Hs * g.Ws,
-                                       fh.col_sum + (size_t)b * g.Hs * g.Ws, gx, gy, gz) * valid
-                       : 0.0f;
-        } else {
-            const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
-            disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws) * valid;
-        }
         const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
         const float v2d = valid2d ? 1.0f : 0.0f;
         const int nblk = g.Cs / CB;
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
 #pragma unroll
                         for (int e = 0; e < CB; ++e) {
                             const float sval = acc[j][e] * v2d;
-                            r[e] = sval * disp;
+                            r[e] = sval * mdisp;
                         }
                         store16<T>(ocl + g.C + (size_t)(blk0 + j) * CB, r);
                     }
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
                     for (int e = 0; e < CB; ++e)
                         if (blk0 + j < nblk) {
                             float sval = acc[j][e] * v2d;
-                            o[(size_t)(g.C + (blk0 + j) * CB + e) * N] = elem<T>::store(sval * disp);
+                            o[(size_t)(g.C + (blk0 + j) * CB + e) * N] = elem<T>::store(sval * mdisp);
                         }
             }
         }
@@ -368,7 +382,8 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
         return set_error(DFM_ERR_INVALID_ARG, "non-positive size in dfm_f2v_desc");
     if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
         return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
-    if (!stereo || !coords || !cam2img || !out || (d->sem_channels > 0 && (!sem || (!softmax && !fh.cost))))
+    const bool want_disp = d->stereo_atten || (d->sem_channels > 0 && !d->no_sem_atten);
+    if (!stereo || !coords || !cam2img || !out || (d->sem_channels > 0 && !sem) || (want_disp && !softmax && !fh.cost))
         return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     if ((long long)d->ds * d->hs * d->ws >= (1ll << 31) || (long long)d->d * d->h * d->w >= (1ll << 31))
         return set_error(DFM_ERR_UNSUPPORTED, "volume too large for 32-bit corner offsets");
@@ -380,6 +395,8 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
     g.Nz = d->nz; g.Ny = d->ny; g.Nx = d->nx;
     g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.depth_min = d->depth_min; g.depth_span = d->depth_span;
     g.cd = g.ch = g.cw = 0;
+    g.st_att = d->stereo_atten ? 1 : 0;
+    g.sem_att = d->no_sem_atten ? 0 : 1;
     g.out_cl = d->out_channels_last ? 1 : 0;
     if (g.out_cl && !f2v_pixel_major(d))
         return set_error(DFM_ERR_UNSUPPORTED, "channels-last output needs channel counts of whole 16-byte blocks");
@@ -497,24 +514,30 @@ __global__ __launch_bounds__(256) void f2v_bwd_kernel(F2vGeom g, const T *__rest
     const bool valid = valid2d && gz >= -1.0f && gz <= 1.0f;
     const T *go = gout + (size_t)b * (g.C + g.Cs) * N + i;
     const size_t vol = (size_t)g.D * g.H * g.W;
+    float disp = 1.0f;  // pred_disp (detached): scales the gradients of the attended branches
+    if (valid && (g.st_att || (g.Cs > 0 && g.sem_att))) {
+        const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+        disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
+    }
     if (valid) {
         const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
         float *gs = gstereo + (size_t)b * g.C * vol;
+        const float sdisp = g.st_att ? disp : 1.0f;
         for (int ch = 0; ch < g.C; ++ch) {
-            const float gv = elem<T>::load(go[(size_t)ch * N]);
+            const float gv = elem<T>::load(go[(size_t)ch * N]) * sdisp;
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (t.ok & (1u << k)) atomicAdd(gs + (size_t)ch * vol + t.o[k], gv * t.w[k]);
         }
     }
-    if (g.Cs > 0 && valid) {  // Voxel_2D = sample(sem) * valid2d * (disp * valid)
-        const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
-        const float disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
+    // Voxel_2D = sample(sem) * valid2d (* disp * valid): without the attention the 2-D mask alone gates it
+    if (g.Cs > 0 && (g.sem_att ? valid : valid2d)) {
+        const float mdisp = g.sem_att ? disp : 1.0f;
         const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
         const size_t plane = (size_t)g.Hsem * g.Wsem;
         float *gm = gsem + (size_t)b * g.Cs * plane;
         for (int ch = 0; ch < g.Cs; ++ch) {
-            const float gv = elem<T>::load(go[(size_t)(g.C + ch) * N]) * disp;
+            const float gv = elem<T>::load(go[(size_t)(g.C + ch) * N]) * mdisp;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (t2.ok & (1u << k)) atomicAdd(gm + (size_t)ch * plane + t2.o[k], gv * t2.w[k]);
@@ -579,19 +602,26 @@ __global__ __launch_bounds__(256) void f2v_bwd_pm_kernel(F2vGeom g, const T *__r
             float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
             float gz = (xs - g.depth_min) / g.depth_span;
             gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
-            if (valid2d && gz >= -1.0f && gz <= 1.0f) {
+            const bool valid = valid2d && gz >= -1.0f && gz <= 1.0f;
+            float disp = 1.0f;
+            if (valid && (g.st_att || (g.Cs > 0 && g.sem_att))) {
+                const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+                disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
+            }
+            if (valid) {
                 const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
+                const float sdisp = g.st_att ? disp : 1.0f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (t.ok & (1u << k)) { f.st[k] = t.o[k]; f.sw[k] = t.w[k]; }
-                if (g.Cs > 0) {  // Voxel_2D = sample(sem) * valid2d * (disp * valid)
-                    const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
-                    const float disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
-                    const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
+                    if (t.ok & (1u << k)) { f.st[k] = t.o[k]; f.sw[k] = t.w[k] * sdisp; }
+            }
+            // Voxel_2D = sample(sem) * valid2d (* disp * valid)
+            if (g.Cs > 0 && (g.sem_att ? valid : valid2d)) {
+                const float mdisp = g.sem_att ? disp : 1.0f;
+                const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (t2.ok & (1u << k)) { f.sm[k] = t2.o[k]; f.mw[k] = t2.w[k] * disp; }
-                }
+                for (int k = 0; k < 4; ++k)
+                    if (t2.ok & (1u << k)) { f.sm[k] = t2.o[k]; f.mw[k] = t2.w[k] * mdisp; }
             }
         }
         foot[tid] = f;
@@ -647,7 +677,8 @@ extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const voi
     if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
     if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
         return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
-    if (!grad_out || !coords || !cam2img || !grad_stereo || (d->sem_channels > 0 && (!grad_sem || !softmax)))
+    if (!grad_out || !coords || !cam2img || !grad_stereo || (d->sem_channels > 0 && !grad_sem) ||
+        ((d->stereo_atten || (d->sem_channels > 0 && !d->no_sem_atten)) && !softmax))
         return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     F2vGeom g;
     g.C = d->channels; g.D = d->d; g.H = d->h; g.W = d->w;
@@ -655,6 +686,10 @@ extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const voi
     g.Cs = d->sem_channels; g.Hsem = d->hsem; g.Wsem = d->wsem;
     g.Nz = d->nz; g.Ny = d->ny; g.Nx = d->nx;
     g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.depth_min = d->depth_min; g.depth_span = d->depth_span;
+    g.cd = g.ch = g.cw = 0;
+    g.out_cl = 0;
+    g.st_att = d->stereo_atten ? 1 : 0;
+    g.sem_att = d->no_sem_atten ? 0 : 1;
     const long long N = (long long)d->nz * d->ny * d->nx;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)(d->channels + d->sem_channels) * (F2V_VT + 1) * sizeof(float) +

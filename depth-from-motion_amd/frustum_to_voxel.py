@@ -66,7 +66,8 @@ def _alloc_out(desc, stereo):
 
 
 def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem_feats,
-                            coordinates_3d, depth_cfg, memory_format=None):
+                            coordinates_3d, depth_cfg, memory_format=None, sem_atten_feat=True,
+                            stereo_atten_feat=False):
     """
     Args:
         stereo_feat: (B, C, D, H, W) cost-volume features
@@ -77,6 +78,9 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
         cur_sem_feats: (B, Cs, H, W) or None (cat_img_feature=False)
         coordinates_3d: (Nz, Ny, Nx, 3) voxel centres in pseudo-LiDAR coordinates
         depth_cfg: dict with 'depth_min', 'depth_max'
+        sem_atten_feat, stereo_atten_feat: the module's switches (feature_transformation.py:141,154):
+            weight Voxel_2D / Voxel by the sampled depth distribution; with neither on the
+            distribution is not touched (``stereo_feat_softmax`` may be None)
         memory_format: layout of the result; default: channels_last_3d when stereo_feat is (the
             NDHWC stack: voxel_convs' MFMA convolution reads it in place), else contiguous
     Returns:
@@ -103,20 +107,26 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     desc.out_channels_last = 1 if (memory_format == torch.channels_last_3d and C % vec == 0 and
                                    cs % vec == 0) else 0
     sem = soft = lazy = None
+    desc.stereo_atten = 1 if stereo_atten_feat else 0
+    desc.no_sem_atten = 0 if sem_atten_feat else 1
     if cur_sem_feats is not None:
         sem = cur_sem_feats.to(stereo.dtype).contiguous()
+        desc.sem_channels, desc.hsem, desc.wsem = sem.shape[1:]
+    if stereo_atten_feat or (sem is not None and sem_atten_feat):  # pred_disp is wanted (:133)
         if isinstance(stereo_feat_softmax, LazyDepthDistribution):
             lazy = stereo_feat_softmax
             if lazy.dtype != stereo.dtype:
                 raise TypeError('the fused depth head needs cost and stereo_feat in the same dtype')
-            if torch.is_grad_enabled() and (stereo_feat.requires_grad or cur_sem_feats.requires_grad):
+            if torch.is_grad_enabled() and (stereo_feat.requires_grad or
+                                            (cur_sem_feats is not None and cur_sem_feats.requires_grad)):
                 raise RuntimeError('the fused DepthHead -> FrustumToVoxel path is inference only '
                                    '(training materialises the distribution for DepthHead.loss)')
             desc.ds, desc.hs, desc.ws = lazy.shape[2:]
         else:
             soft = stereo_feat_softmax.detach().to(stereo.dtype).contiguous()
             desc.ds, desc.hs, desc.ws = soft.shape[2:]
-        desc.sem_channels, desc.hsem, desc.wsem = sem.shape[1:]
+    else:
+        desc.ds = desc.hs = desc.ws = 1
     coords = coordinates_3d.to(device=device, dtype=torch.float32).contiguous()
     desc.nz, desc.ny, desc.nx = coords.shape[:3]
     pad_shape = img_metas[0]['pad_shape']  # the reference uses sample 0's for all (:101)
@@ -136,7 +146,7 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
         with torch.cuda.device(device):
             _capi.check(lib.dfm_frustum_to_voxel_fused_fwd(
                 ctypes.byref(desc), _ptr(stereo.detach()), _ptr(lazy.cost), _ptr(lazy.col_max),
-                _ptr(lazy.col_sum), lazy.scale, _ptr(sem.detach()), _ptr(coords), _ptr(cam4), _ptr(out),
+                _ptr(lazy.col_sum), lazy.scale, _ptr(sem.detach()) if sem is not None else None, _ptr(coords), _ptr(cam4), _ptr(out),
                 _ptr(ws), nbytes, _stream_ptr(device)))
         return out
     return _F2vFn.apply(stereo, sem, soft, coords, cam4, desc)

@@ -192,28 +192,30 @@ def _conv3(cin, cout, norm_cfg, act=True, stride=1, padding=1):
 # --------------------------------------------------------------------------
 # hourglass (conv_modules.py:73-149): keys conv1.0.0, conv2.0, ..., conv5.0/1
 # --------------------------------------------------------------------------
-def _convgn3d(cin, cout, stride):
-    return nn.Sequential(MfmaConv3dG(cin, cout, 3, stride=stride, padding=1, bias=False),
-                         HipGroupNorm(32, cout))
+def _norm3d(channels, gn):
+    # conv_modules.py:42-43,113-127: GroupNorm(32, C) or (Sync)BatchNorm3d -- same state_dict keys
+    return HipGroupNorm(32, channels) if gn else HipBatchNorm3d(channels)
+
+
+def _convgn3d(cin, cout, stride, gn=True):
+    return nn.Sequential(MfmaConv3dG(cin, cout, 3, stride=stride, padding=1, bias=False), _norm3d(cout, gn))
 
 
 class hourglass(nn.Module):  # noqa: N801  (reference class name)
 
     def __init__(self, inplanes, gn=True):
         super().__init__()
-        if not gn:
-            raise NotImplementedError('DfM builds its hourglass with GroupNorm (dfm_backbone.py:37,70)')
         c = inplanes
-        self.conv1 = nn.Sequential(_convgn3d(c, 2 * c, 2), nn.ReLU(inplace=True))
-        self.conv2 = _convgn3d(2 * c, 2 * c, 1)
-        self.conv3 = nn.Sequential(_convgn3d(2 * c, 2 * c, 2), nn.ReLU(inplace=True))
-        self.conv4 = nn.Sequential(_convgn3d(2 * c, 2 * c, 1), nn.ReLU(inplace=True))
+        self.conv1 = nn.Sequential(_convgn3d(c, 2 * c, 2, gn), nn.ReLU(inplace=True))
+        self.conv2 = _convgn3d(2 * c, 2 * c, 1, gn)
+        self.conv3 = nn.Sequential(_convgn3d(2 * c, 2 * c, 2, gn), nn.ReLU(inplace=True))
+        self.conv4 = nn.Sequential(_convgn3d(2 * c, 2 * c, 1, gn), nn.ReLU(inplace=True))
         self.conv5 = nn.Sequential(
             MfmaConvTranspose3d(2 * c, 2 * c, 3, padding=1, output_padding=1, stride=2, bias=False),
-            HipGroupNorm(32, 2 * c))
+            _norm3d(2 * c, gn))
         self.conv6 = nn.Sequential(
             MfmaConvTranspose3d(2 * c, c, 3, padding=1, output_padding=1, stride=2, bias=False),
-            HipGroupNorm(32, c))
+            _norm3d(c, gn))
 
     def forward(self, x, presqu, postsqu):
         # GroupNorm and the ReLU that follows it are one pass of the fused kernel
@@ -415,9 +417,6 @@ class FrustumToVoxel(nn.Module):
                  sem_atten_feat=True, stereo_atten_feat=False, cat_img_feature=True,
                  norm_cfg=dict(type='GN', num_groups=32, requires_grad=True), init_cfg=None):
         super().__init__()
-        if stereo_atten_feat or (cat_img_feature and not sem_atten_feat):
-            raise NotImplementedError('only the shipped setting: sem_atten_feat=True, '
-                                      'stereo_atten_feat=False')
         self.GN = True
         self.num_3dconvs = num_3dconvs
         self.cv_channels = cv_channels
@@ -450,7 +449,9 @@ class FrustumToVoxel(nn.Module):
     def forward(self, stereo_feat, stereo_feat_softmax, img_metas, cur_sem_feats=None):
         voxel = frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas,
                                         cur_sem_feats if self.cat_img_feature else None,
-                                        self._coords_on(stereo_feat.device), self.depth_cfg)
+                                        self._coords_on(stereo_feat.device), self.depth_cfg,
+                                        sem_atten_feat=self.sem_atten_feat,
+                                        stereo_atten_feat=self.stereo_atten_feat)
         return _depth_pool4(self.voxel_pool, self.voxel_convs(voxel))
 
 
@@ -575,9 +576,9 @@ class upconv_module(nn.Module):  # noqa: N801  (reference class name)
 
 
 def _gn_relu(seq, x, relu, residual=None):
-    """conv -> norm (+residual) (+ReLU), one pass when the norm is the HIP GroupNorm"""
+    """conv -> norm (+residual) (+ReLU), one pass when the norm is the HIP GroupNorm / BatchNorm3d"""
     x = seq[0](x)
-    if isinstance(seq[1], HipGroupNorm):
+    if isinstance(seq[1], (HipGroupNorm, HipBatchNorm3d)):
         return seq[1](x, relu=relu, residual=residual)
     x = seq[1](x)
     if residual is not None:

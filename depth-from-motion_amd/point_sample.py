@@ -85,9 +85,47 @@ def _make_desc(feats, npoints, nxyz, num_views, num_frames, scale, crop, flip, p
     return desc
 
 
+def _reverse_3d_flow(points, coord_type, img_meta):
+    """``apply_3d_transformation(points, coord_type, img_meta, reverse=True)``
+    (fusion_layers/coord_transform.py:9-95) on the device, operation by operation in the
+    reference's order: the recorded ``transformation_3d_flow`` undone back to front -- 'T' adds
+    -pcd_trans, 'S' multiplies by 1/pcd_scale_factor, 'R' multiplies by inverse(pcd_rotation) from
+    the right (as an explicit fp32 multiply-add chain over x, y, z, not a BLAS call), 'HF' / 'VF'
+    negate the BEV axes of the coordinate type (core/points/{lidar,cam,depth}_points.py flip).
+    Returns ``points`` itself when there is nothing to undo."""
+    flow = (img_meta or {}).get('transformation_3d_flow') or []
+    if not flow:
+        return points
+    axes = {'LIDAR': (1, 0), 'CAMERA': (0, 2), 'DEPTH': (0, 1)}[coord_type]  # (horizontal, vertical)
+    p = points.clone()
+    for op in flow[::-1]:
+        if op == 'T':
+            t = torch.as_tensor(img_meta.get('pcd_trans', [0.0, 0.0, 0.0]), dtype=torch.float32)
+            p[:, :3] += (-t).to(p.device)
+        elif op == 'S':
+            p[:, :3] *= 1.0 / img_meta.get('pcd_scale_factor', 1.0)
+        elif op == 'R':
+            r = torch.as_tensor(img_meta['pcd_rotation'], dtype=torch.float32) if 'pcd_rotation' in img_meta \
+                else torch.eye(3)
+            ri = torch.inverse(r).to(p.device)
+            x, y, z = p[:, 0].clone(), p[:, 1].clone(), p[:, 2].clone()
+            for j in range(3):
+                p[:, j] = torch.addcmul(torch.addcmul(x * ri[0, j], y, ri[1, j]), z, ri[2, j])
+        elif op == 'HF':
+            if img_meta.get('pcd_horizontal_flip', False):
+                p[:, axes[0]] = -p[:, axes[0]]
+        elif op == 'VF':
+            if img_meta.get('pcd_vertical_flip', False):
+                p[:, axes[1]] = -p[:, axes[1]]
+        else:
+            raise KeyError(f'unknown transformation_3d_flow entry {op!r}')
+    return p
+
+
 class _MvFn(torch.autograd.Function):
     """feats (B, F*Nv, C, Hf, Wf); one launch per sample (its own image transform in
-    ``descs[b]``) straight into one (B, ...) output; proj (B, F*Nv, 16), ori_w (B, F*Nv)."""
+    ``descs[b]``) straight into one (B, ...) output; proj (B, F*Nv, 16), ori_w (B, F*Nv);
+    points (N, 3) shared by the batch or (B, N, 3) per sample (3-D augmentation flows)."""
 
     @staticmethod
     def forward(ctx, feats, points, proj, ori_w, descs, nxyz, want_valid, channels_last=False):
@@ -104,14 +142,15 @@ class _MvFn(torch.autograd.Function):
         elif nxyz is not None:
             out = torch.empty((B, c_out) + tuple(nxyz), dtype=feats.dtype, device=device)
         else:
-            out = torch.empty((B, points.shape[0], c_out), dtype=feats.dtype, device=device)
-        valid = torch.empty((B, points.shape[0]), dtype=torch.uint8, device=device) if want_valid else None
+            out = torch.empty((B, points.shape[-2], c_out), dtype=feats.dtype, device=device)
+        valid = torch.empty((B, points.shape[-2]), dtype=torch.uint8, device=device) if want_valid else None
         nbytes = lib.dfm_point_sample_mv_workspace_bytes(ctypes.byref(d0))
         ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
             for b in range(B):
                 _capi.check(
-                    lib.dfm_point_sample_mv_fwd(ctypes.byref(descs[b]), _ptr(feats[b]), _ptr(points),
+                    lib.dfm_point_sample_mv_fwd(ctypes.byref(descs[b]), _ptr(feats[b]),
+                                                _ptr(points[b] if points.dim() == 3 else points),
                                                 _ptr(proj[b]), _ptr(ori_w[b]), _ptr(out[b]),
                                                 _ptr(valid[b]) if want_valid else None, _ptr(ws),
                                                 nbytes, _stream_ptr(device)))
@@ -135,7 +174,8 @@ class _MvFn(torch.autograd.Function):
         with torch.cuda.device(device):
             for b in range(shape[0]):
                 _capi.check(
-                    lib.dfm_point_sample_mv_bwd(ctypes.byref(ctx.descs[b]), _ptr(go[b]), _ptr(points),
+                    lib.dfm_point_sample_mv_bwd(ctypes.byref(ctx.descs[b]), _ptr(go[b]),
+                                                _ptr(points[b] if points.dim() == 3 else points),
                                                 _ptr(proj[b]), _ptr(ori_w[b]), _ptr(gf[b]), _ptr(ws),
                                                 nbytes, _stream_ptr(device)))
         return gf.to(dtype), None, None, None, None, None, None, None
@@ -159,13 +199,12 @@ def point_sample(img_meta,
     [+ (N,) bool validity when ``valid_flag``]."""
     if padding_mode != 'zeros' or not align_corners:
         raise NotImplementedError('only padding_mode="zeros", align_corners=True (what DfM uses)')
-    if img_meta is not None and img_meta.get('transformation_3d_flow'):
-        raise NotImplementedError('3-D augmentation flows are not part of the DfM multi-view path')
     _require_gpu(img_features, 'img_features')
     assert img_features.dim() == 4 and img_features.shape[0] == 1
     device = img_features.device
     feats = img_features.contiguous()
     pts = torch.as_tensor(points, dtype=torch.float32).to(device).contiguous()
+    pts = _reverse_3d_flow(pts, coord_type, img_meta).contiguous()  # point_fusion.py:57-58
     proj = torch.as_tensor(proj_mat, dtype=torch.float32).reshape(1, 16).to(device).contiguous()
     ori_w = torch.tensor([float(img_shape[1])], dtype=torch.float32, device=device)
     desc = _make_desc(feats, pts.shape[0], None, 1, 1, _scale_xy(img_scale_factor),
@@ -208,6 +247,9 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
     # one upload for the whole batch's matrices
     proj = _upload(torch.from_numpy(np.stack(proj)), device)
     ori_w = _upload(torch.tensor(ori_w, dtype=torch.float32), device)
+    if any(m.get('transformation_3d_flow') for m in img_metas):
+        # point_sample undoes each sample's own 3-D augmentation first (point_fusion.py:57-58)
+        points = torch.stack([_reverse_3d_flow(points, 'LIDAR', m) for m in img_metas]).contiguous()
     out, _ = _MvFn.apply(feats, points, proj, ori_w, descs, nxyz, False,
                          memory_format == torch.channels_last_3d)
     return out

@@ -319,6 +319,10 @@ typedef struct dfm_f2v_desc {
     int32_t out_channels_last; /* forward only: out is (B, nz, ny, nx, C + Cs) in memory (torch
                             * channels_last_3d), what voxel_convs' MFMA convolution reads;
                             * needs channel counts of whole 16-byte blocks                   */
+    int32_t stereo_atten;  /* 1: stereo_atten_feat=True, Voxel *= pred_disp (feature_transformation.py:141) */
+    int32_t no_sem_atten;  /* 1: sem_atten_feat=False, Voxel_2D is NOT weighted by pred_disp (:154);
+                            * both 0 = the shipped config; when neither attention is on, softmax may
+                            * be NULL (the reference never samples it, :133)                           */
 } dfm_f2v_desc;
 
 /*

@@ -316,6 +316,8 @@ typedef struct {
     float depth_min;     /* coordinate offset  (fp32 of the python number)    */
     float depth_span;    /* fp32(depth_max - depth_min)                       */
     float P[12];         /* cam2img[:3] (3x4), row major                      */
+    int32_t stereo_atten;      /* stereo_atten_feat (:141-142): Voxel *= pred_disp           */
+    int32_t no_sem_atten;      /* sem_atten_feat=False (:154-155): Voxel_2D not depth-weighted */
 } dfm_oracle_f2v_params;
 
 static inline float trilinear(const float *vol, int D, int H, int W, float gx, float gy, float gz)
@@ -376,18 +378,23 @@ ORACLE_API void dfm_oracle_frustum_to_voxel(const dfm_oracle_f2v_params *p, cons
         gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
         /* :125-127 */
         const float valid = (valid2d && gz >= -1.0f && gz <= 1.0f) ? 1.0f : 0.0f;
-        /* :130-139 */
-        for (int ch = 0; ch < p->C; ++ch)
-            out[(size_t)ch * N + i] =
-                trilinear(stereo + ch * vol, p->D, p->H, p->W, gx, gy, gz) * valid;
+        /* :130-139: pred_disp only when one of the attentions wants it */
+        float disp = 1.0f;
+        if (p->stereo_atten || (p->Csem > 0 && !p->no_sem_atten))
+            disp = trilinear(soft, p->Ds, p->Hs, p->Ws, gx, gy, gz) * valid;
+        for (int ch = 0; ch < p->C; ++ch) {
+            float s3 = trilinear(stereo + ch * vol, p->D, p->H, p->W, gx, gy, gz) * valid;
+            if (p->stereo_atten) s3 = s3 * disp; /* :141-142 */
+            out[(size_t)ch * N + i] = s3;
+        }
         if (p->Csem > 0) {
-            const float disp = trilinear(soft, p->Ds, p->Hs, p->Ws, gx, gy, gz) * valid;
             const float v2d = valid2d ? 1.0f : 0.0f;
             /* :146-155 semantic feature at z := 0, masked, depth-weighted */
             for (int ch = 0; ch < p->Csem; ++ch) {
                 float s2 = trilinear(sem + ch * semplane, 1, p->Hsem, p->Wsem, gx, gy, 0.0f);
                 s2 = s2 * v2d;
-                out[(size_t)(p->C + ch) * N + i] = s2 * disp;
+                if (!p->no_sem_atten) s2 = s2 * disp;
+                out[(size_t)(p->C + ch) * N + i] = s2;
             }
         }
     }

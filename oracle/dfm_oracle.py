@@ -173,11 +173,12 @@ class F2VParams(ctypes.Structure):
                 ('Wsem', ctypes.c_int32), ('Nz', ctypes.c_int32), ('Ny', ctypes.c_int32),
                 ('Nx', ctypes.c_int32), ('pad_h', ctypes.c_float), ('pad_w', ctypes.c_float),
                 ('depth_min', ctypes.c_float), ('depth_span', ctypes.c_float),
-                ('P', ctypes.c_float * 12)]
+                ('P', ctypes.c_float * 12), ('stereo_atten', ctypes.c_int32),
+                ('no_sem_atten', ctypes.c_int32)]
 
 
 def frustum_to_voxel(stereo, softmax, sem, coordinates_3d, cam2img, pad_shape, depth_min,
-                     depth_max):
+                     depth_max, sem_atten_feat=True, stereo_atten_feat=False):
     """Sampling stage of FrustumToVoxel.forward (feature_transformation.py:82-158):
     stereo (B,C,D,H,W), softmax (B,1,Ds,Hs,Ws), sem (B,Cs,H,W) or None, cam2img (B,4,4)
     -> (B, C+Cs, Nz, Ny, Nx).  pad_shape of sample 0 is used for all (reference :101)."""
@@ -192,6 +193,7 @@ def frustum_to_voxel(stereo, softmax, sem, coordinates_3d, cam2img, pad_shape, d
         p.C, p.D, p.H, p.W = C, D, H, W
         p.Ds, p.Hs, p.Ws = softmax.shape[2:]
         p.Csem = cs
+        p.stereo_atten, p.no_sem_atten = int(bool(stereo_atten_feat)), int(not sem_atten_feat)
         if cs:
             p.Hsem, p.Wsem = sem.shape[2:]
         p.Nz, p.Ny, p.Nx = nz, ny, nx

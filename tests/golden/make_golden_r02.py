@@ -250,6 +250,20 @@ def make_wide_modules():
         y, pre, post = m(x['hg'], None, None)
     out.update(hg_out=y.numpy(), hg_pre=pre.numpy(), hg_post=post.numpy(),
                hg_keys=np.array(list(m.state_dict().keys())))
+    # hourglass(gn=False): (Sync)BatchNorm3d instead of GroupNorm (conv_modules.py:42,113,126); eval mode.
+    # SyncBatchNorm refuses CPU tensors even in eval mode, so its instances are swapped for
+    # BatchNorm3d holding the same parameters and buffers (eval forward is the same F.batch_norm).
+    m = cm.hourglass(32, gn=False).eval()
+    m.load_state_dict(util.synthetic_state_dict(m, 64))
+    out['hgbn_keys'] = np.array(list(m.state_dict().keys()))
+    for seq in (m.conv1[0], m.conv2, m.conv3[0], m.conv4[0]):
+        sbn = seq[1]
+        bn = torch.nn.BatchNorm3d(sbn.num_features).eval()
+        bn.load_state_dict(sbn.state_dict())
+        seq[1] = bn
+    with torch.no_grad():
+        y, pre, post = m(x['hg'], None, None)
+    out.update(hgbn_out=y.numpy(), hgbn_pre=pre.numpy(), hgbn_post=post.numpy())
     m = ref['imvoxel_neck'].OutdoorImVoxelNeck(in_channels=64, out_channels=256).eval()
     m.load_state_dict(util.synthetic_state_dict(m, 62))
     with torch.no_grad():
@@ -262,10 +276,110 @@ def make_wide_modules():
     print('wide modules:', {k: v.shape for k, v in out.items() if k != 'hg_keys'})
 
 
+def make_f2v_variants():
+    """FrustumToVoxel's attention switches (feature_transformation.py:141-142,154-155) on the
+    inputs of f2v_small.npz / f2v_batch2.npz: the sampled volume of the REFERENCE module
+    (voxel_convs / voxel_pool replaced by identities, like make_golden.py:make_f2v)."""
+    import ref_stubs
+    ref_stubs.install()
+    ft = ref_stubs.load_file('mmdet3d/models/necks/feature_transformation.py', 'ref_ft_variants')
+    torch.Tensor.cuda = lambda self, *a, **k: self  # feature_transformation.py:82,93 hard-code .cuda()
+    out = {}
+    for name in ('f2v_small', 'f2v_batch2'):
+        z = np.load(os.path.join(HERE, name + '.npz'))
+        C = z['stereo'].shape[1]
+        metas = [{'cam2img': c.tolist(), 'pad_shape': tuple(int(v) for v in z['pad_shape']) + (3,)}
+                 for c in z['cam2img']]
+        for tag, kw in (('stereo_sem', dict(stereo_atten_feat=True, sem_atten_feat=True)),
+                        ('none', dict(stereo_atten_feat=False, sem_atten_feat=False)),
+                        ('stereo_only', dict(stereo_atten_feat=True, sem_atten_feat=False)),
+                        ('stereo_nocat', dict(stereo_atten_feat=True, cat_img_feature=False))):
+            m = ft.FrustumToVoxel(cv_channels=C, out_channels=C, in_sem_channels=C,
+                                  norm_cfg=dict(type='GN', num_groups=1, requires_grad=True), **kw)
+            m.voxel_convs = torch.nn.Identity()
+            m.voxel_pool = torch.nn.Identity()
+            m.coordinates_3d = torch.from_numpy(z['coordinates_3d'])
+            m.depth_cfg = dict(depth_min=float(z['depth_min']), depth_max=float(z['depth_max']))
+            with torch.no_grad():
+                y = m(torch.from_numpy(z['stereo']), torch.from_numpy(z['softmax']), metas,
+                      torch.from_numpy(z['sem']) if kw.get('cat_img_feature', True) else None)
+            out[f'{name}__{tag}'] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, 'frustum_atten_variants.npz'), **out)
+    print('f2v variants:', {k: v.shape for k, v in out.items()})
+
+
+FLOW_METAS = {  # coord_type, img_meta: every entry of transformation_3d_flow (coord_transform.py:19-24)
+    'lidar_rsthf': ('LIDAR', dict(transformation_3d_flow=['R', 'S', 'T', 'HF'],
+                                  pcd_rotation=[[0.9801, -0.1987, 0.0], [0.1987, 0.9801, 0.0], [0.0, 0.0, 1.0]],
+                                  pcd_scale_factor=1.05, pcd_trans=[0.1, -0.2, 0.05], pcd_horizontal_flip=True)),
+    'lidar_hf_vf_st': ('LIDAR', dict(transformation_3d_flow=['HF', 'VF', 'S', 'T'], pcd_scale_factor=0.96,
+                                     pcd_trans=[-0.3, 0.4, 0.0], pcd_horizontal_flip=True,
+                                     pcd_vertical_flip=True)),
+    'lidar_hf_st': ('LIDAR', dict(transformation_3d_flow=['HF', 'S', 'T'], pcd_scale_factor=0.96,
+                                  pcd_trans=[-0.3, 0.4, 0.0], pcd_horizontal_flip=True)),
+    'camera_hf_vf': ('CAMERA', dict(transformation_3d_flow=['HF', 'VF', 'S'], pcd_scale_factor=1.02,
+                                    pcd_horizontal_flip=True, pcd_vertical_flip=True)),
+    'depth_vf_unset_hf': ('DEPTH', dict(transformation_3d_flow=['T', 'HF', 'VF'], pcd_trans=[0.5, 0.25, -0.125],
+                                        pcd_horizontal_flip=False, pcd_vertical_flip=True)),
+}
+
+
+def make_point_sample_flow():
+    """point_sample with a 3-D augmentation flow in img_meta (point_fusion.py:57-58 ->
+    coord_transform.py:9-95): the REAL apply_3d_transformation / points classes of the reference
+    (make_golden.py stubbed it with the identity: its fixtures carry no flow)."""
+    import types
+    import importlib.util
+    import ref_stubs
+    import make_golden as mg
+    ref_stubs.install()
+    R = ref_stubs.REF_ROOT
+    ac = ref_stubs.load_file('mmdet3d/core/utils/array_converter.py', 'mmdet3d.core.utils.array_converter')
+    cu = types.ModuleType('mmdet3d.core.utils')
+    cu.array_converter, cu.__path__ = ac.array_converter, []
+    sys.modules['mmdet3d.core.utils'] = cu
+    for n in ('mmdet3d.core.bbox', 'mmdet3d.core.bbox.structures'):
+        if n not in sys.modules:
+            m = types.ModuleType(n)
+            m.__path__ = []
+            sys.modules[n] = m
+    ref_stubs.load_file('mmdet3d/core/bbox/structures/utils.py', 'mmdet3d.core.bbox.structures.utils')
+    spec = importlib.util.spec_from_file_location('mmdet3d.core.points', f'{R}/mmdet3d/core/points/__init__.py',
+                                                  submodule_search_locations=[f'{R}/mmdet3d/core/points'])
+    m = importlib.util.module_from_spec(spec)
+    sys.modules['mmdet3d.core.points'] = m
+    spec.loader.exec_module(m)
+    ct = ref_stubs.load_file('mmdet3d/models/fusion_layers/coord_transform.py', 'ref_coord_transform')
+    g = mg.load_reference()
+    g['apply_3d_transformation'] = ct.apply_3d_transformation
+    mg.extract(mg.REF + 'models/fusion_layers/point_fusion.py', ['point_sample'], g)
+    gen = torch.Generator().manual_seed(70)
+    pts = torch.rand(400, 3, generator=gen) * torch.tensor([30.0, 30.0, 3.0]) + torch.tensor([4.0, -15.0, -2.0])
+    out = dict(points=pts.numpy())
+    for name, (ctype, meta) in FLOW_METAS.items():
+        out[f'rev__{name}'] = ct.apply_3d_transformation(pts, ctype, meta, reverse=True).numpy()
+    lidar2img = torch.tensor([[6.0294e+02, -7.0791e+02, -1.2275e+01, -1.7094e+02],
+                              [1.7678e+02, 8.8088e+00, -7.0794e+02, -1.0257e+02],
+                              [9.9998e-01, -1.5283e-03, -5.2907e-03, -3.2757e-01],
+                              [0.0, 0.0, 0.0, 1.0]])
+    img = torch.randn(1, 5, 46, 153, generator=gen)
+    out['ps_img'], out['ps_lidar2img'] = img.numpy(), lidar2img.numpy()
+    for name in ('lidar_rsthf', 'lidar_hf_st'):
+        meta = FLOW_METAS[name][1]
+        for aligned in (True, False):
+            feat, valid = g['point_sample'](meta, img, pts, lidar2img, 'LIDAR', pts.new_tensor([0.125, 0.125]),
+                                            pts.new_tensor([1.0, 0.5]), False, (46, 153), (46, 153),
+                                            aligned=aligned, valid_flag=True)
+            out[f'ps__{name}__{int(aligned)}'] = feat.numpy()
+            out[f'psvalid__{name}__{int(aligned)}'] = valid.numpy()
+    np.savez_compressed(os.path.join(HERE, 'point_sample_flow.npz'), **out)
+    print('point_sample flow:', {k: (v.shape, float(np.mean(v != 0))) for k, v in out.items() if k.startswith('ps__')})
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF_ROOT):
         sys.exit('reference not mounted; fixtures are committed, nothing to do')
-    which = sys.argv[1:] or ['depth_loss', 'configs', 'cfg1', 'bev_spp', 'wide']
+    which = sys.argv[1:] or ['depth_loss', 'configs', 'cfg1', 'bev_spp', 'wide', 'f2v_variants', 'ps_flow']
     torch.set_num_threads(1)
     if 'depth_loss' in which:
         make_depth_loss()
@@ -277,3 +391,7 @@ if __name__ == '__main__':
         make_bev_spp()
     if 'wide' in which:
         make_wide_modules()
+    if 'f2v_variants' in which:
+        make_f2v_variants()
+    if 'ps_flow' in which:
+        make_point_sample_flow()

@@ -67,7 +67,7 @@ def test_depth_head_backward_tiles(pkg, shape, scale):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-5)
 
 
-def _f2v_torch(stereo, soft, sem, coords, cam2img, pad, dmin, dmax):
+def _f2v_torch(stereo, soft, sem, coords, cam2img, pad, dmin, dmax, sem_atten=True, stereo_atten=False):
     """feature_transformation.py:82-158 with torch ops (test-side restatement)."""
     outs = []
     for b in range(stereo.shape[0]):
@@ -86,8 +86,41 @@ def _f2v_torch(stereo, soft, sem, coords, cam2img, pad, dmin, dmax):
         g2 = g.clone()
         g2[..., 2] = 0
         v2 = F.grid_sample(sem[b:b + 1].unsqueeze(2), g2, align_corners=True) * v2d.float()[None, None]
-        outs.append(torch.cat([vox, v2 * disp], 1))
+        if stereo_atten:
+            vox = vox * disp
+        outs.append(torch.cat([vox, v2 * disp if sem_atten else v2], 1))
     return torch.cat(outs)
+
+
+@pytest.mark.parametrize('sem_atten,stereo_atten', [(True, True), (False, False), (False, True)])
+@pytest.mark.parametrize('channels', [3, 8])
+def test_frustum_to_voxel_backward_attention_switches(pkg, channels, sem_atten, stereo_atten):
+    """gradients with stereo_atten_feat / sem_atten_feat (feature_transformation.py:141,154) through
+    both backward kernels (scalar: 3 channels; pixel-major scratch: 8)"""
+    z = np.load(os.path.join(util.GOLDEN, 'f2v_batch2.npz'))
+    reps = channels // z['stereo'].shape[1] + 1
+    rng = np.random.RandomState(7)
+    stereo = torch.from_numpy(np.tile(z['stereo'], (1, reps, 1, 1, 1))[:, :channels] *
+                              rng.rand(1, channels, 1, 1, 1).astype(np.float32)).contiguous()
+    sem = torch.from_numpy(np.tile(z['sem'], (1, reps, 1, 1))[:, :channels] *
+                           rng.rand(1, channels, 1, 1).astype(np.float32)).contiguous()
+    soft = torch.from_numpy(z['softmax'])
+    coords, cam = torch.from_numpy(z['coordinates_3d']), torch.from_numpy(z['cam2img'])
+    pad = tuple(int(v) for v in z['pad_shape'])
+    sr, mr = stereo.clone().requires_grad_(True), sem.clone().requires_grad_(True)
+    ref = _f2v_torch(sr, soft, mr, coords, cam, pad, float(z['depth_min']), float(z['depth_max']),
+                     sem_atten, stereo_atten)
+    go = torch.from_numpy(rng.randn(*ref.shape).astype(np.float32))
+    (ref * go).sum().backward()
+    sg, mg = stereo.cuda().requires_grad_(True), sem.cuda().requires_grad_(True)
+    metas = [{'cam2img': c.tolist(), 'pad_shape': pad + (3,)} for c in z['cam2img']]
+    out = pkg.frustum_to_voxel_sample(sg, soft.cuda(), metas, mg, coords,
+                                      dict(depth_min=float(z['depth_min']), depth_max=float(z['depth_max'])),
+                                      sem_atten_feat=sem_atten, stereo_atten_feat=stereo_atten)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    (out * go.cuda()).sum().backward()
+    np.testing.assert_allclose(sg.grad.cpu().numpy(), sr.grad.numpy(), **TOL)
+    np.testing.assert_allclose(mg.grad.cpu().numpy(), mr.grad.numpy(), **TOL)
 
 
 def test_frustum_to_voxel_backward(pkg):

@@ -33,7 +33,28 @@ def test_oracle_bitexact_vs_reference_module(path):
     assert 0.05 < (z['ref_out'][:, :C] == 0).mean() < 0.95
 
 
-def hip_run(z, dtype=torch.float32, sem=True, stereo_format=torch.contiguous_format):
+VARIANTS = {  # tag in tests/golden/frustum_atten_variants.npz -> the module's switches
+    'stereo_sem': dict(stereo_atten_feat=True, sem_atten_feat=True),
+    'none': dict(stereo_atten_feat=False, sem_atten_feat=False),
+    'stereo_only': dict(stereo_atten_feat=True, sem_atten_feat=False),
+    'stereo_nocat': dict(stereo_atten_feat=True, sem_atten_feat=True),  # cat_img_feature=False
+}
+
+
+@pytest.mark.parametrize('tag', sorted(VARIANTS))
+@pytest.mark.parametrize('name', ['f2v_small', 'f2v_batch2'])
+def test_oracle_attention_switches_bitexact_vs_reference_module(name, tag):
+    """stereo_atten_feat / sem_atten_feat (feature_transformation.py:141-142,154-155) against the
+    sampled volume of the reference module built with those switches (make_golden_r02.py)."""
+    z = np.load(os.path.join(util.GOLDEN, name + '.npz'))
+    ref = np.load(os.path.join(util.GOLDEN, 'frustum_atten_variants.npz'))[f'{name}__{tag}']
+    out = orc.frustum_to_voxel(z['stereo'], z['softmax'], None if tag == 'stereo_nocat' else z['sem'],
+                               z['coordinates_3d'], z['cam2img'], z['pad_shape'],
+                               float(z['depth_min']), float(z['depth_max']), **VARIANTS[tag])
+    assert np.array_equal(util.bits(out), util.bits(ref))
+
+
+def hip_run(z, dtype=torch.float32, sem=True, stereo_format=torch.contiguous_format, **kw):
     pkg = importlib.import_module('depth-from-motion_amd')
     dev = torch.device('cuda:0')
     metas = [{'cam2img': c.tolist(), 'pad_shape': tuple(int(v) for v in z['pad_shape']) + (3,)}
@@ -43,9 +64,32 @@ def hip_run(z, dtype=torch.float32, sem=True, stereo_format=torch.contiguous_for
         torch.from_numpy(z['softmax']).to(dev).to(dtype),
         metas, torch.from_numpy(z['sem']).to(dev).to(dtype) if sem else None,
         torch.from_numpy(z['coordinates_3d']),
-        dict(depth_min=float(z['depth_min']), depth_max=float(z['depth_max'])))
+        dict(depth_min=float(z['depth_min']), depth_max=float(z['depth_max'])), **kw)
     torch.cuda.synchronize()
     return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', sorted(VARIANTS))
+@pytest.mark.parametrize('name', ['f2v_small', 'f2v_batch2'])
+def test_hip_attention_switches_bitexact_vs_reference_module(name, tag):
+    z = np.load(os.path.join(util.GOLDEN, name + '.npz'))
+    ref = np.load(os.path.join(util.GOLDEN, 'frustum_atten_variants.npz'))[f'{name}__{tag}']
+    out = hip_run(z, sem=tag != 'stereo_nocat', **VARIANTS[tag]).cpu().numpy()
+    assert np.array_equal(util.bits(out), util.bits(ref))
+    # 16-byte channel blocks: the pixel-major kernel, channels-last in and out (bf16 vs the oracle)
+    zz = {k: z[k] for k in z.files}
+    reps = 8 // z['stereo'].shape[1] + 1
+    zz['stereo'] = orc.bf16_round(np.tile(z['stereo'], (1, reps, 1, 1, 1))[:, :8])
+    zz['sem'] = orc.bf16_round(np.tile(z['sem'], (1, reps, 1, 1))[:, :8])
+    zz['softmax'] = orc.bf16_round(z['softmax'])
+    sem = None if tag == 'stereo_nocat' else zz['sem']
+    want = orc.bf16_round(orc.frustum_to_voxel(zz['stereo'], zz['softmax'], sem, z['coordinates_3d'],
+                                               z['cam2img'], z['pad_shape'], float(z['depth_min']),
+                                               float(z['depth_max']), **VARIANTS[tag]))
+    for fmt in (torch.contiguous_format, torch.channels_last_3d):
+        got = hip_run(zz, torch.bfloat16, sem=sem is not None, stereo_format=fmt, **VARIANTS[tag])
+        assert np.array_equal(util.bits(got.float().cpu().numpy()), util.bits(want))
 
 
 @pytest.mark.gpu

@@ -333,6 +333,21 @@ def test_wide_modules_mfma_path_vs_reference_modules(mods, monkeypatch):
     for got, key in ((y, 'hg_out'), (pre, 'hg_pre'), (post, 'hg_post')):
         _close_bf16(got.float().cpu().numpy(), z[key])
 
+    # hourglass(gn=False): BatchNorm3d instead of GroupNorm (conv_modules.py:42,113,126), eval mode
+    hg = _load(mods.hourglass(32, gn=False), 64)
+    assert list(hg.state_dict().keys()) == list(z['hgbn_keys'])
+    with torch.no_grad():
+        y, pre, post = hg(x['hg'].cuda(), None, None)
+    for got, key in ((y, 'hgbn_out'), (pre, 'hgbn_pre'), (post, 'hgbn_post')):
+        np.testing.assert_allclose(got.cpu().numpy(), z[key], **CONV_TOL)
+    calls['g'] = 0
+    hgb = hg.to(torch.bfloat16)
+    with torch.no_grad():
+        y, pre, post = hgb(x['hg'].cuda().bfloat16().contiguous(memory_format=cl), None, None)
+    assert calls['g'] == 6
+    for got, key in ((y, 'hgbn_out'), (pre, 'hgbn_pre'), (post, 'hgbn_post')):
+        _close_bf16(got.float().cpu().numpy(), z[key])
+
     for cls, kw, seed, xin, key, nconv in (
             (mods.OutdoorImVoxelNeck, dict(in_channels=64, out_channels=256), 62, 'neck', 'imvoxel_out', 9),
             (mods.DfMNeck, dict(in_channels=64, out_channels=256, num_frames=2), 63, 'dfmneck', 'dfmneck_out', 18)):

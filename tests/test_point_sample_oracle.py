@@ -80,3 +80,24 @@ def test_voxel_sample_oracle_bitexact_vs_reference(tag, kw, aligned):
                            aligned=aligned, **kw)
     ref = z[f'out_{tag}_{"tri" if aligned else "near"}']
     assert np.array_equal(util.bits(out), util.bits(ref))
+
+
+def test_reverse_3d_flow_vs_reference_apply_3d_transformation():
+    """host logic of point_sample's first step (point_fusion.py:57-58): the product's
+    ``_reverse_3d_flow`` against ``apply_3d_transformation(..., reverse=True)`` of the reference
+    (tests/golden/point_sample_flow.npz, make_golden_r02.py) for LIDAR / CAMERA / DEPTH points and
+    every flow entry; exact without a rotation, 1 ulp-level with one (BLAS product restated)."""
+    import importlib
+    import torch
+    sys_path_pkg = importlib.import_module('depth-from-motion_amd.point_sample')
+    from tests.golden.make_golden_r02 import FLOW_METAS
+    z = np.load(os.path.join(util.GOLDEN, 'point_sample_flow.npz'))
+    pts = torch.from_numpy(z['points'])
+    for name, (ctype, meta) in FLOW_METAS.items():
+        got = sys_path_pkg._reverse_3d_flow(pts, ctype, meta).numpy()
+        ref = z[f'rev__{name}']
+        if 'R' in meta['transformation_3d_flow']:
+            np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6)
+        else:
+            assert np.array_equal(util.bits(got), util.bits(ref)), name
+    assert sys_path_pkg._reverse_3d_flow(pts, 'LIDAR', {}) is pts
