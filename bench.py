@@ -67,7 +67,10 @@ KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0
 
 # secondary workloads (other rows of SURVEY.md 8a), reported with the same JSON shape
 SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd_kitti',
-             'backbone', 'backbone_train', 'neck', 'dfm_neck')
+             'backbone', 'backbone_train', 'neck', 'dfm_neck',
+             # the same rows in the layout the bf16 NDHWC pipeline hands them (channels-last sources
+             # sampled in place, channels-last results for the MFMA convolutions that follow)
+             'waymo_cl', 'depth_head_bf16', 'f2v_cl', 'group_norm_cl')
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 
 WORKLOADS = {
@@ -205,11 +208,17 @@ def secondary(args, pkg, dev, rank, world):
             name = ('DfMNeck' if big else 'OutdoorImVoxelNeck') + \
                 '.forward config W (220x300x12 voxels, eval: BN folded into the MFMA conv epilogue, bf16 NDHWC)'
             unit = 'voxel-volumes/s'
-    elif args.workload == 'waymo':
+    elif args.workload in ('waymo', 'waymo_cl'):
         # config W: 5 views x 2 frames, 64 ch, 208x312 level-0 maps, 220x300x12 voxels, concat
         from tests.golden.make_golden import waymo_like_cameras
         B, nv, nf, C, hf, wf, nvox = 2, 5, 2, 64, 208, 312, (220, 300, 12)
         feats = torch.randn(B, nv * nf, C, hf, wf, generator=gen).to(dev)
+        cl = args.workload == 'waymo_cl'
+        esz = 2 if cl else 4
+        if cl:  # what a channels_last bf16 image neck hands over, viewed (B, F*Nv, C, H, W)
+            feats = feats.bfloat16().reshape(B * nv * nf, C, hf, wf).contiguous(
+                memory_format=torch.channels_last).view(B, nv * nf, C, hf, wf)
+            dtype_name = 'bf16'
         cams = waymo_like_cameras(nv, nf, 5)
         cams[:, 0, :] *= 1248 / 156.0
         cams[:, 1, :] *= 832 / 104.0
@@ -218,19 +227,26 @@ def secondary(args, pkg, dev, rank, world):
         pts = pkg.voxel_centers([-35.0, -75.0, -2.0, 75.0, 75.0, 4.0], nvox).to(dev)
 
         def step():
-            return pkg.mv_feature_transformation(feats, [meta] * B, nv, nf, None, nvox, 'concat',
-                                                 points=pts)
-        nbytes = B * 4 * (nv * nf * C * hf * wf + C * nf * nvox[0] * nvox[1] * nvox[2])
-        name, unit = 'multi-view voxel lifting (5 views x 2 frames -> 128x220x300x12, fp32)', 'voxel-volumes/s'
-    elif args.workload == 'depth_head':
+            return pkg.mv_feature_transformation(
+                feats, [meta] * B, nv, nf, None, nvox, 'concat', points=pts,
+                memory_format=torch.channels_last_3d if cl else torch.contiguous_format)
+        nbytes = B * esz * (nv * nf * C * hf * wf + C * nf * nvox[0] * nvox[1] * nvox[2])
+        name = 'multi-view voxel lifting (5 views x 2 frames -> 128x220x300x12, ' + \
+            ('bf16, channels-last views in place -> channels-last volume)' if cl else 'fp32)')
+        unit = 'voxel-volumes/s'
+    elif args.workload in ('depth_head', 'depth_head_bf16'):
         B = 8
         x = (torch.randn(B, 1, 72, 80, 320, generator=gen) * 4).to(dev)
+        esz = 4
+        if args.workload == 'depth_head_bf16':
+            x, esz, dtype_name = x.bfloat16(), 2, 'bf16'
         ds = torch.tensor([(k + 0.5) * (57.6 / 288) + 2 for k in range(288)])
 
         def step():
             return pkg.depth_head_forward(x, ds)
-        nbytes = B * 4 * (72 * 80 * 320 + 2 * 288 * 320 * 1280 + 320 * 1280)
-        name, unit = 'DepthHead.forward (1,72,80,320)->2x(288,320,1280)+map, fp32', 'depth-volumes/s'
+        nbytes = B * esz * (72 * 80 * 320 + 2 * 288 * 320 * 1280 + 320 * 1280)
+        name = f'DepthHead.forward (1,72,80,320)->2x(288,320,1280)+map, {"bf16" if esz == 2 else "fp32"}'
+        unit = 'depth-volumes/s'
     elif args.workload in ('sweep_bwd', 'sweep_bwd_kitti'):
         # backward of the plane sweep on the N* / K shape: grad volume -> fp32 feature grads
         sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
@@ -258,16 +274,22 @@ def secondary(args, pkg, dev, rank, world):
         nbytes = gout.numel() * esz + 2 * g_cur.numel() * 4
         name = f'plane-sweep backward ({w["dtype"]} grad volume -> 2 fp32 feature grads)'
         unit = 'cost-volume-grads/s'
-    elif args.workload == 'group_norm':
+    elif args.workload in ('group_norm', 'group_norm_cl'):
         B = 8
         x = (torch.randn(B, 32, 72, 80, 320, generator=gen) + 0.5).to(dev)
         m = pkg.HipGroupNorm(32, 32).to(dev)
+        esz = 4
+        if args.workload == 'group_norm_cl':
+            x = x.bfloat16().contiguous(memory_format=torch.channels_last_3d)
+            m, esz, dtype_name = m.to(torch.bfloat16), 2, 'bf16'
 
         def step():
             with torch.no_grad():
                 return m(x, relu=True)
-        nbytes = B * 4 * 2 * 32 * 72 * 80 * 320
-        name, unit = 'fused GroupNorm(32,32)+ReLU on (32,72,80,320) fp32 (in + out bytes)', 'volumes/s'
+        nbytes = B * esz * 2 * 32 * 72 * 80 * 320
+        name = 'fused GroupNorm(32,32)+ReLU on (32,72,80,320) ' + \
+            ('bf16 channels_last_3d' if esz == 2 else 'fp32') + ' (in + out bytes)'
+        unit = 'volumes/s'
     else:
         B, C, D, H, W = 8, 32, 72, 80, 320
         stereo = torch.randn(B, C, D, H, W, generator=gen).to(dev)
@@ -280,11 +302,17 @@ def secondary(args, pkg, dev, rank, world):
         K[1, 2] -= 55.0
         metas = [{'cam2img': K.tolist(), 'pad_shape': (320, 1280, 3)}] * B
         cfg = dict(depth_min=2, depth_max=59.6)
+        esz = 4
+        if args.workload == 'f2v_cl':  # the NDHWC stack's cost volume, sampled in place
+            stereo = stereo.bfloat16().contiguous(memory_format=torch.channels_last_3d)
+            soft, sem, esz, dtype_name = soft.bfloat16(), sem.bfloat16(), 2, 'bf16'
 
         def step():
             return pkg.frustum_to_voxel_sample(stereo, soft, metas, sem, coords, cfg)
-        nbytes = B * 4 * (C * D * H * W + 288 * 320 * 1280 + C * H * W + 2 * C * 20 * 304 * 288)
-        name, unit = 'FrustumToVoxel sampling (32x72x80x320 + 288x320x1280 + 32x80x320 -> 64x20x304x288, fp32)', 'voxel-volumes/s'
+        nbytes = B * esz * (C * D * H * W + 288 * 320 * 1280 + C * H * W + 2 * C * 20 * 304 * 288)
+        name = 'FrustumToVoxel sampling (32x72x80x320 + 288x320x1280 + 32x80x320 -> 64x20x304x288, ' + \
+            ('bf16, channels-last in and out)' if esz == 2 else 'fp32)')
+        unit = 'voxel-volumes/s'
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -125,6 +125,7 @@ class MvDesc(ctypes.Structure):
         ('valid_sample', ctypes.c_int32),
         ('dtype', ctypes.c_int32),
         ('out_channels_last', ctypes.c_int32),
+        ('feats_channels_last', ctypes.c_int32),
     ]
 
 

@@ -11,7 +11,8 @@
 // recomputed from the (L1/L2-resident) cost in each of the three column passes
 // (max, sum of exp, normalise) instead of being re-read from HBM.
 // Upsample arithmetic = ATen's: fma(w0, a, w1*b) nested W -> H -> D (bit-exact
-// volume); softmax uses expf (equal to torch's Sleef exp to rounding error).
+// volume); softmax uses exp_nonpos (dfm_common.h; equal to torch's Sleef exp to rounding error)
+// and one reciprocal per column.
 // Bound: HBM write (2 volumes), ~8 cached loads + 1 exp per element.
 #include "dfm_common.h"
 
@@ -43,6 +44,15 @@ __global__ __launch_bounds__(128) void depth_head_kernel(const T *__restrict__ i
     const int Do = D * s, Ho = H * s, Wo = W * s;
     const int pix = (blockIdx.x * 128 + threadIdx.x) * V;
     const int b = blockIdx.y;
+    // the depth interpolation (input planes and weights of output depth d) is the same for every
+    // lane: one LDS table per workgroup, read back as a broadcast, instead of ~20 VALU operations
+    // (a division among them) per lane, depth and pass
+    extern __shared__ float4 dtab[];  // {i0, i1 (as int bits), w0, w1}
+    for (int d = threadIdx.x; d < Do; d += 128) {
+        const UpIdx u = up_index(d, D, Do);
+        dtab[d] = make_float4(__int_as_float(u.i0), __int_as_float(u.i1), u.w0, u.w1);
+    }
+    __syncthreads();
     if (pix >= Ho * Wo) return;
     const int h = pix / Wo, w = pix - h * Wo;  // Wo % V == 0: the V pixels share the row
     const UpIdx uh = up_index(h, H, Ho);
@@ -77,7 +87,9 @@ __global__ __launch_bounds__(128) void depth_head_kernel(const T *__restrict__ i
     float c0[V], c1[V];
     int have = -1;
     auto logits = [&](int d, float (&v)[V]) {
-        const UpIdx ud = up_index(d, D, Do);
+        const float4 te = dtab[d];
+        UpIdx ud;
+        ud.i0 = __float_as_int(te.x); ud.i1 = __float_as_int(te.y); ud.w0 = te.z; ud.w1 = te.w;
         if (ud.i0 != have) {
             if (ud.i0 == have + 1 && have >= 0) {
 #pragma unroll
@@ -97,18 +109,40 @@ __global__ __launch_bounds__(128) void depth_head_kernel(const T *__restrict__ i
     float mx[V], sum[V], acc[V], v[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) { mx[j] = -INFINITY; sum[j] = 0.0f; acc[j] = 0.0f; }
-    for (int d = 0; d < Do; ++d) {
-        logits(d, v);
-        vec_t st;
+    // pass 1: the logits (stored as depth_volumes) with an ONLINE maximum / sum of exponentials over
+    // chunks of CH depths held in registers: the running sum is rescaled once per chunk, when the
+    // maximum moved (exp(0) == 1 exactly otherwise).  The separate sum pass -- a third evaluation of
+    // every logit -- is gone.
+    constexpr int CH = 8;
+    for (int d0 = 0; d0 < Do; d0 += CH) {
+        float vv[CH][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) { st[j] = elem<T>::store(v[j]); mx[j] = fmaxf(mx[j], v[j]); }
-        if constexpr (STORE) __builtin_nontemporal_store(st, (vec_t *)(vcol + (size_t)d * plane_o));
-    }
-    have = -1;
-    for (int d = 0; d < Do; ++d) {
-        logits(d, v);
+        for (int c = 0; c < CH; ++c) {
+            if (d0 + c < Do) {
+                logits(d0 + c, vv[c]);
+                if constexpr (STORE) {
+                    vec_t st;
 #pragma unroll
-        for (int j = 0; j < V; ++j) sum[j] = sum[j] + expf(v[j] - mx[j]);
+                    for (int j = 0; j < V; ++j) st[j] = elem<T>::store(vv[c][j]);
+                    __builtin_nontemporal_store(st, (vec_t *)(vcol + (size_t)(d0 + c) * plane_o));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) vv[c][j] = -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float cm = vv[0][j];
+#pragma unroll
+            for (int c = 1; c < CH; ++c) cm = fmaxf(cm, vv[c][j]);
+            const float mnew = fmaxf(mx[j], cm);
+            float sj = sum[j] * exp_nonpos(mx[j] - mnew);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) sj = sj + exp_nonpos(vv[c][j] - mnew);
+            sum[j] = sj;
+            mx[j] = mnew;
+        }
     }
     have = -1;
     if (!STORE && !pred) {  // statistics only: the expectation pass is not needed
@@ -119,13 +153,18 @@ __global__ __launch_bounds__(128) void depth_head_kernel(const T *__restrict__ i
         }
         return;
     }
+    // one IEEE division per column, one multiplication per element (x / sum and x * (1 / sum) differ by
+    // at most one rounding; the fused FrustumToVoxel evaluates the same expression)
+    float inv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) inv[j] = 1.0f / sum[j];
     for (int d = 0; d < Do; ++d) {
         logits(d, v);
         const float ds = depth_samples[d];
         vec_t st;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            st[j] = elem<T>::store(expf(v[j] - mx[j]) / sum[j]);
+            st[j] = elem<T>::store(exp_nonpos(v[j] - mx[j]) * inv[j]);
             acc[j] = acc[j] + elem<T>::load(st[j]) * ds;
         }
         if constexpr (STORE) __builtin_nontemporal_store(st, (vec_t *)(scol + (size_t)d * plane_o));
@@ -159,26 +198,25 @@ DFM_API int dfm_depth_head_fwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
         return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
     if (!cost || !depth_samples || !depth_volumes || !softmax || !depth_preds)
         return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
-    if (batch > 65535 || (long long)h * scale * w * scale >= (1ll << 31))
+    if (batch > 65535 || (long long)h * scale * w * scale >= (1ll << 31) || (long long)d * scale > 4000)
         return set_error(DFM_ERR_UNSUPPORTED, "shape too large");
     const int npix = h * scale * w * scale;
-    // 4 pixels per lane (16-byte fp32 / 8-byte bf16 stores) when rows and the three
-    // output base pointers allow it, else one
+    // 4 pixels per lane (16-byte fp32 / 8-byte bf16 stores) when rows and the three output base
+    // pointers allow it, else one (8 bf16 pixels per lane need 231 VGPRs: 2 waves per SIMD, slower)
     const size_t esz = dtype == DFM_F32 ? 4 : 2;
-    const bool vec4 = (w * scale) % 4 == 0 &&
-                      (((uintptr_t)depth_volumes | (uintptr_t)softmax | (uintptr_t)depth_preds) %
-                       (4 * esz)) == 0;
-    const int v = vec4 ? 4 : 1;
+    const uintptr_t bases = (uintptr_t)depth_volumes | (uintptr_t)softmax | (uintptr_t)depth_preds;
+    int v = 1;
+    if ((w * scale) % 4 == 0 && bases % (4 * esz) == 0) v = 4;
     dim3 grid((npix / v + 127) / 128, batch);
     hipStream_t st = (hipStream_t)stream;
 #define DFM_DH_LAUNCH(T, V)                                                                       \
-    hipLaunchKernelGGL((depth_head_kernel<T, V, true>), grid, dim3(128), 0, st, (const T *)cost, d, h, \
+    hipLaunchKernelGGL((depth_head_kernel<T, V, true>), grid, dim3(128), (size_t)d * scale * 16, st, (const T *)cost, d, h, \
                        w, scale, depth_samples, (T *)depth_volumes, (T *)softmax, (T *)depth_preds,   \
                        (float *)nullptr, (float *)nullptr)
     if (dtype == DFM_F32) {
-        if (vec4) DFM_DH_LAUNCH(float, 4); else DFM_DH_LAUNCH(float, 1);
+        if (v == 4) DFM_DH_LAUNCH(float, 4); else DFM_DH_LAUNCH(float, 1);
     } else {
-        if (vec4) DFM_DH_LAUNCH(bf16_t, 4); else DFM_DH_LAUNCH(bf16_t, 1);
+        if (v == 4) DFM_DH_LAUNCH(bf16_t, 4); else DFM_DH_LAUNCH(bf16_t, 1);
     }
 #undef DFM_DH_LAUNCH
     hipError_t e = hipGetLastError();
@@ -196,7 +234,7 @@ DFM_API int dfm_depth_head_stats_fwd(int32_t batch, int32_t d, int32_t h, int32_
         return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
     if (!cost || !depth_samples || !col_max || !col_sum)
         return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
-    if (batch > 65535 || (long long)h * scale * w * scale >= (1ll << 31))
+    if (batch > 65535 || (long long)h * scale * w * scale >= (1ll << 31) || (long long)d * scale > 4000)
         return set_error(DFM_ERR_UNSUPPORTED, "shape too large");
     const int npix = h * scale * w * scale;
     // one pixel per lane: there are no wide stores to feed, and 4x the waves hide the latency of the
@@ -205,7 +243,7 @@ DFM_API int dfm_depth_head_stats_fwd(int32_t batch, int32_t d, int32_t h, int32_
     dim3 grid((npix + 127) / 128, batch);
     hipStream_t st = (hipStream_t)stream;
 #define DFM_DH_LAUNCH(T, V)                                                                            \
-    hipLaunchKernelGGL((depth_head_kernel<T, V, false>), grid, dim3(128), 0, st, (const T *)cost, d, h, \
+    hipLaunchKernelGGL((depth_head_kernel<T, V, false>), grid, dim3(128), (size_t)d * scale * 16, st, (const T *)cost, d, h, \
                        w, scale, depth_samples, (T *)nullptr, (T *)nullptr, (T *)depth_preds, col_max,  \
                        col_sum)
     if (dtype == DFM_F32) {
@@ -262,9 +300,9 @@ __global__ __launch_bounds__(256) void depth_head_bwd_kernel(
     const float gp = gpred ? elem<T>::load(gpred[(size_t)b * plane_o + pix]) : 0.0f;
     if (soft_path) {
         for (int d = 0; d < Do; ++d) mx = fmaxf(mx, logit(d));
-        for (int d = 0; d < Do; ++d) sum += expf(logit(d) - mx);
+        for (int d = 0; d < Do; ++d) sum += exp_nonpos(logit(d) - mx);
         for (int d = 0; d < Do; ++d) {
-            const float p = expf(logit(d) - mx) / sum;
+            const float p = exp_nonpos(logit(d) - mx) / sum;
             const float sd = (gsoft ? elem<T>::load(gsoft[col + (size_t)d * plane_o]) : 0.0f) +
                              gp * depth_samples[d];
             dotps += p * sd;
@@ -273,7 +311,7 @@ __global__ __launch_bounds__(256) void depth_head_bwd_kernel(
     for (int d = 0; d < Do; ++d) {
         float gl = gvol ? elem<T>::load(gvol[col + (size_t)d * plane_o]) : 0.0f;
         if (soft_path) {
-            const float p = expf(logit(d) - mx) / sum;
+            const float p = exp_nonpos(logit(d) - mx) / sum;
             const float sd = (gsoft ? elem<T>::load(gsoft[col + (size_t)d * plane_o]) : 0.0f) +
                              gp * depth_samples[d];
             gl += p * (sd - dotps);
@@ -344,10 +382,10 @@ __global__ __launch_bounds__(256) void depth_head_bwd_tile_kernel(
         if (soft_path) {
             for (int d = 0; d < Do; ++d) mx = fmaxf(mx, logit(d));
             have = -1;
-            for (int d = 0; d < Do; ++d) sum += expf(logit(d) - mx);
+            for (int d = 0; d < Do; ++d) sum += exp_nonpos(logit(d) - mx);
             have = -1;
             for (int d = 0; d < Do; ++d) {
-                const float p = expf(logit(d) - mx) / sum;
+                const float p = exp_nonpos(logit(d) - mx) / sum;
                 const float sd = (gsoft ? elem<T>::load(gsoft[col + (size_t)d * plane_o]) : 0.0f) +
                                  gp * depth_samples[d];
                 dotps += p * sd;
@@ -370,7 +408,7 @@ __global__ __launch_bounds__(256) void depth_head_bwd_tile_kernel(
         for (int d = 0; d < Do; ++d) {
             float gl = gvol ? elem<T>::load(gvol[col + (size_t)d * plane_o]) : 0.0f;
             if (soft_path) {
-                const float p = expf(logit(d) - mx) / sum;
+                const float p = exp_nonpos(logit(d) - mx) / sum;
                 const float sd = (gsoft ? elem<T>::load(gsoft[col + (size_t)d * plane_o]) : 0.0f) +
                                  gp * depth_samples[d];
                 gl += p * (sd - dotps);

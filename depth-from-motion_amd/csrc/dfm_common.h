@@ -37,13 +37,15 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v)
     return __uint_as_float(((uint32_t)v) << 16);
 }
 
-// round-to-nearest-even, NaN -> quiet NaN (same as torch's c10::BFloat16)
+// round-to-nearest-even in hardware (v_cvt_pk_bf16_f32 on gfx950: one operation; the integer
+// add-and-shift it replaces cost seven); a NaN stays a quiet NaN (torch's c10::BFloat16 canonicalises
+// it to 0x7fc0, the hardware keeps its sign -- NaN either way)
 __device__ __forceinline__ bf16_t f32_to_bf16(float f)
 {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 h = (__bf16)f;
+    bf16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
 }
 
 // two floats -> packed bf16x2 (lo = a, hi = b), round-to-nearest-even
@@ -137,6 +139,22 @@ __device__ __forceinline__ UpIdx up_index(int i, int in, int out)
     u.w1 = l;
     u.w0 = 1.0f - l;
     return u;
+}
+
+// exp(x) for x <= 0 (a logit minus its column maximum) -- the softmax of DepthHead and of the fused
+// FrustumToVoxel share it, so the two stay bit-identical.  x * log2(e) as a two-word product, the
+// integer part split off before the low word is added (so the low word survives for large |x|), the
+// hardware exp2 on the fraction and a ldexp: ~9 VALU operations, within 1 ulp of libm's expf (which
+// spends half of its ~15 operations on the overflow / underflow cases this argument cannot reach).
+// NaN propagates; anything below -128 (-inf included) gives exp(-128) scaled out of range = 0.
+__device__ __forceinline__ float exp_nonpos(float x)
+{
+    x = x < -128.0f ? -128.0f : x;
+    const float ph = x * 1.44269504088896340736f;
+    const float pl = __builtin_fmaf(x, 1.92596299112661746e-8f, __builtin_fmaf(x, 1.44269504088896340736f, -ph));
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + pl;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
 }
 
 __device__ __forceinline__ float lerp_fma(float w0, float a, float w1, float b)

@@ -89,7 +89,7 @@ __device__ __forceinline__ float fused_disp(const F2vGeom &g, const T *__restric
         // depth_volumes and its softmax are stored (and read back) in T by the unfused pipeline
         const float logit = elem<T>::load(elem<T>::store(lerp_fma(ud.w0, col[0], ud.w1, col[1])));
         const size_t pix = (size_t)yc * W + xc;
-        const float prob = elem<T>::load(elem<T>::store(expf(logit - cmax[pix]) / csum[pix]));
+        const float prob = elem<T>::load(elem<T>::store(exp_nonpos(logit - cmax[pix]) * (1.0f / csum[pix])));
         out = out + prob * wgt[k];
     }
     return out;

@@ -1854,8 +1854,15 @@ DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *gra
         return cw;
     };
     const int cw_cur = pick_cw(cw_max), cw_prev = cw_cur;
-    const int rows_cur = (int)std::min<long long>(std::min(desc->h_in, 8),
-                                                  (long long)budget / ((long long)cw_cur * desc->w_in * 8));
+    int row_cap = 8;
+#ifdef DFM_DEBUG_HOOKS
+    if (const char *e = getenv("DFM_BWD_ROWCAP")) row_cap = atoi(e);
+#endif
+    int rows_cur = (int)std::min<long long>(std::min(desc->h_in, row_cap),
+                                            (long long)budget / ((long long)cw_cur * desc->w_in * 8));
+#ifdef DFM_DEBUG_HOOKS
+    if (const char *e = getenv("DFM_BWD_ROWS")) rows_cur = std::min(rows_cur, std::max(4, atoi(e)));
+#endif
     const int rows_prev = rows_cur;
     const long long hw = (long long)g.h_out * g.w_out;
     if (!force_scatter && rows_cur >= 4 && desc->h_in < 4096 && desc->w_in < 8192) {

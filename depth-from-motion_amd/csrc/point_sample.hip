@@ -236,7 +236,7 @@ DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *d, const void *feats, con
         return fail_ps(DFM_ERR_INVALID_ARG, "nx*ny*nz != num_points");
     if (!feats || !points || !proj || !ori_w || !out)
         return fail_ps(DFM_ERR_INVALID_ARG, "NULL device pointer");
-    if (!workspace || workspace_bytes < dfm_point_sample_mv_workspace_bytes(d))
+    if (!d->feats_channels_last && (!workspace || workspace_bytes < dfm_point_sample_mv_workspace_bytes(d)))
         return fail_ps(DFM_ERR_WORKSPACE, "workspace smaller than dfm_point_sample_mv_workspace_bytes");
     MvGeom g;
     g.num_views = d->num_views; g.num_frames = d->num_frames; g.C = d->channels;
@@ -258,16 +258,23 @@ DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *d, const void *feats, con
     dim3 pg((HW + 63) / 64, (Cp + 31) / 32, nvf);
     const long long nb = (g.N + 255) / 256;
     if (nb > 2147483647ll) return fail_ps(DFM_ERR_UNSUPPORTED, "too many points");
+    // channels-last view features ARE the pixel-major layout: sampled where they lie
+    const bool in_place = d->feats_channels_last != 0;
+    if (in_place && (d->channels % CB != 0 || ((uintptr_t)feats & 15)))
+        return fail_ps(DFM_ERR_UNSUPPORTED, "channels-last view features need whole 16-byte channel blocks");
+    const void *maps = in_place ? feats : workspace;
     if (d->dtype == DFM_F32) {
-        hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg, dim3(256), 0, st,
-                           (const float *)feats, (float *)workspace, g.C, Cp, (long long)HW);
+        if (!in_place)
+            hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg, dim3(256), 0, st,
+                               (const float *)feats, (float *)workspace, g.C, Cp, (long long)HW);
         hipLaunchKernelGGL(mv_sample_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, g,
-                           (const uint4 *)workspace, points, proj, ori_w, (float *)out, valid_out);
+                           (const uint4 *)maps, points, proj, ori_w, (float *)out, valid_out);
     } else {
-        hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg, dim3(256), 0, st,
-                           (const bf16_t *)feats, (bf16_t *)workspace, g.C, Cp, (long long)HW);
+        if (!in_place)
+            hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg, dim3(256), 0, st,
+                               (const bf16_t *)feats, (bf16_t *)workspace, g.C, Cp, (long long)HW);
         hipLaunchKernelGGL(mv_sample_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, g,
-                           (const uint4 *)workspace, points, proj, ori_w, (bf16_t *)out, valid_out);
+                           (const uint4 *)maps, points, proj, ori_w, (bf16_t *)out, valid_out);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_ps(DFM_ERR_HIP, hipGetErrorString(e));

@@ -65,6 +65,16 @@ def _crop_xy(img_crop_offset):
     return float(img_crop_offset), float(img_crop_offset)
 
 
+def _views_channels_last(x):
+    """(B, F*Nv, C, H, W) whose every view is stored (H, W, C) -- what ``.view(B, F*Nv, C, H, W)`` of
+    a channels_last image backbone / neck output is -- with whole 16-byte channel blocks"""
+    if x.dim() != 5 or x.is_contiguous():
+        return False
+    B, V, C, H, W = x.shape
+    return (x.stride() == (V * H * W * C, H * W * C, 1, W * C, C) and C % (16 // x.element_size()) == 0 and
+            x.data_ptr() % 16 == 0)
+
+
 def _make_desc(feats, npoints, nxyz, num_views, num_frames, scale, crop, flip, pad_shape, aligned,
                aggregate, valid_sample):
     nvf, C, Hf, Wf = feats.shape[-4:]
@@ -229,7 +239,9 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
     points = torch.as_tensor(points, dtype=torch.float32).to(device).contiguous()
     nxyz = tuple(int(v) for v in n_voxels)
     nvf = num_views * num_frames
-    feats = batch_feats.contiguous()
+    # channels_last view features are sampled in place (they are the kernel's pixel-major layout)
+    feats_cl = _views_channels_last(batch_feats)
+    feats = batch_feats if feats_cl else batch_feats.contiguous()
     descs, proj, ori_w = [], [], []
     for img_meta in img_metas:
         if 'scale_factor' in img_meta:
@@ -244,6 +256,7 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
         descs.append(_make_desc(feats, points.shape[0], nxyz, num_views, num_frames, scale, crop,
                                 flip, img_meta['input_shape'], False, temporal_aggregate,
                                 valid_sample))
+        descs[-1].feats_channels_last = 1 if feats_cl else 0
     # one upload for the whole batch's matrices
     proj = _upload(torch.from_numpy(np.stack(proj)), device)
     ori_w = _upload(torch.tensor(ori_w, dtype=torch.float32), device)

@@ -264,6 +264,9 @@ typedef struct dfm_mv_desc {
     int32_t out_channels_last; /* forward only, nz > 0: out is (nx, ny, nz, C*F') in memory, a torch
                              * tensor (C*F', nx, ny, nz) in channels_last_3d -- the layout the
                              * NDHWC / MFMA neck convolutions read, no conversion copy         */
+    int32_t feats_channels_last; /* forward only: feats is (F*Nv, feat_h, feat_w, C) in memory (a torch
+                             * channels_last image backbone / neck): sampled in place, no pixel-major
+                             * copy, no workspace; needs C to be whole 16-byte blocks               */
 } dfm_mv_desc;
 
 DFM_API size_t dfm_point_sample_mv_workspace_bytes(const dfm_mv_desc *desc);

@@ -243,3 +243,29 @@ def test_mv_feature_transformation_undoes_each_samples_flow(pkg):
         assert torch.equal(out[b], alone[0])
     assert not torch.equal(out[0], pkg.mv_feature_transformation(
         feats[:1], [meta_from_fixture(z)], nv, nf, z['voxel_range'], z['n_voxels'], str(z['aggregate']))[0])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_mv_channels_last_view_features_are_sampled_in_place(pkg, dtype):
+    """view features coming from a channels_last image backbone ((B*F*Nv, C, H, W) channels_last,
+    viewed (B, F*Nv, C, H, W)) are the kernel's pixel-major layout: same volume, same gradient, no
+    pixel-major copy (dfm_mv_desc.feats_channels_last)"""
+    ps = importlib.import_module('depth-from-motion_amd.point_sample')
+    z = np.load(mv_cases()[0])
+    base = torch.from_numpy(z['feats']).cuda()                      # (1, F*Nv, C, H, W)
+    B, V, C, H, W = base.shape
+    reps = 16 // C + 1
+    feats = base.repeat(2, 1, reps, 1, 1)[:, :, :16].to(dtype).contiguous()
+    feats[1] = feats[1].flip(-1)
+    cl = feats.reshape(2 * V, 16, H, W).contiguous(memory_format=torch.channels_last).view(2, V, 16, H, W)
+    assert ps._views_channels_last(cl) and not ps._views_channels_last(feats)
+    metas = [meta_from_fixture(z)] * 2
+    args = (metas, int(z['num_views']), int(z['num_frames']), z['voxel_range'], z['n_voxels'], str(z['aggregate']))
+    a = feats.clone().requires_grad_(True)
+    b = cl.detach().requires_grad_(True)
+    ya, yb = pkg.mv_feature_transformation(a, *args), pkg.mv_feature_transformation(b, *args)
+    assert torch.equal(ya, yb) and float(ya.abs().sum()) > 0
+    go = torch.randn_like(ya)
+    ya.backward(go)
+    yb.backward(go)
+    torch.testing.assert_close(a.grad.float(), b.grad.float(), rtol=1e-4, atol=1e-4)
