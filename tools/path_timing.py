@@ -48,9 +48,15 @@ def stereo(iters):
     H, W = 320, 1280
     gen = torch.Generator().manual_seed(1)
 
+    cl2d = os.environ.get('DFM_PATH_CL2D') == '1'   # experiment: 2-D necks in channels_last
+    if cl2d:
+        path.neck.to(memory_format=torch.channels_last)
+        path.backbone_3d.to(memory_format=torch.channels_last)
+
     def pyramid():
-        return [torch.randn(1, c, H // s, W // s, generator=gen).to(dev).bfloat16()
-                for c, s in ((3, 1), (64, 2), (128, 4), (128, 4), (128, 4))]
+        out = [torch.randn(1, c, H // s, W // s, generator=gen).to(dev).bfloat16()
+               for c, s in ((3, 1), (64, 2), (128, 4), (128, 4), (128, 4))]
+        return [t.contiguous(memory_format=torch.channels_last) for t in out] if cl2d else out
     cur, prev = pyramid(), pyramid()
     K = bench.KITTI_P2.copy()
     K2 = K.copy()
