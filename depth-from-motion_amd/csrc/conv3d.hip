@@ -252,7 +252,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int t = 4 * gq + j;
-                            if (scnt == 0.0f) sK[t] = q[j];
+                            // the shift is COMMON to the 32 pixel lanes of a half (the value of its
+                            // first lane in the wave's first row): the lanes' sums then add up as they
+                            // are -- no count / mean / M2 merge tree with a division per step at the end
+                            if (d == d0 && r == 0) sK[t] = __shfl(q[j], lane & 32);
                             const float dv = q[j] - sK[t];
                             s1[t] += dv;
                             s2[t] = __builtin_fmaf(dv, dv, s2[t]);
@@ -265,28 +268,26 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
         __syncthreads();  // slab d+2 has landed (vmcnt drained) and slot (d-1) may be refilled
     }
     if constexpr (STATS && !OUT_F32) {
-        // lane -> (count, mean, M2) per channel, merged over the 32 pixel lanes of each half
-        // (Chan's parallel update), written by lanes 0 and 32
+        // shifted sums of the 32 pixel lanes of each half added up (same shift K in all of them),
+        // then (count, mean, M2) per channel, written by lanes 0 and 32
         const int splits = g.tiles_w * g.tiles_h * gridDim.y * 4;
         const int sidx = (blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave;
+        float cn = scnt;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            float cn = scnt, mean = 0.0f, m2 = 0.0f;
-            if (cn > 0.0f) {
-                const float a = s1[t] / cn;
-                mean = sK[t] + a;
-                m2 = fmaxf(s2[t] - s1[t] * a, 0.0f);
-            }
+            float a1 = s1[t], a2 = s2[t];
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) {
-                const float on = __shfl_xor(cn, o), om = __shfl_xor(mean, o), o2 = __shfl_xor(m2, o);
-                const float tot = cn + on;
-                if (tot > 0.0f) {
-                    const float delta = om - mean, f = on / tot;
-                    m2 = m2 + o2 + delta * delta * cn * f;
-                    mean = mean + delta * f;
-                }
-                cn = tot;
+                a1 += __shfl_xor(a1, o);
+                a2 += __shfl_xor(a2, o);
+            }
+            float mean = 0.0f, m2 = 0.0f;
+            if (cn > 0.0f) {
+                const float a = a1 / cn;
+                mean = sK[t] + a;
+                m2 = fmaxf(a2 - a1 * a, 0.0f);
             }
             if (l32 == 0) {
                 const int c = (t & 3) + 8 * (t >> 2) + 4 * half;

@@ -45,6 +45,8 @@ def main():
                 t = timeit(lambda: cv.conv3d_k3_c32(x, packed, depth_chunk=c))
                 print(f'N={N} {D}x{H}x{W} 32->32  MFMA kernel chunk={c:3d}: {t:7.3f} ms  {flops / t / 1e9:7.1f} TFLOP/s'
                       f'  ({flops / t / 1e9 / 2500 * 100:4.1f} % of 2.5 PF)', flush=True)
+            t = timeit(lambda: cv.conv3d_k3_c32(x, packed, stats=True))
+            print(f'N={N} {D}x{H}x{W} 32->32  MFMA kernel + GroupNorm statistics epilogue: {t:7.3f} ms', flush=True)
             t = timeit(lambda: cv.conv3d_k3_c32(x, packed, out_f32=True))
             print(f'N={N} {D}x{H}x{W} 32->32  MFMA kernel fp32-partial out: {t:7.3f} ms', flush=True)
         del x
