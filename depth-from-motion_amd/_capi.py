@@ -23,6 +23,7 @@ EXPORTS = (
     'dfm_plane_sweep_fwd',
     'dfm_plane_sweep_cl_workspace_bytes',
     'dfm_plane_sweep_fwd_channels_last',
+    'dfm_plane_sweep_fwd_nhwc',
     'dfm_plane_sweep_bwd',
     'dfm_plane_sweep_grid',
     'dfm_plane_sweep_last_kernel',
@@ -136,7 +137,7 @@ class F2vDesc(ctypes.Structure):
         'ny', 'nx')] + [(n, ctypes.c_float) for n in ('pad_h', 'pad_w', 'depth_min', 'depth_span')
                         ] + [('dtype', ctypes.c_int32), ('stereo_channels_last', ctypes.c_int32),
                            ('out_channels_last', ctypes.c_int32), ('stereo_atten', ctypes.c_int32),
-                           ('no_sem_atten', ctypes.c_int32)]
+                           ('no_sem_atten', ctypes.c_int32), ('sem_channels_last', ctypes.c_int32)]
 
 
 class VsDesc(ctypes.Structure):
@@ -214,6 +215,8 @@ def lib():
     h.dfm_plane_sweep_cl_workspace_bytes.argtypes = [dp]
     h.dfm_plane_sweep_fwd_channels_last.restype = ctypes.c_int
     h.dfm_plane_sweep_fwd_channels_last.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp]
+    h.dfm_plane_sweep_fwd_nhwc.restype = ctypes.c_int
+    h.dfm_plane_sweep_fwd_nhwc.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp]
     h.dfm_plane_sweep_bwd.restype = ctypes.c_int
     h.dfm_plane_sweep_bwd.argtypes = [dp, vp, fp, fp, fp, fp, fp, fp, vp]
     h.dfm_plane_sweep_grid.restype = ctypes.c_int

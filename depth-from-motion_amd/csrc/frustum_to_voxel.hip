@@ -408,6 +408,9 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
     const long long N = (long long)d->nz * d->ny * d->nx;
     dim3 grid((unsigned)((N + 255) / 256), d->batch);
     hipStream_t st = (hipStream_t)stream;
+    if (d->sem_channels_last && !f2v_pixel_major(d))
+        return set_error(DFM_ERR_UNSUPPORTED,
+                         "channels-last cur_sem_feats needs channel counts of whole 16-byte blocks");
     if (d->stereo_channels_last && (!f2v_pixel_major(d) || ((uintptr_t)stereo & 15)))
         return set_error(DFM_ERR_UNSUPPORTED,
                          "channels-last stereo_feat needs channel counts of whole 16-byte blocks");
@@ -420,7 +423,11 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
         const size_t a = ((size_t)d->batch * d->channels * vox * esz + 255) & ~(size_t)255;
         const bool in_place = d->stereo_channels_last != 0;
         void *stereo_pm = in_place ? const_cast<void *>(stereo) : workspace;
-        void *sem_pm = (char *)workspace + a;
+        // a channels-last (NHWC) semantic map is the pixel-major layout already
+        const bool sem_in_place = d->sem_channels_last != 0 && d->sem_channels > 0;
+        if (sem_in_place && ((uintptr_t)sem & 15))
+            return set_error(DFM_ERR_INVALID_ARG, "channels-last cur_sem_feats must be 16-byte aligned");
+        void *sem_pm = sem_in_place ? const_cast<void *>(sem) : (void *)((char *)workspace + a);
         dim3 pg1((unsigned)((vox + 63) / 64), (d->channels + 31) / 32, d->batch);
         dim3 pg2((unsigned)((pix + 63) / 64), (d->sem_channels + 31) / 32, d->batch);
         if (d->dtype == DFM_F32) {
@@ -428,7 +435,7 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
                 hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg1, dim3(256), 0, st,
                                    (const float *)stereo, (float *)stereo_pm, d->channels,
                                    d->channels, vox);
-            if (d->sem_channels > 0)
+            if (d->sem_channels > 0 && !sem_in_place)
                 hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg2, dim3(256), 0, st,
                                    (const float *)sem, (float *)sem_pm, d->sem_channels,
                                    d->sem_channels, pix);
@@ -440,7 +447,7 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
                 hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg1, dim3(256), 0, st,
                                    (const bf16_t *)stereo, (bf16_t *)stereo_pm, d->channels,
                                    d->channels, vox);
-            if (d->sem_channels > 0)
+            if (d->sem_channels > 0 && !sem_in_place)
                 hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg2, dim3(256), 0, st,
                                    (const bf16_t *)sem, (bf16_t *)sem_pm, d->sem_channels,
                                    d->sem_channels, pix);

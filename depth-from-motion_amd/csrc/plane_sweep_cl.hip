@@ -79,11 +79,16 @@ __device__ __forceinline__ void make_foot(const Tap &t, unsigned map_slot, unsig
 
 template <typename T>
 __global__ __launch_bounds__(256) void sweep_cl_kernel(
-    SweepGeom g, ClGrid tg, const uint4 *__restrict__ ws, const float *__restrict__ depths,
+    SweepGeom g, ClGrid tg, const uint4 *__restrict__ ws, const uint4 *__restrict__ cur_maps,
+    const uint4 *__restrict__ prev_maps, const float *__restrict__ depths,
     const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
     uint4 *__restrict__ out)
 {
+    // cur_maps / prev_maps: the pixel-major maps (B, H, W, C) -- the packed copies inside `ws`, or the
+    // caller's own channels-last (NHWC) feature maps sampled where they lie.  Tap slots are relative
+    // to the lane's map; an out-of-bounds corner is the sentinel slot and reads the zero pixel at ws.
     constexpr int CB = elem<T>::CB;
+    constexpr unsigned ZERO = 0xffffffffu;
     __shared__ Foot foot[256][2];
     const int tid = threadIdx.x;
     // block id = ((tile*D + d)*B + b): sample fastest -> id % 8 == XCD keeps a sample's
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(256) void sweep_cl_kernel(
                     nullptr);
         const Tap tc = make_tap(cx, cy, g.h_in, g.w_in);
         const Tap tp = make_tap(px, py, g.h_in, g.w_in);
-        make_foot(tc, tg.cur_slot + (unsigned)b * HW * g.nblk, tg.zero_slot, g.w_in, g.nblk, foot[tid][0]);
-        make_foot(tp, tg.prev_slot + (unsigned)b * HW * g.nblk, tg.zero_slot, g.w_in, g.nblk, foot[tid][1]);
+        make_foot(tc, (unsigned)b * HW * g.nblk, ZERO, g.w_in, g.nblk, foot[tid][0]);
+        make_foot(tp, (unsigned)b * HW * g.nblk, ZERO, g.w_in, g.nblk, foot[tid][1]);
     }
     __syncthreads();
 
@@ -119,6 +124,7 @@ __global__ __launch_bounds__(256) void sweep_cl_kernel(
     const int half = (lane >> tg.lpi_shift) & 1;
     const int pin = lane >> (tg.lpi_shift + 1);
     const int ppi = 64 >> (tg.lpi_shift + 1);  // points per iteration
+    const uint4 *mp = half ? prev_maps : cur_maps;
     // out slot of (point n, map, block): ((b*N + n)*2 + map)*nblk + block
     const size_t plane0 = ((size_t)b * g.N + (size_t)d * hw + p0) * 2;
     // U points in flight per lane: the loop body is one dependent chain (LDS read -> 4 tap
@@ -136,7 +142,8 @@ __global__ __launch_bounds__(256) void sweep_cl_kernel(
                 const Foot f = foot[min(qq[u], qlast)][half];  // past the tile end: reload, never stored
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    tap[u][k] = ws[f.slot[k] + blk];
+                    const uint4 *src = f.slot[k] == ZERO ? ws : mp + f.slot[k];
+                    tap[u][k] = src[blk];
                     wgt[u][k] = f.w[k];
                 }
             }
@@ -341,11 +348,9 @@ DFM_API size_t dfm_plane_sweep_cl_workspace_bytes(const dfm_sweep_desc *d)
     return zero + 2 * map_bytes(d);
 }
 
-DFM_API int dfm_plane_sweep_fwd_channels_last(const dfm_sweep_desc *d, const void *cur,
-                                              const void *prev, const float *depths,
-                                              const float *cam2img, const float *cam2img_inv,
-                                              const float *cur2prev, void *out, void *workspace,
-                                              size_t workspace_bytes, void *stream)
+static int sweep_cl_impl(const dfm_sweep_desc *d, const void *cur, const void *prev, const float *depths,
+                         const float *cam2img, const float *cam2img_inv, const float *cur2prev, void *out,
+                         void *workspace, size_t workspace_bytes, void *stream, bool nhwc)
 {
     int rc = sweep_check_desc(d);
     if (rc != DFM_OK) return rc;
@@ -355,13 +360,15 @@ DFM_API int dfm_plane_sweep_fwd_channels_last(const dfm_sweep_desc *d, const voi
     if (d->channels % CB)
         return set_error(DFM_ERR_UNSUPPORTED,
                          "channels-last output needs channels to be a multiple of 16 bytes");
-    if (!workspace || workspace_bytes < dfm_plane_sweep_cl_workspace_bytes(d))
-        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_plane_sweep_cl_workspace_bytes");
     const SweepGeom g = sweep_make_geom(d);
     const size_t esz = d->dtype == DFM_BF16 ? 2 : 4;
     const size_t zero = ((size_t)d->channels * esz + 255) & ~(size_t)255;
     const size_t mb = map_bytes(d);
-    if ((zero + 2 * mb) / 16 >= (1ull << 32))
+    if (!workspace || workspace_bytes < (nhwc ? zero : dfm_plane_sweep_cl_workspace_bytes(d)))
+        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_plane_sweep_cl_workspace_bytes");
+    if (nhwc && (((uintptr_t)cur | (uintptr_t)prev) & 15))
+        return set_error(DFM_ERR_INVALID_ARG, "channels-last feature maps must be 16-byte aligned");
+    if (mb / 16 >= 0xffffffffull)
         return set_error(DFM_ERR_UNSUPPORTED, "feature maps too large for 32-bit tap slots");
     hipStream_t st = (hipStream_t)stream;
     char *w8 = (char *)workspace;
@@ -381,7 +388,11 @@ DFM_API int dfm_plane_sweep_fwd_channels_last(const dfm_sweep_desc *d, const voi
     tg.prev_slot = (unsigned)((zero + mb) / 16);
     const long long nb = (long long)tg.tiles * g.D * d->batch;
     if (nb > 2147483647ll) return set_error(DFM_ERR_UNSUPPORTED, "too many lattice points");
-    if (d->dtype == DFM_F32) {
+    const uint4 *cur_maps = (const uint4 *)(nhwc ? (const char *)cur : w8 + zero);
+    const uint4 *prev_maps = (const uint4 *)(nhwc ? (const char *)prev : w8 + zero + mb);
+    if (nhwc) {
+        // the caller's maps ARE pixel-major: nothing to re-lay
+    } else if (d->dtype == DFM_F32) {
         hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg, dim3(256), 0, st, (const float *)cur,
                            (float *)(w8 + zero), d->channels, d->channels, HW);
         hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg, dim3(256), 0, st, (const float *)prev,
@@ -396,16 +407,35 @@ DFM_API int dfm_plane_sweep_fwd_channels_last(const dfm_sweep_desc *d, const voi
     const bool timed = profile_mark(stream, false);
     if (d->dtype == DFM_F32)
         hipLaunchKernelGGL(sweep_cl_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, g, tg,
-                           (const uint4 *)workspace, depths, cam2img, cam2img_inv, cur2prev,
-                           (uint4 *)out);
+                           (const uint4 *)workspace, cur_maps, prev_maps, depths, cam2img, cam2img_inv,
+                           cur2prev, (uint4 *)out);
     else
         hipLaunchKernelGGL(sweep_cl_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, g, tg,
-                           (const uint4 *)workspace, depths, cam2img, cam2img_inv, cur2prev,
-                           (uint4 *)out);
+                           (const uint4 *)workspace, cur_maps, prev_maps, depths, cam2img, cam2img_inv,
+                           cur2prev, (uint4 *)out);
     if (timed) profile_mark(stream, true);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
+}
+
+DFM_API int dfm_plane_sweep_fwd_channels_last(const dfm_sweep_desc *d, const void *cur,
+                                              const void *prev, const float *depths,
+                                              const float *cam2img, const float *cam2img_inv,
+                                              const float *cur2prev, void *out, void *workspace,
+                                              size_t workspace_bytes, void *stream)
+{
+    return sweep_cl_impl(d, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace,
+                         workspace_bytes, stream, false);
+}
+
+DFM_API int dfm_plane_sweep_fwd_nhwc(const dfm_sweep_desc *d, const void *cur, const void *prev,
+                                     const float *depths, const float *cam2img,
+                                     const float *cam2img_inv, const float *cur2prev, void *out,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    return sweep_cl_impl(d, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace,
+                         workspace_bytes, stream, true);
 }
 
 }  // extern "C"

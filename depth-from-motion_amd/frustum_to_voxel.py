@@ -110,7 +110,13 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     desc.stereo_atten = 1 if stereo_atten_feat else 0
     desc.no_sem_atten = 0 if sem_atten_feat else 1
     if cur_sem_feats is not None:
-        sem = cur_sem_feats.to(stereo.dtype).contiguous()
+        sem = cur_sem_feats.to(stereo.dtype)
+        # an NHWC semantic map (channels_last 2-D neck) is sampled in place by the 16-byte-block kernel
+        sem_cl = (C % vec == 0 and cs % vec == 0 and not sem.is_contiguous() and
+                  sem.is_contiguous(memory_format=torch.channels_last) and sem.data_ptr() % 16 == 0)
+        desc.sem_channels_last = 1 if sem_cl else 0
+        if not sem_cl:
+            sem = sem.contiguous()
         desc.sem_channels, desc.hsem, desc.wsem = sem.shape[1:]
     if stereo_atten_feat or (sem is not None and sem_atten_feat):  # pred_disp is wanted (:133)
         if isinstance(stereo_feat_softmax, LazyDepthDistribution):

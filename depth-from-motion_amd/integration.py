@@ -58,6 +58,16 @@ def inject_detector_attributes(detector, depth_cfg=None, voxel_cfg=None):
     return detector
 
 
+def bev_view(vol):
+    """``volume_feat.reshape(-1, C * Nz, Ny, Nx)`` (detectors/dfm.py: the voxel volume seen from above,
+    height folded into the channels).  On the GPU the copy this reshape needs anyway (the volume is
+    channels_last_3d) lands directly in NHWC, the layout BEVHourglass's 2-D convolutions run in."""
+    B, C, nz, ny, nx = vol.shape
+    if not vol.is_cuda:
+        return vol.reshape(B, C * nz, ny, nx)
+    return vol.permute(0, 3, 4, 1, 2).reshape(B, ny, nx, C * nz).permute(0, 3, 1, 2)
+
+
 class DfMStereoPath(nn.Module):
     """The plane-sweep path of the ``DfM`` detector, built from its config ``model`` dict.
 
@@ -115,7 +125,7 @@ class DfMStereoPath(nn.Module):
                 out['volume_feat'] = vol
                 if self.backbone_3d is not None:
                     _, cv, nz, ny, nx = vol.shape
-                    out['bev_feat_prehg'], out['bev_feat'] = self.backbone_3d(vol.reshape(-1, cv * nz, ny, nx))
+                    out['bev_feat_prehg'], out['bev_feat'] = self.backbone_3d(bev_view(vol))
         return out
 
     def loss_dense_depth(self, out, depth_img, depth_fgmask_img=None):

@@ -167,6 +167,9 @@ class _WindowMean2d(nn.AvgPool2d):
             return super().forward(x)
         B, C, H, W = x.shape
         ho, wo = H // kh, W // kw
+        if not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):
+            v = x.permute(0, 2, 3, 1)[:, :ho * kh, :wo * kw].reshape(B, ho, kh, wo, kw, C)
+            return v.float().mean(dim=(2, 4)).to(x.dtype).permute(0, 3, 1, 2)  # stays channels_last
         v = x[:, :, :ho * kh, :wo * kw].reshape(B, C, ho, kh, wo, kw)
         return v.float().mean(dim=(3, 5)).to(x.dtype)
 
@@ -575,6 +578,21 @@ class upconv_module(nn.Module):  # noqa: N801  (reference class name)
         return x
 
 
+def _channels_last_2d(module, feats):
+    """The 2-D producers / consumers either side of the path (SPPUNetNeck,
+    BEVHourglass) run NHWC on the GPU: MIOpen's bf16 / fp32 2-D convolutions are NHWC kernels and wrap
+    an NCHW call in two transposes each (profiles/r02_c29: 588 batched_transpose launches per
+    DfMStereoPath forward), and the stereo / semantic maps they emit are then already in the
+    pixel-major layout the plane sweep and FrustumToVoxel sample (no pack pass).  The 4-D weights
+    are re-laid once; shapes, values and state_dict keys are untouched."""
+    if not feats[0].is_cuda:
+        return feats
+    if not module.__dict__.get('_weights_channels_last', False):
+        module.to(memory_format=torch.channels_last)
+        module.__dict__['_weights_channels_last'] = True
+    return [f.contiguous(memory_format=torch.channels_last) for f in feats]
+
+
 def _gn_relu(seq, x, relu, residual=None):
     """conv -> norm (+residual) (+ReLU), one pass when the norm is the HIP GroupNorm / BatchNorm3d"""
     x = seq[0](x)
@@ -630,6 +648,7 @@ class BEVHourglass(nn.Module):
         pass
 
     def forward(self, spatial_features):
+        spatial_features, = _channels_last_2d(self, [spatial_features])
         prehg = self.compress_conv(spatial_features)
         x = self.bev_hourglass(prehg, None, None)[0]
         return (prehg, x) if self.output_prehg_feat else x
@@ -679,6 +698,7 @@ class SPPUNetNeck(nn.Module):
     def forward(self, feats):
         feat_shape = tuple(feats[self.start_level].shape[2:])
         assert len(feats) == len(self.in_channels)
+        feats = _channels_last_2d(self, list(feats))
         spp = [F.interpolate(branch(feats[-1]), feat_shape, mode='bilinear', align_corners=True)
                for branch in self.spp_branches]
         concat_feature = torch.cat((*feats[self.start_level:], *spp), 1)

@@ -180,13 +180,34 @@ def _current_opts(schedule=None):
     return o
 
 
+def _nhwc(t):
+    """(B, C, H, W) stored (B, H, W, C): torch channels_last, 16-byte aligned whole channel blocks"""
+    return (t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last) and
+            t.shape[1] % (16 // t.element_size()) == 0 and t.data_ptr() % 16 == 0)
+
+
 def plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T, out=None,
                         channels_last=False, schedule=None):
     """Raw launch: everything already on the device.  ``channels_last``: write the volume
-    as (B, D, H, W, 2C) and return it as a (B, 2C, D, H, W) channels_last_3d tensor.
+    as (B, D, H, W, 2C) and return it as a (B, 2C, D, H, W) channels_last_3d tensor; channels_last
+    (NHWC) feature maps are then sampled in place (``dfm_plane_sweep_fwd_nhwc``: no pack pass).
     ``schedule``: bands_per_chunk of this call (None: tuned / default)."""
     lib = _capi.lib()
     device = cur_feats.device
+    if channels_last and _nhwc(cur_feats) and _nhwc(prev_feats):
+        if out is None:
+            out = torch.empty((desc.batch, desc.num_depths, desc.h_out, desc.w_out, 2 * desc.channels),
+                              dtype=cur_feats.dtype, device=device).permute(0, 4, 1, 2, 3)
+        assert out.is_contiguous(memory_format=torch.channels_last_3d)
+        nbytes = 256 + 4 * desc.channels
+        ws = _Workspace.get(device, nbytes)
+        with torch.cuda.device(device):
+            _capi.check(
+                lib.dfm_plane_sweep_fwd_nhwc(
+                    ctypes.byref(desc), _ptr(cur_feats), _ptr(prev_feats), _ptr(depths), _ptr(P),
+                    _ptr(Pinv), _ptr(T), _ptr(out), _ptr(ws), nbytes, _stream_ptr(device)))
+        return out
+    cur_feats, prev_feats = cur_feats.contiguous(), prev_feats.contiguous()
     if channels_last:
         if out is None:
             out = torch.empty((desc.batch, desc.num_depths, desc.h_out, desc.w_out, 2 * desc.channels),
@@ -314,8 +335,9 @@ def build_dfm_cost(cur_feats,
         raise TypeError('cur_feats/prev_feats must both be float32 or bfloat16')
     assert cur_feats.dim() == 4 and cur_feats.shape == prev_feats.shape
     device = cur_feats.device
-    cur_feats = cur_feats.contiguous()
-    prev_feats = prev_feats.contiguous()
+    if not (memory_format == torch.channels_last_3d and _nhwc(cur_feats) and _nhwc(prev_feats)):
+        cur_feats = cur_feats.contiguous()   # NHWC maps feeding a channels-last volume stay as they are
+        prev_feats = prev_feats.contiguous()
     depths = depths.reshape(-1).to(device=device, dtype=torch.float32).contiguous()
     batch_size = cur_feats.shape[0]
     desc = _make_desc(cur_feats, depths.numel(), feat_sample_factor, cost_sample_factor, img_shape,

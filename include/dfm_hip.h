@@ -142,6 +142,14 @@ DFM_API int dfm_plane_sweep_fwd_channels_last(const dfm_sweep_desc *desc, const 
                                               const float *cam2img, const float *cam2img_inv,
                                               const float *cur2prev, void *out, void *workspace,
                                               size_t workspace_bytes, void *stream);
+/* The same, with cur / prev ALSO channels-last: (B, h_in, w_in, C) contiguous (torch channels_last,
+ * what an NHWC 2-D neck emits -- SURVEY.md 8f rank 3), 16-byte aligned.  They are the kernel's
+ * pixel-major layout already and are sampled where they lie: no pack pass; the workspace only has to
+ * hold one zero pixel (>= 256 + 4 * channels bytes is always enough). */
+DFM_API int dfm_plane_sweep_fwd_nhwc(const dfm_sweep_desc *desc, const void *cur, const void *prev,
+                                     const float *depths, const float *cam2img,
+                                     const float *cam2img_inv, const float *cur2prev, void *out,
+                                     void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Backward of the two bilinear samplings w.r.t. the feature maps.
@@ -326,6 +334,9 @@ typedef struct dfm_f2v_desc {
     int32_t no_sem_atten;  /* 1: sem_atten_feat=False, Voxel_2D is NOT weighted by pred_disp (:154);
                             * both 0 = the shipped config; when neither attention is on, softmax may
                             * be NULL (the reference never samples it, :133)                           */
+    int32_t sem_channels_last; /* forward only, with the 16-byte-block kernel: cur_sem_feats is
+                            * (B, hsem, wsem, Cs) in memory (torch channels_last, what an NHWC 2-D neck
+                            * emits): sampled in place, no pixel-major copy                            */
 } dfm_f2v_desc;
 
 /*

@@ -250,3 +250,15 @@ def test_channels_last_output_is_the_same_tensor(dtype):
     assert cl.shape == ref.shape and cl.is_contiguous(memory_format=torch.channels_last_3d)
     assert not cl.is_contiguous()
     assert torch.equal(cl, ref)
+    # an NHWC semantic map (channels_last 2-D neck) is sampled in place: same tensor
+    dev = torch.device('cuda:0')
+    metas = [{'cam2img': c.tolist(), 'pad_shape': tuple(int(v) for v in z['pad_shape']) + (3,)}
+             for c in z['cam2img']]
+    sem = torch.from_numpy(z['sem']).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    assert not sem.is_contiguous()
+    for fmt in (torch.contiguous_format, torch.channels_last_3d):
+        got = pkg.frustum_to_voxel_sample(
+            torch.from_numpy(z['stereo']).to(dev).to(dtype).contiguous(memory_format=fmt),
+            torch.from_numpy(z['softmax']).to(dev).to(dtype), metas, sem, torch.from_numpy(z['coordinates_3d']),
+            dict(depth_min=float(z['depth_min']), depth_max=float(z['depth_max'])))
+        assert torch.equal(got, ref)

@@ -313,6 +313,18 @@ def test_channels_last_volume_equals_reference_layout(pkg, case, dtype, kernel_m
     ob, rb = out.contiguous().view(-1), ref.view(-1)
     bits = torch.int32 if dtype == torch.float32 else torch.int16
     assert torch.equal(ob.view(bits), rb.view(bits))
+    # channels_last (NHWC) feature maps -- what the channels_last 2-D neck emits -- are sampled in
+    # place (dfm_plane_sweep_fwd_nhwc, no pack pass): the same volume bit for bit
+    if C % (16 // c.element_size()) == 0:
+        sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+        cn, pn = (t.contiguous(memory_format=torch.channels_last) for t in (c, p))
+        assert sweep._nhwc(cn) and not sweep._nhwc(c)
+        out2 = pkg.build_dfm_cost(cn, pn, *args, memory_format=torch.channels_last_3d)
+        assert out2.is_contiguous(memory_format=torch.channels_last_3d)
+        assert torch.equal(out2.contiguous().view(-1).view(bits), rb.view(bits))
+        # (the reference layout from NHWC maps goes through a contiguous copy)
+        out3 = pkg.build_dfm_cost(cn, pn, *args)
+        assert torch.equal(out3.view(-1).view(bits), rb.view(bits))
 
 
 def test_channels_last_backward_and_errors(pkg, kernel_mode):
@@ -331,6 +343,12 @@ def test_channels_last_backward_and_errors(pkg, kernel_mode):
     c.grad = p.grad = None
     pkg.build_dfm_cost(c, p, *args).backward(g)
     assert torch.allclose(gc, c.grad, rtol=1e-5, atol=1e-6) and torch.allclose(gp, p.grad, rtol=1e-5, atol=1e-6)
+    # NHWC feature maps: same gradients
+    cn = c.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pn = p.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pkg.build_dfm_cost(cn, pn, *args, memory_format=torch.channels_last_3d).backward(
+        g.contiguous(memory_format=torch.channels_last_3d))
+    assert torch.allclose(gc, cn.grad, rtol=1e-5, atol=1e-6) and torch.allclose(gp, pn.grad, rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError):  # 6 channels are not a whole 16-byte block
         pkg.build_dfm_cost(c[:, :6].detach(), p[:, :6].detach(), *args, memory_format=torch.channels_last_3d)
 
