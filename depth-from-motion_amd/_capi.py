@@ -165,7 +165,7 @@ class Conv3dDesc(ctypes.Structure):
                 ('in_size', ctypes.c_int32 * 3), ('out_size', ctypes.c_int32 * 3),
                 ('stride', ctypes.c_int32 * 3), ('padding', ctypes.c_int32 * 3),
                 ('transposed', ctypes.c_int32 * 3), ('relu', ctypes.c_int32),
-                ('in_channel_stride', ctypes.c_int32)]
+                ('in_channel_stride', ctypes.c_int32), ('kernel1', ctypes.c_int32 * 3)]
 
 
 class Conv3dWgradDesc(ctypes.Structure):

@@ -406,19 +406,21 @@ def _ndhwc_channel_stride(x):
     return ps if ps >= C and ps % 8 == 0 else 0
 
 
-def _conv_desc(n, cin, cout, in_size, out_size, stride, padding, transposed, relu, in_channel_stride=0):
+def _conv_desc(n, cin, cout, in_size, out_size, stride, padding, transposed, relu, in_channel_stride=0,
+               kernel1=(False, False, False)):
     d = _capi.Conv3dDesc()
     d.n, d.cin, d.cout, d.relu = n, cin, cout, 1 if relu else 0
     d.in_channel_stride = 0 if in_channel_stride == cin else in_channel_stride
     for i in range(3):
         d.in_size[i], d.out_size[i] = in_size[i], out_size[i]
         d.stride[i], d.padding[i], d.transposed[i] = stride[i], padding[i], 1 if transposed[i] else 0
+        d.kernel1[i] = 1 if kernel1[i] else 0
     return d
 
 
-def conv3d_g_out_size(in_size, stride, padding, transposed):
-    return tuple(2 * s if t else (s + 2 * p - 3) // st + 1
-                 for s, st, p, t in zip(in_size, stride, padding, transposed))
+def conv3d_g_out_size(in_size, stride, padding, transposed, kernel1=(False, False, False)):
+    return tuple(2 * s if t else ((s - 1) // st + 1 if k1 else (s + 2 * p - 3) // st + 1)
+                 for s, st, p, t, k1 in zip(in_size, stride, padding, transposed, kernel1))
 
 
 def conv3d_g_plan(n, cin, cout, in_size, stride=1, padding=1, transposed=False):
@@ -434,18 +436,20 @@ def conv3d_g_plan(n, cin, cout, in_size, stride=1, padding=1, transposed=False):
 
 
 def conv3d_g(x, packed, cout, stride=1, padding=1, transposed=False, relu=False, scale=None, shift=None,
-             residual=None):
+             residual=None, kernel1=False):
     """x: (N, C_in, D, H, W) bf16 channels_last_3d.  Returns (N, cout, D', H', W') bf16
     channels_last_3d = relu?(conv(x) * scale + shift + residual).  ``transposed``: per-axis flags of
-    the x2 transposed convolution (kernel 3, stride 2, padding 1, output_padding 1)."""
+    the x2 transposed convolution (kernel 3, stride 2, padding 1, output_padding 1); ``kernel1``:
+    per-axis flags of kernel extent 1 (padding 0; the packed 27-tap weights' centre index is used)."""
     cstride = _ndhwc_channel_stride(x)
     assert x.is_cuda and x.dtype == torch.bfloat16 and cstride, 'bf16 channels_last_3d (or a channel slice of it)'
     stride, padding, transposed = _triple(stride), _triple(padding), _triple(transposed)
+    kernel1 = _triple(kernel1)
     N, cin = x.shape[:2]
     in_size = tuple(x.shape[2:])
-    out_size = conv3d_g_out_size(in_size, stride, padding, transposed)
+    out_size = conv3d_g_out_size(in_size, stride, padding, transposed, kernel1)
     out = torch.empty((N, *out_size, cout), dtype=torch.bfloat16, device=x.device)
-    d = _conv_desc(N, cin, cout, in_size, out_size, stride, padding, transposed, relu, cstride)
+    d = _conv_desc(N, cin, cout, in_size, out_size, stride, padding, transposed, relu, cstride, kernel1)
     if scale is not None:
         scale, shift = scale.float().contiguous(), shift.float().contiguous()
         assert scale.numel() == cout and shift.numel() == cout
@@ -458,6 +462,94 @@ def conv3d_g(x, packed, cout, stride=1, padding=1, transposed=False, relu=False,
             _ptr(shift) if shift is not None else None, _ptr(residual) if residual is not None else None,
             _ptr(out), _stream_ptr(x.device)))
     return out.permute(0, 4, 1, 2, 3)
+
+
+# ---------------------------------------------------------------------------------------------
+# 2-D 3x3 convolutions through the same kernel: an NHWC (channels_last) tensor is a depth-1 NDHWC
+# volume and the kernel is (1, 3, 3).  The 2-D producers / consumers either side of the path
+# (SURVEY.md 8f rank 3): SPPUNetNeck (necks/spp_unet_neck.py), BEVHourglass / hourglass2d
+# (backbones/bev_hourglass.py, utils/conv_modules.py).  Inference (no autograd through these).
+# ---------------------------------------------------------------------------------------------
+def pack_conv2d_g_weights(weight, cin, cout, swap=False):
+    """torch 2-D weight (dim0, dim1, 3, 3) -> the 27-tap fragment buffer with the 2-D kernel in its
+    centre depth slice (the depth axis runs with kernel extent 1)"""
+    assert weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+    w3 = weight.new_zeros((*weight.shape[:2], 3, 3, 3))
+    w3[:, :, 1] = weight.detach()
+    return pack_conv3d_g_weights(w3, cin, cout, swap=swap)
+
+
+def conv2d_g_eligible(x, cin, cout):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and cin % 32 == 0 and cout % 32 == 0 and
+            x.shape[1] == cin and not torch.is_grad_enabled() and
+            (x.is_contiguous(memory_format=torch.channels_last) and x.stride(1) == 1))
+
+
+def conv2d_g(x, packed, cout, stride=1, transposed=False, relu=False, scale=None, shift=None, residual=None):
+    """x: (N, C_in, H, W) bf16 channels_last.  3x3 convolution, padding 1, stride 1 | 2 -- or the x2
+    transposed convolution (kernel 3, stride 2, padding 1, output_padding 1) -- with the fused epilogue
+    of ``conv3d_g``; returns (N, cout, H', W') bf16 channels_last."""
+    sh, sw = (stride, stride) if not isinstance(stride, (tuple, list)) else tuple(stride)[-2:]
+    x5 = x.unsqueeze(2)
+    res5 = residual.unsqueeze(2) if residual is not None else None
+    y = conv3d_g(x5, packed, cout, stride=(1, sh, sw), padding=(0, 1, 1),
+                 transposed=(False, bool(transposed), bool(transposed)), relu=relu, scale=scale, shift=shift,
+                 residual=res5, kernel1=(True, False, False))
+    return y.squeeze(2)
+
+
+class _Mfma2dMixin:
+    """packs the 2-D weight once per version (inference: the weights do not change between calls)"""
+
+    def _packed2d(self, cin, cout, swap):
+        key = (self.weight._version, self.weight.data_ptr(), str(self.weight.device))
+        if self.__dict__.get('_pack2d_key') != key:
+            self.__dict__['_pack2d'] = pack_conv2d_g_weights(self.weight, cin, cout, swap=swap)
+            self.__dict__['_pack2d_key'] = key
+        return self.__dict__['_pack2d']
+
+
+class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
+    """nn.Conv2d (same parameters / state_dict keys).  kernel 3, padding 1, stride 1 | 2, dilation 1,
+    groups 1, channels = 32 k, bf16 channels_last input under no_grad: the hand-written MFMA kernel
+    (csrc/conv3d_g.hip with a (1, 3, 3) kernel); anything else: torch's convolution, the module's other
+    documented path.  ``forward_fused`` = relu?(conv(x) * scale + shift + residual) in one launch
+    (eval-mode BatchNorm / bias folded into the epilogue)."""
+
+    def eligible(self, x):
+        return (self.kernel_size == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1) and
+                self.groups == 1 and self.stride in ((1, 1), (2, 2)) and self.padding_mode == 'zeros' and
+                conv2d_g_eligible(x, self.in_channels, self.out_channels))
+
+    def forward_fused(self, x, scale=None, shift=None, residual=None, relu=False):
+        if self.bias is not None:
+            b = self.bias.float()
+            shift = b if shift is None else shift + b * (scale if scale is not None else 1.0)
+            if scale is None:
+                scale = torch.ones_like(b)
+        return conv2d_g(x, self._packed2d(self.in_channels, self.out_channels, False), self.out_channels,
+                        stride=self.stride, relu=relu, scale=scale, shift=shift, residual=residual)
+
+    def forward(self, x):
+        if self.eligible(x):
+            return self.forward_fused(x)
+        return super().forward(x)
+
+
+class MfmaConvTranspose2d(nn.ConvTranspose2d, _Mfma2dMixin):
+    """nn.ConvTranspose2d kernel 3, stride 2, padding 1, output_padding 1 (hourglass2d's up-convs,
+    conv_modules.py:196-214) through the MFMA kernel under the conditions of ``MfmaConv2d``."""
+
+    def eligible(self, x):
+        return (self.kernel_size == (3, 3) and self.padding == (1, 1) and self.stride == (2, 2) and
+                self.output_padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1 and
+                self.bias is None and conv2d_g_eligible(x, self.in_channels, self.out_channels))
+
+    def forward(self, x, output_size=None):
+        if output_size is None and self.eligible(x):
+            return conv2d_g(x, self._packed2d(self.in_channels, self.out_channels, True), self.out_channels,
+                            transposed=True)
+        return super().forward(x, output_size)
 
 
 def _bwd_data_supported(in_size, stride, padding):

@@ -51,6 +51,8 @@ struct GAxis {
     int32_t pad;       // 0..2 (correlation axes)
     int32_t up;        // 1: x2 transposed-convolution axis
     int32_t tiles;
+    int32_t k1;        // 1: the kernel has extent 1 along this axis (2-D convolutions run as depth-1
+                       // volumes: kernel (1, 3, 3)); the only tap is the packed weights' centre index
 };
 
 struct GGeom {
@@ -195,14 +197,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
         }
 
         // taps of this class: counters (jd, jh, jw) -> (weight tap index, block offset in pixels)
-        const int ntw = g.w.up ? 1 + pcw : 3, nth = g.h.up ? 1 + pch : 3, ntd = g.d.up ? 1 + pcd : 3;
+        const int ntw = g.w.up ? 1 + pcw : (g.w.k1 ? 1 : 3), nth = g.h.up ? 1 + pch : (g.h.k1 ? 1 : 3),
+                  ntd = g.d.up ? 1 + pcd : (g.d.k1 ? 1 : 3);
         const int ntaps = ntd * nth * ntw;
         int jd = 0, jh = 0, jw = 0;
         auto tap_cur = [&](int &wt, int &off) {
             // correlation axis: k = j at offset j; up axis: even class -> k 1 @ +0; odd -> k 2 @ +0, k 0 @ +1
-            const int kw = g.w.up ? (pcw ? (jw ? 0 : 2) : 1) : jw;
-            const int kh = g.h.up ? (pch ? (jh ? 0 : 2) : 1) : jh;
-            const int kd = g.d.up ? (pcd ? (jd ? 0 : 2) : 1) : jd;
+            const int kw = g.w.up ? (pcw ? (jw ? 0 : 2) : 1) : (g.w.k1 ? 1 : jw);
+            const int kh = g.h.up ? (pch ? (jh ? 0 : 2) : 1) : (g.h.k1 ? 1 : jh);
+            const int kd = g.d.up ? (pcd ? (jd ? 0 : 2) : 1) : (g.d.k1 ? 1 : jd);
             wt = (kd * 3 + kh) * 3 + kw;
             off = (jd * BH + jh) * BW + jw;
         };
@@ -395,7 +398,7 @@ void axis_fill(GAxis &a, int tile)
     a.tile = tile;
     const int space = a.up ? a.in : a.out;
     a.tiles = (space + tile - 1) / tile;
-    a.block = a.up ? tile + 1 : (tile - 1) * a.stride + 3;
+    a.block = a.up ? tile + 1 : (tile - 1) * a.stride + (a.k1 ? 1 : 3);
 }
 
 // picks (PFW, TD, TH, TW): minimum estimated time = rounds of workgroups over the chip x per-workgroup
@@ -408,8 +411,11 @@ bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
     for (int i = 0; i < 3; ++i) {
         ax[i]->in = d->in_size[i]; ax[i]->out = d->out_size[i];
         ax[i]->stride = d->stride[i]; ax[i]->pad = d->padding[i]; ax[i]->up = d->transposed[i] ? 1 : 0;
+        ax[i]->k1 = d->kernel1[i] ? 1 : 0;
         if (ax[i]->up) classes *= 2;
     }
+    double ntap_all = 1.0;
+    for (int i = 0; i < 3; ++i) ntap_all *= d->kernel1[i] ? 1.0 : 3.0;
     g.cin = d->cin; g.cout = d->cout; g.nchunk = d->cin / 32;
 #ifdef DFM_DEBUG_HOOKS
     {
@@ -454,7 +460,7 @@ bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
                 // per-workgroup cost in clocks.  One tap = 2 k-steps: 2*pfw*cw MFMAs of 32 clocks per
                 // wave, against 4 waves x 2*cw KiB of weight fragments from L2 (~40 B/clk/CU); resident
                 // workgroups share both the MFMA pipes and the L2 port.  Staging ~ 0.1 clk/B.
-                const double taps = resident ? 27.0 : 27.0 / classes;
+                const double taps = resident ? ntap_all : ntap_all / classes;
                 const double mf_tap = (double)pfw * cw * 64.0 * wg_per_cu;
                 const double wt_tap = 8192.0 * cw / 40.0 * wg_per_cu;
                 const double mf = std::max(mf_tap, wt_tap) * taps * g.nchunk;
@@ -482,7 +488,11 @@ int g_check(const dfm_conv3d_desc *d)
     long long in_px = 1, out_px = 1;
     for (int i = 0; i < 3; ++i) {
         if (d->in_size[i] <= 0 || d->out_size[i] <= 0) return set_error(DFM_ERR_INVALID_ARG, "non-positive size");
-        if (d->transposed[i]) {
+        if (d->kernel1[i]) {
+            if (d->transposed[i] || d->padding[i] != 0 || d->stride[i] < 1 || d->stride[i] > 2 ||
+                d->out_size[i] != (d->in_size[i] - 1) / d->stride[i] + 1)
+                return set_error(DFM_ERR_INVALID_ARG, "kernel-extent-1 axes: not transposed, padding 0, out = (in - 1) / stride + 1");
+        } else if (d->transposed[i]) {
             if (d->out_size[i] != 2 * d->in_size[i])
                 return set_error(DFM_ERR_UNSUPPORTED, "transposed axes are kernel 3, stride 2, padding 1, output_padding 1 (out = 2 in)");
         } else {

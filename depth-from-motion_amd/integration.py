@@ -28,6 +28,7 @@ from torch import nn
 
 from . import registry
 from .geometry import prepare_coordinates_3d, prepare_depth
+from .graphs import GraphedCallable
 from .plane_sweep import build_dfm_cost
 from .point_sample import mv_feature_transformation, point_sample, voxel_centers, voxel_sample
 
@@ -99,10 +100,26 @@ class DfMStereoPath(nn.Module):
         # inference-time DepthHead -> FrustumToVoxel fusion; set False to get
         # the materialised upsample_costs / upsample_costs_softmax in eval mode as well
         self.fuse_depth_head = True
+        # inference: replay the launch-bound 2-D necks (SPPUNetNeck, BEVHourglass) as hipGraphs
+        # (graphs.py); opt-in -- the graphs keep static input / output buffers per input signature
+        self.hip_graphs = False
+        self._graphed = {}
+
+    def _run_2d(self, name, module, tensors):
+        """module(tensors) -- through a captured hipGraph when ``hip_graphs`` is on and nothing records
+        gradients.  Each call site has its own graph (the outputs are static buffers: the neck's
+        results for the current frame must survive its call on the previous frame)."""
+        if not (self.hip_graphs and not torch.is_grad_enabled() and not self.training and tensors[0].is_cuda):
+            return module(tensors) if name.startswith('neck') else module(tensors[0])
+        g = self._graphed.get(name)
+        if g is None:
+            fn = (lambda ts: module(ts)) if name.startswith('neck') else (lambda ts: module(ts[0]))
+            g = self._graphed[name] = GraphedCallable(fn)
+        return g(tensors)
 
     def forward(self, cur_feats, prev_feats, img_metas):
-        cur_stereo, cur_sem = self.neck(cur_feats)
-        prev_stereo, _ = self.neck(prev_feats)
+        cur_stereo, cur_sem = self._run_2d('neck_cur', self.neck, list(cur_feats))
+        prev_stereo, _ = self._run_2d('neck_prev', self.neck, list(prev_feats))
         dev = cur_stereo.device
         for meta in img_metas:  # dfm.py:288-293: (N-1,4,4) tensors on the device
             meta['cur2prevs'] = torch.as_tensor(np.asarray(meta['cur2prevs'], dtype=np.float32)
@@ -125,7 +142,7 @@ class DfMStereoPath(nn.Module):
                 out['volume_feat'] = vol
                 if self.backbone_3d is not None:
                     _, cv, nz, ny, nx = vol.shape
-                    out['bev_feat_prehg'], out['bev_feat'] = self.backbone_3d(bev_view(vol))
+                    out['bev_feat_prehg'], out['bev_feat'] = self._run_2d('bev', self.backbone_3d, [bev_view(vol)])
         return out
 
     def loss_dense_depth(self, out, depth_img, depth_fgmask_img=None):

@@ -25,7 +25,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose3d, channel_slice
+from .conv3d import (MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose2d,
+                     MfmaConvTranspose3d, channel_slice)
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .group_norm import HipBatchNorm3d, HipGroupNorm
@@ -85,6 +86,11 @@ class ConvModule(nn.Module):
             # every other 3x3x3 convolution of the path (64 .. 256 channels, stride (1,1,2), padding
             # (1,1,0): the BN3d stacks of the voxel necks): the general MFMA kernel (csrc/conv3d_g.hip)
             conv_cls = MfmaConv3dG
+        elif (conv_type == 'Conv2d' and out_channels % 32 == 0 and in_channels % 32 == 0 and kernel_size == 3
+              and padding == 1 and stride in (1, 2)):
+            # the 3x3 convolutions of the 2-D necks either side of the path (SPPUNetNeck, BEVHourglass):
+            # the same MFMA kernel with a (1, 3, 3) kernel on the NHWC tensor as a depth-1 volume
+            conv_cls = MfmaConv2d
         self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride,
                              padding=padding, bias=norm_cfg is None)
         self.norm_name = None
@@ -553,10 +559,27 @@ class DfMNeck(nn.Module):
 #   SPPUNetNeck              mmdet3d/models/necks/spp_unet_neck.py
 # --------------------------------------------------------------------------
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation=1, gn=False, groups=32):
+    # (MfmaConv2d is an nn.Conv2d: same parameters and keys; its MFMA path covers kernel 3 / padding 1)
     return nn.Sequential(
-        nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
-                  padding=dilation if dilation > 1 else pad, dilation=dilation, bias=False),
+        MfmaConv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
+                   padding=dilation if dilation > 1 else pad, dilation=dilation, bias=False),
         nn.SyncBatchNorm(out_planes) if not gn else HipGroupNorm(groups, out_planes))
+
+
+def _conv_norm_2d(seq, x):
+    """Sequential(conv, norm) of the 2-D necks: an eval-mode BatchNorm folds into the MFMA
+    convolution's epilogue (one launch); otherwise conv, then norm"""
+    conv, norm = seq[0], seq[1]
+    if (isinstance(conv, MfmaConv2d) and isinstance(norm, nn.modules.batchnorm._BatchNorm) and
+            not norm.training and norm.track_running_stats and norm.affine and conv.eligible(x)):
+        key = tuple((t._version, t.data_ptr()) for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var))
+        if seq.__dict__.get('_fold_key') != key:
+            scale = norm.weight.float() / torch.sqrt(norm.running_var.float() + norm.eps)
+            seq.__dict__['_fold'] = (scale, norm.bias.float() - norm.running_mean.float() * scale)
+            seq.__dict__['_fold_key'] = key
+        scale, shift = seq.__dict__['_fold']
+        return conv.forward_fused(x, scale, shift)
+    return norm(conv(x))
 
 
 class upconv_module(nn.Module):  # noqa: N801  (reference class name)
@@ -574,7 +597,7 @@ class upconv_module(nn.Module):  # noqa: N801  (reference class name)
     def forward(self, feats):
         x = feats[0]
         for i in range(self.num_stage):
-            x = F.relu(self.up(self.conv[i](x)) + self.redir[i](feats[i + 1]))
+            x = F.relu(self.up(_conv_norm_2d(self.conv[i], x)) + _conv_norm_2d(self.redir[i], feats[i + 1]))
         return x
 
 
@@ -595,10 +618,9 @@ def _channels_last_2d(module, feats):
 
 def _gn_relu(seq, x, relu, residual=None):
     """conv -> norm (+residual) (+ReLU), one pass when the norm is the HIP GroupNorm / BatchNorm3d"""
-    x = seq[0](x)
     if isinstance(seq[1], (HipGroupNorm, HipBatchNorm3d)):
-        return seq[1](x, relu=relu, residual=residual)
-    x = seq[1](x)
+        return seq[1](seq[0](x), relu=relu, residual=residual)
+    x = _conv_norm_2d(seq, x) if isinstance(seq[0], MfmaConv2d) else seq[1](seq[0](x))
     if residual is not None:
         x = x + residual
     return F.relu(x) if relu else x
@@ -616,7 +638,7 @@ class hourglass2d(nn.Module):  # noqa: N801  (reference class name)
 
         def up(cin, cout):
             return nn.Sequential(
-                nn.ConvTranspose2d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False),
+                MfmaConvTranspose2d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False),
                 nn.SyncBatchNorm(cout) if not gn else HipGroupNorm(32, cout))
         self.conv5 = up(2 * c, 2 * c)
         self.conv6 = up(2 * c, c)
@@ -626,8 +648,8 @@ class hourglass2d(nn.Module):  # noqa: N801  (reference class name)
         pre = _gn_relu(self.conv2, out, False)
         pre = F.relu(pre if postsqu is None else pre + postsqu)
         out = _gn_relu(self.conv4[0], _gn_relu(self.conv3[0], pre, True), True)
-        post = F.relu(self.conv5(out) + (pre if presqu is None else presqu))
-        return self.conv6(post), pre, post
+        post = _gn_relu(self.conv5, out, True, pre if presqu is None else presqu)
+        return _gn_relu(self.conv6, post, False), pre, post
 
 
 @register_module
@@ -695,12 +717,39 @@ class SPPUNetNeck(nn.Module):
     def init_weights(self):
         pass
 
+    def _spp_pool(self, x):
+        """the four non-overlapping window means of the SPP branches (spp_unet_neck.py:60-70).  On the GPU
+        the map is read ONCE: the finest windows (8 x 8) are averaged in fp32 and the coarser means
+        (16, 32, 64: whole multiples, floor mode) are means of those -- instead of four passes over the
+        128-channel map, each through an fp32 copy."""
+        pools = [b[0] for b in self.spp_branches]
+        ks = [p.kernel_size if isinstance(p.kernel_size, tuple) else (p.kernel_size,) * 2 for p in pools]
+        fine = min(ks)
+        ok = (x.is_cuda and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last) and
+              all(isinstance(p, _WindowMean2d) and tuple(p.stride if isinstance(p.stride, tuple) else (p.stride,) * 2) == k
+                  and p.padding in (0, (0, 0)) and not p.ceil_mode and k[0] % fine[0] == 0 and k[1] % fine[1] == 0
+                  for p, k in zip(pools, ks)))
+        if not ok:
+            return [p(x) for p in pools]
+        B, C, H, W = x.shape
+        hf, wf = H // fine[0], W // fine[1]
+        base = x.permute(0, 2, 3, 1)[:, :hf * fine[0], :wf * fine[1]].reshape(B, hf, fine[0], wf, fine[1], C)
+        base = base.mean(dim=(2, 4), dtype=torch.float32)                       # (B, hf, wf, C) fp32
+        out = []
+        for k in ks:
+            rh, rw = k[0] // fine[0], k[1] // fine[1]
+            ho, wo = H // k[0], W // k[1]
+            v = base if (rh, rw) == (1, 1) else \
+                base[:, :ho * rh, :wo * rw].reshape(B, ho, rh, wo, rw, C).mean(dim=(2, 4))
+            out.append(v.to(x.dtype).permute(0, 3, 1, 2))                       # channels_last (B, C, ho, wo)
+        return out
+
     def forward(self, feats):
         feat_shape = tuple(feats[self.start_level].shape[2:])
         assert len(feats) == len(self.in_channels)
         feats = _channels_last_2d(self, list(feats))
-        spp = [F.interpolate(branch(feats[-1]), feat_shape, mode='bilinear', align_corners=True)
-               for branch in self.spp_branches]
+        spp = [F.interpolate(branch[1](pooled), feat_shape, mode='bilinear', align_corners=True)
+               for branch, pooled in zip(self.spp_branches, self._spp_pool(feats[-1]))]
         concat_feature = torch.cat((*feats[self.start_level:], *spp), 1)
         stereo_feature = concat_feature
         if self.with_upconv:

@@ -507,6 +507,10 @@ typedef struct dfm_conv3d_desc {
     int32_t in_channel_stride; /* elements between consecutive input pixels; 0 = cin.  > cin: x  */
                             /* is a channel slice of a wider channels-last tensor (pointer at   */
                             /* its first channel; multiple of 8 so pieces stay 16-byte aligned) */
+    int32_t kernel1[3];     /* != 0: the kernel has extent 1 along this axis (padding 0, not      */
+                            /* transposed; out = (in - 1) / stride + 1): kernel (1, 3, 3) is a 2-D  */
+                            /* convolution of an NHWC tensor seen as a depth-1 volume.  The packed  */
+                            /* weights keep 27 taps; the axis uses the centre index only            */
 } dfm_conv3d_desc;
 /* Bytes of the packed-weight buffer (27 * cin * cout bf16 in fragment order + a zero page). */
 DFM_API size_t dfm_conv3d_g_weight_bytes(int32_t cin, int32_t cout);

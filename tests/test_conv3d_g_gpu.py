@@ -263,3 +263,84 @@ def test_weight_gradient_of_the_transposed_convolution_and_of_channel_slices(cv)
     F.conv3d(x3.float(), w3, padding=1).backward(g3.float())
     got3 = cv.conv3d_weight_grad(_cl(x3, dev), _cl(g3, dev), 1, 1)
     np.testing.assert_allclose(got3.cpu().numpy(), w3.grad.numpy(), rtol=2e-2, atol=2e-2 * float(w3.grad.abs().max()))
+
+
+# ---- 2-D 3x3 convolutions: the same kernel with extent 1 along depth (kernel (1, 3, 3)) on an NHWC
+# tensor seen as a depth-1 volume -- SPPUNetNeck / BEVHourglass ---------------
+def _w2(d0, d1, fan_in, seed):
+    g = torch.Generator().manual_seed(seed + 2000)
+    return (torch.randn(d0, d1, 3, 3, generator=g) * (2.0 / (9 * fan_in)) ** 0.5).bfloat16().float()
+
+
+CONV2D_CASES = [(32, 32, (20, 37), 1), (64, 128, (22, 30), 2), (128, 128, (9, 11), 1), (512, 128, (12, 20), 1),
+                (160, 64, (19, 18), 1), (128, 128, (15, 17), 2), (64, 32, (40, 72), 1)]
+
+
+@pytest.mark.parametrize('cin,cout,size,stride', CONV2D_CASES)
+def test_conv2d_through_the_depth1_kernel_matches_torch(cv, cin, cout, size, stride):
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, *size, generator=g).bfloat16()
+    w = _w2(cout, cin, cin, seed=cin + 7 * cout)
+    ref = F.conv2d(x.float(), w, stride=stride, padding=1)
+    pk = cv.pack_conv2d_g_weights(w.to(dev), cin, cout)
+    xc = x.to(dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert cv.conv2d_g_eligible(xc, cin, cout)
+        out = cv.conv2d_g(xc, pk, cout, stride=stride)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+    # epilogue: folded BatchNorm (scale / shift) + residual + ReLU
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout)
+    res = torch.randn(ref.shape, generator=g).bfloat16()
+    ref2 = torch.relu(ref * scale[None, :, None, None] + shift[None, :, None, None] + res.float())
+    with torch.no_grad():
+        out2 = cv.conv2d_g(xc, pk, cout, stride=stride, relu=True, scale=scale.to(dev), shift=shift.to(dev),
+                           residual=res.to(dev).contiguous(memory_format=torch.channels_last))
+    np.testing.assert_allclose(out2.float().cpu().numpy(), ref2.numpy(), rtol=RTOL, atol=2 * ATOL)
+
+
+@pytest.mark.parametrize('cin,cout,size', [(128, 128, (9, 10)), (128, 64, (12, 19)), (64, 32, (5, 33))])
+def test_transposed_conv2d_through_the_depth1_kernel_matches_torch(cv, cin, cout, size):
+    """hourglass2d conv5 / conv6: ConvTranspose2d(k 3, s 2, p 1, output_padding 1)"""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(cin + size[1])
+    x = torch.randn(2, cin, *size, generator=g).bfloat16()
+    w = _w2(cin, cout, cin, seed=cout)
+    ref = F.conv_transpose2d(x.float(), w, stride=2, padding=1, output_padding=1)
+    pk = cv.pack_conv2d_g_weights(w.to(dev), cin, cout, swap=True)
+    with torch.no_grad():
+        out = cv.conv2d_g(x.to(dev).contiguous(memory_format=torch.channels_last), pk, cout, transposed=True)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_conv2d_modules_take_the_mfma_path_only_where_it_applies(cv, monkeypatch):
+    dev = torch.device('cuda:0')
+    calls = {'n': 0}
+    real = cv.conv3d_g
+
+    def counted(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(cv, 'conv3d_g', counted)
+    m = cv.MfmaConv2d(64, 96 + 32, 3, padding=1, bias=True).to(dev).bfloat16()
+    x = torch.randn(1, 64, 17, 23, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = F.conv2d(x.float(), m.weight.float(), m.bias.float(), padding=1)
+        y = m(x)
+    assert calls['n'] == 1
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=RTOL, atol=ATOL)
+    y2 = m(x)                                # autograd on: torch's convolution
+    assert calls['n'] == 1 and y2.requires_grad
+    with torch.no_grad():
+        m(x.contiguous())                     # NCHW input: torch
+        cv.MfmaConv2d(3, 32, 3, padding=1).to(dev).bfloat16()(x[:, :3].contiguous(memory_format=torch.channels_last))
+    assert calls['n'] == 1
+    t = cv.MfmaConvTranspose2d(64, 32, 3, stride=2, padding=1, output_padding=1, bias=False).to(dev).bfloat16()
+    with torch.no_grad():
+        yt = t(x)
+    assert calls['n'] == 2
+    with torch.no_grad():
+        reft = F.conv_transpose2d(x.float(), t.weight.float(), stride=2, padding=1, output_padding=1)
+    np.testing.assert_allclose(yt.float().cpu().numpy(), reft.cpu().numpy(), rtol=RTOL, atol=ATOL)

@@ -279,8 +279,10 @@ def test_dfm_stereo_path_inference_bf16_ndhwc_matches_fp32(pkg, monkeypatch):
     pb.backbone_stereo.volume_memory_format = torch.channels_last_3d
     with torch.no_grad():
         out = pb([t.bfloat16() for t in feats[0]], [t.bfloat16() for t in feats[1]], [meta()])
-    # 2 x 6 hourglass convolutions; dres0 (2 halves + mono), dres1 x 2, pred.0 x 2, voxel_convs (2 halves)
-    assert calls['g'] == 12 and calls['c32'] == 9, calls
+    # general kernel: 2 x 6 hourglass convolutions + the 3x3 2-D convolutions of SPPUNetNeck (2 x 6) and
+    # BEVHourglass (7) as (1, 3, 3) kernels; 32 -> 32 kernel: dres0 (2 halves + mono), dres1 x 2,
+    # pred.0 x 2, voxel_convs (2 halves)
+    assert calls['g'] == 12 + 12 + 7 and calls['c32'] == 9, calls
     assert out['volume_feat'].shape == (1, 32, 5, 64, 128) and out['bev_feat'].shape == (1, 64, 64, 128)
     for key in ('mono_stereo_costs', 'volume_feat', 'bev_feat'):
         a, b = out[key].float().cpu().numpy(), ref[key].float().cpu().numpy()
@@ -396,3 +398,68 @@ def test_res_module_trains_through_the_mfma_convolutions(mods):
     mostly_close(y, yr, 0.0)
     mostly_close(gx, gxr, 0.01)
     mostly_close(gw, gwr, 0.01)
+
+
+@pytest.mark.gpu
+def test_2d_necks_at_config_widths_mfma_path_vs_torch_path(mods, monkeypatch):
+    """SPPUNetNeck / BEVHourglass with the channel widths of configs/dfm/dfm_r34_1x8_kitti-3d-3class.py:
+    the bf16 channels_last inference path (3x3 convolutions and up-convolutions in the MFMA kernel
+    with a (1, 3, 3) kernel, eval-mode BatchNorm folded into its epilogue) against the same modules
+    run in fp32 by torch (itself pinned to the reference modules at small widths by
+    test_bev_hourglass_and_spp_unet_neck_vs_reference_modules)."""
+    cv = importlib.import_module('depth-from-motion_amd.conv3d')
+    calls = {'n': 0}
+    real = cv.conv3d_g
+
+    def counted(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(cv, 'conv3d_g', counted)
+    gn = dict(type='GN', num_groups=32, requires_grad=True)
+    gen = torch.Generator().manual_seed(71)
+    neck = _load(mods.SPPUNetNeck(in_channels=[3, 64, 128, 128, 128], start_level=2, sem_channels=[128, 32],
+                                  stereo_channels=[32, 32], with_upconv=True, cat_img_feature=True, norm_cfg=gn), 72)
+    H, W = 256, 512   # level-2..4 maps 64 x 128: one 64 x 64 SPP window row
+    feats = [torch.randn(1, c, H // s, W // s, generator=gen).cuda() for c, s in
+             ((3, 1), (64, 2), (128, 4), (128, 4), (128, 4))]
+    with torch.no_grad():
+        ref_st, ref_sem = neck(feats)
+    assert calls['n'] == 0
+    nb = neck.to(torch.bfloat16)
+    with torch.no_grad():
+        st, sem = nb([f.bfloat16() for f in feats])
+    assert calls['n'] == 6, 'conv 512->64, 64->32, redir 64->64, lastconv 32->32, rpnconv 512->128->32'
+    _close_bf16(st.float().cpu().numpy(), ref_st.cpu().numpy())
+    _close_bf16(sem.float().cpu().numpy(), ref_sem.cpu().numpy())
+
+    bev = _load(mods.BEVHourglass(160, 64, norm_cfg=gn), 73)
+    x = torch.randn(1, 160, 40, 48, generator=gen).cuda()
+    with torch.no_grad():
+        ref_pre, ref_post = bev(x)
+    calls['n'] = 0
+    bb = bev.to(torch.bfloat16)
+    with torch.no_grad():
+        pre, post = bb(x.bfloat16())
+    assert calls['n'] == 7, 'compress_conv + the six (transposed) convolutions of hourglass2d'
+    _close_bf16(pre.float().cpu().numpy(), ref_pre.cpu().numpy())
+    _close_bf16(post.float().cpu().numpy(), ref_post.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_hip_graph_replay_of_the_2d_necks_is_the_same_tensor(mods):
+    """graphs.GraphedCallable (hipGraph capture of the launch-bound 2-D necks): replays return what a
+    plain call returns, bit for bit, for new input values and for a second input signature."""
+    graphs = importlib.import_module('depth-from-motion_amd.graphs')
+    gn = dict(type='GN', num_groups=32, requires_grad=True)
+    bev = _load(mods.BEVHourglass(160, 64, norm_cfg=gn), 73).to(torch.bfloat16)
+    g = graphs.GraphedCallable(lambda ts: bev(ts[0]))
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for shape in ((1, 160, 24, 32), (1, 160, 24, 32), (2, 160, 16, 24), (1, 160, 24, 32)):
+            x = torch.randn(*shape, generator=gen).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+            pre, post = g([x])
+            rpre, rpost = bev(x)
+            assert torch.equal(pre, rpre) and torch.equal(post, rpost)
+    assert len(g._graphs) == 2
+    x = torch.randn(1, 160, 24, 32, generator=gen).cuda().bfloat16().requires_grad_(True)
+    assert g([x])[1].requires_grad        # autograd recording: plain call, no graph

@@ -65,6 +65,10 @@ def stereo(iters):
                     scale_factor=[1.0])
     ms = run(lambda: path(cur, prev, [meta()]), iters)
     print(f'DfMStereoPath inference (config K, 320x1280, bf16 NDHWC, depth head fused): {ms:8.2f} ms / sample', flush=True)
+    path.hip_graphs = True
+    ms = run(lambda: path(cur, prev, [meta()]), iters)
+    print(f'  ... with the 2-D necks replayed as hipGraphs (path.hip_graphs = True)      : {ms:8.2f} ms / sample', flush=True)
+    path.hip_graphs = False
     parts = dict(
         neck=lambda: (path.neck(cur), path.neck(prev)),
         backbone_stereo=None)
