@@ -516,10 +516,31 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
     documented path.  ``forward_fused`` = relu?(conv(x) * scale + shift + residual) in one launch
     (eval-mode BatchNorm / bias folded into the epilogue)."""
 
+    def _cin_padded(self):
+        """input channels as the kernel sees them: a narrow input (the 3-channel image of
+        upconv_module's last skip, spp_unet_neck.py:51-56) is zero-padded to one 32-channel chunk"""
+        return 32 if self.in_channels < 32 else self.in_channels
+
     def eligible(self, x):
-        return (self.kernel_size == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1) and
+        if not (self.kernel_size == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1) and
                 self.groups == 1 and self.stride in ((1, 1), (2, 2)) and self.padding_mode == 'zeros' and
-                conv2d_g_eligible(x, self.in_channels, self.out_channels))
+                x.dim() == 4 and x.shape[1] == self.in_channels):
+            return False
+        if self.in_channels >= 32:
+            return conv2d_g_eligible(x, self.in_channels, self.out_channels)
+        # narrow input: the zero-padded NHWC copy is made here, whatever the caller's layout
+        return (x.is_cuda and x.dtype == torch.bfloat16 and self.out_channels % 32 == 0 and
+                not torch.is_grad_enabled())
+
+    def _packed2d_padded(self):
+        key = (self.weight._version, self.weight.data_ptr(), str(self.weight.device))
+        if self.__dict__.get('_pack2d_key') != key:
+            w = self.weight.detach()
+            if self.in_channels < 32:
+                w = torch.cat([w, w.new_zeros(w.shape[0], 32 - self.in_channels, 3, 3)], 1)
+            self.__dict__['_pack2d'] = pack_conv2d_g_weights(w, self._cin_padded(), self.out_channels)
+            self.__dict__['_pack2d_key'] = key
+        return self.__dict__['_pack2d']
 
     def forward_fused(self, x, scale=None, shift=None, residual=None, relu=False):
         if self.bias is not None:
@@ -527,8 +548,13 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
             shift = b if shift is None else shift + b * (scale if scale is not None else 1.0)
             if scale is None:
                 scale = torch.ones_like(b)
-        return conv2d_g(x, self._packed2d(self.in_channels, self.out_channels, False), self.out_channels,
-                        stride=self.stride, relu=relu, scale=scale, shift=shift, residual=residual)
+        if self.in_channels < 32:  # NHWC, zero channels up to 32: one small copy (26 MB at 320 x 1280)
+            B, C, H, W = x.shape
+            xp = x.new_zeros((B, H, W, 32))
+            xp[..., :C] = x.permute(0, 2, 3, 1)
+            x = xp.permute(0, 3, 1, 2)
+        return conv2d_g(x, self._packed2d_padded(), self.out_channels, stride=self.stride, relu=relu,
+                        scale=scale, shift=shift, residual=residual)
 
     def forward(self, x):
         if self.eligible(x):

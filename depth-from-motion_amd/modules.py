@@ -566,20 +566,26 @@ def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation=1, gn=False
         nn.SyncBatchNorm(out_planes) if not gn else HipGroupNorm(groups, out_planes))
 
 
-def _conv_norm_2d(seq, x):
-    """Sequential(conv, norm) of the 2-D necks: an eval-mode BatchNorm folds into the MFMA
-    convolution's epilogue (one launch); otherwise conv, then norm"""
+def _conv_norm_2d(seq, x, residual=None, relu=False):
+    """Sequential(conv, norm) of the 2-D necks (+ residual) (+ ReLU): an eval-mode BatchNorm, the
+    residual add and the ReLU fold into the MFMA convolution's epilogue (one launch); otherwise conv,
+    norm and plain torch ops"""
     conv, norm = seq[0], seq[1]
     if (isinstance(conv, MfmaConv2d) and isinstance(norm, nn.modules.batchnorm._BatchNorm) and
-            not norm.training and norm.track_running_stats and norm.affine and conv.eligible(x)):
+            not norm.training and norm.track_running_stats and norm.affine and conv.eligible(x) and
+            (residual is None or (residual.dtype == x.dtype and
+                                  residual.is_contiguous(memory_format=torch.channels_last)))):
         key = tuple((t._version, t.data_ptr()) for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var))
         if seq.__dict__.get('_fold_key') != key:
             scale = norm.weight.float() / torch.sqrt(norm.running_var.float() + norm.eps)
             seq.__dict__['_fold'] = (scale, norm.bias.float() - norm.running_mean.float() * scale)
             seq.__dict__['_fold_key'] = key
         scale, shift = seq.__dict__['_fold']
-        return conv.forward_fused(x, scale, shift)
-    return norm(conv(x))
+        return conv.forward_fused(x, scale, shift, residual=residual, relu=relu)
+    y = norm(conv(x))
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
 
 
 class upconv_module(nn.Module):  # noqa: N801  (reference class name)
@@ -597,7 +603,9 @@ class upconv_module(nn.Module):  # noqa: N801  (reference class name)
     def forward(self, feats):
         x = feats[0]
         for i in range(self.num_stage):
-            x = F.relu(self.up(_conv_norm_2d(self.conv[i], x)) + _conv_norm_2d(self.redir[i], feats[i + 1]))
+            # relu(up(conv(x)) + redir(skip)): the add and the ReLU ride in redir's convolution epilogue
+            x = _conv_norm_2d(self.redir[i], feats[i + 1], residual=self.up(_conv_norm_2d(self.conv[i], x)),
+                              relu=True)
         return x
 
 

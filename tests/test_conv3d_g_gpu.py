@@ -335,8 +335,17 @@ def test_conv2d_modules_take_the_mfma_path_only_where_it_applies(cv, monkeypatch
     assert calls['n'] == 1 and y2.requires_grad
     with torch.no_grad():
         m(x.contiguous())                     # NCHW input: torch
-        cv.MfmaConv2d(3, 32, 3, padding=1).to(dev).bfloat16()(x[:, :3].contiguous(memory_format=torch.channels_last))
-    assert calls['n'] == 1
+        cv.MfmaConv2d(48, 32, 3, padding=1).to(dev).bfloat16()(x[:, :48].contiguous(memory_format=torch.channels_last))
+    assert calls['n'] == 1                    # 48 input channels: not whole 32-channel chunks
+    # a narrow input (the 3-channel image of upconv_module's last skip) is zero-padded to one chunk
+    n3 = cv.MfmaConv2d(3, 32, 3, padding=1, bias=False).to(dev).bfloat16()
+    x3 = torch.randn(2, 3, 21, 34, device=dev).bfloat16()
+    with torch.no_grad():
+        y3 = n3(x3)
+        ref3 = F.conv2d(x3.float(), n3.weight.float(), padding=1)
+    assert calls['n'] == 2
+    np.testing.assert_allclose(y3.float().cpu().numpy(), ref3.cpu().numpy(), rtol=RTOL, atol=ATOL)
+    calls['n'] = 1
     t = cv.MfmaConvTranspose2d(64, 32, 3, stride=2, padding=1, output_padding=1, bias=False).to(dev).bfloat16()
     with torch.no_grad():
         yt = t(x)

@@ -279,10 +279,10 @@ def test_dfm_stereo_path_inference_bf16_ndhwc_matches_fp32(pkg, monkeypatch):
     pb.backbone_stereo.volume_memory_format = torch.channels_last_3d
     with torch.no_grad():
         out = pb([t.bfloat16() for t in feats[0]], [t.bfloat16() for t in feats[1]], [meta()])
-    # general kernel: 2 x 6 hourglass convolutions + the 3x3 2-D convolutions of SPPUNetNeck (2 x 6) and
+    # general kernel: 2 x 6 hourglass convolutions + the 3x3 2-D convolutions of SPPUNetNeck (2 x 7) and
     # BEVHourglass (7) as (1, 3, 3) kernels; 32 -> 32 kernel: dres0 (2 halves + mono), dres1 x 2,
     # pred.0 x 2, voxel_convs (2 halves)
-    assert calls['g'] == 12 + 12 + 7 and calls['c32'] == 9, calls
+    assert calls['g'] == 12 + 14 + 7 and calls['c32'] == 9, calls
     assert out['volume_feat'].shape == (1, 32, 5, 64, 128) and out['bev_feat'].shape == (1, 64, 64, 128)
     for key in ('mono_stereo_costs', 'volume_feat', 'bev_feat'):
         a, b = out[key].float().cpu().numpy(), ref[key].float().cpu().numpy()
@@ -428,7 +428,7 @@ def test_2d_necks_at_config_widths_mfma_path_vs_torch_path(mods, monkeypatch):
     nb = neck.to(torch.bfloat16)
     with torch.no_grad():
         st, sem = nb([f.bfloat16() for f in feats])
-    assert calls['n'] == 6, 'conv 512->64, 64->32, redir 64->64, lastconv 32->32, rpnconv 512->128->32'
+    assert calls['n'] == 7, 'conv 512->64, 64->32, redir 64->64, 3->32 (padded), lastconv 32->32, rpnconv 512->128->32'
     _close_bf16(st.float().cpu().numpy(), ref_st.cpu().numpy())
     _close_bf16(sem.float().cpu().numpy(), ref_sem.cpu().numpy())
 

@@ -80,12 +80,12 @@ def stereo(iters):
         costs, sf, mf = path.backbone_stereo(cs, ps, [m])
         _, preds, soft = path.depth_head(costs, lazy=True)
         vol = path.feature_transformation(sf, soft, [m], csem)
-    print(f'  SPPUNetNeck x 2 (2-D convs: MIOpen)      : {run(parts["neck"], iters):8.2f} ms')
+    print(f'  SPPUNetNeck x 2 (3x3 convs: MFMA kernel) : {run(parts["neck"], iters):8.2f} ms')
     print(f'  DfMBackbone                              : {run(lambda: path.backbone_stereo(cs, ps, [m]), iters):8.2f} ms')
     print(f'  DepthHead statistics (+ depth_preds)     : {run(lambda: path.depth_head(costs, lazy=True), iters):8.2f} ms')
     print(f'  FrustumToVoxel (fused head + conv + pool): {run(lambda: path.feature_transformation(sf, soft, [m], csem), iters):8.2f} ms')
     _, cv, nz, ny, nx = vol.shape
-    print(f'  BEVHourglass (2-D convs: MIOpen)         : {run(lambda: path.backbone_3d(integ.bev_view(vol)), iters):8.2f} ms', flush=True)
+    print(f'  BEVHourglass (3x3 convs: MFMA kernel)    : {run(lambda: path.backbone_3d(integ.bev_view(vol)), iters):8.2f} ms', flush=True)
 
 
 def mv(iters):
