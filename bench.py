@@ -17,6 +17,8 @@ Workloads (``--workload``):
         scale_factor=1.03 (the general-geometry code path of the same kernel)
   kitti : config K of configs/dfm/dfm_r34_1x8_kitti-3d-3class.py: B=8 (the
         config runs 1/GPU), C=32, 320x1280 fp32, csf=4, D=72 -> (64,72,80,320)
+  kitti_nhwc : the same sweep with channels_last (NHWC) feature maps, what the channels_last
+        SPPUNetNeck emits: sampled in place (dfm_plane_sweep_fwd_from_nhwc), no pack pass
 """
 import argparse
 import ctypes
@@ -81,6 +83,10 @@ WORKLOADS = {
                       dmin=2.0, dmax=59.6, flip=True, scale=1.03),
     'kitti': dict(B=8, C=32, H=320, W=1280, D=72, fsf=1, csf=4, crop=(0, 55), dtype='f32',
                   dmin=2.0, dmax=59.6, flip=False, scale=1.0),
+    # the same sweep fed by the channels_last (NHWC) SPPUNetNeck: maps sampled in place, no pack pass,
+    # reference-layout volume out
+    'kitti_nhwc': dict(B=8, C=32, H=320, W=1280, D=72, fsf=1, csf=4, crop=(0, 55), dtype='f32',
+                       dmin=2.0, dmax=59.6, flip=False, scale=1.0, nhwc=True),
 }
 
 
@@ -412,6 +418,8 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
     gp = torch.Generator().manual_seed(1 + 1000 * rank)
     cur = torch.randn(B, w['C'], w['H'], w['W'], generator=gc).to(dev).to(tdtype)
     prev = torch.randn(B, w['C'], w['H'], w['W'], generator=gp).to(dev).to(tdtype)
+    if w.get('nhwc'):
+        cur, prev = (t.contiguous(memory_format=torch.channels_last) for t in (cur, prev))
     depths = torch.from_numpy(depth_planes(w['D'], w['dmin'], w['dmax'])).to(dev)
     desc = sweep._make_desc(cur, w['D'], w['fsf'], w['csf'], (375, 1242), w['flip'], w['crop'],
                             w['scale'])
@@ -433,13 +441,13 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
         if world > 1:
             torch.distributed.barrier()
 
-    if explicit or args.channels_last or args.no_autotune:
+    if explicit or args.channels_last or args.no_autotune or w.get('nhwc'):
         os.environ['DFM_AUTOTUNE'] = '0'  # keep the first launch from tuning by itself
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     tuned = None
-    if not args.channels_last and not explicit and not args.no_autotune:
+    if not args.channels_last and not explicit and not args.no_autotune and not w.get('nhwc'):
         # untimed, like the warm-up: the library's choice among its candidate launch shapes /
         # workgroup orders for this shape on this part (the first dfm_plane_sweep_fwd of a volume
         # this size ran the autotuner; query what it cached, tune now if it did not)

@@ -24,6 +24,7 @@ EXPORTS = (
     'dfm_plane_sweep_cl_workspace_bytes',
     'dfm_plane_sweep_fwd_channels_last',
     'dfm_plane_sweep_fwd_nhwc',
+    'dfm_plane_sweep_fwd_from_nhwc',
     'dfm_plane_sweep_bwd',
     'dfm_plane_sweep_grid',
     'dfm_plane_sweep_last_kernel',
@@ -179,6 +180,9 @@ class Conv3dWgradDesc(ctypes.Structure):
 DL_LINEAR, DL_HARD, DL_GAUSSIAN, DL_LAPLACIAN = 0, 1, 2, 3
 
 
+DFM_ERR_UNSUPPORTED = -2  # include/dfm_hip.h
+
+
 class DfmHipError(RuntimeError):
     pass
 
@@ -217,6 +221,8 @@ def lib():
     h.dfm_plane_sweep_fwd_channels_last.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp]
     h.dfm_plane_sweep_fwd_nhwc.restype = ctypes.c_int
     h.dfm_plane_sweep_fwd_nhwc.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp]
+    h.dfm_plane_sweep_fwd_from_nhwc.restype = ctypes.c_int
+    h.dfm_plane_sweep_fwd_from_nhwc.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp]
     h.dfm_plane_sweep_bwd.restype = ctypes.c_int
     h.dfm_plane_sweep_bwd.argtypes = [dp, vp, fp, fp, fp, fp, fp, fp, vp]
     h.dfm_plane_sweep_grid.restype = ctypes.c_int

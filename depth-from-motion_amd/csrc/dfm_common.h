@@ -20,12 +20,13 @@ struct SweepGeom;
 // defined in plane_sweep.hip, used by the other plane-sweep translation units
 int sweep_check_desc(const dfm_sweep_desc *d);
 SweepGeom sweep_make_geom(const dfm_sweep_desc *d);
+void sweep_set_last_kernel(int which);  // what dfm_plane_sweep_last_kernel() reports
 // strided sweeps in the reference layout: pixel-major taps + LDS transpose (plane_sweep_cl.hip)
 bool sweep_clt_supported(const dfm_sweep_desc *d, const void *out);
 size_t sweep_clt_workspace_bytes(const dfm_sweep_desc *d);
 int sweep_clt_launch(const dfm_sweep_desc *d, const void *cur, const void *prev, const float *depths,
                      const float *cam2img, const float *cam2img_inv, const float *cur2prev, void *out,
-                     void *workspace, void *stream);
+                     void *workspace, void *stream, bool nhwc = false);
 // records the start (stop=false) / stop event of a timed launch when dfm_profile_begin
 // is active; the start call returns whether this launch is being timed
 bool profile_mark(void *stream, bool stop);

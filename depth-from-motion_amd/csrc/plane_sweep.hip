@@ -1612,6 +1612,7 @@ DFM_API int dfm_profile_end(double *total_ms, int *launches)
 // shared with the other translation units
 int dfm::sweep_check_desc(const dfm_sweep_desc *d) { return check_desc(d); }
 dfm::SweepGeom dfm::sweep_make_geom(const dfm_sweep_desc *d) { return make_geom(d); }
+void dfm::sweep_set_last_kernel(int which) { g_last_kernel = which; }
 bool dfm::profile_mark(void *stream, bool stop)
 {
     hipStream_t st = (hipStream_t)stream;

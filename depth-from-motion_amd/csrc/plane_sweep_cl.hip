@@ -175,10 +175,13 @@ __global__ __launch_bounds__(256) void sweep_cl_kernel(
 // kernel pays a scattered 16-byte tap per channel block.
 template <typename T, int CP>
 __global__ __launch_bounds__(256) void sweep_clt_kernel(
-    SweepGeom g, ClGrid tg, const uint4 *__restrict__ ws, const float *__restrict__ depths,
+    SweepGeom g, ClGrid tg, const uint4 *__restrict__ ws, const uint4 *__restrict__ cur_maps,
+    const uint4 *__restrict__ prev_maps, const float *__restrict__ depths,
     const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
     T *__restrict__ out)
 {
+    // cur_maps / prev_maps, ZERO: as in sweep_cl_kernel (packed copies in ws, or the caller's NHWC maps)
+    constexpr unsigned ZERO = 0xffffffffu;
     constexpr int CB = elem<T>::CB;
     constexpr int BPP = CP / CB;          // 16-byte channel blocks per pass (8)
     constexpr int VEC = 16 / sizeof(T);   // points per 16-byte store
@@ -205,8 +208,8 @@ __global__ __launch_bounds__(256) void sweep_clt_kernel(
                     nullptr);
         const Tap tc = make_tap(cx, cy, g.h_in, g.w_in);
         const Tap tp = make_tap(px, py, g.h_in, g.w_in);
-        make_foot(tc, tg.cur_slot + (unsigned)b * HW * g.nblk, tg.zero_slot, g.w_in, g.nblk, foot[tid][0]);
-        make_foot(tp, tg.prev_slot + (unsigned)b * HW * g.nblk, tg.zero_slot, g.w_in, g.nblk, foot[tid][1]);
+        make_foot(tc, (unsigned)b * HW * g.nblk, ZERO, g.w_in, g.nblk, foot[tid][0]);
+        make_foot(tp, (unsigned)b * HW * g.nblk, ZERO, g.w_in, g.nblk, foot[tid][1]);
     }
     __syncthreads();
 
@@ -216,6 +219,7 @@ __global__ __launch_bounds__(256) void sweep_clt_kernel(
     constexpr int U = 4;
     const int npass = (g.nblk + BPP - 1) / BPP;
     for (int map = 0; map < 2; ++map) {
+        const uint4 *mp = map ? prev_maps : cur_maps;
         for (int pass = 0; pass < npass; ++pass) {
             const int blk = pass * BPP + sub;
             if (blk < g.nblk) {
@@ -229,7 +233,8 @@ __global__ __launch_bounds__(256) void sweep_clt_kernel(
                         const Foot f = foot[min(qq[u], qlast)][map];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            tap[u][k] = ws[f.slot[k] + blk];
+                            const uint4 *src = f.slot[k] == ZERO ? ws : mp + f.slot[k];
+                            tap[u][k] = src[blk];
                             wgt[u][k] = f.w[k];
                         }
                     }
@@ -276,11 +281,9 @@ namespace dfm {
 bool sweep_clt_supported(const dfm_sweep_desc *d, const void *out)
 {
     const int CB = d->dtype == DFM_BF16 ? 8 : 4;
-    const size_t esz = d->dtype == DFM_BF16 ? 2 : 4;
     const long long hw = (long long)d->h_out * d->w_out;
-    const size_t zero = ((size_t)d->channels * esz + 255) & ~(size_t)255;
     return d->channels % CB == 0 && hw % CB == 0 && ((uintptr_t)out & 15) == 0 &&
-           (zero + 2 * map_bytes(d)) / 16 < (1ull << 32);
+           map_bytes(d) / 16 < 0xffffffffull;
 }
 
 size_t sweep_clt_workspace_bytes(const dfm_sweep_desc *d)
@@ -291,7 +294,7 @@ size_t sweep_clt_workspace_bytes(const dfm_sweep_desc *d)
 
 int sweep_clt_launch(const dfm_sweep_desc *d, const void *cur, const void *prev, const float *depths,
                      const float *cam2img, const float *cam2img_inv, const float *cur2prev, void *out,
-                     void *workspace, void *stream)
+                     void *workspace, void *stream, bool nhwc)
 {
     const SweepGeom g = sweep_make_geom(d);
     const size_t esz = d->dtype == DFM_BF16 ? 2 : 4;
@@ -313,7 +316,11 @@ int sweep_clt_launch(const dfm_sweep_desc *d, const void *cur, const void *prev,
     tg.prev_slot = (unsigned)((zero + mb) / 16);
     const long long nb = (long long)tg.tiles * g.D * d->batch;
     if (nb > 2147483647ll) return set_error(DFM_ERR_UNSUPPORTED, "too many lattice points");
-    if (d->dtype == DFM_F32) {
+    const uint4 *cur_maps = (const uint4 *)(nhwc ? (const char *)cur : w8 + zero);
+    const uint4 *prev_maps = (const uint4 *)(nhwc ? (const char *)prev : w8 + zero + mb);
+    if (nhwc) {
+        // channels-last maps are sampled where they lie
+    } else if (d->dtype == DFM_F32) {
         hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg, dim3(256), 0, st, (const float *)cur,
                            (float *)(w8 + zero), d->channels, d->channels, HW);
         hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg, dim3(256), 0, st, (const float *)prev,
@@ -327,10 +334,12 @@ int sweep_clt_launch(const dfm_sweep_desc *d, const void *cur, const void *prev,
     const bool timed = profile_mark(stream, false);
     if (d->dtype == DFM_F32)
         hipLaunchKernelGGL((sweep_clt_kernel<float, 32>), dim3((unsigned)nb), dim3(256), 0, st, g, tg,
-                           (const uint4 *)workspace, depths, cam2img, cam2img_inv, cur2prev, (float *)out);
+                           (const uint4 *)workspace, cur_maps, prev_maps, depths, cam2img, cam2img_inv, cur2prev,
+                           (float *)out);
     else
         hipLaunchKernelGGL((sweep_clt_kernel<bf16_t, 64>), dim3((unsigned)nb), dim3(256), 0, st, g, tg,
-                           (const uint4 *)workspace, depths, cam2img, cam2img_inv, cur2prev, (bf16_t *)out);
+                           (const uint4 *)workspace, cur_maps, prev_maps, depths, cam2img, cam2img_inv, cur2prev,
+                           (bf16_t *)out);
     if (timed) profile_mark(stream, true);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
@@ -427,6 +436,29 @@ DFM_API int dfm_plane_sweep_fwd_channels_last(const dfm_sweep_desc *d, const voi
 {
     return sweep_cl_impl(d, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace,
                          workspace_bytes, stream, false);
+}
+
+/* NHWC feature maps in, the REFERENCE layout (B, 2C, D, h_out, w_out) out: the pixel-major-tap +
+ * LDS-transpose kernel (sweep_clt_kernel) on the caller's maps -- the strided sweeps of config K
+ * without their pack passes (21 % of the step).  DFM_ERR_UNSUPPORTED when that kernel cannot take the
+ * shape (see sweep_clt_supported): the caller falls back to NCHW maps and dfm_plane_sweep_fwd. */
+DFM_API int dfm_plane_sweep_fwd_from_nhwc(const dfm_sweep_desc *d, const void *cur, const void *prev,
+                                          const float *depths, const float *cam2img,
+                                          const float *cam2img_inv, const float *cur2prev, void *out,
+                                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = sweep_check_desc(d);
+    if (rc != DFM_OK) return rc;
+    if (!cur || !prev || !depths || !cam2img || !cam2img_inv || !cur2prev || !out)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (!dfm::sweep_clt_supported(d, out) || (((uintptr_t)cur | (uintptr_t)prev) & 15))
+        return set_error(DFM_ERR_UNSUPPORTED, "channels-last feature maps: shape not covered by the transpose kernel");
+    const size_t zero = ((size_t)d->channels * (d->dtype == DFM_BF16 ? 2 : 4) + 255) & ~(size_t)255;
+    if (!workspace || workspace_bytes < zero)
+        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than one zero pixel");
+    rc = dfm::sweep_clt_launch(d, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace, stream, true);
+    if (rc == DFM_OK) dfm::sweep_set_last_kernel(4);
+    return rc;
 }
 
 DFM_API int dfm_plane_sweep_fwd_nhwc(const dfm_sweep_desc *d, const void *cur, const void *prev,

@@ -207,6 +207,22 @@ def plane_sweep_forward(desc, cur_feats, prev_feats, depths, P, Pinv, T, out=Non
                     ctypes.byref(desc), _ptr(cur_feats), _ptr(prev_feats), _ptr(depths), _ptr(P),
                     _ptr(Pinv), _ptr(T), _ptr(out), _ptr(ws), nbytes, _stream_ptr(device)))
         return out
+    if (not channels_last and _nhwc(cur_feats) and _nhwc(prev_feats) and _current_opts(schedule) is None and
+            (desc.h_out * desc.w_out) % (16 // cur_feats.element_size()) == 0):
+        # NHWC maps, reference-layout volume: the transpose kernel on the caller's maps (no pack pass)
+        if out is None:
+            out = torch.empty((desc.batch, 2 * desc.channels, desc.num_depths, desc.h_out, desc.w_out),
+                              dtype=cur_feats.dtype, device=device)
+        nbytes = 256 + 4 * desc.channels
+        ws = _Workspace.get(device, nbytes)
+        with torch.cuda.device(device):
+            rc = lib.dfm_plane_sweep_fwd_from_nhwc(
+                ctypes.byref(desc), _ptr(cur_feats), _ptr(prev_feats), _ptr(depths), _ptr(P), _ptr(Pinv),
+                _ptr(T), _ptr(out), _ptr(ws), nbytes, _stream_ptr(device))
+        if rc == 0:
+            return out
+        if rc != _capi.DFM_ERR_UNSUPPORTED:
+            _capi.check(rc)
     cur_feats, prev_feats = cur_feats.contiguous(), prev_feats.contiguous()
     if channels_last:
         if out is None:
@@ -335,8 +351,8 @@ def build_dfm_cost(cur_feats,
         raise TypeError('cur_feats/prev_feats must both be float32 or bfloat16')
     assert cur_feats.dim() == 4 and cur_feats.shape == prev_feats.shape
     device = cur_feats.device
-    if not (memory_format == torch.channels_last_3d and _nhwc(cur_feats) and _nhwc(prev_feats)):
-        cur_feats = cur_feats.contiguous()   # NHWC maps feeding a channels-last volume stay as they are
+    if not (_nhwc(cur_feats) and _nhwc(prev_feats)):
+        cur_feats = cur_feats.contiguous()   # (NHWC maps stay as they are: sampled in place where a kernel can)
         prev_feats = prev_feats.contiguous()
     depths = depths.reshape(-1).to(device=device, dtype=torch.float32).contiguous()
     batch_size = cur_feats.shape[0]

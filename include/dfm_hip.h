@@ -150,6 +150,16 @@ DFM_API int dfm_plane_sweep_fwd_nhwc(const dfm_sweep_desc *desc, const void *cur
                                      const float *depths, const float *cam2img,
                                      const float *cam2img_inv, const float *cur2prev, void *out,
                                      void *workspace, size_t workspace_bytes, void *stream);
+/* Channels-last (NHWC) cur / prev as above, out in the REFERENCE layout (B, 2C, D, h_out, w_out):
+ * the strided-sweep kernel (pixel-major taps + LDS transpose) on the caller's maps, no pack pass.
+ * Returns DFM_ERR_UNSUPPORTED for shapes that kernel does not cover (channels not whole 16-byte
+ * blocks, h_out * w_out not a multiple of 16 / sizeof(T), out not 16-byte aligned): hand NCHW maps to
+ * dfm_plane_sweep_fwd then. */
+DFM_API int dfm_plane_sweep_fwd_from_nhwc(const dfm_sweep_desc *desc, const void *cur,
+                                          const void *prev, const float *depths,
+                                          const float *cam2img, const float *cam2img_inv,
+                                          const float *cur2prev, void *out, void *workspace,
+                                          size_t workspace_bytes, void *stream);
 
 /*
  * Backward of the two bilinear samplings w.r.t. the feature maps.
