@@ -978,15 +978,6 @@ __global__ __launch_bounds__(BWD_PTS * bwd_groups(HALF)) void sweep_bwd_tile_ker
     const T *go = gout + ((size_t)b * 2 * g.C + (size_t)HALF * g.C) * g.N + (size_t)d_lo * hw + min(idx, p_hi - 1);
     float *gf = (HALF ? gprev : gcur) + (size_t)b * g.C * HW;
 
-    T gnext[HALF ? VB : 1][CW];  // prev map: the next pass's values, in flight
-    if constexpr (HALF == 1) {
-#pragma unroll
-        for (int k = 0; k < VB; ++k) {
-            const int p = min(grp + k * BWD_GROUPS, np - 1);
-#pragma unroll
-            for (int c = 0; c < CW; ++c) gnext[k][c] = go[(size_t)p * hw + (size_t)min(c, min(CW, g.C) - 1) * g.N];
-        }
-    }
     for (int c0 = 0; c0 < g.C; c0 += CW) {
         const int nc = min(CW, g.C - c0);
         const T *gp = go + (size_t)c0 * g.N;
@@ -1011,40 +1002,29 @@ __global__ __launch_bounds__(BWD_PTS * bwd_groups(HALF)) void sweep_bwd_tile_ker
         };
         // gradient values of up to VB of this lane's planes (slots k0 .. k0+VB-1; slot k is plane
         // grp + k*G), all loads in flight together; planes outside the chunk / map give 0
-        // every load is unconditional (clamped, always-valid address) and the masking happens on
-        // the values afterwards: a load under a runtime condition makes hipcc branch around it
-        // and wait for each one separately (cdna_hip_programming.md, ".s-level traps" (c)).
-        // Issue and mask are separate so a block can be requested a whole pass ahead.
-        auto issue_block = [&](const T *gp_, int nc_, int k0, T (&gv)[VB][CW]) {
+        auto load_block = [&](int k0, T (&gv)[VB][CW]) {
+            // every load is unconditional (clamped, always-valid address) and the masking happens on
+            // the values afterwards: a load under a runtime condition makes hipcc branch around it
+            // and wait for each one separately (cdna_hip_programming.md, ".s-level traps" (c))
 #pragma unroll
             for (int k = 0; k < VB; ++k) {
                 const int p = min(grp + (k0 + k) * BWD_GROUPS, np - 1);
 #pragma unroll
-                for (int c = 0; c < CW; ++c) gv[k][c] = gp_[(size_t)p * hw + (size_t)min(c, nc_ - 1) * g.N];
+                for (int c = 0; c < CW; ++c) gv[k][c] = gp[(size_t)p * hw + (size_t)min(c, nc - 1) * g.N];
             }
-        };
-        auto mask_block = [&](int nc_, int k0, const T (&src)[VB][CW], T (&gv)[VB][CW]) {
 #pragma unroll
             for (int k = 0; k < VB; ++k) {
                 const int p = grp + (k0 + k) * BWD_GROUPS;
                 const bool on = p < np && fpT[min(p, np - 1) * BWD_PTS + pt] != 0u && !BWD_ABLATE(1);
 #pragma unroll
-                for (int c = 0; c < CW; ++c) gv[k][c] = (on && c < nc_) ? src[k][c] : T(0);
+                for (int c = 0; c < CW; ++c) gv[k][c] = (on && c < nc) ? gv[k][c] : T(0);
             }
-        };
-        auto load_block = [&](int k0, T (&gv)[VB][CW]) {
-            issue_block(gp, nc, k0, gv);
-            mask_block(nc, k0, gv, gv);
         };
 
         if constexpr (HALF == 1) {
             static_assert(BWD_MAXP / bwd_groups(1) <= VB, "one block holds all planes of a lane");
-            // the gradient values of pass c0 were requested during pass c0 - CW (the first ones just
-            // before the loop): their latency hides behind that pass's scatter and flush instead of
-            // stalling all 16 waves of the workgroup at the top of every pass
             T gv[VB][CW];
-            mask_block(nc, 0, gnext, gv);
-            if (c0 + CW < g.C) issue_block(gp + (size_t)CW * g.N, min(CW, g.C - c0 - CW), 0, gnext);
+            load_block(0, gv);
             // ---- scale of this pass: max |grad| over the workgroup's values ----------------
             unsigned m = 0u;
 #pragma unroll
