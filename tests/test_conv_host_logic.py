@@ -122,3 +122,37 @@ def test_module_classes_are_their_torch_parents_on_the_cpu(cv):
     xi = torch.randn(1, 3, 9, 13)
     assert torch.equal(pool(xi), F.avg_pool2d(xi, 4, stride=4))
     assert cv.channel_slice(torch.zeros(1, 8, 2, 2, 2), 0, 4).shape == (1, 4, 2, 2, 2)
+
+
+def test_layout_predicates_and_graph_output_flattening_on_the_cpu():
+    """host-side decisions of the NHWC edges, no GPU needed: which tensors count
+    as channels-last for the in-place samplers, output sizes with a kernel-extent-1 axis, and the
+    (nested) output rebuild of graphs.GraphedCallable"""
+    import importlib
+    import torch
+    cv = importlib.import_module('depth-from-motion_amd.conv3d')
+    ps = importlib.import_module('depth-from-motion_amd.point_sample')
+    sw = importlib.import_module('depth-from-motion_amd.plane_sweep')
+    graphs = importlib.import_module('depth-from-motion_amd.graphs')
+    integ = importlib.import_module('depth-from-motion_amd.integration')
+    # a 2-D convolution as a depth-1 volume: kernel (1, 3, 3), padding (0, 1, 1)
+    assert cv.conv3d_g_out_size((1, 320, 1280), (1, 1, 1), (0, 1, 1), (False,) * 3, (True, False, False)) == (1, 320, 1280)
+    assert cv.conv3d_g_out_size((1, 321, 1279), (1, 2, 2), (0, 1, 1), (False,) * 3, (True, False, False)) == (1, 161, 640)
+    assert cv.conv3d_g_out_size((1, 40, 48), (1, 1, 1), (0, 1, 1), (False, True, True), (True, False, False)) == (1, 80, 96)
+    # NHWC feature maps (plane sweep) / per-view NHWC features (multi-view lifting)
+    x = torch.zeros(2, 16, 6, 10, dtype=torch.bfloat16)
+    assert not sw._nhwc(x) and sw._nhwc(x.contiguous(memory_format=torch.channels_last))
+    assert not sw._nhwc(torch.zeros(2, 12, 6, 10, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    f = torch.zeros(2 * 3, 16, 6, 10, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ps._views_channels_last(f.view(2, 3, 16, 6, 10)) and not ps._views_channels_last(torch.zeros(2, 3, 16, 6, 10))
+    # GraphedCallable: nested outputs are flattened for the static buffers and rebuilt in shape
+    a, b, c = torch.ones(1), torch.ones(2), torch.ones(3)
+    flat, rebuild = graphs._flatten((a, [b, (c, None)]))
+    assert [t.numel() for t in flat] == [1, 2, 3]
+    out = rebuild(flat)
+    assert isinstance(out, tuple) and isinstance(out[1], list) and out[1][1][1] is None and out[1][1][0] is c
+    g = graphs.GraphedCallable(lambda ts: ts[0] + 1)
+    assert torch.equal(g([a]), a + 1) and not g._graphs      # CPU tensors: plain call
+    # the BEV view of a voxel volume is the reference's reshape
+    vol = torch.arange(2 * 3 * 4 * 5 * 6, dtype=torch.float32).reshape(2, 3, 4, 5, 6)
+    assert torch.equal(integ.bev_view(vol), vol.reshape(2, 12, 5, 6))
