@@ -61,6 +61,8 @@ EXPORTS = (
     'dfm_depth_loss_bwd',
     'dfm_voxel_sample_fwd',
     'dfm_voxel_sample_bwd',
+    'dfm_spp_tail_workspace_bytes',
+    'dfm_spp_tail_fwd',
     'dfm_group_norm_workspace_bytes',
     'dfm_group_norm_fwd',
     'dfm_group_norm_fwd_channels_last',
@@ -139,6 +141,15 @@ class F2vDesc(ctypes.Structure):
                         ] + [('dtype', ctypes.c_int32), ('stereo_channels_last', ctypes.c_int32),
                            ('out_channels_last', ctypes.c_int32), ('stereo_atten', ctypes.c_int32),
                            ('no_sem_atten', ctypes.c_int32), ('sem_channels_last', ctypes.c_int32)]
+
+
+class SppDesc(ctypes.Structure):
+    """struct dfm_spp_desc"""
+    _fields_ = [('batch', ctypes.c_int32), ('h', ctypes.c_int32), ('w', ctypes.c_int32),
+                ('num_sources', ctypes.c_int32), ('source_channels', ctypes.c_int32 * 4),
+                ('num_branches', ctypes.c_int32), ('in_channels', ctypes.c_int32),
+                ('spp_channels', ctypes.c_int32), ('pooled_h', ctypes.c_int32 * 4),
+                ('pooled_w', ctypes.c_int32 * 4), ('eps', ctypes.c_float)]
 
 
 class VsDesc(ctypes.Structure):
@@ -300,6 +311,11 @@ def lib():
     h.dfm_voxel_sample_fwd.argtypes = [ctypes.POINTER(VsDesc), vp, fp, vp, vp]
     h.dfm_voxel_sample_bwd.restype = ctypes.c_int
     h.dfm_voxel_sample_bwd.argtypes = [ctypes.POINTER(VsDesc), vp, fp, fp, vp]
+    h.dfm_spp_tail_workspace_bytes.restype = ctypes.c_size_t
+    h.dfm_spp_tail_workspace_bytes.argtypes = [ctypes.POINTER(SppDesc)]
+    h.dfm_spp_tail_fwd.restype = ctypes.c_int
+    pp = ctypes.POINTER(ctypes.c_void_p)
+    h.dfm_spp_tail_fwd.argtypes = [ctypes.POINTER(SppDesc), pp, pp, pp, pp, pp, vp, vp, sz, vp]
     i64, f32 = ctypes.c_int64, ctypes.c_float
     h.dfm_group_norm_workspace_bytes.restype = sz
     h.dfm_group_norm_workspace_bytes.argtypes = [i32, i32, i64, i32]

@@ -18,8 +18,11 @@ convolutions of the hourglass and the Conv3d+BN3d(+ReLU) blocks of the voxel nec
 (64 .. 256 channels, stride (1,1,2), padding (1,1,0)) are ``MfmaConv3dG`` /
 ``MfmaConvTranspose3d``: the general MFMA kernel of csrc/conv3d_g.hip (in eval mode the
 BatchNorm folds into its epilogue together with the residual add and the ReLU).
-The 32 -> 1 prediction conv and the 2-D convs are MIOpen through torch.
+The 3x3 2-D convolutions of SPPUNetNeck / BEVHourglass run in the same MFMA kernel (kernel extent 1
+along depth); 1x1 convolutions and bilinear up-sampling outside the fused SPP tail are torch ops.
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -30,7 +33,8 @@ from .conv3d import (MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaCon
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .group_norm import HipBatchNorm3d, HipGroupNorm
-from .plane_sweep import build_dfm_cost
+from . import _capi
+from .plane_sweep import _Workspace, build_dfm_cost
 from .registry import register_module
 
 
@@ -752,13 +756,73 @@ class SPPUNetNeck(nn.Module):
             out.append(v.to(x.dtype).permute(0, 3, 1, 2))                       # channels_last (B, C, ho, wo)
         return out
 
+    def _spp_tail_fused(self, feats):
+        """inference, bf16 NHWC on the GPU: the branches' 1x1 ConvModule (GroupNorm with one channel per
+        group, ReLU), their bilinear up-sampling and the concatenation in two launches
+        (``dfm_spp_tail_fwd``, csrc/spp_tail.hip) instead of ~25; None when the call does not qualify."""
+        srcs = feats[self.start_level:]
+        x = feats[-1]
+        cms = [b[1] for b in self.spp_branches]
+        ok = (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and
+              1 <= len(cms) <= 4 and 1 <= len(srcs) <= 4 and
+              all(t.dtype == x.dtype and t.shape[1] % 8 == 0 and t.shape[2:] == srcs[0].shape[2:] and
+                  not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last) for t in srcs) and
+              all(isinstance(m.conv, nn.Conv2d) and m.conv.kernel_size == (1, 1) and m.conv.bias is None and
+                  m.conv.stride == (1, 1) and m.conv.padding == (0, 0) and m.conv.groups == 1 and
+                  isinstance(getattr(m, m.norm_name or '', None), HipGroupNorm) and
+                  getattr(m, m.norm_name).num_groups == m.conv.out_channels and m.activate is not None and
+                  m.conv.out_channels == self.spp_channel and m.conv.out_channels % 8 == 0 and
+                  m.conv.out_channels <= 64 for m in cms))
+        if not ok:
+            return None
+        pooled = [p.permute(0, 2, 3, 1).contiguous() for p in self._spp_pool(x)]     # (B, ho, wo, C) tiny
+        if ((x.shape[1] * self.spp_channel + 32 * x.shape[1]) * 4 +
+                max(p.shape[1] * p.shape[2] for p in pooled) * self.spp_channel * 2 > 62 * 1024 or
+                256 % self.spp_channel):
+            return None
+        key = tuple((m.conv.weight._version, m.conv.weight.data_ptr()) for m in cms) + \
+            tuple((getattr(m, m.norm_name).weight._version, getattr(m, m.norm_name).bias._version) for m in cms)
+        if self.__dict__.get('_spp_key') != key:
+            self.__dict__['_spp_params'] = [
+                (m.conv.weight.detach().float().reshape(m.conv.out_channels, -1).contiguous(),
+                 getattr(m, m.norm_name).weight.detach().float().contiguous(),
+                 getattr(m, m.norm_name).bias.detach().float().contiguous()) for m in cms]
+            self.__dict__['_spp_key'] = key
+        params = self.__dict__['_spp_params']
+        B, _, H, W = srcs[0].shape
+        d = _capi.SppDesc()
+        d.batch, d.h, d.w = B, H, W
+        d.num_sources, d.num_branches = len(srcs), len(cms)
+        d.in_channels, d.spp_channels = x.shape[1], self.spp_channel
+        d.eps = float(getattr(cms[0], cms[0].norm_name).eps)
+        for i, t in enumerate(srcs):
+            d.source_channels[i] = t.shape[1]
+        for i, p in enumerate(pooled):
+            d.pooled_h[i], d.pooled_w[i] = p.shape[1], p.shape[2]
+        ctot = sum(t.shape[1] for t in srcs) + len(cms) * self.spp_channel
+        out = torch.empty((B, H, W, ctot), dtype=x.dtype, device=x.device)
+        lib = _capi.lib()
+        nbytes = lib.dfm_spp_tail_workspace_bytes(ctypes.byref(d))
+        ws = _Workspace.get(x.device, nbytes)
+
+        def arr(ts):
+            return (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts], *([None] * (4 - len(ts))))
+        with torch.cuda.device(x.device):
+            _capi.check(lib.dfm_spp_tail_fwd(
+                ctypes.byref(d), arr(pooled), arr([p[0] for p in params]), arr([p[1] for p in params]),
+                arr([p[2] for p in params]), arr(list(srcs)), out.data_ptr(), ws.data_ptr(), nbytes,
+                torch.cuda.current_stream(x.device).cuda_stream))
+        return out.permute(0, 3, 1, 2)
+
     def forward(self, feats):
         feat_shape = tuple(feats[self.start_level].shape[2:])
         assert len(feats) == len(self.in_channels)
         feats = _channels_last_2d(self, list(feats))
-        spp = [F.interpolate(branch[1](pooled), feat_shape, mode='bilinear', align_corners=True)
-               for branch, pooled in zip(self.spp_branches, self._spp_pool(feats[-1]))]
-        concat_feature = torch.cat((*feats[self.start_level:], *spp), 1)
+        concat_feature = self._spp_tail_fused(feats)
+        if concat_feature is None:
+            spp = [F.interpolate(branch[1](pooled), feat_shape, mode='bilinear', align_corners=True)
+                   for branch, pooled in zip(self.spp_branches, self._spp_pool(feats[-1]))]
+            concat_feature = torch.cat((*feats[self.start_level:], *spp), 1)
         stereo_feature = concat_feature
         if self.with_upconv:
             stereo_feature = self.upconv_module([stereo_feature, feats[1], feats[0]])

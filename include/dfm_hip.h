@@ -691,6 +691,37 @@ DFM_API int dfm_group_norm_bwd_channels_last(int32_t n, int32_t c, int64_t spati
                                              void *grad_residual, float *grad_gamma, float *grad_beta,
                                              void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------- */
+/* SPPUNetNeck: tail of the pyramid-pooling branches  */
+/* ---------------------------------------------------------------------- */
+
+/* necks/spp_unet_neck.py:60-70,97-106 (inference, bf16, NHWC): every branch's
+ * ConvModule(in_channels -> spp_channels, 1x1, GroupNorm with one channel per group, ReLU) on its
+ * pooled map, the bilinear up-sampling (align_corners=True) of the four results to (h, w) and the
+ * concatenation behind the source maps -- two launches instead of ~25 on a few hundred pixels each. */
+typedef struct dfm_spp_desc {
+    int32_t batch;
+    int32_t h, w;               /* size of the concatenated map (feats[start_level])            */
+    int32_t num_sources;        /* <= 4 maps copied in front (feats[start_level:])               */
+    int32_t source_channels[4]; /* multiples of 8                                                */
+    int32_t num_branches;       /* <= 4                                                          */
+    int32_t in_channels;        /* channels of the pooled maps (feats[-1])                       */
+    int32_t spp_channels;       /* output channels of every branch: multiple of 8, <= 64         */
+    int32_t pooled_h[4], pooled_w[4];
+    float eps;                  /* GroupNorm eps                                                 */
+} dfm_spp_desc;
+DFM_API size_t dfm_spp_tail_workspace_bytes(const dfm_spp_desc *desc);
+/* pooled[i]  : (batch, pooled_h[i], pooled_w[i], in_channels) bf16, the branch's window means   [device]
+ * weight[i]  : (spp_channels, in_channels) fp32, the 1x1 convolution; gamma[i], beta[i]: (spp_channels) fp32
+ * sources[i] : (batch, h, w, source_channels[i]) bf16 NHWC, 16-byte aligned
+ * out        : (batch, h, w, sum(source_channels) + num_branches * spp_channels) bf16 NHWC =
+ *              torch.cat((*sources, *upsampled_branches), 1) in channels_last
+ * The four pointer arrays are HOST arrays of device pointers. */
+DFM_API int dfm_spp_tail_fwd(const dfm_spp_desc *desc, const void *const *pooled, const float *const *weight,
+                             const float *const *gamma, const float *const *beta,
+                             const void *const *sources, void *out, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -431,6 +431,21 @@ def test_2d_necks_at_config_widths_mfma_path_vs_torch_path(mods, monkeypatch):
     assert calls['n'] == 7, 'conv 512->64, 64->32, redir 64->64, 3->32 (padded), lastconv 32->32, rpnconv 512->128->32'
     _close_bf16(st.float().cpu().numpy(), ref_st.cpu().numpy())
     _close_bf16(sem.float().cpu().numpy(), ref_sem.cpu().numpy())
+    # the fused tail of the SPP branches (csrc/spp_tail.hip) against the same steps as torch ops in bf16:
+    # copied source channels bit for bit, interpolated branch channels to bf16 rounding
+    import torch.nn.functional as F
+    with torch.no_grad():
+        cl = [f.bfloat16().contiguous(memory_format=torch.channels_last) for f in feats]
+        fused = nb._spp_tail_fused(cl)
+        assert fused is not None and fused.is_contiguous(memory_format=torch.channels_last)
+        spp = [F.interpolate(b[1](p), tuple(cl[2].shape[2:]), mode='bilinear', align_corners=True)
+               for b, p in zip(nb.spp_branches, nb._spp_pool(cl[-1]))]
+        unfused = torch.cat((*cl[2:], *spp), 1)
+    assert fused.shape == unfused.shape == (1, 512, H // 4, W // 4)
+    assert torch.equal(fused[:, :384], unfused[:, :384])
+    a, b = fused[:, 384:].float().cpu().numpy(), unfused[:, 384:].float().cpu().numpy()
+    assert float(np.abs(b).mean()) > 0.1
+    np.testing.assert_allclose(a, b, rtol=2.0 ** -6, atol=2.0 ** -6)
 
     bev = _load(mods.BEVHourglass(160, 64, norm_cfg=gn), 73)
     x = torch.randn(1, 160, 40, 48, generator=gen).cuda()

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/c69; mkdir -p $O
+timeout 900 python -m pytest tests/test_modules.py -x -q -m gpu 2>&1 | tail -12 | tee $O/tests.txt
+timeout 300 python tools/path_timing.py stereo --iters 10 2>&1 | tail -8 | tee $O/path_timing_stereo.txt
