@@ -30,6 +30,9 @@ NECK = [
     ('neck.res2 256->256', 'conv', 256, 256, (220, 300, 3), 1, 1),
     ('neck.out 256->256 p(1,1,0)', 'conv', 256, 256, (220, 300, 3), 1, (1, 1, 0)),
     ('dfmneck.res0 128->128', 'conv', 128, 128, (220, 300, 12), 1, 1),
+    # candidates for a single-pass 64 -> 32 (today: two 32 -> 32 passes through an fp32 partial)
+    ('dres0 64->32', 'conv', 64, 32, (72, 80, 320), 1, 1),
+    ('voxel_convs 64->32', 'conv', 64, 32, (20, 304, 288), 1, 1),
 ]
 
 
