@@ -3,10 +3,14 @@
 No JIT, no torch.utils.cpp_extension: the library is a plain C-ABI shared
 object (include/dfm_hip.h) that ctypes loads; the built .so stays in-tree so
 it travels to the GPU box with the repo snapshot.
+
+Every csrc/*.hip is its own translation unit: objects are compiled in parallel
+(only the stale ones unless ``force``) into lib/obj/ and linked into the .so.
 """
 import glob
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
@@ -16,7 +20,7 @@ LIB = os.path.join(LIB_DIR, 'libdfm_hip.so')
 
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -ffp-contract=off is part of the numerics contract (csrc/dfm_common.h)
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
          '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
 
 
@@ -24,16 +28,18 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def _headers():
+    return glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
-        glob.glob(os.path.join(ROOT, 'include', '*.h'))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in sources() + _headers())
 
 
-def build_hip(force=False, verbose=False, debug_hooks=False, out=None):
+def build_hip(force=False, verbose=False, debug_hooks=False, out=None, jobs=None):
     """Compile every csrc/*.hip into lib/libdfm_hip.so. Returns the path.
 
     debug_hooks=True adds -DDFM_DEBUG_HOOKS: the DFM_ABLATE switches and the
@@ -43,12 +49,27 @@ def build_hip(force=False, verbose=False, debug_hooks=False, out=None):
     out = out or LIB
     if not force and out == LIB and not _stale():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + (['-DDFM_DEBUG_HOOKS'] if debug_hooks else []) + \
-        ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + sources() + ['-o', out]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    obj_dir = os.path.join(LIB_DIR, 'obj_dbg' if debug_hooks else 'obj')
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = FLAGS + (['-DDFM_DEBUG_HOOKS'] if debug_hooks else []) + \
+        ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+    newest_header = max(os.path.getmtime(h) for h in _headers())
+    objs, todo = [], []
+    for src in sources():
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + '.o')
+        objs.append(obj)
+        if force or not os.path.exists(obj) or \
+                os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            todo.append([HIPCC] + flags + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(todo) or 1, os.cpu_count() or 4)) as pool:
+        list(pool.map(run, todo))
+    run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out])
     return out
 
 

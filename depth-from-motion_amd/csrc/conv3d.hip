@@ -371,12 +371,9 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_to1_fwd(int32_t n, int32_t d, int32_t h
     const uint4 *wfrag = (const uint4 *)packed_weights;
     const uint4 *zero = wfrag + CV_NFRAG * 64;
     const int lds = CV_RING * CV_SLAB_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e_ = hipFuncSetAttribute((const void *)conv3d_k3_c32_kernel<false, false, false, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e_ != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e_));
-        attr_done = true;
+    {
+        const int rc_ = ensure_dynamic_lds((const void *)conv3d_k3_c32_kernel<false, false, false, true>, lds);
+        if (rc_ != DFM_OK) return rc_;
     }
     hipLaunchKernelGGL((conv3d_k3_c32_kernel<false, false, false, true>), dim3(g.tiles_w * g.tiles_h, nchunks, n),
                        dim3(256), lds, (hipStream_t)stream, g, (const bf16_t *)x, wfrag, (const float *)nullptr,
@@ -413,21 +410,16 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_fwd_strided(int32_t n, int32_t d, int32
     const int lds = CV_RING * CV_SLAB_BYTES;
     dim3 grid(g.tiles_w * g.tiles_h, nchunks, n);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_done[6] = {false, false, false, false, false, false};
-#define CV_LAUNCH(F32, ACC, ST, IDX)                                                                   \
+#define CV_LAUNCH(F32, ACC, ST)                                                                        \
     do {                                                                                           \
-        if (!attr_done[IDX]) {                                                                     \
-            hipError_t e_ = hipFuncSetAttribute((const void *)conv3d_k3_c32_kernel<F32, ACC, ST>,  \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
-            if (e_ != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e_));            \
-            attr_done[IDX] = true;                                                                 \
-        }                                                                                          \
+        const int rc_ = ensure_dynamic_lds((const void *)conv3d_k3_c32_kernel<F32, ACC, ST>, lds); \
+        if (rc_ != DFM_OK) return rc_;                                                             \
         hipLaunchKernelGGL((conv3d_k3_c32_kernel<F32, ACC, ST>), grid, dim3(256), lds, st, g,      \
                            (const bf16_t *)x, wfrag, acc_in, out, zero, stats);                    \
     } while (0)
-    if (out_f32) { if (acc_in) CV_LAUNCH(true, true, false, 3); else CV_LAUNCH(true, false, false, 2); }
-    else if (stats) { if (acc_in) CV_LAUNCH(false, true, true, 5); else CV_LAUNCH(false, false, true, 4); }
-    else { if (acc_in) CV_LAUNCH(false, true, false, 1); else CV_LAUNCH(false, false, false, 0); }
+    if (out_f32) { if (acc_in) CV_LAUNCH(true, true, false); else CV_LAUNCH(true, false, false); }
+    else if (stats) { if (acc_in) CV_LAUNCH(false, true, true); else CV_LAUNCH(false, false, true); }
+    else { if (acc_in) CV_LAUNCH(false, true, false); else CV_LAUNCH(false, false, false); }
 #undef CV_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));

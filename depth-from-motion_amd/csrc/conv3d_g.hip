@@ -565,15 +565,10 @@ extern "C" DFM_API int dfm_conv3d_g_fwd(const dfm_conv3d_desc *desc, const void 
     dim3 grid((unsigned)tiles, pl.g.cout_tiles * pl.classes, desc->n);
     hipStream_t st = (hipStream_t)stream;
     const int lds = (int)pl.lds;
-    static bool attr_done[2][4] = {{false, false, false, false}, {false, false, false, false}};
 #define G_LAUNCH(CW_, PFW_)                                                                              \
     do {                                                                                             \
-        if (!attr_done[CW_ - 1][PFW_ - 1]) {                                                         \
-            hipError_t e_ = hipFuncSetAttribute((const void *)conv3d_g_kernel<CW_, PFW_>,            \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-            if (e_ != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e_));              \
-            attr_done[CW_ - 1][PFW_ - 1] = true;                                                     \
-        }                                                                                            \
+        const int rc_ = ensure_dynamic_lds((const void *)conv3d_g_kernel<CW_, PFW_>, 160 * 1024);    \
+        if (rc_ != DFM_OK) return rc_;                                                               \
         hipLaunchKernelGGL((conv3d_g_kernel<CW_, PFW_>), grid, dim3(256), lds, st, pl.g,             \
                            (const bf16_t *)x, wfrag, scale, shift, (const bf16_t *)residual,         \
                            (bf16_t *)out, zero);                                                     \

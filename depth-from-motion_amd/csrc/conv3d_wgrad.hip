@@ -311,20 +311,16 @@ extern "C" DFM_API int dfm_conv3d_wgrad(const dfm_conv3d_wgrad_desc *desc, const
                                         float *out, void *workspace, size_t workspace_bytes, void *stream)
 {
     WPlan pl;
-    const int rc = wgrad_plan(desc, pl);
+    int rc = wgrad_plan(desc, pl);
     if (rc != DFM_OK) return rc;
     if (!g || !x || !out || !workspace) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     if (workspace_bytes < pl.scratch) return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_conv3d_wgrad_workspace_bytes");
     if (((uintptr_t)g & 15) || ((uintptr_t)x & 15)) return set_error(DFM_ERR_INVALID_ARG, "g and x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(pl.g.wgs_per_pair, pl.pairs);
-    static bool attr_done[2] = {false, false};
     const void *kern = pl.sw == 1 ? (const void *)conv3d_wgrad_kernel<1> : (const void *)conv3d_wgrad_kernel<2>;
-    if (!attr_done[pl.sw - 1]) {
-        hipError_t e_ = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e_ != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e_));
-        attr_done[pl.sw - 1] = true;
-    }
+    rc = ensure_dynamic_lds(kern, 160 * 1024);
+    if (rc != DFM_OK) return rc;
     if (pl.lds > 160 * 1024) return set_error(DFM_ERR_UNSUPPORTED, "tile does not fit the LDS");
     if (pl.sw == 1)
         hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, grid, dim3(WG_THREADS), pl.lds, st, pl.g, (const bf16_t *)g,

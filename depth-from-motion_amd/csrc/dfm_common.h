@@ -16,6 +16,9 @@ namespace dfm {
 // records the thread-local message dfm_last_error() returns; defined in
 // plane_sweep.hip, shared by every translation unit of the library
 int set_error(int code, const char *msg);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): defined in
+// plane_sweep.hip (mutex-protected map), used by every kernel with more than 64 KB of LDS
+int ensure_dynamic_lds(const void *kern, int lds_bytes);
 struct SweepGeom;
 // defined in plane_sweep.hip, used by the other plane-sweep translation units
 int sweep_check_desc(const dfm_sweep_desc *d);

@@ -81,6 +81,26 @@ int dfm::set_error(int code, const char *msg)
     return code;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of on
+// every launch.  The attribute is per DEVICE: every translation unit of the library goes through
+// this one (device, kernel) map, so a second GPU driven from the same process gets its own call.
+int dfm::ensure_dynamic_lds(const void *kern, int lds_bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, int> seen;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(mu);
+    int &have = seen[std::make_pair(dev, kern)];
+    if (lds_bytes > have) {
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+        have = lds_bytes;
+    }
+    return DFM_OK;
+}
+
 namespace {
 
 #define HIP_TRY(expr)                                                                    \
@@ -1323,23 +1343,6 @@ size_t flag_bytes(const dfm_sweep_desc *d)
     const long long nblk = (d->channels + V - 1) / V;  // worst case: one block per group
     // int32 counter + one int32 tile id per (worst-case) tile
     return ((size_t)(1 + bands * d->num_depths * 2 * d->batch * nblk) * 4 + 255) & ~(size_t)255;
-}
-
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of
-// on every launch
-int ensure_dynamic_lds(const void *kern, int lds_bytes)
-{
-    static std::mutex mu;
-    static std::map<std::pair<int, const void *>, int> seen;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    int &have = seen[std::make_pair(dev, kern)];
-    if (lds_bytes > have) {
-        HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        have = lds_bytes;
-    }
-    return DFM_OK;
 }
 
 SweepFast make_fast(const dfm_sweep_desc *d)

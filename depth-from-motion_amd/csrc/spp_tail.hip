@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void spp_branch_kernel(SppBranches br, float *
     float *wT = (float *)lds_raw;                 // [K][C]
     float *xs = wT + (size_t)K * C;               // [SPP_TP][K]
     bf16_t *ys = (bf16_t *)(xs + (size_t)SPP_TP * K);  // [P][C], conv output as stored (bf16)
-    __shared__ float mean_s[64], rstd_s[64], red[2][8][64];
+    __shared__ float mean_s[64], rstd_s[64], red[2][256];  // [pass][pg * C + c] = one slot per thread, any C dividing 256
     const bf16_t *x = br.pooled[branch] + (size_t)b * P * K;
     const float *w = br.weight[branch];
     for (int i = threadIdx.x; i < C * K; i += 256) {
@@ -95,11 +95,11 @@ __global__ __launch_bounds__(256) void spp_branch_kernel(SppBranches br, float *
     // npg threads per channel, combined through LDS
     float s = 0.0f;
     for (int p = pg; p < P; p += npg) s += bf16_to_f32(ys[(size_t)p * C + c]);
-    red[0][pg][c] = s;
+    red[0][pg * C + c] = s;
     __syncthreads();
     if ((int)threadIdx.x < C) {
         float t = 0.0f;
-        for (int g = 0; g < npg; ++g) t += red[0][g][threadIdx.x];
+        for (int g = 0; g < npg; ++g) t += red[0][g * C + threadIdx.x];
         mean_s[threadIdx.x] = t / (float)P;
     }
     __syncthreads();
@@ -109,11 +109,11 @@ __global__ __launch_bounds__(256) void spp_branch_kernel(SppBranches br, float *
         const float d = bf16_to_f32(ys[(size_t)p * C + c]) - m;
         v = __builtin_fmaf(d, d, v);
     }
-    red[1][pg][c] = v;
+    red[1][pg * C + c] = v;
     __syncthreads();
     if ((int)threadIdx.x < C) {
         float t = 0.0f;
-        for (int g = 0; g < npg; ++g) t += red[1][g][threadIdx.x];
+        for (int g = 0; g < npg; ++g) t += red[1][g * C + threadIdx.x];
         rstd_s[threadIdx.x] = 1.0f / sqrtf(t / (float)P + br.eps);
     }
     __syncthreads();

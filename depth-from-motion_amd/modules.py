@@ -22,6 +22,7 @@ The 3x3 2-D convolutions of SPPUNetNeck / BEVHourglass run in the same MFMA kern
 along depth); 1x1 convolutions and bilinear up-sampling outside the fused SPP tail are torch ops.
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -44,12 +45,14 @@ def _on_device(owner, name, device):
     t = getattr(owner, name)
     if not torch.is_tensor(t) or t.device == device:
         return t
-    key = (id(t), t._version, str(device))
+    # the entry holds a weak reference to the host tensor: a re-injected tensor that reuses a freed
+    # id() (version 0 again) must not hit a stale device copy
+    key = (t._version, str(device))
     cache = owner.__dict__.setdefault('_dev_cache', {})
     hit = cache.get(name)
-    if hit is None or hit[0] != key:
-        hit = cache[name] = (key, t.to(device=device, dtype=torch.float32).contiguous())
-    return hit[1]
+    if hit is None or hit[0]() is not t or hit[1] != key:
+        hit = cache[name] = (weakref.ref(t), key, t.to(device=device, dtype=torch.float32).contiguous())
+    return hit[2]
 
 
 # --------------------------------------------------------------------------
@@ -454,9 +457,11 @@ class FrustumToVoxel(nn.Module):
         # the detector injects a host tensor (dfm.py:99-100) and the reference uploads it every
         # forward (.cuda(), feature_transformation.py:82): 21 MB at config K; uploaded once here
         c = self.coordinates_3d
-        key = (id(c), c._version, str(device))
-        if getattr(self, '_coords_key', None) != key:
-            self._coords_dev, self._coords_key = c.to(device=device, dtype=torch.float32).contiguous(), key
+        key = (c._version, str(device))
+        ref = self.__dict__.get('_coords_ref')
+        if ref is None or ref() is not c or self.__dict__.get('_coords_key') != key:
+            self.__dict__['_coords_dev'] = c.to(device=device, dtype=torch.float32).contiguous()
+            self.__dict__['_coords_ref'], self.__dict__['_coords_key'] = weakref.ref(c), key
         return self._coords_dev
 
     def forward(self, stereo_feat, stereo_feat_softmax, img_metas, cur_sem_feats=None):
