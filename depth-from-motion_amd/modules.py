@@ -84,9 +84,11 @@ class ConvModule(nn.Module):
         conv_type = 'Conv2d' if conv_cfg is None else conv_cfg['type']
         conv_cls = {'Conv2d': nn.Conv2d, 'Conv3d': nn.Conv3d}[conv_type]
         if (conv_type == 'Conv3d' and out_channels == 32 and in_channels % 32 == 0 and kernel_size == 3
-                and stride == 1 and padding == 1 and norm_cfg is not None):
-            # the full-resolution 3x3x3 convolutions of the aggregation stacks: nn.Conv3d whose
-            # bf16 / NDHWC forward is the hand-written MFMA kernel (csrc/conv3d.hip)
+                and stride == 1 and padding == 1 and norm_cfg is not None and norm_cfg.get('type') == 'GN'):
+            # the full-resolution 3x3x3 convolutions of the aggregation stacks (GroupNorm follows: its
+            # statistics come out of the epilogue): nn.Conv3d whose bf16 / NDHWC forward is the
+            # hand-written MFMA kernel (csrc/conv3d.hip).  Under BatchNorm3d (a voxel neck narrowed to
+            # 32 channels) the general kernel below folds the norm into its epilogue instead.
             conv_cls = MfmaConv3d
         elif (conv_type == 'Conv3d' and out_channels % 32 == 0 and in_channels % 32 == 0 and kernel_size == 3
               and norm_cfg is not None):

@@ -157,3 +157,109 @@ def load_file(relpath, modname, extra_modules=None):
     sys.modules[modname] = m
     spec.loader.exec_module(m)
     return m
+
+
+# --------------------------------------------------------------------------------------------
+# detector level (round 3): the reference's own DfM / MultiViewDfM classes, executed unmodified,
+# with stand-ins for what lies OUTSIDE the path (2-D backbone, detection heads, anchor generator,
+# box utilities).  Used by tests/test_reference_detectors.py to run patch_reference() against the
+# real module files and build configs/dfm/* through the reference's own __init__ / build_* calls.
+# --------------------------------------------------------------------------------------------
+class Placeholder(nn.Module):
+    """what an out-of-path ``type`` builds to (LIGAResNet, ResNet+DCN, FPN, the detection heads):
+    keeps its config, has no parameters, must never be called on the path"""
+
+    def __init__(self, **cfg):
+        super().__init__()
+        self.cfg = cfg
+
+    def init_weights(self):
+        pass
+
+    def forward(self, *a, **k):
+        raise AssertionError(f'out-of-path module {self.cfg.get("type")} was called')
+
+
+class FallbackRegistry(Registry):
+    """Registry.build that resolves unknown type names to ``Placeholder`` (everything SURVEY.md 8
+    marks out of scope) and records them"""
+
+    def __init__(self, name='models'):
+        super().__init__(name)
+        self.placeholders = []
+
+    def build(self, cfg, default_args=None):
+        cfg = dict(cfg)
+        for k, v in (default_args or {}).items():
+            cfg.setdefault(k, v)
+        kind = cfg.pop('type')
+        if kind not in self.module_dict:
+            self.placeholders.append(kind)
+            return Placeholder(type=kind, **cfg)
+        return self.module_dict[kind](**cfg)
+
+
+def load_detectors():
+    """installs the stubs and executes the reference's detector files (dfm.py, multiview_dfm.py),
+    the path's module files and point_fusion.py from /root/reference.  Returns (registry, modules)."""
+    hot = load_hot_path_modules()          # also installs the mmcv / mmdet / mmdet3d skeleton
+    old = sys.modules['mmdet3d.models.builder'].MODELS
+    reg = FallbackRegistry()
+    reg.module_dict.update(old.module_dict)  # the reference classes the hot-path files registered
+
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        m.__dict__.update(attrs)
+        if not hasattr(m, '__path__'):
+            m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    def build(cfg, train_cfg=None, test_cfg=None):
+        return reg.build(cfg)
+
+    for name in ('mmdet.models', 'mmdet.models.builder', 'mmdet3d.models.builder'):
+        mod(name, BACKBONES=reg, NECKS=reg, HEADS=reg, DETECTORS=reg, MODELS=reg, FUSION_LAYERS=reg,
+            build_backbone=build, build_neck=build, build_head=build, build_detector=build)
+    mod('mmcv.ops')
+    mod('mmcv.ops.points_in_boxes', points_in_boxes_part=None)
+
+    class BaseDetector(BaseModule):
+        pass
+    mod('mmdet.models.detectors', BaseDetector=BaseDetector)
+    core = sys.modules['mmdet3d.core.bbox']
+    mod('mmdet3d.core', bbox3d2result=None,
+        build_prior_generator=lambda cfg: types.SimpleNamespace(cfg=dict(cfg)))
+    mod('mmdet3d.core.bbox.structures', points_cam2img=core.points_cam2img, points_img2cam=core.points_img2cam,
+        get_proj_mat_by_coord_type=lambda img_meta, coord_type: img_meta['lidar2img'])
+    mod('mmdet3d.core.points', get_points_type=None)
+    mod('mmdet3d.models.dense_heads', LIGAATSSHead=type('LIGAATSSHead', (), {}),
+        CenterHead=type('CenterHead', (), {}))
+    mod('mmdet3d.models.utils.common_utils', dist_reduce_mean=lambda x: x)
+    mod('mmdet3d.models.detectors')
+    mod('mmdet3d.models.detectors.imitation_utils', NormalizeLayer=nn.Identity, WeightedL2WithSigmaLoss=nn.Identity)
+    out = dict(hot)
+    # fusion_layers: the real coord_transform.py and point_fusion.py (what multiview_dfm.py imports from)
+    fl = mod('mmdet3d.models.fusion_layers')
+    ct = load_file('mmdet3d/models/fusion_layers/coord_transform.py', 'mmdet3d.models.fusion_layers.coord_transform')
+    fl.apply_3d_transformation = ct.apply_3d_transformation
+    out['point_fusion'] = load_file('mmdet3d/models/fusion_layers/point_fusion.py',
+                                    'mmdet3d.models.fusion_layers.point_fusion')
+    fl.point_sample, fl.voxel_sample = out['point_fusion'].point_sample, out['point_fusion'].voxel_sample
+    # the hot-path files executed above registered into the old registry object; re-run them so the
+    # reference classes are what `reg` holds before patch_reference() overrides them
+    for key, rel, name in (('dfm_backbone', 'mmdet3d/models/backbones/dfm_backbone.py',
+                            'mmdet3d.models.backbones.dfm_backbone'),
+                           ('imvoxel_neck', 'mmdet3d/models/necks/imvoxel_neck.py', 'mmdet3d.models.necks.imvoxel_neck'),
+                           ('dfm_neck', 'mmdet3d/models/necks/dfm_neck.py', 'mmdet3d.models.necks.dfm_neck'),
+                           ('feature_transformation', 'mmdet3d/models/necks/feature_transformation.py',
+                            'mmdet3d.models.necks.feature_transformation'),
+                           ('depth_head', 'mmdet3d/models/dense_heads/depth_head.py', 'mmdet3d.models.dense_heads.depth_head'),
+                           ('bev_hourglass', 'mmdet3d/models/backbones/bev_hourglass.py',
+                            'mmdet3d.models.backbones.bev_hourglass'),
+                           ('spp_unet_neck', 'mmdet3d/models/necks/spp_unet_neck.py', 'mmdet3d.models.necks.spp_unet_neck')):
+        out[key] = load_file(rel, name)
+    out['dfm'] = load_file('mmdet3d/models/detectors/dfm.py', 'mmdet3d.models.detectors.dfm')
+    out['multiview_dfm'] = load_file('mmdet3d/models/detectors/multiview_dfm.py',
+                                     'mmdet3d.models.detectors.multiview_dfm')
+    return reg, out

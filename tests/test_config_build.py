@@ -136,25 +136,5 @@ def test_patch_reference_routes_a_mmdet3d_installation_to_this_package(pkg, monk
     assert bb is sys.modules['mmdet3d.models.backbones']
 
 
-@pytest.mark.gpu
-def test_multiview_voxel_path_forward_matches_function(pkg, cfgs):
-    """MultiViewVoxelPath = mv_feature_transformation + neck_3d on a reduced grid."""
-    import numpy as np
-    from tests.test_point_sample_gpu import meta_from_fixture
-    z = np.load(os.path.join(util.GOLDEN, 'mv_mean_2frames.npz'))
-    nv, nf = int(z['num_views']), int(z['num_frames'])
-    C = z['feats'].shape[2]
-    nvox = [int(v) for v in z['n_voxels']]
-    vr = [float(v) for v in z['voxel_range']]
-    model = dict(cfgs[WAYMO]['model'])
-    model['neck_3d'] = dict(type='OutdoorImVoxelNeck', in_channels=C, out_channels=8)
-    model['anchor_generator'] = dict(ranges=[vr])
-    model['voxel_size'] = [(vr[3 + i] - vr[i]) / nvox[i] for i in range(3)]
-    path = pkg.MultiViewVoxelPath(model).cuda().eval()
-    assert path.n_voxels == nvox
-    if nvox[2] != 12:
-        pytest.skip('the neck collapses Nz 12 -> 1; fixture grid has a different height')
-    feats = torch.from_numpy(z['feats']).cuda()
-    with torch.no_grad():
-        out = path(feats, [meta_from_fixture(z)], nv, nf)
-    assert out.shape == (1, 8, nvox[1], nvox[0])
+# MultiViewVoxelPath end to end (lifting -> neck_3d, BASELINE configs #4 / #5) against the reference's
+# detector method + necks: tests/test_path_parity_gpu.py (fixtures of tests/golden/make_golden_r03.py)
