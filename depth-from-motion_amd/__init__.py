@@ -18,7 +18,8 @@ from .group_norm import HipGroupNorm, group_norm  # noqa: F401
 from .geometry import prepare_coordinates_3d, prepare_depth  # noqa: F401
 from .frustum_to_voxel import frustum_to_voxel_sample  # noqa: F401
 from .integration import (DfMStereoPath, MultiViewDfMMixin, MultiViewVoxelPath,  # noqa: F401
-                          inject_detector_attributes, patch_reference)
+                          enable_fast_path, inject_detector_attributes, patch_reference)
+from .conv3d import MfmaPathError, fallback_policy, set_fallback_policy  # noqa: F401
 from .depth_head import depth_distribution_loss  # noqa: F401
 from .point_sample import (mv_feature_transformation, point_sample, voxel_centers,  # noqa: F401
                            voxel_sample)
@@ -26,5 +27,6 @@ from .point_sample import (mv_feature_transformation, point_sample, voxel_center
 __all__ = ['build_dfm_cost', 'plane_sweep_grid', 'point_sample', 'mv_feature_transformation',
            'voxel_centers', 'voxel_sample', 'frustum_to_voxel_sample', 'depth_head_forward', 'prepare_depth',
            'prepare_coordinates_3d', 'group_norm', 'HipGroupNorm', 'DfMStereoPath', 'MultiViewDfMMixin',
-           'MultiViewVoxelPath', 'inject_detector_attributes', 'patch_reference', 'depth_distribution_loss',
+           'MultiViewVoxelPath', 'inject_detector_attributes', 'patch_reference', 'enable_fast_path', 'set_fallback_policy',
+           'fallback_policy', 'MfmaPathError', 'depth_distribution_loss',
            'depth_head_statistics', 'LazyDepthDistribution']

@@ -15,6 +15,7 @@ Backward: the input gradient runs in the same MFMA kernel (transposed, mirrored 
 fragments); the weight gradient is torch's convolution backward (MIOpen).
 """
 import ctypes
+import warnings
 
 import torch
 from torch import nn
@@ -23,6 +24,57 @@ from . import _capi
 from .plane_sweep import _Workspace, _ptr, _stream_ptr
 
 _WDT = {torch.float32: _capi.DFM_F32, torch.bfloat16: _capi.DFM_BF16}
+
+# ---------------------------------------------------------------------------------------------
+# What an ``Mfma*`` module does with a GPU input its kernel does not take (fp32, NCDHW, a shape no
+# tiling fits ...).  The module is an nn.Conv* and CAN run torch's convolution (MIOpen) -- that is how
+# the reference's fp32 pipeline keeps working after ``patch_reference()`` -- but it must not do so
+# silently: 'warn' (default) says so once per (module class, reason), 'raise' (strict mode) makes it
+# an error, 'silent' restores round 2's behaviour.  ``integration.enable_fast_path(model)`` converts a
+# model so that every convolution of the path IS eligible.  CPU tensors never warn: there is no
+# kernel to miss, only the module-wiring tests run there.
+# ---------------------------------------------------------------------------------------------
+_POLICY = {'mode': 'warn'}
+_WARNED = set()
+
+
+class MfmaPathError(RuntimeError):
+    """strict mode: an Mfma* module was handed an input its MFMA kernel does not take"""
+
+
+def set_fallback_policy(mode):
+    """'warn' | 'raise' | 'silent'; returns the previous mode"""
+    if mode not in ('warn', 'raise', 'silent'):
+        raise ValueError(mode)
+    prev, _POLICY['mode'] = _POLICY['mode'], mode
+    return prev
+
+
+def fallback_policy():
+    return _POLICY['mode']
+
+
+def _torch_path(module, x, why):
+    """called by every Mfma* module right before it runs torch's convolution instead of its kernel"""
+    if not x.is_cuda or _POLICY['mode'] == 'silent':
+        return
+    msg = (f'{type(module).__name__}({module.in_channels}->{module.out_channels}): {why}; running torch\'s '
+           'convolution (MIOpen) instead of the MFMA kernel.  depth-from-motion_amd.enable_fast_path(model) '
+           'converts the path to bf16 / channels-last; set_fallback_policy("raise") makes this an error.')
+    if _POLICY['mode'] == 'raise':
+        raise MfmaPathError(msg)
+    key = (type(module).__name__, why)
+    if key not in _WARNED:
+        _WARNED.add(key)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def _why_not_bf16_cl(x, dims):
+    if x.dtype != torch.bfloat16:
+        return f'input dtype {str(x.dtype).replace("torch.", "")} (the kernel takes bfloat16)'
+    if x.dim() != dims:
+        return f'{x.dim()}-D input'
+    return None
 
 
 def pack_conv3d_weights(weight, cin_offset=0, transposed=False):
@@ -123,11 +175,21 @@ class MfmaConv3d(nn.Conv3d):
         super().__init__(*args, **kwargs)
         self._packs, self._pack_key = None, None
 
+    def why_not(self, x):
+        """None when the MFMA kernel takes ``x``, else the reason it does not"""
+        if not x.is_cuda:
+            return 'CPU tensor'
+        if not (self.out_channels == 32 and self.in_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and
+                self.stride == (1, 1, 1) and self.padding == (1, 1, 1) and self.dilation == (1, 1, 1) and
+                self.groups == 1 and self.bias is None):
+            return 'convolution configuration outside the 32-channel kernel\'s coverage'
+        why = _why_not_bf16_cl(x, 5)
+        if why is None and not _ndhwc_channel_stride(x):
+            why = 'input is not channels_last_3d (nor a channel slice of an NDHWC tensor)'
+        return why
+
     def eligible(self, x):
-        return (x.is_cuda and x.dtype == torch.bfloat16 and _ndhwc_channel_stride(x) > 0 and
-                self.out_channels == 32 and self.in_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and self.stride == (1, 1, 1) and
-                self.padding == (1, 1, 1) and self.dilation == (1, 1, 1) and self.groups == 1 and
-                self.bias is None)
+        return self.why_not(x) is None
 
     def _packed(self):
         key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
@@ -137,8 +199,10 @@ class MfmaConv3d(nn.Conv3d):
         return self._packs
 
     def forward(self, x):
-        if self.eligible(x):
+        why = self.why_not(x)
+        if why is None:
             return _MfmaConvFn.apply(x, self.weight, self._packed())
+        _torch_path(self, x, why)
         return super().forward(x)
 
     def forward_with_stats(self, x):
@@ -206,9 +270,15 @@ def conv3d_weight_grad(x_in, g_out, stride, padding):
             out = torch.empty((A, B, 3, 3, 3), dtype=torch.float32, device=x_in.device)
             ws = _Workspace.get(x_in.device, nbytes)
             with torch.cuda.device(x_in.device):
-                _capi.check(lib.dfm_conv3d_wgrad(ctypes.byref(d), _ptr(g_out), _ptr(x_in), _ptr(out), _ptr(ws),
-                                                 nbytes, _stream_ptr(x_in.device)))
-            return out
+                rc = lib.dfm_conv3d_wgrad(ctypes.byref(d), _ptr(g_out), _ptr(x_in), _ptr(out), _ptr(ws),
+                                          nbytes, _stream_ptr(x_in.device))
+            if rc == 0:
+                return out
+            if rc != _capi.DFM_ERR_UNSUPPORTED:  # a tile that does not fit the LDS falls through to the GEMM
+                _capi.check(rc)
+    if x_in.is_cuda and _POLICY['mode'] == 'raise':
+        raise MfmaPathError(f'weight gradient of a {B}->{A} convolution outside the MFMA kernel\'s coverage '
+                            '(channels not multiples of 32, layout, or a tile that does not fit the LDS)')
     return _weight_grad_gemm(x_in, g_out, stride, padding)
 
 
@@ -336,11 +406,20 @@ class MfmaConv3dTo1(nn.Conv3d):
         super().__init__(*args, **kwargs)
         self._cache = _PackCache()
 
+    def why_not(self, x):
+        if not x.is_cuda:
+            return 'CPU tensor'
+        if not (self.in_channels == 32 and self.out_channels == 1 and self.kernel_size == (3, 3, 3) and
+                self.stride == (1, 1, 1) and self.padding == (1, 1, 1) and self.dilation == (1, 1, 1) and
+                self.groups == 1 and self.bias is None):
+            return 'convolution configuration outside the 32 -> 1 kernel\'s coverage'
+        why = _why_not_bf16_cl(x, 5)
+        if why is None and not _is_ndhwc(x):
+            why = 'input is not channels_last_3d'
+        return why
+
     def eligible(self, x):
-        return (x.is_cuda and x.dtype == torch.bfloat16 and _is_ndhwc(x) and self.in_channels == 32 and
-                self.out_channels == 1 and self.kernel_size == (3, 3, 3) and self.stride == (1, 1, 1) and
-                self.padding == (1, 1, 1) and self.dilation == (1, 1, 1) and self.groups == 1 and
-                self.bias is None)
+        return self.why_not(x) is None
 
     def _packed(self):
         def make():
@@ -350,8 +429,10 @@ class MfmaConv3dTo1(nn.Conv3d):
         return self._cache.get(self.weight, make)
 
     def forward(self, x):
-        if self.eligible(x):
+        why = self.why_not(x)
+        if why is None:
             return _MfmaConvTo1Fn.apply(x, self.weight, self._packed())
+        _torch_path(self, x, why)
         return super().forward(x)
 
 
@@ -435,6 +516,28 @@ def conv3d_g_plan(n, cin, cout, in_size, stride=1, padding=1, transposed=False):
                 workgroups=plan[7])
 
 
+_PLAN_OK = {}
+
+
+def conv3d_g_plannable(n, cin, cout, in_size, stride, padding, transposed=False, kernel1=False, in_channel_stride=0):
+    """does ``dfm_conv3d_g_plan`` find a tiling for this problem (sample < 2^31 bytes, a block that
+    fits the LDS, a grid within the launch limits)?  Cached per problem; the Mfma* modules ask before
+    they take the MFMA path, so a shape the kernel rejects runs torch's convolution (with the
+    fallback policy's warning) instead of raising DfmHipError from inside the launch."""
+    stride, padding, transposed, kernel1 = _triple(stride), _triple(padding), _triple(transposed), _triple(kernel1)
+    key = (n, cin, cout, tuple(in_size), stride, padding, transposed, kernel1, in_channel_stride)
+    ok = _PLAN_OK.get(key)
+    if ok is None:
+        out_size = conv3d_g_out_size(in_size, stride, padding, transposed, kernel1)
+        d = _conv_desc(n, cin, cout, in_size, out_size, stride, padding, transposed, False, in_channel_stride, kernel1)
+        plan = (ctypes.c_int64 * 8)()
+        ok = all(o > 0 for o in out_size) and _capi.lib().dfm_conv3d_g_plan(ctypes.byref(d), plan) == 0
+        if len(_PLAN_OK) > 4096:
+            _PLAN_OK.clear()
+        _PLAN_OK[key] = ok
+    return ok
+
+
 def conv3d_g(x, packed, cout, stride=1, padding=1, transposed=False, relu=False, scale=None, shift=None,
              residual=None, kernel1=False):
     """x: (N, C_in, D, H, W) bf16 channels_last_3d.  Returns (N, cout, D', H', W') bf16
@@ -479,10 +582,25 @@ def pack_conv2d_g_weights(weight, cin, cout, swap=False):
     return pack_conv3d_g_weights(w3, cin, cout, swap=swap)
 
 
+def conv2d_g_why_not(x, cin, cout):
+    if not x.is_cuda:
+        return 'CPU tensor'
+    if cin % 32 or cout % 32:
+        return 'channel counts are not multiples of 32'
+    why = _why_not_bf16_cl(x, 4)
+    if why is not None:
+        return why
+    if x.shape[1] != cin:
+        return 'channel count differs from the module\'s'
+    if torch.is_grad_enabled():
+        return 'autograd is recording (the 2-D MFMA path is inference-only)'
+    if not (x.is_contiguous(memory_format=torch.channels_last) and x.stride(1) == 1):
+        return 'input is not channels_last'
+    return None
+
+
 def conv2d_g_eligible(x, cin, cout):
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and cin % 32 == 0 and cout % 32 == 0 and
-            x.shape[1] == cin and not torch.is_grad_enabled() and
-            (x.is_contiguous(memory_format=torch.channels_last) and x.stride(1) == 1))
+    return conv2d_g_why_not(x, cin, cout) is None
 
 
 def conv2d_g(x, packed, cout, stride=1, transposed=False, relu=False, scale=None, shift=None, residual=None):
@@ -521,16 +639,29 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
         upconv_module's last skip, spp_unet_neck.py:51-56) is zero-padded to one 32-channel chunk"""
         return 32 if self.in_channels < 32 else self.in_channels
 
-    def eligible(self, x):
+    def why_not(self, x):
+        if not x.is_cuda:
+            return 'CPU tensor'
         if not (self.kernel_size == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1) and
                 self.groups == 1 and self.stride in ((1, 1), (2, 2)) and self.padding_mode == 'zeros' and
-                x.dim() == 4 and x.shape[1] == self.in_channels):
-            return False
+                self.out_channels % 32 == 0 and (self.in_channels % 32 == 0 or self.in_channels < 32)):
+            return 'convolution configuration outside the kernel\'s coverage (3x3, padding 1, stride 1 | 2)'
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            return 'input shape does not match the module'
         if self.in_channels >= 32:
-            return conv2d_g_eligible(x, self.in_channels, self.out_channels)
-        # narrow input: the zero-padded NHWC copy is made here, whatever the caller's layout
-        return (x.is_cuda and x.dtype == torch.bfloat16 and self.out_channels % 32 == 0 and
-                not torch.is_grad_enabled())
+            why = conv2d_g_why_not(x, self.in_channels, self.out_channels)
+        else:
+            # narrow input: the zero-padded NHWC copy is made here, whatever the caller's layout
+            why = _why_not_bf16_cl(x, 4) or \
+                ('autograd is recording (the 2-D MFMA path is inference-only)' if torch.is_grad_enabled() else None)
+        if why is None and not conv3d_g_plannable(x.shape[0], self._cin_padded(), self.out_channels,
+                                                  (1, x.shape[2], x.shape[3]), (1,) + self.stride, (0, 1, 1),
+                                                  kernel1=(True, False, False)):
+            why = 'no tiling of the general kernel fits this shape'
+        return why
+
+    def eligible(self, x):
+        return self.why_not(x) is None
 
     def _packed2d_padded(self):
         key = (self.weight._version, self.weight.data_ptr(), str(self.weight.device))
@@ -557,8 +688,11 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
                         scale=scale, shift=shift, residual=residual)
 
     def forward(self, x):
-        if self.eligible(x):
+        why = self.why_not(x)
+        if why is None:
             return self.forward_fused(x)
+        if self.kernel_size == (3, 3):  # the 1x1 convolutions built through convbn() are torch's by design
+            _torch_path(self, x, why)
         return super().forward(x)
 
 
@@ -566,15 +700,29 @@ class MfmaConvTranspose2d(nn.ConvTranspose2d, _Mfma2dMixin):
     """nn.ConvTranspose2d kernel 3, stride 2, padding 1, output_padding 1 (hourglass2d's up-convs,
     conv_modules.py:196-214) through the MFMA kernel under the conditions of ``MfmaConv2d``."""
 
-    def eligible(self, x):
-        return (self.kernel_size == (3, 3) and self.padding == (1, 1) and self.stride == (2, 2) and
+    def why_not(self, x):
+        if not x.is_cuda:
+            return 'CPU tensor'
+        if not (self.kernel_size == (3, 3) and self.padding == (1, 1) and self.stride == (2, 2) and
                 self.output_padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1 and
-                self.bias is None and conv2d_g_eligible(x, self.in_channels, self.out_channels))
+                self.bias is None):
+            return 'transposed-convolution configuration outside the kernel\'s coverage'
+        why = conv2d_g_why_not(x, self.in_channels, self.out_channels)
+        if why is None and not conv3d_g_plannable(x.shape[0], self.in_channels, self.out_channels,
+                                                  (1, x.shape[2], x.shape[3]), (1, 1, 1), (0, 1, 1),
+                                                  transposed=(False, True, True), kernel1=(True, False, False)):
+            why = 'no tiling of the general kernel fits this shape'
+        return why
+
+    def eligible(self, x):
+        return self.why_not(x) is None
 
     def forward(self, x, output_size=None):
-        if output_size is None and self.eligible(x):
+        why = self.why_not(x) if output_size is None else 'explicit output_size'
+        if why is None:
             return conv2d_g(x, self._packed2d(self.in_channels, self.out_channels, True), self.out_channels,
                             transposed=True)
+        _torch_path(self, x, why)
         return super().forward(x, output_size)
 
 
@@ -637,22 +785,39 @@ class MfmaConv3dG(nn.Conv3d):
         super().__init__(*args, **kwargs)
         self._cache = _PackCache()
 
-    def eligible(self, x):
-        return (x.is_cuda and x.dtype == torch.bfloat16 and _ndhwc_channel_stride(x) > 0 and
-                self.in_channels % 32 == 0 and
-                self.out_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and
+    def why_not(self, x):
+        if not x.is_cuda:
+            return 'CPU tensor'
+        if not (self.in_channels % 32 == 0 and self.out_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and
                 all(s in (1, 2) for s in self.stride) and all(0 <= p <= 2 for p in self.padding) and
                 self.dilation == (1, 1, 1) and self.groups == 1 and self.bias is None and
-                self.padding_mode == 'zeros' and
-                all(s + 2 * p >= 3 for s, p in zip(x.shape[2:], self.padding)))
+                self.padding_mode == 'zeros'):
+            return 'convolution configuration outside the general kernel\'s coverage'
+        why = _why_not_bf16_cl(x, 5)
+        if why is not None:
+            return why
+        cs = _ndhwc_channel_stride(x)
+        if not cs:
+            return 'input is not channels_last_3d (nor a channel slice of an NDHWC tensor)'
+        if not all(s + 2 * p >= 3 for s, p in zip(x.shape[2:], self.padding)):
+            return 'input smaller than the kernel'
+        if not conv3d_g_plannable(x.shape[0], self.in_channels, self.out_channels, tuple(x.shape[2:]), self.stride,
+                                  self.padding, in_channel_stride=0 if cs == self.in_channels else cs):
+            return 'no tiling of the general kernel fits this shape'
+        return None
+
+    def eligible(self, x):
+        return self.why_not(x) is None
 
     def _packed(self):
         return self._cache.get(self.weight, lambda: pack_conv3d_g_weights(
             self.weight, self.in_channels, self.out_channels))
 
     def forward(self, x):
-        if self.eligible(x):
+        why = self.why_not(x)
+        if why is None:
             return _ConvGFn.apply(x, self.weight, self._packed(), 'conv', self.stride, self.padding)
+        _torch_path(self, x, why)
         return super().forward(x)
 
     def forward_fused(self, x, scale=None, shift=None, residual=None, relu=False):
@@ -671,17 +836,31 @@ class MfmaConvTranspose3d(nn.ConvTranspose3d):
         super().__init__(*args, **kwargs)
         self._cache = _PackCache()
 
+    def why_not(self, x):
+        if not x.is_cuda:
+            return 'CPU tensor'
+        if not (self.in_channels % 32 == 0 and self.out_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and
+                self.stride == (2, 2, 2) and self.padding == (1, 1, 1) and self.output_padding == (1, 1, 1) and
+                self.dilation == (1, 1, 1) and self.groups == 1 and self.bias is None):
+            return 'transposed-convolution configuration outside the general kernel\'s coverage'
+        why = _why_not_bf16_cl(x, 5)
+        if why is None and not _is_ndhwc(x):
+            why = 'input is not channels_last_3d'
+        if why is None and not conv3d_g_plannable(x.shape[0], self.in_channels, self.out_channels,
+                                                  tuple(x.shape[2:]), 1, 1, transposed=True):
+            why = 'no tiling of the general kernel fits this shape'
+        return why
+
     def eligible(self, x):
-        return (x.is_cuda and x.dtype == torch.bfloat16 and _is_ndhwc(x) and self.in_channels % 32 == 0 and
-                self.out_channels % 32 == 0 and self.kernel_size == (3, 3, 3) and self.stride == (2, 2, 2) and
-                self.padding == (1, 1, 1) and self.output_padding == (1, 1, 1) and
-                self.dilation == (1, 1, 1) and self.groups == 1 and self.bias is None)
+        return self.why_not(x) is None
 
     def _packed(self):
         return self._cache.get(self.weight, lambda: pack_conv3d_g_weights(
             self.weight, self.in_channels, self.out_channels, swap=True))
 
     def forward(self, x, output_size=None):
-        if output_size is None and self.eligible(x):
+        why = self.why_not(x) if output_size is None else 'explicit output_size'
+        if why is None:
             return _ConvGFn.apply(x, self.weight, self._packed(), 'convT', self.stride, self.padding)
+        _torch_path(self, x, why)
         return super().forward(x, output_size)

@@ -165,6 +165,10 @@ class MultiViewDfMMixin:
     def feature_transformation(self, batch_feats, img_metas, num_views, num_frames):
         # bf16 features: the volume is written channels-last, the layout the MFMA convolutions of
         # neck_3d read (no conversion copy); ``volume_memory_format`` on the host class overrides
+        fast = getattr(self, 'fast_dtype', None)   # set by enable_fast_path(): lift in bf16 / NDHWC
+        out_dtype = batch_feats.dtype
+        if fast is not None and batch_feats.is_floating_point() and batch_feats.dtype != fast:
+            batch_feats = batch_feats.to(fast)     # the view features, not the volume: Nv*F small maps
         fmt = getattr(self, 'volume_memory_format', None)
         if fmt is None:
             fmt = torch.channels_last_3d if batch_feats.dtype == torch.bfloat16 else torch.contiguous_format
@@ -200,6 +204,11 @@ class MultiViewDfMMixin:
                 volume_feat = self.neck_3d(bev_feat)[1]
             else:
                 volume_feat = self.neck_3d(volume_feat)[0]
+        if fast is not None and volume_feat.dtype != out_dtype:
+            # the caller's dtype at the path's exit (a (B, C_out, Ny, Nx) BEV map: small)
+            volume_feat = volume_feat.to(out_dtype)
+            if batch_stereo_feats is not None:
+                batch_stereo_feats = batch_stereo_feats.to(out_dtype)
         out = (volume_feat, )
         if batch_stereo_feats is not None:
             out += (batch_stereo_feats, )
@@ -241,11 +250,19 @@ _FUNCTION_PATCHES = (
 )
 
 
-def patch_reference():
+def patch_reference(precision=None, strict=False):
     """Route a real mmdet3d (the reference fork) to the HIP path.  Call once after
     ``import mmdet3d`` and before building the model from ``configs/dfm/*``.  Returns a report
     dict {'modules': [...], 'functions': [...], 'methods': [...]}.  Raises ImportError when
-    mmdet3d is not importable (this package never needs it otherwise)."""
+    mmdet3d is not importable (this package never needs it otherwise).
+
+    ``precision='bf16'``: every ``DfM`` / ``MultiViewDfM`` detector built afterwards is passed through
+    ``enable_fast_path(detector, torch.bfloat16, strict=strict)`` at the end of its constructor, so
+    the reference's fp32 pipeline reaches the MFMA kernels without another line of user code (the
+    sampling / norm kernels run either way; without this switch the Mfma* convolutions of an fp32
+    model run torch's convolution and say so once).  ``precision=None`` leaves models as built."""
+    if precision not in (None, 'fp32', 'bf16'):
+        raise ValueError(f'precision must be None, "fp32" or "bf16", got {precision!r}')
     report = {'modules': registry.register_into_mmdet3d(), 'functions': [], 'methods': []}
     for mod_name, attr, fn in _FUNCTION_PATCHES:
         try:
@@ -261,8 +278,137 @@ def patch_reference():
         report['methods'].append('MultiViewDfM.feature_transformation')
     except (ImportError, AttributeError):
         pass
+    if precision == 'bf16':
+        # every module of a detector is built inside DfM.__init__ (MultiViewDfM.__init__ calls it and
+        # adds plain attributes only, multiview_dfm.py:36-65): converting at its end covers both
+        try:
+            cls = importlib.import_module('mmdet3d.models.detectors.dfm').DfM
+        except (ImportError, AttributeError):
+            cls = None
+        if cls is not None and not getattr(cls.__init__, '_dfm_fast', False):
+            cls.__init__ = _init_then_fast_path(cls.__init__, strict)
+            report['methods'].append('DfM.__init__ -> enable_fast_path(bf16)')
     return report
 
 
+def _init_then_fast_path(init, strict):
+    def __init__(self, *args, **kwargs):
+        init(self, *args, **kwargs)
+        self.fast_path_report = enable_fast_path(self, torch.bfloat16, strict=strict)
+    __init__._dfm_fast = True
+    __init__.__wrapped__ = init
+    return __init__
+
+
+# ---------------------------------------------------------------------------------------------
+# the fast path, explicitly: bf16 / channels-last conversion of the path's modules inside a model
+# ---------------------------------------------------------------------------------------------
+def _map_tensors(obj, fn):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, (list, tuple)):
+        out = [_map_tensors(o, fn) for o in obj]
+        return type(obj)(out) if not hasattr(obj, '_fields') else type(obj)(*out)
+    return obj   # dicts are NOT entered: img_metas carry fp32 camera matrices / poses that must stay fp32
+
+
+def _cast_hook(src, dst):
+    """forward pre-hook: floating tensors of dtype ``src`` (or any floating dtype when src is None)
+    among the positional / keyword arguments become ``dst``"""
+    def cast(t):
+        # feature maps and volumes only (>= 4-D): small fp32 geometry tensors pass through untouched
+        if t.dim() >= 4 and t.is_floating_point() and t.dtype != dst and (src is None or t.dtype == src):
+            return t.to(dst)
+        return t
+
+    def hook(module, args, kwargs):
+        return _map_tensors(args, cast), {k: _map_tensors(v, cast) for k, v in kwargs.items()}
+    return hook
+
+
+def _is_norm(m):
+    return isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.GroupNorm))
+
+
+def enable_fast_path(model, dtype=torch.bfloat16, strict=False, boundary_casts=True):
+    """Route every convolution of the path inside ``model`` to the hand-written MFMA kernels.
+
+    ``model``: a reference ``DfM`` / ``MultiViewDfM`` detector built after ``patch_reference()``, a
+    ``DfMStereoPath`` / ``MultiViewVoxelPath``, or any ``nn.Module`` that contains this package's
+    registered classes (the *path roots*: SPPUNetNeck, DfMBackbone, DepthHead, FrustumToVoxel,
+    BEVHourglass, OutdoorImVoxelNeck, DfMNeck).  The reference pipeline runs fp32 / NCHW; the MFMA
+    kernels take bf16 / channels-last.  This call
+
+    * converts the convolution (and every other non-norm) parameter of the path roots to ``dtype``;
+      GroupNorm / BatchNorm parameters and running statistics stay fp32 (the fused norm kernels and
+      the folded epilogues read fp32);
+    * sets ``DfMBackbone.volume_memory_format = channels_last_3d`` (the cost volume is built NDHWC)
+      and marks a multi-view detector so its lifted voxel volume is written bf16 / NDHWC;
+    * ``boundary_casts``: installs forward pre-hooks -- a path root casts floating inputs to ``dtype``;
+      every OTHER child of a module that owns a path root (the 2-D backbone, the detection heads)
+      casts ``dtype`` inputs back to the model's original floating dtype -- so the caller keeps feeding
+      and receiving the tensors it did before;
+    * ``strict=True``: switches the fallback policy to 'raise' (an ineligible input to an Mfma*
+      module is then an error instead of a one-time warning, see conv3d.set_fallback_policy).
+
+    Returns a report dict(roots=[names], converted_parameters=n, cast_back=[names], dtype=...).
+    Idempotent.  ``state_dict`` keys are unchanged; ``load_state_dict`` of an fp32 checkpoint casts
+    on copy as usual."""
+    from . import modules as _m
+    from .conv3d import set_fallback_policy
+    path_classes = tuple(registry.registered().values())
+    names = dict((m, n) for n, m in model.named_modules())
+    roots, inside = [], set()
+    for n, m in model.named_modules():
+        if m in inside:
+            continue
+        if isinstance(m, path_classes):
+            roots.append(m)
+            inside.update(m.modules())
+    orig = next((p.dtype for p in model.parameters() if p.is_floating_point() and p.dtype != dtype),
+                torch.float32)
+    converted = 0
+    for root in roots:
+        for sub in root.modules():
+            if _is_norm(sub):
+                continue
+            for p in sub.parameters(recurse=False):
+                if p.is_floating_point() and p.dtype != dtype:
+                    p.data = p.data.to(dtype)
+                    if p.grad is not None:
+                        p.grad = None
+                    converted += 1
+            for k, b in sub.named_buffers(recurse=False):
+                if b is not None and b.is_floating_point() and b.dtype != dtype:
+                    setattr(sub, k, b.to(dtype))
+        if isinstance(root, _m.DfMBackbone):
+            root.volume_memory_format = torch.channels_last_3d
+        if isinstance(root, _m.FrustumToVoxel) and not isinstance(model, DfMStereoPath):
+            root.output_memory_format = torch.contiguous_format   # dfm.py:325-326 views the volume
+    for m in model.modules():
+        if isinstance(m, MultiViewDfMMixin) or \
+                getattr(type(m), 'feature_transformation', None) is MultiViewDfMMixin.feature_transformation:
+            m.fast_dtype = dtype
+    cast_back = []
+    if boundary_casts:
+        for root in roots:
+            if not root.__dict__.get('_dfm_fast_hook'):
+                root.register_forward_pre_hook(_cast_hook(None, dtype), with_kwargs=True)
+                root.__dict__['_dfm_fast_hook'] = True
+        owners = [m for m in model.modules() if m not in inside and any(c in roots for c in m.children())]
+        for owner in owners:
+            for child in owner.children():
+                if child in inside or any(sub in inside for sub in child.modules()):
+                    continue
+                if not child.__dict__.get('_dfm_fast_hook'):
+                    child.register_forward_pre_hook(_cast_hook(dtype, orig), with_kwargs=True)
+                    child.__dict__['_dfm_fast_hook'] = True
+                cast_back.append(names.get(child, type(child).__name__))
+    if strict:
+        set_fallback_policy('raise')
+    return dict(roots=[names.get(r, type(r).__name__) for r in roots], converted_parameters=converted,
+                cast_back=cast_back, dtype=dtype)
+
+
 __all__ = ['inject_detector_attributes', 'DfMStereoPath', 'MultiViewDfMMixin', 'MultiViewVoxelPath',
-           'patch_reference', 'voxel_centers']
+           'patch_reference', 'enable_fast_path', 'voxel_centers']

@@ -451,6 +451,11 @@ class FrustumToVoxel(nn.Module):
         self.voxel_pool = nn.AvgPool3d((4, 1, 1), stride=(4, 1, 1))
         self.coordinates_3d = None  # injected by the detector (dfm.py:99-100)
         self.depth_cfg = None       # injected by the detector (dfm.py:86)
+        # extension: layout of the returned voxel volume.  None = follow the input (channels_last_3d
+        # for an NDHWC cost volume).  The reference detector does ``volume_feat.view(-1, Cv * Nz, Ny,
+        # Nx)`` (dfm.py:325-326), which needs the contiguous layout: enable_fast_path() sets
+        # torch.contiguous_format here for models that are not DfMStereoPath (a 14 MB copy at config K).
+        self.output_memory_format = None
 
     def init_weights(self):
         pass
@@ -472,7 +477,10 @@ class FrustumToVoxel(nn.Module):
                                         self._coords_on(stereo_feat.device), self.depth_cfg,
                                         sem_atten_feat=self.sem_atten_feat,
                                         stereo_atten_feat=self.stereo_atten_feat)
-        return _depth_pool4(self.voxel_pool, self.voxel_convs(voxel))
+        out = _depth_pool4(self.voxel_pool, self.voxel_convs(voxel))
+        if self.output_memory_format is not None:
+            out = out.contiguous(memory_format=self.output_memory_format)
+        return out
 
 
 # --------------------------------------------------------------------------

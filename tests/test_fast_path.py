@@ -1,0 +1,277 @@
+"""The fast path as an explicit switch: ``enable_fast_path(model)`` /
+``patch_reference(precision='bf16')`` and the fallback policy of the Mfma* modules.
+
+CPU: policy plumbing, what ``enable_fast_path`` converts, the reference's own ``DfM`` constructor
+with ``patch_reference(precision='bf16')`` (build container only).
+GPU: a detector wired like the reference's ``DfM.forward_train`` (dfm.py:264-330: 2-D backbone ->
+neck -> backbone_stereo -> depth_head -> feature_transformation -> ``volume_feat.view`` ->
+backbone_3d -> bbox head) fed fp32 images: after ``enable_fast_path`` every 3x3(x3) convolution of
+the path is an MFMA launch (counted), the outputs come back fp32 and agree with the fp32 run;
+without it the modules warn once (or raise in strict mode) instead of silently running MIOpen.
+"""
+import importlib
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from tests import util
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    return importlib.import_module('depth-from-motion_amd')
+
+
+@pytest.fixture(scope='module')
+def cv():
+    return importlib.import_module('depth-from-motion_amd.conv3d')
+
+
+@pytest.fixture()
+def policy(cv):
+    prev = cv.fallback_policy()
+    cv._WARNED.clear()
+    yield cv
+    cv.set_fallback_policy(prev)
+    cv._WARNED.clear()
+
+
+def _kitti_model():
+    with open(os.path.join(util.GOLDEN, 'configs_dfm.json')) as f:
+        model = dict(json.load(f)['dfm_r34_1x8_kitti-3d-3class.py']['model'])
+    model['depth_cfg'] = dict(model['depth_cfg'], num_bins=32)
+    model['depth_head'] = dict(model['depth_head'], depth_cfg=dict(model['depth_head']['depth_cfg'], num_bins=32))
+    model['voxel_cfg'] = dict(point_cloud_range=[2, -6.4, -3, 27.6, 6.4, 1], voxel_size=[0.2, 0.2, 0.2])
+    return model
+
+
+class _Backbone2d(nn.Module):
+    """stand-in for LIGAResNet (out of the path): an fp32 module emitting the pyramid the neck takes"""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = nn.Conv2d(3, 64, 3, 2, 1)
+        self.c2 = nn.Conv2d(64, 128, 3, 2, 1)
+        self.c3 = nn.Conv2d(128, 128, 3, 1, 1)
+        self.c4 = nn.Conv2d(128, 128, 3, 1, 1)
+
+    def forward(self, img):
+        assert img.dtype == torch.float32, 'the out-of-path backbone keeps running fp32'
+        a = torch.relu(self.c1(img))
+        b = torch.relu(self.c2(a))
+        c = torch.relu(self.c3(b))
+        return a, b, c, torch.relu(self.c4(c))
+
+
+class _BevHead(nn.Module):
+    """stand-in for LIGAAnchor3DHead (out of the path): fp32"""
+
+    def __init__(self, c):
+        super().__init__()
+        self.cls = nn.Conv2d(c, 6, 1)
+
+    def forward(self, feats):
+        assert feats[0].dtype == torch.float32, 'the detection head receives fp32'
+        return self.cls(feats[0])
+
+
+class RefWiredDetector(nn.Module):
+    """the dataflow of the reference's DfM.extract_feat / forward_train (dfm.py:264-330), with this
+    package's registered modules where the config builds them and fp32 stand-ins elsewhere"""
+
+    def __init__(self, pkg, model):
+        super().__init__()
+        path = pkg.DfMStereoPath(model)   # builds + injects exactly like dfm.py:30-112
+        self.backbone = _Backbone2d()
+        self.neck, self.backbone_stereo, self.depth_head = path.neck, path.backbone_stereo, path.depth_head
+        self.feature_transformation, self.backbone_3d = path.feature_transformation, path.backbone_3d
+        self.bbox_head_3d = _BevHead(self.backbone_3d.num_bev_features)
+
+    def forward(self, img, img_metas):
+        cur, prev = img[:, 0], img[:, 1]
+        cur_feats = [cur] + list(self.backbone(cur))
+        prev_feats = [prev] + list(self.backbone(prev))
+        cur_stereo, cur_sem = self.neck(cur_feats)
+        prev_stereo, _ = self.neck(prev_feats)
+        cur2prevs = torch.tensor(np.asarray([m['cur2prevs'] for m in img_metas]), device=img.device, dtype=img.dtype)
+        for i, m in enumerate(img_metas):
+            m['cur2prevs'] = cur2prevs[i]
+        costs, stereo_feats, mono_feats = self.backbone_stereo(cur_stereo, prev_stereo, img_metas)
+        up, soft, preds = self.depth_head(costs)
+        vol = self.feature_transformation(stereo_feats, soft, img_metas, cur_sem)
+        _, cv_, nz, ny, nx = vol.shape
+        bev = vol.view(-1, cv_ * nz, ny, nx)              # dfm.py:325-326: needs the contiguous layout
+        prehg, bev = self.backbone_3d(bev)
+        return self.bbox_head_3d([bev]), preds, up
+
+
+def _meta(H, W):
+    K = util.KITTI_P2.copy()
+    return dict(ori_cam2img=K, cam2img=K.tolist(), cur2prevs=util.pose(0.5, 0.02, 0.0, -0.8)[None].tolist(),
+                ori_shape=(H, W, 3), pad_shape=(H, W, 3), crop_offset=[0, 0], flip=False, scale_factor=[1.0])
+
+
+# ------------------------------------------------------------------------------------------ CPU
+def test_policy_switch_and_reasons(policy):
+    cv = policy
+    assert cv.fallback_policy() == 'warn'
+    assert cv.set_fallback_policy('raise') == 'warn' and cv.fallback_policy() == 'raise'
+    with pytest.raises(ValueError):
+        cv.set_fallback_policy('loud')
+    m = cv.MfmaConv3dG(64, 64, 3, padding=1, bias=False)
+    x = torch.zeros(1, 64, 4, 4, 4)
+    assert m.why_not(x) == 'CPU tensor' and not m.eligible(x)
+    # CPU tensors never warn or raise: the module-wiring tests run torch's convolution there
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        assert m(x).shape == (1, 64, 4, 4, 4)
+    assert cv.MfmaConv3dG(64, 64, 3, padding=1, bias=True).why_not(x) == 'CPU tensor'
+    # a problem the planner rejects (a sample of 2^31 bytes or more) is known before any launch
+    assert not cv.conv3d_g_plannable(1, 256, 256, (4000, 4000, 300), 1, 1)
+    assert cv.conv3d_g_plannable(1, 64, 64, (36, 40, 160), 1, 1)
+
+
+def test_enable_fast_path_converts_convolutions_and_keeps_norms_fp32(pkg, policy):
+    det = RefWiredDetector(pkg, _kitti_model())
+    keys = list(det.state_dict().keys())
+    rep = pkg.enable_fast_path(det)
+    assert set(rep['roots']) == {'neck', 'backbone_stereo', 'depth_head', 'feature_transformation', 'backbone_3d'}
+    assert set(rep['cast_back']) == {'backbone', 'bbox_head_3d'} and rep['converted_parameters'] > 30
+    mods = importlib.import_module('depth-from-motion_amd.modules')
+    for name, m in det.named_modules():
+        in_path = name.split('.')[0] in rep['roots']
+        for pn, p in m.named_parameters(recurse=False):
+            if isinstance(m, (nn.GroupNorm, nn.modules.batchnorm._BatchNorm)) or not in_path:
+                assert p.dtype == torch.float32, (name, pn)
+            else:
+                assert p.dtype == torch.bfloat16, (name, pn)
+    assert det.backbone_stereo.volume_memory_format == torch.channels_last_3d
+    assert det.feature_transformation.output_memory_format == torch.contiguous_format
+    assert list(det.state_dict().keys()) == keys
+    assert pkg.fallback_policy() == 'warn'
+    again = pkg.enable_fast_path(det, strict=True)             # idempotent; strict flips the policy
+    assert again['converted_parameters'] == 0 and pkg.fallback_policy() == 'raise'
+    # a DfMStereoPath keeps the channels-last volume (it reshapes with bev_view, not .view)
+    path = pkg.DfMStereoPath(_kitti_model())
+    pkg.enable_fast_path(path)
+    assert path.feature_transformation.output_memory_format is None
+    assert isinstance(path.backbone_stereo, mods.DfMBackbone) and path.backbone_stereo.dres0.conv.weight.dtype == torch.bfloat16
+    # fp32 checkpoints still load (cast on copy)
+    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in path.state_dict().items()}
+    path.load_state_dict(sd, strict=True)
+    assert path.backbone_stereo.dres0.conv.weight.dtype == torch.bfloat16
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/configs/dfm'), reason='reference not mounted (GPU box)')
+def test_patch_reference_precision_bf16_converts_the_reference_detectors(pkg, policy):
+    before = dict(sys.modules)
+    sys.path.insert(0, util.GOLDEN)
+    try:
+        import make_golden_r02 as g
+        import ref_stubs
+        reg, mods = ref_stubs.load_detectors()
+        with pytest.raises(ValueError):
+            pkg.patch_reference(precision='fp8')
+        rep = pkg.patch_reference(precision='bf16')
+        assert 'DfM.__init__ -> enable_fast_path(bf16)' in rep['methods']
+        assert 'DfM.__init__ -> enable_fast_path(bf16)' not in pkg.patch_reference(precision='bf16')['methods']
+        for cfg_name, det_mod, cls in (('dfm_r34_1x8_kitti-3d-3class.py', 'dfm', 'DfM'),
+                                       ('multiview-dfm_r101_dcn_2x16_waymoD5-3d-3class_camsync_10sweeps.py',
+                                        'multiview_dfm', 'MultiViewDfM')):
+            cfg = g.exec_config(os.path.join('/root/reference/configs/dfm', cfg_name))['model']
+            cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items() if k != 'type'}
+            det = getattr(mods[det_mod], cls)(**cfg)
+            rep = det.fast_path_report
+            if cls == 'DfM':
+                assert set(rep['roots']) == {'neck', 'backbone_stereo', 'depth_head', 'feature_transformation',
+                                             'backbone_3d'}
+                assert det.backbone_stereo.dres0.conv.weight.dtype == torch.bfloat16
+                assert det.backbone_stereo.dres0.gn.weight.dtype == torch.float32
+                assert det.backbone_stereo.volume_memory_format == torch.channels_last_3d
+                assert det.feature_transformation.output_memory_format == torch.contiguous_format
+                assert {'backbone', 'bbox_head_3d'} <= set(rep['cast_back'])
+            else:
+                assert rep['roots'] == ['neck_3d'] and det.fast_dtype == torch.bfloat16
+                assert det.neck_3d.stereo_layers[0].conv0.conv.weight.dtype == torch.bfloat16
+                assert det.neck_3d.stereo_layers[0].conv0.bn.running_var.dtype == torch.float32
+    finally:
+        for k in list(sys.modules):
+            if k not in before and k.split('.')[0] in ('mmcv', 'mmdet', 'mmdet3d', 'ref_depth_head'):
+                del sys.modules[k]
+        sys.path.remove(util.GOLDEN)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_fp32_pipeline_reaches_the_mfma_kernels_through_the_switch(pkg, policy, monkeypatch):
+    cv = policy
+    torch.manual_seed(3)
+    det = RefWiredDetector(pkg, _kitti_model()).cuda().eval()
+    H, W = 256, 512
+    img = torch.randn(1, 2, 3, H, W, generator=torch.Generator().manual_seed(9)).cuda()
+    calls = {'g': 0, 'c32': 0}
+    real_g, real_c = cv.conv3d_g, cv.conv3d_k3_c32
+    monkeypatch.setattr(cv, 'conv3d_g', lambda *a, **k: (calls.__setitem__('g', calls['g'] + 1), real_g(*a, **k))[1])
+    monkeypatch.setattr(cv, 'conv3d_k3_c32',
+                        lambda *a, **k: (calls.__setitem__('c32', calls['c32'] + 1), real_c(*a, **k))[1])
+    # 1. as built (fp32): torch convolutions, and the modules say so -- once per (class, reason)
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ref_cls, ref_preds, ref_up = det(img, [_meta(H, W)])
+    assert calls == {'g': 0, 'c32': 0}
+    msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+    assert any('MfmaConv3d(' in m and 'float32' in m and 'enable_fast_path' in m for m in msgs)
+    assert any('MfmaConv3dG(' in m for m in msgs) and any('MfmaConv2d(' in m for m in msgs)
+    assert len(msgs) == len(set(m.split(':')[0].split('(')[0] + m.split(';')[0].split(':', 1)[1] for m in msgs)), \
+        'one warning per (module class, reason)'
+    # 2. strict mode: the same call is an error
+    cv.set_fallback_policy('raise')
+    with torch.no_grad(), pytest.raises(pkg.MfmaPathError, match='float32'):
+        det(img, [_meta(H, W)])
+    # 3. the switch: same fp32 images in, fp32 out, every convolution of the path an MFMA launch
+    rep = pkg.enable_fast_path(det, strict=True)
+    assert rep['converted_parameters'] > 30
+    with torch.no_grad():
+        cls, preds, up = det(img, [_meta(H, W)])
+    # general kernel: 2 x 6 hourglass + 2 x 7 SPPUNetNeck + 7 BEVHourglass; 32 -> 32 kernel: dres0
+    # (2 halves + mono), dres1 x 2, pred.0 x 2, voxel_convs (2 halves)
+    assert calls == {'g': 12 + 14 + 7, 'c32': 9}, calls
+    assert cls.dtype == torch.float32 and cls.shape == ref_cls.shape
+    assert up.dtype == torch.bfloat16 and up.shape == ref_up.shape      # inside the path: bf16
+    for a, b, name in ((cls, ref_cls, 'head output'), (preds, ref_preds, 'depth_preds')):
+        a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+        err = np.abs(a - b).mean() / (np.abs(b).mean() + 1e-6)
+        assert err < 0.06, f'{name}: mean relative error {err:.3f}'
+
+
+@pytest.mark.gpu
+def test_multiview_path_switch_lifts_in_bf16_and_returns_the_callers_dtype(pkg, policy, monkeypatch):
+    cv = policy
+    with open(os.path.join(util.GOLDEN, 'configs_dfm.json')) as f:
+        model = dict(json.load(f)['multiview-dfm_r101_dcn_2x16_waymoD5-3d-3class_camsync_10sweeps.py']['model'])
+    model['anchor_generator'] = dict(model['anchor_generator'], ranges=[[-11.0, -15.0, -3.0, 11.0, 15.0, 3.0]])
+    model['voxel_size'] = [1.0, 1.0, 0.5]
+    path = pkg.MultiViewVoxelPath(model).cuda().eval()
+    rep = pkg.enable_fast_path(path, strict=True)
+    assert rep['roots'] == ['neck_3d'] and path.fast_dtype == torch.bfloat16
+    sys.path.insert(0, util.GOLDEN)
+    try:
+        import make_golden as g1
+    finally:
+        sys.path.remove(util.GOLDEN)
+    lidar2img = g1.waymo_like_cameras(5, 2, 77)
+    meta = {'ori_lidar2img': [m for m in lidar2img], 'input_shape': (104, 156), 'img_shape': [(100, 150, 3)] * 10}
+    feats = torch.randn(1, 10, 64, 26, 39, generator=torch.Generator().manual_seed(4)).cuda()
+    calls = {'g': 0}
+    real = cv.conv3d_g
+    monkeypatch.setattr(cv, 'conv3d_g', lambda *a, **k: (calls.__setitem__('g', calls['g'] + 1), real(*a, **k))[1])
+    with torch.no_grad():
+        out = path(feats, [meta], 5, 2)
+    assert calls['g'] == 18 and out.dtype == torch.float32 and out.shape == (1, 256, 30, 22)
+    assert torch.isfinite(out).all() and float(out.abs().max()) > 0
