@@ -182,11 +182,16 @@ def secondary(args, pkg, dev, rank, world):
             m.downsampled_depth = pkg.prepare_depth(dict(num_bins=288, depth_min=2, depth_max=59.6,
                                                          downsample_factor=4))[0]
             m.volume_memory_format = cl
+            # DFM_NO_SWEEP_FUSION=1: the materialised cost volume instead of the fused plane sweep +
+            # dres0 / dres0_mono kernel (csrc/sweep_conv.hip) -- the A/B of SURVEY 8f rank 1
+            m.fuse_sweep_dres0 = os.environ.get('DFM_NO_SWEEP_FUSION') != '1'
             meta = dict(ori_cam2img=KITTI_P2, cur2prevs=torch.from_numpy(poses(1, 2 + rank)),
                         ori_shape=(375, 1242, 3), pad_shape=(320, 1280, 3), crop_offset=[0, 55], flip=False,
                         scale_factor=[1.0])
             cur = torch.randn(1, 32, 320, 1280, generator=gen).to(dev).bfloat16().requires_grad_(train)
             prev = torch.randn(1, 32, 320, 1280, generator=gen).to(dev).bfloat16().requires_grad_(train)
+            if os.environ.get('DFM_FEATS_NHWC') == '1' and not train:  # the layout SPPUNetNeck emits
+                cur, prev = (t.contiguous(memory_format=torch.channels_last) for t in (cur, prev))
 
             def step():
                 if train:  # forward + backward (all gradients; no optimizer): 3x the forward FLOPs

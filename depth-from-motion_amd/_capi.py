@@ -45,6 +45,10 @@ EXPORTS = (
     'dfm_point_sample_mv_bwd_workspace_bytes',
     'dfm_point_sample_mv_bwd',
     'dfm_depth_head_bwd',
+    'dfm_sweep_conv_weight_bytes',
+    'dfm_sweep_conv_pack_weights',
+    'dfm_sweep_conv_stats_splits',
+    'dfm_sweep_conv_fwd',
     'dfm_conv3d_k3_c32_weight_bytes',
     'dfm_conv3d_k3_c32_pack_weights',
     'dfm_conv3d_k3_c32_stats_splits',
@@ -277,6 +281,13 @@ def lib():
     h.dfm_point_sample_mv_bwd_workspace_bytes.argtypes = [mp]
     h.dfm_depth_head_bwd.restype = ctypes.c_int
     h.dfm_depth_head_bwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, fp, vp, vp, vp, fp, vp]
+    h.dfm_sweep_conv_weight_bytes.restype = sz
+    h.dfm_sweep_conv_pack_weights.restype = ctypes.c_int
+    h.dfm_sweep_conv_pack_weights.argtypes = [vp, vp, i32, vp, vp]
+    h.dfm_sweep_conv_stats_splits.restype = ctypes.c_int
+    h.dfm_sweep_conv_stats_splits.argtypes = [dp, i32]
+    h.dfm_sweep_conv_fwd.restype = ctypes.c_int
+    h.dfm_sweep_conv_fwd.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, vp, fp, fp, i32, vp]
     h.dfm_conv3d_k3_c32_weight_bytes.restype = sz
     h.dfm_conv3d_k3_c32_pack_weights.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_pack_weights.argtypes = [vp, i32, i32, i32, i32, vp, vp]

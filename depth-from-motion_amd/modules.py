@@ -36,6 +36,7 @@ from .frustum_to_voxel import frustum_to_voxel_sample
 from .group_norm import HipBatchNorm3d, HipGroupNorm
 from . import _capi
 from .plane_sweep import _Workspace, build_dfm_cost
+from .sweep_conv import pack_sweep_conv_weights, sweep_conv_supported, sweep_dres0
 from .registry import register_module
 
 
@@ -294,13 +295,21 @@ class DfMBackbone(nn.Module):
         # Conv3d / GroupNorm stack runs NDHWC end to end (convert the module as well:
         # backbone.to(memory_format=torch.channels_last_3d)); values are unchanged
         self.volume_memory_format = torch.contiguous_format
+        # extension (inference, bf16 NDHWC, 32-channel maps): build_dfm_cost, dres0.conv and
+        # dres0_mono.conv run as ONE kernel and the (B, 2C, D, H, W) volume is never written
+        # (csrc/sweep_conv.hip); False keeps the materialised volume
+        self.fuse_sweep_dres0 = True
+        self._sweep_conv_pack = (None, None)
 
     def init_weights(self):
         pass
 
     @staticmethod
     def _aggregate(first, second, hgs, x):
-        cost = first(x)
+        return DfMBackbone._aggregate_rest(second, hgs, first(x))
+
+    @staticmethod
+    def _aggregate_rest(second, hgs, cost):
         cost = second(cost, residual=cost)
         outs = []
         for hg in hgs:
@@ -308,11 +317,41 @@ class DfMBackbone(nn.Module):
             outs.append(cost)
         return outs if outs else [cost]
 
+    def _sweep_dres0_fusable(self, cur):
+        """the fused plane sweep + dres0 / dres0_mono kernel takes this call: inference, bf16 32-channel
+        maps, the NDHWC stack, both first blocks Conv3d(-> 32) + GroupNorm(one channel per group) + ReLU"""
+        def block_ok(cm, cin):
+            norm = getattr(cm, cm.norm_name or '', None)
+            return (isinstance(cm.conv, MfmaConv3d) and cm.conv.in_channels == cin and cm.conv.out_channels == 32 and
+                    cm.conv.weight.dtype == torch.bfloat16 and isinstance(norm, HipGroupNorm) and
+                    norm.num_groups == 32 and norm.affine and cm.activate is not None)
+        return (self.fuse_sweep_dres0 and not torch.is_grad_enabled() and sweep_conv_supported(cur) and
+                self.in_channels == 32 and self.volume_memory_format == torch.channels_last_3d and
+                block_ok(self.dres0, 64) and block_ok(self.dres0_mono, 32))
+
+    def _sweep_conv_packed(self):
+        ws, wm = self.dres0.conv.weight, self.dres0_mono.conv.weight
+        key = (ws._version, ws.data_ptr(), wm._version, wm.data_ptr(), str(ws.device))
+        if self._sweep_conv_pack[0] != key:
+            self._sweep_conv_pack = (key, pack_sweep_conv_weights(ws, wm))
+        return self._sweep_conv_pack[1]
+
     def forward(self, cur_stereo_feats, prev_stereo_feats, img_metas, cur_sem_feats=None):
         ori_cam2imgs = torch.as_tensor(np.asarray([m['ori_cam2img'] for m in img_metas]),
                                        dtype=torch.float32)
         cur2prevs = torch.stack([torch.as_tensor(m['cur2prevs']) for m in img_metas])
         meta0 = img_metas[0]
+        if self._sweep_dres0_fusable(cur_stereo_feats):
+            # plane sweep + dres0.conv + dres0_mono.conv: one kernel, no cost volume in HBM; GroupNorm
+            # (+ReLU) of both branches from the kernel's statistics partials
+            ys, ps, ym, pm = sweep_dres0(
+                cur_stereo_feats, prev_stereo_feats, _on_device(self, 'downsampled_depth', cur_stereo_feats.device),
+                self.feat_sample_factor, self.cost_sample_factor, ori_cam2imgs, cur2prevs[:, 0],
+                meta0['ori_shape'][:2], self._sweep_conv_packed(), meta0.get('flip', False), meta0['crop_offset'],
+                img_scale_factor=meta0.get('scale_factor', [1.0])[0])
+            stereo = self._aggregate_rest(self.dres1, self.hg_stereo, self.dres0.gn(ys, relu=True, partials=ps))
+            mono = self._aggregate_rest(self.dres1_mono, self.hg_mono, self.dres0_mono.gn(ym, relu=True, partials=pm))
+            return self._predict(stereo, mono)
         # plane sweep: HIP kernel (reference: build_dfm_cost, batch semantics per sample)
         cost_raw = build_dfm_cost(
             cur_stereo_feats, prev_stereo_feats,
@@ -324,6 +363,9 @@ class DfMBackbone(nn.Module):
         stereo = self._aggregate(self.dres0, self.dres1, self.hg_stereo, cost_raw)
         mono = self._aggregate(self.dres0_mono, self.dres1_mono, self.hg_mono,
                                channel_slice(cost_raw, 0, self.in_channels))
+        return self._predict(stereo, mono)
+
+    def _predict(self, stereo, mono):
         assert len(stereo) == 1 and len(mono) == 1, 'Only support num_hg=1 for now.'
         s_cost = self.pred_stereo[0](stereo[0])
         m_cost = self.pred_mono[0](mono[0])

@@ -449,6 +449,40 @@ DFM_API int dfm_depth_head_bwd(int32_t batch, int32_t d, int32_t h, int32_t w, i
                                const void *grad_preds, float *grad_cost, void *stream);
 
 /* ---------------------------------------------------------------------- */
+/* Plane sweep fused into dres0 / dres0_mono (csrc/sweep_conv.hip)            */
+/* Replaces, for 32-channel bf16 feature maps, the sequence                   */
+/*   cost_raw = build_dfm_cost(cur, prev, ...)          dfm_backbone.py:161-172 */
+/*   dres0.conv(cost_raw)        Conv3d(64 -> 32, 3, 1, 1)   dfm_backbone.py:175  */
+/*   dres0_mono.conv(cost_raw[:, :32])  Conv3d(32 -> 32)     dfm_backbone.py:189  */
+/* without materialising the (B, 64, D, h_out, w_out) volume: the sampler fills */
+/* the convolution's LDS block.                                                 */
+/* ---------------------------------------------------------------------- */
+/* Bytes of the packed-weight buffer (4 wave roles x 54 MFMA fragments + a zero page). */
+DFM_API size_t dfm_sweep_conv_weight_bytes(void);
+/* w_stereo : (32, 64, 3, 3, 3), w_mono : (32, 32, 3, 3, 3), contiguous, DFM_F32 or DFM_BF16 [device] */
+DFM_API int dfm_sweep_conv_pack_weights(const void *w_stereo, const void *w_mono, int32_t weight_dtype,
+                                        void *packed, void *stream);
+/* statistics partials per (sample, channel) a forward call with this descriptor / depth_chunk emits */
+DFM_API int dfm_sweep_conv_stats_splits(const dfm_sweep_desc *desc, int32_t depth_chunk);
+/*
+ * desc            : as dfm_plane_sweep_fwd; channels must be 32 and dtype DFM_BF16
+ *                   (DFM_ERR_UNSUPPORTED otherwise: run the unfused sequence)
+ * cur/prev_nhwc   : (B, h_in, w_in, 32) bf16, pixel-major (torch channels_last)     [device]
+ * depths, cam2img, cam2img_inv, cur2prev : as dfm_plane_sweep_fwd                    [device]
+ * y_stereo, y_mono: (B, D, h_out, w_out, 32) bf16 NDHWC: the two convolution outputs BEFORE
+ *                   GroupNorm / ReLU (fp32 accumulation over 27 x 64 / 27 x 32 products of the
+ *                   bf16-rounded samples -- the values the unfused bf16 volume would hold)
+ * stats_*         : fp32 [B][32][splits][3]: count / mean / M2 of the stored values per (sample,
+ *                   channel, workgroup), consumed by dfm_group_norm_apply_channels_last
+ * depth_chunk     : output planes one workgroup walks (0 = chosen from the shape)
+ */
+DFM_API int dfm_sweep_conv_fwd(const dfm_sweep_desc *desc, const void *cur_nhwc, const void *prev_nhwc,
+                               const float *depths, const float *cam2img, const float *cam2img_inv,
+                               const float *cur2prev, const void *packed_weights, void *y_stereo,
+                               void *y_mono, float *stats_stereo, float *stats_mono, int32_t depth_chunk,
+                               void *stream);
+
+/* ---------------------------------------------------------------------- */
 /* MFMA Conv3d 3x3x3, stride 1, pad 1, 32 -> 32 channels, NDHWC bf16         */
 /* (ConvModule / convbn_3d of the aggregation stacks: dfm_backbone.py:50-128, */
 /*  utils/conv_modules.py:27-43)                                              */

@@ -239,9 +239,9 @@ def test_fp32_pipeline_reaches_the_mfma_kernels_through_the_switch(pkg, policy, 
     assert rep['converted_parameters'] > 30
     with torch.no_grad():
         cls, preds, up = det(img, [_meta(H, W)])
-    # general kernel: 2 x 6 hourglass + 2 x 7 SPPUNetNeck + 7 BEVHourglass; 32 -> 32 kernel: dres0
-    # (2 halves + mono), dres1 x 2, pred.0 x 2, voxel_convs (2 halves)
-    assert calls == {'g': 12 + 14 + 7, 'c32': 9}, calls
+    # general kernel: 2 x 6 hourglass + 2 x 7 SPPUNetNeck + 7 BEVHourglass; 32 -> 32 kernel: dres1 x 2,
+    # pred.0 x 2, voxel_convs (2 halves) -- dres0 / dres0_mono run inside the fused plane-sweep kernel
+    assert calls == {'g': 12 + 14 + 7, 'c32': 6}, calls
     assert cls.dtype == torch.float32 and cls.shape == ref_cls.shape
     assert up.dtype == torch.bfloat16 and up.shape == ref_up.shape      # inside the path: bf16
     for a, b, name in ((cls, ref_cls, 'head output'), (preds, ref_preds, 'depth_preds')):

@@ -261,6 +261,9 @@ def test_every_launch_of_the_stereo_path_bf16_matches_its_fp32_replay(pkg, monke
     torch.manual_seed(5)
     path = pkg.DfMStereoPath(model).cuda().eval().to(torch.bfloat16)
     path.backbone_stereo.volume_memory_format = torch.channels_last_3d
+    # every launch replayed: dres0 / dres0_mono as their own launches on the materialised volume (the
+    # fused plane-sweep + dres0 kernel has its own parity tests: tests/test_sweep_conv_gpu.py)
+    path.backbone_stereo.fuse_sweep_dres0 = False
     H, W = 256, 512
     gen = torch.Generator().manual_seed(7)
     feats = [[torch.randn(1, c, H // s, W // s, generator=gen).cuda().bfloat16()
