@@ -164,10 +164,12 @@ def cpu_baseline(w, budget_s=12.0):
     return res
 
 
-def secondary(args, pkg, dev, rank, world):
+def secondary(args, pkg, dev, job):
     """Other hot-path rows on their config shapes; `value` = passes/s of the op over
     one sample batch, roofline from HIP-event step time (one fused kernel per step)."""
-    gen = torch.Generator().manual_seed(rank)
+    rank, world = job.rank, job.world
+    gen = torch.Generator().manual_seed(job.seed(0) // 1000)
+    comm = None
     flops, dtype_name = None, None
     if args.workload in ('backbone', 'backbone_train', 'neck', 'dfm_neck'):
         # the MFMA-bound rows (SURVEY.md 8a a2 / a8 / a9): whole-module forward, bf16 channels_last_3d,
@@ -193,14 +195,49 @@ def secondary(args, pkg, dev, rank, world):
             if os.environ.get('DFM_FEATS_NHWC') == '1' and not train:  # the layout SPPUNetNeck emits
                 cur, prev = (t.contiguous(memory_format=torch.channels_last) for t in (cur, prev))
 
+            fwd_bwd_module, reducer = m, None
+            if train and args.reducer != 'none':
+                # the training step's one collective: the gradient all-reduce of
+                # MMDistributedDataParallel (apis/train.py:222-230), overlapped with backward
+                par = importlib.import_module('depth-from-motion_amd.parallel')
+                if args.reducer == 'ddp':
+                    if not torch.distributed.is_initialized():  # a one-rank group: same code path
+                        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                        os.environ.setdefault('MASTER_PORT', '29533')
+                        torch.distributed.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+                    fwd_bwd_module = torch.nn.parallel.DistributedDataParallel(
+                        m, device_ids=[dev.index], broadcast_buffers=False, bucket_cap_mb=32)
+                else:
+                    reducer = par.GradientBucketReducer(m.parameters())
+                grad_bytes = sum(p.numel() * p.element_size() for p in m.parameters() if p.requires_grad)
+                comm = {'reducer': args.reducer, 'gradient_bytes': grad_bytes,
+                        'buckets': len(reducer.buckets) if reducer is not None else None}
+
+            def fwd_bwd(module):
+                m.zero_grad(set_to_none=True)
+                cost, sf, mf = module(cur, prev, [meta])
+                (cost.float().square().mean() + sf.float().square().mean() + mf.float().square().mean()).backward()
+
             def step():
                 if train:  # forward + backward (all gradients; no optimizer): 3x the forward FLOPs
-                    m.zero_grad(set_to_none=True)
-                    cost, sf, mf = m(cur, prev, [meta])
-                    return (cost.float().square().mean() + sf.float().square().mean() +
-                            mf.float().square().mean()).backward()
+                    fwd_bwd(fwd_bwd_module)
+                    if reducer is not None:
+                        reducer.finalize()
+                    return None
                 with torch.no_grad():
                     return m(cur, prev, [meta])
+            if comm is not None:
+                if reducer is not None:
+                    def no_exchange():
+                        reducer.enabled = False
+                        fwd_bwd(m)
+                        reducer.enabled = True
+                    comm.update(step_without_exchange=no_exchange, reducer_obj=reducer)
+                else:
+                    def no_exchange():
+                        with fwd_bwd_module.no_sync():
+                            fwd_bwd(fwd_bwd_module)
+                    comm.update(step_without_exchange=no_exchange)
             flops = (3 if train else 1) * 0.96e12  # stereo 532 G + mono 430 G per sample
             name = ('DfMBackbone forward + backward' if train else 'DfMBackbone.forward') + \
                 ' config K (plane sweep + 3-D aggregation, 72x80x320, bf16 NDHWC)'
@@ -327,16 +364,28 @@ def secondary(args, pkg, dev, rank, world):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
+    if comm is not None:
+        # the same step WITHOUT the gradient exchange, timed first: what the all-reduce adds on top of
+        # it in the headline below is the communication that backward did not hide
+        no_comm_s, _ = job.timed_steps(comm.pop('step_without_exchange'), args.steps)
+        comm['ms_per_step_no_exchange'] = round(no_comm_s * 1e3 / args.steps, 4)
         step()
+        torch.cuda.synchronize()
+        if 'reducer_obj' in comm:
+            comm['reducer_obj'].launched_during_backward = 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    job.barrier()
+    torch.cuda.synchronize()
+    e0.record()
+    elapsed, every = job.timed_steps(step, args.steps)   # barrier + sync both sides, MAX over ranks
     e1.record()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
     ms = elapsed * 1e3 / args.steps
     dev_ms = e0.elapsed_time(e1) / args.steps
+    if comm is not None:
+        comm['exposed_exchange_ms'] = round(ms - comm['ms_per_step_no_exchange'], 4)
+        if 'reducer_obj' in comm:
+            comm['buckets_launched_during_backward_per_step'] = comm.pop('reducer_obj').launched_during_backward / args.steps
     if flops is not None:
         tf = flops / (dev_ms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -358,7 +407,8 @@ def secondary(args, pkg, dev, rank, world):
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {name}', 'global_batch': B * world,
                        'parallelism': f'dp{world}'},
-            'roofline': roof}), flush=True)
+            'roofline': roof, 'per_rank_ms_per_step': [round(v * 1e3 / args.steps, 4) for v in every],
+            **({'gradient_exchange': comm} if comm is not None else {})}), flush=True)
 
 
 def main():
@@ -380,6 +430,8 @@ def main():
     ap.add_argument('--no-autotune', action='store_true',
                     help='skip dfm_plane_sweep_autotune (workgroup schedule stays at its default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--reducer', default='none', choices=['none', 'ddp', 'bucket'],
+                    help='backbone_train: gradient exchange of the step (DDP, or GradientBucketReducer)')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass')
     args = ap.parse_args()
@@ -406,21 +458,23 @@ def main():
                                       points_per_lane=args.ppl).items() if v}
     if args.no_autotune:
         os.environ['DFM_AUTOTUNE'] = '0'
+    par = importlib.import_module('depth-from-motion_amd.parallel')
+    job = par.BenchJob(rank, world, dev, torch.cuda.synchronize)
     with sweep.launch_options(**explicit):
-        return run(args, pkg, sweep, lib, dev, rank, world, explicit)
+        return run(args, pkg, sweep, lib, dev, job, explicit)
 
 
-def run(args, pkg, sweep, lib, dev, rank, world, explicit):
-
+def run(args, pkg, sweep, lib, dev, job, explicit):
+    rank, world = job.rank, job.world
     if args.workload in SECONDARY:
-        return secondary(args, pkg, dev, rank, world)
+        return secondary(args, pkg, dev, job)
     w = WORKLOADS[args.workload]
     tdtype = torch.bfloat16 if w['dtype'] == 'bf16' else torch.float32
     elem = 2 if w['dtype'] == 'bf16' else 4
     B = w['B']
     # synthetic inputs: cur seed 0, prev seed 1 (+rank so shards differ)
-    gc = torch.Generator().manual_seed(0 + 1000 * rank)
-    gp = torch.Generator().manual_seed(1 + 1000 * rank)
+    gc = torch.Generator().manual_seed(job.seed(0))
+    gp = torch.Generator().manual_seed(job.seed(1))
     cur = torch.randn(B, w['C'], w['H'], w['W'], generator=gc).to(dev).to(tdtype)
     prev = torch.randn(B, w['C'], w['H'], w['W'], generator=gp).to(dev).to(tdtype)
     if w.get('nhwc'):
@@ -442,10 +496,20 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
         sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T, out=out,
                                   channels_last=args.channels_last)
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
+    # which part did the lease land on?  The same binary runs 1.06-1.16k vol/s on parts whose HBM write
+    # path sustains ~4.1 TB/s for this store stream and 1.40-1.47k on the others (profiles/r02_c44_*):
+    # a ~20 ms fill probe of the output buffer makes the bench line explain itself
+    torch.cuda.synchronize()
+    pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out.zero_()
+    pe0.record()
+    for _ in range(3):
+        out.zero_()
+    pe1.record()
+    torch.cuda.synchronize()
+    fill_gbps = 3 * out.numel() * out.element_size() / (pe0.elapsed_time(pe1) * 1e-3) / 1e9
+    part = {'fill_probe_gbps': round(fill_gbps, 1), 'class': 'fast' if fill_gbps >= 4800.0 else 'slow',
+            'note': 'hipMemset-style fill of the output buffer; parts below ~4.8 TB/s cap the sweep near 0.50 of the roofline'}
     if explicit or args.channels_last or args.no_autotune or w.get('nhwc'):
         os.environ['DFM_AUTOTUNE'] = '0'  # keep the first launch from tuning by itself
     for _ in range(args.warmup):
@@ -458,12 +522,12 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
         # this size ran the autotuner; query what it cached, tune now if it did not)
         tuned = sweep.plane_sweep_tuning(desc) or \
             sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
-    verified = None
+    verified, check_agrees = None, None
     if tuned is not None and w['dtype'] == 'bf16':
-        # untimed, part of the tuning: the library's pick is checked against both tile shapes over as
-        # many launches as the timed region has -- its own timing window is a few launches at process
-        # start, and a wrong pick costs 3-6 % (it cost 20 % while re-fetching schedules were still
-        # candidates: profiles/r02_c43_bench_default_mispick.json).  The faster one is used.
+        # untimed, informational: the library's pick (dfm_plane_sweep_autotune: 8 rounds x 4 launches per
+        # candidate, median round) next to both tile shapes timed over as many launches as the timed
+        # region has.  The bench runs WHAT THE LIBRARY PICKED -- what a build_dfm_cost() user gets -- and
+        # reports whether this check agrees (round 2 overrode the library here).
         shapes = {'lanes256_ppl8_planes2_chunk1': dict(kernel=2, lanes=256, points_per_lane=8, bands_per_chunk=1),
                   'lanes512_ppl4_planes2_chunk1': dict(kernel=2, lanes=512, points_per_lane=4, bands_per_chunk=1)}
         verified = {}
@@ -478,36 +542,22 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
                 e1.record()
                 torch.cuda.synchronize()
                 verified[key] = round(e0.elapsed_time(e1) / args.steps, 4)
-        if world > 1:  # every rank must take the same launch shape
-            t = torch.tensor([verified[k] for k in shapes], device=dev)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            verified = {k: round(float(v), 4) for k, v in zip(shapes, t)}
-        best_key = min(verified, key=verified.get)
-        chosen_kw = shapes[best_key]
-        tuned = pkg._capi.SweepOpts(**{sweep._OPT_FIELDS[k]: v for k, v in chosen_kw.items()}).as_dict()
-    else:
-        chosen_kw = {}
+        best_key, verified = job.agree_fastest(verified)
+        verified = {k: round(v, 4) for k, v in verified.items()}
+        check_agrees = schedule_key(tuned) == best_key
+    chosen_kw = {}
     import contextlib
     with (sweep.launch_options(**chosen_kw) if chosen_kw else contextlib.nullcontext()):
         step()
         pkg._capi.check(lib.dfm_profile_begin(args.steps))
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = time.perf_counter() - t0
+        # barrier + synchronize on both sides; the job's time is the MAX over ranks, every rank's own
+        # time is kept to expose stragglers (parallel.BenchJob: the same code runs under gloo in the tests)
+        elapsed, every = job.timed_steps(step, args.steps)
     kms, klaunches = ctypes.c_double(0), ctypes.c_int(0)
     pkg._capi.check(lib.dfm_profile_end(ctypes.byref(kms), ctypes.byref(klaunches)))
-
-    # max over ranks is the job's time; every rank's own time is kept to expose stragglers
-    par = importlib.import_module('depth-from-motion_amd.parallel')
-    elapsed, every = par.gather_rank_times(elapsed, dev)
     per_rank_ms = [round(v * 1e3 / args.steps, 4) for v in every]
     ms_per_step = elapsed * 1e3 / args.steps
-    value = B * world / (ms_per_step / 1e3)
+    value = job.value(B, args.steps, elapsed)
 
     if rank == 0:
         bytes_per_launch = algorithmic_bytes(w, elem) * B
@@ -542,6 +592,7 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
                                                               explicit.items()}).as_dict()),
                 'autotuned': tuned is not None,
                 'tuning_check_ms': verified,
+                'tuning_check_agrees_with_library': check_agrees,
                 'volume_layout': '(B,D,H,W,2C) channels_last_3d' if args.channels_last
                 else '(B,2C,D,H,W) contiguous (the reference layout)',
             },
@@ -565,6 +616,7 @@ def run(args, pkg, sweep, lib, dev, rank, world, explicit):
                 'algorithmic_bytes_per_launch': bytes_per_launch,
             },
             'per_rank_ms_per_step': per_rank_ms,
+            'part': part,
         }
         if world == 1 and not args.channels_last:
             # the public API (what DfMBackbone.forward calls): build_dfm_cost with device-resident

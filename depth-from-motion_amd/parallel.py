@@ -128,6 +128,7 @@ class GradientBucketReducer:
         self._next = 0  # first bucket not launched yet
         self._filled = set()
         self.launched_during_backward = 0
+        self.enabled = True  # False: hooks and finalize() do nothing (a step without the exchange, for A/B timing)
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
     def _buffer(self, bi):
@@ -149,6 +150,8 @@ class GradientBucketReducer:
             self._next += 1
 
     def _hook(self, p):
+        if not self.enabled:
+            return
         bi, off = self._where[p]
         if p in self._filled:  # a second backward before finalize(): gradients accumulate
             raise RuntimeError('GradientBucketReducer: call finalize() after every backward()')
@@ -159,6 +162,8 @@ class GradientBucketReducer:
 
     def finalize(self):
         """Launch the remaining buckets, wait for all, write the averaged sums back."""
+        if not self.enabled:
+            return 0
         self._launch_ready(final=True)
         world = dist.get_world_size() if _active() else 1
         for bi, bucket in enumerate(self.buckets):
@@ -187,3 +192,64 @@ class GradientBucketReducer:
         for h in self._handles:
             h.remove()
         self._handles = []
+
+
+class BenchJob:
+    """bench.py's multi-process protocol (one process per GPU, launched by torch.distributed.run),
+    factored out of the script so that a gloo world on CPU can drive exactly the same code with a
+    stub step (tests/test_distributed_cpu.py): the rank / shard bookkeeping, the barrier-bracketed
+    timed region with the MAX over ranks, the agreement on one launch shape, the whole-job value.
+
+    ``sync``: the device synchronisation (``torch.cuda.synchronize`` on a GPU; a no-op on CPU)."""
+
+    def __init__(self, rank=0, world=1, device=None, sync=None):
+        self.rank, self.world, self.device = int(rank), int(world), device
+        self._sync = sync or (lambda: None)
+        if self.world > 1 and not _active():
+            raise RuntimeError('BenchJob(world > 1) needs an initialised torch.distributed process group')
+        if _active() and dist.get_world_size() != self.world:
+            raise RuntimeError(f'process group has {dist.get_world_size()} ranks, the job says {self.world}')
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def seed(self, base):
+        """shards differ: every rank draws its synthetic batch from its own generator"""
+        return int(base) + 1000 * self.rank
+
+    def shard(self, global_batch):
+        """this rank's contiguous slice [lo, hi) of a global batch (strong scaling)"""
+        return shard_range(global_batch, self.rank, self.world)
+
+    def timed_steps(self, step, steps, clock=None):
+        """EXACTLY ``steps`` calls of ``step`` bracketed by barrier + device sync on both sides.
+        Returns (job seconds = MAX over ranks, [every rank's seconds])."""
+        import time
+        clock = clock or time.perf_counter
+        self.barrier()
+        self._sync()
+        t0 = clock()
+        for _ in range(int(steps)):
+            step()
+        self._sync()
+        self.barrier()
+        elapsed = clock() - t0
+        return gather_rank_times(elapsed, self.device)
+
+    def agree_fastest(self, timings):
+        """``timings``: {candidate: this rank's time}.  Every rank must launch the same shape: a
+        candidate's time is its MAX over ranks, the choice is the minimum of those (ties: the first
+        key in the dict's order, identical on every rank).  Returns (key, {candidate: agreed time})."""
+        keys = list(timings)
+        vals = [float(timings[k]) for k in keys]
+        if self.world > 1:
+            t = torch.tensor(vals, dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            vals = [float(v) for v in t]
+        agreed = dict(zip(keys, vals))
+        return min(keys, key=lambda k: agreed[k]), agreed
+
+    def value(self, units_per_rank_per_step, steps, job_seconds):
+        """whole-job throughput (weak scaling: every rank processes ``units_per_rank_per_step``)"""
+        return units_per_rank_per_step * self.world * steps / job_seconds

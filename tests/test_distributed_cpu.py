@@ -161,3 +161,75 @@ def test_shard_range_covers_the_batch():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
     assert [par.shard_range(64, r, 8) for r in (0, 7)] == [(0, 8), (56, 64)]
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py's multi-process protocol (parallel.BenchJob), driven with a stub step under gloo:
+# the code bench.py runs per rank on RCCL -- seeds / shards, the barrier-bracketed timed region with the
+# MAX over ranks, the agreement on one launch shape, the whole-job value, the reducer A/B switch
+# ---------------------------------------------------------------------------------------------
+def _bench_worker(rank, world, port, q):
+    import time
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    par = importlib.import_module('depth-from-motion_amd.parallel')
+    job = par.BenchJob(rank, world)
+    calls = []
+
+    def step():  # rank 1 is the straggler
+        calls.append(1)
+        time.sleep(0.01 if rank == 0 else 0.03)
+    job_s, every = job.timed_steps(step, 5)
+    # the ranks time the two candidate launch shapes differently: rank 0 prefers 'a', rank 1 'b' strongly
+    local = {'a': 1.0, 'b': 1.2} if rank == 0 else {'a': 2.0, 'b': 0.9}
+    key, agreed = job.agree_fastest(local)
+    # the reducer's A/B switch: a step with the exchange disabled leaves .grad local and launches nothing
+    p = torch.nn.Parameter(torch.ones(4) * (rank + 1))
+    red = par.GradientBucketReducer([p])
+    red.enabled = False
+    (p * 2.0).sum().backward()
+    assert red.finalize() == 0 and red.launched_during_backward == 0
+    local_grad = p.grad.clone()
+    red.enabled = True
+    p.grad = None
+    (p * (rank + 1.0)).sum().backward()
+    red.finalize()
+    q.put((rank, len(calls), job_s, every, key, agreed, job.seed(7), job.shard(9), job.value(8, 5, job_s),
+           local_grad.tolist(), p.grad.tolist()))
+    dist.destroy_process_group()
+
+
+def test_bench_job_protocol_under_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, n0, s0, e0, k0, a0, seed0, sh0, v0, lg0, g0), (r1, n1, s1, e1, k1, a1, seed1, sh1, v1, lg1, g1) = res
+    assert n0 == n1 == 5, 'exactly K timed steps on every rank'
+    assert s0 == s1 == max(e0) and e0 == e1 and len(e0) == 2, 'job time = MAX over ranks, per-rank times kept'
+    assert e0[1] >= 5 * 0.03 * 0.9 and e0[0] >= 5 * 0.01 * 0.9
+    assert e0[0] >= 0.8 * e0[1], 'the closing barrier holds the fast rank until the straggler is done'
+    assert k0 == k1 == 'b' and a0 == a1 == {'a': 2.0, 'b': 1.2}, 'one launch shape for the whole job: MAX then min'
+    assert (seed0, seed1) == (7, 1007) and (sh0, sh1) == ((0, 5), (5, 9))
+    assert abs(v0 - 8 * 2 * 5 / s0) < 1e-9 and v0 == v1
+    assert lg0 == [2.0] * 4 and lg1 == [2.0] * 4, 'exchange disabled: gradients stay local'
+    assert g0 == g1 == [1.5] * 4, 'exchange on: the average over ranks of (1, 2)'
+
+
+def test_bench_job_single_process_needs_no_process_group():
+    par = importlib.import_module('depth-from-motion_amd.parallel')
+    job = par.BenchJob()
+    n = []
+    s, every = job.timed_steps(lambda: n.append(1), 3)
+    assert len(n) == 3 and every == [s] and job.agree_fastest({'x': 2.0, 'y': 1.0})[0] == 'y'
+    assert job.value(8, 3, 2.0) == 12.0 and job.seed(5) == 5 and job.shard(8) == (0, 8)
+    import pytest
+    with pytest.raises(RuntimeError):
+        par.BenchJob(0, 2)
