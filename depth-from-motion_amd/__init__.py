@@ -21,6 +21,8 @@ from .integration import (DfMStereoPath, MultiViewDfMMixin, MultiViewVoxelPath, 
                           enable_fast_path, inject_detector_attributes, patch_reference)
 from .conv3d import MfmaPathError, fallback_policy, set_fallback_policy  # noqa: F401
 from .depth_head import depth_distribution_loss  # noqa: F401
+from .data_geometry import (fold_ref_frame_matrices, select_ref_frames, stage_geometry,  # noqa: F401
+                            video_cur2prevs)
 from .point_sample import (mv_feature_transformation, point_sample, voxel_centers,  # noqa: F401
                            voxel_sample)
 
@@ -28,5 +30,6 @@ __all__ = ['build_dfm_cost', 'plane_sweep_grid', 'point_sample', 'mv_feature_tra
            'voxel_centers', 'voxel_sample', 'frustum_to_voxel_sample', 'depth_head_forward', 'prepare_depth',
            'prepare_coordinates_3d', 'group_norm', 'HipGroupNorm', 'DfMStereoPath', 'MultiViewDfMMixin',
            'MultiViewVoxelPath', 'inject_detector_attributes', 'patch_reference', 'enable_fast_path', 'set_fallback_policy',
-           'fallback_policy', 'MfmaPathError', 'depth_distribution_loss',
+           'fallback_policy', 'MfmaPathError', 'select_ref_frames', 'fold_ref_frame_matrices', 'video_cur2prevs',
+           'stage_geometry', 'depth_distribution_loss',
            'depth_head_statistics', 'LazyDepthDistribution']

@@ -251,14 +251,22 @@ def mv_feature_transformation(batch_feats, img_metas, num_views, num_frames, vox
             scale = (1.0, 1.0)
         flip = img_meta.get('flip', False)
         crop = _crop_xy(img_meta['img_crop_offset']) if 'img_crop_offset' in img_meta else (0.0, 0.0)
-        proj.append(np.asarray(img_meta['ori_lidar2img'][:nvf], dtype=np.float32).reshape(nvf, 16))
+        l2i = img_meta['ori_lidar2img']
+        if torch.is_tensor(l2i):   # staged by data_geometry.stage_geometry: read where it lies
+            proj.append(l2i[:nvf].to(torch.float32).reshape(nvf, 16))
+        else:
+            proj.append(np.asarray(l2i[:nvf], dtype=np.float32).reshape(nvf, 16))
         ori_w.append([float(img_meta['img_shape'][i][1]) for i in range(nvf)])
         descs.append(_make_desc(feats, points.shape[0], nxyz, num_views, num_frames, scale, crop,
                                 flip, img_meta['input_shape'], False, temporal_aggregate,
                                 valid_sample))
         descs[-1].feats_channels_last = 1 if feats_cl else 0
     # one upload for the whole batch's matrices
-    proj = _upload(torch.from_numpy(np.stack(proj)), device)
+    if all(torch.is_tensor(p_) for p_ in proj):
+        proj = torch.stack([p_.to(device) for p_ in proj]).contiguous()   # device tensors: no host round trip
+    else:
+        proj = _upload(torch.from_numpy(np.stack([p_.detach().cpu().numpy() if torch.is_tensor(p_) else p_
+                                                  for p_ in proj])), device)
     ori_w = _upload(torch.tensor(ori_w, dtype=torch.float32), device)
     if any(m.get('transformation_3d_flow') for m in img_metas):
         # point_sample undoes each sample's own 3-D augmentation first (point_fusion.py:57-58)

