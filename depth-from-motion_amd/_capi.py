@@ -42,6 +42,7 @@ EXPORTS = (
     'dfm_frustum_to_voxel_fused_fwd',
     'dfm_frustum_to_voxel_bwd_workspace_bytes',
     'dfm_frustum_to_voxel_bwd',
+    'dfm_point_sample_mv_fwd_batched',
     'dfm_point_sample_mv_bwd_workspace_bytes',
     'dfm_point_sample_mv_bwd',
     'dfm_depth_head_bwd',
@@ -258,6 +259,8 @@ def lib():
     h.dfm_point_sample_mv_workspace_bytes.argtypes = [mp]
     h.dfm_point_sample_mv_fwd.restype = ctypes.c_int
     h.dfm_point_sample_mv_fwd.argtypes = [mp, vp, fp, fp, fp, vp, vp, vp, sz, vp]
+    h.dfm_point_sample_mv_fwd_batched.restype = ctypes.c_int
+    h.dfm_point_sample_mv_fwd_batched.argtypes = [vp, i32, vp, fp, i32, fp, fp, vp, vp, vp]
     h.dfm_frustum_to_voxel_fwd.restype = ctypes.c_int
     h.dfm_frustum_to_voxel_fwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, vp, fp, fp, vp, vp,
                                            ctypes.c_size_t, vp]

@@ -20,6 +20,8 @@
 
 #include <stdio.h>
 
+#include <algorithm>
+
 using namespace dfm;
 
 namespace {
@@ -205,6 +207,134 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Channels-last lifting, a whole batch per launch (the multi-view configs' bf16 path): LPV lanes
+// per voxel, one per 16-byte channel block.
+//   * lane = voxel made a wave's stores 16-byte pieces 128-256 B apart (one per voxel row of the
+//     channels-last volume) and its tap loads 64 different cache lines per instruction; here the
+//     LPV lanes of a voxel read one contiguous (C * sizeof(T))-byte tap and write one contiguous
+//     row piece, and a wave's 64 / LPV voxels are consecutive rows of the volume: whole KiBs;
+//   * the projections of a voxel's F * Nv views are computed ONCE, spread over its LPV lanes
+//     (lane j takes views j, j + LPV, ...), and handed round with wave shuffles;
+//   * blockIdx.y = sample: the per-sample image transform comes from a small by-value table
+//     (one launch per batch instead of one per sample from Python).
+// Nearest sampling only (aligned=False: what MultiViewDfM / ImVoxelNet pass,
+// multiview_dfm.py:169, imvoxelnet.py:71); bilinear keeps the kernel above.  Same per-channel
+// addition order as the reference (views, then frames) -- bit-identical results.
+// ---------------------------------------------------------------------------
+constexpr int MV_MAX_BATCH = 16;
+struct MvBatch {
+    float scale_x[MV_MAX_BATCH], scale_y[MV_MAX_BATCH], crop_x[MV_MAX_BATCH], crop_y[MV_MAX_BATCH];
+    float pad_h[MV_MAX_BATCH], pad_w[MV_MAX_BATCH];
+    int32_t flip[MV_MAX_BATCH];
+    long long points_stride;  // 0: one point set shared by the batch
+};
+
+template <typename T, int LPV>
+__global__ __launch_bounds__(256) void mv_sample_cl_kernel(
+    MvGeom g0, MvBatch mb, const uint4 *__restrict__ feats, const float *__restrict__ points,
+    const float *__restrict__ proj, const float *__restrict__ ori_w, T *__restrict__ out,
+    unsigned char *__restrict__ valid_out)
+{
+    constexpr int CB = elem<T>::CB;
+    constexpr int VPW = 64 / LPV;   // voxels per wave
+    constexpr int KMAX = 4;         // up to 4 * LPV (frame, view) pairs
+    const int b = blockIdx.y;
+    MvGeom g = g0;
+    g.scale_x = mb.scale_x[b]; g.scale_y = mb.scale_y[b]; g.crop_x = mb.crop_x[b]; g.crop_y = mb.crop_y[b];
+    g.pad_h = mb.pad_h[b]; g.pad_w = mb.pad_w[b]; g.flip = mb.flip[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = lane % LPV, vgrp = lane / LPV;
+    const long long o = ((long long)blockIdx.x * 4 + wave) * VPW + vgrp;
+    const bool live = o < g.N;
+    const long long oc = live ? o : g.N - 1;
+    long long pidx = oc;
+    if (g.nz > 0) {
+        const int z = (int)(oc % g.nz);
+        const long long t = oc / g.nz;
+        const int y = (int)(t % g.ny);
+        const int x = (int)(t / g.ny);
+        pidx = ((long long)z * g.ny + y) * g.nx + x;  // anchor order: z-major, then y, then x
+    }
+    const float *pts = points + (size_t)b * mb.points_stride;
+    const float px = pts[3 * pidx], py = pts[3 * pidx + 1], pz = pts[3 * pidx + 2];
+    const int HW = g.Hf * g.Wf, nvf = g.num_views * g.num_frames;
+    const float *pj = proj + (size_t)b * nvf * 16;
+    const float *ow = ori_w + (size_t)b * nvf;
+    const uint4 *fb = feats + (size_t)b * nvf * HW * LPV + blk;
+    const int c_out = g.C * (g.aggregate ? g.num_frames : 1);
+    T *orow = out + ((size_t)b * g.N + (size_t)oc) * c_out + (size_t)blk * CB;
+
+    // this lane's share of the voxel's projections: code = -2 not valid, -1 valid but outside the
+    // map (counts, adds zeros), >= 0 the nearest pixel
+    int code[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int i = k * LPV + blk;
+        code[k] = -2;
+        if (i < nvf) {
+            float nx, ny;
+            const bool ok = project_view(g, pj + 16 * i, ow[i], px, py, pz, nx, ny);
+            if (ok) {  // valid_features[~valid] = 0: a view that does not see the point contributes nothing
+                const float x = ((nx + 1.0f) * 0.5f) * (float)(g.Wf - 1);
+                const float y = ((ny + 1.0f) * 0.5f) * (float)(g.Hf - 1);
+                const float xr = rintf(x), yr = rintf(y);  // nearbyint: round half to even
+                const bool in = (fabsf(x) <= 3.0e38f) && (fabsf(y) <= 3.0e38f) && xr >= 0.0f &&
+                                xr <= (float)(g.Wf - 1) && yr >= 0.0f && yr <= (float)(g.Hf - 1);
+                code[k] = in ? (int)yr * g.Wf + (int)xr : -1;
+            }
+        }
+    }
+    float tot[CB], acc[CB];
+#pragma unroll
+    for (int e = 0; e < CB; ++e) { tot[e] = 0.0f; acc[e] = 0.0f; }
+    int tot_cnt = 0, cnt = 0, nvalid = 0, f = 0, v = 0;
+    const int base = lane - blk;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        for (int j = 0; j < LPV; ++j) {
+            const int i = k * LPV + j;
+            if (i >= nvf) break;
+            const int cd = __shfl(code[k], base + j);
+            if (cd != -2) {
+                ++cnt;
+                ++nvalid;
+                if (cd >= 0) {
+                    float r[CB];
+                    unpack16(fb[((size_t)i * HW + cd) * LPV], r);
+#pragma unroll
+                    for (int e = 0; e < CB; ++e) acc[e] = acc[e] + r[e];  // stack(views).sum(0)
+                }
+            }
+            if (++v == g.num_views) {  // end of frame f
+                if (g.aggregate) {
+                    const float den = (float)max(cnt, 1);
+                    float r[CB];
+#pragma unroll
+                    for (int e = 0; e < CB; ++e) r[e] = acc[e] / den;
+                    if (live) store16<T>(orow + (size_t)f * g.C, r);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CB; ++e) tot[e] = tot[e] + acc[e];  // stack(frames).sum(0)
+                    tot_cnt += cnt;
+                }
+#pragma unroll
+                for (int e = 0; e < CB; ++e) acc[e] = 0.0f;
+                cnt = 0; v = 0; ++f;
+            }
+        }
+    }
+    if (!g.aggregate) {
+        const float den = (float)max(tot_cnt, 1);
+        float r[CB];
+#pragma unroll
+        for (int e = 0; e < CB; ++e) r[e] = tot[e] / den;
+        if (live) store16<T>(orow, r);
+    }
+    if (valid_out && live && blk == 0) valid_out[(size_t)b * g.N + o] = nvalid > 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -275,6 +405,79 @@ DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *d, const void *feats, con
                                (const bf16_t *)feats, (bf16_t *)workspace, g.C, Cp, (long long)HW);
         hipLaunchKernelGGL(mv_sample_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, g,
                            (const uint4 *)maps, points, proj, ori_w, (bf16_t *)out, valid_out);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_ps(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+
+DFM_API int dfm_point_sample_mv_fwd_batched(const dfm_mv_desc *descs, int32_t batch, const void *feats,
+                                            const float *points, int32_t points_per_sample, const float *proj,
+                                            const float *ori_w, void *out, unsigned char *valid_out, void *stream)
+{
+    if (!descs || batch <= 0) return fail_ps(DFM_ERR_INVALID_ARG, "no descriptors");
+    const dfm_mv_desc *d = &descs[0];
+    if (d->num_views <= 0 || d->num_frames <= 0 || d->channels <= 0 || d->feat_h <= 0 || d->feat_w <= 0 ||
+        d->num_points <= 0)
+        return fail_ps(DFM_ERR_INVALID_ARG, "non-positive size in dfm_mv_desc");
+    if (!feats || !points || !proj || !ori_w || !out) return fail_ps(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (d->nz > 0 && (long long)d->nx * d->ny * d->nz != d->num_points)
+        return fail_ps(DFM_ERR_INVALID_ARG, "nx*ny*nz != num_points");
+    const int CB = d->dtype == DFM_BF16 ? 8 : 4;
+    const int nblk = d->channels / CB;
+    // what the lanes-per-voxel kernel covers; anything else: DFM_ERR_UNSUPPORTED, use dfm_point_sample_mv_fwd
+    if ((d->dtype != DFM_F32 && d->dtype != DFM_BF16) || d->mode != 0 || !d->valid_sample || !d->feats_channels_last ||
+        (d->nz > 0 && !d->out_channels_last) || d->channels % CB != 0 || (nblk != 4 && nblk != 8 && nblk != 16) ||
+        d->num_views * d->num_frames > 4 * nblk || ((uintptr_t)feats & 15) || ((uintptr_t)out & 15))
+        return fail_ps(DFM_ERR_UNSUPPORTED, "batched lifting: nearest mode, valid_sample, channels-last views and volume, "
+                                            "4 / 8 / 16 channel blocks, <= 4 x blocks (frame, view) pairs");
+    for (int b = 1; b < batch; ++b) {
+        const dfm_mv_desc &e = descs[b];
+        if (e.num_views != d->num_views || e.num_frames != d->num_frames || e.channels != d->channels ||
+            e.feat_h != d->feat_h || e.feat_w != d->feat_w || e.nx != d->nx || e.ny != d->ny || e.nz != d->nz ||
+            e.num_points != d->num_points || e.mode != d->mode || e.aggregate != d->aggregate ||
+            e.valid_sample != d->valid_sample || e.dtype != d->dtype || e.out_channels_last != d->out_channels_last ||
+            e.feats_channels_last != d->feats_channels_last)
+            return fail_ps(DFM_ERR_INVALID_ARG, "the samples of a batch differ in more than their image transform");
+    }
+    MvGeom g;
+    g.num_views = d->num_views; g.num_frames = d->num_frames; g.C = d->channels;
+    g.Hf = d->feat_h; g.Wf = d->feat_w; g.nblk = nblk;
+    g.nx = d->nx; g.ny = d->ny; g.nz = d->nz; g.N = d->num_points;
+    g.mode = 0; g.aggregate = d->aggregate; g.valid_sample = 1; g.out_cl = d->nz > 0 ? 1 : 0;
+    g.scale_x = g.scale_y = 1.0f; g.crop_x = g.crop_y = 0.0f; g.pad_h = g.pad_w = 1.0f; g.flip = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int vpw = 64 / nblk;
+    const long long nb = (g.N + 4 * vpw - 1) / (4 * vpw);
+    if (nb > 2147483647ll) return fail_ps(DFM_ERR_UNSUPPORTED, "too many points");
+    const size_t esz = d->dtype == DFM_BF16 ? 2 : 4;
+    const size_t feat_stride = (size_t)g.num_views * g.num_frames * g.Hf * g.Wf * g.C * esz;
+    const size_t out_stride = (size_t)g.N * g.C * (g.aggregate ? g.num_frames : 1) * esz;
+    for (int b0 = 0; b0 < batch; b0 += MV_MAX_BATCH) {
+        const int nbatch = std::min(MV_MAX_BATCH, batch - b0);
+        MvBatch mb;
+        for (int i = 0; i < nbatch; ++i) {
+            const dfm_mv_desc &e = descs[b0 + i];
+            mb.scale_x[i] = e.scale_x; mb.scale_y[i] = e.scale_y; mb.crop_x[i] = e.crop_x; mb.crop_y[i] = e.crop_y;
+            mb.pad_h[i] = e.pad_h; mb.pad_w[i] = e.pad_w; mb.flip[i] = e.flip;
+        }
+        mb.points_stride = points_per_sample ? (long long)g.N * 3 : 0;
+        const dim3 grid((unsigned)nb, nbatch);
+        const uint4 *fp = (const uint4 *)((const char *)feats + b0 * feat_stride);
+        const float *pp = points + (size_t)b0 * mb.points_stride;
+        const float *pj = proj + (size_t)b0 * g.num_views * g.num_frames * 16;
+        const float *owp = ori_w + (size_t)b0 * g.num_views * g.num_frames;
+        void *op = (char *)out + b0 * out_stride;
+        unsigned char *vp = valid_out ? valid_out + (size_t)b0 * g.N : nullptr;
+#define MV_CL_LAUNCH(T, LPV) \
+        hipLaunchKernelGGL((mv_sample_cl_kernel<T, LPV>), grid, dim3(256), 0, st, g, mb, fp, pp, pj, owp, (T *)op, vp)
+        if (d->dtype == DFM_BF16) {
+            if (nblk == 4) MV_CL_LAUNCH(bf16_t, 4); else if (nblk == 8) MV_CL_LAUNCH(bf16_t, 8); else MV_CL_LAUNCH(bf16_t, 16);
+        } else {
+            if (nblk == 4) MV_CL_LAUNCH(float, 4); else if (nblk == 8) MV_CL_LAUNCH(float, 8); else MV_CL_LAUNCH(float, 16);
+        }
+#undef MV_CL_LAUNCH
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_ps(DFM_ERR_HIP, hipGetErrorString(e));

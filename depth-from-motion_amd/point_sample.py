@@ -157,7 +157,18 @@ class _MvFn(torch.autograd.Function):
         nbytes = lib.dfm_point_sample_mv_workspace_bytes(ctypes.byref(d0))
         ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
-            for b in range(B):
+            # the whole batch in one launch when the lanes-per-voxel kernel covers the call (channels-last
+            # views and volume, nearest sampling); DFM_ERR_UNSUPPORTED: one launch per sample below
+            rc = _capi.DFM_ERR_UNSUPPORTED
+            if d0.feats_channels_last and d0.mode == 0 and d0.valid_sample and \
+                    (nxyz is None or channels_last) and proj.is_contiguous() and ori_w.is_contiguous():
+                arr = (_capi.MvDesc * B)(*descs)
+                rc = lib.dfm_point_sample_mv_fwd_batched(
+                    arr, B, _ptr(feats), _ptr(points), 1 if points.dim() == 3 else 0, _ptr(proj), _ptr(ori_w),
+                    _ptr(out), _ptr(valid) if want_valid else None, _stream_ptr(device))
+                if rc not in (0, _capi.DFM_ERR_UNSUPPORTED):
+                    _capi.check(rc)
+            for b in range(B if rc != 0 else 0):
                 _capi.check(
                     lib.dfm_point_sample_mv_fwd(ctypes.byref(descs[b]), _ptr(feats[b]),
                                                 _ptr(points[b] if points.dim() == 3 else points),

@@ -304,6 +304,17 @@ DFM_API int dfm_point_sample_mv_fwd(const dfm_mv_desc *desc, const void *feats,
                                     const float *points, const float *proj, const float *ori_w,
                                     void *out, unsigned char *valid, void *workspace,
                                     size_t workspace_bytes, void *stream);
+/* The whole batch in ONE launch (the multi-view configs' channels-last path): descs[batch] differ only in
+ * their image transform (scale / crop / flip / pad); feats (batch, F*Nv, feat_h, feat_w, C) channels-last
+ * views sampled in place, proj (batch, F*Nv, 16), ori_w (batch, F*Nv), out (batch, num_points, C*F') rows
+ * = a (batch, C*F', nx, ny, nz) channels_last_3d volume, valid (batch, num_points) or NULL;
+ * points (num_points, 3) shared (points_per_sample = 0) or (batch, num_points, 3).  Several lanes per
+ * voxel: contiguous tap loads and row stores.  Covers nearest sampling with valid_sample semantics and
+ * 4 / 8 / 16 16-byte channel blocks (C = 64 bf16: 8); DFM_ERR_UNSUPPORTED otherwise -- call
+ * dfm_point_sample_mv_fwd per sample.  Bit-identical results. */
+DFM_API int dfm_point_sample_mv_fwd_batched(const dfm_mv_desc *descs, int32_t batch, const void *feats,
+                                            const float *points, int32_t points_per_sample, const float *proj,
+                                            const float *ori_w, void *out, unsigned char *valid, void *stream);
 /* Backward w.r.t. the view features.  grad_out has the layout of `out`;
  * grad_feats (F*Nv, C, feat_h, feat_w) is FP32, zero-filled by the caller. */
 /* workspace (optional): >= dfm_point_sample_mv_bwd_workspace_bytes(desc) bytes for the

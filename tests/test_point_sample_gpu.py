@@ -269,3 +269,52 @@ def test_mv_channels_last_view_features_are_sampled_in_place(pkg, dtype):
     ya.backward(go)
     yb.backward(go)
     torch.testing.assert_close(a.grad.float(), b.grad.float(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('C,dtype,nv,nf,agg', [(64, torch.bfloat16, 5, 2, 'concat'), (64, torch.bfloat16, 5, 1, 'mean'),
+                                               (32, torch.bfloat16, 5, 3, 'mean'), (64, torch.float32, 5, 2, 'mean'),
+                                               (16, torch.float32, 3, 2, 'concat')])
+def test_batched_lanes_per_voxel_kernel_is_bit_identical_to_the_per_sample_kernel(pkg, C, dtype, nv, nf, agg):
+    """channels-last views -> channels-last volume: ``dfm_point_sample_mv_fwd_batched`` (several lanes
+    per voxel, the whole batch in one launch, per-sample image transforms from a by-value table)
+    against the lane-per-voxel kernel launched per sample on NCHW views (the path the reference
+    fixtures pin bit-exactly above)"""
+    import sys
+    sys.path.insert(0, util.GOLDEN)
+    try:
+        import make_golden as g1
+    finally:
+        sys.path.remove(util.GOLDEN)
+    B, hf, wf = 3, 26, 39
+    gen = torch.Generator().manual_seed(C + nv * nf)
+    feats = torch.randn(B, nv * nf, C, hf, wf, generator=gen).cuda().to(dtype)
+    feats_cl = feats.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+    metas = []
+    for b in range(B):
+        meta = {'ori_lidar2img': [m for m in g1.waymo_like_cameras(nv, nf, 50 + b)], 'input_shape': (104, 156),
+                'img_shape': [(100, 150, 3)] * (nv * nf)}
+        if b == 1:
+            meta.update(scale_factor=np.array([0.95, 1.05, 0.95, 1.05], np.float32), flip=True,
+                        img_crop_offset=np.array([3.0, 2.0], np.float32))
+        if b == 2:
+            meta.update(img_crop_offset=np.array([1.0, 0.0], np.float32))
+        metas.append(meta)
+    vr, nvox = [-11.0, -15.0, -3.0, 11.0, 15.0, 3.0], [22, 30, 12]
+    want = pkg.mv_feature_transformation(feats, metas, nv, nf, vr, nvox, agg)
+    calls = []
+    lib = pkg._capi.lib()
+    real = lib.dfm_point_sample_mv_fwd_batched
+
+    class Spy:
+        def __call__(self, *a):
+            rc = real(*a)
+            calls.append(rc)
+            return rc
+    lib.dfm_point_sample_mv_fwd_batched = Spy()
+    try:
+        got = pkg.mv_feature_transformation(feats_cl, metas, nv, nf, vr, nvox, agg, memory_format=torch.channels_last_3d)
+    finally:
+        lib.dfm_point_sample_mv_fwd_batched = real
+    assert calls == [0], 'the batched kernel took the call'
+    assert got.is_contiguous(memory_format=torch.channels_last_3d) and got.shape == want.shape
+    assert torch.equal(got.contiguous(), want)
