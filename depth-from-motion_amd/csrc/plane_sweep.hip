@@ -823,6 +823,7 @@ __host__ __device__ constexpr int bwd_groups(int half) { return half ? 4 : 2; }
 struct BwdGrid {
     int batch, bands, band_pts, planes, dchunks, rows;
     int ablate;  // debug builds only (DFM_BWD_ABLATE): 1 no gradient loads, 2 no slab atomics, 4 no flush
+    int grad_cl;  // 1: the gradient volume is stored channels-last, (B, D, h, w, 2C) (torch channels_last_3d)
     int row_tiles;  // 0: bands are runs of band_pts points of the flat (h, w) index;
                     // > 0 (strided sweeps): that many bands per lattice row, none crossing rows --
                     // consecutive lattice rows sample feature rows `cost_sample_factor` apart,
@@ -995,12 +996,20 @@ __global__ __launch_bounds__(BWD_PTS * bwd_groups(HALF)) void sweep_bwd_tile_ker
     __syncthreads();
     const int nwin = __builtin_amdgcn_readfirstlane(wins[0]);
 
-    const T *go = gout + ((size_t)b * 2 * g.C + (size_t)HALF * g.C) * g.N + (size_t)d_lo * hw + min(idx, p_hi - 1);
+    // element strides of the gradient volume: the reference layout (B, 2C, D, h, w), or channels-last
+    // (B, D, h, w, 2C) -- what the NDHWC aggregation stack's backward hands over (read in place: the
+    // 236 MB layout conversion at config K cost 2.2 ms per training step, and a lane's CW channels of a
+    // (plane, point) are then adjacent)
+    const size_t s_chan = tg.grad_cl ? (size_t)1 : (size_t)g.N;
+    const size_t s_plane = tg.grad_cl ? (size_t)hw * 2 * g.C : (size_t)hw;
+    const size_t s_point = tg.grad_cl ? (size_t)2 * g.C : (size_t)1;
+    const T *go = gout + (size_t)b * 2 * g.C * g.N + (size_t)HALF * g.C * s_chan + (size_t)d_lo * s_plane +
+                  (size_t)min(idx, p_hi - 1) * s_point;
     float *gf = (HALF ? gprev : gcur) + (size_t)b * g.C * HW;
 
     for (int c0 = 0; c0 < g.C; c0 += CW) {
         const int nc = min(CW, g.C - c0);
-        const T *gp = go + (size_t)c0 * g.N;
+        const T *gp = go + (size_t)c0 * s_chan;
         float fx_scale = 1.0f, fx_inv = 1.0f;
         bool plain = false;  // Inf / NaN in this pass (window): plain float atomics
         int y0 = -1, top = -1;
@@ -1030,7 +1039,7 @@ __global__ __launch_bounds__(BWD_PTS * bwd_groups(HALF)) void sweep_bwd_tile_ker
             for (int k = 0; k < VB; ++k) {
                 const int p = min(grp + (k0 + k) * BWD_GROUPS, np - 1);
 #pragma unroll
-                for (int c = 0; c < CW; ++c) gv[k][c] = gp[(size_t)p * hw + (size_t)min(c, nc - 1) * g.N];
+                for (int c = 0; c < CW; ++c) gv[k][c] = gp[(size_t)p * s_plane + (size_t)min(c, nc - 1) * s_chan];
             }
 #pragma unroll
             for (int k = 0; k < VB; ++k) {
@@ -1838,11 +1847,100 @@ DFM_API int dfm_plane_sweep_bwd(const dfm_sweep_desc *desc, const void *grad_out
                                     grad_prev, stream, nullptr);
 }
 
+}  // extern "C"
+namespace {
+int sweep_bwd_impl(const dfm_sweep_desc *desc, const void *grad_out, const float *depths, const float *cam2img,
+                   const float *cam2img_inv, const float *cur2prev, float *grad_cur, float *grad_prev, void *stream,
+                   const dfm_sweep_opts *opts, bool grad_cl);
+
+// (n, P, C) pixel-major -> (n, C, P) planar: 64 pixels x 8 16-byte channel pieces per workgroup through an
+// LDS tile; 16-byte loads along the channels of a pixel, 16-byte stores along the pixels of a channel.
+// C and P are whole 16-byte runs (checked by the caller).  grid = (ceil(P / 64), ceil(C / (8 * VEC)), n)
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_pixel_major_kernel(const T *__restrict__ src, T *__restrict__ dst,
+                                                                 int C, long long P)
+{
+    constexpr int VEC = 16 / sizeof(T);   // elements per 16-byte piece
+    constexpr int TC = 8 * VEC;           // channels per tile
+    constexpr int PITCH = 64 + VEC;       // tile row: 64 pixels (+ one piece: rows stay 16-byte aligned)
+    __shared__ __attribute__((aligned(16))) T tile[TC * PITCH];
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * TC;
+    const size_t n = blockIdx.z;
+    const T *s = src + n * (size_t)P * C;
+    T *d = dst + n * (size_t)C * P;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = threadIdx.x + 256 * k;          // piece: pixel q / 8, channel piece q % 8
+        const int p = q >> 3, cp = q & 7;
+        if (p0 + p < P && c0 + cp * VEC < C) {
+            const uint4 v = *(const uint4 *)(s + (size_t)(p0 + p) * C + c0 + cp * VEC);
+            T e[VEC];
+            __builtin_memcpy(e, &v, 16);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) tile[(cp * VEC + j) * PITCH + p] = e[j];
+        }
+    }
+    __syncthreads();
+    constexpr int PPR = 64 / VEC;  // 16-byte pieces per tile row
+#pragma unroll
+    for (int k = 0; k < (TC * PPR) / 256; ++k) {
+        const int q = threadIdx.x + 256 * k;
+        const int c = q / PPR, pp = (q % PPR) * VEC;
+        if (c0 + c < C && p0 + pp < P)
+            *(uint4 *)(d + (size_t)(c0 + c) * P + p0 + pp) = *(const uint4 *)(tile + c * PITCH + pp);
+    }
+}
+}
+extern "C" {
 DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *grad_out,
                                      const float *depths, const float *cam2img,
                                      const float *cam2img_inv, const float *cur2prev,
                                      float *grad_cur, float *grad_prev, void *stream,
                                      const dfm_sweep_opts *opts)
+{
+    return sweep_bwd_impl(desc, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_cur, grad_prev, stream, opts,
+                          false);
+}
+
+DFM_API int dfm_plane_sweep_bwd_channels_last(const dfm_sweep_desc *desc, const void *grad_out,
+                                              const float *depths, const float *cam2img,
+                                              const float *cam2img_inv, const float *cur2prev,
+                                              float *grad_cur, float *grad_prev, void *workspace,
+                                              size_t workspace_bytes, void *stream)
+{
+    int rc = check_desc(desc);
+    if (rc != DFM_OK) return rc;
+    if (!grad_out) return fail(DFM_ERR_INVALID_ARG, "NULL device pointer%s");
+    const size_t esz = desc->dtype == DFM_BF16 ? 2 : 4;
+    const long long P = (long long)desc->num_depths * desc->h_out * desc->w_out;
+    const int C2 = 2 * desc->channels, vec = (int)(16 / esz);
+    const size_t vol = (size_t)desc->batch * C2 * P * esz;
+    if (workspace && workspace_bytes >= vol && C2 % vec == 0 && P % vec == 0 && !((uintptr_t)grad_out & 15) &&
+        !((uintptr_t)workspace & 15) && desc->batch <= 65535) {
+        // (B, P, 2C) -> (B, 2C, P) through an LDS tile at copy speed, then the backward on the reference
+        // layout: its lanes are consecutive lattice points, which the planar layout serves with one
+        // coalesced load per (plane, channel); read in place, a wave's 2-byte loads land 4C bytes apart
+        // and every channel pass re-fetches the lines (config K: 2.2 ms instead of 1.2 ms)
+        const dim3 grid((unsigned)((P + 63) / 64), (unsigned)((C2 + 8 * vec - 1) / (8 * vec)), desc->batch);
+        if (desc->dtype == DFM_BF16)
+            hipLaunchKernelGGL(unpack_pixel_major_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream,
+                               (const bf16_t *)grad_out, (bf16_t *)workspace, C2, P);
+        else
+            hipLaunchKernelGGL(unpack_pixel_major_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream,
+                               (const float *)grad_out, (float *)workspace, C2, P);
+        HIP_TRY(hipGetLastError());
+        return sweep_bwd_impl(desc, workspace, depths, cam2img, cam2img_inv, cur2prev, grad_cur, grad_prev, stream,
+                              nullptr, false);
+    }
+    return sweep_bwd_impl(desc, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_cur, grad_prev, stream,
+                          nullptr, true);
+}
+}  // extern "C"
+namespace {
+int sweep_bwd_impl(const dfm_sweep_desc *desc, const void *grad_out, const float *depths, const float *cam2img,
+                   const float *cam2img_inv, const float *cur2prev, float *grad_cur, float *grad_prev, void *stream,
+                   const dfm_sweep_opts *opts, bool grad_cl)
 {
     const bool force_scatter = opts && opts->kernel == 1;
     int rc = check_desc(desc);
@@ -1887,6 +1985,7 @@ DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *gra
         tg.bands = tg.row_tiles ? g.h_out * tg.row_tiles : (int)((hw + tg.band_pts - 1) / tg.band_pts);
         tg.planes = planes;
         tg.ablate = 0;
+        tg.grad_cl = grad_cl ? 1 : 0;
 #ifdef DFM_DEBUG_HOOKS
         {
             const char *ab = getenv("DFM_BWD_ABLATE");
@@ -1926,6 +2025,8 @@ DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *gra
         HIP_TRY(hipGetLastError());
         return DFM_OK;
     }
+    if (grad_cl)  // the scatter kernel reads the reference layout only: the caller converts and calls dfm_plane_sweep_bwd
+        return fail(DFM_ERR_UNSUPPORTED, "channels-last gradient: the LDS-tile backward does not take this shape%s");
     const long long nb = (g.N + 255) / 256;
     if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
     dim3 grid((unsigned)nb, desc->batch);
@@ -1940,6 +2041,8 @@ DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *gra
     HIP_TRY(hipGetLastError());
     return DFM_OK;
 }
+}  // namespace
+extern "C" {
 
 DFM_API int dfm_plane_sweep_grid(const dfm_sweep_desc *desc, int32_t b, const float *depths,
                                  const float *cam2img, const float *cam2img_inv,

@@ -240,6 +240,17 @@ DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *gra
                                      const float *cam2img_inv, const float *cur2prev,
                                      float *grad_cur, float *grad_prev, void *stream,
                                      const dfm_sweep_opts *opts);
+/* The same backward with the gradient volume stored channels-last, (B, D, h_out, w_out, 2C) in memory
+ * (torch channels_last_3d: what the NDHWC aggregation stack's backward hands over).  With a workspace
+ * of the volume's size (16-byte aligned) the gradient is first re-laid (B, 2C, D, h, w) by an LDS-tile
+ * transpose at copy speed; workspace == NULL: read in place (no extra memory, slower: the lanes of the
+ * backward are lattice points).  DFM_ERR_UNSUPPORTED when neither applies (convert and call
+ * dfm_plane_sweep_bwd). */
+DFM_API int dfm_plane_sweep_bwd_channels_last(const dfm_sweep_desc *desc, const void *grad_out,
+                                              const float *depths, const float *cam2img,
+                                              const float *cam2img_inv, const float *cur2prev,
+                                              float *grad_cur, float *grad_prev, void *workspace,
+                                              size_t workspace_bytes, void *stream);
 /* Times the candidate launch shapes / workgroup orders of the LDS-staged kernel with the caller's
  * own arguments (a few launches per candidate; SYNCHRONOUS, `out` is overwritten with valid
  * results) and caches the fastest for this (device, problem shape); later dfm_plane_sweep_fwd

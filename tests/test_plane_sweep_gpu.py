@@ -418,3 +418,46 @@ def test_type_and_shape_errors(pkg):
         pkg.build_dfm_cost(x, x.bfloat16(), torch.ones(3), 1, 1, eye, eye, (8, 8))
     with pytest.raises(AssertionError):
         pkg.build_dfm_cost(x, x[:, :2], torch.ones(3), 1, 1, eye, eye, (8, 8))
+
+
+@pytest.mark.parametrize('in_place', [False, True])
+@pytest.mark.parametrize('shape,fsf,csf,D,dtype', [((2, 32, 24, 78), 16, 1, 9, torch.bfloat16),
+                                                 ((1, 32, 64, 256), 1, 4, 30, torch.bfloat16),
+                                                 ((1, 8, 48, 160), 1, 4, 5, torch.float32)])
+def test_channels_last_gradient_without_a_torch_layout_conversion(pkg, shape, fsf, csf, D, dtype, in_place):
+    """the NDHWC stack hands the cost volume's gradient over channels-last:
+    ``dfm_plane_sweep_bwd_channels_last`` re-lays it with the library's LDS-tile transpose (workspace
+    given) or reads it where it lies (``in_place``: no workspace) -- same gradients as from the
+    reference layout, and the library entry point really took the call"""
+    dev = torch.device('cuda:0')
+    g0 = torch.Generator().manual_seed(shape[1] + D)
+    c = torch.randn(*shape, generator=g0).to(dev).to(dtype).requires_grad_(True)
+    p = torch.randn(*shape, generator=g0).to(dev).to(dtype).requires_grad_(True)
+    B = shape[0]
+    args = (torch.from_numpy(util.depth_planes(D)).to(dev), fsf, csf, torch.from_numpy(np.stack([util.KITTI_P2] * B)),
+            torch.from_numpy(util.random_poses(B, seed=3)), (375, 1242))
+    out = pkg.build_dfm_cost(c, p, *args, memory_format=torch.channels_last_3d)
+    g = torch.randn(out.shape, generator=g0).to(dev).to(dtype)
+    lib = pkg._capi.lib()
+    real, calls = lib.dfm_plane_sweep_bwd_channels_last, []
+
+    class Spy:
+        def __call__(self, *a):
+            a = list(a)
+            if in_place:
+                a[8], a[9] = None, 0   # no workspace: the strided read
+            else:
+                assert a[8] is not None and a[9] == g.numel() * g.element_size()
+            calls.append(real(*a))
+            return calls[-1]
+    lib.dfm_plane_sweep_bwd_channels_last = Spy()
+    try:
+        out.backward(g.contiguous(memory_format=torch.channels_last_3d))
+    finally:
+        lib.dfm_plane_sweep_bwd_channels_last = real
+    assert calls == [0]
+    gc, gp = c.grad.float().clone(), p.grad.float().clone()
+    c.grad = p.grad = None
+    pkg.build_dfm_cost(c, p, *args).backward(g)   # reference layout
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    assert torch.allclose(gc, c.grad.float(), **tol) and torch.allclose(gp, p.grad.float(), **tol)
