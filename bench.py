@@ -509,16 +509,26 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
     # path sustains ~4.1 TB/s for this store stream and 1.40-1.47k on the others (profiles/r02_c44_*):
     # a ~20 ms fill probe of the output buffer makes the bench line explain itself
     torch.cuda.synchronize()
-    pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    out.zero_()
-    pe0.record()
-    for _ in range(3):
-        out.zero_()
-    pe1.record()
-    torch.cuda.synchronize()
-    fill_gbps = 3 * out.numel() * out.element_size() / (pe0.elapsed_time(pe1) * 1e-3) / 1e9
-    part = {'fill_probe_gbps': round(fill_gbps, 1), 'class': 'fast' if fill_gbps >= 4800.0 else 'slow',
-            'note': 'hipMemset-style fill of the output buffer; parts below ~4.8 TB/s cap the sweep near 0.50 of the roofline'}
+    plane_bytes = w['D'] * desc.h_out * desc.w_out * elem
+    part = None
+    if not args.channels_last and plane_bytes % 16 == 0:
+        def probe(fn):
+            pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn()
+            pe0.record()
+            for _ in range(3):
+                fn()
+            pe1.record()
+            torch.cuda.synchronize()
+            return 3 * out.numel() * out.element_size() / (pe0.elapsed_time(pe1) * 1e-3) / 1e9
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        tile_gbps = probe(lambda: pkg._capi.check(lib.dfm_store_probe(
+            ctypes.c_void_p(out.data_ptr()), B, 2 * w['C'], plane_bytes, 0, 0, st)))
+        part = {'tile_store_probe_gbps': round(tile_gbps, 1), 'linear_fill_gbps': round(probe(out.zero_), 1),
+                'class': 'fast' if tile_gbps >= 4800.0 else 'slow',
+                'note': "zeros written in the tile kernel's store pattern (one 4 KiB run per channel plane per "
+                        'workgroup, dfm_store_probe) and as a linear fill; parts whose tile-pattern rate is '
+                        'below ~4.8 TB/s cap the sweep near 0.50 of the roofline'}
     if explicit or args.channels_last or args.no_autotune or w.get('nhwc'):
         os.environ['DFM_AUTOTUNE'] = '0'  # keep the first launch from tuning by itself
     for _ in range(args.warmup):

@@ -1832,6 +1832,45 @@ DFM_API int dfm_plane_sweep_tuning(const dfm_sweep_desc *desc, dfm_sweep_opts *o
     return 1;
 }
 
+// Which part did the process land on?  The tile kernel's store stream -- every workgroup writes a 4 KiB
+// run into each of the 2C channel planes of a sample, planes D*h*w elements apart -- sustains 5.1-5.3 TB/s
+// on most MI355X parts and ~3.9-4.1 TB/s on others (same binary, same clocks; a linear fill runs at
+// 6.8 TB/s on both: profiles/r03_c17_*).  This probe writes zeros in exactly that pattern so that a
+// bench line can say which kind of part produced it.  `out` is overwritten with zeros.
+__global__ __launch_bounds__(256) void store_probe_kernel(uint4 *__restrict__ out, long long plane_vec,
+                                                          long long runs_per_plane, int planes, int pieces, int group)
+{
+    // block = (run, plane group, sample), run fastest: `pieces` x (256 lanes x 16 B = 4 KiB) contiguous per
+    // plane; walks the `group` planes of its plane group (group == planes: the tile kernel's pattern)
+    typedef unsigned int probe_u32x4 __attribute__((ext_vector_type(4)));
+    const long long run = blockIdx.x % runs_per_plane;
+    const int pg = (int)(blockIdx.x / runs_per_plane);
+    probe_u32x4 *p = (probe_u32x4 *)out + ((size_t)blockIdx.y * planes + (size_t)pg * group) * plane_vec +
+                     run * 256 * pieces + threadIdx.x;
+    const probe_u32x4 z = {0u, 0u, 0u, 0u};
+    const int n = min(group, planes - pg * group);
+    for (int c = 0; c < n; ++c)
+        for (int k = 0; k < pieces; ++k) __builtin_nontemporal_store(z, p + (size_t)c * plane_vec + k * 256);
+}
+
+DFM_API int dfm_store_probe(void *out, int32_t batch, int32_t planes, int64_t plane_bytes, int32_t run_bytes,
+                            int32_t planes_per_workgroup, void *stream)
+{
+    if (!out || batch <= 0 || planes <= 0 || plane_bytes < 4096 || ((uintptr_t)out & 15) || (plane_bytes & 15))
+        return fail(DFM_ERR_INVALID_ARG, "store probe: aligned buffer of batch x planes x plane_bytes%s");
+    const int pieces = run_bytes > 0 ? run_bytes / 4096 : 1;  // 0: the tile kernel's 4 KiB runs
+    if (pieces < 1 || pieces * 4096 != (run_bytes > 0 ? run_bytes : 4096) || plane_bytes < 4096ll * pieces)
+        return fail(DFM_ERR_INVALID_ARG, "store probe: run_bytes must be a multiple of 4096%s");
+    const int group = planes_per_workgroup > 0 ? std::min(planes_per_workgroup, planes) : planes;  // 0: all planes
+    const long long plane_vec = plane_bytes / 16, runs = plane_vec / (256 * pieces);  // (a plane's tail is skipped)
+    const long long nblk = runs * ((planes + group - 1) / group);
+    if (nblk > 2147483647ll || batch > 65535) return fail(DFM_ERR_UNSUPPORTED, "store probe: grid too large%s");
+    hipLaunchKernelGGL(store_probe_kernel, dim3((unsigned)nblk, batch), dim3(256), 0, (hipStream_t)stream,
+                       (uint4 *)out, plane_vec, runs, planes, pieces, group);
+    HIP_TRY(hipGetLastError());
+    return DFM_OK;
+}
+
 DFM_API void dfm_plane_sweep_reset_tuning(void)
 {
     std::lock_guard<std::mutex> lk(g_tune_mu);

@@ -263,6 +263,13 @@ DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur
 /* The cached choice for desc's shape on the current device: returns 1 and fills *opts, or 0
  * (nothing cached; *opts zeroed = defaults), or a negative dfm_status. */
 DFM_API int dfm_plane_sweep_tuning(const dfm_sweep_desc *desc, dfm_sweep_opts *opts);
+/* Measurement aid (bench.py): writes zeros into `out` (batch x planes x plane_bytes, 16-byte aligned) in
+ * the tile kernel's store pattern -- one run of run_bytes (0 = the kernel's 4 KiB; multiples of 4096) per
+ * plane per workgroup, a workgroup walking planes_per_workgroup planes (0 = all: the tile kernel) -- so a
+ * bench line can record what this part sustains for that stream (parts differ by ~25 % on it while a
+ * linear fill does not). */
+DFM_API int dfm_store_probe(void *out, int32_t batch, int32_t planes, int64_t plane_bytes, int32_t run_bytes,
+                            int32_t planes_per_workgroup, void *stream);
 DFM_API void dfm_plane_sweep_reset_tuning(void);
 
 /* ---------------------------------------------------------------------- */
