@@ -46,6 +46,11 @@ CASES = {
     'flip_crop_scale': (1, (48, 160), 1, 4, 5, True, (7, 55), 0.97, util.pose(0.4, 0.0, 0.0, -0.5), (2, 59.6), 2),
     'nstar_like_fsf4': (1, (22, 70), 4, 1, 6, False, (0, 0), 1.0, util.pose(2.0, 0.1, -0.02, -1.4), (2, 59.6), 1),
     'behind_camera': (1, (40, 132), 1, 4, 6, False, (0, 0), 1.0, util.pose(5.0, 0.3, 0.0, -9.0), (2, 20.0), 0),
+    # a single depth plane (both depth neighbours are the convolution's zero padding), a volume smaller
+    # than one 8 x 32 tile, three samples with one plane per workgroup
+    'one_plane': (1, (32, 96), 1, 4, 1, False, (0, 0), 1.0, util.pose(0.5, 0.02, 0.0, -0.8), (2, 59.6), 0),
+    'two_planes_tiny': (1, (12, 40), 1, 4, 2, False, (0, 0), 1.0, util.pose(0.5, 0.02, 0.0, -0.8), (2, 59.6), 0),
+    'three_samples_chunk1': (3, (32, 132), 1, 4, 4, False, (0, 5), 1.0, util.pose(-1.0, 0.0, 0.0, -1.2), (2, 30.0), 1),
 }
 
 
