@@ -28,6 +28,7 @@ EXPORTS = (
     'dfm_plane_sweep_bwd',
     'dfm_plane_sweep_grid',
     'dfm_plane_sweep_last_kernel',
+    'dfm_plane_sweep_bwd_last_kernel',
     'dfm_plane_sweep_fwd_opts',
     'dfm_plane_sweep_bwd_opts',
     'dfm_plane_sweep_bwd_channels_last',
@@ -246,6 +247,8 @@ def lib():
     h.dfm_plane_sweep_grid.restype = ctypes.c_int
     h.dfm_plane_sweep_grid.argtypes = [dp, i32, fp, fp, fp, fp, fp, fp, vp]
     h.dfm_plane_sweep_last_kernel.restype = ctypes.c_int
+    h.dfm_plane_sweep_bwd_last_kernel.restype = ctypes.c_int
+    h.dfm_plane_sweep_bwd_last_kernel.argtypes = []
     op = ctypes.POINTER(SweepOpts)
     h.dfm_plane_sweep_fwd_opts.restype = ctypes.c_int
     h.dfm_plane_sweep_fwd_opts.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp, op]

@@ -309,6 +309,67 @@ __device__ __forceinline__ void sweep_point_map(const SweepGeom &g, const SweepF
     oy = ((ny + 1.0f) * 0.5f) * hm1;
 }
 
+// ---- backward of the plane sweep: pieces shared by plane_sweep.hip and plane_sweep_bwd_mfma.hip ----
+// packed footprint of one (plane, point): bit 31 valid, 27..30 = wok eok nok sok,
+// 13..25 = ixw + 1, 0..12 = iyn + 1 (corner in [-1, W-1] x [-1, H-1])
+__device__ __forceinline__ uint32_t bwd_footprint(float sx, float sy, int H, int W, float &fw, float &fn)
+{
+    const bool fin = (fabsf(sx) <= 3.0e38f) && (fabsf(sy) <= 3.0e38f);
+    const float xw = floorf(sx), yn = floorf(sy);
+    fw = sx - xw;
+    fn = sy - yn;
+    const bool wok = fin && xw >= 0.0f && xw <= (float)(W - 1);
+    const bool eok = fin && xw >= -1.0f && xw <= (float)(W - 2);
+    const bool nok = fin && yn >= 0.0f && yn <= (float)(H - 1);
+    const bool sok = fin && yn >= -1.0f && yn <= (float)(H - 2);
+    if (!((wok || eok) && (nok || sok))) return 0u;
+    const int ixw = (int)xw, iyn = (int)yn;
+    return 0x80000000u | ((uint32_t)wok << 27) | ((uint32_t)eok << 28) | ((uint32_t)nok << 29) |
+           ((uint32_t)sok << 30) | ((uint32_t)(ixw + 1) << 13) | (uint32_t)(iyn + 1);
+}
+
+// First plane of the "calm tail" of sample b's sweep over map HALF: from there on, consecutive depth
+// planes move the sample positions of the four lattice corners (the extremes of a field that is
+// affine in the lattice position to first order) by at most (thr_x, thr_y) map pixels, and a
+// lattice row is not stretched beyond 1.4 map pixels per point.  The matrix-product backward takes
+// the planes from the split on, the LDS-atomic backward the planes before it; both call THIS
+// function with the same arguments, so they agree bit for bit on who owns a plane.  All threads of
+// the workgroup call it (`slot` is an LDS word; two barriers inside).
+template <int HALF>
+__device__ __forceinline__ int sweep_calm_split(const SweepGeom &g, const SweepFast &f, const float *__restrict__ P,
+                                                const float *__restrict__ Pinv, const float *__restrict__ Tm,
+                                                const float *__restrict__ depths, float thr_x, float thr_y, int tid,
+                                                int nthreads, int *slot)
+{
+    if (tid == 0) *slot = 0;
+    __syncthreads();
+    for (int d = tid; d + 1 < g.D; d += nthreads) {
+        bool calm = true;
+        float cx[4], cy[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int hi = (k >> 1) ? g.h_out - 1 : 0, wi = (k & 1) ? g.w_out - 1 : 0;
+            float x1, y1;
+            sweep_point_map<HALF>(g, f, P, Pinv, Tm, depths[d], hi, wi, cx[k], cy[k]);
+            sweep_point_map<HALF>(g, f, P, Pinv, Tm, depths[d + 1], hi, wi, x1, y1);
+            calm = calm && fabsf(x1 - cx[k]) <= thr_x && fabsf(y1 - cy[k]) <= thr_y;  // false for NaN
+        }
+        const float sx = 1.4f * (float)(g.w_out - 1) + 2.0f, sy = 1.4f * (float)(g.h_out - 1) + 2.0f;
+        calm = calm && fabsf(cx[1] - cx[0]) <= sx && fabsf(cx[3] - cx[2]) <= sx && fabsf(cy[2] - cy[0]) <= sy &&
+               fabsf(cy[3] - cy[1]) <= sy;
+        if (!calm) atomicMax(slot, d + 1);
+    }
+    __syncthreads();
+    return *slot;
+}
+
+// host side, defined in plane_sweep.hip / plane_sweep_bwd_mfma.hip
+SweepFast sweep_make_fast(const dfm_sweep_desc *d);
+bool sweep_bwd_mfma_supported(const dfm_sweep_desc *d, const void *grad_out);
+int sweep_bwd_mfma_launch(const dfm_sweep_desc *d, int half, const void *grad_out, const float *depths,
+                          const float *P, const float *Pinv, const float *Tm, float *grad_cur, float *grad_prev,
+                          float thr_x, float thr_y, void *stream);
+
 // Bilinear footprint of one sample point: top-left integer corner, the four
 // corner weights (ATen compute_interp_params) and per-corner in-bounds bits.
 struct Tap {

@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -35,6 +36,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local int g_last_kernel = 0;
+std::atomic<int> g_last_bwd_kernel{0};  // process-wide: autograd runs the backward on its own thread
 #ifdef DFM_DEBUG_HOOKS
 unsigned long long *g_trace = nullptr;  // debug builds only: see dfm_debug_set_trace
 #endif
@@ -828,25 +830,9 @@ struct BwdGrid {
                     // > 0 (strided sweeps): that many bands per lattice row, none crossing rows --
                     // consecutive lattice rows sample feature rows `cost_sample_factor` apart,
                     // which one slab window cannot hold
+    int split;      // 1: only the planes before sweep_calm_split (the matrix-product backward takes the rest)
+    float thr_x, thr_y;
 };
-
-// packed footprint of one (plane, point): bit 31 valid, 27..30 = wok eok nok sok,
-// 13..25 = ixw + 1, 0..12 = iyn + 1 (corner in [-1, W-1] x [-1, H-1])
-__device__ __forceinline__ uint32_t bwd_footprint(float sx, float sy, int H, int W, float &fw, float &fn)
-{
-    const bool fin = (fabsf(sx) <= 3.0e38f) && (fabsf(sy) <= 3.0e38f);
-    const float xw = floorf(sx), yn = floorf(sy);
-    fw = sx - xw;
-    fn = sy - yn;
-    const bool wok = fin && xw >= 0.0f && xw <= (float)(W - 1);
-    const bool eok = fin && xw >= -1.0f && xw <= (float)(W - 2);
-    const bool nok = fin && yn >= 0.0f && yn <= (float)(H - 1);
-    const bool sok = fin && yn >= -1.0f && yn <= (float)(H - 2);
-    if (!((wok || eok) && (nok || sok))) return 0u;
-    const int ixw = (int)xw, iyn = (int)yn;
-    return 0x80000000u | ((uint32_t)wok << 27) | ((uint32_t)eok << 28) | ((uint32_t)nok << 29) |
-           ((uint32_t)sok << 30) | ((uint32_t)(ixw + 1) << 13) | (uint32_t)(iyn + 1);
-}
 
 // float -> 64-bit two's-complement fixed point (|x| < 2^61 after scaling): high word =
 // floor(x / 2^32), low word = x - high * 2^32, which the fma delivers exactly except for a negative
@@ -904,14 +890,21 @@ __global__ __launch_bounds__(BWD_PTS * bwd_groups(HALF)) void sweep_bwd_tile_ker
         p_lo = row * g.w_out + t * tg.band_pts;
         p_hi = min(p_lo + tg.band_pts, (row + 1) * g.w_out);
     }
-    const int d_lo = dchunk * tg.planes, d_hi = min(d_lo + tg.planes, g.D);
+    const int d_lo = dchunk * tg.planes;
+    int d_hi = min(d_lo + tg.planes, g.D);
+    const float *Pb = P + b * 16, *Pib = Pinv + b * 16, *Tb = Tm + b * 16;
+    if (tg.split) {  // workgroup-uniform
+        d_hi = min(d_hi, sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, threadIdx.x,
+                                                BWD_PTS * BWD_GROUPS, &yr[0]));
+        if (d_hi <= d_lo) return;
+        __syncthreads();  // yr is initialised below
+    }
     const int np = d_hi - d_lo;
     const int rows = tg.rows, slab_c = rows * W;
     // footprint table behind the slab: [plane][point] x {packed, fw, fn}
     uint32_t *fpT = (uint32_t *)(slab + (size_t)CW * slab_c);
     float *fwT = (float *)(fpT + tg.planes * BWD_PTS);
     float *fnT = fwT + tg.planes * BWD_PTS;
-    const float *Pb = P + b * 16, *Pib = Pinv + b * 16, *Tb = Tm + b * 16;
     const int idx = p_lo + pt;
     const bool live = idx < p_hi;
     const int hi = idx / g.w_out, wi = idx - hi * g.w_out;
@@ -1581,6 +1574,7 @@ extern "C" {
 DFM_API int dfm_version(void) { return 2; }
 DFM_API const char *dfm_last_error(void) { return g_err; }
 DFM_API int dfm_plane_sweep_last_kernel(void) { return g_last_kernel; }
+DFM_API int dfm_plane_sweep_bwd_last_kernel(void) { return g_last_bwd_kernel.load(); }
 #ifdef DFM_DEBUG_HOOKS
 // debug builds only (not in dfm_hip.h): device buffer of 64 x u64 per traced workgroup
 DFM_API void dfm_debug_set_trace(void *buf) { g_trace = (unsigned long long *)buf; }
@@ -1624,6 +1618,7 @@ DFM_API int dfm_profile_end(double *total_ms, int *launches)
 // shared with the other translation units
 int dfm::sweep_check_desc(const dfm_sweep_desc *d) { return check_desc(d); }
 dfm::SweepGeom dfm::sweep_make_geom(const dfm_sweep_desc *d) { return make_geom(d); }
+dfm::SweepFast dfm::sweep_make_fast(const dfm_sweep_desc *d) { return make_fast(d); }
 void dfm::sweep_set_last_kernel(int which) { g_last_kernel = which; }
 bool dfm::profile_mark(void *stream, bool stop)
 {
@@ -2035,6 +2030,26 @@ int sweep_bwd_impl(const dfm_sweep_desc *desc, const void *grad_out, const float
         const long long nb = (long long)tg.bands * tg.dchunks * desc->batch;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
         const SweepFast fast = make_fast(desc);
+        // dense bf16 sweeps: the matrix-product backward (plane_sweep_bwd_mfma.hip) takes the cur map
+        // and the calm planes of the prev map; this kernel keeps the prev map's fast-moving planes
+        // (opts->kernel: 5 = never, 6 = whenever it applies [the default])
+        tg.split = 0;
+        tg.thr_x = 1e9f;  // (the zoom test of sweep_calm_split alone decides: drift costs the matrix-product kernel a flush, not more)
+        tg.thr_y = 1e9f;
+#ifdef DFM_DEBUG_HOOKS
+        if (const char *e = getenv("DFM_BWD_THR_X")) tg.thr_x = (float)atof(e);
+        if (const char *e = getenv("DFM_BWD_THR_Y")) tg.thr_y = (float)atof(e);
+#endif
+        const bool mfma = !(opts && opts->kernel == 5) && !grad_cl && sweep_bwd_mfma_supported(desc, grad_out);
+        if (mfma) {
+            tg.split = 1;
+            rc = sweep_bwd_mfma_launch(desc, 0, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_cur, grad_prev,
+                                       tg.thr_x, tg.thr_y, stream);
+            if (rc != DFM_OK) return rc;
+            rc = sweep_bwd_mfma_launch(desc, 1, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_cur, grad_prev,
+                                       tg.thr_x, tg.thr_y, stream);
+            if (rc != DFM_OK) return rc;
+        }
 #define DFM_BWD_LAUNCH(T, CW, HALF, ROWS)                                                            \
     do {                                                                                             \
         tg.rows = (ROWS);                                                                            \
@@ -2056,12 +2071,13 @@ int sweep_bwd_impl(const dfm_sweep_desc *desc, const void *grad_out, const float
             DFM_BWD_HALF(float, 0, cw_cur, rows_cur);
             DFM_BWD_HALF(float, 1, cw_prev, rows_prev);
         } else {
-            DFM_BWD_HALF(bf16_t, 0, cw_cur, rows_cur);
+            if (!mfma) DFM_BWD_HALF(bf16_t, 0, cw_cur, rows_cur);
             DFM_BWD_HALF(bf16_t, 1, cw_prev, rows_prev);
         }
 #undef DFM_BWD_HALF
 #undef DFM_BWD_LAUNCH
         HIP_TRY(hipGetLastError());
+        g_last_bwd_kernel.store(mfma ? 6 : 5);
         return DFM_OK;
     }
     if (grad_cl)  // the scatter kernel reads the reference layout only: the caller converts and calls dfm_plane_sweep_bwd
@@ -2078,6 +2094,7 @@ int sweep_bwd_impl(const dfm_sweep_desc *desc, const void *grad_out, const float
                            (const bf16_t *)grad_out, depths, cam2img, cam2img_inv, cur2prev,
                            grad_cur, grad_prev);
     HIP_TRY(hipGetLastError());
+    g_last_bwd_kernel.store(1);
     return DFM_OK;
 }
 }  // namespace

@@ -169,6 +169,24 @@ def launch_options(**kw):
         _tls.opts = prev
 
 
+_bwd_kernel = None  # process-wide (autograd runs backward functions on its own threads)
+
+
+@contextlib.contextmanager
+def backward_kernel(kernel):
+    """Force the kernel of every plane-sweep BACKWARD launched inside the block, from any thread
+    (``dfm_plane_sweep_bwd_opts``: 1 = lane-per-point scatter, 5 = LDS-atomic tile kernel for both
+    maps, 6 / None = default: the matrix-product kernel where it applies).  ``launch_options`` is
+    thread-local and never reaches the autograd threads."""
+    global _bwd_kernel
+    prev = _bwd_kernel
+    _bwd_kernel = kernel
+    try:
+        yield
+    finally:
+        _bwd_kernel = prev
+
+
 def _current_opts(schedule=None):
     o = getattr(_tls, 'opts', None)
     if schedule:
@@ -301,6 +319,8 @@ class _PlaneSweepFn(torch.autograd.Function):
         g_cur = torch.zeros(shape, dtype=torch.float32, device=device)
         g_prev = torch.zeros(shape, dtype=torch.float32, device=device)
         opts = _current_opts()
+        if _bwd_kernel is not None:
+            opts = make_opts(kernel=_bwd_kernel)
         if (opts is None and not grad_out.is_contiguous() and grad_out.dim() == 5 and
                 grad_out.is_contiguous(memory_format=torch.channels_last_3d)):
             # the NDHWC stack's gradient is read where it lies (the 236 MB conversion to the reference

@@ -186,6 +186,11 @@ DFM_API int dfm_plane_sweep_grid(const dfm_sweep_desc *desc, int32_t b, const fl
  * (+ direct-tap pass over flagged tiles), 3 = tile kernel with direct taps, 4 = pixel-major
  * taps + LDS transpose (strided sweeps).  Thread-local. */
 DFM_API int dfm_plane_sweep_last_kernel(void);
+/* Which kernel the last plane-sweep BACKWARD call of this process launched (process-wide: autograd
+ * runs backward functions on its own threads): 1 = lane-per-point scatter, 5 = LDS-atomic tile
+ * kernel, 6 = matrix-product kernel (dense bf16 sweeps; the tile kernel keeps the prev map's
+ * fast-moving near planes). */
+DFM_API int dfm_plane_sweep_bwd_last_kernel(void);
 
 /*
  * Launch options of ONE call (the library keeps no process-wide launch state).  Every field:
@@ -235,6 +240,10 @@ DFM_API int dfm_plane_sweep_fwd_opts(const dfm_sweep_desc *desc, const void *cur
                                      const float *cam2img_inv, const float *cur2prev, void *out,
                                      void *workspace, size_t workspace_bytes, void *stream,
                                      const dfm_sweep_opts *opts);
+/* Backward with options: only `kernel` is read -- 1 = lane-per-point scatter kernel, 5 = LDS-atomic
+ * tile kernel for both maps, 0 / 6 = default (dense bf16 sweeps with w_out >= 32, h_out >= 2: the
+ * matrix-product kernel of plane_sweep_bwd_mfma.hip, whose weights are rounded to bf16 like the
+ * gradients; everything else: the tile kernel, fp32 weights). */
 DFM_API int dfm_plane_sweep_bwd_opts(const dfm_sweep_desc *desc, const void *grad_out,
                                      const float *depths, const float *cam2img,
                                      const float *cam2img_inv, const float *cur2prev,

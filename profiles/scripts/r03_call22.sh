@@ -1,0 +1,37 @@
+#!/bin/bash
+# round 3, call 22: matrix-product backward -- parity tests, kernel statistics of the backward bench at
+# several split thresholds and with parts of the kernel switched off (debug build)
+O=gpurun_out/r03c22; mkdir -p $O
+timeout 900 python -m pytest tests/test_sweep_bwd_mfma_gpu.py -q 2>&1 | grep -v "^$" | grep -n "^E  \|passed\|failed\|^FAILED" > $O/tests.txt
+head -40 $O/tests.txt
+R=$PWD
+stats() {  # name, env...
+  name=$1; shift
+  rm -rf /tmp/prof_$name
+  (cd /tmp && export TMPDIR=/tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python $R/bench.py --workload sweep_bwd --steps 4 --warmup 1 > /tmp/bench_$name.txt 2>&1)
+  python - "$name" >> $O/kernel_ms.txt <<'PY'
+import csv, glob, sys
+name = sys.argv[1]
+f = glob.glob(f'/tmp/prof_{name}/**/*kernel_stats.csv', recursive=True)
+out = [name]
+if f:
+    for r in csv.DictReader(open(f[0])):
+        n = r['Name']
+        if 'sweep_bwd' in n:
+            tag = 'mfma_cur' if 'mfma_kernel<0>' in n else 'mfma_prev' if 'mfma_kernel<1>' in n else 'tile_cur' if ', 0>' in n else 'tile_prev'
+            out.append(f"{tag} {float(r['AverageNs'])/1e6:.3f} ms")
+print('  '.join(out))
+PY
+}
+rm -f $O/kernel_ms.txt
+stats release
+D=DFM_HIP_LIB=$R/depth-from-motion_amd/lib/libdfm_hip_dbg.so
+stats dbg $D
+stats thr_4_1 $D DFM_BWD_THR_X=4 DFM_BWD_THR_Y=1
+stats thr_05_015 $D DFM_BWD_THR_X=0.5 DFM_BWD_THR_Y=0.15
+stats thr_inf $D DFM_BWD_THR_X=1e9 DFM_BWD_THR_Y=1e9
+stats noload $D DFM_BWD_ABLATE=16
+stats nomfma $D DFM_BWD_ABLATE=32
+stats noflush $D DFM_BWD_ABLATE=64
+stats noload_nomfma $D DFM_BWD_ABLATE=48
+cat $O/kernel_ms.txt

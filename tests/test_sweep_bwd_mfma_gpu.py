@@ -1,0 +1,182 @@
+"""Backward of dense bf16 plane sweeps through the matrix-product kernel
+(csrc/plane_sweep_bwd_mfma.hip) -- autograd of F.grid_sample in build_dfm_cost, reference
+dfm_backbone.py:296-311.
+
+Checked against (a) torch's CPU fp32 grid_sample autograd on the oracle's grids and (b) the
+LDS-atomic tile kernel (fp32 weights, ``kernel=5``) on the same inputs.  Tolerance: the kernel
+rounds the bilinear weights to bf16 like the gradient values it multiplies them with, so an output
+is a sum of terms with 2^-9 relative error each: |err| <= 2^-8 * sum |w * g| is the hard bound,
+the tests ask for 2^-7 * the map's RMS-level magnitude plus rtol 1e-2."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dfm_oracle as orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU (no fallback path exists)'
+    p = importlib.import_module('depth-from-motion_amd')
+    assert os.path.exists(p._capi.LIB_PATH)
+    return p
+
+
+def _run(pkg, cur, prev, depths, fsf, P, T, img_shape, flip, crop, scale, gout, kernel=None):
+    ps = pkg.plane_sweep
+    dev = torch.device('cuda:0')
+    c = torch.from_numpy(cur).to(dev).to(torch.bfloat16).requires_grad_(True)
+    p = torch.from_numpy(prev).to(dev).to(torch.bfloat16).requires_grad_(True)
+    out = pkg.build_dfm_cost(c, p, torch.from_numpy(depths).to(dev), fsf, 1, torch.from_numpy(P),
+                             torch.from_numpy(T), img_shape, flip, crop, scale)
+    g = gout if torch.is_tensor(gout) else torch.from_numpy(gout).to(dev).to(torch.bfloat16)
+    if kernel is None:
+        out.backward(g)
+    else:
+        with ps.backward_kernel(kernel):
+            out.backward(g)
+    torch.cuda.synchronize()
+    which = pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel()
+    return c.grad.float(), p.grad.float(), which
+
+
+def _case(B, C, H, W, D, fsf, crop=(0, 0), flip=False, scale=1.0, seed=0, img_shape=None, t_z=None,
+          poses='random'):
+    rng = np.random.RandomState(seed)
+    cur = rng.randn(B, C, H, W).astype(np.float32)
+    prev = rng.randn(B, C, H, W).astype(np.float32)
+    P = np.stack([util.KITTI_P2] * B)
+    T = util.random_poses(B, seed=seed + 4)
+    if t_z is not None:
+        T[:, 2, 3] = t_z
+    depths = util.depth_planes(D)
+    gout = orc.bf16_round(rng.randn(B, 2 * C, D, H, W).astype(np.float32))
+    img_shape = img_shape or (H * fsf, W * fsf)
+    return dict(cur=cur, prev=prev, depths=depths, fsf=fsf, P=P, T=T, img_shape=img_shape, flip=flip,
+                crop=crop, scale=scale, gout=gout)
+
+
+def _reference(k, b):
+    """torch CPU fp32 autograd through grid_sample on the oracle's grids, sample b"""
+    H, W = k['cur'].shape[2:]
+    D = len(k['depths'])
+    C = k['cur'].shape[1]
+    Pinv = util.host_inverse(k['P'])
+    prm = orc.sweep_params(H, W, D, k['fsf'], 1, k['P'][b], Pinv[b], k['T'][b], k['img_shape'], k['flip'],
+                           k['crop'], k['scale'])
+    cg, pg = orc.plane_sweep_grid(prm, k['depths'])
+    refs = []
+    for feats, grid, sl in ((k['cur'], cg, slice(0, C)), (k['prev'], pg, slice(C, 2 * C))):
+        f = torch.from_numpy(feats[b:b + 1]).requires_grad_(True)
+        o = torch.nn.functional.grid_sample(f, torch.from_numpy(grid).view(1, 1, -1, 2), mode='bilinear',
+                                            padding_mode='zeros', align_corners=True)
+        o.backward(torch.from_numpy(k['gout'][b:b + 1, sl]).reshape(o.shape))
+        refs.append(f.grad[0].numpy())
+    return refs
+
+
+def _close(got, ref, what):
+    scale = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))) + 1e-30
+    err = np.abs(got - ref)
+    bound = 2.0 ** -7 * scale + 1e-2 * np.abs(ref)
+    bad = err > bound
+    assert not bad.any(), f'{what}: {int(bad.sum())} of {bad.size} off, max err {err.max():.4g} at rms {scale:.4g}'
+
+
+CASES = {
+    # 40 channels: a full and a quarter-filled 32-channel wave
+    'c40': dict(B=2, C=40, H=24, W=96, D=9, fsf=4, seed=1),
+    # odd sizes: rows start on odd elements (unaligned 16-byte runs), shifted last tiles, odd planes
+    'odd_deep': dict(B=1, C=3, H=37, W=53, D=41, fsf=4, seed=3),
+    # augmented geometry
+    'flip_scale_crop': dict(B=1, C=16, H=24, W=96, D=6, fsf=4, crop=(11, 5), flip=True, scale=1.03, seed=5,
+                            img_shape=(96, 384)),
+    # strong forward motion: fast near planes (the tile kernel's share) and a calm tail
+    'forward_motion': dict(B=1, C=8, H=30, W=128, D=40, fsf=4, seed=7, t_z=-1.9),
+    # exactly one tile wide
+    'one_tile': dict(B=1, C=16, H=4, W=32, D=5, fsf=4, seed=9),
+    # more than 128 channels: two workgroups per tile
+    'c160': dict(B=1, C=160, H=8, W=40, D=4, fsf=4, seed=11),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_matrix_product_backward_matches_torch_and_tile_kernel(pkg, name):
+    k = _case(**CASES[name])
+    gc, gp, which = _run(pkg, **k)
+    assert which == 6, 'the matrix-product backward did not take this problem'
+    tc, tp, which5 = _run(pkg, kernel=5, **k)
+    assert which5 == 5
+    for b in range(k['cur'].shape[0]):
+        rc, rp = _reference(k, b)
+        assert np.abs(rc).max() > 0.1 and np.abs(rp).max() > 0.1
+        _close(gc[b].cpu().numpy(), rc, f'{name} cur vs torch, sample {b}')
+        _close(gp[b].cpu().numpy(), rp, f'{name} prev vs torch, sample {b}')
+    _close(gc.cpu().numpy(), tc.cpu().numpy(), f'{name} cur vs tile kernel')
+    _close(gp.cpu().numpy(), tp.cpu().numpy(), f'{name} prev vs tile kernel')
+
+
+def test_cur_map_weights_are_exact_in_bf16(pkg):
+    """an un-augmented cur map is sampled at its own pixels (weights 1 - eps and eps): rounding the
+    weights to bf16 changes nothing beyond eps; the two kernels agree to the last bf16 bit or two of
+    the returned gradient (fp32 sums in different orders, one bf16 rounding)"""
+    k = _case(B=1, C=32, H=16, W=64, D=12, fsf=4, seed=2)
+    gc, _, which = _run(pkg, **k)
+    tc, _, _ = _run(pkg, kernel=5, **k)
+    assert which == 6
+    assert torch.allclose(gc, tc, rtol=2.0 ** -7, atol=1e-3)
+    assert float((gc != tc).float().mean()) < 0.05
+
+
+def _torch_reference_nonfinite(k, g):
+    """CPU autograd with the poisoned gradient volume (float32 copy of the bf16 values)"""
+    kk = dict(k, gout=g.float().cpu().numpy())
+    return _reference(kk, 0)
+
+
+def test_nonfinite_gradients_reach_their_four_taps_only(pkg):
+    """0 * Inf in a matrix product would smear NaN over the accumulator window; the kernel redoes
+    such a window value by value, so exactly torch's pixels are poisoned (the four in-bounds taps of
+    the poisoned point, zero-weight taps included)"""
+    k = _case(B=1, C=16, H=12, W=40, D=5, fsf=4, seed=4)
+    for poison in (float('inf'), float('nan')):
+        g = torch.from_numpy(k['gout']).cuda().to(torch.bfloat16)
+        g[0, 3, 1, 5, 7] = poison
+        g[0, 16 + 9, 4, 6, 20] = poison
+        kk = dict(k, gout=g)
+        gc, gp, which = _run(pkg, **kk)
+        assert which == 6
+        rc, rp = _torch_reference_nonfinite(k, g)
+        for a, r, what in ((gc[0].cpu().numpy(), rc, 'cur'), (gp[0].cpu().numpy(), rp, 'prev')):
+            assert not np.isfinite(r).all(), what
+            assert np.array_equal(np.isfinite(a), np.isfinite(r)), what
+            assert np.array_equal(np.isnan(a), np.isnan(r)), what
+            m = np.isfinite(r)
+            _close(a[m], r[m], what + ': finite part')
+
+
+def test_zero_gradient_and_scale_invariance(pkg):
+    k = _case(B=1, C=8, H=12, W=40, D=3, fsf=4, seed=6)
+    z = dict(k, gout=np.zeros_like(k['gout']))
+    gc, gp, _ = _run(pkg, **z)
+    assert float(gc.abs().max()) == 0.0 and float(gp.abs().max()) == 0.0
+    a, b, _ = _run(pkg, **k)
+    for s in (2.0 ** -60, 2.0 ** 40):  # exact in bf16 and fp32: no fixed-point scale to lose bits
+        a2, b2, _ = _run(pkg, **dict(k, gout=k['gout'] * np.float32(s)))
+        assert torch.equal(a2 / s, a) and torch.equal(b2 / s, b)
+
+
+def test_north_star_geometry_slice(pkg):
+    """the bench's own geometry (94 x 311 maps, 112 planes, its poses), 32 of the 256 channels"""
+    k = _case(B=1, C=32, H=94, W=311, D=112, fsf=4, seed=8, img_shape=(376, 1244), t_z=-1.2)
+    gc, gp, which = _run(pkg, **k)
+    assert which == 6
+    tc, tp, _ = _run(pkg, kernel=5, **k)
+    _close(gc.cpu().numpy(), tc.cpu().numpy(), 'cur vs tile kernel')
+    _close(gp.cpu().numpy(), tp.cpu().numpy(), 'prev vs tile kernel')
