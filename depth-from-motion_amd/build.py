@@ -73,5 +73,27 @@ def build_hip(force=False, verbose=False, debug_hooks=False, out=None, jobs=None
     return out
 
 
+def build_variant(tag, extra_flags, only):
+    """lib/libdfm_hip_<tag>.so: the release objects with the translation units named in ``only``
+    (file names under csrc/) recompiled with ``extra_flags`` -- experiments at release speed, e.g.
+    ``build_variant('noload', ['-DDFM_BM_ABLATE=1'], ['plane_sweep_bwd_mfma.hip'])``."""
+    build_hip()
+    obj_dir = os.path.join(LIB_DIR, 'obj_' + tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = FLAGS + list(extra_flags) + ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+    objs = []
+    for src in sources():
+        base = os.path.splitext(os.path.basename(src))[0] + '.o'
+        if os.path.basename(src) in only:
+            obj = os.path.join(obj_dir, base)
+            subprocess.check_call([HIPCC] + flags + ['-c', src, '-o', obj])
+        else:
+            obj = os.path.join(LIB_DIR, 'obj', base)
+        objs.append(obj)
+    out = os.path.join(LIB_DIR, 'libdfm_hip_%s.so' % tag)
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out])
+    return out
+
+
 if __name__ == '__main__':
     print(build_hip(force=True, verbose=True))

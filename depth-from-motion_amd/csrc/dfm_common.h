@@ -331,15 +331,15 @@ __device__ __forceinline__ uint32_t bwd_footprint(float sx, float sy, int H, int
 // First plane of the "calm tail" of sample b's sweep over map HALF: from there on, consecutive depth
 // planes move the sample positions of the four lattice corners (the extremes of a field that is
 // affine in the lattice position to first order) by at most (thr_x, thr_y) map pixels, and a
-// lattice row is not stretched beyond 1.4 map pixels per point.  The matrix-product backward takes
+// lattice row / column is not stretched beyond `zoom` map pixels per point.  The matrix-product backward takes
 // the planes from the split on, the LDS-atomic backward the planes before it; both call THIS
 // function with the same arguments, so they agree bit for bit on who owns a plane.  All threads of
 // the workgroup call it (`slot` is an LDS word; two barriers inside).
 template <int HALF>
 __device__ __forceinline__ int sweep_calm_split(const SweepGeom &g, const SweepFast &f, const float *__restrict__ P,
                                                 const float *__restrict__ Pinv, const float *__restrict__ Tm,
-                                                const float *__restrict__ depths, float thr_x, float thr_y, int tid,
-                                                int nthreads, int *slot)
+                                                const float *__restrict__ depths, float thr_x, float thr_y, float zoom,
+                                                int tid, int nthreads, int *slot)
 {
     if (tid == 0) *slot = 0;
     __syncthreads();
@@ -354,7 +354,7 @@ __device__ __forceinline__ int sweep_calm_split(const SweepGeom &g, const SweepF
             sweep_point_map<HALF>(g, f, P, Pinv, Tm, depths[d + 1], hi, wi, x1, y1);
             calm = calm && fabsf(x1 - cx[k]) <= thr_x && fabsf(y1 - cy[k]) <= thr_y;  // false for NaN
         }
-        const float sx = 1.4f * (float)(g.w_out - 1) + 2.0f, sy = 1.4f * (float)(g.h_out - 1) + 2.0f;
+        const float sx = zoom * (float)(g.w_out - 1) + 2.0f, sy = zoom * (float)(g.h_out - 1) + 2.0f;
         calm = calm && fabsf(cx[1] - cx[0]) <= sx && fabsf(cx[3] - cx[2]) <= sx && fabsf(cy[2] - cy[0]) <= sy &&
                fabsf(cy[3] - cy[1]) <= sy;
         if (!calm) atomicMax(slot, d + 1);
@@ -369,6 +369,12 @@ bool sweep_bwd_mfma_supported(const dfm_sweep_desc *d, const void *grad_out);
 int sweep_bwd_mfma_launch(const dfm_sweep_desc *d, int half, const void *grad_out, const float *depths,
                           const float *P, const float *Pinv, const float *Tm, float *grad_cur, float *grad_prev,
                           float thr_x, float thr_y, void *stream);
+// zoom (map pixels per lattice point) up to which the matrix-product backward takes a plane of the prev
+// map: whole 32-point segments up to SWEEP_BWD_ZOOM_ONE, in two 16-point passes up to
+// SWEEP_BWD_ZOOM_TWO, in four 8-point passes up to SWEEP_BWD_ZOOM_FOUR (its accumulator window is 48
+// columns x 6 rows); beyond that the LDS-atomic tile kernel (the two kernels split the planes by
+// sweep_calm_split with SWEEP_BWD_ZOOM_FOUR)
+constexpr float SWEEP_BWD_ZOOM_ONE = 1.4f, SWEEP_BWD_ZOOM_TWO = 2.75f, SWEEP_BWD_ZOOM_FOUR = 3.9f;
 
 // Bilinear footprint of one sample point: top-left integer corner, the four
 // corner weights (ATen compute_interp_params) and per-corner in-bounds bits.

@@ -894,7 +894,7 @@ __global__ __launch_bounds__(BWD_PTS * bwd_groups(HALF)) void sweep_bwd_tile_ker
     int d_hi = min(d_lo + tg.planes, g.D);
     const float *Pb = P + b * 16, *Pib = Pinv + b * 16, *Tb = Tm + b * 16;
     if (tg.split) {  // workgroup-uniform
-        d_hi = min(d_hi, sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, threadIdx.x,
+        d_hi = min(d_hi, sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, SWEEP_BWD_ZOOM_FOUR, threadIdx.x,
                                                 BWD_PTS * BWD_GROUPS, &yr[0]));
         if (d_hi <= d_lo) return;
         __syncthreads();  // yr is initialised below

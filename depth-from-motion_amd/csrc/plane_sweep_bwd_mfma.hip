@@ -51,12 +51,12 @@ constexpr int BM_SLOTS = 3; // image rows one lattice row may touch in one plane
 constexpr int BM_FRAG = 1024;                                  // bytes of one B fragment (64 lanes x 16)
 constexpr int BM_IMG = BM_TH * BM_SLOTS * BM_NT * BM_FRAG;     // fragment image of one plane: 18 KB
 constexpr int BM_WAVES = 4;                                    // waves per tile, at most
-constexpr int BM_CHUNK = 28;                                   // planes per footprint table
+constexpr int BM_RING = 3;                                     // planes of footprints ahead of the image
 // LDS of one tile (a workgroup holds two neighbouring tiles)
 constexpr int BM_OFF_TAPS = 2 * BM_IMG;                        // [2][64][4] u16 element offsets of the written weights
-constexpr int BM_OFF_TABLE = BM_OFF_TAPS + 2 * 64 * 4 * 2;     // [3][BM_CHUNK][64] packed footprint, fw, fn
-constexpr int BM_OFF_EXT = BM_OFF_TABLE + 3 * BM_CHUNK * 64 * 4;  // [BM_CHUNK][8] extents
-constexpr int BM_OFF_META = BM_OFF_EXT + BM_CHUNK * 8 * 4;     // [32] ints
+constexpr int BM_OFF_TABLE = BM_OFF_TAPS + 2 * 64 * 4 * 2;     // [3][BM_RING][64] packed footprint, fw, fn
+constexpr int BM_OFF_EXT = BM_OFF_TABLE + 3 * BM_RING * 64 * 4;  // [BM_RING][8] extents
+constexpr int BM_OFF_META = BM_OFF_EXT + BM_RING * 8 * 4;      // [32] ints
 constexpr int BM_TILE_LDS = BM_OFF_META + 32 * 4;
 constexpr int BM_LDS = 2 * BM_TILE_LDS;
 
@@ -73,7 +73,10 @@ struct BmGrid {
     unsigned long long *trace;  // debug builds (dfm_debug_set_bm_trace): cycles per phase of workgroup 0's waves
 };
 
-#ifdef DFM_DEBUG_HOOKS
+#ifdef DFM_BM_ABLATE  // experiments at release speed: -DDFM_BM_ABLATE=<mask> (1 no gradient loads, 2 no MFMA, 4 no flush, 8 no producer)
+#define BM_AB(bit) (((DFM_BM_ABLATE) & (bit)) != 0)
+#define BM_STAMP(i) do { } while (0)
+#elif defined(DFM_DEBUG_HOOKS)
 #define BM_AB(bit) ((tg.ablate & (bit)) != 0)
 // cycles since the previous stamp are added to phase i of this wave
 #define BM_STAMP(i)                                                                       \
@@ -175,14 +178,14 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
     unsigned char *img = lds;                                       // [2][BM_IMG]
     unsigned short *taps = (unsigned short *)(lds + BM_OFF_TAPS);
     uint32_t *tab_f = (uint32_t *)(lds + BM_OFF_TABLE);
-    float *tab_w = (float *)(tab_f + BM_CHUNK * 64), *tab_n = tab_w + BM_CHUNK * 64;
+    float *tab_w = (float *)(tab_f + BM_RING * 64), *tab_n = tab_w + BM_RING * 64;
     int *ext = (int *)(lds + BM_OFF_EXT);
     int *meta = (int *)(lds + BM_OFF_META);
 
     // consecutive work items (neighbouring tile pairs of one lattice row pair) on one XCD
     const int work = (blockIdx.x & 7) * tg.per_xcd + (blockIdx.x >> 3);
     if (work >= tg.total) return;
-#ifdef DFM_DEBUG_HOOKS
+#if defined(DFM_DEBUG_HOOKS) && !defined(DFM_BM_ABLATE)
     unsigned long long tsum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
     int t = work;
@@ -208,52 +211,69 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
     for (int i = wave * 64 + lane; i < 2 * 64 * 4; i += 64 * nw) taps[i] = 0xffffu;
     if (wave == 0 && lane < 32) meta[lane] = 0;
     __syncthreads();
-    int d_start = 0;
+    // planes [0, d_start): the tile kernel (zoom beyond SWEEP_BWD_ZOOM_FOUR); [d_start, d_four): four
+    // steps each, 8 of a segment's 32 points at a time; [d_four, d_two): two steps of 16 points (a whole
+    // segment zoomed beyond SWEEP_BWD_ZOOM_ONE is wider than the accumulator window); the rest: one step
+    int d_start = 0, d_four = 0, d_two = 0;
     if (HALF) {
-        d_start = sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, tid, 2 * 64 * nw,
-                                         (int *)(lds_all + BM_OFF_META) + 31);
+        int *slot = (int *)(lds_all + BM_OFF_META) + 31;
+        d_start = sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, SWEEP_BWD_ZOOM_FOUR, tid,
+                                         2 * 64 * nw, slot);
         if (d_start >= g.D) return;
+        __syncthreads();
+        d_four = max(d_start, sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, SWEEP_BWD_ZOOM_TWO,
+                                                     tid, 2 * 64 * nw, slot));
+        __syncthreads();
+        d_two = max(d_four, sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, SWEEP_BWD_ZOOM_ONE,
+                                                   tid, 2 * 64 * nw, slot));
     }
+    const int n4 = d_four - d_start, n2 = d_two - d_four, nsteps = 4 * n4 + 2 * n2 + (g.D - d_two);
+    auto step_plane = [&](int t) -> int {
+        return t < 4 * n4 ? d_start + (t >> 2) : t < 4 * n4 + 2 * n2 ? d_four + ((t - 4 * n4) >> 1) : d_two + (t - 4 * n4 - 2 * n2);
+    };
+    // which of a segment's four 8-point groups step t takes: bit i = group i
+    auto step_groups = [&](int t) -> unsigned {
+        return t < 4 * n4 ? 1u << (t & 3) : t < 4 * n4 + 2 * n2 ? 3u << (2 * ((t - 4 * n4) & 1)) : 15u;
+    };
 
-    // ---- footprints of the tile's 64 points (one per lane) in the planes [t0, t0 + BM_CHUNK): all
-    //      waves of the tile, a plane each; extents of the plane's in-bounds taps next to them ------
-    auto fill_table = [&](int t0) {
+    // ---- footprints of the tile's 64 points (one per lane) for step t, two steps ahead of the image
+    //      that needs them (ring of BM_RING steps); extents of the in-bounds taps next to them ------
+    auto fill_step = [&](int t) {
         const int lane = opaque(tid) & 63, phh = lane >> 5, pk = lane & 31, ph = h0 + phh, pw = w0 + pk;
-        const bool p_own = tile_live && ph >= own_h && pw >= own_w;
-        for (int p = wave; p < BM_CHUNK && t0 + p < g.D; p += nw) {
-            float sx, sy, fw = 0.0f, fn = 0.0f;
-            uint32_t f = 0u;
-            if (p_own) {
-                sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depths[t0 + p], ph, pw, sx, sy);
-                f = bwd_footprint(sx, sy, H, W, fw, fn);
-            }
-            tab_f[p * 64 + lane] = f;
-            tab_w[p * 64 + lane] = fw;
-            tab_n[p * 64 + lane] = fn;
-            const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
-            const bool wok = f & (1u << 27), eok = f & (1u << 28), nok = f & (1u << 29), sok = f & (1u << 30);
-            const int big = 0x3fffffff;
-            int xlo = half_wave_reduce(f ? (wok ? ixw : ixw + 1) : big, OpMin());
-            int xhi = half_wave_reduce(f ? (eok ? ixw + 1 : ixw) : -big, OpMax());
-            const int ylo = half_wave_reduce(f ? (nok ? iyn : iyn + 1) : big, OpMin());
-            const int yhi = half_wave_reduce(f ? (sok ? iyn + 1 : iyn) : -big, OpMax());
-            // lanes 31 / 63 hold the extents of lattice row 0 / 1
-            if ((lane & 31) == 31) {
-                int *e = ext + p * 8 + 4 * phh;
-                e[0] = xlo;
-                e[1] = xhi;
-                e[2] = ylo;
-                e[3] = yhi;
-            }
+        const bool p_own = tile_live && ph >= own_h && pw >= own_w && ((step_groups(t) >> (pk >> 3)) & 1u);
+        const int p = t % BM_RING;
+        float sx, sy, fw = 0.0f, fn = 0.0f;
+        uint32_t f = 0u;
+        if (p_own) {
+            sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depths[step_plane(t)], ph, pw, sx, sy);
+            f = bwd_footprint(sx, sy, H, W, fw, fn);
+        }
+        tab_f[p * 64 + lane] = f;
+        tab_w[p * 64 + lane] = fw;
+        tab_n[p * 64 + lane] = fn;
+        const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
+        const bool wok = f & (1u << 27), eok = f & (1u << 28), nok = f & (1u << 29), sok = f & (1u << 30);
+        const int big = 0x3fffffff;
+        const int xlo = half_wave_reduce(f ? (wok ? ixw : ixw + 1) : big, OpMin());
+        const int xhi = half_wave_reduce(f ? (eok ? ixw + 1 : ixw) : -big, OpMax());
+        const int ylo = half_wave_reduce(f ? (nok ? iyn : iyn + 1) : big, OpMin());
+        const int yhi = half_wave_reduce(f ? (sok ? iyn + 1 : iyn) : -big, OpMax());
+        // lanes 31 / 63 hold the extents of lattice row 0 / 1
+        if ((lane & 31) == 31) {
+            int *e = ext + p * 8 + 4 * phh;
+            e[0] = xlo;
+            e[1] = xhi;
+            e[2] = ylo;
+            e[3] = yhi;
         }
     };
 
-    // ---- the fragment image of plane d from the table: one lattice point per lane -------------
-    auto produce = [&](int d, int t0, int buf) {
+    // ---- the fragment image of step t from its footprints: one lattice point per lane ----------
+    auto produce = [&](int t, int buf) {
         const int lane = opaque(tid) & 63, phh = lane >> 5, pk = lane & 31;
         unsigned short *img16 = (unsigned short *)(img + buf * BM_IMG);
         unsigned short *tl = taps + (buf * 64 + lane) * 4;
-        const int p = d - t0;
+        const int p = t % BM_RING;
         const uint32_t f = tab_f[p * 64 + lane];
         const float fw = tab_w[p * 64 + lane], fn = tab_n[p * 64 + lane];
         const int *e = ext + p * 8;
@@ -352,12 +372,14 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
     };
     zero_acc();
 
-    // per-value path (plain float atomics, torch's semantics for Inf / NaN): planes [da, db) of this
+    // per-value path (plain float atomics, torch's semantics for Inf / NaN): steps [ta, tb) of this
     // wave's channels
-    auto slow_planes = [&](int da, int db) {
+    auto slow_steps = [&](int ta, int tb) {
         if (!wave_live) return;
         const int l_ = opaque(lane), ac = l_ & 15, akg = l_ >> 4;
-        for (int d = da; d < db; ++d) {
+        for (int t = ta; t < tb; ++t) {
+            const int d = step_plane(t);
+            if (!((step_groups(t) >> akg) & 1u)) continue;  // this lane's 8 points belong to another step
             const float depth = depths[d];
             for (int hh = 0; hh < BM_TH; ++hh)
                 for (int j = 0; j < 8; ++j) {
@@ -389,9 +411,9 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
     };
 
     unsigned touched = 0u;  // (row, column block) pairs written since the last flush
-    int epoch_start = d_start;
-    auto flush = [&](int xb, int yb, int d_end) {
-        if (!wave_live || !touched) { touched = 0u; epoch_start = d_end; return; }
+    int epoch_start = 0;  // first step accumulated since the last flush
+    auto flush = [&](int xb, int yb, int t_end) {
+        if (!wave_live || !touched) { touched = 0u; epoch_start = t_end; return; }
         bool bad = false;
 #pragma unroll
         for (int mt = 0; mt < BM_MT; ++mt)
@@ -403,7 +425,7 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
                     for (int j = 0; j < 4; ++j)
                         bad |= (__float_as_uint(acc[mt][r][nt][j]) & 0x7f800000u) == 0x7f800000u;
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
-            slow_planes(epoch_start, d_end);
+            slow_steps(epoch_start, t_end);
         } else if (!BM_AB(4)) {
             const int l_ = opaque(lane), ac = l_ & 15, akg = l_ >> 4;
 #pragma unroll
@@ -425,34 +447,31 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
         }
         zero_acc();
         touched = 0u;
-        epoch_start = d_end;
+        epoch_start = t_end;
     };
 
-    int t0 = d_start;  // first plane of the footprint table
-    fill_table(t0);
+    // prologue: footprints of the first two steps, the first step's image and gradient words
+    for (int t = wave; t < min(2, nsteps); t += nw) fill_step(t);
     ARaw raw[BM_MT][BM_TH];
 #pragma unroll
     for (int mt = 0; mt < BM_MT; ++mt)
 #pragma unroll
         for (int hh = 0; hh < BM_TH; ++hh) raw[mt][hh] = ARaw{u32x4_t{0u, 0u, 0u, 0u}, 0u};
-    if (wave_live) load_plane(d_start, raw);
+    if (wave_live) load_plane(step_plane(0), raw);
     bm_barrier();
-    if (wave == 0) produce(d_start, t0, d_start & 1);
+    if (wave == 0) produce(0, 0);
     bm_barrier();
     int xb = 0, yb = 0;
-    for (int d = d_start; d < g.D; ++d) {
-        const int buf = d & 1;
+    for (int t = 0; t < nsteps; ++t) {
+        const int buf = t & 1, d = step_plane(t);
         BM_STAMP(0);  // loop overhead
-        if (d + 1 < g.D && d + 1 == t0 + BM_CHUNK) {  // the next plane opens a new table (workgroup-uniform)
-            t0 += BM_CHUNK;
-            fill_table(t0);
-            bm_barrier();
-        }
-        BM_STAMP(8);  // footprint table
-        // (the producer's registers come and go before the consumer's fragments are live)
-        if (d + 1 < g.D && wave == ((d + 1) % nw) && !BM_AB(8)) produce(d + 1, t0, buf ^ 1);
-        BM_STAMP(1);  // produce
-        // this plane's A fragments out of the raw words, then the next plane's loads into them
+        // one wave: footprints of step t + 2; another: the image of step t + 1 (their registers come
+        // and go before the consumer's fragments are live)
+        if (t + 2 < nsteps && wave == ((t + 2) % nw) && !BM_AB(8)) fill_step(t + 2);
+        BM_STAMP(8);  // footprints
+        if (t + 1 < nsteps && wave == ((t + 1) % nw) && !BM_AB(8)) produce(t + 1, buf ^ 1);
+        BM_STAMP(1);  // image
+        // this step's A fragments out of the raw words, then the next step's loads into them
         bf16x8_t a[BM_MT][BM_TH];
         if (wave_live) {
             const int l_ = opaque(lane);
@@ -462,9 +481,9 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
                 for (int hh = 0; hh < BM_TH; ++hh)
                     a[mt][hh] = a_frag(raw[mt][hh], ((uintptr_t)a_addr(l_, d, mt, hh) & 2) != 0,
                                        c0 + mt * 16 + (l_ & 15) >= g.C);
-            load_plane(d + 1, raw);
+            load_plane(step_plane(min(t + 1, nsteps - 1)), raw);
         }
-        BM_STAMP(2);  // wait for this plane's gradient words, issue the next plane's
+        BM_STAMP(2);  // wait for this step's gradient words, issue the next step's
         const int flags = __builtin_amdgcn_readfirstlane(meta[buf * 8 + BM_M_FLAGS]);
         const int nxb = __builtin_amdgcn_readfirstlane(meta[buf * 8 + BM_M_XB]);
         const int nyb = __builtin_amdgcn_readfirstlane(meta[buf * 8 + BM_M_YB]);
@@ -473,13 +492,13 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
         const int row0 = __builtin_amdgcn_readfirstlane(meta[buf * 8 + BM_M_ROW]);
         const int row1 = __builtin_amdgcn_readfirstlane(meta[buf * 8 + BM_M_ROW + 1]);
         BM_STAMP(3);  // meta
-        if (flags & BM_FLUSH) flush(xb, yb, d);
+        if (flags & BM_FLUSH) flush(xb, yb, t);
         BM_STAMP(4);  // flush
         xb = nxb;
         yb = nyb;
         if (flags & BM_SLOW) {
-            slow_planes(d, d + 1);
-            epoch_start = d + 1;
+            slow_steps(t, t + 1);
+            epoch_start = t + 1;
         } else if (!(flags & BM_EMPTY) && wave_live && !BM_AB(2)) {
             const unsigned char *im = img + buf * BM_IMG + opaque(lane) * 16;
 #pragma unroll
@@ -507,9 +526,9 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
         bm_barrier();
         BM_STAMP(6);  // barrier
     }
-    flush(xb, yb, g.D);
+    flush(xb, yb, nsteps);
     BM_STAMP(7);
-#ifdef DFM_DEBUG_HOOKS
+#if defined(DFM_DEBUG_HOOKS) && !defined(DFM_BM_ABLATE)
     if (tg.trace && work == 0 && lane == 0 && sel == 0)
         for (int i = 0; i < 12; ++i) tg.trace[wave * 12 + i] = tsum[i];
 #endif
