@@ -524,7 +524,15 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         tile_gbps = probe(lambda: pkg._capi.check(lib.dfm_store_probe(
             ctypes.c_void_p(out.data_ptr()), B, 2 * w['C'], plane_bytes, 0, 0, st)))
+        # shader clock under a VALU load on every CU (dfm_clock_probe): the store probe alone does not single
+        # out the parts that run the same binary 25 % slower at a normal store rate (profiles/r03_c38_*)
+        clk = torch.zeros(3, dtype=torch.int64, device=dev)
+        pkg._capi.check(lib.dfm_clock_probe(ctypes.c_void_p(clk.data_ptr()), 1 << 18, st))
+        torch.cuda.synchronize()
+        cyc, ref = (int(v) for v in clk[:2].tolist())
+        ghz = cyc / max(ref, 1) / 10.0
         part = {'tile_store_probe_gbps': round(tile_gbps, 1), 'linear_fill_gbps': round(probe(out.zero_), 1),
+                'shader_clock_ghz_under_fma_load': round(ghz, 3),
                 'class': 'fast' if tile_gbps >= 4800.0 else 'slow',
                 'note': "zeros written in the tile kernel's store pattern (one 4 KiB run per channel plane per "
                         'workgroup, dfm_store_probe) and as a linear fill; parts whose tile-pattern rate is '

@@ -36,6 +36,7 @@ EXPORTS = (
     'dfm_plane_sweep_tuning',
     'dfm_plane_sweep_reset_tuning',
     'dfm_store_probe',
+    'dfm_clock_probe',
     'dfm_point_sample_mv_workspace_bytes',
     'dfm_point_sample_mv_fwd',
     'dfm_frustum_to_voxel_workspace_bytes',
@@ -256,6 +257,8 @@ def lib():
     h.dfm_plane_sweep_bwd_opts.argtypes = [dp, vp, fp, fp, fp, fp, fp, fp, vp, op]
     h.dfm_store_probe.restype = ctypes.c_int
     h.dfm_store_probe.argtypes = [vp, i32, i32, ctypes.c_int64, i32, i32, vp]
+    h.dfm_clock_probe.restype = ctypes.c_int
+    h.dfm_clock_probe.argtypes = [vp, i32, vp]
     h.dfm_plane_sweep_bwd_channels_last.restype = ctypes.c_int
     h.dfm_plane_sweep_bwd_channels_last.argtypes = [dp, vp, fp, fp, fp, fp, fp, fp, vp, sz, vp]
     h.dfm_plane_sweep_autotune.restype = ctypes.c_int

@@ -1866,6 +1866,35 @@ DFM_API int dfm_store_probe(void *out, int32_t batch, int32_t planes, int64_t pl
     return DFM_OK;
 }
 
+// the shader clock this part sustains with every CU busy: cycles (s_memtime) and 100 MHz reference
+// ticks (s_memrealtime) across `iterations` dependent FMAs per lane, written by workgroup 0
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long *out, int iterations, float seed)
+{
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    float x0 = seed + threadIdx.x, x1 = seed * 2.0f, x2 = seed * 3.0f, x3 = seed * 4.0f;
+    for (int i = 0; i < iterations; ++i) {
+        x0 = __builtin_fmaf(x0, 0.999f, 0.5f);
+        x1 = __builtin_fmaf(x1, 0.998f, 0.25f);
+        x2 = __builtin_fmaf(x2, 0.997f, 0.125f);
+        x3 = __builtin_fmaf(x3, 0.996f, 0.0625f);
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+    if (x0 + x1 + x2 + x3 == 12345.678f) out[2] = 1;  // keeps the loop
+}
+
+DFM_API int dfm_clock_probe(void *out3, int32_t iterations, void *stream)
+{
+    if (!out3 || iterations <= 0 || ((uintptr_t)out3 & 7)) return fail(DFM_ERR_INVALID_ARG, "clock probe: 3 x u64 device buffer%s");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (unsigned long long *)out3,
+                       iterations, 1.0f);
+    HIP_TRY(hipGetLastError());
+    return DFM_OK;
+}
+
 DFM_API void dfm_plane_sweep_reset_tuning(void)
 {
     std::lock_guard<std::mutex> lk(g_tune_mu);

@@ -279,6 +279,12 @@ DFM_API int dfm_plane_sweep_tuning(const dfm_sweep_desc *desc, dfm_sweep_opts *o
  * linear fill does not). */
 DFM_API int dfm_store_probe(void *out, int32_t batch, int32_t planes, int64_t plane_bytes, int32_t run_bytes,
                             int32_t planes_per_workgroup, void *stream);
+
+/* Part diagnostics (bench.py `part`): every CU runs `iterations` dependent FMAs per lane; out3[0] = shader
+ * clock cycles (s_memtime) and out3[1] = 100 MHz reference ticks (s_memrealtime) that workgroup 0 saw go
+ * by: cycles / ticks / 10 = the shader clock in GHz this part sustains under a VALU load.  out3: 3 x u64
+ * on the device. */
+DFM_API int dfm_clock_probe(void *out3, int32_t iterations, void *stream);
 DFM_API void dfm_plane_sweep_reset_tuning(void);
 
 /* ---------------------------------------------------------------------- */
