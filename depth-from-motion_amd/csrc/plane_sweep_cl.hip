@@ -218,11 +218,14 @@ __global__ __launch_bounds__(256) void sweep_clt_kernel(
     const int qlast = npts - 1;
     constexpr int U = 4;
     const int npass = (g.nblk + BPP - 1) / BPP;
+#ifndef DFM_CLT_ABLATE  // experiments at release speed (build_variant): 1 no cur gather, 2 no prev gather, 4 no stores
+#define DFM_CLT_ABLATE 0
+#endif
     for (int map = 0; map < 2; ++map) {
         const uint4 *mp = map ? prev_maps : cur_maps;
         for (int pass = 0; pass < npass; ++pass) {
             const int blk = pass * BPP + sub;
-            if (blk < g.nblk) {
+            if (blk < g.nblk && !((DFM_CLT_ABLATE >> map) & 1)) {
                 for (int it = 0; it < 64; it += U * PPI) {
                     uint4 tap[U][4];
                     float wgt[U][4];
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void sweep_clt_kernel(
             constexpr int VPR = 256 / VEC;  // vectors per row
             for (int idx = tid; idx < crem * VPR; idx += 256) {
                 const int row = idx / VPR, v = idx - row * VPR;
-                if (v * VEC < npts) {
+                if (v * VEC < npts && !(DFM_CLT_ABLATE & 4)) {
                     const u32x4_t val = *(const u32x4_t *)(tile + row * PITCH + v * VEC);
                     const size_t ch = (size_t)b * 2 * g.C + (size_t)map * g.C + pass * CP + row;
                     __builtin_nontemporal_store(val, (u32x4_t *)(out + (ch * g.D + d) * hw + p0 + v * VEC));
