@@ -328,36 +328,31 @@ __device__ __forceinline__ uint32_t bwd_footprint(float sx, float sy, int H, int
            ((uint32_t)sok << 30) | ((uint32_t)(ixw + 1) << 13) | (uint32_t)(iyn + 1);
 }
 
-// First plane of the "calm tail" of sample b's sweep over map HALF: from there on, consecutive depth
-// planes move the sample positions of the four lattice corners (the extremes of a field that is
-// affine in the lattice position to first order) by at most (thr_x, thr_y) map pixels, and a
-// lattice row / column is not stretched beyond `zoom` map pixels per point.  The matrix-product backward takes
-// the planes from the split on, the LDS-atomic backward the planes before it; both call THIS
-// function with the same arguments, so they agree bit for bit on who owns a plane.  All threads of
-// the workgroup call it (`slot` is an LDS word; two barriers inside).
+// First plane of sample b's sweep over map HALF from which on no lattice row / column is stretched
+// beyond `zoom` map pixels per lattice point (forward motion zooms the nearest planes of the prev map;
+// a plane qualifies only if every later plane does).  Judged on the sample positions of the four
+// lattice corners, the extremes of a projective map.  The matrix-product backward takes the planes
+// from the split on, the LDS-atomic backward the planes before it; both call THIS function with the
+// same arguments, so they agree bit for bit on who owns a plane.  All threads of the workgroup call
+// it (`slot` is an LDS word; two barriers inside).
 template <int HALF>
-__device__ __forceinline__ int sweep_calm_split(const SweepGeom &g, const SweepFast &f, const float *__restrict__ P,
+__device__ __forceinline__ int sweep_zoom_split(const SweepGeom &g, const SweepFast &f, const float *__restrict__ P,
                                                 const float *__restrict__ Pinv, const float *__restrict__ Tm,
-                                                const float *__restrict__ depths, float thr_x, float thr_y, float zoom,
-                                                int tid, int nthreads, int *slot)
+                                                const float *__restrict__ depths, float zoom, int tid, int nthreads,
+                                                int *slot)
 {
     if (tid == 0) *slot = 0;
     __syncthreads();
-    for (int d = tid; d + 1 < g.D; d += nthreads) {
-        bool calm = true;
+    const float sx = zoom * (float)(g.w_out - 1) + 2.0f, sy = zoom * (float)(g.h_out - 1) + 2.0f;
+    for (int d = tid; d < g.D; d += nthreads) {
         float cx[4], cy[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int hi = (k >> 1) ? g.h_out - 1 : 0, wi = (k & 1) ? g.w_out - 1 : 0;
-            float x1, y1;
-            sweep_point_map<HALF>(g, f, P, Pinv, Tm, depths[d], hi, wi, cx[k], cy[k]);
-            sweep_point_map<HALF>(g, f, P, Pinv, Tm, depths[d + 1], hi, wi, x1, y1);
-            calm = calm && fabsf(x1 - cx[k]) <= thr_x && fabsf(y1 - cy[k]) <= thr_y;  // false for NaN
-        }
-        const float sx = zoom * (float)(g.w_out - 1) + 2.0f, sy = zoom * (float)(g.h_out - 1) + 2.0f;
-        calm = calm && fabsf(cx[1] - cx[0]) <= sx && fabsf(cx[3] - cx[2]) <= sx && fabsf(cy[2] - cy[0]) <= sy &&
-               fabsf(cy[3] - cy[1]) <= sy;
-        if (!calm) atomicMax(slot, d + 1);
+        for (int k = 0; k < 4; ++k)
+            sweep_point_map<HALF>(g, f, P, Pinv, Tm, depths[d], (k >> 1) ? g.h_out - 1 : 0, (k & 1) ? g.w_out - 1 : 0,
+                                  cx[k], cy[k]);
+        const bool ok = fabsf(cx[1] - cx[0]) <= sx && fabsf(cx[3] - cx[2]) <= sx && fabsf(cy[2] - cy[0]) <= sy &&
+                        fabsf(cy[3] - cy[1]) <= sy;  // false for NaN
+        if (!ok) atomicMax(slot, d + 1);
     }
     __syncthreads();
     return *slot;
@@ -368,12 +363,12 @@ SweepFast sweep_make_fast(const dfm_sweep_desc *d);
 bool sweep_bwd_mfma_supported(const dfm_sweep_desc *d, const void *grad_out);
 int sweep_bwd_mfma_launch(const dfm_sweep_desc *d, int half, const void *grad_out, const float *depths,
                           const float *P, const float *Pinv, const float *Tm, float *grad_cur, float *grad_prev,
-                          float thr_x, float thr_y, void *stream);
+                          void *stream);
 // zoom (map pixels per lattice point) up to which the matrix-product backward takes a plane of the prev
 // map: whole 32-point segments up to SWEEP_BWD_ZOOM_ONE, in two 16-point passes up to
 // SWEEP_BWD_ZOOM_TWO, in four 8-point passes up to SWEEP_BWD_ZOOM_FOUR (its accumulator window is 48
 // columns x 6 rows); beyond that the LDS-atomic tile kernel (the two kernels split the planes by
-// sweep_calm_split with SWEEP_BWD_ZOOM_FOUR)
+// sweep_zoom_split with SWEEP_BWD_ZOOM_FOUR)
 constexpr float SWEEP_BWD_ZOOM_ONE = 1.4f, SWEEP_BWD_ZOOM_TWO = 2.75f, SWEEP_BWD_ZOOM_FOUR = 3.9f;
 
 // Bilinear footprint of one sample point: top-left integer corner, the four

@@ -830,8 +830,7 @@ struct BwdGrid {
                     // > 0 (strided sweeps): that many bands per lattice row, none crossing rows --
                     // consecutive lattice rows sample feature rows `cost_sample_factor` apart,
                     // which one slab window cannot hold
-    int split;      // 1: only the planes before sweep_calm_split (the matrix-product backward takes the rest)
-    float thr_x, thr_y;
+    int split;      // 1: only the planes before sweep_zoom_split (the matrix-product backward takes the rest)
 };
 
 // float -> 64-bit two's-complement fixed point (|x| < 2^61 after scaling): high word =
@@ -894,7 +893,7 @@ __global__ __launch_bounds__(BWD_PTS * bwd_groups(HALF)) void sweep_bwd_tile_ker
     int d_hi = min(d_lo + tg.planes, g.D);
     const float *Pb = P + b * 16, *Pib = Pinv + b * 16, *Tb = Tm + b * 16;
     if (tg.split) {  // workgroup-uniform
-        d_hi = min(d_hi, sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, SWEEP_BWD_ZOOM_FOUR, threadIdx.x,
+        d_hi = min(d_hi, sweep_zoom_split<HALF>(g, fast, Pb, Pib, Tb, depths, SWEEP_BWD_ZOOM_FOUR, threadIdx.x,
                                                 BWD_PTS * BWD_GROUPS, &yr[0]));
         if (d_hi <= d_lo) return;
         __syncthreads();  // yr is initialised below
@@ -2059,24 +2058,19 @@ int sweep_bwd_impl(const dfm_sweep_desc *desc, const void *grad_out, const float
         const long long nb = (long long)tg.bands * tg.dchunks * desc->batch;
         if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
         const SweepFast fast = make_fast(desc);
-        // dense bf16 sweeps: the matrix-product backward (plane_sweep_bwd_mfma.hip) takes the cur map
-        // and the calm planes of the prev map; this kernel keeps the prev map's fast-moving planes
-        // (opts->kernel: 5 = never, 6 = whenever it applies [the default])
+        // dense bf16 sweeps: the matrix-product backward (plane_sweep_bwd_mfma.hip) takes the cur map and
+        // the prev map's planes up to a zoom of SWEEP_BWD_ZOOM_FOUR map pixels per lattice point; this
+        // kernel keeps the (nearest) planes beyond that (opts->kernel: 5 = never, 6 = whenever it applies
+        // [the default])
         tg.split = 0;
-        tg.thr_x = 1e9f;  // (the zoom test of sweep_calm_split alone decides: drift costs the matrix-product kernel a flush, not more)
-        tg.thr_y = 1e9f;
-#ifdef DFM_DEBUG_HOOKS
-        if (const char *e = getenv("DFM_BWD_THR_X")) tg.thr_x = (float)atof(e);
-        if (const char *e = getenv("DFM_BWD_THR_Y")) tg.thr_y = (float)atof(e);
-#endif
         const bool mfma = !(opts && opts->kernel == 5) && !grad_cl && sweep_bwd_mfma_supported(desc, grad_out);
         if (mfma) {
             tg.split = 1;
             rc = sweep_bwd_mfma_launch(desc, 0, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_cur, grad_prev,
-                                       tg.thr_x, tg.thr_y, stream);
+                                       stream);
             if (rc != DFM_OK) return rc;
             rc = sweep_bwd_mfma_launch(desc, 1, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_cur, grad_prev,
-                                       tg.thr_x, tg.thr_y, stream);
+                                       stream);
             if (rc != DFM_OK) return rc;
         }
 #define DFM_BWD_LAUNCH(T, CW, HALF, ROWS)                                                            \

@@ -21,10 +21,12 @@
 // for the far planes of the prev map -- and are added to the gradient map with coalesced global
 // atomics when the window has to move.
 //
-// Planes where the prev footprints move quickly (the nearest planes: pixels per plane) would flush
-// every plane or two; they stay with sweep_bwd_tile_kernel.  Both kernels derive the split plane from
-// the same device function on the same inputs (sweep_calm_split: the drift of the four lattice
-// corners between consecutive planes), so every (plane, point) is handled by exactly one of them.
+// Forward motion zooms the nearest planes of the prev map to several map pixels per lattice point: a
+// 32-point segment then no longer fits the 48-column window.  Such planes take two steps of 16 points
+// or four of 8 (same loop, a point mask); beyond SWEEP_BWD_ZOOM_FOUR the plane stays with
+// sweep_bwd_tile_kernel.  Both kernels derive the split plane from the same device function on the same
+// inputs (sweep_zoom_split: the sample positions of the four lattice corners), so every (plane, point)
+// is handled by exactly one of them.
 //
 // Numerics: the weights are rounded to bf16 (the gradients already are), products and sums are fp32
 // in the MFMA.  A tile whose window sum turns non-finite is redone by a per-value path with plain
@@ -68,7 +70,6 @@ enum { BM_M_FLAGS = 0, BM_M_XB = 1, BM_M_YB = 2, BM_M_BITS = 3, BM_M_ROW = 5, BM
 struct BmGrid {
     int batch, pairs_w, tiles_w, tiles_h, cblocks, waves;
     int per_xcd, total;
-    float thr_x, thr_y;
     int ablate;  // debug builds: 1 no gradient loads, 2 no MFMA, 4 no flush, 8 no producer
     unsigned long long *trace;  // debug builds (dfm_debug_set_bm_trace): cycles per phase of workgroup 0's waves
 };
@@ -217,14 +218,14 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
     int d_start = 0, d_four = 0, d_two = 0;
     if (HALF) {
         int *slot = (int *)(lds_all + BM_OFF_META) + 31;
-        d_start = sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, SWEEP_BWD_ZOOM_FOUR, tid,
+        d_start = sweep_zoom_split<HALF>(g, fast, Pb, Pib, Tb, depths, SWEEP_BWD_ZOOM_FOUR, tid,
                                          2 * 64 * nw, slot);
         if (d_start >= g.D) return;
         __syncthreads();
-        d_four = max(d_start, sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, SWEEP_BWD_ZOOM_TWO,
+        d_four = max(d_start, sweep_zoom_split<HALF>(g, fast, Pb, Pib, Tb, depths, SWEEP_BWD_ZOOM_TWO,
                                                      tid, 2 * 64 * nw, slot));
         __syncthreads();
-        d_two = max(d_four, sweep_calm_split<HALF>(g, fast, Pb, Pib, Tb, depths, tg.thr_x, tg.thr_y, SWEEP_BWD_ZOOM_ONE,
+        d_two = max(d_four, sweep_zoom_split<HALF>(g, fast, Pb, Pib, Tb, depths, SWEEP_BWD_ZOOM_ONE,
                                                    tid, 2 * 64 * nw, slot));
     }
     const int n4 = d_four - d_start, n2 = d_two - d_four, nsteps = 4 * n4 + 2 * n2 + (g.D - d_two);
@@ -546,7 +547,7 @@ bool sweep_bwd_mfma_supported(const dfm_sweep_desc *d, const void *grad_out)
 
 int sweep_bwd_mfma_launch(const dfm_sweep_desc *d, int half, const void *grad_out, const float *depths,
                           const float *P, const float *Pinv, const float *Tm, float *grad_cur, float *grad_prev,
-                          float thr_x, float thr_y, void *stream)
+                          void *stream)
 {
     const SweepGeom g = sweep_make_geom(d);
     SweepFast fast = sweep_make_fast(d);
@@ -562,8 +563,6 @@ int sweep_bwd_mfma_launch(const dfm_sweep_desc *d, int half, const void *grad_ou
     if (total > (1ll << 30)) return set_error(DFM_ERR_UNSUPPORTED, "too many lattice tiles");
     tg.total = (int)total;
     tg.per_xcd = (tg.total + 7) / 8;
-    tg.thr_x = thr_x;
-    tg.thr_y = thr_y;
     tg.ablate = 0;
     tg.trace = nullptr;
 #ifdef DFM_DEBUG_HOOKS

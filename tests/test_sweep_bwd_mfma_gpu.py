@@ -180,3 +180,15 @@ def test_north_star_geometry_slice(pkg):
     tc, tp, _ = _run(pkg, kernel=5, **k)
     _close(gc.cpu().numpy(), tc.cpu().numpy(), 'cur vs tile kernel')
     _close(gp.cpu().numpy(), tp.cpu().numpy(), 'prev vs tile kernel')
+
+
+def test_clock_probe_reports_a_plausible_shader_clock(pkg):
+    """dfm_clock_probe (bench.py's part diagnostics): cycles / 100 MHz reference ticks under an FMA load"""
+    import ctypes
+    lib = pkg._capi.lib()
+    buf = torch.zeros(3, dtype=torch.int64, device='cuda:0')
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pkg._capi.check(lib.dfm_clock_probe(ctypes.c_void_p(buf.data_ptr()), 1 << 16, st))
+    torch.cuda.synchronize()
+    cyc, ref = (int(v) for v in buf[:2].tolist())
+    assert ref > 0 and 0.3 < cyc / ref / 10.0 < 3.5
