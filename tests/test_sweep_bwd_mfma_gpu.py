@@ -47,7 +47,7 @@ def _run(pkg, cur, prev, depths, fsf, P, T, img_shape, flip, crop, scale, gout, 
 
 
 def _case(B, C, H, W, D, fsf, crop=(0, 0), flip=False, scale=1.0, seed=0, img_shape=None, t_z=None,
-          poses='random'):
+          pose=None):
     rng = np.random.RandomState(seed)
     cur = rng.randn(B, C, H, W).astype(np.float32)
     prev = rng.randn(B, C, H, W).astype(np.float32)
@@ -55,6 +55,10 @@ def _case(B, C, H, W, D, fsf, crop=(0, 0), flip=False, scale=1.0, seed=0, img_sh
     T = util.random_poses(B, seed=seed + 4)
     if t_z is not None:
         T[:, 2, 3] = t_z
+    if pose is not None:
+        a = np.radians(pose['yaw'])
+        c_, s_ = np.cos(a), np.sin(a)
+        T[:] = np.array([[c_, 0, s_, pose['tx']], [0, 1, 0, 0], [-s_, 0, c_, pose['tz']], [0, 0, 0, 1]], np.float32)
     depths = util.depth_planes(D)
     gout = orc.bf16_round(rng.randn(B, 2 * C, D, H, W).astype(np.float32))
     img_shape = img_shape or (H * fsf, W * fsf)
@@ -103,6 +107,10 @@ CASES = {
     'one_tile': dict(B=1, C=16, H=4, W=32, D=5, fsf=4, seed=9),
     # more than 128 channels: two workgroups per tile
     'c160': dict(B=1, C=160, H=8, W=40, D=4, fsf=4, seed=11),
+    # a single plane, a quarter-filled channel block, 33 columns (the second tile owns one column)
+    'd1_c8_w33': dict(B=1, C=8, H=6, W=33, D=1, fsf=4, seed=13),
+    # strong rotation + lateral motion: slanted rows, footprints leaving the map on one side
+    'rotation': dict(B=2, C=16, H=20, W=72, D=12, fsf=4, seed=15, pose=dict(yaw=8.0, tx=0.8, tz=-0.6)),
 }
 
 
@@ -120,6 +128,16 @@ def test_matrix_product_backward_matches_torch_and_tile_kernel(pkg, name):
         _close(gp[b].cpu().numpy(), rp, f'{name} prev vs torch, sample {b}')
     _close(gc.cpu().numpy(), tc.cpu().numpy(), f'{name} cur vs tile kernel')
     _close(gp.cpu().numpy(), tp.cpu().numpy(), f'{name} prev vs tile kernel')
+
+
+def test_prev_map_entirely_outside(pkg):
+    """a pose that throws every prev sample out of the map: zero prev gradient, the cur gradient as usual"""
+    k = _case(B=1, C=16, H=8, W=40, D=4, fsf=4, seed=17, pose=dict(yaw=0.0, tx=500.0, tz=0.0))
+    gc, gp, which = _run(pkg, **k)
+    assert which == 6
+    assert float(gp.abs().max()) == 0.0
+    rc, _ = _reference(k, 0)
+    _close(gc[0].cpu().numpy(), rc, 'cur vs torch')
 
 
 def test_cur_map_weights_are_exact_in_bf16(pkg):
