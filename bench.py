@@ -400,9 +400,16 @@ def secondary(args, pkg, dev, job):
                 'algorithmic_flops_per_step': flops}
     else:
         achieved = nbytes / (dev_ms * 1e-3) / 1e9
+        traffic = None
+        if args.workload == 'sweep_bwd':  # PMC passes of this workload: profiles/r03_sweep_bwd_traffic.json
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'r03_sweep_bwd_traffic.json')) as f:
+                    traffic = json.load(f)['sweep_bwd']['hbm_bytes_per_launch']
+            except (OSError, ValueError, KeyError):
+                traffic = None
         roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4),
-                'traffic': None, 'kernel_ms': round(dev_ms, 4),
+                'traffic': traffic, 'kernel_ms': round(dev_ms, 4),
                 'algorithmic_bytes_per_launch': nbytes}
     if rank == 0:
         print(json.dumps({
