@@ -46,6 +46,7 @@ EXPORTS = (
     'dfm_frustum_to_voxel_fused_fwd',
     'dfm_frustum_to_voxel_bwd_workspace_bytes',
     'dfm_frustum_to_voxel_bwd',
+    'dfm_frustum_to_voxel_fused_bwd',
     'dfm_point_sample_mv_fwd_batched',
     'dfm_point_sample_mv_bwd_workspace_bytes',
     'dfm_point_sample_mv_bwd',
@@ -68,6 +69,8 @@ EXPORTS = (
     'dfm_conv3d_wgrad',
     'dfm_depth_loss_fwd',
     'dfm_depth_loss_bwd',
+    'dfm_depth_loss_fused_fwd',
+    'dfm_depth_loss_fused_bwd',
     'dfm_voxel_sample_fwd',
     'dfm_voxel_sample_bwd',
     'dfm_spp_tail_workspace_bytes',
@@ -288,6 +291,9 @@ def lib():
     h.dfm_frustum_to_voxel_bwd.restype = ctypes.c_int
     h.dfm_frustum_to_voxel_bwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, fp, fp, fp, fp, vp,
                                            ctypes.c_size_t, vp]
+    h.dfm_frustum_to_voxel_fused_bwd.restype = ctypes.c_int
+    h.dfm_frustum_to_voxel_fused_bwd.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, fp, fp, i32, fp, fp, fp, fp, vp,
+                                                 ctypes.c_size_t, vp]
     h.dfm_frustum_to_voxel_bwd_workspace_bytes.restype = ctypes.c_size_t
     h.dfm_frustum_to_voxel_bwd_workspace_bytes.argtypes = [ctypes.POINTER(F2vDesc)]
     h.dfm_point_sample_mv_bwd.restype = ctypes.c_int
@@ -333,6 +339,10 @@ def lib():
     h.dfm_depth_loss_fwd.argtypes = [lp, vp, fp, fp, fp, vp, vp]
     h.dfm_depth_loss_bwd.restype = ctypes.c_int
     h.dfm_depth_loss_bwd.argtypes = [lp, vp, fp, fp, fp, vp, vp]
+    h.dfm_depth_loss_fused_fwd.restype = ctypes.c_int
+    h.dfm_depth_loss_fused_fwd.argtypes = [lp, vp, i32, fp, fp, fp, vp, vp]
+    h.dfm_depth_loss_fused_bwd.restype = ctypes.c_int
+    h.dfm_depth_loss_fused_bwd.argtypes = [lp, vp, i32, fp, fp, fp, fp, vp]
     h.dfm_voxel_sample_fwd.restype = ctypes.c_int
     h.dfm_voxel_sample_fwd.argtypes = [ctypes.POINTER(VsDesc), vp, fp, vp, vp]
     h.dfm_voxel_sample_bwd.restype = ctypes.c_int

@@ -498,7 +498,7 @@ namespace {
 
 template <typename T>
 __global__ __launch_bounds__(256) void f2v_bwd_kernel(F2vGeom g, const T *__restrict__ gout,
-                                                      const T *__restrict__ soft,
+                                                      const T *__restrict__ soft, FusedHead fh,
                                                       const float *__restrict__ coords,
                                                       const float *__restrict__ cam2img,
                                                       float *__restrict__ gstereo,
@@ -523,8 +523,13 @@ __global__ __launch_bounds__(256) void f2v_bwd_kernel(F2vGeom g, const T *__rest
     const size_t vol = (size_t)g.D * g.H * g.W;
     float disp = 1.0f;  // pred_disp (detached): scales the gradients of the attended branches
     if (valid && (g.st_att || (g.Cs > 0 && g.sem_att))) {
-        const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
-        disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
+        if (fh.cost) {  // the depth head fused (training): the distribution evaluated where it is sampled
+            disp = fused_disp<T>(g, (const T *)fh.cost + (size_t)b * g.cd * g.ch * g.cw,
+                                 fh.col_max + (size_t)b * g.Hs * g.Ws, fh.col_sum + (size_t)b * g.Hs * g.Ws, gx, gy, gz);
+        } else {
+            const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+            disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
+        }
     }
     if (valid) {
         const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
@@ -570,7 +575,7 @@ struct BwdFoot {
 
 template <typename T>
 __global__ __launch_bounds__(256) void f2v_bwd_pm_kernel(F2vGeom g, const T *__restrict__ gout,
-                                                         const T *__restrict__ soft,
+                                                         const T *__restrict__ soft, FusedHead fh,
                                                          const float *__restrict__ coords,
                                                          const float *__restrict__ cam2img,
                                                          float *__restrict__ gst_pm,
@@ -612,8 +617,14 @@ __global__ __launch_bounds__(256) void f2v_bwd_pm_kernel(F2vGeom g, const T *__r
             const bool valid = valid2d && gz >= -1.0f && gz <= 1.0f;
             float disp = 1.0f;
             if (valid && (g.st_att || (g.Cs > 0 && g.sem_att))) {
-                const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
-                disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
+                if (fh.cost) {
+                    disp = fused_disp<T>(g, (const T *)fh.cost + (size_t)b * g.cd * g.ch * g.cw,
+                                         fh.col_max + (size_t)b * g.Hs * g.Ws, fh.col_sum + (size_t)b * g.Hs * g.Ws,
+                                         gx, gy, gz);
+                } else {
+                    const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+                    disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
+                }
             }
             if (valid) {
                 const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
@@ -675,17 +686,15 @@ extern "C" DFM_API size_t dfm_frustum_to_voxel_bwd_workspace_bytes(const dfm_f2v
     return ((a + 255) & ~(size_t)255) + ((b + 255) & ~(size_t)255) + 256;
 }
 
-extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const void *grad_out,
-                                                const void *softmax, const float *coords,
-                                                const float *cam2img, float *grad_stereo,
-                                                float *grad_sem, void *workspace,
-                                                size_t workspace_bytes, void *stream)
+static int f2v_bwd_impl(const dfm_f2v_desc *d, const void *grad_out, const void *softmax, FusedHead fh,
+                        int head_scale, const float *coords, const float *cam2img, float *grad_stereo,
+                        float *grad_sem, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
     if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
         return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
     if (!grad_out || !coords || !cam2img || !grad_stereo || (d->sem_channels > 0 && !grad_sem) ||
-        ((d->stereo_atten || (d->sem_channels > 0 && !d->no_sem_atten)) && !softmax))
+        ((d->stereo_atten || (d->sem_channels > 0 && !d->no_sem_atten)) && !softmax && !fh.cost))
         return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     F2vGeom g;
     g.C = d->channels; g.D = d->d; g.H = d->h; g.W = d->w;
@@ -694,6 +703,11 @@ extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const voi
     g.Nz = d->nz; g.Ny = d->ny; g.Nx = d->nx;
     g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.depth_min = d->depth_min; g.depth_span = d->depth_span;
     g.cd = g.ch = g.cw = 0;
+    if (fh.cost) {
+        if (head_scale <= 0 || d->ds % head_scale || d->hs % head_scale || d->ws % head_scale)
+            return set_error(DFM_ERR_INVALID_ARG, "ds, hs, ws must be multiples of the depth head's scale");
+        g.cd = d->ds / head_scale; g.ch = d->hs / head_scale; g.cw = d->ws / head_scale;
+    }
     g.out_cl = 0;
     g.st_att = d->stereo_atten ? 1 : 0;
     g.sem_att = d->no_sem_atten ? 0 : 1;
@@ -715,11 +729,11 @@ extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const voi
         dim3 grid((unsigned)((N + F2V_VT - 1) / F2V_VT), d->batch);
         if (d->dtype == DFM_F32)
             hipLaunchKernelGGL(f2v_bwd_pm_kernel<float>, grid, dim3(256), lds, st, g,
-                               (const float *)grad_out, (const float *)softmax, coords, cam2img,
+                               (const float *)grad_out, (const float *)softmax, fh, coords, cam2img,
                                gst_pm, gsem_pm);
         else
             hipLaunchKernelGGL(f2v_bwd_pm_kernel<bf16_t>, grid, dim3(256), lds, st, g,
-                               (const bf16_t *)grad_out, (const bf16_t *)softmax, coords, cam2img,
+                               (const bf16_t *)grad_out, (const bf16_t *)softmax, fh, coords, cam2img,
                                gst_pm, gsem_pm);
         dim3 t1((unsigned)((vox + 63) / 64), (d->channels + 31) / 32, d->batch);
         hipLaunchKernelGGL(add_from_pixel_major_kernel<float>, t1, dim3(256), 0, st, gst_pm, grad_stereo,
@@ -737,14 +751,35 @@ extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const voi
     dim3 grid((unsigned)((N + 255) / 256), d->batch);
     if (d->dtype == DFM_F32)
         hipLaunchKernelGGL(f2v_bwd_kernel<float>, grid, dim3(256), 0, st, g, (const float *)grad_out,
-                           (const float *)softmax, coords, cam2img, grad_stereo, grad_sem);
+                           (const float *)softmax, fh, coords, cam2img, grad_stereo, grad_sem);
     else
         hipLaunchKernelGGL(f2v_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, g,
-                           (const bf16_t *)grad_out, (const bf16_t *)softmax, coords, cam2img,
+                           (const bf16_t *)grad_out, (const bf16_t *)softmax, fh, coords, cam2img,
                            grad_stereo, grad_sem);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
+}
+
+extern "C" DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *d, const void *grad_out,
+                                                const void *softmax, const float *coords,
+                                                const float *cam2img, float *grad_stereo,
+                                                float *grad_sem, void *workspace,
+                                                size_t workspace_bytes, void *stream)
+{
+    return f2v_bwd_impl(d, grad_out, softmax, FusedHead{nullptr, nullptr, nullptr}, 0, coords, cam2img, grad_stereo,
+                        grad_sem, workspace, workspace_bytes, stream);
+}
+
+extern "C" DFM_API int dfm_frustum_to_voxel_fused_bwd(const dfm_f2v_desc *d, const void *grad_out, const void *cost,
+                                                      const float *col_max, const float *col_sum,
+                                                      int32_t head_scale, const float *coords,
+                                                      const float *cam2img, float *grad_stereo, float *grad_sem,
+                                                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!cost || !col_max || !col_sum) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    return f2v_bwd_impl(d, grad_out, nullptr, FusedHead{cost, col_max, col_sum}, head_scale, coords, cam2img,
+                        grad_stereo, grad_sem, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------

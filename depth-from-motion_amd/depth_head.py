@@ -64,11 +64,16 @@ class LazyDepthDistribution:
     ``frustum_to_voxel_sample`` accept it in place of ``stereo_feat_softmax`` and evaluate the
     distribution at the voxels' corners on the fly -- bit-identical to sampling the materialised
     tensor (inference; the reference detaches the distribution anyway, feature_transformation.py:136).
-    ``materialize()`` returns the (B, 1, sD, sH, sW) tensor if somebody needs it after all."""
+    ``materialize()`` returns the (B, 1, sD, sH, sW) tensor if somebody needs it after all.
 
-    def __init__(self, cost, col_max, col_sum, depth_samples, scale):
+    Training (``cost_with_grad``: the cost as it sits in the autograd graph): ``DepthHead.loss`` accepts
+    the object in place of ``depth_volumes`` and evaluates the logits of the valid pixels from the cost
+    (``fused_depth_distribution_loss``); its backward and FrustumToVoxel's need no volume either."""
+
+    def __init__(self, cost, col_max, col_sum, depth_samples, scale, cost_with_grad=None):
         self.cost, self.col_max, self.col_sum = cost, col_max, col_sum
         self.depth_samples, self.scale = depth_samples, scale
+        self.cost_with_grad = cost_with_grad
         B, _, D, H, W = cost.shape
         self.shape = (B, 1, scale * D, scale * H, scale * W)
         self.dtype, self.device = cost.dtype, cost.device
@@ -76,15 +81,20 @@ class LazyDepthDistribution:
     def detach(self):
         return self
 
+    def flatten(self, start_dim=0, end_dim=-1):  # the detector folds (B, N) before the loss: N = 1 here
+        return self
+
     def materialize(self):
         return depth_head_forward(self.cost, self.depth_samples, self.scale)[1]
 
 
-def depth_head_statistics(stereo_features, depth_samples, downsample_factor=4, need_preds=True):
+def depth_head_statistics(stereo_features, depth_samples, downsample_factor=4, need_preds=True, keep_graph=False):
     """The inference form of ``depth_head_forward``: (LazyDepthDistribution, depth_preds) from one
     statistics pass over the low-resolution cost -- none of the three (B, 1, sD, sH, sW) tensors
     (472 MB each per sample at config K) is written.  ``need_preds=False`` skips the expectation
-    pass (depth_preds is None): the detector's inference path does not read it."""
+    pass (depth_preds is None): the detector's inference path does not read it.
+    ``keep_graph=True`` (training): the distribution remembers ``stereo_features`` as it sits in the
+    autograd graph, for ``DepthHead.loss`` (depth_preds itself carries no gradient here)."""
     _require_gpu(stereo_features, 'stereo_features')
     if stereo_features.dtype not in _DTYPES:
         raise TypeError('stereo_features must be float32 or bfloat16')
@@ -102,7 +112,7 @@ def depth_head_statistics(stereo_features, depth_samples, downsample_factor=4, n
                                                          _ptr(cmax), _ptr(csum),
                                                          _ptr(pred) if need_preds else None,
                                                          _stream_ptr(x.device)))
-    return LazyDepthDistribution(x, cmax, csum, ds, s), pred
+    return LazyDepthDistribution(x, cmax, csum, ds, s, cost_with_grad=stereo_features if keep_graph else None), pred
 
 
 # ---------------------------------------------------------------------------
@@ -139,23 +149,7 @@ class _DepthLossFn(torch.autograd.Function):
         return gv, None, None, None
 
 
-def depth_distribution_loss(depth_volumes, depth_img, depth_samples, loss_type, min_depth, max_depth,
-                            alpha=1.0, gamma=2.0):
-    """Unreduced depth-distribution loss per pixel and the validity mask.
-
-    depth_volumes [B*N, D, H, W] logits, depth_img [B*N, H, W]; returns (pixel_loss [B*N,H,W]
-    fp32 -- 0 at invalid pixels --, valid [B*N,H,W] bool).  ``loss_type`` as in the reference
-    config: ce | balanced_ce | focal | balanced_focal | hard_ce | gaussian_<s> | laplacian_<s>.
-    """
-    _require_gpu(depth_volumes, 'depth_volumes')
-    if depth_volumes.dtype not in _DTYPES:
-        raise TypeError('depth_volumes must be float32 or bfloat16')
-    vol = depth_volumes.contiguous()
-    B, D, H, W = vol.shape
-    img = depth_img.to(device=vol.device, dtype=torch.float32).contiguous()
-    assert img.shape == (B, H, W), (img.shape, vol.shape)
-    ds = depth_samples.to(device=vol.device, dtype=torch.float32).contiguous()
-    assert ds.numel() == D
+def _loss_desc(B, D, H, W, dtype, depth_samples, loss_type, min_depth, max_depth, alpha, gamma):
     d = _capi.DepthLossDesc()
     d.batch, d.num_depths, d.h, d.w = B, D, H, W
     d.focal = 1 if loss_type in ('focal', 'balanced_focal') else 0
@@ -176,6 +170,82 @@ def depth_distribution_loss(depth_volumes, depth_img, depth_samples, loss_type, 
     # the host copy of two scalars, not a device sync on the hot tensor
     two = depth_samples[:2].detach().to('cpu', torch.float32)
     d.interval = float(two[1] - two[0])
-    d.dtype = _DTYPES[vol.dtype]
+    d.dtype = _DTYPES[dtype]
+    return d
+
+
+def depth_distribution_loss(depth_volumes, depth_img, depth_samples, loss_type, min_depth, max_depth,
+                            alpha=1.0, gamma=2.0):
+    """Unreduced depth-distribution loss per pixel and the validity mask.
+
+    depth_volumes [B*N, D, H, W] logits, depth_img [B*N, H, W]; returns (pixel_loss [B*N,H,W]
+    fp32 -- 0 at invalid pixels --, valid [B*N,H,W] bool).  ``loss_type`` as in the reference
+    config: ce | balanced_ce | focal | balanced_focal | hard_ce | gaussian_<s> | laplacian_<s>.
+    ``depth_volumes`` may be a ``LazyDepthDistribution`` (``fused_depth_distribution_loss``).
+    """
+    if isinstance(depth_volumes, LazyDepthDistribution):
+        return fused_depth_distribution_loss(depth_volumes, depth_img, depth_samples, loss_type, min_depth,
+                                             max_depth, alpha, gamma)
+    _require_gpu(depth_volumes, 'depth_volumes')
+    if depth_volumes.dtype not in _DTYPES:
+        raise TypeError('depth_volumes must be float32 or bfloat16')
+    vol = depth_volumes.contiguous()
+    B, D, H, W = vol.shape
+    img = depth_img.to(device=vol.device, dtype=torch.float32).contiguous()
+    assert img.shape == (B, H, W), (img.shape, vol.shape)
+    ds = depth_samples.to(device=vol.device, dtype=torch.float32).contiguous()
+    assert ds.numel() == D
+    d = _loss_desc(B, D, H, W, vol.dtype, depth_samples, loss_type, min_depth, max_depth, alpha, gamma)
     loss, valid = _DepthLossFn.apply(vol, img, ds, d)
+    return loss, valid.bool()
+
+
+class _FusedDepthLossFn(torch.autograd.Function):
+    """the same per-pixel loss from the LOW-RESOLUTION cost (dfm_depth_loss_fused_fwd/bwd): the logits of
+    a valid pixel's column are evaluated on the fly, the backward goes through the transposed upsample
+    straight into the cost's gradient -- no (B, 1, sD, sH, sW) tensor in either direction"""
+
+    @staticmethod
+    def forward(ctx, cost, depth_img, ds, desc, scale):
+        lib = _capi.lib()
+        device = cost.device
+        x = cost.contiguous()
+        B, H, W = desc.batch, desc.h, desc.w
+        loss = torch.empty((B, H, W), dtype=torch.float32, device=device)
+        valid = torch.empty((B, H, W), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _capi.check(lib.dfm_depth_loss_fused_fwd(ctypes.byref(desc), _ptr(x), scale, _ptr(depth_img), _ptr(ds),
+                                                     _ptr(loss), _ptr(valid), _stream_ptr(device)))
+        ctx.save_for_backward(x, depth_img, ds)
+        ctx.desc, ctx.scale = desc, scale
+        ctx.mark_non_differentiable(valid)
+        return loss, valid
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_valid):
+        x, depth_img, ds = ctx.saved_tensors
+        lib = _capi.lib()
+        device = x.device
+        g = g_loss.contiguous().float()
+        gx = torch.zeros(x.shape, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            _capi.check(lib.dfm_depth_loss_fused_bwd(ctypes.byref(ctx.desc), _ptr(x), ctx.scale, _ptr(depth_img),
+                                                     _ptr(ds), _ptr(g), _ptr(gx), _stream_ptr(device)))
+        return gx.to(x.dtype), None, None, None, None
+
+
+def fused_depth_distribution_loss(dist, depth_img, depth_samples, loss_type, min_depth, max_depth,
+                                  alpha=1.0, gamma=2.0):
+    """``depth_distribution_loss`` on a ``LazyDepthDistribution`` (DepthHead fused, training): pixel_loss is
+    bit-identical to the loss on the materialised ``depth_volumes``; differentiable w.r.t.
+    ``dist.cost_with_grad``."""
+    cost = dist.cost_with_grad if dist.cost_with_grad is not None else dist.cost
+    _require_gpu(cost, 'cost')
+    B, _, sD, sH, sW = dist.shape
+    img = depth_img.to(device=cost.device, dtype=torch.float32).contiguous()
+    assert img.shape == (B, sH, sW), (img.shape, dist.shape)
+    ds = depth_samples.to(device=cost.device, dtype=torch.float32).contiguous()
+    assert ds.numel() == sD
+    d = _loss_desc(B, sD, sH, sW, cost.dtype, depth_samples, loss_type, min_depth, max_depth, alpha, gamma)
+    loss, valid = _FusedDepthLossFn.apply(cost, img, ds, d, int(dist.scale))
     return loss, valid.bool()

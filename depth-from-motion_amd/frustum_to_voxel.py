@@ -57,6 +57,52 @@ class _F2vFn(torch.autograd.Function):
         return g_st.to(dtype), (g_sem.to(dtype) if g_sem is not None else None), None, None, None, None
 
 
+class _F2vFusedFn(torch.autograd.Function):
+    """the DepthHead fused into the sampling, with autograd (training): forward =
+    dfm_frustum_to_voxel_fused_fwd, backward = dfm_frustum_to_voxel_fused_bwd -- the depth distribution
+    (detached in the reference, feature_transformation.py:136) is evaluated from the low-resolution cost in
+    both directions"""
+
+    @staticmethod
+    def forward(ctx, stereo, sem, cost, col_max, col_sum, scale, coords, cam4, desc):
+        lib = _capi.lib()
+        device = stereo.device
+        out = _alloc_out(desc, stereo)
+        nbytes = lib.dfm_frustum_to_voxel_workspace_bytes(ctypes.byref(desc))
+        ws = _Workspace.get(device, nbytes)
+        with torch.cuda.device(device):
+            _capi.check(lib.dfm_frustum_to_voxel_fused_fwd(
+                ctypes.byref(desc), _ptr(stereo), _ptr(cost), _ptr(col_max), _ptr(col_sum), scale,
+                _ptr(sem) if sem is not None else None, _ptr(coords), _ptr(cam4), _ptr(out), _ptr(ws), nbytes,
+                _stream_ptr(device)))
+        ctx.desc, ctx.scale = desc, scale
+        ctx.has_sem = sem is not None
+        ctx.shapes = (stereo.shape, None if sem is None else sem.shape, stereo.dtype)
+        ctx.save_for_backward(coords, cam4, cost, col_max, col_sum)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        coords, cam4, cost, col_max, col_sum = ctx.saved_tensors
+        lib = _capi.lib()
+        desc = ctx.desc
+        st_shape, sem_shape, dtype = ctx.shapes
+        device = grad_out.device
+        go = grad_out.contiguous().to(dtype)
+        g_st = torch.zeros(st_shape, dtype=torch.float32, device=device)
+        g_sem = torch.zeros(sem_shape, dtype=torch.float32, device=device) if ctx.has_sem else None
+        bdesc = desc
+        nbytes = lib.dfm_frustum_to_voxel_bwd_workspace_bytes(ctypes.byref(bdesc))
+        ws = _Workspace.get(device, nbytes)
+        with torch.cuda.device(device):
+            _capi.check(lib.dfm_frustum_to_voxel_fused_bwd(
+                ctypes.byref(bdesc), _ptr(go), _ptr(cost), _ptr(col_max), _ptr(col_sum), ctx.scale, _ptr(coords),
+                _ptr(cam4), _ptr(g_st), _ptr(g_sem) if g_sem is not None else None, _ptr(ws), nbytes,
+                _stream_ptr(device)))
+        return (g_st.to(dtype), (g_sem.to(dtype) if g_sem is not None else None), None, None, None, None, None,
+                None, None)
+
+
 def _alloc_out(desc, stereo):
     ctot = desc.channels + desc.sem_channels
     if desc.out_channels_last:  # (B, Nz, Ny, Nx, C) in memory = channels_last_3d
@@ -123,10 +169,6 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
             lazy = stereo_feat_softmax
             if lazy.dtype != stereo.dtype:
                 raise TypeError('the fused depth head needs cost and stereo_feat in the same dtype')
-            if torch.is_grad_enabled() and (stereo_feat.requires_grad or
-                                            (cur_sem_feats is not None and cur_sem_feats.requires_grad)):
-                raise RuntimeError('the fused DepthHead -> FrustumToVoxel path is inference only '
-                                   '(training materialises the distribution for DepthHead.loss)')
             desc.ds, desc.hs, desc.ws = lazy.shape[2:]
         else:
             soft = stereo_feat_softmax.detach().to(stereo.dtype).contiguous()
@@ -144,6 +186,11 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     cam4 = torch.eye(4).repeat(B, 1, 1)
     cam4[:, :cam.shape[1], :cam.shape[2]] = cam
     cam4 = _upload(cam4.reshape(B, 16), device)
+    if lazy is not None and torch.is_grad_enabled() and (stereo.requires_grad or
+                                                         (sem is not None and sem.requires_grad)):
+        # training with the depth head fused (the backward ignores the input layouts, like _F2vFn's)
+        return _F2vFusedFn.apply(stereo, sem, lazy.cost, lazy.col_max, lazy.col_sum, int(lazy.scale), coords, cam4,
+                                 desc)
     if lazy is not None:
         lib = _capi.lib()
         out = _alloc_out(desc, stereo)

@@ -129,11 +129,13 @@ class DfMStereoPath(nn.Module):
         out = dict(mono_stereo_costs=costs, stereo_feats=stereo_feats, mono_feats=mono_feats,
                    cur_sem_feat=cur_sem)
         if self.depth_head is not None:
-            # inference: the depth head is fused into FrustumToVoxel's sampling kernel (the
-            # distribution is never materialised; upsample_costs is None).  Training keeps the
-            # volumes: DepthHead.loss reads upsample_costs (dfm.py:348-356).
-            fuse = (self.fuse_depth_head and not torch.is_grad_enabled() and
-                    hasattr(self, 'feature_transformation') and not self.depth_head.with_convs)
+            # the depth head is fused into FrustumToVoxel's sampling kernel: the distribution is never
+            # materialised.  Inference: upsample_costs is None.  Training: upsample_costs is the lazy
+            # distribution, which DepthHead.loss (dfm.py:348-356) evaluates from the low-resolution cost;
+            # the l1 losses differentiate depth_preds and keep the materialised head.
+            fuse = (self.fuse_depth_head and hasattr(self, 'feature_transformation') and
+                    not self.depth_head.with_convs and
+                    (not torch.is_grad_enabled() or self.depth_head.depth_loss_type not in ('l1', 'purel1')))
             up, preds, soft = self.depth_head(costs, lazy=True) if fuse else \
                 (lambda v, s, p: (v, p, s))(*self.depth_head(costs))
             out.update(upsample_costs=up, upsample_costs_softmax=soft, depth_preds=preds)

@@ -413,15 +413,20 @@ class DepthHead(nn.Module):
         self.depth_samples = None  # injected by the detector (dfm.py:90)
 
     def forward(self, stereo_features, lazy=False):
-        """``lazy=True`` (extension, inference, single view): returns (None, depth_preds,
-        LazyDepthDistribution) -- the distribution is handed to FrustumToVoxel unmaterialised and
-        evaluated inside its sampling kernel (the DepthHead -> FrustumToVoxel fusion)."""
+        """``lazy=True`` (extension, single view): returns (None, depth_preds, LazyDepthDistribution) --
+        the distribution is handed to FrustumToVoxel unmaterialised and evaluated inside its sampling
+        kernel (the DepthHead -> FrustumToVoxel fusion).  While autograd records (training) the first
+        result is the distribution too: ``loss`` accepts it in place of ``depth_volumes`` and
+        evaluates the valid pixels' logits from the low-resolution cost, forward and backward."""
         _, _, D, H, W = stereo_features.shape
         x = stereo_features
         if lazy and not self.with_convs and x.shape[1] == 1:
+            # with autograd recording (training) the distribution keeps the cost's graph node: DepthHead.loss
+            # takes it in place of depth_volumes (returned FIRST for that); depth_preds carries no gradient
+            train = torch.is_grad_enabled() and x.requires_grad
             dist, pred = depth_head_statistics(x, _on_device(self, 'depth_samples', x.device),
-                                               self.downsample_factor)
-            return None, pred, dist
+                                               self.downsample_factor, keep_graph=train)
+            return (dist if train else None), pred, dist
         if self.with_convs:
             x = self.conv_depth(x).view(-1, self.num_views, D, H, W)
         if x.shape[1] != 1:
@@ -672,16 +677,26 @@ class upconv_module(nn.Module):  # noqa: N801  (reference class name)
 
 def _channels_last_2d(module, feats):
     """The 2-D producers / consumers either side of the path (SPPUNetNeck,
-    BEVHourglass) run NHWC on the GPU: MIOpen's bf16 / fp32 2-D convolutions are NHWC kernels and wrap
-    an NCHW call in two transposes each (profiles/r02_c29: 588 batched_transpose launches per
-    DfMStereoPath forward), and the stereo / semantic maps they emit are then already in the
-    pixel-major layout the plane sweep and FrustumToVoxel sample (no pack pass).  The 4-D weights
-    are re-laid once; shapes, values and state_dict keys are untouched."""
+    BEVHourglass) run NHWC on the GPU at INFERENCE: the MFMA convolution kernel and the fused SPP tail
+    read NHWC, MIOpen's own NHWC kernels wrap an NCHW call in two transposes each (profiles/r02_c29: 588
+    batched_transpose launches per DfMStereoPath forward), and the stereo / semantic maps they emit are
+    then already in the pixel-major layout the plane sweep and FrustumToVoxel sample (no pack pass).
+    The 4-D weights are re-laid once; shapes, values and state_dict keys are untouched.
+
+    While autograd records (training) the modules keep the caller's layout and contiguous weights: the
+    2-D MFMA path is inference-only, and torch's NHWC training kernels on this stack are MIOpen's naive
+    convolutions (60 ms per weight gradient) and ATen's channels-last bilinear backward (171 ms per call):
+    2.1 s of a 2.2 s DfMStereoPath training step at config K (profiles/r03_c43_*)."""
     if not feats[0].is_cuda:
         return feats
-    if not module.__dict__.get('_weights_channels_last', False):
-        module.to(memory_format=torch.channels_last)
-        module.__dict__['_weights_channels_last'] = True
+    train = torch.is_grad_enabled() and (module.training or any(f.requires_grad for f in feats))
+    want = torch.contiguous_format if train else torch.channels_last
+    if module.__dict__.get('_weights_format') is not want:
+        module.to(memory_format=want)
+        module.__dict__['_weights_format'] = want
+        module.__dict__['_weights_channels_last'] = not train
+    if train:
+        return [f.contiguous() for f in feats]
     return [f.contiguous(memory_format=torch.channels_last) for f in feats]
 
 

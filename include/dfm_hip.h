@@ -433,6 +433,14 @@ DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *desc, const void *grad_
                                      const void *softmax, const float *coords,
                                      const float *cam2img, float *grad_stereo, float *grad_sem,
                                      void *workspace, size_t workspace_bytes, void *stream);
+/* The same backward with the depth head fused (training): pred_disp, which scales the gradients of the
+ * attended branches, is evaluated from the low-resolution cost + column statistics exactly as
+ * dfm_frustum_to_voxel_fused_fwd does; no (B, 1, ds, hs, ws) tensor is read. */
+DFM_API int dfm_frustum_to_voxel_fused_bwd(const dfm_f2v_desc *desc, const void *grad_out, const void *cost,
+                                           const float *col_max, const float *col_sum, int32_t head_scale,
+                                           const float *coords, const float *cam2img, float *grad_stereo,
+                                           float *grad_sem, void *workspace, size_t workspace_bytes,
+                                           void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* voxel_sample (voxel volume -> frustum), point_fusion.py:324-410          */
@@ -696,6 +704,19 @@ DFM_API int dfm_depth_loss_fwd(const dfm_depth_loss_desc *desc, const void *dept
 DFM_API int dfm_depth_loss_bwd(const dfm_depth_loss_desc *desc, const void *depth_volumes,
                                const float *depth_img, const float *depth_samples,
                                const float *grad_pixel_loss, void *grad_volumes, void *stream);
+/* DepthHead.loss fused with the depth head (training): `cost` is the LOW-RESOLUTION
+ * (B, 1, D/s, h/s, w/s) volume [desc->dtype] that DepthHead.forward upsamples (desc->num_depths / h / w are
+ * the upsampled sizes, s = head_scale); the logits of a valid pixel's column are evaluated on the fly with
+ * dfm_depth_head_fwd's arithmetic (pixel_loss is bit-identical to dfm_depth_loss_fwd on the materialised
+ * depth_volumes), and the backward adds grad_pixel_loss * d pixel_loss / d logits through the transposed
+ * upsample into grad_cost (B, 1, D/s, h/s, w/s) FP32, zero-filled (or pre-accumulated) by the caller --
+ * what dfm_depth_loss_bwd + dfm_depth_head_bwd(grad_volumes) compute through two (B, D, h, w) tensors. */
+DFM_API int dfm_depth_loss_fused_fwd(const dfm_depth_loss_desc *desc, const void *cost, int32_t head_scale,
+                                     const float *depth_img, const float *depth_samples,
+                                     float *pixel_loss, unsigned char *valid, void *stream);
+DFM_API int dfm_depth_loss_fused_bwd(const dfm_depth_loss_desc *desc, const void *cost, int32_t head_scale,
+                                     const float *depth_img, const float *depth_samples,
+                                     const float *grad_pixel_loss, float *grad_cost, void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* fused GroupNorm (+ReLU) of the aggregation stacks                        */

@@ -230,8 +230,6 @@ def test_fused_depth_head_is_bit_identical_to_the_materialised_pipeline(path, dt
     assert float(ref[:, C:].abs().sum()) > 0   # the distribution-weighted half is not trivially zero
     assert torch.equal(pred2, pred)
     assert torch.equal(lazy.materialize(), soft)
-    with pytest.raises(RuntimeError, match='inference only'):
-        pkg.frustum_to_voxel_sample(stereo.clone().requires_grad_(True), lazy, metas, sem, coords, cfg)
 
 
 @pytest.mark.gpu
