@@ -691,7 +691,9 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
         why = self.why_not(x)
         if why is None:
             return self.forward_fused(x)
-        if self.kernel_size == (3, 3):  # the 1x1 convolutions built through convbn() are torch's by design
+        # the 1x1 convolutions built through convbn() are torch's by design; so is everything while autograd
+        # records (the 2-D MFMA path is inference-only: modules._channels_last_2d keeps the necks NCHW then)
+        if self.kernel_size == (3, 3) and not (torch.is_grad_enabled() and (x.requires_grad or self.training)):
             _torch_path(self, x, why)
         return super().forward(x)
 
@@ -722,7 +724,8 @@ class MfmaConvTranspose2d(nn.ConvTranspose2d, _Mfma2dMixin):
         if why is None:
             return conv2d_g(x, self._packed2d(self.in_channels, self.out_channels, True), self.out_channels,
                             transposed=True)
-        _torch_path(self, x, why)
+        if not (torch.is_grad_enabled() and (x.requires_grad or self.training)):  # (inference-only path, as above)
+            _torch_path(self, x, why)
         return super().forward(x, output_size)
 
 
