@@ -540,10 +540,12 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
         ghz = cyc / max(ref, 1) / 10.0
         part = {'tile_store_probe_gbps': round(tile_gbps, 1), 'linear_fill_gbps': round(probe(out.zero_), 1),
                 'shader_clock_ghz_under_fma_load': round(ghz, 3),
-                'class': 'fast' if tile_gbps >= 4800.0 else 'slow',
+                'class': 'normal-store' if tile_gbps >= 4800.0 else 'slow-store',
                 'note': "zeros written in the tile kernel's store pattern (one 4 KiB run per channel plane per "
-                        'workgroup, dfm_store_probe) and as a linear fill; parts whose tile-pattern rate is '
-                        'below ~4.8 TB/s cap the sweep near 0.50 of the roofline'}
+                        'workgroup, dfm_store_probe) and as a linear fill, and the shader clock under an FMA load on '
+                        'every CU (dfm_clock_probe).  Parts whose tile-pattern rate is below ~4.8 TB/s cap the sweep '
+                        'near 0.50 of the roofline; parts with a normal store rate have also been seen to run the same '
+                        'binary at 0.50 instead of 0.63 (profiles/r03_c38_*: 5.3 TB/s probe, 1.98 GHz)'}
     if explicit or args.channels_last or args.no_autotune or w.get('nhwc'):
         os.environ['DFM_AUTOTUNE'] = '0'  # keep the first launch from tuning by itself
     for _ in range(args.warmup):
