@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Cycles per phase of workgroup 0 of the matrix-product plane-sweep backward (debug build:
-DFM_HIP_LIB=.../libdfm_hip_dbg.so).  N* shape, one sample.  Phases per plane iteration:
-0 loop overhead, 1 produce (the wave whose turn it is), 2 wait for this plane's gradient words + issue
-the next plane's, 3 meta, 4 flush, 5 fragments + MFMA, 6 barrier, 7 final flush."""
+DFM_HIP_LIB=.../libdfm_hip_dbg.so).  N* shape, one sample.  Phases per step: 0 loop overhead, 8 footprints
+of step t + 2 (the wave whose turn it is), 1 fragment image of step t + 1 (another wave), 2 wait for this
+step's gradient words + issue the next step's, 3 meta, 4 flush, 5 fragments + MFMA, 6 barrier, 7 final
+flush.  (The debug build runs ~2.5x slower than the release build: relative numbers only.)"""
 import ctypes, importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
