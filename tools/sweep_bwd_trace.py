@@ -32,7 +32,7 @@ lib.dfm_debug_set_bm_trace(ctypes.c_void_p(buf.data_ptr()))
 run()
 lib.dfm_debug_set_bm_trace(None)
 t = buf.cpu().numpy()[:128].reshape(2, 64)[:, :48].reshape(2, 4, 12).astype(np.float64)
-names = ['loop', 'produce(tail)', 'grad wait+issue', 'meta', 'flush', 'frag+mfma', 'barrier', 'final flush', 'table', '-', '-', '-']
+names = ['loop', 'image', 'grad wait+issue', 'meta', 'flush', 'frag+mfma', 'barrier', 'final flush', 'footprints', '-', '-', '-']
 for half, nm in ((0, 'cur'), (1, 'prev')):
     print(f'{nm} map, workgroup 0 (cycles summed over its planes; per plane of {D} in brackets)')
     for wv in range(4):
