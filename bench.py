@@ -545,7 +545,8 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
                         'workgroup, dfm_store_probe) and as a linear fill, and the shader clock under an FMA load on '
                         'every CU (dfm_clock_probe).  Parts whose tile-pattern rate is below ~4.8 TB/s cap the sweep '
                         'near 0.50 of the roofline; parts with a normal store rate have also been seen to run the same '
-                        'binary at 0.50 instead of 0.63 (profiles/r03_c38_*: 5.3 TB/s probe, 1.98 GHz)'}
+                        'binary at 0.50 instead of 0.63 with the same shader clock (profiles/r03_c38_*, r03_c52_*: 5.3 TB/s probe vs 5.5-5.65, '
+                        '1.98-2.07 GHz on both kinds): the probes bracket the cause, they do not name it'}
     if explicit or args.channels_last or args.no_autotune or w.get('nhwc'):
         os.environ['DFM_AUTOTUNE'] = '0'  # keep the first launch from tuning by itself
     for _ in range(args.warmup):
