@@ -52,6 +52,9 @@ struct Launch {
     int planes;      // depth planes per workgroup
     int band_chunk;  // adjacent bands scheduled back to back
     int ppl;         // lattice points per lane
+    int align;       // tile boundaries: multiples of this many points (8, 16, 32 or 64)
+    int pipe;        // LDS tile kernel body: 1 serial (stage | barrier | blend + store | barrier),
+                     // 2 pipelined (two buffers, one barrier per block, stores never waited for)
 };
 
 struct TuneKey {
@@ -315,6 +318,8 @@ struct TileGrid {
     int dgroups;           // ceil(D / planes)
     int blocks_per_group;  // channel blocks one workgroup sweeps
     int band_chunk;        // adjacent bands scheduled together (see the block id map)
+    int align;             // tile boundaries are multiples of this many points of the flat (d,h,w) index
+                           // (a power of two >= 8): 32 points = 64 bytes of bf16, a whole memory-side write
     unsigned long long *trace;  // perf experiments only: per-phase s_memtime stamps
     int ablate;            // perf experiments only (DFM_ABLATE): 1 no staging,
                            // 2 no volume stores, 4 no taps/blend; results are wrong
@@ -324,7 +329,15 @@ struct TileGrid {
 // LDS == false: same lane/point/store structure, taps straight from the blocked
 //               map in global memory; runs only the tiles flagged by the LDS
 //               kernel (spill list) -- or, as sweep_tile_kernel<.., false>, every tile.
-template <typename T, int NT, bool LDS, int V>
+// buffer stride of the pipelined (PIPE) body, in 16-byte slots: two buffers + the 8 scratch slots
+// make 78.4 KiB, so two workgroups share a CU's 160 KiB with room for the allocation granule; the
+// stride is a compile-time constant
+// because the second buffer is addressed through the 16-bit immediate offset of ds_read_b128
+constexpr int PIPE_BUF_SLOTS = 2504;  // 8 rows of 311 pixels + pad
+constexpr int PIPE_LDS_BYTES = (8 + 2 * PIPE_BUF_SLOTS) * 16;
+template <int N> struct IntC { static constexpr int value = N; };
+
+template <typename T, int NT, bool LDS, int V, bool PIPE = false>
 __device__ __forceinline__ void tile_body(
     const int bid, const SweepGeom &g, const SweepFast &fast, const TileGrid &tg, int lds_slots,
     const uint4 *__restrict__ cur_blk, const uint4 *__restrict__ prev_blk,
@@ -338,6 +351,7 @@ __device__ __forceinline__ void tile_body(
     // waves fit a CU for the same tile (the wave's run per channel is 512 B instead of 1 KiB).
     static_assert(V == 4 || V == 8, "points per lane");
     static_assert(V * sizeof(T) == 16 || V * sizeof(T) == 8, "8- or 16-byte stores");
+    static_assert(LDS || !PIPE, "the pipelined body is an LDS-staged body");
     constexpr int VW = V * (int)sizeof(T) / 4;  // dwords per channel vector
     constexpr int PAD = 8; // slots in front of the rows (keeps q = p + PAD >= 7)
     constexpr int SLAB = 8;  // slab starts at a multiple of 8 so the swizzle stays inside it
@@ -380,17 +394,31 @@ __device__ __forceinline__ void tile_body(
     const int d_tile = dgroup * tg.planes + tid / lanes_per_plane;
     const int tid_p = tid % lanes_per_plane;
     const long long hw_ll = (long long)g.h_out * g.w_out;
+    // A plane's tiles cover [a0, a1): from the 16-byte vector that holds the plane's first point to
+    // the one that holds the next plane's.  The cuts BETWEEN the bands of a plane are multiples of
+    // tg.align points of the flat index (band_pts is one), so that two workgroups never share a
+    // memory-side write: with 16-byte-aligned cuts every band boundary of every channel plane left
+    // two partial 64-byte writes behind, and the store stream alone ran 27 % slower
+    // (profiles/r04_c2_*: 5.52 -> 4.35 ms with nothing but the stores left in the kernel).
     const long long a0 = (d_tile * hw_ll) & ~7ll;
     const long long a1 = d_tile >= g.D - 1 ? g.N : (((d_tile + 1) * hw_ll) & ~7ll);
-    const long long t_end = d_tile < g.D ? min(a0 + (long long)(band + 1) * tg.band_pts, a1) : 0;
-    const long long n0 = a0 + (long long)band * tg.band_pts + (long long)tid_p * V;
-    const bool active = n0 < t_end;
+    const long long base = a0 & ~(long long)(tg.align - 1);
+    const long long t_end = d_tile < g.D ? min(base + (long long)(band + 1) * tg.band_pts, a1) : 0;
+    const long long n0 = base + (long long)band * tg.band_pts + (long long)tid_p * V;
+    const bool active = n0 >= a0 && n0 < t_end;
     const int W = g.w_in, H = g.h_in;
     const int HW = H * W;
 
     if (LDS) {
         // slot 0: bbox scratch
-        if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; }
+        if (tid == 0) {
+            bb[0] = 0x7fffffff;
+            bb[1] = -1;
+            // zero corner of each buffer: slot 0 of the slab (q < PAD is never a pixel, and the
+            // swizzle keeps slots 0..7 among themselves); the DMA never writes it
+            lds[SLAB] = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (PIPE) lds[SLAB + PIPE_BUF_SLOTS] = make_uint4(0u, 0u, 0u, 0u);
+        }
         __syncthreads();
     }
 
@@ -413,7 +441,7 @@ __device__ __forceinline__ void tile_body(
             else sweep_point_map<0>(g, fast, Pb, Pib, Tb, depths[d], hi, wi, sx, sy);
             int rN, rS, ix;
             uint32_t ok = footprint(sx, sy, H, W, rN, rS, ix, fw[j], fn[j]);
-            // A tile starts at a multiple of 8 in the flat index, so its first vector can
+            // A plane's first tile starts at a multiple of 8 in the flat index, so its first vector can
             // hold up to 7 points of the PREVIOUS depth plane (last image row) next to
             // points of the first rows of this one: staging both would take the whole
             // map.  The LDS pass writes zeros there; sweep_patch_kernel fills them in.
@@ -461,7 +489,8 @@ __device__ __forceinline__ void tile_body(
         }
         cnt = (y1 - y0 + 1) * W;  // pixels (16-B slots) to stage per block
         nslots = (PAD + cnt + 1 + 7) & ~7;
-        const bool fits = SLAB + nslots <= lds_slots;
+        const bool fits = PIPE ? nslots <= min(PIPE_BUF_SLOTS, (lds_slots - SLAB) / 2)
+                               : SLAB + nslots <= lds_slots;
         if (!fits) {
             // rows beyond the LDS budget: queue the tile for the next pass (once per tile)
             if (tid == 0 && blk_lo_ovr <= 0) spill_list[1 + atomicAdd(&spill_list[0], 1)] = bid;
@@ -471,12 +500,8 @@ __device__ __forceinline__ void tile_body(
         // the staged rows + PAD), or the zero slot for an out-of-bounds corner.
         // Nothing in the channel loop depends on the in-bounds bits any more.
         const int off = PAD - y0 * W;
-        // zero corner: slab slot 0 (q < PAD is never a pixel, and the swizzle keeps
-        // slots 0..7 among themselves), zeroed here once
+        // zero corner: slab slot 0, zeroed with the scratch slot above
         constexpr int ZERO = SLAB << 4;
-        if (tid == 0) {
-            lds[SLAB] = make_uint4(0u, 0u, 0u, 0u);
-        }
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const uint32_t ok = (okbits >> (4 * j)) & 15u;
@@ -521,7 +546,11 @@ __device__ __forceinline__ void tile_body(
     TRACE_STAMP();
 
     // blend the V points x CB channels of one channel block and store them
-    auto compute_store = [&](int blk, const uint4 *gsrc) {
+    // (bufc: which LDS buffer the taps come from -- the pipelined body's second buffer is reached
+    // through the instruction's immediate offset, so the tap addresses never change)
+    auto compute_store = [&](int blk, const uint4 *gsrc, auto bufc) {
+        constexpr int BOFF = decltype(bufc)::value * PIPE_BUF_SLOTS * 16;
+        static_assert(BOFF < 65536, "ds_read_b128 immediate offset");
         const int cbase = blk * CB;
         uint32_t pk[CB][VW];  // per channel: one 16- (or 8-) byte vector of V points
         if (ABLATE(4)) {
@@ -537,18 +566,20 @@ __device__ __forceinline__ void tile_body(
             // LDS returns in order, so lgkmcnt(4) == "point j has landed".
             u32x4_t q[2][4];
             float keep[CB];  // even point of a pair, waiting for its odd partner
-            asm volatile("ds_read_b128 %0, %1" : "=v"(q[0][0]) : "v"(ta[0][0]));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(q[0][1]) : "v"(ta[0][1]));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(q[0][2]) : "v"(ta[0][2]));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(q[0][3]) : "v"(ta[0][3]));
+#define DFM_TAP_READ(dst, addr) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(BOFF))
+            DFM_TAP_READ(q[0][0], ta[0][0]);
+            DFM_TAP_READ(q[0][1], ta[0][1]);
+            DFM_TAP_READ(q[0][2], ta[0][2]);
+            DFM_TAP_READ(q[0][3], ta[0][3]);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const int cb = j & 1, nb = cb ^ 1;
                 if (j + 1 < V) {
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(q[nb][0]) : "v"(ta[j + 1][0]));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(q[nb][1]) : "v"(ta[j + 1][1]));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(q[nb][2]) : "v"(ta[j + 1][2]));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(q[nb][3]) : "v"(ta[j + 1][3]));
+                    DFM_TAP_READ(q[nb][0], ta[j + 1][0]);
+                    DFM_TAP_READ(q[nb][1], ta[j + 1][1]);
+                    DFM_TAP_READ(q[nb][2], ta[j + 1][2]);
+                    DFM_TAP_READ(q[nb][3], ta[j + 1][3]);
                     asm volatile("s_waitcnt lgkmcnt(4)"
                                  : "+v"(q[cb][0]), "+v"(q[cb][1]), "+v"(q[cb][2]), "+v"(q[cb][3]));
                 } else {
@@ -612,7 +643,7 @@ __device__ __forceinline__ void tile_body(
 
     if constexpr (!LDS) {
         for (int blk = blk_lo; blk < blk_hi; ++blk) {
-            compute_store(blk, src);
+            compute_store(blk, src, IntC<0>{});
             src += HW;
         }
     } else {
@@ -633,18 +664,63 @@ __device__ __forceinline__ void tile_body(
         // stage -> barrier -> blend+store -> barrier.  (A double-buffered variant
         // with counted vmcnt measured no faster on MI355X and doubled the LDS per
         // workgroup; profiles/r01_v6_double_buffer_variants.txt.)
-        for (int blk = blk_lo; blk < blk_hi; ++blk) {
+        if constexpr (!PIPE) {
+            for (int blk = blk_lo; blk < blk_hi; ++blk) {
+                stage(SLAB, src);
+                TRACE_STAMP();
+                __syncthreads();  // drains the DMA (vmcnt) and makes the rows visible
+                TRACE_STAMP();
+                if (active) compute_store(blk, src, IntC<0>{});
+                TRACE_STAMP();
+                src += HW;
+                __syncthreads();  // everyone is done with the rows before the refill
+                TRACE_STAMP();
+            }
+        } else {
+            // Pipelined body: two LDS buffers, ONE barrier per channel block, and no wait for the
+            // volume stores.  Per block k:   wait for DMA(k) | barrier | issue DMA(k+1) into the
+            // other buffer | blend + store block k.
+            // vmcnt counts loads and stores of a wave in issue order (gfx9: one in-order counter), so
+            // "DMA(k) has landed" is "everything but the newest stores(k-1) has retired": a counted
+            // vmcnt(CB) (one store per channel of the block and lane).  The serial body above waits vmcnt(0) before
+            // its barrier -- for the DMA AND for the acknowledgement of the previous block's stores,
+            // which on parts with a slow HBM write path is what the kernel then runs at
+            // (profiles/r03_c53_*: the stores add 1.2 ms on a fast part, 2.7 ms on a slow one, to a
+            // sampling skeleton of the same 4.5 ms).  Here a store has a whole block (~3 us) to be
+            // acknowledged, the DMA of the next rows flies under the blend, and the barrier that
+            // protected the single buffer against its refill is gone.
+            // A wave with no lattice point issues no stores: it waits vmcnt(0).
+            const bool wave_stores = __any(active) != 0;  // wave-uniform
+            auto wait_rows = [&]() {
+                if (wave_stores && !ABLATE(2))
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(CB) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            };
             stage(SLAB, src);
             TRACE_STAMP();
-            __syncthreads();  // drains the DMA (vmcnt) and makes the rows visible
-            TRACE_STAMP();
-            if (active) compute_store(blk, src);
-            TRACE_STAMP();
-            src += HW;
-            __syncthreads();  // everyone is done with the rows before the refill
-            TRACE_STAMP();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            for (int blk = blk_lo;;) {
+                if (blk + 1 < blk_hi) stage(SLAB + PIPE_BUF_SLOTS, src + HW);
+                TRACE_STAMP();
+                if (active) compute_store(blk, src, IntC<0>{});
+                TRACE_STAMP();
+                src += HW;
+                if (++blk >= blk_hi) break;
+                wait_rows();
+                TRACE_STAMP();
+                if (blk + 1 < blk_hi) stage(SLAB, src + HW);
+                TRACE_STAMP();
+                if (active) compute_store(blk, src, IntC<1>{});
+                TRACE_STAMP();
+                src += HW;
+                if (++blk >= blk_hi) break;
+                wait_rows();
+                TRACE_STAMP();
+            }
         }
     }
+#undef DFM_TAP_READ
 }
 
 #ifndef DFM_TILE_WAVES
@@ -653,15 +729,15 @@ __device__ __forceinline__ void tile_body(
 // one workgroup per tile; LDS == false is the "direct taps for every tile" mode.
 // V * sizeof(T) == 8 (bf16, 4 points per lane): compiled for 4 waves per SIMD (<= 128 VGPRs),
 // i.e. two 512-lane workgroups or one 1024-lane workgroup per CU.
-template <typename T, int NT, bool LDS, int V>
+template <typename T, int NT, bool LDS, int V, bool PIPE = false>
 __global__ __launch_bounds__(NT, (LDS ? (V * sizeof(T) == 8 ? 4 : DFM_TILE_WAVES) : 1)) void sweep_tile_kernel(
     SweepGeom g, SweepFast fast, TileGrid tg, int lds_slots, const uint4 *__restrict__ cur_blk,
     const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
     const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
     T *__restrict__ out, int *__restrict__ spill_list)
 {
-    tile_body<T, NT, LDS, V>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk, depths, P, Pinv,
-                             Tm, out, spill_list);
+    tile_body<T, NT, LDS, V, PIPE>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk, depths, P,
+                                   Pinv, Tm, out, spill_list);
 }
 
 // the tiles the LDS pass queued (spill_list[0] = count), a fixed small grid strides over them:
@@ -702,12 +778,12 @@ __global__ __launch_bounds__(NT, (V * sizeof(T) == 8 ? 4 : DFM_TILE_WAVES)) void
     }
 }
 
-// The <= 7 lattice points in front of every depth-plane boundary that the LDS pass
+// The < align lattice points in front of every depth-plane boundary that the LDS pass
 // masked (see sweep_tile_kernel): direct taps, scalar stores.  grid = (D-1, 2, B),
-// block = 8 points x 32 channel-block lanes.
+// block = 8 points x 32 channel-block lanes, looping over the boundary's points.
 template <typename T>
 __global__ __launch_bounds__(256) void sweep_patch_kernel(
-    SweepGeom g, SweepFast fast, const uint4 *__restrict__ cur_blk,
+    SweepGeom g, SweepFast fast, int align, const uint4 *__restrict__ cur_blk,
     const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
     const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
     T *__restrict__ out)
@@ -717,27 +793,28 @@ __global__ __launch_bounds__(256) void sweep_patch_kernel(
     const int half = blockIdx.y, b = blockIdx.z;
     const long long hw = (long long)g.h_out * g.w_out;
     const long long edge = d_next * hw;
-    const long long n = (edge & ~7ll) + (threadIdx.x >> 5);
-    if (n >= edge) return;  // this boundary has fewer foreign points
     const int d = d_next - 1;
-    const int rem = (int)(n - (long long)d * hw);
-    const int hi = rem / g.w_out, wi = rem - hi * g.w_out;
-    float sx, sy;
-    if (half) sweep_point_map<1>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, sx, sy);
-    else sweep_point_map<0>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, sx, sy);
-    const Tap t = make_tap(sx, sy, g.h_in, g.w_in);
     const int HW = g.h_in * g.w_in;
-    const int i00 = t.iy * g.w_in + t.ix, i01 = i00 + t.dx;
-    const int i10 = i00 + t.dy * g.w_in, i11 = i10 + t.dx;
     const uint4 *mb = (half ? prev_blk : cur_blk) + (size_t)b * g.nblk * HW;
-    T *o = out + ((size_t)b * 2 * g.C + (size_t)half * g.C) * g.N + n;
-    for (int blk = threadIdx.x & 31; blk < g.nblk; blk += 32) {
-        const uint4 *q = mb + (size_t)blk * HW;
-        float r[CB];
-        blend<CB>(t, q[i00], q[i01], q[i10], q[i11], r);
+    (void)align;
+    for (long long n = (edge & ~7ll) + (threadIdx.x >> 5); n < edge; n += 8) {
+        const int rem = (int)(n - (long long)d * hw);
+        const int hi = rem / g.w_out, wi = rem - hi * g.w_out;
+        float sx, sy;
+        if (half) sweep_point_map<1>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, sx, sy);
+        else sweep_point_map<0>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], hi, wi, sx, sy);
+        const Tap t = make_tap(sx, sy, g.h_in, g.w_in);
+        const int i00 = t.iy * g.w_in + t.ix, i01 = i00 + t.dx;
+        const int i10 = i00 + t.dy * g.w_in, i11 = i10 + t.dx;
+        T *o = out + ((size_t)b * 2 * g.C + (size_t)half * g.C) * g.N + n;
+        for (int blk = threadIdx.x & 31; blk < g.nblk; blk += 32) {
+            const uint4 *q = mb + (size_t)blk * HW;
+            float r[CB];
+            blend<CB>(t, q[i00], q[i01], q[i10], q[i11], r);
 #pragma unroll
-        for (int k = 0; k < CB; ++k)
-            if (blk * CB + k < g.C) o[(size_t)(blk * CB + k) * g.N] = elem<T>::store(r[k]);
+            for (int k = 0; k < CB; ++k)
+                if (blk * CB + k < g.C) o[(size_t)(blk * CB + k) * g.N] = elem<T>::store(r[k]);
+        }
     }
 }
 
@@ -1340,7 +1417,7 @@ size_t flag_bytes(const dfm_sweep_desc *d)
 {
     const int V = d->dtype == DFM_BF16 ? 8 : 4;
     const long long hw = (long long)d->h_out * d->w_out;
-    const long long bands = (hw + 7 + 64ll * V - 1) / (64ll * V);  // smallest tile (one wave per plane)
+    const long long bands = (hw + 7 + 63 + 64ll * V - 1) / (64ll * V);  // smallest tile (one wave per plane), coarsest alignment
     const long long nblk = (d->channels + V - 1) / V;  // worst case: one block per group
     // int32 counter + one int32 tile id per (worst-case) tile
     return ((size_t)(1 + bands * d->num_depths * 2 * d->batch * nblk) * 4 + 255) & ~(size_t)255;
@@ -1363,11 +1440,17 @@ int resolve(const dfm_sweep_desc *d, const dfm_sweep_opts *o, Launch &L)
     const int CB = d->dtype == DFM_BF16 ? 8 : 4;
     L.kernel = o ? o->kernel : 0;
     L.lanes = o && o->lanes_per_workgroup ? o->lanes_per_workgroup : 256;
-    L.lds_kib = o && o->lds_kib ? o->lds_kib : 52;
+    L.lds_kib = o && o->lds_kib ? o->lds_kib : 0;  // 0: resolved below (depends on the body)
     L.bpg = o && o->blocks_per_group ? o->blocks_per_group : (1 << 20);
     L.planes = o && o->planes_per_workgroup ? o->planes_per_workgroup : 2;
     L.band_chunk = o && o->bands_per_chunk ? o->bands_per_chunk : 1;
     L.ppl = o && o->points_per_lane ? o->points_per_lane : CB;
+    L.align = o && o->store_align_points ? o->store_align_points : 8;
+    if (L.align != 8 && L.align != 16 && L.align != 32 && L.align != 64)
+        return fail(DFM_ERR_INVALID_ARG, "opts: store_align_points in {8,16,32,64}%s");
+    L.pipe = o && o->pipeline ? o->pipeline : 2;
+    if (L.pipe != 1 && L.pipe != 2) return fail(DFM_ERR_INVALID_ARG, "opts: pipeline must be 0, 1 or 2%s");
+    if (!L.lds_kib) L.lds_kib = L.pipe == 2 ? 80 : 52;
     if (L.kernel < 0 || L.kernel > 4) return fail(DFM_ERR_INVALID_ARG, "opts: kernel must be 0..4%s");
     if (L.lanes != 128 && L.lanes != 256 && L.lanes != 512 && L.lanes != 1024)
         return fail(DFM_ERR_INVALID_ARG, "opts: lanes_per_workgroup in {128,256,512,1024}%s");
@@ -1397,8 +1480,14 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
     while ((NT / 64) % tg.planes) --tg.planes;  // whole waves per plane
     tg.dgroups = (g.D + tg.planes - 1) / tg.planes;
     const long long per_plane = (long long)(NT / tg.planes) * V;  // points per plane and tile
-    tg.bands = (int)((hw + 7 + per_plane - 1) / per_plane);
-    tg.band_pts = (int)((((hw + 7 + tg.bands - 1) / tg.bands) + 7) & ~7ll);
+    // tile boundaries at multiples of L.align points where the tile shape allows it (a tile holds
+    // per_plane points of a plane; per_plane is a multiple of 256 except for test-sized workgroups)
+    tg.align = (int)std::min<long long>(L.align, per_plane & -per_plane);
+    const long long am = tg.align - 1;
+    // a plane's tiles span at most hw + 7 points (its first vector may start 7 points early) plus
+    // the am points between the aligned base of the cuts and that vector
+    tg.bands = (int)((hw + 7 + am + per_plane - 1) / per_plane);
+    tg.band_pts = (int)((((hw + 7 + am + tg.bands - 1) / tg.bands) + am) & ~am);
     tg.blocks_per_group = bpg;
     tg.band_chunk = std::max(1, std::min(L.band_chunk, tg.bands));
     tg.trace = nullptr;
@@ -1417,15 +1506,26 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
     int rc = DFM_OK;
     const SweepFast fast = make_fast(d);
     if (which == 2) {
-        const void *kern = (const void *)sweep_tile_kernel<T, NT, true, V>;
-        rc = ensure_dynamic_lds(kern, lds_bytes);
-        if (rc != DFM_OK) return rc;
         int *spill2 = (int *)((char *)spill_list + flag_bytes(d));
         HIP_TRY(hipMemsetAsync(spill_list, 0, 4, st));
         HIP_TRY(hipMemsetAsync(spill2, 0, 4, st));
-        hipLaunchKernelGGL((sweep_tile_kernel<T, NT, true, V>), dim3((unsigned)nb), dim3(NT),
-                           lds_bytes, st, g, fast, tg, lds_bytes / 16, cur_blk, prev_blk, depths, P,
-                           Pinv, Tm, out, spill_list);
+        if (L.pipe == 2) {
+            // fixed 80 KiB - 128 B (two buffers at a compile-time stride); lds_kib only lowers the
+            // budget a tile's rows are checked against (tests force spills that way)
+            const void *kern = (const void *)sweep_tile_kernel<T, NT, true, V, true>;
+            rc = ensure_dynamic_lds(kern, PIPE_LDS_BYTES);
+            if (rc != DFM_OK) return rc;
+            hipLaunchKernelGGL((sweep_tile_kernel<T, NT, true, V, true>), dim3((unsigned)nb), dim3(NT),
+                               PIPE_LDS_BYTES, st, g, fast, tg, std::min(lds_bytes, PIPE_LDS_BYTES) / 16,
+                               cur_blk, prev_blk, depths, P, Pinv, Tm, out, spill_list);
+        } else {
+            const void *kern = (const void *)sweep_tile_kernel<T, NT, true, V>;
+            rc = ensure_dynamic_lds(kern, lds_bytes);
+            if (rc != DFM_OK) return rc;
+            hipLaunchKernelGGL((sweep_tile_kernel<T, NT, true, V>), dim3((unsigned)nb), dim3(NT),
+                               lds_bytes, st, g, fast, tg, lds_bytes / 16, cur_blk, prev_blk, depths, P,
+                               Pinv, Tm, out, spill_list);
+        }
         // tiles whose rows exceeded the LDS budget (about 1 % at N*): once more with 144 KiB of
         // LDS, split by channel block; then direct taps for what is left
         {
@@ -1444,7 +1544,7 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
                            cur_blk, prev_blk, depths, P, Pinv, Tm, out, spill2);
         if (g.D > 1 && hw % 8 != 0)
             hipLaunchKernelGGL(sweep_patch_kernel<T>, dim3(g.D - 1, 2, d->batch), dim3(256), 0, st,
-                               g, fast, cur_blk, prev_blk, depths, P, Pinv, Tm, out);
+                               g, fast, tg.align, cur_blk, prev_blk, depths, P, Pinv, Tm, out);
     } else {
         hipLaunchKernelGGL((sweep_tile_kernel<T, NT, false, V>), dim3((unsigned)nb), dim3(NT), 16,
                            st, g, fast, tg, 0, cur_blk, prev_blk, depths, P, Pinv, Tm, out,
@@ -1570,7 +1670,7 @@ bool takes_lds_tiles(const dfm_sweep_desc *d, const void *out)
 
 extern "C" {
 
-DFM_API int dfm_version(void) { return 2; }
+DFM_API int dfm_version(void) { return 3; }
 DFM_API const char *dfm_last_error(void) { return g_err; }
 DFM_API int dfm_plane_sweep_last_kernel(void) { return g_last_kernel; }
 DFM_API int dfm_plane_sweep_bwd_last_kernel(void) { return g_last_bwd_kernel.load(); }

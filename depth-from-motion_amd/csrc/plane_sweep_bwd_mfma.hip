@@ -28,10 +28,14 @@
 // inputs (sweep_zoom_split: the sample positions of the four lattice corners), so every (plane, point)
 // is handled by exactly one of them.
 //
-// Numerics: the weights are rounded to bf16 (the gradients already are), products and sums are fp32
-// in the MFMA.  A tile whose window sum turns non-finite is redone by a per-value path with plain
-// float atomics, so Inf / NaN gradients propagate to their four taps exactly as in torch (a matrix
-// product would smear 0 * Inf over the window).
+// Numerics: the fp32 bilinear weight w enters the matrix product as TWO bf16 terms, hi = bf16(w) and
+// lo = bf16(w - hi) (w - hi is exact in fp32), each in its own fragment image: |w - hi - lo| <= 2^-18 |w|,
+// the gradients are bf16 already, products are exact and sums fp32 in the MFMA -- i.e. fp32 arithmetic
+// on (to 2^-18) fp32 weights, like the reference's autograd of grid_sample; a single bf16 term
+// (round 3) was a 2^-9 relative error per term.  Costs a second fragment read + MFMA per fragment on a
+// pipe that was a quarter busy.  A tile whose window sum turns non-finite is redone by a per-value path
+// with plain float atomics, so Inf / NaN gradients propagate to their four taps exactly as in torch (a
+// matrix product would smear 0 * Inf over the window).
 #include <algorithm>
 #include <type_traits>
 
@@ -51,7 +55,8 @@ constexpr int BM_NT = 3;    //                     16-column blocks
 constexpr int BM_MT = 2;    // 16-channel blocks per wave
 constexpr int BM_SLOTS = 3; // image rows one lattice row may touch in one plane
 constexpr int BM_FRAG = 1024;                                  // bytes of one B fragment (64 lanes x 16)
-constexpr int BM_IMG = BM_TH * BM_SLOTS * BM_NT * BM_FRAG;     // fragment image of one plane: 18 KB
+constexpr int BM_IMG1 = BM_TH * BM_SLOTS * BM_NT * BM_FRAG;    // fragment image of one plane and one weight term: 18 KB
+constexpr int BM_IMG = 2 * BM_IMG1;                            // [hi | lo] terms of the weights
 constexpr int BM_WAVES = 4;                                    // waves per tile, at most
 constexpr int BM_RING = 3;                                     // planes of footprints ahead of the image
 // LDS of one tile (a workgroup holds two neighbouring tiles)
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned off = tl[q];
-            if (off != 0xffffu) img16[off] = 0;
+            if (off != 0xffffu) { img16[off] = 0; img16[off + BM_IMG1 / 2] = 0; }
         }
         const int xmin = min(x0lo, x1lo), xmax = max(x0hi, x1hi), ymin = min(y0lo, y1lo), ymax = max(y0hi, y1hi);
         int flags = 0;
@@ -324,7 +329,9 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
                     const int y = iyn + (q >> 1), n = ixw + (q & 1) - xb;
                     const int fr = (phh * BM_SLOTS + (y - rbase)) * BM_NT + (n >> 4);
                     off = (unsigned)(fr * (BM_FRAG / 2) + ((pk >> 3) * 16 + (n & 15)) * 8 + (pk & 7));
-                    img16[off] = f32_to_bf16(wq[q]);
+                    const bf16_t hi = f32_to_bf16(wq[q]);
+                    img16[off] = hi;
+                    img16[off + BM_IMG1 / 2] = f32_to_bf16(wq[q] - bf16_to_f32(hi));
                     bits |= 1u << ((y - yb) * BM_NT + (n >> 4));
                 }
                 tl[q] = (unsigned short)off;
@@ -510,15 +517,18 @@ __global__ __launch_bounds__(2 * 64 * BM_WAVES, 2) void sweep_bwd_mfma_kernel(
 #pragma unroll
                 for (int r = 0; r < BM_R; ++r) {
                     if (!((bits >> (r * BM_NT)) & 7u)) continue;
-                    bf16x8_t bfr[BM_NT];
 #pragma unroll
-                    for (int nt = 0; nt < BM_NT; ++nt)
-                        bfr[nt] = *(const bf16x8_t *)(imh + (r * BM_NT + nt) * BM_FRAG);
+                    for (int term = 0; term < 2; ++term) {  // hi, then lo
+                        bf16x8_t bfr[BM_NT];
 #pragma unroll
-                    for (int nt = 0; nt < BM_NT; ++nt)
+                        for (int nt = 0; nt < BM_NT; ++nt)
+                            bfr[nt] = *(const bf16x8_t *)(imh + term * BM_IMG1 + (r * BM_NT + nt) * BM_FRAG);
 #pragma unroll
-                        for (int mt = 0; mt < BM_MT; ++mt)
-                            acc[mt][r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][hh], bfr[nt], acc[mt][r][nt], 0, 0, 0);
+                        for (int nt = 0; nt < BM_NT; ++nt)
+#pragma unroll
+                            for (int mt = 0; mt < BM_MT; ++mt)
+                                acc[mt][r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][hh], bfr[nt], acc[mt][r][nt], 0, 0, 0);
+                    }
                 }
             }
             touched |= bits0 | bits1;

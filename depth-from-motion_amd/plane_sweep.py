@@ -144,12 +144,13 @@ class _Workspace:
 _tls = threading.local()
 _OPT_FIELDS = {'kernel': 'kernel', 'lanes': 'lanes_per_workgroup', 'lds_kib': 'lds_kib',
                'blocks_per_group': 'blocks_per_group', 'planes': 'planes_per_workgroup',
-               'bands_per_chunk': 'bands_per_chunk', 'points_per_lane': 'points_per_lane'}
+               'bands_per_chunk': 'bands_per_chunk', 'points_per_lane': 'points_per_lane',
+               'pipeline': 'pipeline', 'store_align': 'store_align_points'}
 
 
 def make_opts(**kw):
     """dfm_sweep_opts from keywords (kernel, lanes, lds_kib, blocks_per_group, planes,
-    bands_per_chunk, points_per_lane); unspecified fields = library default."""
+    bands_per_chunk, points_per_lane, pipeline, store_align); unspecified fields = library default."""
     o = _capi.SweepOpts()
     for k, v in kw.items():
         setattr(o, _OPT_FIELDS[k], int(v or 0))
@@ -312,40 +313,50 @@ class _PlaneSweepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         depths, P, Pinv, T = ctx.saved_tensors
-        desc = ctx.desc
-        lib = _capi.lib()
-        device = grad_out.device
-        shape = (desc.batch, desc.channels, desc.h_in, desc.w_in)
-        g_cur = torch.zeros(shape, dtype=torch.float32, device=device)
-        g_prev = torch.zeros(shape, dtype=torch.float32, device=device)
-        opts = _current_opts()
-        if _bwd_kernel is not None:
-            opts = make_opts(kernel=_bwd_kernel)
-        if (opts is None and not grad_out.is_contiguous() and grad_out.dim() == 5 and
-                grad_out.is_contiguous(memory_format=torch.channels_last_3d)):
-            # the NDHWC stack's gradient is read where it lies (the 236 MB conversion to the reference
-            # layout cost 2.2 ms of a 20 ms training step at config K)
-            # up to 2 GB: re-laid by the library's LDS-tile transpose (copy speed) into a scratch of the
-            # volume's size; larger volumes are read in place (no extra memory)
-            nbytes = grad_out.numel() * grad_out.element_size()
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes <= (2 << 30) else None
-            with torch.cuda.device(device):
-                rc = lib.dfm_plane_sweep_bwd_channels_last(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P),
-                                                           _ptr(Pinv), _ptr(T), _ptr(g_cur), _ptr(g_prev),
-                                                           _ptr(ws) if ws is not None else None,
-                                                           nbytes if ws is not None else 0, _stream_ptr(device))
-            if rc == 0:
-                return g_cur.to(ctx.in_dtype), g_prev.to(ctx.in_dtype), None, None, None, None, None, None
-            if rc != _capi.DFM_ERR_UNSUPPORTED:
-                _capi.check(rc)
-        grad_out = grad_out.contiguous()
-        with torch.cuda.device(device):
-            _capi.check(
-                lib.dfm_plane_sweep_bwd_opts(ctypes.byref(desc), _ptr(grad_out), _ptr(depths),
-                                             _ptr(P), _ptr(Pinv), _ptr(T), _ptr(g_cur), _ptr(g_prev),
-                                             _stream_ptr(device),
-                                             ctypes.byref(opts) if opts is not None else None))
+        g_cur, g_prev = plane_sweep_backward(ctx.desc, grad_out, depths, P, Pinv, T)
         return g_cur.to(ctx.in_dtype), g_prev.to(ctx.in_dtype), None, None, None, None, None, None
+
+
+def plane_sweep_backward(desc, grad_out, depths, P, Pinv, T):
+    """Gradients of the plane sweep with respect to the two feature maps, in **fp32** --
+    ``(grad_cur, grad_prev)``, each ``(B, C, H, W)`` -- from the gradient of the volume
+    (``dfm_plane_sweep_bwd``; autograd of ``F.grid_sample`` at dfm_backbone.py:296-311).  The autograd
+    function casts them to the maps' dtype; tests and mixed-precision trainers that keep fp32 master
+    gradients take them from here."""
+    lib = _capi.lib()
+    device = grad_out.device
+    _require_gpu(grad_out, 'grad_out')
+    shape = (desc.batch, desc.channels, desc.h_in, desc.w_in)
+    g_cur = torch.zeros(shape, dtype=torch.float32, device=device)
+    g_prev = torch.zeros(shape, dtype=torch.float32, device=device)
+    opts = _current_opts()
+    if _bwd_kernel is not None:
+        opts = make_opts(kernel=_bwd_kernel)
+    if (opts is None and not grad_out.is_contiguous() and grad_out.dim() == 5 and
+            grad_out.is_contiguous(memory_format=torch.channels_last_3d)):
+        # the NDHWC stack's gradient is read where it lies (the 236 MB conversion to the reference
+        # layout cost 2.2 ms of a 20 ms training step at config K)
+        # up to 2 GB: re-laid by the library's LDS-tile transpose (copy speed) into a scratch of the
+        # volume's size; larger volumes are read in place (no extra memory)
+        nbytes = grad_out.numel() * grad_out.element_size()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes <= (2 << 30) else None
+        with torch.cuda.device(device):
+            rc = lib.dfm_plane_sweep_bwd_channels_last(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P),
+                                                       _ptr(Pinv), _ptr(T), _ptr(g_cur), _ptr(g_prev),
+                                                       _ptr(ws) if ws is not None else None,
+                                                       nbytes if ws is not None else 0, _stream_ptr(device))
+        if rc == 0:
+            return g_cur, g_prev
+        if rc != _capi.DFM_ERR_UNSUPPORTED:
+            _capi.check(rc)
+    grad_out = grad_out.contiguous()
+    with torch.cuda.device(device):
+        _capi.check(
+            lib.dfm_plane_sweep_bwd_opts(ctypes.byref(desc), _ptr(grad_out), _ptr(depths),
+                                         _ptr(P), _ptr(Pinv), _ptr(T), _ptr(g_cur), _ptr(g_prev),
+                                         _stream_ptr(device),
+                                         ctypes.byref(opts) if opts is not None else None))
+    return g_cur, g_prev
 
 
 def build_dfm_cost(cur_feats,

@@ -62,7 +62,7 @@ typedef enum dfm_dtype { DFM_F32 = 0, DFM_BF16 = 1 } dfm_dtype;
 /* ---------------------------------------------------------------------- */
 /* library                                                                 */
 /* ---------------------------------------------------------------------- */
-DFM_API int dfm_version(void);            /* ABI version, currently 2     */
+DFM_API int dfm_version(void);            /* ABI version, currently 3     */
 DFM_API const char *dfm_last_error(void); /* thread-local, never NULL     */
 
 /* Per-launch device timing of the volume-writing kernel, measured with HIP
@@ -205,8 +205,10 @@ DFM_API int dfm_plane_sweep_bwd_last_kernel(void);
  *                        channel plane -- or 3 where 4 does not apply.  For the backward call:
  *                        1 = the lane-per-point scatter fallback.
  *   lanes_per_workgroup  128 | 256 | 512 | 1024 (tile kernels; default 256)
- *   lds_kib              dynamic LDS per workgroup, 4..160 (default 52); a tile whose feature
- *                        rows do not fit is redone with direct taps
+ *   lds_kib              LDS budget per workgroup, 4..160 (default: 52 serial body, 80 pipelined body
+ *                        -- whose allocation is fixed at 80 KiB and whose two buffers get half the
+ *                        budget each); a tile whose feature rows do not fit gets a second chance
+ *                        with 144 KiB and is else redone with direct taps
  *   blocks_per_group     16-byte channel blocks one workgroup sweeps (default: all)
  *   planes_per_workgroup consecutive depth planes that share one workgroup's staged rows
  *                        (default 2; rounded down to a divisor of lanes/64)
@@ -218,6 +220,14 @@ DFM_API int dfm_plane_sweep_bwd_last_kernel(void);
  *   points_per_lane      16/sizeof(T) (default: one 16-byte store per channel), or 4 with
  *                        DFM_BF16 and 512/1024 lanes: 8-byte stores, half the registers per
  *                        lane, twice the waves per CU for the same tile
+ *   pipeline             body of the LDS tile kernel: 1 = serial (stage a channel block's rows,
+ *                        barrier, blend + store, barrier), 2 (default) = pipelined: two LDS
+ *                        buffers, the next block's rows fly under the blend, one barrier per
+ *                        block, and no wait for the volume stores' acknowledgements
+ *   store_align_points   8 | 16 | 32 | 64: tile boundaries of the LDS tile kernel are multiples of this
+ *                        many lattice points of a channel plane's flat (d,h,w) index, i.e. every run of
+ *                        stores starts and ends on a 16 / 32 / 64 / 128-byte boundary of bf16 data
+ *                        (x2 for fp32) relative to the plane's first element
  */
 typedef struct dfm_sweep_opts {
     int32_t kernel;
@@ -227,7 +237,9 @@ typedef struct dfm_sweep_opts {
     int32_t planes_per_workgroup;
     int32_t bands_per_chunk;
     int32_t points_per_lane;
-    int32_t reserved;
+    int32_t pipeline;
+    int32_t store_align_points;
+    int32_t reserved[3];
 } dfm_sweep_opts;
 
 /* dfm_plane_sweep_fwd with explicit launch options.  opts == NULL is dfm_plane_sweep_fwd: the

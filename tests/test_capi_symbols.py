@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_version_and_error_string(pkg):
     lib = pkg._capi.lib()
-    assert lib.dfm_version() == 2
+    assert lib.dfm_version() == 3
     assert isinstance(lib.dfm_last_error(), bytes)
 
 

@@ -3,7 +3,8 @@
 BASELINE.json's metric is quoted on B=8, C=256, D=112, 94x311, bf16.  These tests run exactly
 that launch -- same inputs as bench.py (bench.WORKLOADS / bench.poses / KITTI P2), B=8, the LDS
 tile kernel -- under every launch configuration the library's autotuner can pick ({256 lanes x 8
-points, 512 lanes x 4 points} x bands_per_chunk {1, 15}; 29 as an extra) and under the augmented
+points, 512 lanes x 4 points} x bands_per_chunk {1, 15}; 29 as an extra; the pipelined body and the
+serial one) and under the augmented
 geometry of SURVEY.md 8d's second run
 (flip, crop offset (11,55), scale 1.03), and compare >= 8 whole depth planes x 16 channels of
 each half of every sample bit-for-bit with bf16(oracle(bf16 inputs)).  Whole planes include the
@@ -77,10 +78,15 @@ def _compare(out, w, cur, prev, depths, T, flip, crop, scale):
         assert not bad.any(), f'sample {b}: {int(bad.sum())} of {bad.size} values differ'
 
 
+# (pipeline unset = the library default, the pipelined body; *_serial pins the round-1..3 body)
 CANDIDATES = {'l256_p8_c1': dict(kernel=2), 'l256_p8_c15': dict(kernel=2, bands_per_chunk=15),
               'l512_p4_c1': dict(kernel=2, lanes=512, points_per_lane=4),
               'l512_p4_c15': dict(kernel=2, lanes=512, points_per_lane=4, bands_per_chunk=15),
-              'l256_p8_c29': dict(kernel=2, bands_per_chunk=29)}
+              'l256_p8_c29': dict(kernel=2, bands_per_chunk=29),
+              'l256_p8_c1_serial': dict(kernel=2, pipeline=1),
+              'l512_p4_c1_serial': dict(kernel=2, lanes=512, points_per_lane=4, pipeline=1),
+              'l256_p8_c1_a64': dict(kernel=2, store_align=64),
+              'l256_p8_c1_serial_a32': dict(kernel=2, pipeline=1, store_align=32)}
 
 
 @pytest.mark.parametrize('cand', sorted(CANDIDATES))

@@ -39,19 +39,35 @@ def pkg():
 #               shapes it does not cover (odd channel counts / plane sizes) take the default dispatch
 #   lds256_chunk: shipped shape with 3 adjacent bands scheduled back to back
 #   lds512_v4 / lds1024_v4: 4 points per lane (bf16: 8-byte stores, 4 waves per SIMD)
+#   pipe*     : the pipelined body of the LDS tile kernel (two LDS buffers, one barrier per channel
+#               block, counted vmcnt; the default since round 4) in the shapes the library ships,
+#               with odd / even numbers of channel blocks per workgroup, and with a budget that
+#               sends tiles to the second-chance and direct passes; the lds* modes pin the serial body
+#   *_a32/_a64: tile boundaries at multiples of 32 / 64 lattice points (whole 64- / 128-byte writes)
 MODES = {'gather': dict(kernel=1, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
-         'lds128_p1': dict(kernel=2, lanes=128, lds_kib=36, blocks_per_group=1, planes=1),
-         'lds128_p2': dict(kernel=2, lanes=128, lds_kib=36, blocks_per_group=1000, planes=2),
-         'lds256_p1': dict(kernel=2, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
-         'lds256_p2': dict(kernel=2, lanes=256, lds_kib=52, blocks_per_group=1000, planes=2),
-         'lds256_p4': dict(kernel=2, lanes=256, lds_kib=52, blocks_per_group=1000, planes=4),
-         'lds256_chunk': dict(kernel=2, lanes=256, lds_kib=52, planes=2, bands_per_chunk=3),
-         'lds512_v4': dict(kernel=2, lanes=512, lds_kib=52, planes=2, points_per_lane=4),
+         'lds128_p1': dict(kernel=2, lanes=128, lds_kib=36, blocks_per_group=1, planes=1, pipeline=1),
+         'lds128_p2': dict(kernel=2, lanes=128, lds_kib=36, blocks_per_group=1000, planes=2, pipeline=1),
+         'lds256_p1': dict(kernel=2, lanes=256, lds_kib=64, blocks_per_group=4, planes=1, pipeline=1),
+         'lds256_p2': dict(kernel=2, lanes=256, lds_kib=52, blocks_per_group=1000, planes=2, pipeline=1),
+         'lds256_p4': dict(kernel=2, lanes=256, lds_kib=52, blocks_per_group=1000, planes=4, pipeline=1),
+         'lds256_chunk': dict(kernel=2, lanes=256, lds_kib=52, planes=2, bands_per_chunk=3, pipeline=1),
+         'lds512_v4': dict(kernel=2, lanes=512, lds_kib=52, planes=2, points_per_lane=4, pipeline=1),
          'lds1024_v4': dict(kernel=2, lanes=1024, lds_kib=64, planes=4, points_per_lane=4,
-                            bands_per_chunk=2),
+                            bands_per_chunk=2, pipeline=1),
          'lds_spill': dict(kernel=2, lanes=128, lds_kib=4, blocks_per_group=2, planes=2,
-                           bands_per_chunk=2),
-         'lds_respill': dict(kernel=2, lanes=256, lds_kib=16, planes=2),
+                           bands_per_chunk=2, pipeline=1),
+         'lds_respill': dict(kernel=2, lanes=256, lds_kib=16, planes=2, pipeline=1),
+         'pipe256': dict(kernel=2, lanes=256, planes=2, pipeline=2),
+         'pipe256_b3': dict(kernel=2, lanes=256, planes=1, blocks_per_group=3, pipeline=2),
+         'pipe128_b1': dict(kernel=2, lanes=128, planes=2, blocks_per_group=1, pipeline=2),
+         'pipe512_v4': dict(kernel=2, lanes=512, planes=2, points_per_lane=4, pipeline=2),
+         'pipe1024_v4': dict(kernel=2, lanes=1024, planes=4, points_per_lane=4, bands_per_chunk=2,
+                             pipeline=2),
+         'pipe_spill': dict(kernel=2, lanes=128, lds_kib=4, blocks_per_group=2, planes=2, pipeline=2),
+         'pipe_respill': dict(kernel=2, lanes=256, lds_kib=24, planes=2, pipeline=2),
+         'pipe256_a64': dict(kernel=2, lanes=256, planes=2, pipeline=2, store_align=64),
+         'lds256_a32': dict(kernel=2, lanes=256, lds_kib=52, planes=2, pipeline=1, store_align=32),
+         'pipe512_v4_a64': dict(kernel=2, lanes=512, planes=2, points_per_lane=4, pipeline=2, store_align=64),
          'direct': dict(kernel=3, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
          'clt': dict(kernel=4)}
 

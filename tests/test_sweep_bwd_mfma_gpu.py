@@ -3,10 +3,17 @@
 dfm_backbone.py:296-311.
 
 Checked against (a) torch's CPU fp32 grid_sample autograd on the oracle's grids and (b) the
-LDS-atomic tile kernel (fp32 weights, ``kernel=5``) on the same inputs.  Tolerance: the kernel
-rounds the bilinear weights to bf16 like the gradient values it multiplies them with, so an output
-is a sum of terms with 2^-9 relative error each: |err| <= 2^-8 * sum |w * g| is the hard bound,
-the tests ask for 2^-7 * the map's RMS-level magnitude plus rtol 1e-2."""
+LDS-atomic tile kernel (fp32 weights, ``kernel=5``) on the same inputs, on the kernels' fp32 results
+(``plane_sweep_backward``; the autograd function rounds them to the maps' dtype afterwards).
+
+Tolerance.  The kernel feeds every fp32 bilinear weight to the matrix core as hi + lo bf16 terms
+(|w - hi - lo| <= 2^-18 |w|), products are exact and sums fp32: an output differs from fp32 arithmetic
+on fp32 weights by at most 2^-18 * sum_k w_k |g_k| plus the usual fp32 summation-order noise
+(<= n * 2^-24 of the same sum, n <= a few hundred terms).  ``_close`` asserts exactly that bound,
+element by element -- sum_k w_k |g_k| is torch's own backward run on |grad| -- as 2^-17 * sum w|g|,
+and, as a second, magnitude-free statement, rtol 1e-3 + atol 2e-5 * rms(reference) (SURVEY 8c asks
+sampling kernels for rtol 1e-4 / atol 1e-5 on unit-scale data; these gradients have rms ~ 10-20).
+Round 3's single bf16 weight term needed 2^-7 * rms + rtol 1e-2."""
 import importlib
 import os
 
@@ -29,21 +36,38 @@ def pkg():
 
 
 def _run(pkg, cur, prev, depths, fsf, P, T, img_shape, flip, crop, scale, gout, kernel=None):
+    """fp32 (grad_cur, grad_prev) of the kernel under test + which backward kernel ran"""
     ps = pkg.plane_sweep
     dev = torch.device('cuda:0')
-    c = torch.from_numpy(cur).to(dev).to(torch.bfloat16).requires_grad_(True)
-    p = torch.from_numpy(prev).to(dev).to(torch.bfloat16).requires_grad_(True)
-    out = pkg.build_dfm_cost(c, p, torch.from_numpy(depths).to(dev), fsf, 1, torch.from_numpy(P),
-                             torch.from_numpy(T), img_shape, flip, crop, scale)
+    B = cur.shape[0]
+    c = torch.from_numpy(cur).to(dev).to(torch.bfloat16)
     g = gout if torch.is_tensor(gout) else torch.from_numpy(gout).to(dev).to(torch.bfloat16)
+    desc = ps._make_desc(c, len(depths), fsf, 1, img_shape, flip, crop, scale)
+    Pm, Pinv, Tm = ps.camera_matrices(torch.from_numpy(P), torch.from_numpy(T), B, dev)
+    d = torch.from_numpy(depths).to(dev)
     if kernel is None:
-        out.backward(g)
+        gc, gp = ps.plane_sweep_backward(desc, g, d, Pm, Pinv, Tm)
     else:
         with ps.backward_kernel(kernel):
-            out.backward(g)
+            gc, gp = ps.plane_sweep_backward(desc, g, d, Pm, Pinv, Tm)
     torch.cuda.synchronize()
+    assert gc.dtype == torch.float32 and gp.dtype == torch.float32
     which = pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel()
-    return c.grad.float(), p.grad.float(), which
+    return gc, gp, which
+
+
+def test_autograd_returns_the_rounded_fp32_gradients(pkg):
+    """build_dfm_cost(...).backward() hands autograd the same numbers, cast to the maps' dtype"""
+    k = _case(B=1, C=8, H=12, W=40, D=3, fsf=4, seed=21)
+    dev = torch.device('cuda:0')
+    c = torch.from_numpy(k['cur']).to(dev).to(torch.bfloat16).requires_grad_(True)
+    p = torch.from_numpy(k['prev']).to(dev).to(torch.bfloat16).requires_grad_(True)
+    out = pkg.build_dfm_cost(c, p, torch.from_numpy(k['depths']).to(dev), k['fsf'], 1, torch.from_numpy(k['P']),
+                             torch.from_numpy(k['T']), k['img_shape'], k['flip'], k['crop'], k['scale'])
+    out.backward(torch.from_numpy(k['gout']).to(dev).to(torch.bfloat16))
+    gc, gp, which = _run(pkg, **k)
+    assert which == 6
+    assert torch.equal(c.grad, gc.to(torch.bfloat16)) and torch.equal(p.grad, gp.to(torch.bfloat16))
 
 
 def _case(B, C, H, W, D, fsf, crop=(0, 0), flip=False, scale=1.0, seed=0, img_shape=None, t_z=None,
@@ -66,8 +90,9 @@ def _case(B, C, H, W, D, fsf, crop=(0, 0), flip=False, scale=1.0, seed=0, img_sh
                 crop=crop, scale=scale, gout=gout)
 
 
-def _reference(k, b):
-    """torch CPU fp32 autograd through grid_sample on the oracle's grids, sample b"""
+def _reference(k, b, absolute=False):
+    """torch CPU fp32 autograd through grid_sample on the oracle's grids, sample b
+    (absolute=True: the same backward on |grad|, i.e. sum_k w_k |g_k| per map element)"""
     H, W = k['cur'].shape[2:]
     D = len(k['depths'])
     C = k['cur'].shape[1]
@@ -75,20 +100,33 @@ def _reference(k, b):
     prm = orc.sweep_params(H, W, D, k['fsf'], 1, k['P'][b], Pinv[b], k['T'][b], k['img_shape'], k['flip'],
                            k['crop'], k['scale'])
     cg, pg = orc.plane_sweep_grid(prm, k['depths'])
+    gout = np.abs(k['gout']) if absolute else k['gout']
     refs = []
     for feats, grid, sl in ((k['cur'], cg, slice(0, C)), (k['prev'], pg, slice(C, 2 * C))):
         f = torch.from_numpy(feats[b:b + 1]).requires_grad_(True)
         o = torch.nn.functional.grid_sample(f, torch.from_numpy(grid).view(1, 1, -1, 2), mode='bilinear',
                                             padding_mode='zeros', align_corners=True)
-        o.backward(torch.from_numpy(k['gout'][b:b + 1, sl]).reshape(o.shape))
+        o.backward(torch.from_numpy(gout[b:b + 1, sl]).reshape(o.shape))
         refs.append(f.grad[0].numpy())
     return refs
 
 
-def _close(got, ref, what):
+MAX_REL = {'value': 0.0}  # largest |err| / (sum w|g|) seen in this session, printed by the last test
+
+
+def _close(got, ref, what, ref_abs=None):
+    """ref_abs = sum_k w_k |g_k| (torch's backward on |grad|): the rigorous bound; without it (kernel
+    against kernel, or a masked comparison) the magnitude-free statement alone"""
     scale = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))) + 1e-30
-    err = np.abs(got - ref)
-    bound = 2.0 ** -7 * scale + 1e-2 * np.abs(ref)
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    if ref_abs is not None:
+        bad = err > 2.0 ** -17 * ref_abs.astype(np.float64) + 1e-30
+        assert not bad.any(), (f'{what}: {int(bad.sum())} of {bad.size} beyond 2^-17 * sum w|g|, '
+                               f'max err {err.max():.4g} at rms {scale:.4g}')
+        m = ref_abs > 0
+        if m.any():
+            MAX_REL['value'] = max(MAX_REL['value'], float((err[m] / ref_abs[m]).max()))
+    bound = 2e-5 * scale + 1e-3 * np.abs(ref)
     bad = err > bound
     assert not bad.any(), f'{what}: {int(bad.sum())} of {bad.size} off, max err {err.max():.4g} at rms {scale:.4g}'
 
@@ -123,9 +161,10 @@ def test_matrix_product_backward_matches_torch_and_tile_kernel(pkg, name):
     assert which5 == 5
     for b in range(k['cur'].shape[0]):
         rc, rp = _reference(k, b)
+        ac, ap = _reference(k, b, absolute=True)
         assert np.abs(rc).max() > 0.1 and np.abs(rp).max() > 0.1
-        _close(gc[b].cpu().numpy(), rc, f'{name} cur vs torch, sample {b}')
-        _close(gp[b].cpu().numpy(), rp, f'{name} prev vs torch, sample {b}')
+        _close(gc[b].cpu().numpy(), rc, f'{name} cur vs torch, sample {b}', ac)
+        _close(gp[b].cpu().numpy(), rp, f'{name} prev vs torch, sample {b}', ap)
     _close(gc.cpu().numpy(), tc.cpu().numpy(), f'{name} cur vs tile kernel')
     _close(gp.cpu().numpy(), tp.cpu().numpy(), f'{name} prev vs tile kernel')
 
@@ -137,19 +176,19 @@ def test_prev_map_entirely_outside(pkg):
     assert which == 6
     assert float(gp.abs().max()) == 0.0
     rc, _ = _reference(k, 0)
-    _close(gc[0].cpu().numpy(), rc, 'cur vs torch')
+    ac, _ = _reference(k, 0, absolute=True)
+    _close(gc[0].cpu().numpy(), rc, 'cur vs torch', ac)
 
 
-def test_cur_map_weights_are_exact_in_bf16(pkg):
-    """an un-augmented cur map is sampled at its own pixels (weights 1 - eps and eps): rounding the
-    weights to bf16 changes nothing beyond eps; the two kernels agree to the last bf16 bit or two of
-    the returned gradient (fp32 sums in different orders, one bf16 rounding)"""
+def test_cur_map_kernels_agree_to_fp32_noise(pkg):
+    """an un-augmented cur map is sampled at its own pixels (weights 1 - eps and eps, which hi + lo
+    represent to 2^-18): the matrix-product kernel and the fixed-point tile kernel then differ by
+    summation order only"""
     k = _case(B=1, C=32, H=16, W=64, D=12, fsf=4, seed=2)
     gc, _, which = _run(pkg, **k)
     tc, _, _ = _run(pkg, kernel=5, **k)
     assert which == 6
-    assert torch.allclose(gc, tc, rtol=2.0 ** -7, atol=1e-3)
-    assert float((gc != tc).float().mean()) < 0.05
+    assert torch.allclose(gc, tc, rtol=1e-5, atol=1e-4)
 
 
 def _torch_reference_nonfinite(k, g):
@@ -198,6 +237,12 @@ def test_north_star_geometry_slice(pkg):
     tc, tp, _ = _run(pkg, kernel=5, **k)
     _close(gc.cpu().numpy(), tc.cpu().numpy(), 'cur vs tile kernel')
     _close(gp.cpu().numpy(), tp.cpu().numpy(), 'prev vs tile kernel')
+    rc, rp = _reference(k, 0)
+    ac, ap = _reference(k, 0, absolute=True)
+    _close(gc[0].cpu().numpy(), rc, 'cur vs torch', ac)
+    _close(gp[0].cpu().numpy(), rp, 'prev vs torch', ap)
+    print(f'\nmatrix-product backward: largest |err| / sum w|g| over this session = {MAX_REL["value"]:.3g} '
+          f'(2^{np.log2(max(MAX_REL["value"], 1e-30)):.1f}; bound asserted 2^-17)')
 
 
 def test_clock_probe_reports_a_plausible_shader_clock(pkg):

@@ -5,7 +5,7 @@
 //         -o tools/sweep_bench
 //   tools/sweep_bench [--workload nstar|nstar_aug|kitti] [--rounds R] [--launches L] [--batch B]
 //                     cfg [cfg ...]
-//   cfg = comma list of kernel= lanes= lds= bpg= planes= chunk= ppl=   ("default" = library defaults)
+//   cfg = comma list of kernel= lanes= lds= bpg= planes= chunk= ppl= pipe= align=   ("default" = library defaults)
 //
 // Every round times each configuration once (L back-to-back launches between two HIP events on
 // the launch stream), round-robin, so the variants see the same clock / thermal state
@@ -33,6 +33,17 @@
             exit(2);                                                                       \
         }                                                                                  \
     } while (0)
+
+// 64-bit checksum of the volume (sum of 32-bit words times an odd per-position weight): every
+// configuration must reproduce the first one's volume bit for bit
+__global__ void checksum_kernel(const uint32_t *__restrict__ p, size_t n, unsigned long long *out)
+{
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        acc += (unsigned long long)p[i] * (2 * (i & 0xffff) + 1);
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static inline uint32_t rnd()
@@ -100,6 +111,8 @@ static dfm_sweep_opts parse_cfg(const std::string &s)
         else if (k == "planes") o.planes_per_workgroup = v;
         else if (k == "chunk") o.bands_per_chunk = v;
         else if (k == "ppl") o.points_per_lane = v;
+        else if (k == "pipe") o.pipeline = v;
+        else if (k == "align") o.store_align_points = v;
         else { fprintf(stderr, "unknown cfg key '%s'\n", k.c_str()); exit(2); }
         pos = e + 1;
     }
@@ -187,14 +200,23 @@ int main(int argc, char **argv)
     for (auto &c : cfgs) opts.push_back(parse_cfg(c));
     std::vector<std::vector<float>> ms(cfgs.size());
     // reference checksum from the first configuration: every other one must reproduce the volume
-    std::vector<uint64_t> sums(cfgs.size(), 0);
+    std::vector<unsigned long long> sums(cfgs.size(), 0);
     auto run = [&](size_t i) {
         int rc = dfm_plane_sweep_fwd_opts(&d, cur, prev, depths, P, Pinv, T, out, ws, wsb, st, &opts[i]);
         if (rc != DFM_OK) { fprintf(stderr, "cfg %s: %s\n", cfgs[i].c_str(), dfm_last_error()); exit(3); }
     };
+    unsigned long long *dsum;
+    CK(hipMalloc((void **)&dsum, 8));
+    bool same = true;
     for (size_t i = 0; i < cfgs.size(); ++i) {  // warm up (and page in every code object)
+        CK(hipMemsetAsync(out, 0xff, out_elems * esz, st));
         run(i);
+        CK(hipMemsetAsync(dsum, 0, 8, st));
+        hipLaunchKernelGGL(checksum_kernel, dim3(256 * 16), dim3(256), 0, st, (const uint32_t *)out,
+                           out_elems * esz / 4, dsum);
+        CK(hipMemcpyAsync(&sums[i], dsum, 8, hipMemcpyDeviceToHost, st));
         CK(hipStreamSynchronize(st));
+        if (sums[i] != sums[0]) same = false;
     }
     for (int r = 0; r < rounds; ++r)
         for (size_t i = 0; i < cfgs.size(); ++i) {
@@ -211,8 +233,10 @@ int main(int argc, char **argv)
     for (size_t i = 0; i < cfgs.size(); ++i) {
         std::sort(ms[i].begin(), ms[i].end());
         const float med = ms[i][ms[i].size() / 2], mn = ms[i][0];
-        printf("%-44s median %8.4f ms  min %8.4f ms   %7.1f GB/s (median)  %7.1f vol/s\n", cfgs[i].c_str(),
-               med, mn, alg_bytes / (med * 1e-3) / 1e9, batch / (med * 1e-3));
+        printf("%-44s median %8.4f ms  min %8.4f ms   %7.1f GB/s (median)  %7.1f vol/s  checksum %016llx%s\n",
+               cfgs[i].c_str(), med, mn, alg_bytes / (med * 1e-3) / 1e9, batch / (med * 1e-3),
+               (unsigned long long)sums[i], sums[i] == sums[0] ? "" : "  != first configuration");
     }
+    if (!same) printf("# CHECKSUM MISMATCH (expected with a DFM_ABLATE debug build)\n");
     return 0;
 }
