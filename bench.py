@@ -37,31 +37,67 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
-# HBM bytes per launch of the N* tile kernel from separate rocprofv3 --pmc passes (FETCH_SIZE and
-# WRITE_SIZE in their own runs; FETCH x2 = the guide's gfx950 correction for wide coalesced
-# reads), one entry per launch configuration the autotuner can pick:
-# profiles/r02_nstar_traffic.json, written by tools/pmc_traffic.py in the same gpurun lease as
-# a bench line.  Algorithmic = 27.06 GB.
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_nstar_traffic.json')
 # the reference's own build_dfm_cost on PyTorch-CPU, timed in the build container by
 # tools/ref_cpu_timing.py (/root/reference does not exist on the GPU box)
 REF_CPU_FILE = os.path.join(ROOT, 'profiles', 'r02_reference_cpu_timing.json')
 
 
 def schedule_key(opts):
-    """canonical name of a launch configuration (dict of dfm_sweep_opts fields)"""
+    """canonical name of a launch configuration (dict of dfm_sweep_opts fields; 0 = library default)"""
     o = opts or {}
-    return 'lanes{}_ppl{}_planes{}_chunk{}'.format(o.get('lanes_per_workgroup') or 256,
-                                                   o.get('points_per_lane') or 8,
-                                                   o.get('planes_per_workgroup') or 2,
-                                                   o.get('bands_per_chunk') or 1)
+    ppl = o.get('points_per_lane') or 8
+    key = 'lanes{}_ppl{}_planes{}_chunk{}_{}_cut{}'.format(
+        o.get('lanes_per_workgroup') or 256, ppl, o.get('planes_per_workgroup') or 2,
+        o.get('bands_per_chunk') or 1, 'serial' if o.get('pipeline') == 1 else 'pipelined',
+        o.get('store_align_points') or 64)
+    return key + ('_8Bstores' if ppl == 4 and o.get('pair_stores') == 2 else '')
 
 
-def measured_traffic(workload, key):
+def sweep_bench_cfg(opts):
+    """the same configuration as a tools/sweep_bench argument"""
+    o = opts or {}
+    names = (('kernel', 'kernel'), ('lanes_per_workgroup', 'lanes'), ('lds_kib', 'lds'),
+             ('blocks_per_group', 'bpg'), ('planes_per_workgroup', 'planes'), ('bands_per_chunk', 'chunk'),
+             ('points_per_lane', 'ppl'), ('pipeline', 'pipe'), ('store_align_points', 'align'),
+             ('pair_stores', 'pair'))
+    items = [f'{short}={o[k]}' for k, short in names if o.get(k)]
+    return ','.join(items) or 'default'
+
+
+def measure_traffic(workload, opts, timeout=90):
+    """HBM bytes per launch of the configuration that ran, measured NOW on this part: two separate
+    rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; no trace domains beside --pmc) over the torch-free
+    tools/sweep_bench, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over the launch's kernels
+    (tools/pmc_traffic.py; the x2 is MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads).
+    None when rocprofv3 or the harness is missing or a pass fails -- never a number from another run."""
+    import shutil
+    import subprocess
+    if workload not in ('nstar', 'nstar_aug', 'kitti') or not shutil.which('rocprofv3'):
+        return None
+    exe = os.path.join(ROOT, 'tools', 'sweep_bench')
     try:
-        with open(TRAFFIC_FILE) as f:
-            return json.load(f).get(workload, {}).get(key, {}).get('hbm_bytes_per_launch')
-    except (OSError, ValueError):
+        if not os.path.exists(exe):
+            subprocess.run(['hipcc', '--offload-arch=gfx950', '-O2', '-std=c++17', '-I', os.path.join(ROOT, 'include'),
+                            os.path.join(ROOT, 'tools', 'sweep_bench.cpp'), '-L',
+                            os.path.join(ROOT, 'depth-from-motion_amd', 'lib'), '-ldfm_hip',
+                            '-Wl,-rpath,$ORIGIN/../depth-from-motion_amd/lib', '-o', exe],
+                           check=True, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import pmc_traffic
+        cfg = sweep_bench_cfg(opts)
+        fetch = pmc_traffic.one_pass('FETCH_SIZE', cfg, workload, '/tmp/bench_pmc', timeout)
+        write = pmc_traffic.one_pass('WRITE_SIZE', cfg, workload, '/tmp/bench_pmc', timeout)
+        # the library's kernels only (the harness also fills and checksums the volume)
+        fetch = {k: v for k, v in fetch.items() if pmc_traffic.is_library_kernel(k)}
+        write = {k: v for k, v in write.items() if pmc_traffic.is_library_kernel(k)}
+        kernels = set(fetch) | set(write)
+        total = sum(2 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in kernels) * 1024
+        return {'hbm_bytes_per_launch': total,
+                'fetch_bytes_x2': sum(2 * v for v in fetch.values()) * 1024,
+                'write_bytes': sum(write.values()) * 1024,
+                'how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/sweep_bench '
+                       f'{cfg}, this part, this run'} if total > 0 else None
+    except Exception:  # a failed pass must not fail the bench
         return None
 
 KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791],
@@ -164,9 +200,11 @@ def cpu_baseline(w, budget_s=12.0):
     return res
 
 
-def secondary(args, pkg, dev, job):
+def secondary(args, pkg, dev, job, emit=True):
     """Other hot-path rows on their config shapes; `value` = passes/s of the op over
-    one sample batch, roofline from HIP-event step time (one fused kernel per step)."""
+    one sample batch, roofline from HIP-event step time (one fused kernel per step).
+    emit=False: return the JSON line's dict instead of printing it (the default run's
+    ``secondary`` block)."""
     rank, world = job.rank, job.world
     gen = torch.Generator().manual_seed(job.seed(0) // 1000)
     comm = None
@@ -400,31 +438,96 @@ def secondary(args, pkg, dev, job):
                 'algorithmic_flops_per_step': flops}
     else:
         achieved = nbytes / (dev_ms * 1e-3) / 1e9
-        traffic = None
-        if args.workload == 'sweep_bwd':  # PMC passes of this workload: profiles/r03_sweep_bwd_traffic.json
-            try:
-                with open(os.path.join(ROOT, 'profiles', 'r03_sweep_bwd_traffic.json')) as f:
-                    traffic = json.load(f)['sweep_bwd']['hbm_bytes_per_launch']
-            except (OSError, ValueError, KeyError):
-                traffic = None
+        traffic = None  # (tools/pmc_summary.py over this command gives the counters of a secondary row)
         roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4),
                 'traffic': traffic, 'kernel_ms': round(dev_ms, 4),
                 'algorithmic_bytes_per_launch': nbytes}
-    if rank == 0:
-        print(json.dumps({
-            'metric': unit.replace('/s', '/sec'), 'value': round(B * world / (ms / 1e3), 2),
-            'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': dtype_name or ('bf16' if args.workload == 'sweep_bwd' else 'f32'),
-            'data': 'synthetic',
-            'config': {'workload': f'{args.workload}: {name}', 'global_batch': B * world,
-                       'parallelism': f'dp{world}'},
-            'roofline': roof, 'per_rank_ms_per_step': [round(v * 1e3 / args.steps, 4) for v in every],
-            **({'gradient_exchange': comm} if comm is not None else {})}), flush=True)
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and world == 1:
+    line = {
+        'metric': unit.replace('/s', '/sec'), 'value': round(B * world / (ms / 1e3), 2),
+        'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': dtype_name or ('bf16' if args.workload == 'sweep_bwd' else 'f32'),
+        'data': 'synthetic',
+        'config': {'workload': f'{args.workload}: {name}', 'global_batch': B * world,
+                   'parallelism': f'dp{world}'},
+        'roofline': roof, 'per_rank_ms_per_step': [round(v * 1e3 / args.steps, 4) for v in every],
+        **({'gradient_exchange': comm} if comm is not None else {})}
+    if rank == 0 and emit:
+        print(json.dumps(line), flush=True)
+    if emit and torch.distributed.is_available() and torch.distributed.is_initialized() and world == 1:
         torch.distributed.destroy_process_group()   # the one-rank group of --reducer ddp
+    return line
+
+
+def secondary_block(pkg, sweep, dev, job, budget_s=45.0):
+    """What else the default run witnesses, after the timed headline and never as ``value``: other rows
+    of SURVEY.md 8a on their config shapes, a few steps each -- the plane-sweep backward at N*, the
+    shipped config's strided sweep (config K, NHWC maps), DfMBackbone.forward and the voxel neck.
+    Each entry: value + unit, ms per step, fraction of its roofline.  A row that fails or would overrun
+    the wall-clock budget is reported as skipped, not silently dropped."""
+    import types
+    out = {}
+    t_start = time.perf_counter()
+    for wl in ('sweep_bwd', 'kitti_nhwc', 'backbone', 'neck'):
+        if time.perf_counter() - t_start > budget_s:
+            out[wl] = {'skipped': 'wall-clock budget of the secondary block spent'}
+            continue
+        try:
+            if wl in WORKLOADS:
+                line = quick_sweep_row(pkg, sweep, dev, wl, steps=10, warmup=3)
+            else:
+                a = types.SimpleNamespace(workload=wl, steps=10, warmup=3, reducer='none')
+                if wl == 'backbone':
+                    os.environ.setdefault('DFM_FEATS_NHWC', '1')  # the layout SPPUNetNeck hands over
+                line = secondary(a, pkg, dev, job, emit=False)
+            r = line['roofline']
+            out[wl] = {'what': line['config']['workload'], 'value': line['value'], 'unit': line['unit'],
+                       'ms_per_step': line['ms_per_step'], 'bound': r['bound'], 'achieved': r['achieved'],
+                       'roofline_unit': r['unit'], 'frac': r['frac'], 'steps': line['steps']}
+        except Exception as e:  # a secondary row must not take the headline down with it
+            out[wl] = {'skipped': f'{type(e).__name__}: {e}'[:200]}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    out['wall_s'] = round(time.perf_counter() - t_start, 1)
+    return out
+
+
+def quick_sweep_row(pkg, sweep, dev, wl, steps, warmup):
+    """a forward plane sweep of WORKLOADS[wl] through the public launch, HIP events around the steps"""
+    w = WORKLOADS[wl]
+    tdtype = torch.bfloat16 if w['dtype'] == 'bf16' else torch.float32
+    elem = 2 if w['dtype'] == 'bf16' else 4
+    B = w['B']
+    g = torch.Generator().manual_seed(7)
+    cur = torch.randn(B, w['C'], w['H'], w['W'], generator=g).to(dev).to(tdtype)
+    prev = torch.randn(B, w['C'], w['H'], w['W'], generator=g).to(dev).to(tdtype)
+    if w.get('nhwc'):
+        cur, prev = (t.contiguous(memory_format=torch.channels_last) for t in (cur, prev))
+    depths = torch.from_numpy(depth_planes(w['D'], w['dmin'], w['dmax'])).to(dev)
+    desc = sweep._make_desc(cur, w['D'], w['fsf'], w['csf'], (375, 1242), w['flip'], w['crop'], w['scale'])
+    P, Pinv, T = sweep.camera_matrices(torch.from_numpy(np.stack([KITTI_P2] * B)),
+                                       torch.from_numpy(poses(B, 2)), B, dev)
+    out = torch.empty((B, 2 * w['C'], w['D'], desc.h_out, desc.w_out), dtype=tdtype, device=dev)
+    for _ in range(warmup):
+        sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    nbytes = algorithmic_bytes(w, elem) * B
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {'value': round(B / (ms * 1e-3), 2), 'unit': 'cost-volumes/s', 'ms_per_step': round(ms, 4), 'steps': steps,
+            'config': {'workload': f'{wl}: plane-sweep forward B={B} x (2C={2 * w["C"]}, D={w["D"]}, '
+                                   f'{desc.h_out}x{desc.w_out}) {w["dtype"]}, csf={w["csf"]}'
+                                   + (', NHWC maps sampled in place' if w.get('nhwc') else '')},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBPS, 4)}}
 
 
 def main():
@@ -449,7 +552,13 @@ def main():
     ap.add_argument('--reducer', default='none', choices=['none', 'ddp', 'bucket'],
                     help='backbone_train: gradient exchange of the step (DDP, or GradientBucketReducer)')
     ap.add_argument('--traffic-bytes', type=float, default=None,
-                    help='HBM bytes per launch from a separate rocprofv3 --pmc pass')
+                    help='HBM bytes per launch from a separate rocprofv3 --pmc pass (default: measured in this run)')
+    ap.add_argument('--no-traffic', action='store_true', help='skip the in-run rocprofv3 --pmc passes')
+    ap.add_argument('--no-secondary', action='store_true', help="skip the default run's secondary rows")
+    ap.add_argument('--no-smi', action='store_true', help='skip the amd-smi / rocm-smi readings')
+    ap.add_argument('--pipeline', type=int, default=0, help='LDS kernel body: 1 serial, 2 pipelined')
+    ap.add_argument('--store-align', type=int, default=0, help='LDS kernel: band cuts at multiples of 8|16|32|64 points')
+    ap.add_argument('--pair-stores', type=int, default=0, help='4 points per lane: 1 paired 16-byte stores, 2 8-byte stores')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -471,7 +580,8 @@ def main():
     explicit = {k: v for k, v in dict(kernel=args.kernel, lanes=args.lanes, lds_kib=args.lds_kib,
                                       blocks_per_group=args.bpg, planes=args.planes,
                                       bands_per_chunk=args.band_chunk,
-                                      points_per_lane=args.ppl).items() if v}
+                                      points_per_lane=args.ppl, pipeline=args.pipeline,
+                                      store_align=args.store_align, pair_stores=args.pair_stores).items() if v}
     if args.no_autotune:
         os.environ['DFM_AUTOTUNE'] = '0'
     par = importlib.import_module('depth-from-motion_amd.parallel')
@@ -512,9 +622,12 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
         sweep.plane_sweep_forward(desc, cur, prev, depths, P, Pinv, T, out=out,
                                   channels_last=args.channels_last)
 
-    # which part did the lease land on?  The same binary runs 1.06-1.16k vol/s on parts whose HBM write
-    # path sustains ~4.1 TB/s for this store stream and 1.40-1.47k on the others (profiles/r02_c44_*):
-    # a ~20 ms fill probe of the output buffer makes the bench line explain itself
+    # which part did the lease land on?  Rounds 1-3 saw the same binary at 0.63 of the roofline on some
+    # parts and at 0.48 on others; round 4 found the cause in the kernel's own store stream -- every band
+    # cut of every channel plane left two partial 64-byte writes behind, which some parts absorb and others
+    # do not (profiles/r04_c1..c4_*) -- and removed it.  The probes stay as a record of the part: the tile
+    # kernel's store pattern replayed as zeros, a linear fill, the shader clock under an FMA load, and what
+    # the SMI tools report under load (tools/part_info.py).
     torch.cuda.synchronize()
     plane_bytes = w['D'] * desc.h_out * desc.w_out * elem
     part = None
@@ -531,8 +644,6 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         tile_gbps = probe(lambda: pkg._capi.check(lib.dfm_store_probe(
             ctypes.c_void_p(out.data_ptr()), B, 2 * w['C'], plane_bytes, 0, 0, st)))
-        # shader clock under a VALU load on every CU (dfm_clock_probe): the store probe alone does not single
-        # out the parts that run the same binary 25 % slower at a normal store rate (profiles/r03_c38_*)
         clk = torch.zeros(3, dtype=torch.int64, device=dev)
         pkg._capi.check(lib.dfm_clock_probe(ctypes.c_void_p(clk.data_ptr()), 1 << 18, st))
         torch.cuda.synchronize()
@@ -540,13 +651,24 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
         ghz = cyc / max(ref, 1) / 10.0
         part = {'tile_store_probe_gbps': round(tile_gbps, 1), 'linear_fill_gbps': round(probe(out.zero_), 1),
                 'shader_clock_ghz_under_fma_load': round(ghz, 3),
-                'class': 'normal-store' if tile_gbps >= 4800.0 else 'slow-store',
-                'note': "zeros written in the tile kernel's store pattern (one 4 KiB run per channel plane per "
-                        'workgroup, dfm_store_probe) and as a linear fill, and the shader clock under an FMA load on '
-                        'every CU (dfm_clock_probe).  Parts whose tile-pattern rate is below ~4.8 TB/s cap the sweep '
-                        'near 0.50 of the roofline; parts with a normal store rate have also been seen to run the same '
-                        'binary at 0.50 instead of 0.63 with the same shader clock (profiles/r03_c38_*, r03_c52_*: 5.3 TB/s probe vs 5.5-5.65, '
-                        '1.98-2.07 GHz on both kinds): the probes bracket the cause, they do not name it'}
+                'note': "zeros in 4 KiB runs walking every channel plane (dfm_store_probe), a linear fill, the shader "
+                        'clock under an FMA load on every CU (dfm_clock_probe); smi: amd-smi / rocm-smi readings, '
+                        'clocks and power sampled while the sweep runs'}
+        if rank == 0 and not args.no_smi:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                import part_info
+
+                def load():
+                    torch.cuda.set_device(dev)
+                    for _ in range(400):
+                        step()
+                    torch.cuda.synchronize()
+                os.environ['DFM_AUTOTUNE'] = '0'
+                part['smi'] = part_info.collect(load)
+                os.environ.pop('DFM_AUTOTUNE', None)
+            except Exception as e:
+                part['smi'] = {'error': repr(e)}
     if explicit or args.channels_last or args.no_autotune or w.get('nhwc'):
         os.environ['DFM_AUTOTUNE'] = '0'  # keep the first launch from tuning by itself
     for _ in range(args.warmup):
@@ -561,12 +683,13 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
             sweep.plane_sweep_autotune(desc, cur, prev, depths, P, Pinv, T, out)
     verified, check_agrees = None, None
     if tuned is not None and w['dtype'] == 'bf16':
-        # untimed, informational: the library's pick (dfm_plane_sweep_autotune: 8 rounds x 4 launches per
+        # untimed, informational: the library's pick (dfm_plane_sweep_autotune: 4 rounds x 2 launches per
         # candidate, median round) next to both tile shapes timed over as many launches as the timed
         # region has.  The bench runs WHAT THE LIBRARY PICKED -- what a build_dfm_cost() user gets -- and
         # reports whether this check agrees (round 2 overrode the library here).
-        shapes = {'lanes256_ppl8_planes2_chunk1': dict(kernel=2, lanes=256, points_per_lane=8, bands_per_chunk=1),
-                  'lanes512_ppl4_planes2_chunk1': dict(kernel=2, lanes=512, points_per_lane=4, bands_per_chunk=1)}
+        shapes = [dict(kernel=2, lanes=256, points_per_lane=8, bands_per_chunk=1),
+                  dict(kernel=2, lanes=512, points_per_lane=4, bands_per_chunk=1)]
+        shapes = {schedule_key(sweep.make_opts(**kw).as_dict()): kw for kw in shapes}
         verified = {}
         for key, kw in shapes.items():
             with sweep.launch_options(**kw):
@@ -641,14 +764,9 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
                 'frac': round(achieved / HBM_PEAK_GBPS, 4),
                 # the same bytes over the whole timed step (pack pass + launch gaps included)
                 'frac_step': round(bytes_per_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                # PMC traffic of the launch configuration that actually ran (None if that
-                # configuration has no committed counter pass)
-                'traffic': args.traffic_bytes if args.traffic_bytes is not None else (
-                    None if args.channels_last or lib.dfm_plane_sweep_last_kernel() != 2 else
-                    measured_traffic(args.workload, schedule_key(
-                        tuned if tuned is not None else
-                        pkg._capi.SweepOpts(**{sweep._OPT_FIELDS[k]: v
-                                               for k, v in explicit.items()}).as_dict()))),
+                # HBM bytes per launch of the configuration that ran, from counter passes made in THIS
+                # run on THIS part after the timed region (measure_traffic); null if they cannot be made
+                'traffic': args.traffic_bytes,
                 'kernel_ms': round(avg_kernel_ms, 4),
                 'algorithmic_bytes_per_launch': bytes_per_launch,
             },
@@ -708,6 +826,18 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
                              'frac': round(bytes_per_launch / (k_cl * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                              'kernel_ms': round(k_cl, 4)}}
             del out_cl
+        ran = tuned if tuned is not None else pkg._capi.SweepOpts(
+            **{sweep._OPT_FIELDS[k]: v for k, v in explicit.items()}).as_dict()
+        if (world == 1 and args.traffic_bytes is None and not args.no_traffic and not args.channels_last
+                and lib.dfm_plane_sweep_last_kernel() == 2 and not w.get('nhwc')):
+            torch.cuda.empty_cache()
+            tr = measure_traffic(args.workload, ran)
+            if tr is not None:
+                line['roofline']['traffic'] = tr['hbm_bytes_per_launch']
+                line['roofline']['traffic_detail'] = tr
+        if world == 1 and args.workload == 'nstar' and not explicit and not args.channels_last and not args.no_secondary:
+            torch.cuda.empty_cache()
+            line['secondary'] = secondary_block(pkg, sweep, dev, job)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(w)
         print(json.dumps(line), flush=True)

@@ -53,6 +53,7 @@ struct Launch {
     int band_chunk;  // adjacent bands scheduled back to back
     int ppl;         // lattice points per lane
     int align;       // tile boundaries: multiples of this many points (8, 16, 32 or 64)
+    int pair;        // 4 points per lane: 16-byte stores through a lane-pair exchange (1) or 8-byte stores (0)
     int pipe;        // LDS tile kernel body: 1 serial (stage | barrier | blend + store | barrier),
                      // 2 pipelined (two buffers, one barrier per block, stores never waited for)
 };
@@ -318,6 +319,7 @@ struct TileGrid {
     int dgroups;           // ceil(D / planes)
     int blocks_per_group;  // channel blocks one workgroup sweeps
     int band_chunk;        // adjacent bands scheduled together (see the block id map)
+    int pair_stores;       // 4 points per lane (bf16): lane pairs trade halves and store 16-byte vectors
     int align;             // tile boundaries are multiples of this many points of the flat (d,h,w) index
                            // (a power of two >= 8): 32 points = 64 bytes of bf16, a whole memory-side write
     unsigned long long *trace;  // perf experiments only: per-phase s_memtime stamps
@@ -627,6 +629,37 @@ __device__ __forceinline__ void tile_body(
             }
         }
         TRACE_STAMP();
+        if constexpr (VW == 2) {
+            // 8-byte halves of a 16-byte vector lie in neighbouring lanes (4 points per lane): the pair
+            // trades halves -- the even lane takes channel 2i of both, the odd lane channel 2i + 1 -- and
+            // each stores ONE 16-byte vector per channel pair instead of two 8-byte ones (half the store
+            // instructions of the workgroup, whole 16-byte lane accesses; 4 v_cndmask_b32_dpp per pair).
+            // The tile's cuts are multiples of 8 points and an even lane's first point is one, so the two
+            // lanes of a pair are active together.
+            if (tg.pair_stores) {
+                const bool odd = tid & 1;
+#pragma unroll
+                for (int kp = 0; kp < CB / 2; ++kp) {
+                    const int ka = 2 * kp, kb = ka + 1;
+                    if (cbase + kb < g.C) {
+                        // quad_perm [1,0,3,2]: the neighbour's value
+                        const uint32_t na0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk[ka][0], 0xb1, 0xf, 0xf, false);
+                        const uint32_t na1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk[ka][1], 0xb1, 0xf, 0xf, false);
+                        const uint32_t nb0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk[kb][0], 0xb1, 0xf, 0xf, false);
+                        const uint32_t nb1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk[kb][1], 0xb1, 0xf, 0xf, false);
+                        // even: channel ka = {own points 0-3, neighbour's 4-7}; odd: channel kb = {neighbour's 0-3, own 4-7}
+                        const u32x4_t v = {odd ? nb0 : pk[ka][0], odd ? nb1 : pk[ka][1],
+                                           odd ? pk[kb][0] : na0, odd ? pk[kb][1] : na1};
+                        T *dst = o + (size_t)(cbase + ka + (odd ? 1 : 0)) * g.N - (odd ? 4 : 0);
+                        if (!ABLATE(2) || v.x == 0x12345u) __builtin_nontemporal_store(v, (u32x4_t *)dst);
+                    } else if (cbase + ka < g.C && (!ABLATE(2) || pk[ka][0] == 0x12345u)) {
+                        u32x2_t v = {pk[ka][0], pk[ka][1]};  // an odd channel count's last channel
+                        __builtin_nontemporal_store(v, (u32x2_t *)(o + (size_t)(cbase + ka) * g.N));
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < CB; ++k) {
             if (cbase + k < g.C && (!ABLATE(2) || pk[k][0] == 0x12345u)) {
@@ -691,9 +724,12 @@ __device__ __forceinline__ void tile_body(
             // protected the single buffer against its refill is gone.
             // A wave with no lattice point issues no stores: it waits vmcnt(0).
             const bool wave_stores = __any(active) != 0;  // wave-uniform
+            const bool paired = VW == 2 && tg.pair_stores;  // one 16-byte store per channel PAIR
             auto wait_rows = [&]() {
-                if (wave_stores && !ABLATE(2))
+                if (wave_stores && !ABLATE(2) && !paired)
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(CB) : "memory");
+                else if (wave_stores && !ABLATE(2))
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(CB / 2) : "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             };
@@ -1445,9 +1481,10 @@ int resolve(const dfm_sweep_desc *d, const dfm_sweep_opts *o, Launch &L)
     L.planes = o && o->planes_per_workgroup ? o->planes_per_workgroup : 2;
     L.band_chunk = o && o->bands_per_chunk ? o->bands_per_chunk : 1;
     L.ppl = o && o->points_per_lane ? o->points_per_lane : CB;
-    L.align = o && o->store_align_points ? o->store_align_points : 8;
+    L.align = o && o->store_align_points ? o->store_align_points : 64;
     if (L.align != 8 && L.align != 16 && L.align != 32 && L.align != 64)
         return fail(DFM_ERR_INVALID_ARG, "opts: store_align_points in {8,16,32,64}%s");
+    L.pair = o && o->pair_stores ? (o->pair_stores == 1) : 1;  // 0 default (on), 1 on, 2 off
     L.pipe = o && o->pipeline ? o->pipeline : 2;
     if (L.pipe != 1 && L.pipe != 2) return fail(DFM_ERR_INVALID_ARG, "opts: pipeline must be 0, 1 or 2%s");
     if (!L.lds_kib) L.lds_kib = L.pipe == 2 ? 80 : 52;
@@ -1492,6 +1529,7 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
     tg.band_chunk = std::max(1, std::min(L.band_chunk, tg.bands));
     tg.trace = nullptr;
     tg.ablate = 0;
+    tg.pair_stores = L.pair;
 #ifdef DFM_DEBUG_HOOKS
     tg.trace = g_trace;
     {
@@ -1824,13 +1862,15 @@ DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur
     TuneKey key;
     rc = tune_key(desc, key);
     if (rc != DFM_OK) return rc;
-    // candidates: 8 points per lane x 256 lanes, 4 points per lane x 512 lanes (bf16), both with
-    // bands_per_chunk 1.  The re-fetching schedules are no longer candidates: bands_per_chunk 29 moved
-    // 41 GB and 15 moves 37 GB of HBM traffic per N* launch against 28 GB (profiles/r02_nstar_traffic.json);
-    // 15 gained 3 % on the slowest parts seen, but a short timing window picked it once on a part where
-    // it then ran 20 % SLOWER in steady state (profiles/r02_c43_bench_default_mispick.json: 6.75 ms
-    // against 5.46 ms for 512 x 4 in the same lease).  A wrong pick between the two remaining shapes
-    // costs at most the 3-6 % they differ by; bands_per_chunk stays available through dfm_sweep_opts.
+    // candidates: 8 points per lane x 256 lanes, 4 points per lane x 512 lanes (bf16, lane pairs storing
+    // 16-byte vectors); both with the pipelined body, band cuts on 128-byte boundaries and
+    // bands_per_chunk 1.  Since round 4 the two are within 0-4 % of each other on every part seen
+    // (profiles/r04_c2..c4_*): with whole 64-byte writes the parts that ran round 3's binary at 0.48 of
+    // the roofline run either shape at 0.59-0.60.  The re-fetching schedules are no candidates:
+    // bands_per_chunk 29 moved 41 GB and 15 moves 37 GB of HBM traffic per N* launch against 28 GB
+    // (profiles/r02_nstar_traffic.json), and a short timing window once picked 15 on a part where it
+    // then ran 20 % slower in steady state (profiles/r02_c43_bench_default_mispick.json); with aligned
+    // cuts chunks of 2 / 4 measure 3-8 % slower (r04_c4).  bands_per_chunk stays in dfm_sweep_opts.
     std::vector<dfm_sweep_opts> cand;
     {
         dfm_sweep_opts o;
@@ -1846,16 +1886,14 @@ DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur
     hipStream_t st = (hipStream_t)stream;
     dfm_sweep_opts best = cand[0];
     if (takes_lds_tiles(desc, out)) {
-        // Robust timing (the first version timed each candidate once, back to back, from a cold
-        // start and picked a schedule 20 % slower than the best on one box; the second one -- 5 rounds
-        // of 3 launches, minimum -- still mis-picked once between the two tile shapes, so bench.py
-        // re-timed them over its own longer window and overrode the library: a build_dfm_cost() user
-        // did not get what the bench reported).  Now the library's own window IS that long: warm the
-        // part up with the default shape, then ROUNDS round-robin passes over the candidates, PER
-        // launches per measurement (8 x 4 launches per candidate, ~0.18 s per candidate at N*), and the
-        // MEDIAN round per candidate -- a single lucky round no longer decides.  One-time cost per
-        // (device, shape); bench.py reports the library's pick and no longer overrides it.
-        constexpr int ROUNDS = 8, PER = 4;
+        // Timing window: warm every candidate up (code objects, clocks), then ROUNDS round-robin passes
+        // of PER launches per candidate and the MEDIAN round -- 8 timed launches per candidate, ~0.1 s
+        // for both at N*.  (History: one cold launch per candidate picked a schedule 20 % slower than
+        // the best; 5 x 3 launches with the minimum still mis-picked once between candidates 5 % apart;
+        // round 3 spent 8 x 4 launches per candidate, 0.4 s of first-call latency inside a thin ABI.
+        // Now the candidates are within a few per cent on every part seen, a wrong pick costs that, and
+        // the window is sized to that.)  One-time cost per (device, shape).
+        constexpr int ROUNDS = 4, PER = 2;
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));

@@ -145,12 +145,13 @@ _tls = threading.local()
 _OPT_FIELDS = {'kernel': 'kernel', 'lanes': 'lanes_per_workgroup', 'lds_kib': 'lds_kib',
                'blocks_per_group': 'blocks_per_group', 'planes': 'planes_per_workgroup',
                'bands_per_chunk': 'bands_per_chunk', 'points_per_lane': 'points_per_lane',
-               'pipeline': 'pipeline', 'store_align': 'store_align_points'}
+               'pipeline': 'pipeline', 'store_align': 'store_align_points',
+               'pair_stores': 'pair_stores'}
 
 
 def make_opts(**kw):
     """dfm_sweep_opts from keywords (kernel, lanes, lds_kib, blocks_per_group, planes,
-    bands_per_chunk, points_per_lane, pipeline, store_align); unspecified fields = library default."""
+    bands_per_chunk, points_per_lane, pipeline, store_align, pair_stores); unspecified fields = library default."""
     o = _capi.SweepOpts()
     for k, v in kw.items():
         setattr(o, _OPT_FIELDS[k], int(v or 0))

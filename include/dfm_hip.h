@@ -227,7 +227,9 @@ DFM_API int dfm_plane_sweep_bwd_last_kernel(void);
  *   store_align_points   8 | 16 | 32 | 64: tile boundaries of the LDS tile kernel are multiples of this
  *                        many lattice points of a channel plane's flat (d,h,w) index, i.e. every run of
  *                        stores starts and ends on a 16 / 32 / 64 / 128-byte boundary of bf16 data
- *                        (x2 for fp32) relative to the plane's first element
+ *                        (x2 for fp32) relative to the plane's first element (default 64)
+ *   pair_stores          points_per_lane = 4 with DFM_BF16: 1 (default) = neighbouring lanes trade their
+ *                        8-byte halves and store one 16-byte vector per channel pair, 2 = 8-byte stores
  */
 typedef struct dfm_sweep_opts {
     int32_t kernel;
@@ -239,7 +241,8 @@ typedef struct dfm_sweep_opts {
     int32_t points_per_lane;
     int32_t pipeline;
     int32_t store_align_points;
-    int32_t reserved[3];
+    int32_t pair_stores;
+    int32_t reserved[2];
 } dfm_sweep_opts;
 
 /* dfm_plane_sweep_fwd with explicit launch options.  opts == NULL is dfm_plane_sweep_fwd: the

@@ -85,7 +85,9 @@ CANDIDATES = {'l256_p8_c1': dict(kernel=2), 'l256_p8_c15': dict(kernel=2, bands_
               'l256_p8_c29': dict(kernel=2, bands_per_chunk=29),
               'l256_p8_c1_serial': dict(kernel=2, pipeline=1),
               'l512_p4_c1_serial': dict(kernel=2, lanes=512, points_per_lane=4, pipeline=1),
-              'l256_p8_c1_a64': dict(kernel=2, store_align=64),
+              'l256_p8_c1_a8': dict(kernel=2, store_align=8),
+              'l512_p4_c1_unpaired': dict(kernel=2, lanes=512, points_per_lane=4, pair_stores=2),
+              'l512_p4_c2': dict(kernel=2, lanes=512, points_per_lane=4, bands_per_chunk=2),
               'l256_p8_c1_serial_a32': dict(kernel=2, pipeline=1, store_align=32)}
 
 

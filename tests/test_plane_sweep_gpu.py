@@ -43,6 +43,7 @@ def pkg():
 #               block, counted vmcnt; the default since round 4) in the shapes the library ships,
 #               with odd / even numbers of channel blocks per workgroup, and with a budget that
 #               sends tiles to the second-chance and direct passes; the lds* modes pin the serial body
+#   *_unpaired: 4 points per lane with 8-byte stores (default: lane pairs trade halves, 16-byte stores)
 #   *_a32/_a64: tile boundaries at multiples of 32 / 64 lattice points (whole 64- / 128-byte writes)
 MODES = {'gather': dict(kernel=1, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
          'lds128_p1': dict(kernel=2, lanes=128, lds_kib=36, blocks_per_group=1, planes=1, pipeline=1),
@@ -68,6 +69,10 @@ MODES = {'gather': dict(kernel=1, lanes=256, lds_kib=64, blocks_per_group=4, pla
          'pipe256_a64': dict(kernel=2, lanes=256, planes=2, pipeline=2, store_align=64),
          'lds256_a32': dict(kernel=2, lanes=256, lds_kib=52, planes=2, pipeline=1, store_align=32),
          'pipe512_v4_a64': dict(kernel=2, lanes=512, planes=2, points_per_lane=4, pipeline=2, store_align=64),
+         'lds256_a8': dict(kernel=2, lanes=256, lds_kib=52, planes=2, pipeline=1, store_align=8),
+         'pipe512_v4_unpaired': dict(kernel=2, lanes=512, planes=2, points_per_lane=4, pipeline=2, pair_stores=2),
+         'lds256_v4_unpaired': dict(kernel=2, lanes=256, planes=2, points_per_lane=4, pipeline=1, pair_stores=2,
+                                    store_align=16),
          'direct': dict(kernel=3, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
          'clt': dict(kernel=4)}
 

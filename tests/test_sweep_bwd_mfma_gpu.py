@@ -226,7 +226,10 @@ def test_zero_gradient_and_scale_invariance(pkg):
     a, b, _ = _run(pkg, **k)
     for s in (2.0 ** -60, 2.0 ** 40):  # exact in bf16 and fp32: no fixed-point scale to lose bits
         a2, b2, _ = _run(pkg, **dict(k, gout=k['gout'] * np.float32(s)))
-        assert torch.equal(a2 / s, a) and torch.equal(b2 / s, b)
+        # (windows of neighbouring tiles meet in the map through fp32 atomics whose order is not fixed:
+        # two runs agree to the last fp32 bit or two, not bit for bit)
+        for x2, x in ((a2, a), (b2, b)):
+            assert torch.allclose(x2 / s, x, rtol=4e-7, atol=4e-7 * float(x.abs().max()))
 
 
 def test_north_star_geometry_slice(pkg):

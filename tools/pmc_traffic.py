@@ -37,6 +37,11 @@ def key_of(cfg):
                                                    kv.get('planes', 2), kv.get('chunk', 1))
 
 
+def is_library_kernel(name):
+    """the plane sweep's own kernels (tools/sweep_bench also fills and checksums the volume)"""
+    return any(t in name for t in ('sweep_', 'pack_blocked', 'pack_pixel_major'))
+
+
 def one_pass(counter, cfg, workload, scratch, timeout):
     d = os.path.join(scratch, f'{counter}_{key_of(cfg)}')
     shutil.rmtree(d, ignore_errors=True)
@@ -75,6 +80,8 @@ def main():
         except (subprocess.SubprocessError, OSError) as e:  # a pass that aborts must not lose the others
             print(f'{cfg}: pass failed: {e}', file=sys.stderr)
             continue
+        fetch = {k: v for k, v in fetch.items() if is_library_kernel(k)}
+        write = {k: v for k, v in write.items() if is_library_kernel(k)}
         kernels = sorted(set(fetch) | set(write))
         total = sum(2 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in kernels) * 1024
         tile_bytes = sum(2 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in kernels

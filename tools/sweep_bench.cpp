@@ -5,7 +5,7 @@
 //         -o tools/sweep_bench
 //   tools/sweep_bench [--workload nstar|nstar_aug|kitti] [--rounds R] [--launches L] [--batch B]
 //                     cfg [cfg ...]
-//   cfg = comma list of kernel= lanes= lds= bpg= planes= chunk= ppl= pipe= align=   ("default" = library defaults)
+//   cfg = comma list of kernel= lanes= lds= bpg= planes= chunk= ppl= pipe= align= pair=   ("default" = library defaults)
 //
 // Every round times each configuration once (L back-to-back launches between two HIP events on
 // the launch stream), round-robin, so the variants see the same clock / thermal state
@@ -113,6 +113,7 @@ static dfm_sweep_opts parse_cfg(const std::string &s)
         else if (k == "ppl") o.points_per_lane = v;
         else if (k == "pipe") o.pipeline = v;
         else if (k == "align") o.store_align_points = v;
+        else if (k == "pair") o.pair_stores = v;
         else { fprintf(stderr, "unknown cfg key '%s'\n", k.c_str()); exit(2); }
         pos = e + 1;
     }
