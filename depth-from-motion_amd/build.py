@@ -7,7 +7,10 @@ it travels to the GPU box with the repo snapshot.
 Every csrc/*.hip is its own translation unit: objects are compiled in parallel
 (only the stale ones unless ``force``) into lib/obj/ and linked into the .so.
 """
+import contextlib
+import fcntl
 import glob
+import hashlib
 import os
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -39,6 +42,30 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in sources() + _headers())
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """one builder at a time per checkout: torchrun ranks / pytest-xdist workers that find a stale
+    library wait for the first one instead of compiling and linking the same files concurrently"""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
+def _flags_tag(flags):
+    """objects are keyed on what they were compiled WITH as well as when: changing FLAGS or HIPCC
+    rebuilds them (object staleness used to be mtime-only)"""
+    try:
+        ver = subprocess.run([HIPCC, '--version'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             timeout=30).stdout
+    except (OSError, subprocess.SubprocessError):
+        ver = b''
+    return hashlib.sha1(' '.join(flags).encode() + b'|' + HIPCC.encode() + b'|' + ver).hexdigest()[:16]
+
+
 def build_hip(force=False, verbose=False, debug_hooks=False, out=None, jobs=None):
     """Compile every csrc/*.hip into lib/libdfm_hip.so. Returns the path.
 
@@ -49,27 +76,48 @@ def build_hip(force=False, verbose=False, debug_hooks=False, out=None, jobs=None
     out = out or LIB
     if not force and out == LIB and not _stale():
         return LIB
+    with _build_lock():
+        if not force and out == LIB and not _stale():  # another process built it while this one waited
+            return LIB
+        return _build_locked(force, verbose, debug_hooks, out, jobs)
+
+
+def _build_locked(force, verbose, debug_hooks, out, jobs):
     obj_dir = os.path.join(LIB_DIR, 'obj_dbg' if debug_hooks else 'obj')
     os.makedirs(obj_dir, exist_ok=True)
     flags = FLAGS + (['-DDFM_DEBUG_HOOKS'] if debug_hooks else []) + \
         ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+    tag = _flags_tag(flags)
+    tag_file = os.path.join(obj_dir, '.flags')
+    try:
+        same_flags = open(tag_file).read().strip() == tag
+    except OSError:
+        same_flags = False
     newest_header = max(os.path.getmtime(h) for h in _headers())
     objs, todo = [], []
     for src in sources():
         obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + '.o')
         objs.append(obj)
-        if force or not os.path.exists(obj) or \
+        if force or not same_flags or not os.path.exists(obj) or \
                 os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
-            todo.append([HIPCC] + flags + ['-c', src, '-o', obj])
+            todo.append((obj, [HIPCC] + flags + ['-c', src, '-o', obj + '.tmp']))
 
     def run(cmd):
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
 
+    def compile_one(item):
+        obj, cmd = item
+        run(cmd)
+        os.replace(obj + '.tmp', obj)  # a reader never sees a half-written object
+
     with ThreadPoolExecutor(max_workers=jobs or min(len(todo) or 1, os.cpu_count() or 4)) as pool:
-        list(pool.map(run, todo))
-    run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out])
+        list(pool.map(compile_one, todo))
+    with open(tag_file, 'w') as f:
+        f.write(tag + '\n')
+    run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out + '.tmp'])
+    os.replace(out + '.tmp', out)
     return out
 
 

@@ -9,6 +9,7 @@ import torch
 
 from . import _capi
 from .depth_head import LazyDepthDistribution
+from .geometry import stack_meta
 from .plane_sweep import _DTYPES, _Workspace, _ptr, _require_gpu, _stream_ptr, _upload
 
 
@@ -182,10 +183,11 @@ def frustum_to_voxel_sample(stereo_feat, stereo_feat_softmax, img_metas, cur_sem
     desc.depth_min = float(depth_cfg['depth_min'])
     desc.depth_span = float(depth_cfg['depth_max'] - depth_cfg['depth_min'])
     desc.dtype = _DTYPES[stereo.dtype]
-    cam = torch.as_tensor(np.asarray([m['cam2img'] for m in img_metas], dtype=np.float32))
-    cam4 = torch.eye(4).repeat(B, 1, 1)
+    cam = stack_meta(img_metas, 'cam2img')  # (staged on the device by stage_geometry: padded where it lies)
+    cam4 = torch.eye(4, device=cam.device).repeat(B, 1, 1)
     cam4[:, :cam.shape[1], :cam.shape[2]] = cam
-    cam4 = _upload(cam4.reshape(B, 16), device)
+    cam4 = cam4.reshape(B, 16).contiguous() if cam.is_cuda and cam.device == device else \
+        _upload(cam4.cpu().reshape(B, 16), device)
     if lazy is not None and torch.is_grad_enabled() and (stereo.requires_grad or
                                                          (sem is not None and sem.requires_grad)):
         # training with the depth head fused (the backward ignores the input layouts, like _F2vFn's)

@@ -8,6 +8,20 @@ import numpy as np
 import torch
 
 
+def stack_meta(img_metas, key, dtype=torch.float32):
+    """``[m[key] for m in img_metas]`` as ONE tensor of ``dtype``.  Matrices that a collate step put on
+    the device (``data_geometry.stage_geometry``) are stacked where they lie -- no host round trip, no
+    sync; lists / numpy arrays give a host tensor like the reference's ``torch.tensor([...])``
+    (dfm.py:288-291, dfm_backbone.py:236).  A batch that mixes the two is gathered on the device of its
+    tensors."""
+    vals = [m[key] for m in img_metas]
+    if any(torch.is_tensor(v) for v in vals):
+        dev = next(v.device for v in vals if torch.is_tensor(v))
+        return torch.stack([(v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v, dtype=np.float64))).to(
+            device=dev, dtype=dtype) for v in vals])
+    return torch.as_tensor(np.asarray(vals), dtype=dtype)
+
+
 def prepare_depth(depth_cfg, downsampled_depth_offset=0.5):
     """-> (downsampled_depth (num_bins // ds,), depth (num_bins,)) fp32 plane depths /
     bin centres: d_i = (i + offset) * ds * interval + depth_min."""

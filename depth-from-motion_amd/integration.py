@@ -280,6 +280,16 @@ def patch_reference(precision=None, strict=False):
         report['methods'].append('MultiViewDfM.feature_transformation')
     except (ImportError, AttributeError):
         pass
+    try:
+        # dfm.py:288-291 builds ``torch.tensor([img_meta['cur2prevs'] ...])``, which cannot take the device
+        # tensors of a batch staged by data_geometry.stage_geometry: hand it host arrays (one 64-byte-per-
+        # frame copy back; DfMStereoPath and the registered DfMBackbone read staged matrices in place)
+        cls = importlib.import_module('mmdet3d.models.detectors.dfm').DfM
+        if not getattr(cls.extract_feat, '_dfm_staged_metas', False):
+            cls.extract_feat = _extract_feat_with_staged_metas(cls.extract_feat)
+            report['methods'].append('DfM.extract_feat (accepts device-staged cur2prevs)')
+    except (ImportError, AttributeError):
+        pass
     if precision == 'bf16':
         # every module of a detector is built inside DfM.__init__ (MultiViewDfM.__init__ calls it and
         # adds plain attributes only, multiview_dfm.py:36-65): converting at its end covers both
@@ -290,13 +300,33 @@ def patch_reference(precision=None, strict=False):
         if cls is not None and not getattr(cls.__init__, '_dfm_fast', False):
             cls.__init__ = _init_then_fast_path(cls.__init__, strict)
             report['methods'].append('DfM.__init__ -> enable_fast_path(bf16)')
+        elif cls is not None:  # patched before: the wrapper reads the strictness of the latest call
+            _patch_state['strict'] = bool(strict)
+            report['methods'].append(f'DfM.__init__ already patched (strict={bool(strict)} from now on)')
     return report
 
 
+def _extract_feat_with_staged_metas(extract_feat):
+    def wrapped(self, img, img_metas, *args, **kwargs):
+        for meta in img_metas:
+            v = meta.get('cur2prevs')
+            if torch.is_tensor(v):
+                meta['cur2prevs'] = v.detach().cpu().numpy()
+        return extract_feat(self, img, img_metas, *args, **kwargs)
+    wrapped._dfm_staged_metas = True
+    wrapped.__wrapped__ = extract_feat
+    return wrapped
+
+
+_patch_state = {'strict': False}  # the latest patch_reference(precision='bf16', strict=...) call decides
+
+
 def _init_then_fast_path(init, strict):
+    _patch_state['strict'] = bool(strict)
+
     def __init__(self, *args, **kwargs):
         init(self, *args, **kwargs)
-        self.fast_path_report = enable_fast_path(self, torch.bfloat16, strict=strict)
+        self.fast_path_report = enable_fast_path(self, torch.bfloat16, strict=_patch_state['strict'])
     __init__._dfm_fast = True
     __init__.__wrapped__ = init
     return __init__
@@ -406,10 +436,15 @@ def enable_fast_path(model, dtype=torch.bfloat16, strict=False, boundary_casts=T
                     child.register_forward_pre_hook(_cast_hook(dtype, orig), with_kwargs=True)
                     child.__dict__['_dfm_fast_hook'] = True
                 cast_back.append(names.get(child, type(child).__name__))
+    report = dict(roots=[names.get(r, type(r).__name__) for r in roots], converted_parameters=converted,
+                  cast_back=cast_back, dtype=dtype, fallback_policy=None)
     if strict:
+        # PROCESS-WIDE (conv3d.set_fallback_policy): every Mfma* module of every model in this process
+        # raises on an ineligible input from now on, backward included; the report says so, and
+        # set_fallback_policy('warn') restores the default
         set_fallback_policy('raise')
-    return dict(roots=[names.get(r, type(r).__name__) for r in roots], converted_parameters=converted,
-                cast_back=cast_back, dtype=dtype)
+        report['fallback_policy'] = "process-wide 'raise' (conv3d.set_fallback_policy)"
+    return report
 
 
 __all__ = ['inject_detector_attributes', 'DfMStereoPath', 'MultiViewDfMMixin', 'MultiViewVoxelPath',

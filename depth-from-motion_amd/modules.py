@@ -33,6 +33,7 @@ from .conv3d import (MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaCon
                      MfmaConvTranspose3d, channel_slice)
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
+from .geometry import stack_meta
 from .group_norm import HipBatchNorm3d, HipGroupNorm
 from . import _capi
 from .plane_sweep import _Workspace, build_dfm_cost
@@ -317,7 +318,7 @@ class DfMBackbone(nn.Module):
             outs.append(cost)
         return outs if outs else [cost]
 
-    def _sweep_dres0_fusable(self, cur):
+    def _sweep_dres0_fusable(self, cur, prev=None):
         """the fused plane sweep + dres0 / dres0_mono kernel takes this call: inference, bf16 32-channel
         maps, the NDHWC stack, both first blocks Conv3d(-> 32) + GroupNorm(one channel per group) + ReLU"""
         def block_ok(cm, cin):
@@ -326,6 +327,7 @@ class DfMBackbone(nn.Module):
                     cm.conv.weight.dtype == torch.bfloat16 and isinstance(norm, HipGroupNorm) and
                     norm.num_groups == 32 and norm.affine and cm.activate is not None)
         return (self.fuse_sweep_dres0 and not torch.is_grad_enabled() and sweep_conv_supported(cur) and
+                (prev is None or (prev.dtype == cur.dtype and prev.shape == cur.shape and prev.device == cur.device)) and
                 self.in_channels == 32 and self.volume_memory_format == torch.channels_last_3d and
                 block_ok(self.dres0, 64) and block_ok(self.dres0_mono, 32))
 
@@ -337,11 +339,11 @@ class DfMBackbone(nn.Module):
         return self._sweep_conv_pack[1]
 
     def forward(self, cur_stereo_feats, prev_stereo_feats, img_metas, cur_sem_feats=None):
-        ori_cam2imgs = torch.as_tensor(np.asarray([m['ori_cam2img'] for m in img_metas]),
-                                       dtype=torch.float32)
-        cur2prevs = torch.stack([torch.as_tensor(m['cur2prevs']) for m in img_metas])
+        # (matrices staged on the device by data_geometry.stage_geometry are read where they lie)
+        ori_cam2imgs = stack_meta(img_metas, 'ori_cam2img')
+        cur2prevs = stack_meta(img_metas, 'cur2prevs')
         meta0 = img_metas[0]
-        if self._sweep_dres0_fusable(cur_stereo_feats):
+        if self._sweep_dres0_fusable(cur_stereo_feats, prev_stereo_feats):
             # plane sweep + dres0.conv + dres0_mono.conv: one kernel, no cost volume in HBM; GroupNorm
             # (+ReLU) of both branches from the kernel's statistics partials
             ys, ps, ym, pm = sweep_dres0(
@@ -426,7 +428,9 @@ class DepthHead(nn.Module):
             train = torch.is_grad_enabled() and x.requires_grad
             dist, pred = depth_head_statistics(x, _on_device(self, 'depth_samples', x.device),
                                                self.downsample_factor, keep_graph=train)
-            return (dist if train else None), pred, dist
+            # (grad mode with a cost that records nothing -- a frozen backbone, a validation loss -- still
+            # hands the distribution over: loss() evaluates it, there is just nothing to differentiate)
+            return (dist if torch.is_grad_enabled() else None), pred, dist
         if self.with_convs:
             x = self.conv_depth(x).view(-1, self.num_views, D, H, W)
         if x.shape[1] != 1:

@@ -172,6 +172,7 @@ def launch_options(**kw):
 
 
 _bwd_kernel = None  # process-wide (autograd runs backward functions on its own threads)
+_bwd_kernel_lock = threading.RLock()  # one override at a time: nested use is fine, two threads take turns
 
 
 @contextlib.contextmanager
@@ -181,12 +182,13 @@ def backward_kernel(kernel):
     maps, 6 / None = default: the matrix-product kernel where it applies).  ``launch_options`` is
     thread-local and never reaches the autograd threads."""
     global _bwd_kernel
-    prev = _bwd_kernel
-    _bwd_kernel = kernel
-    try:
-        yield
-    finally:
-        _bwd_kernel = prev
+    with _bwd_kernel_lock:
+        prev = _bwd_kernel
+        _bwd_kernel = kernel
+        try:
+            yield
+        finally:
+            _bwd_kernel = prev
 
 
 def _current_opts(schedule=None):

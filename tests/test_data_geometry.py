@@ -112,3 +112,53 @@ def test_staged_batch_drives_the_kernels_to_the_same_bits(dg, z):
     got_sw = sweep(metas[1])
     assert got_sw.shape == want_sw.shape
     assert float((got_sw - want_sw).abs().max()) <= 1e-4 * float(want_sw.abs().max())
+
+
+def test_stack_meta_reads_lists_arrays_and_staged_tensors(dg, z):
+    geom = importlib.import_module('depth-from-motion_amd.geometry')
+    _, kitti = _metas(z, dg)
+    metas = [dict(kitti), dict(kitti)]
+    want = np.stack([np.asarray(kitti['cur2prevs'], dtype=np.float32)] * 2)
+    host = geom.stack_meta(metas, 'cur2prevs')
+    assert host.dtype == torch.float32 and np.array_equal(host.numpy(), want)
+    dg.stage_geometry(metas, 'cpu')
+    staged = geom.stack_meta(metas, 'cur2prevs')
+    assert torch.is_tensor(metas[0]['cur2prevs']) and np.array_equal(staged.numpy(), want)
+    mixed = geom.stack_meta([metas[0], dict(kitti)], 'ori_cam2img')
+    assert np.array_equal(mixed.numpy(), np.stack([util.KITTI_P2.astype(np.float32)] * 2))
+
+
+@pytest.mark.gpu
+def test_stereo_path_runs_on_a_batch_staged_on_the_device(dg):
+    """INTEGRATION.md 'Data side': metas staged by stage_geometry(..., 'cuda') drive DfMStereoPath
+    (DfMBackbone's plane sweep + FrustumToVoxel) to the bits of the host-meta run, without a host copy"""
+    import json
+    import os
+    pkg = importlib.import_module('depth-from-motion_amd')
+    with open(os.path.join(util.GOLDEN, 'configs_dfm.json')) as f:
+        model = dict(json.load(f)['dfm_r34_1x8_kitti-3d-3class.py']['model'])
+    model['depth_cfg'] = dict(model['depth_cfg'], num_bins=32)
+    model['depth_head'] = dict(model['depth_head'], depth_cfg=dict(model['depth_head']['depth_cfg'], num_bins=32))
+    model['voxel_cfg'] = dict(point_cloud_range=[2, -6.4, -3, 27.6, 6.4, 1], voxel_size=[0.2, 0.2, 0.2])
+    torch.manual_seed(5)
+    path = pkg.DfMStereoPath(model).cuda().eval()
+    H, W = 128, 256
+    gen = torch.Generator().manual_seed(7)
+    feats = [[torch.randn(2, c, H // s, W // s, generator=gen).cuda()
+              for c, s in ((3, 1), (64, 2), (128, 4), (128, 4), (128, 4))] for _ in range(2)]
+    K = util.KITTI_P2.copy()
+
+    def metas():
+        return [dict(ori_cam2img=K.copy(), cam2img=K.tolist(), cur2prevs=util.pose(0.5, 0.02 * (i + 1), 0.0, -0.8)[None],
+                     ori_shape=(H, W, 3), pad_shape=(H, W, 3), crop_offset=[0, 0], flip=False, scale_factor=[1.0])
+                for i in range(2)]
+    with torch.no_grad():
+        want = path(feats[0], feats[1], metas())
+        staged = metas()
+        assert dg.stage_geometry(staged, 'cuda') > 0 and staged[1]['cam2img'].is_cuda
+        got = path(feats[0], feats[1], staged)
+    for k in ('volume_feat', 'bev_feat', 'depth_preds'):
+        if want.get(k) is not None:
+            a, b = got[k].float(), want[k].float()
+            # the device-side inverse of the intrinsics may differ from the host's in the last bit
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6, k
