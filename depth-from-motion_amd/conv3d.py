@@ -18,6 +18,7 @@ import ctypes
 import warnings
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import _capi
@@ -583,6 +584,8 @@ def pack_conv2d_g_weights(weight, cin, cout, swap=False):
 
 
 def conv2d_g_why_not(x, cin, cout):
+    """inference path: a bf16 channels_last input under no_grad (training goes through
+    ``_Conv2dGFn``, which takes any layout: ``MfmaConv2d.train_why_not``)"""
     if not x.is_cuda:
         return 'CPU tensor'
     if cin % 32 or cout % 32:
@@ -593,7 +596,7 @@ def conv2d_g_why_not(x, cin, cout):
     if x.shape[1] != cin:
         return 'channel count differs from the module\'s'
     if torch.is_grad_enabled():
-        return 'autograd is recording (the 2-D MFMA path is inference-only)'
+        return 'autograd is recording (inference path)'
     if not (x.is_contiguous(memory_format=torch.channels_last) and x.stride(1) == 1):
         return 'input is not channels_last'
     return None
@@ -614,6 +617,85 @@ def conv2d_g(x, packed, cout, stride=1, transposed=False, relu=False, scale=None
                  transposed=(False, bool(transposed), bool(transposed)), relu=relu, scale=scale, shift=shift,
                  residual=res5, kernel1=(True, False, False))
     return y.squeeze(2)
+
+
+def _embed2d(w):
+    """(a, b, 3, 3) -> (a, b, 3, 3, 3) with the 2-D kernel in the centre depth slice"""
+    w3 = w.new_zeros((*w.shape[:2], 3, 3, 3))
+    w3[:, :, 1] = w
+    return w3
+
+
+class _Conv2dGFn(torch.autograd.Function):
+    """Training path of the 2-D 3x3 convolutions of SPPUNetNeck / BEVHourglass (spp_unet_neck.py:93-119,
+    bev_hourglass.py:36-137, conv_modules.py:152-214): forward, backward-data and backward-weight in the
+    hand-written MFMA kernels (csrc/conv3d_g.hip with a (1, 3, 3) kernel, csrc/conv3d_wgrad.hip) on NHWC
+    copies of the operands; input and output keep the CALLER's layout, so the torch ops either side
+    (BatchNorm, bilinear resize, concatenation: NCHW while training) are untouched.
+    kind 'conv': nn.Conv2d k3 p1 stride 1 | 2 (+bias); 'convT': nn.ConvTranspose2d k3 s2 p1 op1."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, kind, stride):
+        cl = torch.channels_last
+        keep_cl = x.is_contiguous(memory_format=cl) and not x.is_contiguous()
+        xcl = x.detach().contiguous(memory_format=cl)
+        cin = weight.shape[1] if kind == 'conv' else weight.shape[0]
+        cout = weight.shape[0] if kind == 'conv' else weight.shape[1]
+        w = weight.detach()
+        if cin < 32:  # the 3-channel image skip: zero channels up to one 32-channel chunk
+            B, C, H, W = xcl.shape
+            xp = xcl.new_zeros((B, H, W, 32))
+            xp[..., :C] = xcl.permute(0, 2, 3, 1)
+            xcl = xp.permute(0, 3, 1, 2)
+            w = torch.cat([w, w.new_zeros(w.shape[0], 32 - cin, 3, 3)], 1)
+        cin_p = max(cin, 32)
+        scale = shift = None
+        if bias is not None:
+            shift = bias.detach().float()
+            scale = torch.ones_like(shift)
+        if kind == 'conv':
+            packed = pack_conv2d_g_weights(w, cin_p, cout)
+            y = conv2d_g(xcl, packed, cout, stride=stride, scale=scale, shift=shift)
+        else:
+            packed = pack_conv2d_g_weights(w, cin_p, cout, swap=True)
+            y = conv2d_g(xcl, packed, cout, transposed=True)
+        ctx.save_for_backward(xcl, weight)
+        ctx.cfg = (kind, stride, cin, cout, bias is not None, keep_cl)
+        return y if keep_cl else y.contiguous()
+
+    @staticmethod
+    def backward(ctx, gy):
+        xcl, weight = ctx.saved_tensors
+        kind, stride, cin, cout, has_bias, keep_cl = ctx.cfg
+        cin_p = max(cin, 32)
+        gcl = gy.contiguous(memory_format=torch.channels_last)
+        g5, x5 = gcl.unsqueeze(2), xcl.unsqueeze(2)
+        k1 = (True, False, False)
+        gx = gw = gb = None
+        w = weight.detach()
+        if kind == 'conv':
+            if cin < 32:
+                w = torch.cat([w, w.new_zeros(w.shape[0], 32 - cin, 3, 3)], 1)
+            if ctx.needs_input_grad[0]:
+                # backward-data = the same kernel on the mirrored, channel-swapped weights; a stride-2 axis
+                # becomes a transposed axis (even extents, padding 1: MfmaConv2d.train_why_not)
+                up = stride == 2
+                pk = pack_conv3d_g_weights(_embed2d(w), cout, cin_p, swap=True, flip=4 if up else 7)
+                gx = conv3d_g(g5, pk, cin_p, stride=1, padding=(0, 1, 1), transposed=(False, up, up),
+                              kernel1=k1).squeeze(2)[:, :cin]
+            if ctx.needs_input_grad[1]:
+                gw = conv3d_weight_grad(x5, g5, (1, stride, stride), (1, 1, 1))[:, :cin, 1].to(weight.dtype)
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = gcl.float().sum((0, 2, 3)).to(weight.dtype)
+        else:
+            if ctx.needs_input_grad[0]:
+                pk = pack_conv3d_g_weights(_embed2d(w), cout, cin, swap=False, flip=0)
+                gx = conv3d_g(g5, pk, cin, stride=(1, 2, 2), padding=(0, 1, 1), kernel1=k1).squeeze(2)
+            if ctx.needs_input_grad[1]:
+                gw = conv3d_weight_grad(g5, x5, (1, 2, 2), (1, 1, 1))[:, :, 1].to(weight.dtype)
+        if gx is not None and not keep_cl:
+            gx = gx.contiguous()
+        return gx, gw, gb, None, None
 
 
 class _Mfma2dMixin:
@@ -663,6 +745,29 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
     def eligible(self, x):
         return self.why_not(x) is None
 
+    def train_why_not(self, x):
+        """why a call with autograd recording does NOT take the MFMA kernels (None: it does)"""
+        if not x.is_cuda:
+            return 'CPU tensor'
+        if not (self.kernel_size == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1) and
+                self.groups == 1 and self.stride in ((1, 1), (2, 2)) and self.padding_mode == 'zeros' and
+                self.out_channels % 32 == 0 and (self.in_channels % 32 == 0 or self.in_channels < 32)):
+            return 'convolution configuration outside the kernel\'s coverage (3x3, padding 1, stride 1 | 2)'
+        if x.dim() != 4 or x.shape[1] != self.in_channels or x.dtype != torch.bfloat16 or \
+                self.weight.dtype != torch.bfloat16:
+            return 'not a bf16 call of this module'
+        n, _, h, w = x.shape
+        st = self.stride[0]
+        if st == 2 and (h % 2 or w % 2):
+            return 'odd extent under stride 2 (backward-data is a transposed convolution)'
+        cin, cout = self._cin_padded(), self.out_channels
+        ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
+        if not (conv3d_g_plannable(n, cin, cout, (1, h, w), (1, st, st), (0, 1, 1), kernel1=(True, False, False)) and
+                conv3d_g_plannable(n, cout, cin, (1, ho, wo), (1, 1, 1), (0, 1, 1),
+                                   transposed=(False, st == 2, st == 2), kernel1=(True, False, False))):
+            return 'no tiling of the general kernel fits this shape'
+        return None
+
     def _packed2d_padded(self):
         key = (self.weight._version, self.weight.data_ptr(), str(self.weight.device))
         if self.__dict__.get('_pack2d_key') != key:
@@ -688,12 +793,25 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
                         scale=scale, shift=shift, residual=residual)
 
     def forward(self, x):
-        why = self.why_not(x)
-        if why is None:
-            return self.forward_fused(x)
-        # the 1x1 convolutions built through convbn() are torch's by design; so is everything while autograd
-        # records (the 2-D MFMA path is inference-only: modules._channels_last_2d keeps the necks NCHW then)
-        if self.kernel_size == (3, 3) and not (torch.is_grad_enabled() and (x.requires_grad or self.training)):
+        if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1 and
+                x.is_cuda and x.dim() == 4 and not x.is_contiguous() and
+                x.is_contiguous(memory_format=torch.channels_last) and x.dtype == self.weight.dtype):
+            # a 1x1 convolution of an NHWC tensor IS a matrix product over its pixel rows: hipBLASLt forward
+            # and backward instead of MIOpen's NHWC kernels (naive on this stack: 14 ms per call,
+            # profiles/r03_c43_*); the result is the same channels_last tensor torch would return
+            y = F.linear(x.permute(0, 2, 3, 1), self.weight.view(self.out_channels, self.in_channels), self.bias)
+            return y.permute(0, 3, 1, 2)
+        recording = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)
+        if recording:
+            why = self.train_why_not(x)
+            if why is None:
+                return _Conv2dGFn.apply(x, self.weight, self.bias, 'conv', self.stride[0])
+        else:
+            why = self.why_not(x)
+            if why is None:
+                return self.forward_fused(x)
+        # (the 1x1 convolutions built through convbn() are torch's by design)
+        if self.kernel_size == (3, 3):
             _torch_path(self, x, why)
         return super().forward(x)
 
@@ -719,13 +837,39 @@ class MfmaConvTranspose2d(nn.ConvTranspose2d, _Mfma2dMixin):
     def eligible(self, x):
         return self.why_not(x) is None
 
+    def train_why_not(self, x):
+        if not x.is_cuda:
+            return 'CPU tensor'
+        if not (self.kernel_size == (3, 3) and self.padding == (1, 1) and self.stride == (2, 2) and
+                self.output_padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1 and
+                self.bias is None and self.in_channels % 32 == 0 and self.out_channels % 32 == 0):
+            return 'transposed-convolution configuration outside the kernel\'s coverage'
+        if x.dim() != 4 or x.shape[1] != self.in_channels or x.dtype != torch.bfloat16 or \
+                self.weight.dtype != torch.bfloat16:
+            return 'not a bf16 call of this module'
+        n, _, h, w = x.shape
+        k1 = (True, False, False)
+        if not (conv3d_g_plannable(n, self.in_channels, self.out_channels, (1, h, w), (1, 1, 1), (0, 1, 1),
+                                   transposed=(False, True, True), kernel1=k1) and
+                conv3d_g_plannable(n, self.out_channels, self.in_channels, (1, 2 * h, 2 * w), (1, 2, 2), (0, 1, 1),
+                                   kernel1=k1)):
+            return 'no tiling of the general kernel fits this shape'
+        return None
+
     def forward(self, x, output_size=None):
-        why = self.why_not(x) if output_size is None else 'explicit output_size'
-        if why is None:
-            return conv2d_g(x, self._packed2d(self.in_channels, self.out_channels, True), self.out_channels,
-                            transposed=True)
-        if not (torch.is_grad_enabled() and (x.requires_grad or self.training)):  # (inference-only path, as above)
-            _torch_path(self, x, why)
+        recording = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)
+        if output_size is not None:
+            why = 'explicit output_size'
+        elif recording:
+            why = self.train_why_not(x)
+            if why is None:
+                return _Conv2dGFn.apply(x, self.weight, None, 'convT', 2)
+        else:
+            why = self.why_not(x)
+            if why is None:
+                return conv2d_g(x, self._packed2d(self.in_channels, self.out_channels, True), self.out_channels,
+                                transposed=True)
+        _torch_path(self, x, why)
         return super().forward(x, output_size)
 
 

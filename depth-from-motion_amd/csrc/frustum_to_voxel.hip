@@ -21,6 +21,31 @@
 // Bound: HBM write of the volume + one read of the sources.
 #include "dfm_common.h"
 
+// A lane (= one voxel) writes its channels-last row as 16-byte pieces; the lanes of a store instruction
+// are 128-256 B apart, so one instruction touches 64 partial lines that the row's other stores complete.
+// PLAIN stores let the L2 merge them: the non-temporal form pushed partial lines out and measured 1.9x
+// slower here (f2v_cl 1.93 -> 3.59 ms, profiles/r04_c7_lift_nt_vs_plain.txt) -- while the batched
+// multi-view kernel (point_sample.hip), whose lanes write whole contiguous KiBs, gains 6 % from nt.
+#define DFM_LIFT_PLAIN 1
+template <typename T>
+__device__ __forceinline__ void lift_store16(T *p, const float (&f)[dfm::vec16<T>::N])
+{
+#ifdef DFM_LIFT_PLAIN
+    dfm::store16<T>(p, f);
+#else
+    typedef uint32_t lift_u32x4 __attribute__((ext_vector_type(4)));
+    lift_u32x4 v;
+    if constexpr (sizeof(T) == 4) {
+        v = lift_u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+    } else {
+        v = lift_u32x4{dfm::pack_bf16x2(f[0], f[1]), dfm::pack_bf16x2(f[2], f[3]), dfm::pack_bf16x2(f[4], f[5]),
+                       dfm::pack_bf16x2(f[6], f[7])};
+    }
+    __builtin_nontemporal_store(v, (lift_u32x4 *)p);
+#endif
+}
+
+
 using namespace dfm;
 
 namespace {
@@ -286,7 +311,7 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
                         float r[CB];
 #pragma unroll
                         for (int e = 0; e < CB; ++e) r[e] = acc[j][e] * valid * sdisp;
-                        store16<T>(ocl + (size_t)(blk0 + j) * CB, r);
+                        lift_store16<T>(ocl + (size_t)(blk0 + j) * CB, r);
                     }
             } else {
 #pragma unroll
@@ -333,7 +358,7 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
                             const float sval = acc[j][e] * v2d;
                             r[e] = sval * mdisp;
                         }
-                        store16<T>(ocl + g.C + (size_t)(blk0 + j) * CB, r);
+                        lift_store16<T>(ocl + g.C + (size_t)(blk0 + j) * CB, r);
                     }
             } else {
 #pragma unroll

@@ -289,6 +289,27 @@ __global__ __launch_bounds__(256) void sweep_gather_kernel(
 // ---------------------------------------------------------------------------
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
+// How the volume's 16-byte vectors leave the CU.  Default: non-temporal (global_store_dwordx4 ... nt).
+// -DDFM_STORE_FLAVOUR=1 plain, 2 sc1, 3 sc0 sc1 (write-through), 4 sc1 nt: experiment builds
+// (build.build_variant), measured in profiles/r04_c6_*.
+#ifndef DFM_STORE_FLAVOUR
+#define DFM_STORE_FLAVOUR 0
+#endif
+__device__ __forceinline__ void vol_store16(const u32x4_t &v, void *p)
+{
+#if DFM_STORE_FLAVOUR == 0
+    __builtin_nontemporal_store(v, (u32x4_t *)p);
+#elif DFM_STORE_FLAVOUR == 1
+    *(u32x4_t *)p = v;
+#elif DFM_STORE_FLAVOUR == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif DFM_STORE_FLAVOUR == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+
 // s_waitcnt immediate (gfx9 encoding) that waits only on vmcnt <= n
 __device__ __forceinline__ constexpr int waitcnt_vm(int n)
 {
@@ -651,7 +672,7 @@ __device__ __forceinline__ void tile_body(
                         const u32x4_t v = {odd ? nb0 : pk[ka][0], odd ? nb1 : pk[ka][1],
                                            odd ? pk[kb][0] : na0, odd ? pk[kb][1] : na1};
                         T *dst = o + (size_t)(cbase + ka + (odd ? 1 : 0)) * g.N - (odd ? 4 : 0);
-                        if (!ABLATE(2) || v.x == 0x12345u) __builtin_nontemporal_store(v, (u32x4_t *)dst);
+                        if (!ABLATE(2) || v.x == 0x12345u) vol_store16(v, dst);
                     } else if (cbase + ka < g.C && (!ABLATE(2) || pk[ka][0] == 0x12345u)) {
                         u32x2_t v = {pk[ka][0], pk[ka][1]};  // an odd channel count's last channel
                         __builtin_nontemporal_store(v, (u32x2_t *)(o + (size_t)(cbase + ka) * g.N));
@@ -665,7 +686,7 @@ __device__ __forceinline__ void tile_body(
             if (cbase + k < g.C && (!ABLATE(2) || pk[k][0] == 0x12345u)) {
                 if constexpr (VW == 4) {
                     u32x4_t v = {pk[k][0], pk[k][1], pk[k][2], pk[k][3]};
-                    __builtin_nontemporal_store(v, (u32x4_t *)(o + (size_t)(cbase + k) * g.N));
+                    vol_store16(v, o + (size_t)(cbase + k) * g.N);
                 } else {
                     u32x2_t v = {pk[k][0], pk[k][1]};
                     __builtin_nontemporal_store(v, (u32x2_t *)(o + (size_t)(cbase + k) * g.N));

@@ -18,6 +18,30 @@
 // Bound: HBM write of the volume + L2-resident gathers; no reuse to stage.
 #include "dfm_common.h"
 
+// The lifted volume (hundreds of MB, written once, read by a later kernel) leaves the CU with
+// non-temporal 16-byte stores: the batched channels-last kernel writes whole contiguous KiBs per
+// instruction and gains 6 % (waymo_cl 0.2366 -> 0.2235 ms, profiles/r04_c7_lift_nt_vs_plain.txt);
+// -DDFM_LIFT_PLAIN builds the plain-store variant.  (FrustumToVoxel's lane-per-voxel kernel must NOT
+// use nt: its stores are partial lines per instruction, see frustum_to_voxel.hip.)
+template <typename T>
+__device__ __forceinline__ void lift_store16(T *p, const float (&f)[dfm::vec16<T>::N])
+{
+#ifdef DFM_LIFT_PLAIN
+    dfm::store16<T>(p, f);
+#else
+    typedef uint32_t lift_u32x4 __attribute__((ext_vector_type(4)));
+    lift_u32x4 v;
+    if constexpr (sizeof(T) == 4) {
+        v = lift_u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+    } else {
+        v = lift_u32x4{dfm::pack_bf16x2(f[0], f[1]), dfm::pack_bf16x2(f[2], f[3]), dfm::pack_bf16x2(f[4], f[5]),
+                       dfm::pack_bf16x2(f[6], f[7])};
+    }
+    __builtin_nontemporal_store(v, (lift_u32x4 *)p);
+#endif
+}
+
+
 #include <stdio.h>
 
 #include <algorithm>
@@ -161,7 +185,7 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
                             float r[CB];
 #pragma unroll
                             for (int k = 0; k < CB; ++k) r[k] = acc[j][k] / den;
-                            store16<T>(obase + (size_t)f * g.C + (size_t)(blk0 + j) * CB, r);
+                            lift_store16<T>(obase + (size_t)f * g.C + (size_t)(blk0 + j) * CB, r);
                         }
                 } else {
 #pragma unroll
@@ -191,7 +215,7 @@ __global__ __launch_bounds__(256) void mv_sample_kernel(
                         float r[CB];
 #pragma unroll
                         for (int k = 0; k < CB; ++k) r[k] = tot[j][k] / den;
-                        store16<T>(obase + (size_t)(blk0 + j) * CB, r);
+                        lift_store16<T>(obase + (size_t)(blk0 + j) * CB, r);
                     }
             } else {
 #pragma unroll
@@ -313,7 +337,7 @@ __global__ __launch_bounds__(256) void mv_sample_cl_kernel(
                     float r[CB];
 #pragma unroll
                     for (int e = 0; e < CB; ++e) r[e] = acc[e] / den;
-                    if (live) store16<T>(orow + (size_t)f * g.C, r);
+                    if (live) lift_store16<T>(orow + (size_t)f * g.C, r);
                 } else {
 #pragma unroll
                     for (int e = 0; e < CB; ++e) tot[e] = tot[e] + acc[e];  // stack(frames).sum(0)
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(256) void mv_sample_cl_kernel(
         float r[CB];
 #pragma unroll
         for (int e = 0; e < CB; ++e) r[e] = tot[e] / den;
-        if (live) store16<T>(orow, r);
+        if (live) lift_store16<T>(orow, r);
     }
     if (valid_out && live && blk == 0) valid_out[(size_t)b * g.N + o] = nvalid > 0;
 }

@@ -22,6 +22,7 @@ The 3x3 2-D convolutions of SPPUNetNeck / BEVHourglass run in the same MFMA kern
 along depth); 1x1 convolutions and bilinear up-sampling outside the fused SPP tail are torch ops.
 """
 import ctypes
+import os
 import weakref
 
 import numpy as np
@@ -97,10 +98,11 @@ class ConvModule(nn.Module):
             # every other 3x3x3 convolution of the path (64 .. 256 channels, stride (1,1,2), padding
             # (1,1,0): the BN3d stacks of the voxel necks): the general MFMA kernel (csrc/conv3d_g.hip)
             conv_cls = MfmaConv3dG
-        elif (conv_type == 'Conv2d' and out_channels % 32 == 0 and in_channels % 32 == 0 and kernel_size == 3
-              and padding == 1 and stride in (1, 2)):
-            # the 3x3 convolutions of the 2-D necks either side of the path (SPPUNetNeck, BEVHourglass):
-            # the same MFMA kernel with a (1, 3, 3) kernel on the NHWC tensor as a depth-1 volume
+        elif conv_type == 'Conv2d':
+            # the convolutions of the 2-D necks either side of the path (SPPUNetNeck, BEVHourglass): 3x3 /
+            # padding 1 / stride 1 | 2 with whole 32-channel chunks run the same MFMA kernel with a (1, 3, 3)
+            # kernel on the NHWC tensor as a depth-1 volume; a 1x1 convolution of an NHWC tensor is a matrix
+            # product; everything else is nn.Conv2d's own forward (MfmaConv2d IS an nn.Conv2d)
             conv_cls = MfmaConv2d
         self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride,
                              padding=padding, bias=norm_cfg is None)
@@ -658,6 +660,58 @@ def _conv_norm_2d(seq, x, residual=None, relu=False):
     return F.relu(y) if relu else y
 
 
+_INTERP_MATRICES = {}
+
+
+def _interp_matrix(n_in, n_out, align_corners, scale, device):
+    """(n_out, n_in) fp32 matrix of 1-D bilinear interpolation, taken from ATen itself (its forward on
+    the identity), so it carries exactly the weights F.interpolate applies"""
+    key = (n_in, n_out, bool(align_corners), scale, str(device))
+    m = _INTERP_MATRICES.get(key)
+    if m is None:
+        eye = torch.eye(n_in, dtype=torch.float32, device=device).view(1, n_in, 1, n_in)
+        kw = dict(scale_factor=(1.0, scale)) if scale is not None else dict(size=(1, n_out))
+        m = F.interpolate(eye, mode='bilinear', align_corners=align_corners, **kw).view(n_in, n_out).t().contiguous()
+        if len(_INTERP_MATRICES) > 256:
+            _INTERP_MATRICES.clear()
+        _INTERP_MATRICES[key] = m
+    return m
+
+
+class _BilinearResizeFn(torch.autograd.Function):
+    """F.interpolate(mode='bilinear') whose BACKWARD is two small matrix products, gX = A_h^T gY A_w
+    (bilinear resampling is separable and linear).  ATen's upsample_bilinear2d_backward scatters with
+    atomics: 0.67 ms per call on the necks' maps, 12 calls = 8 of the 41 ms of a DfMStereoPath training
+    step at config K (profiles/r04_c8_*); the SPP branches' few-pixel maps serialise on a handful of
+    addresses.  The forward is ATen's own (bit-identical to the reference's)."""
+
+    @staticmethod
+    def forward(ctx, x, size, scale, align_corners):
+        ctx.cfg = (tuple(x.shape[2:]), scale, align_corners)
+        kw = dict(scale_factor=scale) if scale is not None else dict(size=size)
+        return F.interpolate(x, mode='bilinear', align_corners=align_corners, **kw)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (h_in, w_in), scale, ac = ctx.cfg
+        B, C, h_out, w_out = gy.shape
+        a_w = _interp_matrix(w_in, w_out, ac, scale, gy.device)            # (w_out, w_in)
+        a_h = _interp_matrix(h_in, h_out, ac, scale, gy.device)            # (h_out, h_in)
+        g = gy.reshape(B * C, h_out, w_out).float()
+        g = torch.matmul(g, a_w)                                           # (BC, h_out, w_in)
+        g = torch.matmul(a_h.t(), g)                                       # (BC, h_in, w_in)
+        return g.view(B, C, h_in, w_in).to(gy.dtype), None, None, None
+
+
+def bilinear_resize(x, size=None, scale_factor=None, align_corners=False):
+    """``F.interpolate(x, size / scale_factor, mode='bilinear', align_corners=...)``; on the GPU with autograd
+    recording the backward runs as matrix products (``_BilinearResizeFn``)"""
+    if x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+        return _BilinearResizeFn.apply(x, tuple(size) if size is not None else None, scale_factor, bool(align_corners))
+    kw = dict(scale_factor=scale_factor) if scale_factor is not None else dict(size=size)
+    return F.interpolate(x, mode='bilinear', align_corners=align_corners, **kw)
+
+
 class upconv_module(nn.Module):  # noqa: N801  (reference class name)
 
     def __init__(self, in_channels, up_channels):
@@ -674,8 +728,9 @@ class upconv_module(nn.Module):  # noqa: N801  (reference class name)
         x = feats[0]
         for i in range(self.num_stage):
             # relu(up(conv(x)) + redir(skip)): the add and the ReLU ride in redir's convolution epilogue
-            x = _conv_norm_2d(self.redir[i], feats[i + 1], residual=self.up(_conv_norm_2d(self.conv[i], x)),
-                              relu=True)
+            up = bilinear_resize(_conv_norm_2d(self.conv[i], x), scale_factor=self.up.scale_factor,
+                                 align_corners=bool(self.up.align_corners))
+            x = _conv_norm_2d(self.redir[i], feats[i + 1], residual=up, relu=True)
         return x
 
 
@@ -687,19 +742,25 @@ def _channels_last_2d(module, feats):
     then already in the pixel-major layout the plane sweep and FrustumToVoxel sample (no pack pass).
     The 4-D weights are re-laid once; shapes, values and state_dict keys are untouched.
 
-    While autograd records (training) the modules keep the caller's layout and contiguous weights: the
-    2-D MFMA path is inference-only, and torch's NHWC training kernels on this stack are MIOpen's naive
-    convolutions (60 ms per weight gradient) and ATen's channels-last bilinear backward (171 ms per call):
-    2.1 s of a 2.2 s DfMStereoPath training step at config K (profiles/r03_c43_*)."""
+    Training (autograd recording) runs NHWC as well since round 4: the 3x3 convolutions train through the
+    MFMA kernels (conv3d._Conv2dGFn: forward, backward-data, backward-weight), the 1x1 convolutions of an
+    NHWC tensor are matrix products, GroupNorm is the HIP kernel in either layout and the bilinear resizes
+    have a matrix-product backward (bilinear_resize) -- the three things that made torch's NHWC training
+    path 2.1 s per DfMStereoPath step in round 3 (MIOpen's naive NHWC convolutions, ATen's channels-last
+    bilinear backward; profiles/r03_c43_*).  ``DFM_TRAIN_NCHW=1`` (or ``module.train_nhwc = False``) keeps the
+    round-3 behaviour: NCHW between the layers, each MFMA convolution converting its operands."""
     if not feats[0].is_cuda:
         return feats
     train = torch.is_grad_enabled() and (module.training or any(f.requires_grad for f in feats))
-    want = torch.contiguous_format if train else torch.channels_last
+    # (an fp32 model's 3x3 convolutions are torch's: keep them away from MIOpen's NHWC kernels)
+    nhwc = not train or (feats[0].dtype == torch.bfloat16 and
+                         module.__dict__.get('train_nhwc', os.environ.get('DFM_TRAIN_NCHW') != '1'))
+    want = torch.channels_last if nhwc else torch.contiguous_format
     if module.__dict__.get('_weights_format') is not want:
         module.to(memory_format=want)
         module.__dict__['_weights_format'] = want
-        module.__dict__['_weights_channels_last'] = not train
-    if train:
+        module.__dict__['_weights_channels_last'] = nhwc
+    if not nhwc:
         return [f.contiguous() for f in feats]
     return [f.contiguous(memory_format=torch.channels_last) for f in feats]
 
@@ -794,8 +855,8 @@ class SPPUNetNeck(nn.Module):
             assert start_level >= 1
         self.lastconv = nn.Sequential(
             ConvModule(stereo_channel, stereo_channels[0], 3, stride=1, padding=1, norm_cfg=norm_cfg),
-            nn.Conv2d(stereo_channels[0], stereo_channels[1], kernel_size=1, padding=0, stride=1,
-                      bias=False))
+            MfmaConv2d(stereo_channels[0], stereo_channels[1], kernel_size=1, padding=0, stride=1,
+                       bias=False))
         if cat_img_feature:
             self.rpnconv = nn.Sequential(
                 ConvModule(concat_channel, sem_channels[0], 3, stride=1, padding=1, norm_cfg=norm_cfg),
@@ -896,7 +957,7 @@ class SPPUNetNeck(nn.Module):
         feats = _channels_last_2d(self, list(feats))
         concat_feature = self._spp_tail_fused(feats)
         if concat_feature is None:
-            spp = [F.interpolate(branch[1](pooled), feat_shape, mode='bilinear', align_corners=True)
+            spp = [bilinear_resize(branch[1](pooled), size=feat_shape, align_corners=True)
                    for branch, pooled in zip(self.spp_branches, self._spp_pool(feats[-1]))]
             concat_feature = torch.cat((*feats[self.start_level:], *spp), 1)
         stereo_feature = concat_feature

@@ -331,8 +331,9 @@ def test_conv2d_modules_take_the_mfma_path_only_where_it_applies(cv, monkeypatch
         y = m(x)
     assert calls['n'] == 1
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=RTOL, atol=ATOL)
-    y2 = m(x)                                # autograd on: torch's convolution
-    assert calls['n'] == 1 and y2.requires_grad
+    y2 = m(x)                                # autograd on: the training path, the same kernel
+    assert calls['n'] == 2 and y2.requires_grad
+    calls['n'] = 1
     with torch.no_grad():
         m(x.contiguous())                     # NCHW input: torch
         cv.MfmaConv2d(48, 32, 3, padding=1).to(dev).bfloat16()(x[:, :48].contiguous(memory_format=torch.channels_last))
@@ -353,3 +354,83 @@ def test_conv2d_modules_take_the_mfma_path_only_where_it_applies(cv, monkeypatch
     with torch.no_grad():
         reft = F.conv_transpose2d(x.float(), t.weight.float(), stride=2, padding=1, output_padding=1)
     np.testing.assert_allclose(yt.float().cpu().numpy(), reft.cpu().numpy(), rtol=RTOL, atol=ATOL)
+
+
+MODULE2D_CASES = [
+    ('conv', 64, 64, (20, 36), 1, False, 'nchw'),
+    ('conv', 128, 64, (16, 24), 2, False, 'nchw'),
+    ('conv', 32, 96, (9, 13), 1, True, 'nhwc'),
+    ('conv', 3, 32, (12, 20), 1, False, 'nchw'),      # the image skip of upconv_module: padded to 32 channels
+    ('convT', 64, 32, (7, 11), 2, False, 'nchw'),
+    ('convT', 128, 128, (6, 10), 2, False, 'nhwc'),
+]
+
+
+@pytest.mark.parametrize('kind,cin,cout,size,stride,bias,layout', MODULE2D_CASES)
+def test_conv2d_modules_train_through_the_mfma_kernels(cv, monkeypatch, kind, cin, cout, size, stride, bias, layout):
+    """MfmaConv2d / MfmaConvTranspose2d with autograd recording (spp_unet_neck.py:93-119,
+    bev_hourglass.py:36-137): forward, backward-data and backward-weight in the MFMA kernels, in the
+    caller's layout, against torch fp32 autograd on the bf16-rounded operands"""
+    dev = torch.device('cuda:0')
+    launched = {'g': 0, 'w': 0}
+    real_g, real_w = cv.conv3d_g, cv.conv3d_weight_grad
+    monkeypatch.setattr(cv, 'conv3d_g', lambda *a, **k: (launched.__setitem__('g', launched['g'] + 1), real_g(*a, **k))[1])
+    monkeypatch.setattr(cv, 'conv3d_weight_grad',
+                        lambda *a, **k: (launched.__setitem__('w', launched['w'] + 1), real_w(*a, **k))[1])
+    torch.manual_seed(cin + 3 * cout)
+    if kind == 'conv':
+        m = cv.MfmaConv2d(cin, cout, 3, stride=stride, padding=1, bias=bias).to(dev).bfloat16()
+    else:
+        m = cv.MfmaConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1, bias=False).to(dev).bfloat16()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, cin, *size, generator=g).bfloat16()
+    xb = x.to(dev)
+    if layout == 'nhwc':
+        xb = xb.contiguous(memory_format=torch.channels_last)
+    xb.requires_grad_(cin >= 32)
+    assert m.train_why_not(xb) is None
+    y = m(xb)
+    assert launched['g'] == 1
+    assert y.is_contiguous() if layout == 'nchw' else y.is_contiguous(memory_format=torch.channels_last)
+    xr = x.float().requires_grad_(True)
+    wr = m.weight.detach().float().cpu().requires_grad_(True)
+    br = m.bias.detach().float().cpu().requires_grad_(True) if bias else None
+    if kind == 'conv':
+        yr = F.conv2d(xr, wr, br, stride=stride, padding=1)
+    else:
+        yr = F.conv_transpose2d(xr, wr, stride=2, padding=1, output_padding=1)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), yr.detach().numpy(), rtol=RTOL, atol=ATOL)
+    gy = torch.randn(yr.shape, generator=g).bfloat16()
+    y.backward(gy.to(dev))
+    yr.backward(gy.float())
+    assert launched['w'] == 1 and launched['g'] == (2 if cin >= 32 else 1)
+    if cin >= 32:
+        np.testing.assert_allclose(xb.grad.float().cpu().numpy(), xr.grad.numpy(), rtol=RTOL, atol=5e-3)
+        assert xb.grad.stride() == xb.stride()
+    scale = float(wr.grad.abs().max())
+    np.testing.assert_allclose(m.weight.grad.float().cpu().numpy(), wr.grad.numpy(), rtol=2.0 ** -7, atol=2.0 ** -8 * scale)
+    if bias:
+        np.testing.assert_allclose(m.bias.grad.float().cpu().numpy(), br.grad.numpy(), rtol=2.0 ** -7,
+                                   atol=2.0 ** -8 * float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize('hin,win,size,scale,ac', [(3, 7, (20, 33), None, True), (5, 8, None, 2.0, False),
+                                                   (1, 4, (80, 320), None, True), (40, 160, None, 2.0, False)])
+def test_bilinear_resize_backward_as_matrix_products(hin, win, size, scale, ac):
+    """modules.bilinear_resize: ATen's forward, backward gX = A_h^T gY A_w (spp_unet_neck.py:60-70, 83-91)"""
+    import importlib
+    mods = importlib.import_module('depth-from-motion_amd.modules')
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(hin + win)
+    x = torch.randn(2, 32, hin, win, generator=g).bfloat16()
+    xb = x.to(dev).requires_grad_(True)
+    y = mods.bilinear_resize(xb, size=size, scale_factor=scale, align_corners=ac)
+    xr = x.float().requires_grad_(True)
+    kw = dict(scale_factor=scale) if scale is not None else dict(size=size)
+    yr = F.interpolate(xr, mode='bilinear', align_corners=ac, **kw)
+    assert torch.equal(y.detach().cpu(), F.interpolate(x.to(dev), mode='bilinear', align_corners=ac, **kw).cpu())
+    gy = torch.randn(yr.shape, generator=g).bfloat16()
+    y.backward(gy.to(dev))
+    yr.backward(gy.float())
+    ref = xr.grad.numpy()
+    np.testing.assert_allclose(xb.grad.float().cpu().numpy(), ref, rtol=2.0 ** -7, atol=2.0 ** -8 * float(np.abs(ref).max()))

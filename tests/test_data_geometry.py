@@ -142,7 +142,7 @@ def test_stereo_path_runs_on_a_batch_staged_on_the_device(dg):
     model['voxel_cfg'] = dict(point_cloud_range=[2, -6.4, -3, 27.6, 6.4, 1], voxel_size=[0.2, 0.2, 0.2])
     torch.manual_seed(5)
     path = pkg.DfMStereoPath(model).cuda().eval()
-    H, W = 128, 256
+    H, W = 256, 512   # (the SPP branches pool 64 x 64 windows of the quarter-resolution map)
     gen = torch.Generator().manual_seed(7)
     feats = [[torch.randn(2, c, H // s, W // s, generator=gen).cuda()
               for c, s in ((3, 1), (64, 2), (128, 4), (128, 4), (128, 4))] for _ in range(2)]
