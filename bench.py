@@ -197,7 +197,47 @@ def cpu_baseline(w, budget_s=12.0):
             res['reference_torch_cpu'] = json.load(f)
     except (OSError, ValueError):
         pass
+    try:
+        res['torch_cpu_grid_sample_this_box'] = torch_cpu_sampling(w, prm, depths, orc)
+    except Exception as e:  # never fail the bench line over a reported baseline
+        res['torch_cpu_grid_sample_this_box'] = {'error': repr(e)[:200]}
     return res
+
+
+def torch_cpu_sampling(w, prm, depths, orc, budget_s=8.0):
+    """The reference's own compute for this path is two ``F.grid_sample`` calls (dfm_backbone.py:296-311;
+    building the grids is negligible next to them).  /root/reference does not exist on the GPU box, so its
+    file cannot be timed here -- but the same library function can: ``F.grid_sample`` (bilinear, zeros,
+    align_corners=True) on PyTorch-CPU with this host's cores, on the grids the oracle builds for the same
+    geometry, one sample, a channel subset sized to the budget, scaled by C.  A reported baseline."""
+    import torch.nn.functional as F
+    cg, pg = orc.plane_sweep_grid(prm, depths)
+    cg = torch.from_numpy(cg).view(1, 1, -1, 2)
+    pg = torch.from_numpy(pg).view(1, 1, -1, 2)
+    threads = torch.get_num_threads()
+
+    def run(c_sub):
+        cur = torch.randn(1, c_sub, w['H'], w['W'])
+        prev = torch.randn(1, c_sub, w['H'], w['W'])
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            a = F.grid_sample(cur, cg, mode='bilinear', padding_mode='zeros', align_corners=True)
+            b = F.grid_sample(prev, pg, mode='bilinear', padding_mode='zeros', align_corners=True)
+            torch.cat([a.view(1, c_sub, prm.D, prm.h_out, prm.w_out), b.view(1, c_sub, prm.D, prm.h_out, prm.w_out)], 1)
+        return time.perf_counter() - t0
+    run(1)
+    t1 = run(2)
+    c_sub = int(max(2, min(w['C'], round(2 * (budget_s / 3.0) / max(t1, 1e-6)))))
+    reps, total = 0, 0.0
+    while total < budget_s and reps < 8:
+        total += run(c_sub)
+        reps += 1
+    sec_per_volume = total / reps * (w['C'] / c_sub)
+    return {'value': 1.0 / sec_per_volume, 'unit': 'cost-volumes/s', 'threads': threads,
+            'what': 'F.grid_sample x 2 + cat (the reference function\'s compute, dfm_backbone.py:296-313) on '
+                    'PyTorch-CPU fp32, this host',
+            'sample': f'1 sample, {c_sub} of {w["C"]} channels x D={w["D"]} x {prm.h_out}x{prm.w_out}, '
+                      f'{reps} repetitions, {total:.1f} s, scaled by C'}
 
 
 def secondary(args, pkg, dev, job, emit=True):
