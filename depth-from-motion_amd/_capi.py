@@ -64,6 +64,7 @@ EXPORTS = (
     'dfm_conv3d_g_weight_bytes',
     'dfm_conv3d_g_pack_weights',
     'dfm_conv3d_g_fwd',
+    'dfm_conv3d_g_fwd_f32',
     'dfm_conv3d_g_plan',
     'dfm_conv3d_wgrad_workspace_bytes',
     'dfm_conv3d_wgrad',
@@ -328,6 +329,8 @@ def lib():
     h.dfm_conv3d_g_pack_weights.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     h.dfm_conv3d_g_fwd.restype = ctypes.c_int
     h.dfm_conv3d_g_fwd.argtypes = [cp, vp, vp, fp, fp, vp, vp, vp]
+    h.dfm_conv3d_g_fwd_f32.restype = ctypes.c_int
+    h.dfm_conv3d_g_fwd_f32.argtypes = [cp, vp, vp, vp, vp, vp]
     h.dfm_conv3d_g_plan.restype = ctypes.c_int
     h.dfm_conv3d_g_plan.argtypes = [cp, ctypes.POINTER(ctypes.c_int64)]
     wp = ctypes.POINTER(Conv3dWgradDesc)

@@ -203,6 +203,12 @@ class MfmaConv3d(nn.Conv3d):
         why = self.why_not(x)
         if why is None:
             return _MfmaConvFn.apply(x, self.weight, self._packed())
+        if x.is_cuda and x.dtype == torch.float32 and 'coverage' not in why:
+            why32 = _split_why_not(self, x, 'conv')
+            if why32 is None:  # an fp32 model: the general kernel in split precision
+                return _ConvGSplitFn.apply(x, self.weight, _split_packs(self, self.in_channels, 32, False), 'conv',
+                                           self.stride, self.padding)
+            why = f'{why}; split precision: {why32}'
         _torch_path(self, x, why)
         return super().forward(x)
 
@@ -433,6 +439,13 @@ class MfmaConv3dTo1(nn.Conv3d):
         why = self.why_not(x)
         if why is None:
             return _MfmaConvTo1Fn.apply(x, self.weight, self._packed())
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and 'coverage' not in why and
+                _FP32_MODE['mode'] != 'torch' and x.shape[1] == 32 and
+                conv3d_g_plannable(x.shape[0], 32, 32, tuple(x.shape[2:]), 1, 1)):
+            # an fp32 model: the general kernel in split precision on the weight zero-padded to 32 output
+            # channels (MIOpen's naive kernel takes 1.4 s for this convolution at config K)
+            w32 = torch.cat([self.weight, self.weight.new_zeros((31, 32, 3, 3, 3))], 0)
+            return _ConvGSplitFn.apply(x, w32, None, 'conv', (1, 1, 1), (1, 1, 1))[:, :1].contiguous()
         _torch_path(self, x, why)
         return super().forward(x)
 
@@ -566,6 +579,187 @@ def conv3d_g(x, packed, cout, stride=1, padding=1, transposed=False, relu=False,
             _ptr(shift) if shift is not None else None, _ptr(residual) if residual is not None else None,
             _ptr(out), _stream_ptr(x.device)))
     return out.permute(0, 4, 1, 2, 3)
+
+
+def conv3d_g_f32(x, packed, cout, stride=1, padding=1, transposed=False, kernel1=False, acc=None):
+    """The general kernel with its fp32 accumulators stored as they are (``dfm_conv3d_g_fwd_f32``):
+    x (N, C_in, D, H, W) bf16 channels_last_3d -> fp32 (N, D', H', W', cout), plus ``acc`` (same shape;
+    accumulated in place when given)."""
+    cstride = _ndhwc_channel_stride(x)
+    assert x.is_cuda and x.dtype == torch.bfloat16 and cstride, 'bf16 channels_last_3d (or a channel slice of it)'
+    stride, padding, transposed, kernel1 = _triple(stride), _triple(padding), _triple(transposed), _triple(kernel1)
+    N, cin = x.shape[:2]
+    in_size = tuple(x.shape[2:])
+    out_size = conv3d_g_out_size(in_size, stride, padding, transposed, kernel1)
+    if acc is not None:
+        assert acc.dtype == torch.float32 and tuple(acc.shape) == (N, *out_size, cout) and acc.is_contiguous()
+        out = acc
+    else:
+        out = torch.empty((N, *out_size, cout), dtype=torch.float32, device=x.device)
+    d = _conv_desc(N, cin, cout, in_size, out_size, stride, padding, transposed, False, cstride, kernel1)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().dfm_conv3d_g_fwd_f32(ctypes.byref(d), _ptr(x), _ptr(packed),
+                                                     _ptr(acc) if acc is not None else None, _ptr(out),
+                                                     _stream_ptr(x.device)))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# fp32 models (the reference's default precision) on the same MFMA kernels: split precision.
+#   x = x0 + x1 + x2, w = w0 + w1 + w2: bf16 pieces, 8 + 8 + 8 = every significand bit of an fp32 value
+#   conv(x, w) = sum over i + j <= 2 of conv(x_i, w_j)        (dropped: products of order 2^-27)
+# six launches whose exact bf16 x bf16 products accumulate in fp32 (conv3d_g_f32) -- fp32-equivalent; with
+# two pieces / three launches ('split2') 2^-17 of the sum of |products|.  torch's own fp32 convolution on
+# this stack is MIOpen's naive kernel: 1.4 s per 32 -> 1 Conv3d, 31 ms per 2-D convolution, 2.9 s per
+# DfMStereoPath training step (profiles/r03_c46_*, r04_c13_*).  Forward, backward-data, backward-weight.
+# ---------------------------------------------------------------------------------------------
+_FP32_MODE = {'mode': 'split'}
+_SPLIT_PIECES = {'split': 3, 'split2': 2}
+
+
+def set_fp32_mode(mode):
+    """How fp32 CUDA inputs of the Mfma* convolutions run.  'split' (default): the MFMA kernels on THREE
+    bf16 pieces per operand (8 + 8 + 8 = all 24 significand bits; the six products of total order <= 2,
+    dropped terms 2^-27): fp32-equivalent results.  'split2': two pieces, three products (2^-17 of the sum of
+    |products|, half the launches).  'torch': torch's convolution (MIOpen) as in rounds 1-3.  Returns the
+    previous mode."""
+    if mode not in ('split', 'split2', 'torch'):
+        raise ValueError(mode)
+    prev, _FP32_MODE['mode'] = _FP32_MODE['mode'], mode
+    return prev
+
+
+def split_pieces(t, n=None):
+    """fp32 tensor -> n bf16 tensors of the same memory format whose sum is t to 2^-(9 n): each piece is the
+    bf16 rounding of what the previous ones left (the remainders are exact in fp32)"""
+    n = n or _SPLIT_PIECES.get(_FP32_MODE['mode'], 3)
+    pieces, r = [], t
+    for i in range(n):
+        p = r.to(torch.bfloat16)
+        pieces.append(p)
+        if i + 1 < n:
+            r = r - p
+    return pieces
+
+
+def _split_pairs(n):
+    """(operand piece, weight piece) index pairs of total order < n, largest products first"""
+    return [(i, j) for order in range(n) for i in range(order, -1, -1) for j in (order - i,)]
+
+
+def conv3d_g_split(x, weight, cin, cout, swap=False, flip=0, stride=1, padding=1, transposed=False, kernel1=False,
+                   packs=None):
+    """fp32 convolution through 6 (or 3) bf16 launches accumulated in fp32.  x: fp32 (N, cin, D, H, W), any
+    layout; weight: fp32 5-D torch weight (as ``pack_conv3d_g_weights`` takes it).  Returns fp32
+    (N, cout, D', H', W'), a channels_last_3d view.  ``packs``: cached fragment buffers of the weight's
+    pieces."""
+    xs = split_pieces(x.contiguous(memory_format=torch.channels_last_3d))
+    n = len(xs)
+    if packs is None or len(packs) != n:
+        packs = [pack_conv3d_g_weights(w, cin, cout, swap=swap, flip=flip)
+                 for w in split_pieces(weight.detach().float(), n)]
+    kw = dict(stride=stride, padding=padding, transposed=transposed, kernel1=kernel1)
+    y = None
+    for i, j in _split_pairs(n):
+        y = conv3d_g_f32(xs[i], packs[j], cout, acc=y, **kw)
+    return y.permute(0, 4, 1, 2, 3)
+
+
+def conv3d_weight_grad_split(x_in, g_out, stride, padding):
+    """``conv3d_weight_grad`` of fp32 operands: the significant pairings of their bf16 pieces, summed in fp32"""
+    xs = split_pieces(x_in.contiguous(memory_format=torch.channels_last_3d))
+    gs = split_pieces(g_out.contiguous(memory_format=torch.channels_last_3d), len(xs))
+    out = None
+    for i, j in _split_pairs(len(xs)):
+        t = conv3d_weight_grad(xs[i], gs[j], stride, padding)
+        out = t if out is None else out + t
+    return out
+
+
+class _ConvGSplitFn(torch.autograd.Function):
+    """nn.Conv3d / nn.ConvTranspose3d (k3 s2 p1 op1) of an fp32 model through the MFMA kernels in split
+    precision; input and output keep the caller's layout (NCDHW for the reference's pipeline).
+    ``two_d``: x is a depth-1 view of an NCHW / NHWC tensor and weight a 2-D kernel embedded in the centre
+    depth slice (``_embed2d``): kernel extent 1 along depth, stride / transposition on (h, w) only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, packs, kind, stride, padding, two_d=False):
+        cl = torch.channels_last_3d
+        keep_cl = x.is_contiguous(memory_format=cl) and not x.is_contiguous()
+        xd = x.detach()
+        k1 = (True, False, False) if two_d else False
+        if kind == 'conv':
+            cout, cin = weight.shape[:2]
+            y = conv3d_g_split(xd, weight, cin, cout, stride=stride, padding=padding, kernel1=k1, packs=packs)
+        else:
+            cin, cout = weight.shape[:2]
+            y = conv3d_g_split(xd, weight, cin, cout, swap=True, stride=1, padding=(0, 1, 1) if two_d else 1,
+                               transposed=(False, True, True) if two_d else True, kernel1=k1, packs=packs)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (kind, stride, padding, keep_cl, two_d)
+        return y if keep_cl else y.contiguous()
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        kind, stride, padding, keep_cl, two_d = ctx.cfg
+        gx = gw = None
+        in_size = tuple(x.shape[2:])
+        w = weight.detach().float()
+        k1 = (True, False, False) if two_d else False
+        wpad = (1, 1, 1) if two_d else None   # weight gradient of a depth-1 volume: the 27-tap kernel, depth padded
+        if kind == 'conv':
+            cout, cin = weight.shape[:2]
+            stride, padding = _triple(stride), _triple(padding)
+            if ctx.needs_input_grad[0]:
+                if _bwd_data_supported(in_size, stride, (1, 1, 1) if two_d else padding):
+                    up = tuple(st == 2 for st in stride)
+                    flip = sum(b for b, st in zip((4, 2, 1), stride) if st == 1)
+                    bpad = (0, 1, 1) if two_d else tuple(2 - p for p in padding)
+                    gx = conv3d_g_split(gy, w, cout, cin, swap=True, flip=flip, stride=1, padding=bpad,
+                                        transposed=up, kernel1=k1)
+                else:
+                    gx = torch.ops.aten.convolution_backward(
+                        gy, x, w, None, list(stride), list((1, 1, 1) if two_d else padding), [1, 1, 1], False,
+                        [0, 0, 0], 1, [True, False, False])[0]
+            if ctx.needs_input_grad[1]:
+                gw = conv3d_weight_grad_split(x, gy, stride, wpad or padding).to(weight.dtype)
+        else:
+            cin, cout = weight.shape[:2]
+            if ctx.needs_input_grad[0]:
+                gx = conv3d_g_split(gy, w, cout, cin, swap=False, flip=0, stride=(1, 2, 2) if two_d else 2,
+                                    padding=(0, 1, 1) if two_d else 1, kernel1=k1)
+            if ctx.needs_input_grad[1]:
+                gw = conv3d_weight_grad_split(gy, x, (1, 2, 2) if two_d else 2, wpad or 1).to(weight.dtype)
+        if gx is not None and not keep_cl:
+            gx = gx.contiguous()
+        return gx, gw, None, None, None, None, None
+
+
+def _split_why_not(module, x, kind):
+    """why an fp32 CUDA input does NOT take the split-precision MFMA path (None: it does)"""
+    if _FP32_MODE['mode'] == 'torch':
+        return 'set_fp32_mode("torch")'
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] == module.in_channels):
+        return 'not an fp32 GPU call of this module'
+    n, size = x.shape[0], tuple(x.shape[2:])
+    if kind == 'conv':
+        if not all(s + 2 * p >= 3 for s, p in zip(size, module.padding)):
+            return 'input smaller than the kernel'
+        ok = conv3d_g_plannable(n, module.in_channels, module.out_channels, size, module.stride, module.padding)
+    else:
+        ok = conv3d_g_plannable(n, module.in_channels, module.out_channels, size, 1, 1, transposed=True)
+    return None if ok else 'no tiling of the general kernel fits this shape'
+
+
+def _split_packs(module, cin, cout, swap):
+    """(hi, lo) fragment buffers of the module's fp32 weight, cached per weight version"""
+    key = (module.weight._version, module.weight.data_ptr(), str(module.weight.device), _FP32_MODE['mode'])
+    if module.__dict__.get('_split_key') != key:
+        module.__dict__['_split_packs'] = [pack_conv3d_g_weights(w, cin, cout, swap=swap)
+                                           for w in split_pieces(module.weight.detach().float())]
+        module.__dict__['_split_key'] = key
+    return module.__dict__['_split_packs']
 
 
 # ---------------------------------------------------------------------------------------------
@@ -810,10 +1004,32 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
             why = self.why_not(x)
             if why is None:
                 return self.forward_fused(x)
+        if self.kernel_size == (3, 3) and x.is_cuda and x.dtype == torch.float32 and 'coverage' not in why:
+            y = self._forward_fp32_split(x)
+            if y is not None:
+                return y
         # (the 1x1 convolutions built through convbn() are torch's by design)
         if self.kernel_size == (3, 3):
             _torch_path(self, x, why)
         return super().forward(x)
+
+    def _forward_fp32_split(self, x):
+        """an fp32 model: the depth-1 form of the general kernel in split precision (None: not applicable)"""
+        if _FP32_MODE['mode'] == 'torch' or x.dim() != 4 or x.shape[1] != self.in_channels:
+            return None
+        n, cin, h, w_ = x.shape
+        st, cout, cin_p = self.stride[0], self.out_channels, self._cin_padded()
+        if not conv3d_g_plannable(n, cin_p, cout, (1, h, w_), (1, st, st), (0, 1, 1), kernel1=(True, False, False)):
+            return None
+        w = self.weight
+        if cin < 32:  # the 3-channel image skip: zero channels up to one 32-channel chunk
+            x = torch.cat([x, x.new_zeros((n, 32 - cin, h, w_))], 1)
+            w = torch.cat([w, w.new_zeros((cout, 32 - cin, 3, 3))], 1)
+        keep_cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        y = _ConvGSplitFn.apply(x.unsqueeze(2), _embed2d(w), None, 'conv', (1, st, st), (0, 1, 1), True).squeeze(2)
+        if self.bias is not None:
+            y = y + self.bias.view(1, -1, 1, 1)
+        return y if keep_cl else y.contiguous()
 
 
 class MfmaConvTranspose2d(nn.ConvTranspose2d, _Mfma2dMixin):
@@ -869,6 +1085,13 @@ class MfmaConvTranspose2d(nn.ConvTranspose2d, _Mfma2dMixin):
             if why is None:
                 return conv2d_g(x, self._packed2d(self.in_channels, self.out_channels, True), self.out_channels,
                                 transposed=True)
+        if (output_size is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and
+                'coverage' not in why and _FP32_MODE['mode'] != 'torch' and x.shape[1] == self.in_channels and
+                conv3d_g_plannable(x.shape[0], self.in_channels, self.out_channels, (1, x.shape[2], x.shape[3]),
+                                   (1, 1, 1), (0, 1, 1), transposed=(False, True, True), kernel1=(True, False, False))):
+            keep_cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+            y = _ConvGSplitFn.apply(x.unsqueeze(2), _embed2d(self.weight), None, 'convT', 2, 1, True).squeeze(2)
+            return y if keep_cl else y.contiguous()
         _torch_path(self, x, why)
         return super().forward(x, output_size)
 
@@ -964,6 +1187,13 @@ class MfmaConv3dG(nn.Conv3d):
         why = self.why_not(x)
         if why is None:
             return _ConvGFn.apply(x, self.weight, self._packed(), 'conv', self.stride, self.padding)
+        if x.is_cuda and x.dtype == torch.float32 and 'coverage' not in why:
+            why32 = _split_why_not(self, x, 'conv')
+            if why32 is None:  # an fp32 model: the same kernel in split precision
+                return _ConvGSplitFn.apply(x, self.weight,
+                                           _split_packs(self, self.in_channels, self.out_channels, False), 'conv',
+                                           self.stride, self.padding)
+            why = f'{why}; split precision: {why32}'
         _torch_path(self, x, why)
         return super().forward(x)
 
@@ -1009,5 +1239,12 @@ class MfmaConvTranspose3d(nn.ConvTranspose3d):
         why = self.why_not(x) if output_size is None else 'explicit output_size'
         if why is None:
             return _ConvGFn.apply(x, self.weight, self._packed(), 'convT', self.stride, self.padding)
+        if output_size is None and x.is_cuda and x.dtype == torch.float32 and 'coverage' not in why:
+            why32 = _split_why_not(self, x, 'convT')
+            if why32 is None:  # an fp32 model: the same kernel in split precision
+                return _ConvGSplitFn.apply(x, self.weight,
+                                           _split_packs(self, self.in_channels, self.out_channels, True), 'convT',
+                                           self.stride, self.padding)
+            why = f'{why}; split precision: {why32}'
         _torch_path(self, x, why)
         return super().forward(x, output_size)

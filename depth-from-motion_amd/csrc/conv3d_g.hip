@@ -105,7 +105,10 @@ __global__ void conv3d_g_pack_kernel(const TW *__restrict__ w, int rows, int kk,
     }
 }
 
-template <int CW, int PFW>
+// F32 == true: the split-precision mode of fp32 models (dfm_conv3d_g_fwd_f32): the fp32 accumulators are
+// stored as they are -- plus `residual`, then a float buffer of the output's shape -- so that the terms
+// x_hi*w_hi + x_lo*w_hi + x_hi*w_lo of one convolution add up in fp32 over three launches.
+template <int CW, int PFW, bool F32 = false>
 __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
     GGeom g, const bf16_t *__restrict__ x, const uint4 *__restrict__ wfrag,
     const float *__restrict__ scale, const float *__restrict__ shift,
@@ -376,7 +379,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
                 }
             }
         };
-        if (scale) {
+        if constexpr (F32) {
+            const float *acc_in = (const float *)residual;
+            float *out32 = (float *)out;
+#pragma unroll
+            for (int f = 0; f < PFW; ++f) {
+                if (opix[f] < 0) continue;
+                const size_t vox = osample + (size_t)opix[f];
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int ch = (ct * CW + c) * 32 + 8 * gq + 4 * half;
+                        float4 v = make_float4(acc[f][c][4 * gq], acc[f][c][4 * gq + 1], acc[f][c][4 * gq + 2],
+                                               acc[f][c][4 * gq + 3]);
+                        if (acc_in) {
+                            const float4 a = *(const float4 *)(acc_in + vox * g.cout + ch);
+                            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                        }
+                        *(float4 *)(out32 + vox * g.cout + ch) = v;
+                    }
+            }
+        } else if (scale) {
             if (residual) epilogue(std::true_type{}, std::true_type{});
             else epilogue(std::true_type{}, std::false_type{});
         } else {
@@ -546,9 +570,28 @@ extern "C" DFM_API int dfm_conv3d_g_pack_weights(const void *weight, int32_t wei
     return DFM_OK;
 }
 
+static int conv3d_g_launch(const dfm_conv3d_desc *desc, const void *x, const void *packed_weights,
+                           const float *scale, const float *shift, const void *residual, void *out,
+                           void *stream, bool f32);
+
 extern "C" DFM_API int dfm_conv3d_g_fwd(const dfm_conv3d_desc *desc, const void *x, const void *packed_weights,
                                         const float *scale, const float *shift, const void *residual,
                                         void *out, void *stream)
+{
+    return conv3d_g_launch(desc, x, packed_weights, scale, shift, residual, out, stream, false);
+}
+
+extern "C" DFM_API int dfm_conv3d_g_fwd_f32(const dfm_conv3d_desc *desc, const void *x, const void *packed_weights,
+                                            const float *acc_in, float *out, void *stream)
+{
+    if (desc && desc->relu) return set_error(DFM_ERR_INVALID_ARG, "the fp32-accumulating form has no epilogue");
+    if ((((uintptr_t)out) | ((uintptr_t)acc_in)) & 15) return set_error(DFM_ERR_INVALID_ARG, "fp32 buffers must be 16-byte aligned");
+    return conv3d_g_launch(desc, x, packed_weights, nullptr, nullptr, acc_in, out, stream, true);
+}
+
+static int conv3d_g_launch(const dfm_conv3d_desc *desc, const void *x, const void *packed_weights,
+                           const float *scale, const float *shift, const void *residual, void *out,
+                           void *stream, bool f32)
 {
     const int rc = g_check(desc);
     if (rc != DFM_OK) return rc;
@@ -567,11 +610,19 @@ extern "C" DFM_API int dfm_conv3d_g_fwd(const dfm_conv3d_desc *desc, const void 
     const int lds = (int)pl.lds;
 #define G_LAUNCH(CW_, PFW_)                                                                              \
     do {                                                                                             \
-        const int rc_ = ensure_dynamic_lds((const void *)conv3d_g_kernel<CW_, PFW_>, 160 * 1024);    \
-        if (rc_ != DFM_OK) return rc_;                                                               \
-        hipLaunchKernelGGL((conv3d_g_kernel<CW_, PFW_>), grid, dim3(256), lds, st, pl.g,             \
-                           (const bf16_t *)x, wfrag, scale, shift, (const bf16_t *)residual,         \
-                           (bf16_t *)out, zero);                                                     \
+        if (f32) {                                                                                   \
+            const int rc_ = ensure_dynamic_lds((const void *)conv3d_g_kernel<CW_, PFW_, true>, 160 * 1024); \
+            if (rc_ != DFM_OK) return rc_;                                                           \
+            hipLaunchKernelGGL((conv3d_g_kernel<CW_, PFW_, true>), grid, dim3(256), lds, st, pl.g,   \
+                               (const bf16_t *)x, wfrag, scale, shift, (const bf16_t *)residual,     \
+                               (bf16_t *)out, zero);                                                 \
+        } else {                                                                                     \
+            const int rc_ = ensure_dynamic_lds((const void *)conv3d_g_kernel<CW_, PFW_>, 160 * 1024); \
+            if (rc_ != DFM_OK) return rc_;                                                           \
+            hipLaunchKernelGGL((conv3d_g_kernel<CW_, PFW_>), grid, dim3(256), lds, st, pl.g,         \
+                               (const bf16_t *)x, wfrag, scale, shift, (const bf16_t *)residual,     \
+                               (bf16_t *)out, zero);                                                 \
+        }                                                                                            \
     } while (0)
     if (pl.cw == 2) {
         switch (pl.pfw) {

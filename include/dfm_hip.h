@@ -649,6 +649,15 @@ DFM_API int dfm_conv3d_g_pack_weights(const void *weight, int32_t weight_dtype, 
 DFM_API int dfm_conv3d_g_fwd(const dfm_conv3d_desc *desc, const void *x, const void *packed_weights,
                              const float *scale, const float *shift, const void *residual,
                              void *out, void *stream);
+/* Split-precision mode for fp32 models: the same kernel, but the fp32 accumulators are stored as they
+ * are into `out` (fp32, (N, D', H', W', cout)), plus `acc_in` (same shape, may be NULL, may equal `out`).
+ * A fp32 convolution y = conv(x, w) is then three launches on bf16 operands,
+ *   x = x_hi + x_lo, w = w_hi + w_lo:  y = conv(x_hi, w_hi) + conv(x_lo, w_hi) + conv(x_hi, w_lo)
+ * accumulated in fp32 (the dropped term is 2^-18 of a product): what nn.Conv3d / ConvTranspose3d
+ * (dfm_backbone.py:175-201, conv_modules.py:73-149, imvoxel_neck.py:26-55) compute at the reference's
+ * default precision, without MIOpen.  desc->relu must be 0; no scale / shift / residual. */
+DFM_API int dfm_conv3d_g_fwd_f32(const dfm_conv3d_desc *desc, const void *x, const void *packed_weights,
+                                 const float *acc_in, float *out, void *stream);
 /* The tiling dfm_conv3d_g_fwd uses for desc: {pixel fragments per wave, channel fragments per
  * wave, tile d, tile h, tile w, staged pixels, LDS bytes, workgroups}. */
 DFM_API int dfm_conv3d_g_plan(const dfm_conv3d_desc *desc, int64_t *plan8);

@@ -434,3 +434,109 @@ def test_bilinear_resize_backward_as_matrix_products(hin, win, size, scale, ac):
     yr.backward(gy.float())
     ref = xr.grad.numpy()
     np.testing.assert_allclose(xb.grad.float().cpu().numpy(), ref, rtol=2.0 ** -7, atol=2.0 ** -8 * float(np.abs(ref).max()))
+
+
+SPLIT_CASES = [
+    ('conv', 'MfmaConv3dG', 32, 64, (8, 12, 16), 2, 1),
+    ('conv', 'MfmaConv3dG', 64, 64, (6, 10, 12), 1, 1),
+    ('conv', 'MfmaConv3d', 64, 32, (5, 9, 12), 1, 1),
+    ('conv', 'MfmaConv3dG', 64, 128, (4, 8, 12), (1, 1, 2), 1),
+    ('convT', 'MfmaConvTranspose3d', 64, 32, (3, 6, 8), 2, 1),
+]
+
+
+@pytest.mark.parametrize('mode,nl,tol', [('split', 6, 2e-6), ('split2', 3, 1e-4)])
+@pytest.mark.parametrize('kind,cls,cin,cout,size,stride,padding', SPLIT_CASES)
+def test_fp32_modules_run_the_mfma_kernels_in_split_precision(cv, monkeypatch, kind, cls, cin, cout, size, stride,
+                                                              padding, mode, nl, tol):
+    """the reference's default precision (dfm_backbone.py:175-201, conv_modules.py:73-149): an fp32 NCDHW
+    call of an Mfma* module = six (three bf16 pieces per operand: fp32-equivalent) or three ('split2')
+    bf16 launches accumulated in fp32, forward and both gradients; compared with torch fp32 autograd on the
+    CPU (whose own summation order differs at the 1e-6 level)"""
+    dev = torch.device('cuda:0')
+    launched = {'f': 0, 'w': 0}
+    real_f, real_w = cv.conv3d_g_f32, cv.conv3d_weight_grad
+    monkeypatch.setattr(cv, 'conv3d_g_f32', lambda *a, **k: (launched.__setitem__('f', launched['f'] + 1), real_f(*a, **k))[1])
+    monkeypatch.setattr(cv, 'conv3d_weight_grad',
+                        lambda *a, **k: (launched.__setitem__('w', launched['w'] + 1), real_w(*a, **k))[1])
+    prev = cv.set_fp32_mode(mode)
+    try:
+        torch.manual_seed(cin + cout)
+        if kind == 'conv':
+            m = getattr(cv, cls)(cin, cout, 3, stride=stride, padding=padding, bias=False).to(dev)
+        else:
+            m = cv.MfmaConvTranspose3d(cin, cout, 3, stride=2, padding=1, output_padding=1, bias=False).to(dev)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(2, cin, *size, generator=g)
+        xb = x.to(dev).requires_grad_(True)
+        y = m(xb)
+        assert launched['f'] == nl and y.dtype == torch.float32 and y.is_contiguous()
+        xr = x.clone().requires_grad_(True)
+        wr = m.weight.detach().cpu().clone().requires_grad_(True)
+        if kind == 'conv':
+            yr = F.conv3d(xr, wr, stride=stride, padding=padding)
+        else:
+            yr = F.conv_transpose3d(xr, wr, stride=2, padding=1, output_padding=1)
+        sc = float(yr.detach().abs().max())
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=tol, atol=tol * sc)
+        gy = torch.randn(yr.shape, generator=g)
+        y.backward(gy.to(dev))
+        yr.backward(gy)
+        assert launched['f'] == 2 * nl and launched['w'] == nl
+        np.testing.assert_allclose(xb.grad.cpu().numpy(), xr.grad.numpy(), rtol=tol, atol=tol * float(xr.grad.abs().max()))
+        np.testing.assert_allclose(m.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=tol,
+                                   atol=4 * tol * float(wr.grad.abs().max()))
+        cv.set_fp32_mode('torch')
+        with torch.no_grad():
+            y_t = m(x.to(dev))
+        assert launched['f'] == 2 * nl
+        np.testing.assert_allclose(y_t.cpu().numpy(), yr.detach().numpy(), rtol=1e-3, atol=1e-3 * sc)
+    finally:
+        cv.set_fp32_mode(prev)
+
+
+def test_fp32_prediction_and_2d_convolutions_in_split_precision(cv, monkeypatch):
+    """Conv3d(32 -> 1) (dfm_backbone.py:120-127), Conv2d 3x3 stride 1 | 2 (+bias, 3-channel input) and
+    ConvTranspose2d x2 (conv_modules.py:152-214) of an fp32 model: forward + gradients vs torch fp32"""
+    dev = torch.device('cuda:0')
+    launched = {'f': 0}
+    real_f = cv.conv3d_g_f32
+    monkeypatch.setattr(cv, 'conv3d_g_f32', lambda *a, **k: (launched.__setitem__('f', launched['f'] + 1), real_f(*a, **k))[1])
+    g = torch.Generator().manual_seed(3)
+    cases = [
+        (cv.MfmaConv3dTo1(32, 1, 3, 1, 1, bias=False), (2, 32, 5, 8, 12),
+         lambda x, w, b: F.conv3d(x, w, padding=1)),
+        (cv.MfmaConv2d(64, 96, 3, stride=1, padding=1, bias=True), (2, 64, 14, 22),
+         lambda x, w, b: F.conv2d(x, w, b, padding=1)),
+        (cv.MfmaConv2d(128, 64, 3, stride=2, padding=1, bias=False), (1, 128, 16, 24),
+         lambda x, w, b: F.conv2d(x, w, stride=2, padding=1)),
+        (cv.MfmaConv2d(3, 32, 3, stride=1, padding=1, bias=False), (2, 3, 12, 20),
+         lambda x, w, b: F.conv2d(x, w, padding=1)),
+        (cv.MfmaConvTranspose2d(64, 32, 3, stride=2, padding=1, output_padding=1, bias=False), (2, 64, 7, 11),
+         lambda x, w, b: F.conv_transpose2d(x, w, stride=2, padding=1, output_padding=1)),
+    ]
+    for m, shape, ref_fn in cases:
+        torch.manual_seed(shape[1])
+        m = m.to(dev)
+        x = torch.randn(*shape, generator=g)
+        xb = x.to(dev).requires_grad_(True)
+        before = launched['f']
+        y = m(xb)
+        assert launched['f'] == before + 6, type(m).__name__
+        xr = x.clone().requires_grad_(True)
+        wr = m.weight.detach().cpu().clone().requires_grad_(True)
+        br = m.bias.detach().cpu().clone().requires_grad_(True) if m.bias is not None else None
+        yr = ref_fn(xr, wr, br)
+        assert y.shape == yr.shape and y.is_contiguous()
+        tol = 2e-6
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=tol,
+                                   atol=tol * float(yr.detach().abs().max()))
+        gy = torch.randn(yr.shape, generator=g)
+        y.backward(gy.to(dev))
+        yr.backward(gy)
+        np.testing.assert_allclose(xb.grad.cpu().numpy(), xr.grad.numpy(), rtol=tol, atol=tol * float(xr.grad.abs().max()))
+        np.testing.assert_allclose(m.weight.grad.cpu().numpy(), wr.grad.numpy(), rtol=tol,
+                                   atol=4 * tol * float(wr.grad.abs().max()))
+        if br is not None:
+            np.testing.assert_allclose(m.bias.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-5,
+                                       atol=1e-5 * float(br.grad.abs().max()))

@@ -220,20 +220,41 @@ def test_fp32_pipeline_reaches_the_mfma_kernels_through_the_switch(pkg, policy, 
     monkeypatch.setattr(cv, 'conv3d_g', lambda *a, **k: (calls.__setitem__('g', calls['g'] + 1), real_g(*a, **k))[1])
     monkeypatch.setattr(cv, 'conv3d_k3_c32',
                         lambda *a, **k: (calls.__setitem__('c32', calls['c32'] + 1), real_c(*a, **k))[1])
-    # 1. as built (fp32): torch convolutions, and the modules say so -- once per (class, reason)
+    f32 = {'n': 0}
+    real_f = cv.conv3d_g_f32
+    monkeypatch.setattr(cv, 'conv3d_g_f32', lambda *a, **k: (f32.__setitem__('n', f32['n'] + 1), real_f(*a, **k))[1])
+    # 1. as built (fp32, the reference's default precision): the MFMA kernels in split precision -- no bf16
+    #    launch, no torch convolution for a 3x3(x3) convolution whose channel counts the kernels cover
     with torch.no_grad(), warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
         ref_cls, ref_preds, ref_up = det(img, [_meta(H, W)])
-    assert calls == {'g': 0, 'c32': 0}
+    assert calls == {'g': 0, 'c32': 0} and f32['n'] >= 6 * 30, f32
     msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
-    assert any('MfmaConv3d(' in m and 'float32' in m and 'enable_fast_path' in m for m in msgs)
-    assert any('MfmaConv3dG(' in m for m in msgs) and any('MfmaConv2d(' in m for m in msgs)
-    assert len(msgs) == len(set(m.split(':')[0].split('(')[0] + m.split(';')[0].split(':', 1)[1] for m in msgs)), \
-        'one warning per (module class, reason)'
-    # 2. strict mode: the same call is an error
-    cv.set_fallback_policy('raise')
-    with torch.no_grad(), pytest.raises(pkg.MfmaPathError, match='float32'):
-        det(img, [_meta(H, W)])
+    assert not any('float32' in m for m in msgs), msgs
+    # 1b. set_fp32_mode('torch') restores rounds 1-3: torch convolutions, and the modules say so -- once per
+    #     (class, reason)
+    prev_mode = cv.set_fp32_mode('torch')
+    try:
+        n_before = f32['n']
+        with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            t_cls, t_preds, _ = det(img, [_meta(H, W)])
+        assert f32['n'] == n_before
+        msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+        assert any('MfmaConv3d(' in m and 'float32' in m and 'enable_fast_path' in m for m in msgs)
+        assert any('MfmaConv3dG(' in m for m in msgs) and any('MfmaConv2d(' in m for m in msgs)
+        assert len(msgs) == len(set(m.split(':')[0].split('(')[0] + m.split(';')[0].split(':', 1)[1] for m in msgs)), \
+            'one warning per (module class, reason)'
+        # split precision reproduces torch's fp32 convolutions (summation order apart)
+        for a, b in ((ref_cls, t_cls), (ref_preds, t_preds)):
+            assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-5
+        # 2. strict mode: the same call is an error
+        cv.set_fallback_policy('raise')
+        with torch.no_grad(), pytest.raises(pkg.MfmaPathError, match='float32'):
+            det(img, [_meta(H, W)])
+    finally:
+        cv.set_fp32_mode(prev_mode)
+    cv.set_fallback_policy('warn')
     # 3. the switch: same fp32 images in, fp32 out, every convolution of the path an MFMA launch
     rep = pkg.enable_fast_path(det, strict=True)
     assert rep['converted_parameters'] > 30

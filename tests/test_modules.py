@@ -94,7 +94,18 @@ def _load(module, seed):
 
 
 @pytest.mark.gpu
-def test_dfm_backbone_forward_vs_reference_module(mods, gold):
+def test_dfm_backbone_forward_vs_reference_module(mods, gold, monkeypatch):
+    """fp32, the reference's default precision: every 3x3x3 convolution of the aggregation stacks runs the
+    MFMA kernel in split precision (conv3d._ConvGSplitFn: three bf16 launches accumulated in fp32) -- no
+    torch / MIOpen convolution behind this comparison with the reference module's output"""
+    import importlib
+    cv = importlib.import_module('depth-from-motion_amd.conv3d')
+    launched = {'n': 0}
+    real = cv.conv3d_g_f32
+    monkeypatch.setattr(cv, 'conv3d_g_f32', lambda *a, **k: (launched.__setitem__('n', launched['n'] + 1), real(*a, **k))[1])
+    torch_convs = {'n': 0}
+    real_torch = cv._torch_path
+    monkeypatch.setattr(cv, '_torch_path', lambda *a, **k: (torch_convs.__setitem__('n', torch_convs['n'] + 1), real_torch(*a, **k))[1])
     m = _load(mods.DfMBackbone(in_channels=4, cv_channels=32, cost_sample_factor=4,
                                depth_cfg=DEPTH_CFG), 11)
     m.downsampled_depth = torch.from_numpy(gold['bb_depths'])
@@ -107,6 +118,11 @@ def test_dfm_backbone_forward_vs_reference_module(mods, gold):
     np.testing.assert_allclose(sfeat.cpu().numpy(), gold['bb_stereo'], **CONV_TOL)
     np.testing.assert_allclose(mfeat.cpu().numpy(), gold['bb_mono'], **CONV_TOL)
     np.testing.assert_allclose(cost.cpu().numpy(), gold['bb_cost'], **CONV_TOL)
+    # dres1 (2 convolutions) + the hourglass (6) per branch, 3 launches each; dres0 / dres0_mono have 8 / 4
+    # input channels here (in_channels=4) and the 32 -> 1 prediction heads are not 3x3x3 -> 32 k: torch
+    # 6 launches each (three bf16 pieces per operand)
+    assert launched['n'] >= 2 * 8 * 6, launched
+    assert torch_convs['n'] <= 4, torch_convs
 
 
 @pytest.mark.gpu
