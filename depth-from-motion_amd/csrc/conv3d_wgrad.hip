@@ -68,7 +68,11 @@ __device__ __forceinline__ void transpose4x8(const uint4 (&q)[4], u32x2_t (&t)[8
     }
 }
 
-template <int SW>
+// FLAT: the volume has depth 1 and depth padding 1 (a 2-D convolution run as a depth-1 volume: the
+// training path of the 2-D necks).  Only the centre depth slice of the 27 taps can be non-zero, so one
+// slice is staged instead of three and the three waves take the three kernel ROWS (kh) instead of the
+// three depth slices: a third of the staging and of the MFMAs of the general form.
+template <int SW, bool FLAT = false>
 __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const bf16_t *__restrict__ G,
                                                                  const bf16_t *__restrict__ X,
                                                                  float *__restrict__ part)
@@ -78,16 +82,17 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
     constexpr int NPH = SW;                 // phases (stride 2: even / odd input positions)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int RH = (WG_TH - 1) * g.sh + 3;  // input rows per depth slice
-    bf16_t *XS = (bf16_t *)smem;                                  // [3][RH][NPH][32][EP]
-    bf16_t *GT = XS + (size_t)3 * RH * NPH * 32 * EP;             // [WG_TH][32][TW]
+    constexpr int NZ = FLAT ? 1 : 3;        // staged depth slices
+    bf16_t *XS = (bf16_t *)smem;                                  // [NZ][RH][NPH][32][EP]
+    bf16_t *GT = XS + (size_t)NZ * RH * NPH * 32 * EP;            // [WG_TH][32][TW]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l32 = lane & 31, half = lane >> 5;
     const int pair = blockIdx.y;
     const int a0 = (pair / g.b_tiles) * 32, b0 = (pair % g.b_tiles) * 32;
 
-    f32x16_t acc[3][3];
+    f32x16_t acc[NZ][3];  // FLAT: acc[0][kw] of this wave's kernel row
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NZ; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
 
         // ---- stage x^T: rows (z, ihr), phases, 4 channel blocks, EP / 4 groups of 4 positions ----
         {
-            const int items = 3 * RH * NPH * 4 * (EP / 4);
+            const int items = NZ * RH * NPH * 4 * (EP / 4);
             const bf16_t *xb = X + (size_t)n * g.xsN + b0;
             for (int it = tid; it < items; it += WG_THREADS) {
                 int q = it;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
                 const int ph = q % NPH; q /= NPH;
                 const int ihr = q % RH;
                 const int z = q / RH;
-                const int id = od * g.sd - g.pd + z;
+                const int id = od * g.sd - g.pd + (FLAT ? 1 : z);
                 const int ih = oh0 * g.sh - g.ph + ihr;
                 const bool rok = (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi;
                 const bf16_t *rowp = xb + (size_t)id * g.xsD + (size_t)ih * g.xsH + cb * 8;
@@ -159,8 +164,8 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
         }
         __syncthreads();
 
-        // ---- MFMAs: wave = kernel depth slice ----
-        const int z = wave;
+        // ---- MFMAs: wave = kernel depth slice (FLAT: kernel row of the one slice) ----
+        const int z = FLAT ? 0 : wave;
 #pragma unroll
         for (int ohr = 0; ohr < WG_TH; ++ohr) {
 #pragma unroll
@@ -172,7 +177,8 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
                 }
                 const int m0 = ks * 16 + half * 8 + 8;
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
+                for (int khi = 0; khi < NZ; ++khi) {
+                    const int kh = FLAT ? wave : khi;
                     const int ihr = ohr * g.sh + kh;
                     const bf16_t *base = XS + ((size_t)(z * RH + ihr) * NPH * 32 + l32) * EP;
                     u32x4_t f0, f1, f2;
@@ -198,9 +204,9 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
                     __builtin_memcpy(&b0f, &f0, 16);
                     __builtin_memcpy(&b1f, &f1, 16);
                     __builtin_memcpy(&b2f, &f2, 16);
-                    acc[kh][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0f, acc[kh][0], 0, 0, 0);
-                    acc[kh][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1f, acc[kh][1], 0, 0, 0);
-                    acc[kh][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2f, acc[kh][2], 0, 0, 0);
+                    acc[khi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0f, acc[khi][0], 0, 0, 0);
+                    acc[khi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1f, acc[khi][1], 0, 0, 0);
+                    acc[khi][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2f, acc[khi][2], 0, 0, 0);
                 }
             }
         }
@@ -210,14 +216,15 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
     // ---- this workgroup's partial: part[pair][wg][tap][a][b] ----
     float *pp = part + ((size_t)pair * g.wgs_per_pair + blockIdx.x) * (27 * 1024);
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int khi = 0; khi < NZ; ++khi)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            const int tap = (wave * 3 + kh) * 3 + kw;
+            // FLAT: the centre slice's row `wave` (the reduce pass writes zeros for the other two slices)
+            const int tap = FLAT ? (3 + wave) * 3 + kw : (wave * 3 + khi) * 3 + kw;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int a = 8 * (i >> 2) + 4 * half + (i & 3);
-                pp[((size_t)tap * 32 + a) * 32 + l32] = acc[kh][kw][i];
+                pp[((size_t)tap * 32 + a) * 32 + l32] = acc[khi][kw][i];
             }
         }
 }
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
 // 64 consecutive elements per block, the workgroup partials split over 4 thread groups (the sum of
 // up to 512 partials per element is latency-bound when one thread walks them all)
 __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *__restrict__ part, int wgs_per_pair,
-                                                                  int b_tiles, int B, int swap_hw,
+                                                                  int b_tiles, int B, int swap_hw, int flat,
                                                                   float *__restrict__ out)
 {
     __shared__ float sh[4][64];
@@ -235,7 +242,10 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *_
     const int idx = blockIdx.x * 64 + e;  // tap * 1024 + a * 32 + b  (27 * 1024 is a multiple of 64)
     const float *p = part + (size_t)pair * wgs_per_pair * (27 * 1024) + idx;
     float s = 0.0f;
-    for (int w = sub; w < wgs_per_pair; w += 4) s += p[(size_t)w * (27 * 1024)];
+    // flat (depth-1 volume): only the centre depth slice (taps 9..17) was computed and written
+    const bool live = !flat || ((idx >> 10) >= 9 && (idx >> 10) < 18);  // (uniform per block: 1024 % 64 == 0)
+    if (live)
+        for (int w = sub; w < wgs_per_pair; w += 4) s += p[(size_t)w * (27 * 1024)];
     sh[sub][e] = s;
     __syncthreads();
     if (sub) return;
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *_
 
 struct WPlan {
     WGeom g;
-    int sw, swap, pairs;
+    int sw, swap, pairs, flat;
     size_t lds, scratch;
 };
 
@@ -293,7 +303,9 @@ int wgrad_plan(const dfm_conv3d_wgrad_desc *d, WPlan &pl)
     int wpp = (int)std::max<long long>(1, std::min<long long>((512 + pl.pairs - 1) / pl.pairs, (nt + 7) / 8));
     g.wgs_per_pair = wpp;
     const int RH = (WG_TH - 1) * g.sh + 3, EP = TW + 16;
-    pl.lds = ((size_t)3 * RH * pl.sw * 32 * EP + (size_t)WG_TH * 32 * TW) * 2;
+    // a depth-1 volume with depth padding 1 (a 2-D convolution): the centre depth slice only
+    pl.flat = (g.Di == 1 && g.Do == 1 && g.pd == 1 && g.sd == 1) ? 1 : 0;
+    pl.lds = ((size_t)(pl.flat ? 1 : 3) * RH * pl.sw * 32 * EP + (size_t)WG_TH * 32 * TW) * 2;
     pl.scratch = (size_t)pl.pairs * wpp * 27 * 1024 * sizeof(float);
     return DFM_OK;
 }
@@ -318,18 +330,22 @@ extern "C" DFM_API int dfm_conv3d_wgrad(const dfm_conv3d_wgrad_desc *desc, const
     if (((uintptr_t)g & 15) || ((uintptr_t)x & 15)) return set_error(DFM_ERR_INVALID_ARG, "g and x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(pl.g.wgs_per_pair, pl.pairs);
-    const void *kern = pl.sw == 1 ? (const void *)conv3d_wgrad_kernel<1> : (const void *)conv3d_wgrad_kernel<2>;
-    rc = ensure_dynamic_lds(kern, 160 * 1024);
-    if (rc != DFM_OK) return rc;
     if (pl.lds > 160 * 1024) return set_error(DFM_ERR_UNSUPPORTED, "tile does not fit the LDS");
-    if (pl.sw == 1)
-        hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, grid, dim3(WG_THREADS), pl.lds, st, pl.g, (const bf16_t *)g,
-                           (const bf16_t *)x, (float *)workspace);
-    else
-        hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, grid, dim3(WG_THREADS), pl.lds, st, pl.g, (const bf16_t *)g,
-                           (const bf16_t *)x, (float *)workspace);
+#define W_LAUNCH(SW_, FLAT_)                                                                              \
+    do {                                                                                               \
+        rc = ensure_dynamic_lds((const void *)conv3d_wgrad_kernel<SW_, FLAT_>, 160 * 1024);            \
+        if (rc != DFM_OK) return rc;                                                                   \
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<SW_, FLAT_>), grid, dim3(WG_THREADS), pl.lds, st, pl.g, \
+                           (const bf16_t *)g, (const bf16_t *)x, (float *)workspace);                  \
+    } while (0)
+    if (pl.sw == 1) {
+        if (pl.flat) W_LAUNCH(1, true); else W_LAUNCH(1, false);
+    } else {
+        if (pl.flat) W_LAUNCH(2, true); else W_LAUNCH(2, false);
+    }
+#undef W_LAUNCH
     hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(27 * 1024 / 64, pl.pairs), dim3(256), 0, st,
-                       (const float *)workspace, pl.g.wgs_per_pair, pl.g.b_tiles, desc->b, pl.swap, out);
+                       (const float *)workspace, pl.g.wgs_per_pair, pl.g.b_tiles, desc->b, pl.swap, pl.flat, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
