@@ -112,8 +112,8 @@ class SweepOpts(ctypes.Structure):
     """struct dfm_sweep_opts: launch options of ONE plane-sweep call (0 = library default)"""
     _fields_ = [(n, ctypes.c_int32) for n in (
         'kernel', 'lanes_per_workgroup', 'lds_kib', 'blocks_per_group', 'planes_per_workgroup',
-        'bands_per_chunk', 'points_per_lane', 'pipeline', 'store_align_points', 'pair_stores')] + \
-        [('reserved', ctypes.c_int32 * 2)]
+        'bands_per_chunk', 'points_per_lane', 'pipeline', 'store_align_points', 'pair_stores',
+        'unpack')] + [('reserved', ctypes.c_int32 * 1)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != 'reserved'}

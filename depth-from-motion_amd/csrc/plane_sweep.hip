@@ -54,6 +54,7 @@ struct Launch {
     int ppl;         // lattice points per lane
     int align;       // tile boundaries: multiples of this many points (8, 16, 32 or 64)
     int pair;        // 4 points per lane: 16-byte stores through a lane-pair exchange (1) or 8-byte stores (0)
+    int unpack;      // bf16 taps: 1 unpacked by the matrix core, 0 by VALU shifts
     int pipe;        // LDS tile kernel body: 1 serial (stage | barrier | blend + store | barrier),
                      // 2 pipelined (two buffers, one barrier per block, stores never waited for)
 };
@@ -124,12 +125,17 @@ namespace {
 // rocprofv3 duration is ~0.19 ms either way: it starts while the previous launch's 26.8 GB of
 // volume writes are still draining to HBM.
 constexpr int PACK_PPL = 1;
+// flags[0] (zeroed by the host before the launch) gets bit 0 when a bf16 feature value is not a finite,
+// normal number or +0: Inf / NaN, a denormal, or -0.  The tile kernel then unpacks with VALU shifts instead
+// of the matrix core (see compute_store): a product 0 x Inf inside the selecting MFMA would be NaN for the
+// block's other seven channels, and the matrix core's sum of zeros loses the sign of -0 (and may flush a
+// denormal) -- values a trained network does not produce, but the results stay the reference's bit for bit.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__ src0,
                                                            const T *__restrict__ src1,
                                                            uint4 *__restrict__ dst0,
                                                            uint4 *__restrict__ dst1, int batch,
-                                                           int C, int HW, int nblk)
+                                                           int C, int HW, int nblk, int *__restrict__ flags)
 {
     constexpr int CB = elem<T>::CB;
     const int pix0 = blockIdx.x * (256 * PACK_PPL) + threadIdx.x;
@@ -146,6 +152,7 @@ __global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__
         for (int j = 0; j < CB; ++j)
             v[i][j] = (blk * CB + j < C && pix < HW) ? src[(size_t)j * HW + pix] : T(0);
     }
+    bool odd_value = false;
 #pragma unroll
     for (int i = 0; i < PACK_PPL; ++i) {
         const int pix = pix0 + i * 256;
@@ -153,7 +160,20 @@ __global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__
             uint4 q;
             memcpy(&q, v[i], 16);
             dst[pix] = q;
+            if constexpr (sizeof(T) == 2) {
+                const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int hbit = 0; hbit < 32; hbit += 16) {
+                        const uint32_t e = (w4[k] >> hbit) & 0xffffu, ex = e & 0x7f80u;
+                        odd_value |= ex == 0x7f80u || (ex == 0u && e != 0u);
+                    }
+            }
         }
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (flags && __any(odd_value) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
     }
 }
 
@@ -195,6 +215,21 @@ __device__ __forceinline__ void blend_nomask(const Tap &t, const uint4 &qnw, con
     unpack16(qne, b);
     unpack16(qsw, c);
     unpack16(qse, d);
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        float acc = a[j] * t.nw;
+        acc = __builtin_fmaf(b[j], t.ne, acc);
+        acc = __builtin_fmaf(c[j], t.sw, acc);
+        acc = __builtin_fmaf(d[j], t.se, acc);
+        r[j] = acc;
+    }
+}
+
+// the same chain on taps that are fp32 already (the matrix-core unpack of the tile kernel)
+template <int CB>
+__device__ __forceinline__ void blend_f32(const Tap &t, const float (&a)[CB], const float (&b)[CB],
+                                          const float (&c)[CB], const float (&d)[CB], float (&r)[CB])
+{
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
         float acc = a[j] * t.nw;
@@ -340,6 +375,8 @@ struct TileGrid {
     int dgroups;           // ceil(D / planes)
     int blocks_per_group;  // channel blocks one workgroup sweeps
     int band_chunk;        // adjacent bands scheduled together (see the block id map)
+    const int *flags;      // flags[0] != 0: the maps hold a non-finite / denormal / -0 bf16 value (pack_blocked_kernel)
+    int mfma_unpack;       // bf16: unpack the taps with the matrix core (when flags allow) instead of VALU shifts
     int pair_stores;       // 4 points per lane (bf16): lane pairs trade halves and store 16-byte vectors
     int align;             // tile boundaries are multiples of this many points of the flat (d,h,w) index
                            // (a power of two >= 8): 32 points = 64 bytes of bf16, a whole memory-side write
@@ -360,7 +397,7 @@ constexpr int PIPE_BUF_SLOTS = 2504;  // 8 rows of 311 pixels + pad
 constexpr int PIPE_LDS_BYTES = (8 + 2 * PIPE_BUF_SLOTS) * 16;
 template <int N> struct IntC { static constexpr int value = N; };
 
-template <typename T, int NT, bool LDS, int V, bool PIPE = false>
+template <typename T, int NT, bool LDS, int V, bool PIPE = false, bool MXK = false>
 __device__ __forceinline__ void tile_body(
     const int bid, const SweepGeom &g, const SweepFast &fast, const TileGrid &tg, int lds_slots,
     const uint4 *__restrict__ cur_blk, const uint4 *__restrict__ prev_blk,
@@ -375,6 +412,7 @@ __device__ __forceinline__ void tile_body(
     static_assert(V == 4 || V == 8, "points per lane");
     static_assert(V * sizeof(T) == 16 || V * sizeof(T) == 8, "8- or 16-byte stores");
     static_assert(LDS || !PIPE, "the pipelined body is an LDS-staged body");
+    static_assert(!MXK || (LDS && sizeof(T) == 2 && V == 8), "matrix-core unpack: bf16, LDS taps, 8 points per lane");
     constexpr int VW = V * (int)sizeof(T) / 4;  // dwords per channel vector
     constexpr int PAD = 8; // slots in front of the rows (keeps q = p + PAD >= 7)
     constexpr int SLAB = 8;  // slab starts at a multiple of 8 so the swizzle stays inside it
@@ -443,6 +481,15 @@ __device__ __forceinline__ void tile_body(
             if constexpr (PIPE) lds[SLAB + PIPE_BUF_SLOTS] = make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
+    }
+
+    if constexpr (MXK) {
+        // maps with a non-finite / denormal / -0 value (pack_blocked_kernel's flag): this build has no VALU
+        // unpack -- the tile goes to the second-chance pass, which has (one queue entry per tile)
+        if (__builtin_amdgcn_readfirstlane(tg.flags[0]) != 0) {
+            if (tid == 0 && blk_lo_ovr <= 0) spill_list[1 + atomicAdd(&spill_list[0], 1)] = bid;
+            return;
+        }
     }
 
     // ---- per-lane footprints: pixel index relative to row 0 of the map ----------
@@ -546,6 +593,16 @@ __device__ __forceinline__ void tile_body(
         }
     }
     const int wave = tid >> 6, lane = tid & 63;
+    // the selecting A operand of the matrix-core unpack (see compute_store): in each 4-lane block of
+    // v_mfma_f32_4x4x4_16b_bf16, lane i holds row i of the 4x4 identity
+    typedef __bf16 mxs_bf16x4 __attribute__((ext_vector_type(4)));
+    mxs_bf16x4 mx_sel;
+    if constexpr (MXK) {
+        const int i = lane & 3;
+        const uint32_t s2[2] = {i == 0 ? 0x3f80u : i == 1 ? 0x3f800000u : 0u,
+                                i == 2 ? 0x3f80u : i == 3 ? 0x3f800000u : 0u};
+        __builtin_memcpy(&mx_sel, s2, 8);
+    }
     // debug trace: wave 0 of every 509th workgroup stamps its phases
 #ifdef DFM_DEBUG_HOOKS
     unsigned long long *tr = (LDS && tg.trace && (bid % 509) == 0 && tid == 0)
@@ -571,8 +628,17 @@ __device__ __forceinline__ void tile_body(
     // blend the V points x CB channels of one channel block and store them
     // (bufc: which LDS buffer the taps come from -- the pipelined body's second buffer is reached
     // through the instruction's immediate offset, so the tap addresses never change)
-    auto compute_store = [&](int blk, const uint4 *gsrc, auto bufc) {
+    // mxc (bf16, LDS taps): unpack with the matrix core.  v_mfma_f32_4x4x4_16b_bf16 multiplies, in each of its
+    // 16 four-lane blocks, a 4x4 A (lane i: row i) by a 4x4 B (lane i: column i = four bf16 of ITS OWN tap) and
+    // leaves column i of the product in lane i: against the identity that is the lane's four channels in
+    // fp32 (1.0 x v is exact, the other three terms are +0).  Two such products replace a tap's eight VALU
+    // unpacks (v_and_b32 2.5 clocks, v_lshlrev_b32 4.0: 26 of the ~54 clocks a point's tap costs this
+    // wave, profiles/r04_c6_valu_microbench.txt) on a pipe this kernel does not use otherwise, 8 clocks each.
+    // Exact for finite normal values and +0 -- pack_blocked_kernel flags anything else (0 x Inf would be
+    // NaN for the lane's other channels; -0 and denormals) and the VALU path runs.
+    auto compute_store = [&](int blk, const uint4 *gsrc, auto bufc, auto mxc) {
         constexpr int BOFF = decltype(bufc)::value * PIPE_BUF_SLOTS * 16;
+        constexpr bool MX = decltype(mxc)::value != 0 && MXK;
         static_assert(BOFF < 65536, "ds_read_b128 immediate offset");
         const int cbase = blk * CB;
         uint32_t pk[CB][VW];  // per channel: one 16- (or 8-) byte vector of V points
@@ -581,6 +647,71 @@ __device__ __forceinline__ void tile_body(
             for (int k = 0; k < CB; ++k)
 #pragma unroll
                 for (int j = 0; j < VW; ++j) pk[k][j] = (uint32_t)qN[j] + k + blk;
+        } else if constexpr (MX) {
+            typedef __bf16 mx_bf16x4 __attribute__((ext_vector_type(4)));
+            typedef float mx_f32x4 __attribute__((ext_vector_type(4)));
+#define DFM_TAP_READ(dst, addr) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(BOFF))
+            const mx_f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            // one tap -> its CB channels in fp32 (two 4x4x4 products, 4 channels each)
+            auto cvt = [&](const u32x4_t &qq, float (&f)[CB]) {
+                mx_bf16x4 b0, b1;
+                const uint32_t h0[2] = {qq.x, qq.y}, h1[2] = {qq.z, qq.w};
+                __builtin_memcpy(&b0, h0, 8);
+                __builtin_memcpy(&b1, h1, 8);
+                const mx_f32x4 lo = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(mx_sel, b0, z4, 0, 0, 0);
+                f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+                if constexpr (CB == 8) {  // (the branch only runs for bf16: CB == 8)
+                    const mx_f32x4 hi = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(mx_sel, b1, z4, 0, 0, 0);
+                    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+                }
+            };
+            // reads run one point ahead of the conversions (LDS returns in order: lgkmcnt(4) == "point j has
+            // landed"); a point's taps are converted and folded into the chain one at a time, so only one
+            // tap's fp32 channels are live beside the accumulators
+            u32x4_t q[2][4];
+            float keep[CB];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) DFM_TAP_READ(q[0][c4], ta[0][c4]);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int cb = j & 1, nb = cb ^ 1;
+                if (j + 1 < V) {
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) DFM_TAP_READ(q[nb][c4], ta[j + 1][c4]);
+                    asm volatile("s_waitcnt lgkmcnt(4)"
+                                 : "+v"(q[cb][0]), "+v"(q[cb][1]), "+v"(q[cb][2]), "+v"(q[cb][3]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(q[cb][0]), "+v"(q[cb][1]), "+v"(q[cb][2]), "+v"(q[cb][3]));
+                }
+                // (opaque copies: hipcc otherwise hoists the four weights of all 8 points out of the channel-
+                // block loop -- 32 registers this body does not have)
+                float w = fw[j], n = fn[j];
+                asm volatile("" : "+v"(w), "+v"(n));
+                const float e = 1.0f - w, s2 = 1.0f - n;
+                const float wt[4] = {s2 * e, s2 * w, n * e, n * w};  // nw ne sw se: blend_nomask's chain
+                float r[CB];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    float f[CB];
+                    cvt(q[cb][c4], f);
+#pragma unroll
+                    for (int k = 0; k < CB; ++k) r[k] = c4 == 0 ? f[k] * wt[0] : __builtin_fmaf(f[k], wt[c4], r[k]);
+                }
+                // (pins the chain here: the vectoriser otherwise builds one tree from the 16-byte store
+                // vectors down through all 8 points and sinks every chain below the last conversion)
+                if constexpr (CB == 8)
+                    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
+                                      "+v"(r[6]), "+v"(r[7]));
+#pragma unroll
+                for (int k = 0; k < CB; ++k) {
+                    if constexpr (sizeof(T) == 4) pk[k][j] = __float_as_uint(r[k]);
+                    else if (j & 1) pk[k][j >> 1] = pack_bf16x2(keep[k], r[k]);
+                    else keep[k] = r[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else if constexpr (LDS) {
             // Taps come from LDS through inline-asm ds_read_b128 (hipcc would put
             // a vmcnt(0) in front of the first LDS read after an LDS-DMA was
@@ -589,8 +720,6 @@ __device__ __forceinline__ void tile_body(
             // LDS returns in order, so lgkmcnt(4) == "point j has landed".
             u32x4_t q[2][4];
             float keep[CB];  // even point of a pair, waiting for its odd partner
-#define DFM_TAP_READ(dst, addr) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(BOFF))
             DFM_TAP_READ(q[0][0], ta[0][0]);
             DFM_TAP_READ(q[0][1], ta[0][1]);
             DFM_TAP_READ(q[0][2], ta[0][2]);
@@ -697,7 +826,7 @@ __device__ __forceinline__ void tile_body(
 
     if constexpr (!LDS) {
         for (int blk = blk_lo; blk < blk_hi; ++blk) {
-            compute_store(blk, src, IntC<0>{});
+            compute_store(blk, src, IntC<0>{}, IntC<0>{});
             src += HW;
         }
     } else {
@@ -724,7 +853,7 @@ __device__ __forceinline__ void tile_body(
                 TRACE_STAMP();
                 __syncthreads();  // drains the DMA (vmcnt) and makes the rows visible
                 TRACE_STAMP();
-                if (active) compute_store(blk, src, IntC<0>{});
+                if (active) compute_store(blk, src, IntC<0>{}, IntC<MXK ? 1 : 0>{});
                 TRACE_STAMP();
                 src += HW;
                 __syncthreads();  // everyone is done with the rows before the refill
@@ -760,7 +889,7 @@ __device__ __forceinline__ void tile_body(
             for (int blk = blk_lo;;) {
                 if (blk + 1 < blk_hi) stage(SLAB + PIPE_BUF_SLOTS, src + HW);
                 TRACE_STAMP();
-                if (active) compute_store(blk, src, IntC<0>{});
+                if (active) compute_store(blk, src, IntC<0>{}, IntC<MXK ? 1 : 0>{});
                 TRACE_STAMP();
                 src += HW;
                 if (++blk >= blk_hi) break;
@@ -768,7 +897,7 @@ __device__ __forceinline__ void tile_body(
                 TRACE_STAMP();
                 if (blk + 1 < blk_hi) stage(SLAB, src + HW);
                 TRACE_STAMP();
-                if (active) compute_store(blk, src, IntC<1>{});
+                if (active) compute_store(blk, src, IntC<1>{}, IntC<MXK ? 1 : 0>{});
                 TRACE_STAMP();
                 src += HW;
                 if (++blk >= blk_hi) break;
@@ -786,15 +915,15 @@ __device__ __forceinline__ void tile_body(
 // one workgroup per tile; LDS == false is the "direct taps for every tile" mode.
 // V * sizeof(T) == 8 (bf16, 4 points per lane): compiled for 4 waves per SIMD (<= 128 VGPRs),
 // i.e. two 512-lane workgroups or one 1024-lane workgroup per CU.
-template <typename T, int NT, bool LDS, int V, bool PIPE = false>
-__global__ __launch_bounds__(NT, (LDS ? (V * sizeof(T) == 8 ? 4 : DFM_TILE_WAVES) : 1)) void sweep_tile_kernel(
+template <typename T, int NT, bool LDS, int V, bool PIPE = false, bool MXK = false>
+__global__ __launch_bounds__(NT, (LDS ? (V * sizeof(T) == 8 ? 4 : (MXK ? 2 : DFM_TILE_WAVES)) : 1)) void sweep_tile_kernel(
     SweepGeom g, SweepFast fast, TileGrid tg, int lds_slots, const uint4 *__restrict__ cur_blk,
     const uint4 *__restrict__ prev_blk, const float *__restrict__ depths,
     const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
     T *__restrict__ out, int *__restrict__ spill_list)
 {
-    tile_body<T, NT, LDS, V, PIPE>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk, depths, P,
-                                   Pinv, Tm, out, spill_list);
+    tile_body<T, NT, LDS, V, PIPE, MXK>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk, depths, P,
+                                        Pinv, Tm, out, spill_list);
 }
 
 // the tiles the LDS pass queued (spill_list[0] = count), a fixed small grid strides over them:
@@ -1506,6 +1635,7 @@ int resolve(const dfm_sweep_desc *d, const dfm_sweep_opts *o, Launch &L)
     if (L.align != 8 && L.align != 16 && L.align != 32 && L.align != 64)
         return fail(DFM_ERR_INVALID_ARG, "opts: store_align_points in {8,16,32,64}%s");
     L.pair = o && o->pair_stores ? (o->pair_stores == 1) : 1;  // 0 default (on), 1 on, 2 off
+    L.unpack = o && o->unpack ? (o->unpack == 1) : 1;          // 0 default (matrix core), 1 matrix core, 2 VALU
     L.pipe = o && o->pipeline ? o->pipeline : 2;
     if (L.pipe != 1 && L.pipe != 2) return fail(DFM_ERR_INVALID_ARG, "opts: pipeline must be 0, 1 or 2%s");
     if (!L.lds_kib) L.lds_kib = L.pipe == 2 ? 80 : 52;
@@ -1551,6 +1681,8 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
     tg.trace = nullptr;
     tg.ablate = 0;
     tg.pair_stores = L.pair;
+    tg.mfma_unpack = L.unpack;
+    tg.flags = (const int *)((const char *)spill_list + 2 * flag_bytes(d));  // set by pack_blocked_kernel
 #ifdef DFM_DEBUG_HOOKS
     tg.trace = g_trace;
     {
@@ -1568,8 +1700,19 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
         int *spill2 = (int *)((char *)spill_list + flag_bytes(d));
         HIP_TRY(hipMemsetAsync(spill_list, 0, 4, st));
         HIP_TRY(hipMemsetAsync(spill2, 0, 4, st));
-        if (L.pipe == 2) {
-            // fixed 80 KiB - 128 B (two buffers at a compile-time stride); lds_kib only lowers the
+        constexpr bool CAN_MX = sizeof(T) == 2 && V == 8;
+        if (L.pipe == 2 && CAN_MX && L.unpack) {
+            // bf16, 8 points per lane: the build that unpacks the taps with the matrix core
+            if constexpr (CAN_MX) {
+                const void *kern = (const void *)sweep_tile_kernel<T, NT, true, V, true, true>;
+                rc = ensure_dynamic_lds(kern, PIPE_LDS_BYTES);
+                if (rc != DFM_OK) return rc;
+                hipLaunchKernelGGL((sweep_tile_kernel<T, NT, true, V, true, true>), dim3((unsigned)nb), dim3(NT),
+                                   PIPE_LDS_BYTES, st, g, fast, tg, std::min(lds_bytes, PIPE_LDS_BYTES) / 16,
+                                   cur_blk, prev_blk, depths, P, Pinv, Tm, out, spill_list);
+            }
+        } else if (L.pipe == 2) {
+            // fixed 78 KiB (two buffers at a compile-time stride); lds_kib only lowers the
             // budget a tile's rows are checked against (tests force spills that way)
             const void *kern = (const void *)sweep_tile_kernel<T, NT, true, V, true>;
             rc = ensure_dynamic_lds(kern, PIPE_LDS_BYTES);
@@ -1629,8 +1772,10 @@ int launch_fwd(const dfm_sweep_desc *d, const Launch &L, const void *cur, const 
     uint4 *cur_blk = (uint4 *)ws;
     uint4 *prev_blk = (uint4 *)((char *)ws + blocked_bytes(d));
     dim3 pg((HW + 256 * PACK_PPL - 1) / (256 * PACK_PPL), g.nblk, 2 * d->batch);
+    int *feat_flags = (int *)((char *)ws + 2 * blocked_bytes(d) + 2 * flag_bytes(d));
+    HIP_TRY(hipMemsetAsync(feat_flags, 0, 4, st));
     hipLaunchKernelGGL(pack_blocked_kernel<T>, pg, dim3(256), 0, st, (const T *)cur, (const T *)prev,
-                       cur_blk, prev_blk, d->batch, g.C, HW, g.nblk);
+                       cur_blk, prev_blk, d->batch, g.C, HW, g.nblk, feat_flags);
     constexpr int CB = elem<T>::CB;
     // the tile kernels store one aligned vector of V points per channel: every channel
     // plane (N elements) has to start 16-byte aligned.
@@ -1689,7 +1834,8 @@ int run_fwd(const dfm_sweep_desc *desc, const Launch &L, const void *cur, const 
 // blocked maps + spill lists (tile kernels), or the pixel-major maps of the strided-sweep kernel
 size_t fwd_workspace_bytes(const dfm_sweep_desc *desc)
 {
-    return std::max(2 * blocked_bytes(desc) + 2 * flag_bytes(desc), sweep_clt_workspace_bytes(desc));
+    // blocked maps + the two spill lists + the feature-flag word of the pack pass
+    return std::max(2 * blocked_bytes(desc) + 2 * flag_bytes(desc) + 256, sweep_clt_workspace_bytes(desc));
 }
 
 int check_fwd_args(const dfm_sweep_desc *desc, const void *cur, const void *prev,

@@ -146,7 +146,7 @@ _OPT_FIELDS = {'kernel': 'kernel', 'lanes': 'lanes_per_workgroup', 'lds_kib': 'l
                'blocks_per_group': 'blocks_per_group', 'planes': 'planes_per_workgroup',
                'bands_per_chunk': 'bands_per_chunk', 'points_per_lane': 'points_per_lane',
                'pipeline': 'pipeline', 'store_align': 'store_align_points',
-               'pair_stores': 'pair_stores'}
+               'pair_stores': 'pair_stores', 'unpack': 'unpack'}
 
 
 def make_opts(**kw):

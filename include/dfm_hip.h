@@ -230,6 +230,9 @@ DFM_API int dfm_plane_sweep_bwd_last_kernel(void);
  *                        (x2 for fp32) relative to the plane's first element (default 64)
  *   pair_stores          points_per_lane = 4 with DFM_BF16: 1 (default) = neighbouring lanes trade their
  *                        8-byte halves and store one 16-byte vector per channel pair, 2 = 8-byte stores
+ *   unpack               DFM_BF16, LDS tile kernel: 1 (default) = the taps are unpacked to fp32 by the matrix
+ *                        core (two selecting v_mfma_f32_16x16x32_bf16 per tap, exact), 2 = by VALU shifts.
+ *                        Maps that hold a non-finite, denormal or -0 value always take the VALU form.
  */
 typedef struct dfm_sweep_opts {
     int32_t kernel;
@@ -242,7 +245,8 @@ typedef struct dfm_sweep_opts {
     int32_t pipeline;
     int32_t store_align_points;
     int32_t pair_stores;
-    int32_t reserved[2];
+    int32_t unpack;
+    int32_t reserved[1];
 } dfm_sweep_opts;
 
 /* dfm_plane_sweep_fwd with explicit launch options.  opts == NULL is dfm_plane_sweep_fwd: the

@@ -53,7 +53,7 @@ def test_invalid_desc_is_rejected_without_touching_the_gpu(pkg):
     desc.dtype = 0
     # two blocked maps (4 samples x 1 block x 16 px x 16 B) + the two spill lists (second-chance
     # LDS pass, direct pass: int32 counter + 1 band x 4 planes x 2 maps x 4 samples tile ids each)
-    assert lib.dfm_plane_sweep_workspace_bytes(ctypes.byref(desc)) == 2 * 1024 + 2 * 256
+    assert lib.dfm_plane_sweep_workspace_bytes(ctypes.byref(desc)) == 2 * 1024 + 2 * 256 + 256
     # NULL pointers
     assert lib.dfm_plane_sweep_fwd(ctypes.byref(desc), None, None, None, None, None, None, None,
                                    None, 0, None) == -1

@@ -43,6 +43,7 @@ def pkg():
 #               block, counted vmcnt; the default since round 4) in the shapes the library ships,
 #               with odd / even numbers of channel blocks per workgroup, and with a budget that
 #               sends tiles to the second-chance and direct passes; the lds* modes pin the serial body
+#   *_valu    : bf16 taps unpacked by the VALU (default for pipelined 8-point bf16 tiles: the matrix core)
 #   *_unpaired: 4 points per lane with 8-byte stores (default: lane pairs trade halves, 16-byte stores)
 #   *_a32/_a64: tile boundaries at multiples of 32 / 64 lattice points (whole 64- / 128-byte writes)
 MODES = {'gather': dict(kernel=1, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
@@ -67,6 +68,7 @@ MODES = {'gather': dict(kernel=1, lanes=256, lds_kib=64, blocks_per_group=4, pla
          'pipe_spill': dict(kernel=2, lanes=128, lds_kib=4, blocks_per_group=2, planes=2, pipeline=2),
          'pipe_respill': dict(kernel=2, lanes=256, lds_kib=24, planes=2, pipeline=2),
          'pipe256_a64': dict(kernel=2, lanes=256, planes=2, pipeline=2, store_align=64),
+         'pipe256_valu': dict(kernel=2, lanes=256, planes=2, pipeline=2, unpack=2),
          'lds256_a32': dict(kernel=2, lanes=256, lds_kib=52, planes=2, pipeline=1, store_align=32),
          'pipe512_v4_a64': dict(kernel=2, lanes=512, planes=2, points_per_lane=4, pipeline=2, store_align=64),
          'lds256_a8': dict(kernel=2, lanes=256, lds_kib=52, planes=2, pipeline=1, store_align=8),
@@ -140,6 +142,33 @@ def test_bf16_exact_vs_oracle(pkg, path):
                   dtype=torch.bfloat16)
     assert out.dtype == torch.bfloat16
     assert np.array_equal(util.bits(out.float().cpu().numpy()), util.bits(ref))
+
+
+@pytest.mark.parametrize('special', ['neg_zero', 'denormal', 'inf', 'nan'])
+def test_bf16_special_values_take_the_valu_unpack(pkg, special):
+    """the matrix-core unpack of the pipelined bf16 tile kernel is exact for finite normal values and +0
+    only: the pack kernel flags anything else and the tiles run through the VALU unpack.  The volume must
+    equal the oracle's bit for bit (NaN payloads aside) with ONE special value planted in each map."""
+    z = np.load(util.sweep_fixture_paths()[0])
+    fsf, csf, P, T, img_shape, flip, crop, scale = fixture_args(z)
+    cur16, prev16 = orc.bf16_round(z['cur']).copy(), orc.bf16_round(z['prev']).copy()
+    val = {'neg_zero': np.float32(-0.0), 'denormal': np.frombuffer(np.uint32(0x00010000).tobytes(), np.float32)[0],
+           'inf': np.float32(np.inf), 'nan': np.float32(np.nan)}[special]
+    C, H, W = cur16.shape[1:]
+    cur16[0, C // 2, H // 2, W // 3] = val
+    prev16[0, 1 % C, H // 3, W // 2] = val
+    # a whole channel of -0 / denormals as well (sign and exponent of a blend of four such taps)
+    if special in ('neg_zero', 'denormal'):
+        cur16[0, 0] = val
+    with np.errstate(invalid='ignore'):
+        ref = orc.bf16_round(
+            orc.build_dfm_cost(cur16, prev16, z['depths'], fsf, csf, P, z['Pinv'][None], T, img_shape,
+                               flip, crop, scale))
+    out = run_hip(pkg, cur16, prev16, z['depths'], fsf, csf, P, T, img_shape, flip, crop, scale,
+                  dtype=torch.bfloat16).float().cpu().numpy()
+    nan_ref, nan_out = np.isnan(ref), np.isnan(out)
+    assert np.array_equal(nan_ref, nan_out)
+    assert np.array_equal(util.bits(np.where(nan_out, 0, out)), util.bits(np.where(nan_ref, 0, ref)))
 
 
 @pytest.mark.parametrize('W', [101, 104])  # 101: D*H*W not a multiple of 8 -> gather kernel

@@ -114,6 +114,7 @@ static dfm_sweep_opts parse_cfg(const std::string &s)
         else if (k == "pipe") o.pipeline = v;
         else if (k == "align") o.store_align_points = v;
         else if (k == "pair") o.pair_stores = v;
+        else if (k == "unpack") o.unpack = v;
         else { fprintf(stderr, "unknown cfg key '%s'\n", k.c_str()); exit(2); }
         pos = e + 1;
     }
