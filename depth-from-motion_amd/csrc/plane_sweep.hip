@@ -395,6 +395,10 @@ struct TileGrid {
 // because the second buffer is addressed through the 16-bit immediate offset of ds_read_b128
 constexpr int PIPE_BUF_SLOTS = 2504;  // 8 rows of 311 pixels + pad
 constexpr int PIPE_LDS_BYTES = (8 + 2 * PIPE_BUF_SLOTS) * 16;
+// experiments (build_variant): how the matrix-core unpack is written
+#ifndef DFM_MX_MODE
+#define DFM_MX_MODE 1   // 1 products and chain steps in a pinned order, 2 left to hipcc
+#endif
 template <int N> struct IntC { static constexpr int value = N; };
 
 template <typename T, int NT, bool LDS, int V, bool PIPE = false, bool MXK = false>
@@ -636,12 +640,11 @@ __device__ __forceinline__ void tile_body(
     // wave, profiles/r04_c6_valu_microbench.txt) on a pipe this kernel does not use otherwise, 8 clocks each.
     // Exact for finite normal values and +0 -- pack_blocked_kernel flags anything else (0 x Inf would be
     // NaN for the lane's other channels; -0 and denormals) and the VALU path runs.
-    auto compute_store = [&](int blk, const uint4 *gsrc, auto bufc, auto mxc) {
+    // pk: per channel, one 16- (or 8-) byte vector of V points
+    auto compute_block = [&](int blk, const uint4 *gsrc, auto bufc, auto mxc, uint32_t (&pk)[CB][VW]) {
         constexpr int BOFF = decltype(bufc)::value * PIPE_BUF_SLOTS * 16;
         constexpr bool MX = decltype(mxc)::value != 0 && MXK;
         static_assert(BOFF < 65536, "ds_read_b128 immediate offset");
-        const int cbase = blk * CB;
-        uint32_t pk[CB][VW];  // per channel: one 16- (or 8-) byte vector of V points
         if (ABLATE(4)) {
 #pragma unroll
             for (int k = 0; k < CB; ++k)
@@ -666,9 +669,18 @@ __device__ __forceinline__ void tile_body(
                     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
                 }
             };
+            (void)cvt;
+            // half a tap (4 channels): ONE 4x4x4 product
+            auto cvt_half = [&](uint32_t lo, uint32_t hi, float *f) {
+                mx_bf16x4 bfrag;
+                const uint32_t h[2] = {lo, hi};
+                __builtin_memcpy(&bfrag, h, 8);
+                const mx_f32x4 d4 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(mx_sel, bfrag, z4, 0, 0, 0);
+                f[0] = d4[0]; f[1] = d4[1]; f[2] = d4[2]; f[3] = d4[3];
+            };
             // reads run one point ahead of the conversions (LDS returns in order: lgkmcnt(4) == "point j has
-            // landed"); a point's taps are converted and folded into the chain one at a time, so only one
-            // tap's fp32 channels are live beside the accumulators
+            // landed"); a point's taps are converted and folded into the chain one at a time, so only two
+            // taps' fp32 channels are live beside the accumulators
             u32x4_t q[2][4];
             float keep[CB];
 #pragma unroll
@@ -689,6 +701,12 @@ __device__ __forceinline__ void tile_body(
                 // block loop -- 32 registers this body does not have)
                 float w = fw[j], n = fn[j];
                 asm volatile("" : "+v"(w), "+v"(n));
+                // One product, then four VALU operations, strictly alternating, each product a whole tap ahead
+                // of the chain step that consumes it: two 4x4x4 products back to back hold the wave's issue for
+                // the matrix pipe (8 clocks), and products placed right in front of their consumers wait out
+                // the latency.  hipcc's own placement varies from build to build between 5.16 and 5.7 ms
+                // (profiles/r04_c21/c22/c23), so the order is pinned with scheduling fences.
+#if DFM_MX_MODE == 2
                 const float e = 1.0f - w, s2 = 1.0f - n;
                 const float wt[4] = {s2 * e, s2 * w, n * e, n * w};  // nw ne sw se: blend_nomask's chain
                 float r[CB];
@@ -699,6 +717,47 @@ __device__ __forceinline__ void tile_body(
 #pragma unroll
                     for (int k = 0; k < CB; ++k) r[k] = c4 == 0 ? f[k] * wt[0] : __builtin_fmaf(f[k], wt[c4], r[k]);
                 }
+#else
+                float fa[CB], fb[CB], r[CB];
+#define DFM_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define DFM_CHAIN(dst, src, wgt, lo, first)                                                          \
+    _Pragma("unroll") for (int k = lo; k < lo + 4; ++k) dst[k] = first ? src[k] * wgt : __builtin_fmaf(src[k], wgt, dst[k])
+                cvt_half(q[cb][0].x, q[cb][0].y, &fa[0]);
+                DFM_FENCE();
+                const float e = 1.0f - w, s2 = 1.0f - n;
+                DFM_FENCE();
+                cvt_half(q[cb][0].z, q[cb][0].w, &fa[4]);
+                DFM_FENCE();
+                const float wt[4] = {s2 * e, s2 * w, n * e, n * w};  // nw ne sw se: blend_nomask's chain
+                DFM_FENCE();
+                cvt_half(q[cb][1].x, q[cb][1].y, &fb[0]);
+                DFM_FENCE();
+                DFM_CHAIN(r, fa, wt[0], 0, true);
+                DFM_FENCE();
+                cvt_half(q[cb][1].z, q[cb][1].w, &fb[4]);
+                DFM_FENCE();
+                DFM_CHAIN(r, fa, wt[0], 4, true);
+                DFM_FENCE();
+                cvt_half(q[cb][2].x, q[cb][2].y, &fa[0]);
+                DFM_FENCE();
+                DFM_CHAIN(r, fb, wt[1], 0, false);
+                DFM_FENCE();
+                cvt_half(q[cb][2].z, q[cb][2].w, &fa[4]);
+                DFM_FENCE();
+                DFM_CHAIN(r, fb, wt[1], 4, false);
+                DFM_FENCE();
+                cvt_half(q[cb][3].x, q[cb][3].y, &fb[0]);
+                DFM_FENCE();
+                DFM_CHAIN(r, fa, wt[2], 0, false);
+                DFM_FENCE();
+                cvt_half(q[cb][3].z, q[cb][3].w, &fb[4]);
+                DFM_FENCE();
+                DFM_CHAIN(r, fa, wt[2], 4, false);
+                DFM_CHAIN(r, fb, wt[3], 0, false);
+                DFM_CHAIN(r, fb, wt[3], 4, false);
+#undef DFM_CHAIN
+#undef DFM_FENCE
+#endif
                 // (pins the chain here: the vectoriser otherwise builds one tree from the 16-byte store
                 // vectors down through all 8 points and sinks every chain below the last conversion)
                 if constexpr (CB == 8)
@@ -779,6 +838,9 @@ __device__ __forceinline__ void tile_body(
             }
         }
         TRACE_STAMP();
+    };
+    auto store_block = [&](int blk, const uint32_t (&pk)[CB][VW]) {
+        const int cbase = blk * CB;
         if constexpr (VW == 2) {
             // 8-byte halves of a 16-byte vector lie in neighbouring lanes (4 points per lane): the pair
             // trades halves -- the even lane takes channel 2i of both, the odd lane channel 2i + 1 -- and
@@ -822,6 +884,11 @@ __device__ __forceinline__ void tile_body(
                 }
             }
         }
+    };
+    auto compute_store = [&](int blk, const uint4 *gsrc, auto bufc, auto mxc) {
+        uint32_t pk[CB][VW];
+        compute_block(blk, gsrc, bufc, mxc, pk);
+        store_block(blk, pk);
     };
 
     if constexpr (!LDS) {
@@ -886,6 +953,11 @@ __device__ __forceinline__ void tile_body(
             stage(SLAB, src);
             TRACE_STAMP();
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // (Tried and dropped, profiles/r04_c21..c26: issuing the stores of block k AFTER its barrier -- a
+            // store then has two block periods to be acknowledged -- 8 % slower on a box where it mattered:
+            // the four waves store in one synchronised burst; the block in two half passes, channels 0-3,
+            // their stores, channels 4-7 -- no faster; starting every second workgroup of a CU half a
+            // block period late -- no effect.)
             for (int blk = blk_lo;;) {
                 if (blk + 1 < blk_hi) stage(SLAB + PIPE_BUF_SLOTS, src + HW);
                 TRACE_STAMP();
@@ -1635,10 +1707,12 @@ int resolve(const dfm_sweep_desc *d, const dfm_sweep_opts *o, Launch &L)
     if (L.align != 8 && L.align != 16 && L.align != 32 && L.align != 64)
         return fail(DFM_ERR_INVALID_ARG, "opts: store_align_points in {8,16,32,64}%s");
     L.pair = o && o->pair_stores ? (o->pair_stores == 1) : 1;  // 0 default (on), 1 on, 2 off
-    L.unpack = o && o->unpack ? (o->unpack == 1) : 1;          // 0 default (matrix core), 1 matrix core, 2 VALU
+    // 0 default (matrix core), 1 matrix core, 2 VALU
+    if (o && (o->unpack < 0 || o->unpack > 2)) return fail(DFM_ERR_INVALID_ARG, "opts: unpack must be 0, 1 or 2%s");
+    L.unpack = o && o->unpack ? (o->unpack == 1) : 1;
     L.pipe = o && o->pipeline ? o->pipeline : 2;
     if (L.pipe != 1 && L.pipe != 2) return fail(DFM_ERR_INVALID_ARG, "opts: pipeline must be 0, 1 or 2%s");
-    if (!L.lds_kib) L.lds_kib = L.pipe == 2 ? 80 : 52;
+    if (!L.lds_kib) L.lds_kib = L.pipe >= 2 ? 80 : 52;
     if (L.kernel < 0 || L.kernel > 4) return fail(DFM_ERR_INVALID_ARG, "opts: kernel must be 0..4%s");
     if (L.lanes != 128 && L.lanes != 256 && L.lanes != 512 && L.lanes != 1024)
         return fail(DFM_ERR_INVALID_ARG, "opts: lanes_per_workgroup in {128,256,512,1024}%s");
@@ -1701,7 +1775,7 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
         HIP_TRY(hipMemsetAsync(spill_list, 0, 4, st));
         HIP_TRY(hipMemsetAsync(spill2, 0, 4, st));
         constexpr bool CAN_MX = sizeof(T) == 2 && V == 8;
-        if (L.pipe == 2 && CAN_MX && L.unpack) {
+        if (L.pipe >= 2 && CAN_MX && L.unpack) {
             // bf16, 8 points per lane: the build that unpacks the taps with the matrix core
             if constexpr (CAN_MX) {
                 const void *kern = (const void *)sweep_tile_kernel<T, NT, true, V, true, true>;
@@ -1711,7 +1785,7 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
                                    PIPE_LDS_BYTES, st, g, fast, tg, std::min(lds_bytes, PIPE_LDS_BYTES) / 16,
                                    cur_blk, prev_blk, depths, P, Pinv, Tm, out, spill_list);
             }
-        } else if (L.pipe == 2) {
+        } else if (L.pipe >= 2) {
             // fixed 78 KiB (two buffers at a compile-time stride); lds_kib only lowers the
             // budget a tile's rows are checked against (tests force spills that way)
             const void *kern = (const void *)sweep_tile_kernel<T, NT, true, V, true>;
