@@ -29,7 +29,8 @@ bool sweep_clt_supported(const dfm_sweep_desc *d, const void *out);
 size_t sweep_clt_workspace_bytes(const dfm_sweep_desc *d);
 int sweep_clt_launch(const dfm_sweep_desc *d, const void *cur, const void *prev, const float *depths,
                      const float *cam2img, const float *cam2img_inv, const float *cur2prev, void *out,
-                     void *workspace, void *stream, bool nhwc = false);
+                     void *workspace, void *stream, bool nhwc = false, bool walk = true);
+bool sweep_cltw_supported(const dfm_sweep_desc *d, const void *out);
 // records the start (stop=false) / stop event of a timed launch when dfm_profile_begin
 // is active; the start call returns whether this launch is being timed
 bool profile_mark(void *stream, bool stop);

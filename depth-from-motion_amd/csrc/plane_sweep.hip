@@ -1713,7 +1713,7 @@ int resolve(const dfm_sweep_desc *d, const dfm_sweep_opts *o, Launch &L)
     L.pipe = o && o->pipeline ? o->pipeline : 2;
     if (L.pipe != 1 && L.pipe != 2) return fail(DFM_ERR_INVALID_ARG, "opts: pipeline must be 0, 1 or 2%s");
     if (!L.lds_kib) L.lds_kib = L.pipe >= 2 ? 80 : 52;
-    if (L.kernel < 0 || L.kernel > 4) return fail(DFM_ERR_INVALID_ARG, "opts: kernel must be 0..4%s");
+    if (L.kernel < 0 || L.kernel > 5) return fail(DFM_ERR_INVALID_ARG, "opts: kernel must be 0..5%s");
     if (L.lanes != 128 && L.lanes != 256 && L.lanes != 512 && L.lanes != 1024)
         return fail(DFM_ERR_INVALID_ARG, "opts: lanes_per_workgroup in {128,256,512,1024}%s");
     if (L.lds_kib < 4 || L.lds_kib > 160 || L.bpg < 1 || L.planes < 1 || L.band_chunk < 1)
@@ -1838,8 +1838,12 @@ int launch_fwd(const dfm_sweep_desc *d, const Launch &L, const void *cur, const 
     const int HW = d->h_in * d->w_in;
     // strided sweeps (cost_sample_factor >= 2: config K) in the reference layout: pixel-major taps
     // + an LDS transpose (kernel 4, plane_sweep_cl.hip) instead of the direct tile kernel (3)
-    if ((L.kernel == 4 || (L.kernel == 0 && d->cost_sample_factor >= 1.5f)) && sweep_clt_supported(d, out)) {
-        const int rc4 = sweep_clt_launch(d, cur, prev, depths, P, Pinv, Tm, out, ws, (void *)st);
+    // (kernel 5: the same with the depth axis walked per wave -- what 0 picks where it applies; 4 pins the
+    // per-plane kernel)
+    if ((L.kernel == 4 || L.kernel == 5 || (L.kernel == 0 && d->cost_sample_factor >= 1.5f)) &&
+        sweep_clt_supported(d, out)) {
+        const int rc4 = sweep_clt_launch(d, cur, prev, depths, P, Pinv, Tm, out, ws, (void *)st, false,
+                                         L.kernel != 4);
         if (rc4 == DFM_OK) g_last_kernel = 4;
         return rc4;
     }

@@ -27,12 +27,14 @@
 #include "dfm_common.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 using namespace dfm;
 
 namespace {
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4w_t __attribute__((ext_vector_type(4)));
 
 struct ClGrid {
     int batch, tiles;     // tiles of 256 points per depth plane
@@ -269,6 +271,215 @@ __global__ __launch_bounds__(256) void sweep_clt_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Strided sweeps, reference layout, WALKING the depth axis (fp32, config K).
+//
+// sweep_clt_kernel fetches the four taps of every (point, plane) anew: 8 x 128 bytes per point and
+// plane for both maps, 15 GB of L2 -> L1 traffic for a 3.8 GB volume, and its time is the sum of its
+// store time and its gather time (profiles/r03_c39_*).  But a point's footprint barely moves from one
+// plane to the next: the cur position is the lattice pixel up to rounding noise (the footprint flips
+// between two neighbouring pixel pairs), the prev position slides along its epipolar line by less
+// than a pixel per plane beyond ~20 m: over the planes of config K 60 % of the footprints equal the
+// previous plane's.
+//
+// So a WAVE owns 32 consecutive lattice points of one map and a run of 24 depth planes, keeps each
+// point's 2x2 footprint (the lane's 16-byte channel block of it) in registers, and per plane
+//   * loads only the taps whose offset differs from the previous plane's (hand-masked buffer loads; an
+//     out-of-bounds corner is an offset beyond the buffer, which the hardware answers with zeros),
+//   * blends in ATen's order, transposes the 32 points x 32 channels through a wave-private LDS tile
+//     and stores one 128-byte run per channel,
+// with the loads of plane d + 1 issued BEFORE the stores of plane d (a counted vmcnt then waits for the
+// loads without waiting for a store acknowledgement).
+// Lanes: (sub = lane & 7: channel block, pin = lane >> 3: point of a group of 8); 4 groups = 32
+// points.  Footprints are computed lane = point for TWO planes at a time (lanes 32-63: the next plane)
+// in the reference's op order (sweep_point_map) and handed over through a ring of three planes in LDS,
+// which is also where the previous plane's offsets and the weights are re-read from (registers go to
+// the taps: 114 VGPRs, four waves per SIMD).  No workgroup barrier: the four waves of a workgroup (four
+// neighbouring 32-point tiles) only share the launch.
+// Measured (profiles/r04_c28..c34): 1.22 ms against the per-plane kernel's 1.36-1.47 ms on the same
+// boxes (0.47 of 8 TB/s against 0.39-0.43).  Not more, because with the volume's stores streaming
+// through the L2 a tap re-read a few planes (10+ us) later misses it: the L2 -> L1 requests drop
+// three-fold, the fabric reads grow from 0.87 to 2.4 GB, and with both loads and stores in flight the
+// kernel takes 1.3 ms where either alone takes 0.56 / 0.69 ms over a 0.43 ms skeleton
+// (r04_c32_walk_kernel_ablation.txt).  Permuting the cached taps when a footprint moves by one pixel
+// (25-35 % of the planes) saves another third of the loads but costs more issue slots than it saves
+// (first version, r04_c28).
+// ---------------------------------------------------------------------------
+#ifndef DFM_WALK_ABLATE  // experiments at release speed (build_variant): 1 no tap loads, 2 no stores
+#define DFM_WALK_ABLATE 0
+#endif
+#ifndef DFM_WALK_WAVES
+#define DFM_WALK_WAVES 4  // waves per SIMD the walking kernel is compiled for (5 spills, 3 is 8 % slower: profiles/r04_c33_*)
+#endif
+struct WalkGrid {
+    int batch, tiles, chunks, chunk_planes, passes;
+};
+
+// one tap, loaded only by the lanes whose cached offset differs: exec masking by hand (a branch per tap
+// costs more than the load), through the maps' raw buffer descriptor
+__device__ __forceinline__ void walk_load_if(u32x4_t &v, unsigned long long need, unsigned off, const u32x4_t &rs)
+{
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "buffer_load_dwordx4 %[v], %[off], %[rs], 0 offen\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [v] "+v"(v), [sv] "=&s"(save)
+                 : [m] "s"(need), [off] "v"(off), [rs] "s"(rs)
+                 : "memory", "scc");  // (s_and_saveexec writes SCC)
+}
+
+template <int HALF>
+__device__ __forceinline__ void walk_body(const SweepGeom &g, const SweepFast &fast, const int b, const int tile,
+                                          const int d0, const int d1, const int pass, const int lane,
+                                          Foot (*foot_s)[32], float *tile_s, const uint4 *__restrict__ mp,
+                                          const unsigned map_bytes_all, const float *__restrict__ depths,
+                                          const float *__restrict__ P, const float *__restrict__ Pinv,
+                                          const float *__restrict__ Tm, float *__restrict__ out)
+{
+    // Taps come through a raw buffer descriptor of the maps: an out-of-bounds corner is an offset beyond
+    // the buffer, which the hardware answers with zeros (grid_sample's zeros padding) -- no zero pixel, no
+    // 64-bit address arithmetic, no select per tap.
+    constexpr unsigned OOB = 0xf0000000u;
+    constexpr int G = 4, PTS = 8 * G;
+    constexpr int PITCH = PTS + 4;  // floats per tile row: rows stay 16-byte aligned
+    u32x4_t rs;
+    {
+        const unsigned long long base = (unsigned long long)mp;
+        rs.x = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        rs.y = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));  // stride 0: raw
+        rs.z = (unsigned)__builtin_amdgcn_readfirstlane((int)map_bytes_all);
+        rs.w = 0x00020000u;
+    }
+    const int sub = lane & 7, pin = lane >> 3;
+    const int hw = g.h_out * g.w_out;
+    const int HW = g.h_in * g.w_in;
+    const int p0 = tile * PTS;
+    const unsigned boff = (unsigned)(pass * 8 + sub) * 16u;
+    // this lane's lattice point in the footprint phase
+    const int fp = p0 + (lane & 31);
+    const int fhi = fp / g.w_out, fwi = fp - fhi * g.w_out;
+    const unsigned pix_bytes = (unsigned)g.nblk * 16u;
+    const unsigned smp_off = (unsigned)b * (unsigned)HW * pix_bytes;
+    u32x4_t tap[G][4];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tap[gi][k] = u32x4_t{0, 0, 0, 0};
+    // footprints of planes d, d + 1 (lanes 32-63: the second plane), lane = point, reference op order, into
+    // a ring of three planes: the offsets of plane d - 1 are what the cache holds when plane d arrives
+    auto footprints = [&](int d) {
+        const int dd = d + (lane >> 5);
+        // (both depths through the scalar cache: a per-lane load would put a vmcnt(0) -- a wait for the
+        // previous plane's store acknowledgements -- into the loop)
+        const float dep0 = depths[d], dep1 = depths[min(d + 1, d1 - 1)];
+        if (dd < d1) {
+            float x, y;
+            sweep_point_map<HALF>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, (lane >> 5) ? dep1 : dep0, fhi,
+                                  fwi, x, y);
+            const Tap t = make_tap(x, y, g.h_in, g.w_in);
+            const int i00 = t.iy * g.w_in + t.ix, i01 = i00 + t.dx;
+            const int i10 = i00 + t.dy * g.w_in, i11 = i10 + t.dx;
+            Foot f;
+            f.slot[0] = (t.ok & 1u) ? smp_off + (unsigned)i00 * pix_bytes : OOB;
+            f.slot[1] = (t.ok & 2u) ? smp_off + (unsigned)i01 * pix_bytes : OOB;
+            f.slot[2] = (t.ok & 4u) ? smp_off + (unsigned)i10 * pix_bytes : OOB;
+            f.slot[3] = (t.ok & 8u) ? smp_off + (unsigned)i11 * pix_bytes : OOB;
+            f.w[0] = t.nw; f.w[1] = t.ne; f.w[2] = t.sw; f.w[3] = t.se;
+            foot_s[(dd - d0) % 3][lane & 31] = f;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // bring the cache to plane d: load the taps whose offset differs from plane d - 1's
+    auto update = [&](int d, bool first) {
+        const Foot *fnew = foot_s[(d - d0) % 3], *fold = foot_s[(d - d0 + 2) % 3];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const u32x4_t sn = *(const u32x4_t *)fnew[gi * 8 + pin].slot;
+            const u32x4_t so = *(const u32x4_t *)fold[gi * 8 + pin].slot;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long need =
+                    (DFM_WALK_ABLATE & 1) ? 0ull : __builtin_amdgcn_ballot_w64(first || sn[k] != so[k]);
+                walk_load_if(tap[gi][k], need, sn[k] + boff, rs);
+            }
+        }
+    };
+    // the four channel rows this lane flushes: row i * 8 + (lane >> 3), points (lane & 7) * 4 ..
+    float *orow = out + (((size_t)b * 2 * g.C + (size_t)HALF * g.C + pass * 32 + (lane >> 3)) * g.D + d0) * hw + p0 +
+                  (lane & 7) * 4;
+    const size_t row8 = (size_t)8 * g.D * hw;
+    footprints(d0);
+    update(d0, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Per plane: blend d | footprints / loads for d + 1 | transpose + store d.  The loads of d + 1 are OLDER
+    // than the stores of d, so the wait for them (vmcnt(4): everything but the four newest operations, the
+    // stores) does not wait for the acknowledgement of those stores.
+    for (int d = d0; d < d1; ++d) {
+        asm volatile("s_waitcnt vmcnt(4)"
+                     : "+v"(tap[0][0]), "+v"(tap[0][1]), "+v"(tap[0][2]), "+v"(tap[0][3]), "+v"(tap[1][0]),
+                       "+v"(tap[1][1]), "+v"(tap[1][2]), "+v"(tap[1][3]), "+v"(tap[2][0]), "+v"(tap[2][1]),
+                       "+v"(tap[2][2]), "+v"(tap[2][3]), "+v"(tap[3][0]), "+v"(tap[3][1]), "+v"(tap[3][2]),
+                       "+v"(tap[3][3])
+                     :
+                     : "memory");
+        const Foot *fcur = foot_s[(d - d0) % 3];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            float r[4], w4[4];
+            const f32x4w_t wv = *(const f32x4w_t *)fcur[gi * 8 + pin].w;
+            w4[0] = wv.x; w4[1] = wv.y; w4[2] = wv.z; w4[3] = wv.w;
+            blend4<4>(w4, make_uint4(tap[gi][0].x, tap[gi][0].y, tap[gi][0].z, tap[gi][0].w),
+                      make_uint4(tap[gi][1].x, tap[gi][1].y, tap[gi][1].z, tap[gi][1].w),
+                      make_uint4(tap[gi][2].x, tap[gi][2].y, tap[gi][2].z, tap[gi][2].w),
+                      make_uint4(tap[gi][3].x, tap[gi][3].y, tap[gi][3].z, tap[gi][3].w), r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile_s[(sub * 4 + j) * PITCH + gi * 8 + pin] = r[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (d + 1 < d1) {
+            if (((d + 1 - d0) & 1) == 0) footprints(d + 1);
+            update(d + 1, false);
+        }
+        // 32 channels x 32 points: 8 lanes per channel row, one 128-byte run each
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4_t val = *(const u32x4_t *)(tile_s + (i * 8 + (lane >> 3)) * PITCH + (lane & 7) * 4);
+            if (!(DFM_WALK_ABLATE & 2) || val.x == 0x12345u) __builtin_nontemporal_store(val, (u32x4_t *)(orow + i * row8));
+        }
+        orow += hw;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256, DFM_WALK_WAVES) void sweep_cltw_kernel(
+    SweepGeom g, SweepFast fast, WalkGrid tg, const uint4 *__restrict__ cur_maps, const uint4 *__restrict__ prev_maps,
+    unsigned map_bytes_all, const float *__restrict__ depths, const float *__restrict__ P,
+    const float *__restrict__ Pinv, const float *__restrict__ Tm, float *__restrict__ out)
+{
+    __shared__ Foot foot_s[4][3][32];
+    __shared__ __attribute__((aligned(16))) float tile_s[4][32 * 36];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // block id = (((tile4 * 2 + map) * passes + pass) * chunks + chunk) * B + b: sample fastest (id % 8 == XCD
+    // keeps a sample's maps in one L2), then the depth chunks of one tile (the same cur pixels)
+    int th = blockIdx.x;
+    const int b = th % tg.batch;
+    th /= tg.batch;
+    const int chunk = th % tg.chunks;
+    th /= tg.chunks;
+    const int pass = th % tg.passes;
+    th /= tg.passes;
+    const int map = th & 1;
+    const int tile = (th >> 1) * 4 + wave;
+    if (tile >= tg.tiles) return;
+    const int d0 = chunk * tg.chunk_planes, d1 = min(g.D, d0 + tg.chunk_planes);
+    if (map == 0)
+        walk_body<0>(g, fast, b, tile, d0, d1, pass, lane, foot_s[wave], tile_s[wave], cur_maps, map_bytes_all,
+                     depths, P, Pinv, Tm, out);
+    else
+        walk_body<1>(g, fast, b, tile, d0, d1, pass, lane, foot_s[wave], tile_s[wave], prev_maps, map_bytes_all,
+                     depths, P, Pinv, Tm, out);
+}
+
 size_t map_bytes(const dfm_sweep_desc *d)
 {
     return ((size_t)d->batch * d->channels * d->h_in * d->w_in * (d->dtype == DFM_BF16 ? 2 : 4) + 255) &
@@ -295,9 +506,18 @@ size_t sweep_clt_workspace_bytes(const dfm_sweep_desc *d)
     return zero + 2 * map_bytes(d);
 }
 
+// the depth-walking kernel: fp32, whole 32-channel passes, whole 32-point tiles
+bool sweep_cltw_supported(const dfm_sweep_desc *d, const void *out)
+{
+    const long long hw = (long long)d->h_out * d->w_out;
+    // (tap offsets are 32-bit byte offsets into a map, 0xf0000000 marks an out-of-bounds corner)
+    return d->dtype == DFM_F32 && d->channels % 32 == 0 && hw % 32 == 0 && sweep_clt_supported(d, out) &&
+           map_bytes(d) < 0xe0000000ull;
+}
+
 int sweep_clt_launch(const dfm_sweep_desc *d, const void *cur, const void *prev, const float *depths,
                      const float *cam2img, const float *cam2img_inv, const float *cur2prev, void *out,
-                     void *workspace, void *stream, bool nhwc)
+                     void *workspace, void *stream, bool nhwc, bool walk)
 {
     const SweepGeom g = sweep_make_geom(d);
     const size_t esz = d->dtype == DFM_BF16 ? 2 : 4;
@@ -335,7 +555,21 @@ int sweep_clt_launch(const dfm_sweep_desc *d, const void *cur, const void *prev,
                            (bf16_t *)(w8 + zero + mb), d->channels, d->channels, HW);
     }
     const bool timed = profile_mark(stream, false);
-    if (d->dtype == DFM_F32)
+    if (walk && sweep_cltw_supported(d, out)) {
+        WalkGrid wg;
+        wg.batch = d->batch;
+        wg.tiles = (int)(hw / 32);
+        wg.chunk_planes = g.D >= 48 ? 24 : (g.D + 1) & ~1;
+#ifdef DFM_WALK_CHUNK_ENV  // experiments
+        if (const char *e = getenv("DFM_WALK_CHUNK")) wg.chunk_planes = atoi(e);
+#endif
+        wg.chunks = (g.D + wg.chunk_planes - 1) / wg.chunk_planes;
+        wg.passes = g.nblk / 8;
+        const long long nw = (long long)((wg.tiles + 3) / 4) * 2 * wg.passes * wg.chunks * d->batch;
+        if (nw > 2147483647ll) return set_error(DFM_ERR_UNSUPPORTED, "too many lattice points");
+        hipLaunchKernelGGL(sweep_cltw_kernel, dim3((unsigned)nw), dim3(256), 0, st, g, sweep_make_fast(d), wg,
+                           cur_maps, prev_maps, (unsigned)mb, depths, cam2img, cam2img_inv, cur2prev, (float *)out);
+    } else if (d->dtype == DFM_F32)
         hipLaunchKernelGGL((sweep_clt_kernel<float, 32>), dim3((unsigned)nb), dim3(256), 0, st, g, tg,
                            (const uint4 *)workspace, cur_maps, prev_maps, depths, cam2img, cam2img_inv, cur2prev,
                            (float *)out);

@@ -195,15 +195,19 @@ DFM_API int dfm_plane_sweep_bwd_last_kernel(void);
 /*
  * Launch options of ONE call (the library keeps no process-wide launch state).  Every field:
  * 0 = the library's default.
- *   kernel               1/2/3/4 = force that kernel (2 and 3 need D*h_out*w_out to be a multiple
+ *   kernel               1/2/3/4/5 = force that kernel (2 and 3 need D*h_out*w_out to be a multiple
  *                        of 16/sizeof(T), else the call uses 1; 4 needs whole 16-byte channel
  *                        blocks and h_out*w_out a multiple of 16/sizeof(T), else the default
  *                        dispatch applies).  default = 2 for dense sweeps (cost_sample_factor
  *                        < 1.5); strided ones (config K) take 4: taps from pixel-major maps
  *                        (one contiguous run of channels per tap), the workgroup's 256 points x
  *                        32/64 channels transposed through LDS and stored as 1 KiB runs per
- *                        channel plane -- or 3 where 4 does not apply.  For the backward call:
- *                        1 = the lane-per-point scatter fallback.
+ *                        channel plane -- or 3 where 4 does not apply; fp32 sweeps with whole
+ *                        32-channel passes and 32-point tiles take 5 instead: a wave walks a run of
+ *                        depth planes over its 32 points with each point's 2x2 footprint cached in
+ *                        registers, and loads only the taps that changed since the previous plane
+ *                        (config K: 2.3-2.8 of 8 per point and plane); 4 pins the per-plane kernel.
+ *                        For the backward call: 1 = the lane-per-point scatter fallback.
  *   lanes_per_workgroup  128 | 256 | 512 | 1024 (tile kernels; default 256)
  *   lds_kib              LDS budget per workgroup, 4..160 (default: 52 serial body, 80 pipelined body
  *                        -- whose allocation is fixed at 80 KiB and whose two buffers get half the

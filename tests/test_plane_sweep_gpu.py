@@ -37,6 +37,8 @@ def pkg():
 #   direct    : tile kernel with direct taps for every tile (strided sweeps)
 #   clt       : pixel-major taps + LDS transpose to the reference layout (strided sweeps, config K);
 #               shapes it does not cover (odd channel counts / plane sizes) take the default dispatch
+#   cltw      : the same with the depth axis walked per wave, footprints cached in registers (fp32, 32-channel
+#               passes, 32-point tiles; what the default picks for strided sweeps where it applies)
 #   lds256_chunk: shipped shape with 3 adjacent bands scheduled back to back
 #   lds512_v4 / lds1024_v4: 4 points per lane (bf16: 8-byte stores, 4 waves per SIMD)
 #   pipe*     : the pipelined body of the LDS tile kernel (two LDS buffers, one barrier per channel
@@ -76,7 +78,8 @@ MODES = {'gather': dict(kernel=1, lanes=256, lds_kib=64, blocks_per_group=4, pla
          'lds256_v4_unpaired': dict(kernel=2, lanes=256, planes=2, points_per_lane=4, pipeline=1, pair_stores=2,
                                     store_align=16),
          'direct': dict(kernel=3, lanes=256, lds_kib=64, blocks_per_group=4, planes=1),
-         'clt': dict(kernel=4)}
+         'clt': dict(kernel=4),
+         'cltw': dict(kernel=5)}
 
 
 @pytest.fixture(params=sorted(MODES), autouse=True)
