@@ -397,13 +397,24 @@ def secondary(args, pkg, dev, job, emit=True):
         g_prev = torch.zeros_like(g_cur)
         lib = pkg._capi.lib()
 
+        # strided fp32 sweeps: the cur map from the 3x3-window kernel (pixel-major gradient map), the prev map from
+        # the tile kernel -- what plane_sweep_backward() does for them; everything else dfm_plane_sweep_bwd
+        walk = [w['csf'] >= 1.5 and tdt == torch.float32]
+        prev_only = sweep.make_opts(kernel=8)
+
         def step():
             g_cur.zero_()
             g_prev.zero_()
-            pkg._capi.check(lib.dfm_plane_sweep_bwd(
-                ctypes.byref(desc), gout.data_ptr(), depths.data_ptr(), P.data_ptr(), Pinv.data_ptr(),
-                T.data_ptr(), g_cur.data_ptr(), g_prev.data_ptr(),
-                torch.cuda.current_stream(dev).cuda_stream))
+            a = (ctypes.byref(desc), gout.data_ptr(), depths.data_ptr(), P.data_ptr(), Pinv.data_ptr(), T.data_ptr())
+            st = torch.cuda.current_stream(dev).cuda_stream
+            if walk[0]:
+                rc = lib.dfm_plane_sweep_bwd_cur_nhwc(*a, g_cur.data_ptr(), st)
+                if rc == 0:
+                    pkg._capi.check(lib.dfm_plane_sweep_bwd_opts(*a, g_prev.data_ptr(), g_prev.data_ptr(), st,
+                                                                 ctypes.byref(prev_only)))
+                    return
+                walk[0] = False
+            pkg._capi.check(lib.dfm_plane_sweep_bwd(*a, g_cur.data_ptr(), g_prev.data_ptr(), st))
         nbytes = gout.numel() * esz + 2 * g_cur.numel() * 4
         name = f'plane-sweep backward ({w["dtype"]} grad volume -> 2 fp32 feature grads)'
         unit = 'cost-volume-grads/s'
@@ -494,6 +505,10 @@ def secondary(args, pkg, dev, job, emit=True):
                    'parallelism': f'dp{world}'},
         'roofline': roof, 'per_rank_ms_per_step': [round(v * 1e3 / args.steps, 4) for v in every],
         **({'gradient_exchange': comm} if comm is not None else {})}
+    if args.workload.startswith('sweep_bwd'):
+        # 1 scatter, 5 LDS-atomic tiles, 6 matrix product
+        line['config']['bwd_kernel'] = int(pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel())
+        line['config']['cur_map_window_kernel'] = bool(walk[0])
     if rank == 0 and emit:
         print(json.dumps(line), flush=True)
     if emit and torch.distributed.is_available() and torch.distributed.is_initialized() and world == 1:

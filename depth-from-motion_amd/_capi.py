@@ -32,6 +32,7 @@ EXPORTS = (
     'dfm_plane_sweep_fwd_opts',
     'dfm_plane_sweep_bwd_opts',
     'dfm_plane_sweep_bwd_channels_last',
+    'dfm_plane_sweep_bwd_cur_nhwc',
     'dfm_plane_sweep_autotune',
     'dfm_plane_sweep_tuning',
     'dfm_plane_sweep_reset_tuning',
@@ -266,6 +267,8 @@ def lib():
     h.dfm_clock_probe.argtypes = [vp, i32, vp]
     h.dfm_plane_sweep_bwd_channels_last.restype = ctypes.c_int
     h.dfm_plane_sweep_bwd_channels_last.argtypes = [dp, vp, fp, fp, fp, fp, fp, fp, vp, sz, vp]
+    h.dfm_plane_sweep_bwd_cur_nhwc.restype = ctypes.c_int
+    h.dfm_plane_sweep_bwd_cur_nhwc.argtypes = [dp, vp, fp, fp, fp, fp, fp, vp]
     h.dfm_plane_sweep_autotune.restype = ctypes.c_int
     h.dfm_plane_sweep_autotune.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp, op]
     h.dfm_plane_sweep_tuning.restype = ctypes.c_int

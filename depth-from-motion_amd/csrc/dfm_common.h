@@ -24,6 +24,7 @@ struct SweepGeom;
 int sweep_check_desc(const dfm_sweep_desc *d);
 SweepGeom sweep_make_geom(const dfm_sweep_desc *d);
 void sweep_set_last_kernel(int which);  // what dfm_plane_sweep_last_kernel() reports
+void sweep_set_last_bwd_kernel(int which);  // what dfm_plane_sweep_bwd_last_kernel() reports
 // strided sweeps in the reference layout: pixel-major taps + LDS transpose (plane_sweep_cl.hip)
 bool sweep_clt_supported(const dfm_sweep_desc *d, const void *out);
 size_t sweep_clt_workspace_bytes(const dfm_sweep_desc *d);

@@ -2002,6 +2002,7 @@ int dfm::sweep_check_desc(const dfm_sweep_desc *d) { return check_desc(d); }
 dfm::SweepGeom dfm::sweep_make_geom(const dfm_sweep_desc *d) { return make_geom(d); }
 dfm::SweepFast dfm::sweep_make_fast(const dfm_sweep_desc *d) { return make_fast(d); }
 void dfm::sweep_set_last_kernel(int which) { g_last_kernel = which; }
+void dfm::sweep_set_last_bwd_kernel(int which) { g_last_bwd_kernel.store(which); }
 bool dfm::profile_mark(void *stream, bool stop)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -2388,6 +2389,8 @@ int sweep_bwd_impl(const dfm_sweep_desc *desc, const void *grad_out, const float
                    const dfm_sweep_opts *opts, bool grad_cl)
 {
     const bool force_scatter = opts && opts->kernel == 1;
+    // 8: the tile kernel for the prev map only (the caller has the cur map from dfm_plane_sweep_bwd_cur_nhwc)
+    const bool skip_cur = opts && opts->kernel == 8;
     int rc = check_desc(desc);
     if (rc != DFM_OK) return rc;
     if (!grad_out || !depths || !cam2img || !cam2img_inv || !cur2prev || !grad_cur || !grad_prev)
@@ -2446,7 +2449,7 @@ int sweep_bwd_impl(const dfm_sweep_desc *desc, const void *grad_out, const float
         // kernel keeps the (nearest) planes beyond that (opts->kernel: 5 = never, 6 = whenever it applies
         // [the default])
         tg.split = 0;
-        const bool mfma = !(opts && opts->kernel == 5) && !grad_cl && sweep_bwd_mfma_supported(desc, grad_out);
+        const bool mfma = !(opts && (opts->kernel == 5 || skip_cur)) && !grad_cl && sweep_bwd_mfma_supported(desc, grad_out);
         if (mfma) {
             tg.split = 1;
             rc = sweep_bwd_mfma_launch(desc, 0, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_cur, grad_prev,
@@ -2474,10 +2477,10 @@ int sweep_bwd_impl(const dfm_sweep_desc *desc, const void *grad_out, const float
         else DFM_BWD_LAUNCH(T, 2, HALF, ROWS);                                                       \
     } while (0)
         if (desc->dtype == DFM_F32) {
-            DFM_BWD_HALF(float, 0, cw_cur, rows_cur);
+            if (!skip_cur) DFM_BWD_HALF(float, 0, cw_cur, rows_cur);
             DFM_BWD_HALF(float, 1, cw_prev, rows_prev);
         } else {
-            if (!mfma) DFM_BWD_HALF(bf16_t, 0, cw_cur, rows_cur);
+            if (!mfma && !skip_cur) DFM_BWD_HALF(bf16_t, 0, cw_cur, rows_cur);
             DFM_BWD_HALF(bf16_t, 1, cw_prev, rows_prev);
         }
 #undef DFM_BWD_HALF
@@ -2488,6 +2491,7 @@ int sweep_bwd_impl(const dfm_sweep_desc *desc, const void *grad_out, const float
     }
     if (grad_cl)  // the scatter kernel reads the reference layout only: the caller converts and calls dfm_plane_sweep_bwd
         return fail(DFM_ERR_UNSUPPORTED, "channels-last gradient: the LDS-tile backward does not take this shape%s");
+    if (skip_cur) return fail(DFM_ERR_UNSUPPORTED, "prev-only backward: the LDS-tile kernel does not take this shape%s");
     const long long nb = (g.N + 255) / 256;
     if (nb > 2147483647ll) return fail(DFM_ERR_UNSUPPORTED, "too many lattice points%s");
     dim3 grid((unsigned)nb, desc->batch);

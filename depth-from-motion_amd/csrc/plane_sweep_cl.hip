@@ -480,6 +480,209 @@ __global__ __launch_bounds__(256, DFM_WALK_WAVES) void sweep_cltw_kernel(
                      depths, P, Pinv, Tm, out);
 }
 
+// ---------------------------------------------------------------------------
+// Backward of strided fp32 sweeps, CUR map (autograd of F.grid_sample at dfm_backbone.py:296-311 with
+// cost_sample_factor >= 2: config K).
+//
+// The LDS-atomic tile kernel (plane_sweep.hip) stages whole feature rows per depth chunk: for a
+// strided sweep 15 of 16 staged pixels receive nothing, and config K takes 10.7 ms, half of it for the
+// cur map -- whose sample position does not move with depth at all: it is the lattice pixel up to
+// rounding noise, so over ALL planes a point's taps stay inside one 3x3 pixel window.  A WAVE owns 16
+// lattice points and the whole depth run and keeps the window's nine fp32 accumulators (the lane's 4
+// channels of each) in registers; a plane routes its four weight x gradient products into the window
+// by the footprint's position in it (selects, no memory), and the window is written out ONCE, at the
+// end: 36 no-return buffer atomics per lane into the PIXEL-MAJOR gradient map (B, H, W, C) -- the 8
+// lanes of a point cover a pixel's 128 bytes; a pixel outside the map is an offset beyond the buffer and
+// the hardware drops it.  A footprint that leaves the window (never, for a lattice-aligned sweep) adds
+// its products with atomics of its own.  A zero weight still multiplies (0 x Inf = NaN reaches the tap,
+// as in ATen); an out-of-bounds tap is skipped.
+// The gradient volume is read in the reference layout, 32 channels x 16 points per plane as 64-byte
+// rows, and transposed through a wave-private LDS tile; plane d + 1 is requested before plane d is
+// processed.
+// (Flushing an accumulator whenever its tap moves -- the forward's walking scheme mirrored, for both
+// maps -- was built first: 19.5 ms.  Partially masked atomic instructions cost their full 64 lane
+// slots; only the full-wave flushes at the end of a run were cheap: profiles/r04_c40..c42.)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void walk_flush_if(float (&a)[4], unsigned long long need, unsigned off, const u32x4_t &rs)
+{
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "buffer_atomic_add_f32 %[a0], %[off], %[rs], 0 offen\n\t"
+                 "buffer_atomic_add_f32 %[a1], %[off], %[rs], 0 offen offset:4\n\t"
+                 "buffer_atomic_add_f32 %[a2], %[off], %[rs], 0 offen offset:8\n\t"
+                 "buffer_atomic_add_f32 %[a3], %[off], %[rs], 0 offen offset:12\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(save)
+                 : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [m] "s"(need), [off] "v"(off),
+                   [rs] "s"(rs)
+                 : "memory", "scc");
+}
+
+struct CurFoot {
+    uint32_t f;  // bwd_footprint's packed corner + in-bounds bits
+    float fw, fn;
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(256, 3) void sweep_bwdc_kernel(
+    SweepGeom g, SweepFast fast, int batch, int tiles, int passes, float *__restrict__ gcur, unsigned map_bytes_all,
+    const float *__restrict__ depths, const float *__restrict__ P, const float *__restrict__ Pinv,
+    const float *__restrict__ Tm, const float *__restrict__ gout)
+{
+    constexpr unsigned OOB = 0xf0000000u;
+    constexpr int G = 2, PTS = 8 * G;
+    constexpr int PITCH = 36;  // floats per POINT row of the tile (32 channels + 16 bytes)
+    __shared__ __attribute__((aligned(16))) CurFoot foot_all[4][4][PTS];
+    __shared__ int anchor_all[4][PTS][2];
+    __shared__ __attribute__((aligned(16))) float tile_all[4][PTS * PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    CurFoot(*foot_s)[PTS] = foot_all[wave];
+    int(*anchor_s)[2] = anchor_all[wave];
+    float *tile_s = tile_all[wave];
+    // block id = ((tile4 * passes + pass) * B + b): sample fastest (id % 8 == XCD)
+    int th = blockIdx.x;
+    const int b = th % batch;
+    th /= batch;
+    const int pass = th % passes;
+    th /= passes;
+    const int tile = th * 4 + wave;
+    if (tile >= tiles) return;
+    u32x4_t rs;
+    {
+        const unsigned long long base = (unsigned long long)gcur;
+        rs.x = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        rs.y = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+        rs.z = (unsigned)__builtin_amdgcn_readfirstlane((int)map_bytes_all);
+        rs.w = 0x00020000u;
+    }
+    const int sub = lane & 7, pin = lane >> 3;
+    const int hw = g.h_out * g.w_out, H = g.h_in, W = g.w_in;
+    const int p0 = tile * PTS;
+    const unsigned boff = (unsigned)(pass * 8 + sub) * 16u;
+    const unsigned pix_bytes = (unsigned)g.nblk * 16u;
+    // footprint phase: lane = (plane of four, point)
+    const int fp = p0 + (lane & 15);
+    const int fhi = fp / g.w_out, fwi = fp - fhi * g.w_out;
+    auto footprints = [&](int d) {
+        const int k4 = lane >> 4, dd = min(d + k4, g.D - 1);
+        float sx, sy, fw, fn;
+        sweep_point_map<0>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[dd], fhi, fwi, sx, sy);
+        CurFoot cf;
+        cf.f = bwd_footprint(sx, sy, H, W, fw, fn);
+        cf.fw = fw;
+        cf.fn = fn;
+        cf.pad = 0u;
+        foot_s[k4][lane & 15] = cf;
+        if (d == 0 && k4 == 0) {
+            // the window: the pixel nearest to the first plane's position and its eight neighbours
+            const bool fin = (fabsf(sx) <= 1.0e9f) && (fabsf(sy) <= 1.0e9f);
+            anchor_s[lane & 15][0] = fin ? (int)rintf(sx) - 1 : 0;
+            anchor_s[lane & 15][1] = fin ? (int)rintf(sy) - 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    float acc[G][3][3][4];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[gi][r][c][j] = 0.0f;
+    // the two channel rows this lane reads: row i * 16 + (lane >> 2), points (lane & 3) * 4 ..
+    const float *grow = gout + (((size_t)b * 2 * g.C + pass * 32 + (lane >> 2)) * g.D) * hw + p0 + (lane & 3) * 4;
+    const size_t row16 = (size_t)16 * g.D * hw;
+    u32x4_t gv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) gv[i] = __builtin_nontemporal_load((const u32x4_t *)(grow + i * row16));
+    footprints(0);
+    int ax[G], ay[G];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        ax[gi] = anchor_s[gi * 8 + pin][0];
+        ay[gi] = anchor_s[gi * 8 + pin][1];
+    }
+    for (int d = 0; d < g.D; ++d) {
+        if (d && (d & 3) == 0) footprints(d);
+        // this plane's rows -> tile[point][channel]; the next plane's rows are requested
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = i * 16 + (lane >> 2), q = (lane & 3) * 4;
+            tile_s[(q + 0) * PITCH + ch] = __uint_as_float(gv[i].x);
+            tile_s[(q + 1) * PITCH + ch] = __uint_as_float(gv[i].y);
+            tile_s[(q + 2) * PITCH + ch] = __uint_as_float(gv[i].z);
+            tile_s[(q + 3) * PITCH + ch] = __uint_as_float(gv[i].w);
+        }
+        grow += hw;
+        if (d + 1 < g.D) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gv[i] = __builtin_nontemporal_load((const u32x4_t *)(grow + i * row16));
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const int q = gi * 8 + pin;
+            const u32x4_t fr = *(const u32x4_t *)&foot_s[d & 3][q];
+            const f32x4w_t gq = *(const f32x4w_t *)(tile_s + q * PITCH + sub * 4);
+            const uint32_t f = fr.x;
+            const float fw = __uint_as_float(fr.y), fn = __uint_as_float(fr.z);
+            const bool wok = f & (1u << 27), eok = f & (1u << 28), nok = f & (1u << 29), sok = f & (1u << 30);
+            const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
+            const int dx = ixw - ax[gi], dy = iyn - ay[gi];
+            const bool valid = f != 0u;
+            const bool inwin = valid && (unsigned)dx <= 1u && (unsigned)dy <= 1u;
+            const float cwt = 1.0f - fw, cet = fw, rnt = 1.0f - fn, rst = fn;
+            const float wq[4] = {rnt * cwt, rnt * cet, rst * cwt, rst * cet};
+            const bool okq[4] = {wok && nok, eok && nok, wok && sok, eok && sok};
+            float pr[4][4];  // [tap][channel]: weight x gradient, 0 for a tap outside the map
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pr[k][c] = okq[k] ? gq[c] * wq[k] : 0.0f;
+            if (__builtin_amdgcn_ballot_w64(valid && !inwin) != 0ull) {
+                // the footprint left the window: its products go to memory directly
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long need = __builtin_amdgcn_ballot_w64(valid && !inwin && okq[k]);
+                    const unsigned off = ((unsigned)(b * H + iyn + (k >> 1)) * (unsigned)W + (unsigned)(ixw + (k & 1))) * pix_bytes + boff;
+                    walk_flush_if(pr[k], need, off, rs);
+                }
+            }
+            const bool x0 = inwin && dx == 0, x1 = inwin && dx == 1, y0 = dy == 0, y1 = dy == 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // columns of the window: west/east taps land on columns dx, dx + 1
+                const float n0 = x0 ? pr[0][c] : 0.0f, n1 = x0 ? pr[1][c] : (x1 ? pr[0][c] : 0.0f), n2 = x1 ? pr[1][c] : 0.0f;
+                const float s0 = x0 ? pr[2][c] : 0.0f, s1 = x0 ? pr[3][c] : (x1 ? pr[2][c] : 0.0f), s2 = x1 ? pr[3][c] : 0.0f;
+                // rows: north/south taps land on rows dy, dy + 1
+                acc[gi][0][0][c] += y0 ? n0 : 0.0f;
+                acc[gi][0][1][c] += y0 ? n1 : 0.0f;
+                acc[gi][0][2][c] += y0 ? n2 : 0.0f;
+                acc[gi][1][0][c] += y0 ? s0 : (y1 ? n0 : 0.0f);
+                acc[gi][1][1][c] += y0 ? s1 : (y1 ? n1 : 0.0f);
+                acc[gi][1][2][c] += y0 ? s2 : (y1 ? n2 : 0.0f);
+                acc[gi][2][0][c] += y1 ? s0 : 0.0f;
+                acc[gi][2][1][c] += y1 ? s1 : 0.0f;
+                acc[gi][2][2][c] += y1 ? s2 : 0.0f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the windows
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int y = ay[gi] + r, x = ax[gi] + c;
+                const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                const unsigned off = in ? ((unsigned)(b * H + y) * (unsigned)W + (unsigned)x) * pix_bytes + boff : OOB;
+                walk_flush_if(acc[gi][r][c], ~0ull, off, rs);
+            }
+}
+
 size_t map_bytes(const dfm_sweep_desc *d)
 {
     return ((size_t)d->batch * d->channels * d->h_in * d->w_in * (d->dtype == DFM_BF16 ? 2 : 4) + 255) &
@@ -705,6 +908,39 @@ DFM_API int dfm_plane_sweep_fwd_nhwc(const dfm_sweep_desc *d, const void *cur, c
 {
     return sweep_cl_impl(d, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace,
                          workspace_bytes, stream, true);
+}
+
+/* Backward of a strided fp32 sweep, CUR map only, into a PIXEL-MAJOR gradient map: grad_cur is (B, H, W, C)
+ * fp32 in memory (torch: a channels_last tensor of shape (B, C, H, W)), zero-initialised by the caller and
+ * accumulated into with atomics; grad_out is the reference layout (B, 2C, D, h_out, w_out), fp32, of which the
+ * first C channels are read.  sweep_bwdc_kernel (csrc/plane_sweep_cl.hip): a wave keeps the 3x3 pixel window a
+ * point's cur taps stay in over all depth planes in registers and writes it out once.  The prev map comes from
+ * dfm_plane_sweep_bwd_opts with opts->kernel = 8 (the LDS-atomic tile kernel, prev map only).
+ * DFM_ERR_UNSUPPORTED unless fp32, channels % 32 == 0 and h_out * w_out % 16 == 0 (the caller then uses
+ * dfm_plane_sweep_bwd for both maps).  Replaces autograd of the first F.grid_sample call of build_dfm_cost
+ * (reference dfm_backbone.py:296-303). */
+DFM_API int dfm_plane_sweep_bwd_cur_nhwc(const dfm_sweep_desc *d, const void *grad_out, const float *depths,
+                                         const float *cam2img, const float *cam2img_inv, const float *cur2prev,
+                                         float *grad_cur, void *stream)
+{
+    int rc = sweep_check_desc(d);
+    if (rc != DFM_OK) return rc;
+    if (!grad_out || !depths || !cam2img || !cam2img_inv || !cur2prev || !grad_cur)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    const long long hw = (long long)d->h_out * d->w_out;
+    if (d->dtype != DFM_F32 || d->channels % 32 || hw % 16 || (((uintptr_t)grad_out | (uintptr_t)grad_cur) & 15) ||
+        map_bytes(d) >= 0xe0000000ull || d->h_in >= 4096 || d->w_in >= 8192)
+        return set_error(DFM_ERR_UNSUPPORTED, "pixel-major cur backward: fp32, channels % 32 == 0, h_out * w_out % 16 == 0");
+    const SweepGeom g = sweep_make_geom(d);
+    const int tiles = (int)(hw / 16), passes = g.nblk / 8;
+    const long long nw = (long long)((tiles + 3) / 4) * passes * d->batch;
+    if (nw > 2147483647ll) return set_error(DFM_ERR_UNSUPPORTED, "too many lattice points");
+    hipLaunchKernelGGL(sweep_bwdc_kernel, dim3((unsigned)nw), dim3(256), 0, (hipStream_t)stream, g, sweep_make_fast(d),
+                       d->batch, tiles, passes, grad_cur, (unsigned)map_bytes(d), depths, cam2img, cam2img_inv, cur2prev,
+                       (const float *)grad_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
 }
 
 }  // extern "C"

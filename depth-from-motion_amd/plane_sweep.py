@@ -330,8 +330,6 @@ def plane_sweep_backward(desc, grad_out, depths, P, Pinv, T):
     device = grad_out.device
     _require_gpu(grad_out, 'grad_out')
     shape = (desc.batch, desc.channels, desc.h_in, desc.w_in)
-    g_cur = torch.zeros(shape, dtype=torch.float32, device=device)
-    g_prev = torch.zeros(shape, dtype=torch.float32, device=device)
     opts = _current_opts()
     if _bwd_kernel is not None:
         opts = make_opts(kernel=_bwd_kernel)
@@ -343,6 +341,8 @@ def plane_sweep_backward(desc, grad_out, depths, P, Pinv, T):
         # volume's size; larger volumes are read in place (no extra memory)
         nbytes = grad_out.numel() * grad_out.element_size()
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes <= (2 << 30) else None
+        g_cur = torch.zeros(shape, dtype=torch.float32, device=device)
+        g_prev = torch.zeros(shape, dtype=torch.float32, device=device)
         with torch.cuda.device(device):
             rc = lib.dfm_plane_sweep_bwd_channels_last(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P),
                                                        _ptr(Pinv), _ptr(T), _ptr(g_cur), _ptr(g_prev),
@@ -353,6 +353,29 @@ def plane_sweep_backward(desc, grad_out, depths, P, Pinv, T):
         if rc != _capi.DFM_ERR_UNSUPPORTED:
             _capi.check(rc)
     grad_out = grad_out.contiguous()
+    if (opts is None and desc.cost_sample_factor >= 1.5 and grad_out.dtype == torch.float32 and
+            desc.channels % 32 == 0 and (desc.h_out * desc.w_out) % 16 == 0):
+        # strided fp32 sweeps (config K): the cur map's taps of a lattice point stay inside one 3x3 pixel
+        # window over all depth planes -- a wave keeps it in registers and writes it out once, into a
+        # PIXEL-MAJOR gradient map (returned as a channels_last (B, C, H, W) tensor, the layout the NHWC
+        # necks' backward wants); the prev map stays with the LDS-atomic tile kernel
+        g_cur = torch.zeros((desc.batch, desc.h_in, desc.w_in, desc.channels), dtype=torch.float32,
+                            device=device).permute(0, 3, 1, 2)
+        g_prev = torch.zeros(shape, dtype=torch.float32, device=device)
+        prev_only = make_opts(kernel=8)
+        with torch.cuda.device(device):
+            rc = lib.dfm_plane_sweep_bwd_opts(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P), _ptr(Pinv),
+                                              _ptr(T), _ptr(g_prev), _ptr(g_prev), _stream_ptr(device),
+                                              ctypes.byref(prev_only))
+            if rc == 0:
+                rc = lib.dfm_plane_sweep_bwd_cur_nhwc(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P),
+                                                      _ptr(Pinv), _ptr(T), _ptr(g_cur), _stream_ptr(device))
+        if rc == 0:
+            return g_cur, g_prev
+        if rc != _capi.DFM_ERR_UNSUPPORTED:
+            _capi.check(rc)
+    g_cur = torch.zeros(shape, dtype=torch.float32, device=device)
+    g_prev = torch.zeros(shape, dtype=torch.float32, device=device)
     with torch.cuda.device(device):
         _capi.check(
             lib.dfm_plane_sweep_bwd_opts(ctypes.byref(desc), _ptr(grad_out), _ptr(depths),

@@ -189,7 +189,7 @@ DFM_API int dfm_plane_sweep_last_kernel(void);
 /* Which kernel the last plane-sweep BACKWARD call of this process launched (process-wide: autograd
  * runs backward functions on its own threads): 1 = lane-per-point scatter, 5 = LDS-atomic tile
  * kernel, 6 = matrix-product kernel (dense bf16 sweeps; the tile kernel keeps the prev map's
- * fast-moving near planes). */
+ * fast-moving near planes).  (dfm_plane_sweep_bwd_cur_nhwc does not change it.) */
 DFM_API int dfm_plane_sweep_bwd_last_kernel(void);
 
 /*
@@ -283,6 +283,19 @@ DFM_API int dfm_plane_sweep_bwd_channels_last(const dfm_sweep_desc *desc, const 
                                               const float *cam2img_inv, const float *cur2prev,
                                               float *grad_cur, float *grad_prev, void *workspace,
                                               size_t workspace_bytes, void *stream);
+/* Backward of a STRIDED fp32 sweep (cost_sample_factor >= 2: config K), CUR map only, into a PIXEL-MAJOR
+ * gradient map: grad_cur is (B, H, W, C) fp32 in memory (torch: a channels_last tensor of shape
+ * (B, C, H, W)), zero-initialised by the caller and accumulated into with atomics; grad_out is the reference
+ * layout (B, 2C, D, h_out, w_out), fp32, of which the first C channels are read.  The cur map's sample
+ * position does not move with depth (it is the lattice pixel up to rounding noise): a wave keeps the 3x3 pixel
+ * window a point's taps stay in over ALL depth planes in registers and writes it out once (csrc/
+ * plane_sweep_cl.hip: sweep_bwdc_kernel).  The prev map comes from dfm_plane_sweep_bwd_opts with
+ * opts->kernel = 8 (the LDS-atomic tile kernel, prev map only).  DFM_ERR_UNSUPPORTED unless fp32,
+ * channels % 32 == 0 and h_out * w_out % 16 == 0: the caller then uses dfm_plane_sweep_bwd for both maps.
+ * Replaces autograd of the first F.grid_sample call of build_dfm_cost (reference dfm_backbone.py:296-303). */
+DFM_API int dfm_plane_sweep_bwd_cur_nhwc(const dfm_sweep_desc *desc, const void *grad_out, const float *depths,
+                                         const float *cam2img, const float *cam2img_inv,
+                                         const float *cur2prev, float *grad_cur, void *stream);
 /* Times the candidate launch shapes / workgroup orders of the LDS-staged kernel with the caller's
  * own arguments (a few launches per candidate; SYNCHRONOUS, `out` is overwritten with valid
  * results) and caches the fastest for this (device, problem shape); later dfm_plane_sweep_fwd

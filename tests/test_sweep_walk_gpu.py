@@ -96,3 +96,84 @@ def test_walk_batched(pkg):
     ref = orc.build_dfm_cost(cur, prev, depths, 1, 4, P, util.host_inverse(P), T, (375, 1242), False, (0, 0), 1.0)
     got = _hip(pkg, cur, prev, depths, args, kernel=5)
     assert np.array_equal(util.bits(got), util.bits(ref))
+
+
+# ---- backward of strided fp32 sweeps: the cur map's 3x3 windows in registers (dfm_plane_sweep_bwd_cur_nhwc) ----
+
+@pytest.mark.parametrize('B,C,H,W,D,t_z', [(1, 32, 64, 256, 7, None), (2, 32, 32, 128, 51, None),
+                                           (1, 64, 32, 128, 9, -4.0), (1, 32, 64, 256, 1, None)])
+def test_walk_backward_matches_torch_cpu_autograd(pkg, B, C, H, W, D, t_z):
+    """gradients of both maps against torch CPU autograd through F.grid_sample on the oracle's grids
+    (test_plane_sweep_gpu._check_backward's bar), and the kernel the call took"""
+    from tests.test_plane_sweep_gpu import _check_backward
+    _check_backward(pkg, B, C, H, W, D, 1, 4, (0, 0), seed=D + C, img_shape=(375, 1242), t_z=t_z)
+    assert pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel() == 5  # (the prev map: tile kernel, prev only)
+
+
+def test_walk_backward_equals_tile_kernel_and_is_channels_last(pkg):
+    """cur gradient from the window kernel == the tile kernel's (fp32 sums in another order)"""
+    sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(3)
+    C, H, W, D = 32, 64, 256, 13
+    args = (torch.from_numpy(util.depth_planes(D)).to(dev), 1, 4, torch.from_numpy(util.KITTI_P2[None]),
+            torch.from_numpy(util.random_poses(1, seed=9)), (375, 1242))
+    cur = rng.randn(1, C, H, W).astype(np.float32)
+    prev = rng.randn(1, C, H, W).astype(np.float32)
+    gout = torch.from_numpy(rng.randn(1, 2 * C, D, H // 4, W // 4).astype(np.float32)).to(dev)
+    grads = []
+    for kernel in (None, 5):
+        c = torch.from_numpy(cur).to(dev).requires_grad_(True)
+        p = torch.from_numpy(prev).to(dev).requires_grad_(True)
+        with sweep.backward_kernel(kernel):
+            pkg.build_dfm_cost(c, p, *args).backward(gout)
+        torch.cuda.synchronize()
+        grads.append((c.grad, p.grad, pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel()))
+    # (autograd re-lays a leaf's gradient to the leaf's strides: the layouts are checked on the raw call below)
+    for a, b in zip(grads[0][:2], grads[1][:2]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+
+
+def test_walk_backward_nonfinite_and_zero_gradients(pkg):
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(0)
+    C, H, W, D = 32, 32, 128, 4
+    args = (torch.from_numpy(util.depth_planes(D)).to(dev), 1, 4, torch.from_numpy(util.KITTI_P2[None]),
+            torch.from_numpy(util.random_poses(1, seed=1)), (375, 1242))
+    for poison in (None, float('nan'), float('inf')):
+        c = torch.from_numpy(rng.randn(1, C, H, W).astype(np.float32)).to(dev).requires_grad_(True)
+        p = torch.from_numpy(rng.randn(1, C, H, W).astype(np.float32)).to(dev).requires_grad_(True)
+        g = torch.zeros(1, 2 * C, D, H // 4, W // 4, device=dev)
+        if poison is not None:
+            g[0, 3, 1, 5, 7] = poison
+        pkg.build_dfm_cost(c, p, *args).backward(g)
+        if poison is None:
+            assert float(c.grad.abs().max()) == 0.0 and float(p.grad.abs().max()) == 0.0
+        else:
+            # the value reaches its (up to) four taps of channel 3 and nothing else
+            bad = ~torch.isfinite(c.grad)
+            assert bool(bad.any()) and int(bad.sum()) <= 4 and bool(bad[0, 3].any())
+            assert not bool((~torch.isfinite(p.grad)).any())
+
+
+def test_walk_backward_raw_call_returns_a_pixel_major_cur_gradient(pkg):
+    """plane_sweep_backward() on a strided fp32 sweep: the cur gradient comes back channels_last (the window
+    kernel's pixel-major map), the prev gradient planar (tile kernel); both equal the forced tile kernel's"""
+    sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(8)
+    B, C, H, W, D = 2, 32, 32, 128, 6
+    cur = torch.empty(B, C, H, W, device=dev)
+    desc = sweep._make_desc(cur, D, 1, 4, (375, 1242), False, (0, 0), 1.0)
+    depths = torch.from_numpy(util.depth_planes(D)).to(dev)
+    P, Pinv, T = sweep.camera_matrices(torch.from_numpy(np.stack([util.KITTI_P2] * B)),
+                                       torch.from_numpy(util.random_poses(B, seed=2)), B, dev)
+    gout = torch.from_numpy(rng.randn(B, 2 * C, D, H // 4, W // 4).astype(np.float32)).to(dev)
+    g_cur, g_prev = sweep.plane_sweep_backward(desc, gout, depths, P, Pinv, T)
+    assert g_cur.shape == (B, C, H, W) and g_cur.is_contiguous(memory_format=torch.channels_last)
+    assert not g_cur.is_contiguous() and g_prev.is_contiguous()
+    with sweep.launch_options(kernel=5):
+        t_cur, t_prev = sweep.plane_sweep_backward(desc, gout, depths, P, Pinv, T)
+    assert t_cur.is_contiguous()
+    assert torch.allclose(g_cur, t_cur, rtol=1e-5, atol=1e-5 * float(t_cur.abs().max()))
+    assert torch.equal(g_prev, t_prev) or torch.allclose(g_prev, t_prev, rtol=1e-5, atol=1e-6)
