@@ -110,6 +110,13 @@ def test_walk_backward_matches_torch_cpu_autograd(pkg, B, C, H, W, D, t_z):
     assert pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel() == 5  # (the prev map: tile kernel, prev only)
 
 
+def test_walk_backward_overlapping_windows(pkg):
+    """cost_sample_factor 2: neighbouring points' 3x3 windows share a pixel column / row -- the window flush then
+    uses device-scope atomics (two waves, possibly on two XCDs, add to the same words)"""
+    from tests.test_plane_sweep_gpu import _check_backward
+    _check_backward(pkg, 2, 32, 64, 128, 5, 1, 2, (0, 0), seed=21, img_shape=(375, 1242))
+
+
 def test_walk_backward_equals_tile_kernel_and_is_channels_last(pkg):
     """cur gradient from the window kernel == the tile kernel's (fp32 sums in another order)"""
     sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
