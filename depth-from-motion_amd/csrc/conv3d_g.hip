@@ -330,31 +330,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
                 G_WAIT(q1, 0);
                 mfmas(wcur[1], q1);
             };
-            // two taps per trip: the weight buffers really alternate (a one-tap loop has to copy the next tap's
-            // 8 * CW weight registers into place: 2 of the 5 VALU operations per MFMA)
-            // (the 96- and 128-accumulator shapes spill with the doubled body: they keep the copy)
-            if constexpr (PFW * CW <= 4) {
-                int j = 0;
-                for (; j + 2 < ntaps; j += 2) {
-                    step(wa, wb);
-                    step(wb, wa);
-                }
-                if (ntaps - j == 2) {
-                    step(wa, wb);
-                    last(wb);
-                } else {
-                    last(wa);
-                }
-            } else {
-                for (int j = 0; j + 1 < ntaps; ++j) {
-                    step(wa, wb);
+            for (int j = 0; j + 1 < ntaps; ++j) {
+                step(wa, wb);
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int cw = 0; cw < CW; ++cw) wa[ks][cw] = wb[ks][cw];
-                }
-                last(wa);
+                    for (int cw = 0; cw < CW; ++cw) wa[ks][cw] = wb[ks][cw];
             }
+            last(wa);
 #undef G_WAIT
 #undef G_WAIT_PFW
         }

@@ -19,6 +19,8 @@
 // depth distribution is sampled where it lies.  Shapes whose channel counts are not a
 // whole number of 16-byte blocks take the scalar kernel on the caller's layout.
 // Bound: HBM write of the volume + one read of the sources.
+#include <type_traits>
+
 #include "dfm_common.h"
 
 // A lane (= one voxel) writes its channels-last row as 16-byte pieces; the lanes of a store instruction
@@ -374,6 +376,168 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
     }
 }
 
+// Channels-last output, several lanes per voxel.  f2v_pm_kernel is one lane = one voxel: a tap is 64-128
+// contiguous bytes per LANE, so the 64 lanes of every load touch 64 different cache lines, and a voxel's
+// channels-last row leaves as 16-byte pieces 128-256 bytes apart.  Here the geometry (corner offsets, weights,
+// masks, the depth probability) is computed lane = voxel as before and parked in LDS (128 bytes per voxel);
+// then each source in turn (stereo feature: 8 corners, semantic feature: 4) is gathered with lane = (voxel,
+// 16-byte channel block of the source): a tap is ONE coalesced 16-byte load per lane -- the 4 or 8 lanes of a
+// voxel cover the corner's contiguous channels --, two voxels per lane are in flight (16 / 8 independent taps),
+// and a voxel's half of the row leaves as whole 64-byte runs of neighbouring voxels (non-temporal: nothing
+// re-reads it here).  Same arithmetic, corner by corner in ATen's order.  f2v_cl (config K, bf16): 1.93 ->
+// 1.35 ms (profiles/r04_c51_*); a first version with both sources in one pass (lanes 0-3 stereo, 4-7
+// semantic: divergent halves, one voxel per lane in flight) measured 2.57 ms (r04_c50).
+template <typename T>
+__global__ __launch_bounds__(256) void f2v_pm8_kernel(F2vGeom g, const uint4 *__restrict__ stereo_pm,
+                                                      const T *__restrict__ soft, const uint4 *__restrict__ sem_pm,
+                                                      const float *__restrict__ coords,
+                                                      const float *__restrict__ cam2img, T *__restrict__ out,
+                                                      FusedHead fh)
+{
+    constexpr int CB = elem<T>::CB;
+    struct Rec {
+        int o[8];
+        float w[8];
+        int o2[4];
+        float w2[4];
+        float valid, sdisp, v2d, mdisp;
+        uint32_t ok, ok2, pad0, pad1;
+    };
+    static_assert(sizeof(Rec) == 128, "one record = 128 bytes");
+    __shared__ __attribute__((aligned(16))) Rec rec[256];
+    const long long N = (long long)g.Nz * g.Ny * g.Nx;
+    const long long i0 = (long long)blockIdx.x * 256;
+    const int b = blockIdx.y;
+    {
+        const long long i = min(i0 + threadIdx.x, N - 1);
+        const float xs = coords[3 * i], ys = coords[3 * i + 1], zs = coords[3 * i + 2];
+        const float *P = cam2img + 16 * b;
+        const float a = dot4_chain(-ys, -zs, xs, 1.0f, P + 0);
+        const float bb = dot4_chain(-ys, -zs, xs, 1.0f, P + 4);
+        const float c = dot4_chain(-ys, -zs, xs, 1.0f, P + 8);
+        const float u = a / c, v = bb / c;
+        const bool valid2d = (u >= 0.0f) && (u <= g.pad_w) && (v >= 0.0f) && (v <= g.pad_h);
+        float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
+        float gz = (xs - g.depth_min) / g.depth_span;
+        gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
+        const float valid = (valid2d && gz >= -1.0f && gz <= 1.0f) ? 1.0f : 0.0f;
+        float disp = 1.0f;
+        if (g.st_att || (g.Cs > 0 && g.sem_att)) {
+            if (fh.cost) {
+                disp = valid != 0.0f
+                           ? fused_disp<T>(g, (const T *)fh.cost + (size_t)b * g.cd * g.ch * g.cw,
+                                           fh.col_max + (size_t)b * g.Hs * g.Ws,
+                                           fh.col_sum + (size_t)b * g.Hs * g.Ws, gx, gy, gz) * valid
+                           : 0.0f;
+            } else {
+                const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+                disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws) * valid;
+            }
+        }
+        Rec r;
+        const Tri t = make_tri(gx, gy, gz, g.D, g.H, g.W);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { r.o[k] = t.o[k]; r.w[k] = t.w[k]; }
+        r.ok = t.ok;
+        r.ok2 = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { r.o2[k] = 0; r.w2[k] = 0.0f; }
+        if (g.Cs > 0) {
+            const Tri t2 = make_tri(gx, gy, 0.0f, 1, g.Hsem, g.Wsem);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { r.o2[k] = t2.o[k]; r.w2[k] = t2.w[k]; }
+            r.ok2 = t2.ok & 15u;  // D == 1: the z1 corners are never in bounds
+        }
+        r.valid = valid;
+        r.sdisp = g.st_att ? disp : 1.0f;  // x * 1.0f is exact: one code path
+        r.v2d = valid2d ? 1.0f : 0.0f;
+        r.mdisp = g.sem_att ? disp : 1.0f;
+        r.pad0 = r.pad1 = 0u;
+        rec[threadIdx.x] = r;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nbs = g.C / CB, nbm = g.Cs / CB, nbt = nbs + nbm;
+    const uint4 *sv = stereo_pm + (size_t)b * g.D * g.H * g.W * nbs;
+    const uint4 *sp = sem_pm + (size_t)b * g.Hsem * g.Wsem * nbm;
+    typedef uint32_t f2v_u32x4 __attribute__((ext_vector_type(4)));
+    // One source at a time (all lanes run the same corners), L lanes per voxel (L = 4 or 8 blocks of the
+    // source per trip), TWO voxels per lane in flight: 16 (stereo) / 8 (semantic) independent taps per lane.
+    auto gather = [&](auto stereo_c, const uint4 *src, int nb, int bi0, int L) {
+        constexpr bool ST = decltype(stereo_c)::value;
+        constexpr int NK = ST ? 8 : 4;
+        const int sh = L == 4 ? 2 : 3, vpi = 64 >> sh;  // voxels per trip
+        const int j = lane & (L - 1), vp = lane >> sh;
+        for (int bb = j; bb < nb; bb += L) {
+            for (int v0 = 0; v0 < 64; v0 += 2 * vpi) {
+                float acc[2][CB];
+                int qq[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    qq[u] = wave * 64 + v0 + u * vpi + vp;
+#pragma unroll
+                    for (int e = 0; e < CB; ++e) acc[u][e] = 0.0f;
+                }
+                uint4 tapv[2][NK];
+                uint32_t okv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const Rec &r = rec[qq[u]];
+                    okv[u] = ST ? r.ok : r.ok2;
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        // (an out-of-bounds corner's offset is 0: addressable, never used)
+                        const int o = ST ? r.o[k] : r.o2[k];
+                        tapv[u][k] = src[(size_t)o * nb + bb];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const Rec &r = rec[qq[u]];
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        if (!(okv[u] & (1u << k))) continue;
+                        float v[CB];
+                        unpack16(tapv[u][k], v);
+                        const float w = ST ? r.w[k] : r.w2[k];
+#pragma unroll
+                        for (int e = 0; e < CB; ++e) acc[u][e] = acc[u][e] + v[e] * w;
+                    }
+                    float res[CB];
+                    if constexpr (ST) {
+                        const float va = r.valid, sd = r.sdisp;
+#pragma unroll
+                        for (int e = 0; e < CB; ++e) res[e] = acc[u][e] * va * sd;
+                    } else {
+                        const float v2 = r.v2d, md = r.mdisp;
+#pragma unroll
+                        for (int e = 0; e < CB; ++e) {
+                            const float sval = acc[u][e] * v2;
+                            res[e] = sval * md;
+                        }
+                    }
+                    const long long i = i0 + qq[u];
+                    if (i < N) {
+                        f2v_u32x4 pk;
+                        if constexpr (sizeof(T) == 4) {
+                            pk = f2v_u32x4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]),
+                                           __float_as_uint(res[3])};
+                        } else {
+                            pk = f2v_u32x4{dfm::pack_bf16x2(res[0], res[1]), dfm::pack_bf16x2(res[2], res[3]),
+                                           dfm::pack_bf16x2(res[4], res[5]), dfm::pack_bf16x2(res[6], res[7])};
+                        }
+                        T *dst = out + ((size_t)b * N + i) * (g.C + g.Cs) + (size_t)(bi0 + bb) * CB;
+                        __builtin_nontemporal_store(pk, (f2v_u32x4 *)dst);
+                    }
+                }
+            }
+        }
+    };
+    gather(std::true_type{}, sv, nbs, 0, nbs % 8 == 0 ? 8 : 4);
+    if (nbm > 0) gather(std::false_type{}, sp, nbm, nbs, nbm % 8 == 0 ? 8 : 4);
+    (void)nbt;
+}
+
 }  // namespace
 
 extern "C" {
@@ -383,6 +547,14 @@ static bool f2v_pixel_major(const dfm_f2v_desc *d)
 {
     const int CB = d->dtype == DFM_BF16 ? 8 : 4;
     return d->channels % CB == 0 && d->sem_channels % CB == 0;
+}
+
+// the several-lanes-per-voxel kernel: 4 or 8 sixteen-byte blocks of a source per trip
+static bool f2v_lanes_per_voxel(const dfm_f2v_desc *d)
+{
+    const int CB = d->dtype == DFM_BF16 ? 8 : 4;
+    const int nbs = d->channels / CB, nbm = d->sem_channels / CB;
+    return nbs % 4 == 0 && nbm % 4 == 0;
 }
 
 DFM_API size_t dfm_frustum_to_voxel_workspace_bytes(const dfm_f2v_desc *d)
@@ -464,6 +636,11 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
                 hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg2, dim3(256), 0, st,
                                    (const float *)sem, (float *)sem_pm, d->sem_channels,
                                    d->sem_channels, pix);
+            if (g.out_cl && f2v_lanes_per_voxel(d))
+                hipLaunchKernelGGL(f2v_pm8_kernel<float>, grid, dim3(256), 0, st, g,
+                                   (const uint4 *)stereo_pm, (const float *)softmax,
+                                   (const uint4 *)sem_pm, coords, cam2img, (float *)out, fh);
+            else
             hipLaunchKernelGGL(f2v_pm_kernel<float>, grid, dim3(256), 0, st, g,
                                (const uint4 *)stereo_pm, (const float *)softmax,
                                (const uint4 *)sem_pm, coords, cam2img, (float *)out, fh);
@@ -476,6 +653,11 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
                 hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg2, dim3(256), 0, st,
                                    (const bf16_t *)sem, (bf16_t *)sem_pm, d->sem_channels,
                                    d->sem_channels, pix);
+            if (g.out_cl && f2v_lanes_per_voxel(d))
+                hipLaunchKernelGGL(f2v_pm8_kernel<bf16_t>, grid, dim3(256), 0, st, g,
+                                   (const uint4 *)stereo_pm, (const bf16_t *)softmax,
+                                   (const uint4 *)sem_pm, coords, cam2img, (bf16_t *)out, fh);
+            else
             hipLaunchKernelGGL(f2v_pm_kernel<bf16_t>, grid, dim3(256), 0, st, g,
                                (const uint4 *)stereo_pm, (const bf16_t *)softmax,
                                (const uint4 *)sem_pm, coords, cam2img, (bf16_t *)out, fh);
