@@ -519,13 +519,14 @@ def secondary(args, pkg, dev, job, emit=True):
 def secondary_block(pkg, sweep, dev, job, budget_s=45.0):
     """What else the default run witnesses, after the timed headline and never as ``value``: other rows
     of SURVEY.md 8a on their config shapes, a few steps each -- the plane-sweep backward at N*, the
-    shipped config's strided sweep (config K, NHWC maps), DfMBackbone.forward and the voxel neck.
+    shipped config's strided sweep (config K, NHWC maps) and its backward, FrustumToVoxel's channels-last sampling,
+    DfMBackbone.forward and the voxel neck.
     Each entry: value + unit, ms per step, fraction of its roofline.  A row that fails or would overrun
     the wall-clock budget is reported as skipped, not silently dropped."""
     import types
     out = {}
     t_start = time.perf_counter()
-    for wl in ('sweep_bwd', 'kitti_nhwc', 'backbone', 'neck'):
+    for wl in ('sweep_bwd', 'kitti_nhwc', 'sweep_bwd_kitti', 'f2v_cl', 'backbone', 'neck'):
         if time.perf_counter() - t_start > budget_s:
             out[wl] = {'skipped': 'wall-clock budget of the secondary block spent'}
             continue
