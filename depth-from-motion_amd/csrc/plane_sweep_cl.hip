@@ -499,43 +499,28 @@ __global__ __launch_bounds__(256, DFM_WALK_WAVES) void sweep_cltw_kernel(
 // The gradient volume is read in the reference layout, 32 channels x 16 points per plane as 64-byte
 // rows, and transposed through a wave-private LDS tile; plane d + 1 is requested before plane d is
 // processed.
-// (Two schemes for BOTH maps were built first and dropped, profiles/r04_c40..c46: flushing an accumulator
+// (Two schemes for BOTH maps were built first and dropped, profiles/r04_c40..c53: flushing an accumulator
 // whenever its tap moves -- the forward's walking scheme mirrored -- 19.5 ms; a dense pixel-major scatter
-// of every (point, plane) with full-wave device-scope atomics 21.7 ms, 26 GB of HBM writes: on this
-// multi-XCD part a device-scope float atomic is performed memory-side, ~5 ms per dword atomic per lane and
-// tap.  What is cheap is what this kernel does: each pixel line written by exactly one wave, once, at the
-// end, with L2-local atomics.  The prev map, whose taps move, stays with the LDS-atomic tile kernel.)
+// of every (point, plane) with full-wave atomics 21.7 ms and 26 GB of HBM writes for a 0.42 GB map, ~5 ms per
+// dword atomic per lane and tap, proportional to their number: each of them re-visits every map line tens of
+// times with the gradient volume streaming through the L2 in between, and a visit of a line that has left the
+// L2 is a fill and a write-back.  This kernel visits each line once: 0.9 GB of writes.  The sc1 bit on the
+// atomics changes neither time nor traffic.  The prev map, whose taps move, stays with the LDS-atomic tile
+// kernel.)
 // ---------------------------------------------------------------------------
-// DEVICE: device-scope atomics (sc1: performed memory-side on this multi-XCD part, coherent between the
-// XCDs' L2s) -- needed wherever two waves may add to the same word; !DEVICE: performed in the issuing XCD's
-// L2 (written back at the end of the kernel), an order of magnitude cheaper, correct where every word has
-// exactly one writer.
-template <bool DEVICE>
 __device__ __forceinline__ void walk_flush_if(float (&a)[4], unsigned long long need, unsigned off, const u32x4_t &rs)
 {
     unsigned long long save;
-    if constexpr (DEVICE)
-        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                     "buffer_atomic_add_f32 %[a0], %[off], %[rs], 0 offen sc1\n\t"
-                     "buffer_atomic_add_f32 %[a1], %[off], %[rs], 0 offen offset:4 sc1\n\t"
-                     "buffer_atomic_add_f32 %[a2], %[off], %[rs], 0 offen offset:8 sc1\n\t"
-                     "buffer_atomic_add_f32 %[a3], %[off], %[rs], 0 offen offset:12 sc1\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [sv] "=&s"(save)
-                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [m] "s"(need), [off] "v"(off),
-                       [rs] "s"(rs)
-                     : "memory", "scc");
-    else
-        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                     "buffer_atomic_add_f32 %[a0], %[off], %[rs], 0 offen\n\t"
-                     "buffer_atomic_add_f32 %[a1], %[off], %[rs], 0 offen offset:4\n\t"
-                     "buffer_atomic_add_f32 %[a2], %[off], %[rs], 0 offen offset:8\n\t"
-                     "buffer_atomic_add_f32 %[a3], %[off], %[rs], 0 offen offset:12\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [sv] "=&s"(save)
-                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [m] "s"(need), [off] "v"(off),
-                       [rs] "s"(rs)
-                     : "memory", "scc");
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "buffer_atomic_add_f32 %[a0], %[off], %[rs], 0 offen\n\t"
+                 "buffer_atomic_add_f32 %[a1], %[off], %[rs], 0 offen offset:4\n\t"
+                 "buffer_atomic_add_f32 %[a2], %[off], %[rs], 0 offen offset:8\n\t"
+                 "buffer_atomic_add_f32 %[a3], %[off], %[rs], 0 offen offset:12\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(save)
+                 : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [m] "s"(need), [off] "v"(off),
+                   [rs] "s"(rs)
+                 : "memory", "scc");
 }
 
 struct CurFoot {
@@ -545,8 +530,7 @@ struct CurFoot {
 };
 
 __global__ __launch_bounds__(256, 3) void sweep_bwdc_kernel(
-    SweepGeom g, SweepFast fast, int batch, int tiles, int passes, int exclusive, float *__restrict__ gcur,
-    unsigned map_bytes_all,
+    SweepGeom g, SweepFast fast, int batch, int tiles, int passes, float *__restrict__ gcur, unsigned map_bytes_all,
     const float *__restrict__ depths, const float *__restrict__ P, const float *__restrict__ Pinv,
     const float *__restrict__ Tm, const float *__restrict__ gout)
 {
@@ -667,7 +651,7 @@ __global__ __launch_bounds__(256, 3) void sweep_bwdc_kernel(
                 for (int k = 0; k < 4; ++k) {
                     const unsigned long long need = __builtin_amdgcn_ballot_w64(valid && !inwin && okq[k]);
                     const unsigned off = ((unsigned)(b * H + iyn + (k >> 1)) * (unsigned)W + (unsigned)(ixw + (k & 1))) * pix_bytes + boff;
-                    walk_flush_if<true>(pr[k], need, off, rs);
+                    walk_flush_if(pr[k], need, off, rs);
                 }
             }
             const bool x0 = inwin && dx == 0, x1 = inwin && dx == 1, y0 = dy == 0, y1 = dy == 1;
@@ -700,9 +684,7 @@ __global__ __launch_bounds__(256, 3) void sweep_bwdc_kernel(
                 const int y = ay[gi] + r, x = ax[gi] + c;
                 const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
                 const unsigned off = in ? ((unsigned)(b * H + y) * (unsigned)W + (unsigned)x) * pix_bytes + boff : OOB;
-                // lattice points >= 3 map pixels apart: the windows are disjoint, every pixel line has one writer
-                if (exclusive) walk_flush_if<false>(acc[gi][r][c], ~0ull, off, rs);
-                else walk_flush_if<true>(acc[gi][r][c], ~0ull, off, rs);
+                walk_flush_if(acc[gi][r][c], ~0ull, off, rs);
             }
 }
 
@@ -959,8 +941,7 @@ DFM_API int dfm_plane_sweep_bwd_cur_nhwc(const dfm_sweep_desc *d, const void *gr
     const long long nw = (long long)((tiles + 3) / 4) * passes * d->batch;
     if (nw > 2147483647ll) return set_error(DFM_ERR_UNSUPPORTED, "too many lattice points");
     hipLaunchKernelGGL(sweep_bwdc_kernel, dim3((unsigned)nw), dim3(256), 0, (hipStream_t)stream, g, sweep_make_fast(d),
-                       d->batch, tiles, passes, (int)(d->cost_sample_factor >= 3.0f), grad_cur, (unsigned)map_bytes(d), depths,
-                       cam2img, cam2img_inv, cur2prev,
+                       d->batch, tiles, passes, grad_cur, (unsigned)map_bytes(d), depths, cam2img, cam2img_inv, cur2prev,
                        (const float *)grad_out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));

@@ -111,8 +111,8 @@ def test_walk_backward_matches_torch_cpu_autograd(pkg, B, C, H, W, D, t_z):
 
 
 def test_walk_backward_overlapping_windows(pkg):
-    """cost_sample_factor 2: neighbouring points' 3x3 windows share a pixel column / row -- the window flush then
-    uses device-scope atomics (two waves, possibly on two XCDs, add to the same words)"""
+    """cost_sample_factor 2: neighbouring points' 3x3 windows share a pixel column / row -- two waves add to the
+    same words of the gradient map (the window flush is atomic for that reason)"""
     from tests.test_plane_sweep_gpu import _check_backward
     _check_backward(pkg, 2, 32, 64, 128, 5, 1, 2, (0, 0), seed=21, img_shape=(375, 1242))
 
