@@ -225,21 +225,6 @@ __device__ __forceinline__ void blend_nomask(const Tap &t, const uint4 &qnw, con
     }
 }
 
-// the same chain on taps that are fp32 already (the matrix-core unpack of the tile kernel)
-template <int CB>
-__device__ __forceinline__ void blend_f32(const Tap &t, const float (&a)[CB], const float (&b)[CB],
-                                          const float (&c)[CB], const float (&d)[CB], float (&r)[CB])
-{
-#pragma unroll
-    for (int j = 0; j < CB; ++j) {
-        float acc = a[j] * t.nw;
-        acc = __builtin_fmaf(b[j], t.ne, acc);
-        acc = __builtin_fmaf(c[j], t.sw, acc);
-        acc = __builtin_fmaf(d[j], t.se, acc);
-        r[j] = acc;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // direct-gather forward: grid (ceil(N/256), B)
 // ---------------------------------------------------------------------------
