@@ -57,7 +57,7 @@ def _hip(pkg, cur, prev, depths, args, kernel, nhwc=False):
 
 @pytest.mark.parametrize('C,H,W,D,far', [(32, 64, 256, 6, False), (32, 64, 256, 7, False), (32, 64, 256, 51, False),
                                          (64, 32, 128, 9, False), (32, 64, 256, 12, True), (96, 32, 128, 2, False),
-                                         (32, 64, 256, 1, False)])
+                                         (32, 64, 256, 1, False), (32, 32, 160, 5, False)])  # (w_out 40: tiles span rows)
 @pytest.mark.parametrize('nhwc', [False, True], ids=['nchw', 'nhwc'])
 def test_walk_matches_oracle_and_per_plane_kernel(pkg, C, H, W, D, far, nhwc):
     cur, prev, depths, P, T, args = _case(C, H, W, D, 4, seed=C + D, far_pose=far)
@@ -101,7 +101,8 @@ def test_walk_batched(pkg):
 # ---- backward of strided fp32 sweeps: the cur map's 3x3 windows in registers (dfm_plane_sweep_bwd_cur_nhwc) ----
 
 @pytest.mark.parametrize('B,C,H,W,D,t_z', [(1, 32, 64, 256, 7, None), (2, 32, 32, 128, 51, None),
-                                           (1, 64, 32, 128, 9, -4.0), (1, 32, 64, 256, 1, None)])
+                                           (1, 64, 32, 128, 9, -4.0), (1, 32, 64, 256, 1, None),
+                                           (1, 32, 32, 160, 6, None)])  # (w_out 40: 16-point tiles span rows)
 def test_walk_backward_matches_torch_cpu_autograd(pkg, B, C, H, W, D, t_z):
     """gradients of both maps against torch CPU autograd through F.grid_sample on the oracle's grids
     (test_plane_sweep_gpu._check_backward's bar), and the kernel the call took"""
