@@ -386,8 +386,10 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
 // and a voxel's half of the row leaves as whole 64-byte runs of neighbouring voxels (non-temporal: nothing
 // re-reads it here).  Same arithmetic, corner by corner in ATen's order.  f2v_cl (config K, bf16): 1.93 ->
 // 1.35 ms (profiles/r04_c51_*); a first version with both sources in one pass (lanes 0-3 stereo, 4-7
-// semantic: divergent halves, one voxel per lane in flight) measured 2.57 ms (r04_c50).
-template <typename T>
+// semantic: divergent halves, one voxel per lane in flight) measured 2.57 ms (r04_c50).  PLANAR: the
+// reference layout (B, C + Cs, Nz, Ny, Nx) from the same gather (gather_planar below): f2v fp32 3.86 ->
+// 2.93 ms (r04_c59).
+template <typename T, bool PLANAR>
 __global__ __launch_bounds__(256) void f2v_pm8_kernel(F2vGeom g, const uint4 *__restrict__ stereo_pm,
                                                       const T *__restrict__ soft, const uint4 *__restrict__ sem_pm,
                                                       const float *__restrict__ coords,
@@ -533,8 +535,88 @@ __global__ __launch_bounds__(256) void f2v_pm8_kernel(F2vGeom g, const uint4 *__
             }
         }
     };
-    gather(std::true_type{}, sv, nbs, 0, nbs % 8 == 0 ? 8 : 4);
-    if (nbm > 0) gather(std::false_type{}, sp, nbm, nbs, nbm % 8 == 0 ? 8 : 4);
+    // Planar output (B, C + Cs, Nz, Ny, Nx), the reference layout: the same gather, but a lane keeps ONE channel
+    // block for FOUR CONSECUTIVE voxels (four trips, two voxels in flight) and stores, per channel, one vector
+    // of those four voxels -- the lanes of a store instruction that share a channel are 8 (fp32) / 16 (bf16)
+    // neighbouring voxel groups: whole 128-byte lines per channel plane, no transpose through LDS.
+    auto gather_planar = [&](auto stereo_c, const uint4 *src, int nb, int ch0, int L) {
+        constexpr bool ST = decltype(stereo_c)::value;
+        constexpr int NK = ST ? 8 : 4;
+        const int sh = L == 4 ? 2 : 3, ngr = 64 >> sh;  // voxel groups per round
+        const int j = lane & (L - 1), vg = lane >> sh;
+        for (int bb = j; bb < nb; bb += L) {
+            for (int v0 = 0; v0 < 64; v0 += 4 * ngr) {
+                const int qb = wave * 64 + v0 + 4 * vg;  // this lane's four voxels: qb .. qb + 3
+                float res[4][CB];
+#pragma unroll
+                for (int t0 = 0; t0 < 4; t0 += 2) {
+                    uint4 tapv[2][NK];
+                    uint32_t okv[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const Rec &r = rec[qb + t0 + u];
+                        okv[u] = ST ? r.ok : r.ok2;
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) {
+                            const int o = ST ? r.o[k] : r.o2[k];
+                            tapv[u][k] = src[(size_t)o * nb + bb];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const Rec &r = rec[qb + t0 + u];
+                        float acc[CB];
+#pragma unroll
+                        for (int e = 0; e < CB; ++e) acc[e] = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) {
+                            if (!(okv[u] & (1u << k))) continue;
+                            float v[CB];
+                            unpack16(tapv[u][k], v);
+                            const float w = ST ? r.w[k] : r.w2[k];
+#pragma unroll
+                            for (int e = 0; e < CB; ++e) acc[e] = acc[e] + v[e] * w;
+                        }
+                        if constexpr (ST) {
+                            const float va = r.valid, sd = r.sdisp;
+#pragma unroll
+                            for (int e = 0; e < CB; ++e) res[t0 + u][e] = acc[e] * va * sd;
+                        } else {
+                            const float v2 = r.v2d, md = r.mdisp;
+#pragma unroll
+                            for (int e = 0; e < CB; ++e) {
+                                const float sval = acc[e] * v2;
+                                res[t0 + u][e] = sval * md;
+                            }
+                        }
+                    }
+                }
+                const long long i = i0 + qb;
+                if (i < N) {  // (N % 4 == 0: a group of four is inside or outside as a whole)
+                    T *dst = out + ((size_t)b * (g.C + g.Cs) + ch0 + (size_t)bb * CB) * N + i;
+#pragma unroll
+                    for (int e = 0; e < CB; ++e) {
+                        if constexpr (sizeof(T) == 4) {
+                            const f2v_u32x4 pk = {__float_as_uint(res[0][e]), __float_as_uint(res[1][e]),
+                                                  __float_as_uint(res[2][e]), __float_as_uint(res[3][e])};
+                            __builtin_nontemporal_store(pk, (f2v_u32x4 *)(dst + (size_t)e * N));
+                        } else {
+                            typedef uint32_t f2v_u32x2 __attribute__((ext_vector_type(2)));
+                            const f2v_u32x2 pk = {dfm::pack_bf16x2(res[0][e], res[1][e]), dfm::pack_bf16x2(res[2][e], res[3][e])};
+                            __builtin_nontemporal_store(pk, (f2v_u32x2 *)(dst + (size_t)e * N));
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if constexpr (!PLANAR) {
+        gather(std::true_type{}, sv, nbs, 0, nbs % 8 == 0 ? 8 : 4);
+        if (nbm > 0) gather(std::false_type{}, sp, nbm, nbs, nbm % 8 == 0 ? 8 : 4);
+    } else {
+        gather_planar(std::true_type{}, sv, nbs, 0, nbs % 8 == 0 ? 8 : 4);
+        if (nbm > 0) gather_planar(std::false_type{}, sp, nbm, g.C, nbm % 8 == 0 ? 8 : 4);
+    }
     (void)nbt;
 }
 
@@ -636,8 +718,12 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
                 hipLaunchKernelGGL(pack_pixel_major_kernel<float>, pg2, dim3(256), 0, st,
                                    (const float *)sem, (float *)sem_pm, d->sem_channels,
                                    d->sem_channels, pix);
-            if (g.out_cl && f2v_lanes_per_voxel(d))
-                hipLaunchKernelGGL(f2v_pm8_kernel<float>, grid, dim3(256), 0, st, g,
+            if (f2v_lanes_per_voxel(d) && g.out_cl)
+                hipLaunchKernelGGL((f2v_pm8_kernel<float, false>), grid, dim3(256), 0, st, g,
+                                   (const uint4 *)stereo_pm, (const float *)softmax,
+                                   (const uint4 *)sem_pm, coords, cam2img, (float *)out, fh);
+            else if (f2v_lanes_per_voxel(d) && N % 4 == 0 && !((uintptr_t)out & 15))
+                hipLaunchKernelGGL((f2v_pm8_kernel<float, true>), grid, dim3(256), 0, st, g,
                                    (const uint4 *)stereo_pm, (const float *)softmax,
                                    (const uint4 *)sem_pm, coords, cam2img, (float *)out, fh);
             else
@@ -653,8 +739,12 @@ static int f2v_fwd_impl(const dfm_f2v_desc *d, const void *stereo, const void *s
                 hipLaunchKernelGGL(pack_pixel_major_kernel<bf16_t>, pg2, dim3(256), 0, st,
                                    (const bf16_t *)sem, (bf16_t *)sem_pm, d->sem_channels,
                                    d->sem_channels, pix);
-            if (g.out_cl && f2v_lanes_per_voxel(d))
-                hipLaunchKernelGGL(f2v_pm8_kernel<bf16_t>, grid, dim3(256), 0, st, g,
+            if (f2v_lanes_per_voxel(d) && g.out_cl)
+                hipLaunchKernelGGL((f2v_pm8_kernel<bf16_t, false>), grid, dim3(256), 0, st, g,
+                                   (const uint4 *)stereo_pm, (const bf16_t *)softmax,
+                                   (const uint4 *)sem_pm, coords, cam2img, (bf16_t *)out, fh);
+            else if (f2v_lanes_per_voxel(d) && N % 4 == 0 && !((uintptr_t)out & 15))
+                hipLaunchKernelGGL((f2v_pm8_kernel<bf16_t, true>), grid, dim3(256), 0, st, g,
                                    (const uint4 *)stereo_pm, (const bf16_t *)softmax,
                                    (const uint4 *)sem_pm, coords, cam2img, (bf16_t *)out, fh);
             else
