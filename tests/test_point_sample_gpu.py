@@ -166,6 +166,38 @@ def test_voxel_sample_backward_vs_torch_grid_sample(pkg, aligned):
     assert float(v.grad.abs().sum()) > 0
 
 
+@pytest.mark.parametrize('aligned', [True, False])
+def test_voxel_sample_backward_vs_the_oracle_operator(pkg, aligned):
+    """the gradient against the ORACLE's forward, not the library's own: voxel_sample is linear in the voxel
+    features, out = A v; the CPU oracle (point_fusion.py:324-410 restated) applied to one-hot volumes -- one
+    channel per voxel, a single call -- gives A column by column, and dfm_voxel_sample_bwd must return A^T g."""
+    z = np.load(os.path.join(util.GOLDEN, 'voxel_sample.npz'))
+    Nx, Ny, Nz = z['vox'].shape[2:]
+    nvox = Nx * Ny * Nz
+    kw = dict(scale=(0.95, 1.05), crop=(3.0, 2.0), flip=True)
+    onehot = np.zeros((1, nvox, Nx, Ny, Nz), np.float32)
+    onehot.reshape(nvox, nvox)[np.arange(nvox), np.arange(nvox)] = 1.0
+    A = orc.voxel_sample(onehot, z['voxel_range'], z['voxel_size'], z['depth_samples'], z['proj_inv'], 4,
+                         kw['scale'], kw['crop'], kw['flip'], (104, 156), (100, 150), aligned=aligned)[0]
+    A = A.reshape(nvox, -1).astype(np.float64)          # row k: the output of a one at voxel k
+    rng = np.random.RandomState(12)
+    dev = torch.device('cuda:0')
+    v = torch.from_numpy(rng.randn(1, 2, Nx, Ny, Nz).astype(np.float32)).to(dev).requires_grad_(True)
+    out = pkg.voxel_sample(v, z['voxel_range'], z['voxel_size'], torch.from_numpy(z['depth_samples']),
+                           torch.from_numpy(z['proj']), 4, torch.tensor(kw['scale']), torch.tensor(kw['crop']),
+                           kw['flip'], (104, 156), (100, 150), aligned=aligned,
+                           proj_inv=torch.from_numpy(z['proj_inv']))
+    g = rng.randn(*out.shape).astype(np.float32)
+    out.backward(torch.from_numpy(g).to(dev))
+    got = v.grad.cpu().numpy()[0].reshape(2, nvox)
+    want = (A @ g[0].reshape(2, -1).astype(np.float64).T).T   # (2, nvox)
+    assert np.abs(want).max() > 0.5
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
+    # and the forward of the same call equals the operator applied to v
+    fwd = (v.detach().cpu().numpy()[0].reshape(2, nvox).astype(np.float64) @ A).reshape(out.shape[1:])
+    np.testing.assert_allclose(out.detach().cpu().numpy()[0], fwd, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize('path', mv_cases(), ids=lambda p: os.path.basename(p)[:-4])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_mv_channels_last_volume_is_the_same_tensor(pkg, path, dtype):
