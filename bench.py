@@ -104,7 +104,7 @@ KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0
                      [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
 
 # secondary workloads (other rows of SURVEY.md 8a), reported with the same JSON shape
-SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd_kitti',
+SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd_kitti', 'voxel_sample', 'voxel_sample_bwd',
              'backbone', 'backbone_train', 'neck', 'dfm_neck',
              # the same rows in the layout the bf16 NDHWC pipeline hands them (channels-last sources
              # sampled in place, channels-last results for the MFMA convolutions that follow)
@@ -367,6 +367,30 @@ def secondary(args, pkg, dev, job, emit=True):
         name = 'multi-view voxel lifting (5 views x 2 frames -> 128x220x300x12, ' + \
             ('bf16, channels-last views in place -> channels-last volume)' if cl else 'fp32)')
         unit = 'voxel-volumes/s'
+    elif args.workload in ('voxel_sample', 'voxel_sample_bwd'):
+        # SURVEY 8a row a10 (point_fusion.py:324-410; unused by the released configs): config K's voxel grid
+        # (288 x 304 x 20, 32 channels) sampled back into its frustum (72 x 80 x 320)
+        B, C = 1, 32
+        vr, vs = [2.0, -30.4, -3.0, 59.6, 30.4, 1.0], [0.2, 0.2, 0.2]
+        vox = torch.randn(1, C, 288, 304, 20, generator=gen).to(dev)
+        ds = torch.tensor([(k + 0.5) * (57.6 / 288) + 2 for k in range(288)])
+        proj = torch.from_numpy(KITTI_P2.copy())
+        a = (vr, vs, ds, proj, 4, torch.tensor([1.0, 1.0]), torch.tensor([0.0, 0.0]), False, (320, 1280), (320, 1280))
+        bwd = args.workload == 'voxel_sample_bwd'
+        if bwd:
+            vox.requires_grad_(True)
+            gout = torch.randn(1, C, 72, 80, 320, generator=gen).to(dev)
+
+        def step():
+            out = pkg.voxel_sample(vox, *a, aligned=True)
+            if bwd:
+                vox.grad = None
+                out.backward(gout)
+            return out
+        esz = 4
+        nbytes = esz * C * (288 * 304 * 20 + 72 * 80 * 320) * (2 if bwd else 1)
+        name = 'voxel_sample ' + ('forward + backward' if bwd else 'forward') + ' (32 x 288x304x20 voxels -> 72x80x320 frustum, fp32)'
+        unit = 'frustum-volumes/s'
     elif args.workload in ('depth_head', 'depth_head_bf16'):
         B = 8
         x = (torch.randn(B, 1, 72, 80, 320, generator=gen) * 4).to(dev)
