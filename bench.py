@@ -240,6 +240,13 @@ def torch_cpu_sampling(w, prm, depths, orc, budget_s=8.0):
                       f'{reps} repetitions, {total:.1f} s, scaled by C'}
 
 
+def rank_census(job):
+    """{'ranks_seen': N, 'collective': 'rccl x.y.z'}: a SUM all-reduce of a one per rank over the job's
+    process group -- the line's own evidence that RCCL reached ``n_gpus`` ranks (1 / None without a group)"""
+    par = importlib.import_module('depth-from-motion_amd.parallel')
+    return {'ranks_seen': job.ranks_seen(), 'collective': par.collective_library()}
+
+
 def secondary(args, pkg, dev, job, emit=True):
     """Other hot-path rows on their config shapes; `value` = passes/s of the op over
     one sample batch, roofline from HIP-event step time (one fused kernel per step).
@@ -528,6 +535,7 @@ def secondary(args, pkg, dev, job, emit=True):
         'config': {'workload': f'{args.workload}: {name}', 'global_batch': B * world,
                    'parallelism': f'dp{world}'},
         'roofline': roof, 'per_rank_ms_per_step': [round(v * 1e3 / args.steps, 4) for v in every],
+        **rank_census(job),
         **({'gradient_exchange': comm} if comm is not None else {})}
     if args.workload.startswith('sweep_bwd'):
         # 1 scatter, 5 LDS-atomic tiles, 6 matrix product
@@ -641,10 +649,18 @@ def main():
     ap.add_argument('--pair-stores', type=int, default=0, help='4 points per lane: 1 paired 16-byte stores, 2 8-byte stores')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` is ONE command: no launcher around it -> this process becomes the
+        # launcher (one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1; the reference's
+        # tools/dist_train.sh:10-20 in one line) and the ranks below print the line
+        par = importlib.import_module('depth-from-motion_amd.parallel')
+        sys.exit(par.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), 'bench.py needs a GPU: there is no CPU product path'
+    assert args.gpus <= torch.cuda.device_count() or world > 1, \
+        f'--gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
@@ -796,6 +812,7 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
     kms, klaunches = ctypes.c_double(0), ctypes.c_int(0)
     pkg._capi.check(lib.dfm_profile_end(ctypes.byref(kms), ctypes.byref(klaunches)))
     per_rank_ms = [round(v * 1e3 / args.steps, 4) for v in every]
+    census = rank_census(job)   # a collective: every rank takes part
     ms_per_step = elapsed * 1e3 / args.steps
     value = job.value(B, args.steps, elapsed)
 
@@ -825,7 +842,8 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
                 'parallelism': f'dp{world}',
                 'kernel': 'sweep_cl_kernel' if args.channels_last else
                 {1: 'sweep_gather_kernel', 2: 'sweep_tile_kernel<LDS>', 3: 'sweep_tile_kernel<direct>',
-                 4: 'sweep_clt_kernel (pixel-major taps + LDS transpose)'}.get(
+                 4: 'sweep_clt_kernel (pixel-major taps + LDS transpose)',
+                 5: 'sweep_cltw_kernel (pixel-major taps, depth axis walked per wave)'}.get(
                     lib.dfm_plane_sweep_last_kernel(), 'none'),
                 'launch': schedule_key(tuned if tuned is not None else
                                        pkg._capi.SweepOpts(**{sweep._OPT_FIELDS[k]: v for k, v in
@@ -851,6 +869,7 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
                 'algorithmic_bytes_per_launch': bytes_per_launch,
             },
             'per_rank_ms_per_step': per_rank_ms,
+            **census,
             'part': part,
         }
         if world == 1 and not args.channels_last:

@@ -66,6 +66,22 @@ def _flags_tag(flags):
     return hashlib.sha1(' '.join(flags).encode() + b'|' + HIPCC.encode() + b'|' + ver).hexdigest()[:16]
 
 
+def _verify_walk(obj):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('verify_walk_asm', os.path.join(ROOT, 'tools', 'verify_walk_asm.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.check_object(obj)
+
+
+def walk_kernel_check():
+    """what the last build's disassembly check of sweep_cltw_kernel said: 'verified', or its findings"""
+    try:
+        return open(os.path.join(LIB_DIR, 'obj', 'walk_kernel_check.txt')).read().strip()
+    except OSError:
+        return None
+
+
 def build_hip(force=False, verbose=False, debug_hooks=False, out=None, jobs=None):
     """Compile every csrc/*.hip into lib/libdfm_hip.so. Returns the path.
 
@@ -110,6 +126,21 @@ def _build_locked(force, verbose, debug_hooks, out, jobs):
     def compile_one(item):
         obj, cmd = item
         run(cmd)
+        if os.path.basename(obj) == 'plane_sweep_cl.o':
+            # the depth-walking sweep's taps are written by asynchronous loads issued from inline asm: check
+            # in the machine code that THIS hipcc left the tap registers alone between a load and its wait
+            # (tools/verify_walk_asm.py); if not, build the file without that kernel (the per-plane kernel
+            # takes its calls, same bits)
+            findings = _verify_walk(obj + '.tmp')
+            with open(os.path.join(obj_dir, 'walk_kernel_check.txt'), 'w') as f:
+                f.write('\n'.join(findings) if findings else 'verified')
+                f.write('\n')
+            if findings:
+                import warnings
+                warnings.warn('sweep_cltw_kernel failed its disassembly check with this hipcc (%s ...): '
+                              'building plane_sweep_cl.hip with -DDFM_WALK_UNVERIFIED' % findings[0][:120],
+                              RuntimeWarning)
+                run(cmd[:1] + ['-DDFM_WALK_UNVERIFIED'] + cmd[1:])
         os.replace(obj + '.tmp', obj)  # a reader never sees a half-written object
 
     with ThreadPoolExecutor(max_workers=jobs or min(len(todo) or 1, os.cpu_count() or 4)) as pool:

@@ -55,14 +55,22 @@ def fallback_policy():
     return _POLICY['mode']
 
 
+def module_fallback_policy(module):
+    """the policy that governs ``module``: its own ``fallback_policy`` attribute (what
+    ``integration.enable_fast_path`` sets on the Mfma* modules of the model it converts) or, without one,
+    the process-wide mode"""
+    return getattr(module, 'fallback_policy', None) or _POLICY['mode']
+
+
 def _torch_path(module, x, why):
     """called by every Mfma* module right before it runs torch's convolution instead of its kernel"""
-    if not x.is_cuda or _POLICY['mode'] == 'silent':
+    mode = module_fallback_policy(module)
+    if not x.is_cuda or mode == 'silent':
         return
     msg = (f'{type(module).__name__}({module.in_channels}->{module.out_channels}): {why}; running torch\'s '
            'convolution (MIOpen) instead of the MFMA kernel.  depth-from-motion_amd.enable_fast_path(model) '
            'converts the path to bf16 / channels-last; set_fallback_policy("raise") makes this an error.')
-    if _POLICY['mode'] == 'raise':
+    if mode == 'raise':
         raise MfmaPathError(msg)
     key = (type(module).__name__, why)
     if key not in _WARNED:
@@ -638,7 +646,9 @@ def split_pieces(t, n=None):
         p = r.to(torch.bfloat16)
         pieces.append(p)
         if i + 1 < n:
-            r = r - p
+            # (a non-finite value -- or one that rounds to bf16's infinity -- lives in the first piece alone: its
+            # remainder Inf - Inf = NaN would turn torch's Inf / finite result into NaN)
+            r = torch.nan_to_num_(r - p, nan=0.0, posinf=0.0, neginf=0.0)
     return pieces
 
 
@@ -909,6 +919,19 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
     (csrc/conv3d_g.hip with a (1, 3, 3) kernel); anything else: torch's convolution, the module's other
     documented path.  ``forward_fused`` = relu?(conv(x) * scale + shift + residual) in one launch
     (eval-mode BatchNorm / bias folded into the epilogue)."""
+
+    @staticmethod
+    def covers(in_channels, out_channels, kernel_size, stride=1, padding=0):
+        """would an ``MfmaConv2d`` of this configuration ever reach an MFMA / matrix-product path?  (what
+        ``modules.ConvModule`` asks before choosing this class over a plain nn.Conv2d: 3x3 / padding 1 /
+        stride 1 | 2 with whole 32-channel chunks -- or a narrow input padded to one chunk -- and 1x1 / stride 1 /
+        padding 0; any other Conv2d of a 2-D neck stays torch's, silently, as it always was)"""
+        pair = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)  # noqa: E731
+        k, st, pd = pair(kernel_size), pair(stride), pair(padding)
+        if k == (1, 1):
+            return st == (1, 1) and pd == (0, 0)
+        return (k == (3, 3) and pd == (1, 1) and st in ((1, 1), (2, 2)) and out_channels % 32 == 0 and
+                (in_channels % 32 == 0 or in_channels < 32))
 
     def _cin_padded(self):
         """input channels as the kernel sees them: a narrow input (the 3-channel image of

@@ -108,11 +108,16 @@ __global__ void conv3d_g_pack_kernel(const TW *__restrict__ w, int rows, int kk,
 // F32 == true: the split-precision mode of fp32 models (dfm_conv3d_g_fwd_f32): the fp32 accumulators are
 // stored as they are -- plus `residual`, then a float buffer of the output's shape -- so that the terms
 // x_hi*w_hi + x_lo*w_hi + x_hi*w_lo of one convolution add up in fp32 over three launches.
+// (the F32 build's `residual` -- its fp32 partial sum -- MAY be the buffer it writes, dfm_conv3d_g_fwd_f32's
+// acc_in == out: those two parameters are not __restrict__ there)
+typedef const bf16_t *__restrict__ g_res_restrict_t;
+typedef bf16_t *__restrict__ g_out_restrict_t;
 template <int CW, int PFW, bool F32 = false>
 __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
     GGeom g, const bf16_t *__restrict__ x, const uint4 *__restrict__ wfrag,
     const float *__restrict__ scale, const float *__restrict__ shift,
-    const bf16_t *__restrict__ residual, bf16_t *__restrict__ out,
+    std::conditional_t<F32, const bf16_t *, g_res_restrict_t> residual,
+    std::conditional_t<F32, bf16_t *, g_out_restrict_t> out,
     const uint4 *__restrict__ zero_page)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk[];

@@ -1827,10 +1827,8 @@ int launch_fwd(const dfm_sweep_desc *d, const Launch &L, const void *cur, const 
     // per-plane kernel)
     if ((L.kernel == 4 || L.kernel == 5 || (L.kernel == 0 && d->cost_sample_factor >= 1.5f)) &&
         sweep_clt_supported(d, out)) {
-        const int rc4 = sweep_clt_launch(d, cur, prev, depths, P, Pinv, Tm, out, ws, (void *)st, false,
-                                         L.kernel != 4);
-        if (rc4 == DFM_OK) g_last_kernel = 4;
-        return rc4;
+        // (sweep_clt_launch reports which body it launched: 5 walking, 4 per plane)
+        return sweep_clt_launch(d, cur, prev, depths, P, Pinv, Tm, out, ws, (void *)st, false, L.kernel != 4);
     }
     uint4 *cur_blk = (uint4 *)ws;
     uint4 *prev_blk = (uint4 *)((char *)ws + blocked_bytes(d));

@@ -449,6 +449,9 @@ __device__ __forceinline__ void walk_body(const SweepGeom &g, const SweepFast &f
         orow += hw;
         __builtin_amdgcn_wave_barrier();
     }
+    // nothing is in flight into a tap register past this point (the last plane issues no loads; the build's
+    // disassembly check -- tools/verify_walk_asm.py -- follows every path from a masked load to a wait)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __global__ __launch_bounds__(256, DFM_WALK_WAVES) void sweep_cltw_kernel(
@@ -718,6 +721,15 @@ size_t sweep_clt_workspace_bytes(const dfm_sweep_desc *d)
 bool sweep_cltw_supported(const dfm_sweep_desc *d, const void *out)
 {
     const long long hw = (long long)d->h_out * d->w_out;
+#ifdef DFM_WALK_UNVERIFIED
+    // build.py disassembles sweep_cltw_kernel after compiling it (tools/verify_walk_asm.py): its taps are
+    // written by asynchronous buffer loads issued from inline asm, which is only sound if hipcc neither
+    // copies, spills nor reads a tap register between a load and the counted s_waitcnt that covers it.
+    // A build whose disassembly does not show that is compiled again with this macro: the per-plane
+    // kernel (4) takes the calls, bit-identical results, 7-17 % slower.
+    (void)hw;
+    return false;
+#endif
     // (tap offsets are 32-bit byte offsets into a map, 0xf0000000 marks an out-of-bounds corner)
     return d->dtype == DFM_F32 && d->channels % 32 == 0 && hw % 32 == 0 && sweep_clt_supported(d, out) &&
            map_bytes(d) < 0xe0000000ull;
@@ -763,7 +775,8 @@ int sweep_clt_launch(const dfm_sweep_desc *d, const void *cur, const void *prev,
                            (bf16_t *)(w8 + zero + mb), d->channels, d->channels, HW);
     }
     const bool timed = profile_mark(stream, false);
-    if (walk && sweep_cltw_supported(d, out)) {
+    const bool walking = walk && sweep_cltw_supported(d, out);
+    if (walking) {
         WalkGrid wg;
         wg.batch = d->batch;
         wg.tiles = (int)(hw / 32);
@@ -788,6 +801,7 @@ int sweep_clt_launch(const dfm_sweep_desc *d, const void *cur, const void *prev,
     if (timed) profile_mark(stream, true);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    sweep_set_last_kernel(walking ? 5 : 4);  // which body ran: 5 = the depth-walking kernel, 4 = per plane
     return DFM_OK;
 }
 
@@ -901,9 +915,7 @@ DFM_API int dfm_plane_sweep_fwd_from_nhwc(const dfm_sweep_desc *d, const void *c
     const size_t zero = ((size_t)d->channels * (d->dtype == DFM_BF16 ? 2 : 4) + 255) & ~(size_t)255;
     if (!workspace || workspace_bytes < zero)
         return set_error(DFM_ERR_WORKSPACE, "workspace smaller than one zero pixel");
-    rc = dfm::sweep_clt_launch(d, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace, stream, true);
-    if (rc == DFM_OK) dfm::sweep_set_last_kernel(4);
-    return rc;
+    return dfm::sweep_clt_launch(d, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace, stream, true);
 }
 
 DFM_API int dfm_plane_sweep_fwd_nhwc(const dfm_sweep_desc *d, const void *cur, const void *prev,

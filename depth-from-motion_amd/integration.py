@@ -362,7 +362,7 @@ def _is_norm(m):
     return isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.GroupNorm))
 
 
-def enable_fast_path(model, dtype=torch.bfloat16, strict=False, boundary_casts=True):
+def enable_fast_path(model, dtype=torch.bfloat16, strict=True, boundary_casts=True):
     """Route every convolution of the path inside ``model`` to the hand-written MFMA kernels.
 
     ``model``: a reference ``DfM`` / ``MultiViewDfM`` detector built after ``patch_reference()``, a
@@ -380,14 +380,16 @@ def enable_fast_path(model, dtype=torch.bfloat16, strict=False, boundary_casts=T
       every OTHER child of a module that owns a path root (the 2-D backbone, the detection heads)
       casts ``dtype`` inputs back to the model's original floating dtype -- so the caller keeps feeding
       and receiving the tensors it did before;
-    * ``strict=True``: switches the fallback policy to 'raise' (an ineligible input to an Mfma*
-      module is then an error instead of a one-time warning, see conv3d.set_fallback_policy).
+    * ``strict`` (default True): every Mfma* module INSIDE ``model`` gets ``fallback_policy = 'raise'`` -- an
+      input its kernel does not take (wrong dtype / layout, a shape no tiling fits) is an error there instead
+      of a one-time warning and torch's convolution.  Per model: other models in the process keep the
+      process-wide mode (conv3d.set_fallback_policy; 'warn' by default).  ``strict=False`` leaves the
+      modules' policy as it is.
 
     Returns a report dict(roots=[names], converted_parameters=n, cast_back=[names], dtype=...).
     Idempotent.  ``state_dict`` keys are unchanged; ``load_state_dict`` of an fp32 checkpoint casts
     on copy as usual."""
     from . import modules as _m
-    from .conv3d import set_fallback_policy
     path_classes = tuple(registry.registered().values())
     names = dict((m, n) for n, m in model.named_modules())
     roots, inside = [], set()
@@ -439,11 +441,15 @@ def enable_fast_path(model, dtype=torch.bfloat16, strict=False, boundary_casts=T
     report = dict(roots=[names.get(r, type(r).__name__) for r in roots], converted_parameters=converted,
                   cast_back=cast_back, dtype=dtype, fallback_policy=None)
     if strict:
-        # PROCESS-WIDE (conv3d.set_fallback_policy): every Mfma* module of every model in this process
-        # raises on an ineligible input from now on, backward included; the report says so, and
-        # set_fallback_policy('warn') restores the default
-        set_fallback_policy('raise')
-        report['fallback_policy'] = "process-wide 'raise' (conv3d.set_fallback_policy)"
+        from . import conv3d as _c
+        kinds = (_c.MfmaConv3d, _c.MfmaConv3dG, _c.MfmaConvTranspose3d, _c.MfmaConv2d, _c.MfmaConvTranspose2d)
+        n_strict = 0
+        for root in roots:
+            for sub in root.modules():
+                if isinstance(sub, kinds):
+                    sub.fallback_policy = 'raise'
+                    n_strict += 1
+        report['fallback_policy'] = f"'raise' on the {n_strict} Mfma* modules of this model"
     return report
 
 

@@ -98,11 +98,12 @@ class ConvModule(nn.Module):
             # every other 3x3x3 convolution of the path (64 .. 256 channels, stride (1,1,2), padding
             # (1,1,0): the BN3d stacks of the voxel necks): the general MFMA kernel (csrc/conv3d_g.hip)
             conv_cls = MfmaConv3dG
-        elif conv_type == 'Conv2d':
+        elif conv_type == 'Conv2d' and MfmaConv2d.covers(in_channels, out_channels, kernel_size, stride, padding):
             # the convolutions of the 2-D necks either side of the path (SPPUNetNeck, BEVHourglass): 3x3 /
             # padding 1 / stride 1 | 2 with whole 32-channel chunks run the same MFMA kernel with a (1, 3, 3)
             # kernel on the NHWC tensor as a depth-1 volume; a 1x1 convolution of an NHWC tensor is a matrix
-            # product; everything else is nn.Conv2d's own forward (MfmaConv2d IS an nn.Conv2d)
+            # product.  A configuration outside that coverage (48 channels, padding 2, stride 3 ...) stays a
+            # plain nn.Conv2d: it never had a kernel here, so strict mode has nothing to complain about
             conv_cls = MfmaConv2d
         self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride,
                              padding=padding, bias=norm_cfg is None)

@@ -233,9 +233,21 @@ class BenchJob:
         for _ in range(int(steps)):
             step()
         self._sync()
-        self.barrier()
+        # the rank's clock stops when ITS device is done; the closing barrier only keeps the ranks
+        # together for what follows (the job's time is the MAX over ranks either way, and a fast rank's
+        # own time is no longer padded with its wait for the straggler)
         elapsed = clock() - t0
+        self.barrier()
         return gather_rank_times(elapsed, self.device)
+
+    def ranks_seen(self):
+        """How many ranks the collective library actually reached: an all-reduce (SUM) of a one per rank
+        over the job's process group (RCCL on a GPU node).  bench.py prints it next to ``n_gpus``."""
+        if self.world == 1 and not _active():
+            return 1
+        t = torch.ones(1, dtype=torch.int32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
 
     def agree_fastest(self, timings):
         """``timings``: {candidate: this rank's time}.  Every rank must launch the same shape: a
@@ -253,3 +265,50 @@ class BenchJob:
     def value(self, units_per_rank_per_step, steps, job_seconds):
         """whole-job throughput (weak scaling: every rank processes ``units_per_rank_per_step``)"""
         return units_per_rank_per_step * self.world * steps / job_seconds
+
+
+def collective_library():
+    """'rccl x.y.z' when the process group runs on the nccl (= RCCL on ROCm) backend, else the backend's name"""
+    if not _active():
+        return None
+    backend = dist.get_backend()
+    if backend == 'nccl':
+        try:
+            v = torch.cuda.nccl.version()
+            return 'rccl ' + '.'.join(str(x) for x in (v if isinstance(v, tuple) else (v,)))
+        except Exception:  # noqa: BLE001 -- a version string is informational
+            return 'rccl'
+    return str(backend)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(script, argv, nproc, port=None, extra_env=None, capture=False):
+    """Run ``python script argv...`` as ``nproc`` ranks of ONE node under ``torch.distributed.run`` -- what
+    ``tools/dist_train.sh:10-20`` does for the reference (``python -m torch.distributed.launch
+    --nproc_per_node=$GPUS``) -- so that ``python bench.py --gpus N`` is one self-contained command.  The
+    children see RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and take the ordinary per-rank path; rendezvous on
+    127.0.0.1 (the container hostname may not resolve).  Returns the launcher's exit code (and its stdout
+    when ``capture``)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or nproc) // int(nproc))))
+    env.update(extra_env or {})
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={int(nproc)}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port or free_port()), script] + list(argv)
+    if capture:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        return r.returncode, r.stdout, r.stderr
+    return subprocess.call(cmd, env=env)

@@ -184,7 +184,9 @@ DFM_API int dfm_plane_sweep_grid(const dfm_sweep_desc *desc, int32_t b, const fl
 /* Which kernel the last dfm_plane_sweep_fwd on this thread dispatched:
  * 0 = none yet, 1 = lane-per-point gather kernel, 2 = LDS-staged tile kernel
  * (+ direct-tap pass over flagged tiles), 3 = tile kernel with direct taps, 4 = pixel-major
- * taps + LDS transpose (strided sweeps).  Thread-local. */
+ * taps + LDS transpose (strided sweeps, one depth plane per workgroup), 5 = the same with the depth
+ * axis walked per wave (what strided fp32 sweeps take by default; a shape it does not cover -- or a
+ * build whose disassembly check failed, see build.py -- reports 4).  Thread-local. */
 DFM_API int dfm_plane_sweep_last_kernel(void);
 /* Which kernel the last plane-sweep BACKWARD call of this process launched (process-wide: autograd
  * runs backward functions on its own threads): 1 = lane-per-point scatter, 5 = LDS-atomic tile
@@ -672,11 +674,15 @@ DFM_API int dfm_conv3d_g_fwd(const dfm_conv3d_desc *desc, const void *x, const v
                              void *out, void *stream);
 /* Split-precision mode for fp32 models: the same kernel, but the fp32 accumulators are stored as they
  * are into `out` (fp32, (N, D', H', W', cout)), plus `acc_in` (same shape, may be NULL, may equal `out`).
- * A fp32 convolution y = conv(x, w) is then three launches on bf16 operands,
- *   x = x_hi + x_lo, w = w_hi + w_lo:  y = conv(x_hi, w_hi) + conv(x_lo, w_hi) + conv(x_hi, w_lo)
- * accumulated in fp32 (the dropped term is 2^-18 of a product): what nn.Conv3d / ConvTranspose3d
- * (dfm_backbone.py:175-201, conv_modules.py:73-149, imvoxel_neck.py:26-55) compute at the reference's
- * default precision, without MIOpen.  desc->relu must be 0; no scale / shift / residual. */
+ * A fp32 convolution y = conv(x, w) is then a few launches on bf16 operands accumulated in fp32.
+ * The Python host's default (conv3d.set_fp32_mode('split'), three pieces per operand, all 24 significand
+ * bits): x = x0 + x1 + x2, w = w0 + w1 + w2,  y = sum over i + j <= 2 of conv(x_i, w_j) -- SIX launches, the
+ * dropped terms are 2^-27 of a product.  set_fp32_mode('split2'): two pieces, THREE launches,
+ *   y = conv(x0, w0) + conv(x1, w0) + conv(x0, w1)   (dropped term 2^-18 of a product).
+ * Either way: what nn.Conv3d / ConvTranspose3d (dfm_backbone.py:175-201, conv_modules.py:73-149,
+ * imvoxel_neck.py:26-55) compute at the reference's default precision, without MIOpen.  A non-finite
+ * operand value travels in the first piece only (its remainders are zero, not Inf - Inf).
+ * desc->relu must be 0; no scale / shift / residual. */
 DFM_API int dfm_conv3d_g_fwd_f32(const dfm_conv3d_desc *desc, const void *x, const void *packed_weights,
                                  const float *acc_in, float *out, void *stream);
 /* The tiling dfm_conv3d_g_fwd uses for desc: {pixel fragments per wave, channel fragments per

@@ -154,9 +154,23 @@ def test_enable_fast_path_converts_convolutions_and_keeps_norms_fp32(pkg, policy
     assert det.backbone_stereo.volume_memory_format == torch.channels_last_3d
     assert det.feature_transformation.output_memory_format == torch.contiguous_format
     assert list(det.state_dict().keys()) == keys
+    # strict is the default and PER MODEL: the Mfma* modules of this detector raise on an input their kernel
+    # does not take, the process-wide mode (other models) stays 'warn'
+    cv = importlib.import_module('depth-from-motion_amd.conv3d')
+    kinds = (cv.MfmaConv3d, cv.MfmaConv3dG, cv.MfmaConvTranspose3d, cv.MfmaConv2d, cv.MfmaConvTranspose2d)
+    mine = [m for m in det.modules() if isinstance(m, kinds)]
+    assert mine and all(cv.module_fallback_policy(m) == 'raise' for m in mine) and "'raise'" in rep['fallback_policy']
     assert pkg.fallback_policy() == 'warn'
-    again = pkg.enable_fast_path(det, strict=True)             # idempotent; strict flips the policy
-    assert again['converted_parameters'] == 0 and pkg.fallback_policy() == 'raise'
+    other = mods.DfMBackbone(in_channels=32)
+    assert all(cv.module_fallback_policy(m) == 'warn' for m in other.modules() if isinstance(m, kinds))
+    again = pkg.enable_fast_path(det, strict=False)            # idempotent; strict=False leaves the policy alone
+    assert again['converted_parameters'] == 0 and again['fallback_policy'] is None
+    assert all(cv.module_fallback_policy(m) == 'raise' for m in mine) and pkg.fallback_policy() == 'warn'
+    # a 2-D convolution outside the kernels' coverage was never an Mfma* module: strict mode has nothing to say
+    odd = mods.ConvModule(48, 48, 3, padding=1, norm_cfg=dict(type='BN2d'))
+    assert type(odd.conv) is nn.Conv2d and type(mods.ConvModule(64, 64, 3, padding=2, norm_cfg=dict(type='BN2d')).conv) is nn.Conv2d
+    assert isinstance(mods.ConvModule(64, 32, 3, padding=1, norm_cfg=dict(type='BN2d')).conv, cv.MfmaConv2d)
+    assert isinstance(mods.ConvModule(64, 48, 1, norm_cfg=dict(type='BN2d')).conv, cv.MfmaConv2d)
     # a DfMStereoPath keeps the channels-last volume (it reshapes with bev_view, not .view)
     path = pkg.DfMStereoPath(_kitti_model())
     pkg.enable_fast_path(path)

@@ -51,7 +51,9 @@ def _hip(pkg, cur, prev, depths, args, kernel, nhwc=False):
         with sweep.launch_options(kernel=kernel):
             out = call()
     torch.cuda.synchronize()
-    assert pkg._capi.lib().dfm_plane_sweep_last_kernel() == 4
+    # the dispatcher reports the body that ran: 5 = the depth-walking kernel (every shape of this file is one
+    # it covers), 4 = the per-plane kernel where it is pinned
+    assert pkg._capi.lib().dfm_plane_sweep_last_kernel() == (4 if (kernel == 4 and not nhwc) else 5)
     return out.cpu().numpy()
 
 
