@@ -119,6 +119,13 @@ WORKLOADS = {
                       dmin=2.0, dmax=59.6, flip=True, scale=1.03),
     'kitti': dict(B=8, C=32, H=320, W=1280, D=72, fsf=1, csf=4, crop=(0, 55), dtype='f32',
                   dmin=2.0, dmax=59.6, flip=False, scale=1.0),
+    # N* with ONE -0 per map and sample (a value the matrix-core unpack is not exact for): the tiles that stage
+    # that feature row take the VALU unpack, every other tile the matrix core (per-row flags of the pack pass;
+    # rounds 3-4 flipped the whole launch); `nstar_negzero_all`: a whole channel of -0, every tile on the VALU body
+    'nstar_negzero': dict(B=8, C=256, H=94, W=311, D=112, fsf=4, csf=1, crop=(0, 0), dtype='bf16',
+                          dmin=2.0, dmax=59.6, flip=False, scale=1.0, plant='one'),
+    'nstar_negzero_all': dict(B=8, C=256, H=94, W=311, D=112, fsf=4, csf=1, crop=(0, 0), dtype='bf16',
+                              dmin=2.0, dmax=59.6, flip=False, scale=1.0, plant='channel'),
     # the same sweep fed by the channels_last (NHWC) SPPUNetNeck: maps sampled in place, no pack pass,
     # reference-layout volume out
     'kitti_nhwc': dict(B=8, C=32, H=320, W=1280, D=72, fsf=1, csf=4, crop=(0, 55), dtype='f32',
@@ -198,10 +205,22 @@ def cpu_baseline(w, budget_s=12.0):
     except (OSError, ValueError):
         pass
     try:
-        res['torch_cpu_grid_sample_this_box'] = torch_cpu_sampling(w, prm, depths, orc)
+        ts = torch_cpu_sampling(w, prm, depths, orc)
     except Exception as e:  # never fail the bench line over a reported baseline
         res['torch_cpu_grid_sample_this_box'] = {'error': repr(e)[:200]}
-    return res
+        return res
+    # The line's CPU baseline is the REFERENCE'S compute through the REFERENCE'S library on this box's host
+    # cores: the two F.grid_sample calls + cat of build_dfm_cost (dfm_backbone.py:296-313) on PyTorch-CPU.
+    # (/root/reference cannot travel to the GPU box, so the function's own file is timed in the build
+    # container only: `reference_torch_cpu`.)  The C port of the oracle -- faster than torch on the same
+    # cores -- is reported beside it.
+    port = {k: res[k] for k in ('value', 'unit', 'cores', 'sample')}
+    port['what'] = 'oracle/dfm_oracle.c (C restatement of the reference algorithm, OpenMP over rows)'
+    out = {'value': ts['value'], 'unit': ts['unit'], 'cores': ts['threads'], 'kind': 'reference',
+           'sample': ts['sample'], 'what': ts['what'], 'c_port': port}
+    if 'reference_torch_cpu' in res:
+        out['reference_torch_cpu'] = res['reference_torch_cpu']
+    return out
 
 
 def torch_cpu_sampling(w, prm, depths, orc, budget_s=8.0):
@@ -558,7 +577,8 @@ def secondary_block(pkg, sweep, dev, job, budget_s=45.0):
     import types
     out = {}
     t_start = time.perf_counter()
-    for wl in ('sweep_bwd', 'kitti_nhwc', 'sweep_bwd_kitti', 'f2v_cl', 'backbone', 'neck'):
+    for wl in ('sweep_bwd', 'kitti_nhwc', 'sweep_bwd_kitti', 'f2v_cl', 'backbone', 'neck', 'nstar_negzero',
+               'nstar_negzero_all'):
         if time.perf_counter() - t_start > budget_s:
             out[wl] = {'skipped': 'wall-clock budget of the secondary block spent'}
             continue
@@ -582,6 +602,17 @@ def secondary_block(pkg, sweep, dev, job, budget_s=45.0):
     return out
 
 
+def plant_special(cur, prev, w):
+    """WORKLOADS[..]['plant']: -0 values in the synthetic maps ('one': one per map and sample; 'channel': a whole
+    channel of them)"""
+    if w.get('plant') == 'one':
+        cur[:, 0, w['H'] // 2, w['W'] // 2] = -0.0
+        prev[:, 1, w['H'] // 3, w['W'] // 3] = -0.0
+    elif w.get('plant') == 'channel':
+        cur[:, 0] = -0.0
+        prev[:, 1] = -0.0
+
+
 def quick_sweep_row(pkg, sweep, dev, wl, steps, warmup):
     """a forward plane sweep of WORKLOADS[wl] through the public launch, HIP events around the steps"""
     w = WORKLOADS[wl]
@@ -591,6 +622,7 @@ def quick_sweep_row(pkg, sweep, dev, wl, steps, warmup):
     g = torch.Generator().manual_seed(7)
     cur = torch.randn(B, w['C'], w['H'], w['W'], generator=g).to(dev).to(tdtype)
     prev = torch.randn(B, w['C'], w['H'], w['W'], generator=g).to(dev).to(tdtype)
+    plant_special(cur, prev, w)
     if w.get('nhwc'):
         cur, prev = (t.contiguous(memory_format=torch.channels_last) for t in (cur, prev))
     depths = torch.from_numpy(depth_planes(w['D'], w['dmin'], w['dmax'])).to(dev)
@@ -699,6 +731,7 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
     gp = torch.Generator().manual_seed(job.seed(1))
     cur = torch.randn(B, w['C'], w['H'], w['W'], generator=gc).to(dev).to(tdtype)
     prev = torch.randn(B, w['C'], w['H'], w['W'], generator=gp).to(dev).to(tdtype)
+    plant_special(cur, prev, w)
     if w.get('nhwc'):
         cur, prev = (t.contiguous(memory_format=torch.channels_last) for t in (cur, prev))
     depths = torch.from_numpy(depth_planes(w['D'], w['dmin'], w['dmax'])).to(dev)

@@ -387,8 +387,12 @@ __device__ __forceinline__ Tap make_tap(float x, float y, int H, int W)
     Tap t;
     const bool fin = (fabsf(x) <= 3.0e38f) && (fabsf(y) <= 3.0e38f);  // false for NaN/Inf
     const float xw = floorf(x), yn = floorf(y);
-    const float w = x - xw, e = 1.0f - w, n = y - yn, s = 1.0f - n;
-    t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
+    // Non-finite coordinates (a projection that divides by z = 0, utils.py:209): every tap is out of bounds AND
+    // every weight is zero -- Inf - floor(Inf) is NaN, and a NaN weight times a masked (zero) tap is NaN, which
+    // is what F.grid_sample on PyTorch-CPU returns there; the oracle, these kernels and torch's GPU kernel
+    // return 0 (tests/golden/plane_sweep_zero_depth.npz pins it).
+    const float w = fin ? x - xw : 0.0f, e = 1.0f - w, n = fin ? y - yn : 0.0f, s = 1.0f - n;
+    t.nw = fin ? s * e : 0.0f; t.ne = s * w; t.sw = n * e; t.se = n * w;
     // in-bounds tests in the float domain (exact for |v| < 2^24; beyond that
     // everything is out of bounds, like ATen's saturating int conversion)
     const bool wok = fin && xw >= 0.0f && xw <= (float)(W - 1);

@@ -125,17 +125,27 @@ namespace {
 // rocprofv3 duration is ~0.19 ms either way: it starts while the previous launch's 26.8 GB of
 // volume writes are still draining to HBM.
 constexpr int PACK_PPL = 1;
-// flags[0] (zeroed by the host before the launch) gets bit 0 when a bf16 feature value is not a finite,
-// normal number or +0: Inf / NaN, a denormal, or -0.  The tile kernel then unpacks with VALU shifts instead
-// of the matrix core (see compute_store): a product 0 x Inf inside the selecting MFMA would be NaN for the
-// block's other seven channels, and the matrix core's sum of zeros loses the sign of -0 (and may flush a
-// denormal) -- values a trained network does not produce, but the results stay the reference's bit for bit.
+// flags[(map * batch + sample) * H + row] (zeroed by sweep_reset_kernel before the launch) gets bit 0 when a
+// bf16 feature value of that map ROW (any channel) is not a finite, normal number or +0: Inf / NaN, a denormal,
+// or -0.  A tile whose staged rows include a flagged row unpacks with VALU shifts instead of the matrix core
+// (see compute_store): a product 0 x Inf inside the selecting MFMA would be NaN for the block's other seven
+// channels, and the matrix core's sum of zeros loses the sign of -0 (and may flush a denormal) -- values a
+// trained network rarely produces, but the results stay the reference's bit for bit.  (Rounds 3-4 kept ONE
+// flag per launch: a single -0 anywhere in the batch sent every tile of the launch to the second-chance pass.)
+// the two spill counters and the pack pass's row flags (n_flags words)
+__global__ void sweep_reset_kernel(int *flags, int n_flags, int *b, int *c)
+{
+    for (int i = threadIdx.x; i < n_flags; i += blockDim.x) flags[i] = 0;
+    if (threadIdx.x == 0) { *b = 0; *c = 0; }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__ src0,
                                                            const T *__restrict__ src1,
                                                            uint4 *__restrict__ dst0,
                                                            uint4 *__restrict__ dst1, int batch,
-                                                           int C, int HW, int nblk, int *__restrict__ flags)
+                                                           int C, int HW, int nblk, int *__restrict__ flags,
+                                                           int W)
 {
     constexpr int CB = elem<T>::CB;
     const int pix0 = blockIdx.x * (256 * PACK_PPL) + threadIdx.x;
@@ -152,7 +162,6 @@ __global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__
         for (int j = 0; j < CB; ++j)
             v[i][j] = (blk * CB + j < C && pix < HW) ? src[(size_t)j * HW + pix] : T(0);
     }
-    bool odd_value = false;
 #pragma unroll
     for (int i = 0; i < PACK_PPL; ++i) {
         const int pix = pix0 + i * 256;
@@ -161,6 +170,7 @@ __global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__
             memcpy(&q, v[i], 16);
             dst[pix] = q;
             if constexpr (sizeof(T) == 2) {
+                bool odd_value = false;
                 const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -169,11 +179,13 @@ __global__ __launch_bounds__(256) void pack_blocked_kernel(const T *__restrict__
                         const uint32_t e = (w4[k] >> hbit) & 0xffffu, ex = e & 0x7f80u;
                         odd_value |= ex == 0x7f80u || (ex == 0u && e != 0u);
                     }
+                // (rare: a plain load first, so that a map full of -0 does not queue 10^6 atomics on one word)
+                if (flags && odd_value) {
+                    int *f = flags + (size_t)blockIdx.z * (HW / W) + pix / W;
+                    if (__builtin_nontemporal_load(f) == 0) atomicOr(f, 1);
+                }
             }
         }
-    }
-    if constexpr (sizeof(T) == 2) {
-        if (flags && __any(odd_value) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
     }
 }
 
@@ -347,8 +359,11 @@ __device__ __forceinline__ uint32_t footprint(float x, float y, int H, int W, in
     ix = (t.ok & 5u) ? t.ix : t.ix - ((t.ok & 10u) ? 1 : 0);
     rN = t.iy;
     rS = t.iy + t.dy;  // a lone south tap (yn == -1): rN == rS == 0, north masked
-    fw = x - floorf(x);
-    fn = y - floorf(y);
+    // (non-finite coordinates: fractions 0, so the weights are 1, 0, 0, 0 on four masked -- zero -- taps: the
+    // point is 0, not NaN x 0; see make_tap)
+    const bool fin = (fabsf(x) <= 3.0e38f) && (fabsf(y) <= 3.0e38f);
+    fw = fin ? x - floorf(x) : 0.0f;
+    fn = fin ? y - floorf(y) : 0.0f;
     return t.ok;
 }
 
@@ -360,7 +375,8 @@ struct TileGrid {
     int dgroups;           // ceil(D / planes)
     int blocks_per_group;  // channel blocks one workgroup sweeps
     int band_chunk;        // adjacent bands scheduled together (see the block id map)
-    const int *flags;      // flags[0] != 0: the maps hold a non-finite / denormal / -0 bf16 value (pack_blocked_kernel)
+    const int *flags;      // flags[(map * batch + b) * H + row] != 0: that row of that map holds a non-finite /
+                           // denormal / -0 bf16 value (pack_blocked_kernel)
     int mfma_unpack;       // bf16: unpack the taps with the matrix core (when flags allow) instead of VALU shifts
     int pair_stores;       // 4 points per lane (bf16): lane pairs trade halves and store 16-byte vectors
     int align;             // tile boundaries are multiples of this many points of the flat (d,h,w) index
@@ -387,13 +403,16 @@ constexpr int PIPE_LDS_BYTES = (8 + 2 * PIPE_BUF_SLOTS) * 16;
 template <int N> struct IntC { static constexpr int value = N; };
 
 template <typename T, int NT, bool LDS, int V, bool PIPE = false, bool MXK = false>
-__device__ __forceinline__ void tile_body(
+__device__ __forceinline__ int tile_body(
     const int bid, const SweepGeom &g, const SweepFast &fast, const TileGrid &tg, int lds_slots,
     const uint4 *__restrict__ cur_blk, const uint4 *__restrict__ prev_blk,
     const float *__restrict__ depths, const float *__restrict__ P,
     const float *__restrict__ Pinv, const float *__restrict__ Tm, T *__restrict__ out,
-    int *__restrict__ spill_list, int blk_lo_ovr = -1, int blk_hi_ovr = -1)
+    int *__restrict__ spill_list, int blk_lo_ovr = -1, int blk_hi_ovr = -1, bool retry_inline = false)
 {
+    // returns (workgroup-uniform), when retry_inline is set: 1 = the tile's rows exceed THIS body's LDS budget
+    // (the caller runs the serial body over the same dynamic LDS as ONE buffer, then direct taps), 2 = a staged
+    // row holds a value the matrix-core unpack is not exact for (the caller runs the VALU body); 0 otherwise
     constexpr int CB = elem<T>::CB;
     // V = points per lane.  V == CB: one 16-byte store per channel (the default).  V == 4 with
     // bf16: 8-byte stores, half the footprint / output registers per lane, so twice as many
@@ -435,7 +454,7 @@ __device__ __forceinline__ void tile_body(
     const int nchunks = (tg.bands + tg.band_chunk - 1) / tg.band_chunk;
     const int band = (th % nchunks) * tg.band_chunk + band_in;
     const int group = th / nchunks;
-    if (band >= tg.bands) return;
+    if (band >= tg.bands) return 0;
     // (the second-chance pass hands a flagged tile to several workgroups, each with its own
     // range of channel blocks)
     const int blk_lo = blk_lo_ovr >= 0 ? blk_lo_ovr : group * tg.blocks_per_group;
@@ -470,15 +489,6 @@ __device__ __forceinline__ void tile_body(
             if constexpr (PIPE) lds[SLAB + PIPE_BUF_SLOTS] = make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
-    }
-
-    if constexpr (MXK) {
-        // maps with a non-finite / denormal / -0 value (pack_blocked_kernel's flag): this build has no VALU
-        // unpack -- the tile goes to the second-chance pass, which has (one queue entry per tile)
-        if (__builtin_amdgcn_readfirstlane(tg.flags[0]) != 0) {
-            if (tid == 0 && blk_lo_ovr <= 0) spill_list[1 + atomicAdd(&spill_list[0], 1)] = bid;
-            return;
-        }
     }
 
     // ---- per-lane footprints: pixel index relative to row 0 of the map ----------
@@ -544,16 +554,30 @@ __device__ __forceinline__ void tile_body(
                     }
                 }
             }
-            return;
+            return 0;
         }
         cnt = (y1 - y0 + 1) * W;  // pixels (16-B slots) to stage per block
         nslots = (PAD + cnt + 1 + 7) & ~7;
         const bool fits = PIPE ? nslots <= min(PIPE_BUF_SLOTS, (lds_slots - SLAB) / 2)
                                : SLAB + nslots <= lds_slots;
         if (!fits) {
-            // rows beyond the LDS budget: queue the tile for the next pass (once per tile)
+            // rows beyond the LDS budget: the caller retries in place with a larger one, or the tile is
+            // queued for the next pass (once per tile)
+            if (retry_inline) return 1;
             if (tid == 0 && blk_lo_ovr <= 0) spill_list[1 + atomicAdd(&spill_list[0], 1)] = bid;
-            return;
+            return 0;
+        }
+        if constexpr (MXK) {
+            // a staged row with a non-finite / denormal / -0 value (pack_blocked_kernel's row flags): this body
+            // has no VALU unpack -- the caller runs the one that has (same rows for every wave: uniform)
+            const int nrows = y1 - y0 + 1;  // <= 8: the tile fits one pipelined buffer
+            const int *rf = tg.flags + ((size_t)half * batch + b) * H + y0;
+            const bool odd_row = (tid & 63) < nrows && rf[tid & 63] != 0;
+            if (__any(odd_row)) {
+                if (retry_inline) return 2;
+                if (tid == 0 && blk_lo_ovr <= 0) spill_list[1 + atomicAdd(&spill_list[0], 1)] = bid;
+                return 0;
+            }
         }
         // LDS byte address of each corner: swizzled slot of pixel q (= index in
         // the staged rows + PAD), or the zero slot for an out-of-bounds corner.
@@ -572,7 +596,7 @@ __device__ __forceinline__ void tile_body(
         }
         src += (size_t)y0 * W;
     } else {
-        if (!active) return;
+        if (!active) return 0;
         // direct taps: keep every index inside the map (masked taps are discarded)
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -964,6 +988,7 @@ __device__ __forceinline__ void tile_body(
         }
     }
 #undef DFM_TAP_READ
+    return 0;
 }
 
 #ifndef DFM_TILE_WAVES
@@ -979,8 +1004,42 @@ __global__ __launch_bounds__(NT, (LDS ? (V * sizeof(T) == 8 ? 4 : (MXK ? 2 : DFM
     const float *__restrict__ P, const float *__restrict__ Pinv, const float *__restrict__ Tm,
     T *__restrict__ out, int *__restrict__ spill_list)
 {
-    tile_body<T, NT, LDS, V, PIPE, MXK>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk, depths, P,
-                                        Pinv, Tm, out, spill_list);
+    int st = tile_body<T, NT, LDS, V, PIPE, MXK>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk, depths, P,
+                                                 Pinv, Tm, out, spill_list, -1, -1, PIPE);
+    if constexpr (PIPE) {
+        // Second chances IN PLACE (round 5).  A tile whose rows exceed one of the pipelined body's two buffers
+        // (8 rows of 311 pixels; about 1 % of the tiles at N*: the nearest planes of the prev map) runs the
+        // serial body -- stage, barrier, blend + store, barrier -- with the two buffers as one (16 rows); what
+        // does not fit that either takes direct taps.  The separate second-chance launch (sweep_respill_kernel,
+        // 144 KiB of LDS, one workgroup per CU) cost 0.145 ms per N* launch for 1 % of the tiles -- a latency
+        // chain on a mostly idle chip; here those tiles cost their workgroup about 1.5 block periods among 512
+        // resident ones, and a dense pipelined launch queues nothing: the second-chance and direct kernels are
+        // not launched at all.  A tile that stages a row with a value the matrix-core unpack is not exact for
+        // (pack_blocked_kernel's row flags) runs the pipelined body with the VALU unpack: per TILE, where rounds
+        // 3-4 sent the whole launch to the second-chance pass.
+        if constexpr (MXK) {
+            if (st == 2) {
+                __syncthreads();  // (every lane has read the bounding rows of the previous attempt)
+                st = tile_body<T, NT, true, V, true, false>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk,
+                                                            depths, P, Pinv, Tm, out, spill_list, -1, -1, true);
+            }
+        }
+        if (st == 1) {
+            __syncthreads();
+            // 16-byte stores (the default shapes): direct taps in place as the last resort; the 8-byte-store
+            // shapes (128 registers per lane) keep the queue and the direct-tap launch for it
+            constexpr bool INPLACE3 = V * sizeof(T) == 16;
+            st = tile_body<T, NT, true, V, false, false>(blockIdx.x, g, fast, tg, lds_slots, cur_blk, prev_blk, depths,
+                                                         P, Pinv, Tm, out, spill_list, -1, -1, INPLACE3);
+            if constexpr (INPLACE3) {
+                if (st == 1) {
+                    __syncthreads();
+                    tile_body<T, NT, false, V>(blockIdx.x, g, fast, tg, 0, cur_blk, prev_blk, depths, P, Pinv, Tm,
+                                               out, nullptr);
+                }
+            }
+        }
+    }
 }
 
 // the tiles the LDS pass queued (spill_list[0] = count), a fixed small grid strides over them:
@@ -1656,6 +1715,12 @@ size_t blocked_bytes(const dfm_sweep_desc *d)
 }
 
 // one spill flag per (tile, sample) of the LDS kernel at its smallest tile
+// the pack pass's flags: one word per (map, sample, feature row)
+size_t row_flag_bytes(const dfm_sweep_desc *d)
+{
+    return (((size_t)2 * d->batch * d->h_in * 4) + 255) & ~(size_t)255;
+}
+
 size_t flag_bytes(const dfm_sweep_desc *d)
 {
     const int V = d->dtype == DFM_BF16 ? 8 : 4;
@@ -1756,9 +1821,7 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
     int rc = DFM_OK;
     const SweepFast fast = make_fast(d);
     if (which == 2) {
-        int *spill2 = (int *)((char *)spill_list + flag_bytes(d));
-        HIP_TRY(hipMemsetAsync(spill_list, 0, 4, st));
-        HIP_TRY(hipMemsetAsync(spill2, 0, 4, st));
+        int *spill2 = (int *)((char *)spill_list + flag_bytes(d));  // (both counters: sweep_reset_kernel, launch_fwd)
         constexpr bool CAN_MX = sizeof(T) == 2 && V == 8;
         if (L.pipe >= 2 && CAN_MX && L.unpack) {
             // bf16, 8 points per lane: the build that unpacks the taps with the matrix core
@@ -1787,9 +1850,12 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
                                lds_bytes, st, g, fast, tg, lds_bytes / 16, cur_blk, prev_blk, depths, P,
                                Pinv, Tm, out, spill_list);
         }
-        // tiles whose rows exceeded the LDS budget (about 1 % at N*): once more with 144 KiB of
+        // The pipelined kernels with 16-byte stores take every second chance in place (serial body over both
+        // buffers, then direct taps): nothing is ever queued and the two launches below would be empty.
+        const bool queues = !(L.pipe >= 2 && V * sizeof(T) == 16);
+        // tiles whose rows exceeded the LDS budget: once more with 144 KiB of
         // LDS, split by channel block; then direct taps for what is left
-        {
+        if (queues) {
             // (a test-sized budget below 16 KiB keeps its size, so that the direct pass stays covered)
             const int BIG = L.lds_kib < 16 ? lds_bytes : 144 * 1024;
             const void *rk = (const void *)sweep_respill_kernel<T, NT, V>;
@@ -1801,8 +1867,9 @@ int launch_tiles(int which, const dfm_sweep_desc *d, const SweepGeom &g, const L
                                tg, BIG / 16, rgroups, rbpg, cur_blk, prev_blk, depths, P, Pinv, Tm, out,
                                (const int *)spill_list, spill2);
         }
-        hipLaunchKernelGGL((sweep_spill_kernel<T, NT, V>), dim3(512), dim3(NT), 16, st, g, fast, tg,
-                           cur_blk, prev_blk, depths, P, Pinv, Tm, out, spill2);
+        if (queues)
+            hipLaunchKernelGGL((sweep_spill_kernel<T, NT, V>), dim3(512), dim3(NT), 16, st, g, fast, tg,
+                               cur_blk, prev_blk, depths, P, Pinv, Tm, out, spill2);
         if (g.D > 1 && hw % 8 != 0)
             hipLaunchKernelGGL(sweep_patch_kernel<T>, dim3(g.D - 1, 2, d->batch), dim3(256), 0, st,
                                g, fast, tg.align, cur_blk, prev_blk, depths, P, Pinv, Tm, out);
@@ -1834,9 +1901,14 @@ int launch_fwd(const dfm_sweep_desc *d, const Launch &L, const void *cur, const 
     uint4 *prev_blk = (uint4 *)((char *)ws + blocked_bytes(d));
     dim3 pg((HW + 256 * PACK_PPL - 1) / (256 * PACK_PPL), g.nblk, 2 * d->batch);
     int *feat_flags = (int *)((char *)ws + 2 * blocked_bytes(d) + 2 * flag_bytes(d));
-    HIP_TRY(hipMemsetAsync(feat_flags, 0, 4, st));
+    // the whole build is timed (dfm_profile_begin): pack pass, tile kernel, second-chance / direct / patch passes
+    const bool timed = profile_mark(st, false);
+    // the pack pass's row flags and the two spill counters: one launch (three hipMemsetAsync were three)
+    hipLaunchKernelGGL(sweep_reset_kernel, dim3(1), dim3(256), 0, st, feat_flags, 2 * d->batch * d->h_in,
+                       (int *)((char *)ws + 2 * blocked_bytes(d)),
+                       (int *)((char *)ws + 2 * blocked_bytes(d) + flag_bytes(d)));
     hipLaunchKernelGGL(pack_blocked_kernel<T>, pg, dim3(256), 0, st, (const T *)cur, (const T *)prev,
-                       cur_blk, prev_blk, d->batch, g.C, HW, g.nblk, feat_flags);
+                       cur_blk, prev_blk, d->batch, g.C, HW, g.nblk, feat_flags, d->w_in);
     constexpr int CB = elem<T>::CB;
     // the tile kernels store one aligned vector of V points per channel: every channel
     // plane (N elements) has to start 16-byte aligned.
@@ -1847,7 +1919,6 @@ int launch_fwd(const dfm_sweep_desc *d, const Launch &L, const void *cur, const 
     int which = !vec_ok ? 1 : (d->cost_sample_factor < 1.5f ? 2 : 3);
     if (L.kernel == 1 || (L.kernel == 3 && vec_ok)) which = L.kernel;
     if (L.kernel == 2 && vec_ok) which = 2;
-    const bool timed = profile_mark(st, false);
     int rc = DFM_OK;
     if (which == 1) {
         const long long nb = (g.N + 255) / 256;
@@ -1896,7 +1967,8 @@ int run_fwd(const dfm_sweep_desc *desc, const Launch &L, const void *cur, const 
 size_t fwd_workspace_bytes(const dfm_sweep_desc *desc)
 {
     // blocked maps + the two spill lists + the feature-flag word of the pack pass
-    return std::max(2 * blocked_bytes(desc) + 2 * flag_bytes(desc) + 256, sweep_clt_workspace_bytes(desc));
+    return std::max(2 * blocked_bytes(desc) + 2 * flag_bytes(desc) + row_flag_bytes(desc),
+                    sweep_clt_workspace_bytes(desc));
 }
 
 int check_fwd_args(const dfm_sweep_desc *desc, const void *cur, const void *prev,

@@ -65,10 +65,12 @@ typedef enum dfm_dtype { DFM_F32 = 0, DFM_BF16 = 1 } dfm_dtype;
 DFM_API int dfm_version(void);            /* ABI version, currently 3     */
 DFM_API const char *dfm_last_error(void); /* thread-local, never NULL     */
 
-/* Per-launch device timing of the volume-writing kernel, measured with HIP
- * events recorded on the caller's stream around that kernel only (not the
- * small re-blocking pre-pass).  begin() arms up to max_launches pairs;
- * end() waits for them and returns the summed kernel time and the count. */
+/* Per-call device timing of the plane-sweep build, measured with HIP events
+ * recorded on the caller's stream around EVERYTHING a dfm_plane_sweep_fwd call
+ * launches on the dense path: the re-blocking pack pass, the tile kernel and
+ * the second-chance / direct / patch passes (rounds 1-4 left the pack pass out;
+ * the strided-sweep kernels time their volume-writing kernel).  begin() arms up to
+ * max_launches pairs; end() waits for them and returns the summed time and the count. */
 DFM_API int dfm_profile_begin(int max_launches);
 DFM_API int dfm_profile_end(double *total_ms, int *launches);
 

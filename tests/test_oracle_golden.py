@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import dfm_oracle as orc
+from tests import util
 
 
 def _bits(a):
@@ -40,10 +41,36 @@ def test_build_dfm_cost_bitexact(path):
                              bool(z['flip']), z['crop'], float(z['scale']))
     ref = z['ref_out']
     assert out.shape == ref.shape
+    if 'zero_depth' in path:
+        # the one fixture that reaches non-finite sampling coordinates: torch-CPU gives NaN there, the oracle 0
+        assert util.assert_matches_reference(out, ref) > 0
+        return
     assert np.isfinite(ref).all()
     # value-equal everywhere (treats +0 == -0), and bit-equal
     assert np.array_equal(out, ref)
     assert np.array_equal(_bits(out), _bits(ref))
+
+
+def test_zero_depth_case_reaches_non_finite_coordinates_and_pins_the_deviation():
+    """SURVEY 8c's adversarial case taken to its end: plane 1 of this fixture sits at z = 0 in the previous
+    camera, the reference's projection divides by zero, its grid is +-Inf there, and F.grid_sample on
+    PyTorch-CPU returns NaN for exactly those points (all channels of the prev half); the cur half and the
+    other planes are finite.  The oracle reproduces the reference's grid bit for bit -- Inf included -- and
+    answers those points with +0 (the chosen behaviour: zeros padding, as torch's GPU kernel)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    z = np.load(os.path.join(here, 'plane_sweep_zero_depth.npz'))
+    C, D = z['cur'].shape[1], z['depths'].size
+    ref = z['ref_out'][0]
+    hw = ref.shape[2] * ref.shape[3]
+    bad = ~np.isfinite(z['ref_prev_grid']).all(1)
+    assert bad.sum() == hw and bad.reshape(D, hw)[1].all(), 'every point of plane 1, and only those'
+    assert np.isfinite(z['ref_cur_grid']).all() and np.isfinite(ref[:C]).all()
+    nan = np.isnan(ref[C:])
+    assert np.array_equal(nan, np.broadcast_to(bad.reshape(1, D, *ref.shape[2:]), nan.shape))
+    out = orc.build_dfm_cost(z['cur'], z['prev'], z['depths'], float(z['fsf']), float(z['csf']),
+                             z['P'][None], z['Pinv'][None], z['T'][None], z['img_shape'],
+                             bool(z['flip']), z['crop'], float(z['scale']))[0]
+    assert (out[C:, 1] == 0).all() and np.signbit(out[C:, 1]).sum() == 0
 
 
 def test_behind_camera_case_really_goes_out_of_bounds():

@@ -114,6 +114,10 @@ def test_fp32_bitexact_vs_reference_fixture(pkg, path):
     z = np.load(path)
     out = run_hip(pkg, z['cur'], z['prev'], z['depths'], *fixture_args(z)).cpu().numpy()
     assert out.shape == z['ref_out'].shape
+    if 'zero_depth' in path:
+        # non-finite sampling coordinates: the reference (torch-CPU) gives NaN, the kernels +0 (util's docstring)
+        assert util.assert_matches_reference(out, z['ref_out']) > 0
+        return
     assert np.array_equal(out, z['ref_out'])
     assert np.array_equal(util.bits(out), util.bits(z['ref_out']))
 

@@ -70,3 +70,19 @@ def synthetic_state_dict(module, seed):
             fan_in = v[0].numel()
             out[k] = torch.randn(v.shape, generator=gen) * (2.0 / fan_in) ** 0.5
     return out
+
+
+def assert_matches_reference(out, ref):
+    """A plane-sweep volume against the reference's: bit-equal wherever the reference is finite.  Where the
+    reference is NaN -- F.grid_sample on PyTorch-CPU answers NON-FINITE sampling coordinates (a division by
+    z = 0 in the unguarded projection, utils.py:209) with NaN, its bilinear weights being Inf - Inf -- the
+    oracle and the HIP kernels give exactly +0, what `padding_mode='zeros'` gives every other coordinate
+    outside the map (and what torch's GPU kernel gives).  tests/golden/plane_sweep_zero_depth.npz is the
+    reference-generated fixture that reaches such coordinates; every other fixture is finite everywhere."""
+    out = np.asarray(out, np.float32)
+    ref = np.asarray(ref, np.float32)
+    assert out.shape == ref.shape
+    nan = np.isnan(ref)
+    assert np.array_equal(bits(np.where(nan, np.float32(0), out)), bits(np.where(nan, np.float32(0), ref)))
+    assert np.array_equal(bits(out[nan]), np.zeros(int(nan.sum()), np.uint32)), 'reference NaN <-> exactly +0 here'
+    return int(nan.sum())
