@@ -66,12 +66,31 @@ def _flags_tag(flags):
     return hashlib.sha1(' '.join(flags).encode() + b'|' + HIPCC.encode() + b'|' + ver).hexdigest()[:16]
 
 
-def _verify_walk(obj):
+def _checker():
     import importlib.util
-    spec = importlib.util.spec_from_file_location('verify_walk_asm', os.path.join(ROOT, 'tools', 'verify_walk_asm.py'))
+    spec = importlib.util.spec_from_file_location('verify_async_asm', os.path.join(ROOT, 'tools', 'verify_async_asm.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.check_object(obj)
+    return mod
+
+
+def _verify_walk(obj):
+    return _checker().check_object(obj)
+
+
+class AsyncAsmCheckError(RuntimeError):
+    """this hipcc placed a register copy / use under an in-flight inline-asm LDS read: the kernel would be
+    wrong whenever the LDS answers late (tools/verify_async_asm.py).  The build refuses the object."""
+
+
+def _verify_lds(obj):
+    """every kernel of the object: no register named between an inline-asm ds_read and the counted wait that
+    covers it (the hazard that made round 4's two-taps conv loop run-dependent)"""
+    bad = _checker().check_object_lds(obj)
+    if bad:
+        k, f = next(iter(bad.items()))
+        raise AsyncAsmCheckError('%s: %d kernel(s) fail the LDS-read check, e.g. %s: %s' % (
+            os.path.basename(obj), len(bad), k[:80], f[0][:200]))
 
 
 def walk_kernel_check():
@@ -141,6 +160,7 @@ def _build_locked(force, verbose, debug_hooks, out, jobs):
                               'building plane_sweep_cl.hip with -DDFM_WALK_UNVERIFIED' % findings[0][:120],
                               RuntimeWarning)
                 run(cmd[:1] + ['-DDFM_WALK_UNVERIFIED'] + cmd[1:])
+        _verify_lds(obj + '.tmp')
         os.replace(obj + '.tmp', obj)  # a reader never sees a half-written object
 
     with ThreadPoolExecutor(max_workers=jobs or min(len(todo) or 1, os.cpu_count() or 4)) as pool:

@@ -1,7 +1,8 @@
-"""The depth-walking sweep (csrc/plane_sweep_cl.hip: sweep_cltw_kernel) loads its taps asynchronously from
-inline asm; build.py checks in the machine code of every build that hipcc left those registers alone
-between a load and the wait that covers it (tools/verify_walk_asm.py), and builds without the kernel when
-it did not.  Here: the shipped build verifies, and the checker catches what it is there to catch."""
+"""Registers written behind the compiler's back: the depth-walking sweep's masked buffer loads and the
+inline-asm `ds_read_b128` fragments of the MFMA / tile kernels.  build.py checks in the machine code of
+every build that hipcc left those registers alone between a load and the wait that covers it
+(tools/verify_async_asm.py).  Here: the shipped build verifies, and the checker catches what it is there to
+catch -- including the register copy that made round 4's two-taps conv loop run-dependent."""
 import importlib
 import importlib.util
 import os
@@ -11,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _checker():
-    spec = importlib.util.spec_from_file_location('verify_walk_asm', os.path.join(ROOT, 'tools', 'verify_walk_asm.py'))
+    spec = importlib.util.spec_from_file_location('verify_async_asm', os.path.join(ROOT, 'tools', 'verify_async_asm.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -61,3 +62,34 @@ def test_checker_flags_a_copy_a_spill_and_a_missing_wait():
     assert chk.check('\n'.join(weak))
     # a kernel that is not there
     assert chk.check(text, kernel='no_such_kernel')
+
+
+def test_every_shipped_object_passes_the_lds_read_check():
+    import glob
+    build = importlib.import_module('depth-from-motion_amd.build')
+    build.build_hip()
+    chk = _checker()
+    objs = sorted(glob.glob(os.path.join(build.LIB_DIR, 'obj', '*.o')))
+    assert len(objs) >= 13
+    for obj in objs:
+        assert chk.check_object_lds(obj) == {}, obj
+
+
+def test_lds_check_flags_the_copy_that_broke_the_two_taps_conv_loop():
+    """Round 4's `step(wa, wb); step(wb, wa)` variant of conv3d_g_kernel gave run-dependent results: its two
+    loop exits met in front of the last tap and hipcc resolved the phi of the IN-FLIGHT activation fragment
+    with a register copy placed before the `s_waitcnt lgkmcnt` (v_mov_b64 v[120:121], v[84:85]; the MFMAs then
+    read v[120:123]).  Re-create that instruction in the shipped kernel's disassembly: the checker must object."""
+    build = importlib.import_module('depth-from-motion_amd.build')
+    build.build_hip()
+    chk = _checker()
+    text = chk.disassemble_object(os.path.join(build.LIB_DIR, 'obj', 'conv3d_g.o'))
+    ks = chk.kernels(text)
+    name = next(k for k in ks if 'conv3d_g_kernelILi2ELi1ELb0' in k)
+    ins = list(ks[name])
+    assert chk.check_lds(ins) == []
+    i = next(i for i, (a, mn, ops) in enumerate(ins) if mn == 'ds_read_b128')
+    lo = int(re.search(r'v\[(\d+):', ins[i][2]).group(1))
+    ins.insert(i + 1, (ins[i][0], 'v_mov_b64_e32', 'v[200:201], v[%d:%d]' % (lo, lo + 1)))
+    found = chk.check_lds(ins)
+    assert found and 'v_mov_b64_e32' in found[0] and 'in flight' in found[0]
