@@ -112,7 +112,22 @@ __global__ void conv3d_g_pack_kernel(const TW *__restrict__ w, int rows, int kk,
 // acc_in == out: those two parameters are not __restrict__ there)
 typedef const bf16_t *__restrict__ g_res_restrict_t;
 typedef bf16_t *__restrict__ g_out_restrict_t;
-template <int CW, int PFW, bool F32 = false>
+// FAST (round 5): the body for plain correlations whose w axis has the full 3-tap kernel (every convolution of the
+// voxel necks and the stride-1 / stride-2 hourglass convolutions; not the transposed ones).  Same tiling, staging
+// and epilogue; the tap loop is rebuilt around what the counters of round 2 said the generic loop spends its
+// issue slots on (5.2 VALU + 3.4 SALU per MFMA: fragment addresses re-derived per tap, tap bookkeeping, 64-bit
+// weight pointers, the copy of the next tap's weights into place):
+//   * the LDS swizzle is a function of the pixel's block COLUMN, so a tap row (jd, jh) moves a fragment's
+//     address by a workgroup-uniform constant: 3 addresses per pixel fragment are computed once, a read is
+//     one v_add (k-step 0) or one v_xor (k-step 1);
+//   * the taps are walked as rows of 3 (6 k-steps, unrolled): row offsets are a handful of scalar operations
+//     per 6 * PFW * CW MFMAs, no per-tap counters or selects;
+//   * weight fragments rotate through THREE register buffers with the row's period (6 k-steps = 2 x 3), loaded
+//     two k-steps ahead through a uniform base + lane offset: no copies, no per-lane pointer arithmetic;
+//   * all rows but the last run in a do-while (at least two rows), the last row is peeled and prefetches
+//     nothing: no branch joins while an LDS read is in flight except the loop header's own back edge
+//     (tools/verify_async_asm.py checks the build).
+template <int CW, int PFW, bool F32 = false, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
     GGeom g, const bf16_t *__restrict__ x, const uint4 *__restrict__ wfrag,
     const float *__restrict__ scale, const float *__restrict__ shift,
@@ -148,17 +163,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
     const int chunk_bytes = g.nrounds * 4096;
 
     // stage the halo block of one 32-channel chunk into LDS buffer `buf`: piece q = 16 bytes, LDS
-    // position q * 16 holds slot (q & 3) ^ swizzle of block pixel q >> 2 (zero page outside the volume)
+    // position q * 16 holds slot (q & 3) ^ swizzle of block pixel q >> 2 (zero page outside the volume);
+    // swizzle(pixel) = (block column >> 2) & 3
     auto stage = [&](int chunk, int buf) {
         const unsigned char *src = xs + chunk * 64;
         unsigned char *dst = blk + buf * chunk_bytes + wave * 1024;
         for (int r = 0; r < g.nrounds; ++r) {
             const int q = r * 256 + tid;
-            const int p = q >> 2, sl = (q & 3) ^ ((p >> 2) & 3);
+            const int p = q >> 2;
             const int bd = (int)(((float)p + 0.5f) * g.r_bhw);
             const int rem = p - bd * BHW;
             const int bh = (int)(((float)rem + 0.5f) * g.r_bw);
             const int bw = rem - bh * BW;
+            const int sl = (q & 3) ^ ((bw >> 2) & 3);  // swizzle by block column: tap rows shift addresses uniformly
             const int d = bd0 + bd, h = bh0 + bh, w = bw0 + bw;
             const bool ok = p < g.block_px && (unsigned)d < (unsigned)g.d.in && (unsigned)h < (unsigned)g.h.in &&
                             (unsigned)w < (unsigned)g.w.in;
@@ -177,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
 
     // ---- this lane's pixels: PFW fragments of 32 consecutive tile positions per wave -----------
     int base_bp[PFW], tpos[PFW];  // block pixel of tap (0,0,0); packed tile coordinates
+    int bwb[PFW];                 // ... and its block column (the swizzle's argument)
     {
         const int sd = g.d.up ? 1 : g.d.stride, sh = g.h.up ? 1 : g.h.stride, sw = g.w.up ? 1 : g.w.stride;
 #pragma unroll
@@ -185,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
             const int tw = i % g.w.tile, i2 = i / g.w.tile;
             const int th = i2 % g.h.tile, td = i2 / g.h.tile;
             base_bp[f] = (td * sd * BH + th * sh) * BW + tw * sw;
+            bwb[f] = tw * sw;
             tpos[f] = (td << 20) | (th << 10) | tw;  // tile extents <= 512
         }
     }
@@ -209,7 +228,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
                   ntd = g.d.up ? 1 + pcd : (g.d.k1 ? 1 : 3);
         const int ntaps = ntd * nth * ntw;
         int jd = 0, jh = 0, jw = 0;
+        int jwc = 0;  // the current tap's column shift inside the block (its jw counter)
         auto tap_cur = [&](int &wt, int &off) {
+            jwc = jw;
             // correlation axis: k = j at offset j; up axis: even class -> k 1 @ +0; odd -> k 2 @ +0, k 0 @ +1
             const int kw = g.w.up ? (pcw ? (jw ? 0 : 2) : 1) : (g.w.k1 ? 1 : jw);
             const int kh = g.h.up ? (pch ? (jh ? 0 : 2) : 1) : (g.h.k1 ? 1 : jh);
@@ -232,6 +253,122 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[f][c][i] = 0.0f;
 
+        if constexpr (FAST) {
+            // ---- the row-walking tap loop (see the template's comment) ----------------------------------
+            uint32_t A[PFW][3];  // LDS address of the fragment's pixel at column shift jw, row (0, 0), k-step 0
+#pragma unroll
+            for (int f = 0; f < PFW; ++f)
+#pragma unroll
+                for (int j3 = 0; j3 < 3; ++j3)
+                    A[f][j3] = lds0 + (uint32_t)(base_bp[f] + j3) * 64u +
+                               ((((uint32_t)half) ^ (((uint32_t)(bwb[f] + j3) >> 2) & 3u)) << 4);
+            const int nth_f = g.h.k1 ? 1 : 3;
+            const int nrows = (g.d.k1 ? 1 : 3) * nth_f;  // 9 (3-D) or 3 (a 2-D convolution as a depth-1 volume)
+            const uint32_t lane16 = (uint32_t)lane * 16u;
+            constexpr int KSB = CW * 1024;  // bytes of one (tap, k-step): CW fragments of 64 lanes x 16 B
+            // LDS byte offset / weight byte offset of tap row r = (jd, jh)
+            auto row_lds = [&](int r) -> uint32_t {
+                const int rd = r / nth_f, rh = r - rd * nth_f;
+                return (uint32_t)((rd * BH + rh) * BW) * 64u;
+            };
+            auto row_wt = [&](int r) -> uint32_t {
+                const int rd = r / nth_f, rh = r - rd * nth_f;
+                const int kd = g.d.k1 ? 1 : rd, kh = g.h.k1 ? 1 : rh;
+                return (uint32_t)((kd * 3 + kh) * 3) * 2u * KSB;
+            };
+            for (int chunk = 0; chunk < g.nchunk; ++chunk) {
+                if (chunk > 0) __syncthreads();  // every wave is done reading the previous chunk's block
+                stage(chunk, 0);
+                const char *wchunk = (const char *)(wfrag + (size_t)(ct * g.nchunk + chunk) * 27 * 2 * CW * 64);
+                bf16x8_t w[3][CW];   // weight fragments of k-steps s, s + 1, s + 2 (mod 3)
+                u32x4_t q[2][PFW];   // activation fragments of k-steps s, s + 1 (mod 2)
+                uint32_t addr[PFW];  // the k-step-0 addresses of the tap being read (k-step 1 = ^ 32)
+                auto wld = [&](const char *wrow, int t, bf16x8_t (&dst)[CW]) {  // k-step t of a row: tap t >> 1
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) {
+                        const uint4 v = *(const uint4 *)(wrow + (t * CW + c) * 1024 + lane16);
+                        __builtin_memcpy(&dst[c], &v, 16);
+                    }
+                };
+                auto rd0 = [&](int j3, uint32_t lrow, u32x4_t (&dst)[PFW]) {
+#pragma unroll
+                    for (int f = 0; f < PFW; ++f) {
+                        addr[f] = A[f][j3] + lrow;
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(dst[f]) : "v"(addr[f]));
+                    }
+                };
+                auto rd1 = [&](u32x4_t (&dst)[PFW]) {
+#pragma unroll
+                    for (int f = 0; f < PFW; ++f) {
+                        const uint32_t a = addr[f] ^ 32u;
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(dst[f]) : "v"(a));
+                    }
+                };
+#define G_WAIT(Q, N)                                                                                         \
+                do {                                                                                         \
+                    if constexpr (PFW == 1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]));           \
+                    if constexpr (PFW == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1])); \
+                    if constexpr (PFW == 3) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2])); \
+                    if constexpr (PFW == 4) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3])); \
+                } while (0)
+#define G_WAIT_PFW(Q)                                                                                        \
+                do {                                                                                         \
+                    if constexpr (PFW == 1) G_WAIT(Q, 1);                                                    \
+                    if constexpr (PFW == 2) G_WAIT(Q, 2);                                                    \
+                    if constexpr (PFW == 3) G_WAIT(Q, 3);                                                    \
+                    if constexpr (PFW == 4) G_WAIT(Q, 4);                                                    \
+                } while (0)
+                // one tap row: 6 k-steps.  Before step s runs, the reads of step s + 1 and the weights of
+                // step s + 2 are requested (the next row's first steps at the end of a row, unless LAST)
+                auto row = [&](auto last_c, uint32_t lcur, uint32_t lnext, const char *wcur, const char *wnext) {
+                    constexpr bool LAST = decltype(last_c)::value;
+#pragma unroll
+                    for (int st = 0; st < 6; ++st) {
+                        asm volatile("" ::: "memory");  // keep the weight loads where they are written
+                        bool reads_ahead = true;
+                        if (st + 1 < 6) {
+                            if ((st + 1) & 1) rd1(q[(st + 1) & 1]);
+                            else rd0((st + 1) >> 1, lcur, q[(st + 1) & 1]);
+                        } else if constexpr (!LAST) {
+                            rd0(0, lnext, q[0]);
+                        } else {
+                            reads_ahead = false;
+                        }
+                        if (st + 2 < 6) wld(wcur, st + 2, w[(st + 2) % 3]);
+                        else if constexpr (!LAST) wld(wnext, st + 2 - 6, w[(st + 2) % 3]);
+                        if (reads_ahead) G_WAIT_PFW(q[st & 1]);
+                        else G_WAIT(q[st & 1], 0);
+#pragma unroll
+                        for (int f = 0; f < PFW; ++f) {
+                            bf16x8_t xf;
+                            __builtin_memcpy(&xf, &q[st & 1][f], 16);
+#pragma unroll
+                            for (int c = 0; c < CW; ++c)
+                                acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[st % 3][c], xf, acc[f][c], 0, 0, 0);
+                        }
+                    }
+                };
+                // weights of the first two k-steps travel while the block lands
+                uint32_t lcur = row_lds(0);
+                const char *wcur = wchunk + row_wt(0);
+                wld(wcur, 0, w[0]);
+                wld(wcur, 1, w[1]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();  // the block has landed
+                rd0(0, lcur, q[0]);
+                int r = 0;
+                do {  // rows 0 .. nrows - 2 (nrows >= 3)
+                    const uint32_t lnext = row_lds(r + 1);
+                    const char *wnext = wchunk + row_wt(r + 1);
+                    row(std::false_type{}, lcur, lnext, wcur, wnext);
+                    lcur = lnext;
+                    wcur = wnext;
+                } while (++r < nrows - 1);
+                row(std::true_type{}, lcur, 0u, wcur, wcur);
+#undef G_WAIT
+#undef G_WAIT_PFW
+            }
+        } else {
         for (int chunk = 0; chunk < g.nchunk; ++chunk) {
             const uint32_t ldsb = lds0 + (g.resident ? chunk * chunk_bytes : 0);
             // one round of ds_read_b128: the PFW B fragments of a tap.  k-step 0 computes the swizzled
@@ -242,7 +379,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
 #pragma unroll
                 for (int f = 0; f < PFW; ++f) {
                     const int bp = base_bp[f] + off;
-                    uint32_t a = ldsb + (uint32_t)bp * 64u + ((((uint32_t)half) ^ (((uint32_t)bp >> 2) & 3u)) << 4);
+                    uint32_t a = ldsb + (uint32_t)bp * 64u +
+                                 ((((uint32_t)half) ^ (((uint32_t)(bwb[f] + jwc) >> 2) & 3u)) << 4);
 #ifdef DFM_DEBUG_HOOKS
                     if (g.ablate & 4) a = ldsb + ((uint32_t)(off & 15) << 10) + lane * 16;
 #endif
@@ -347,6 +485,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
 #undef G_WAIT_PFW
         }
 
+        }
         // ---- epilogue: lane = pixel (l32) x 4 groups of 4 consecutive channels per channel fragment ----
         auto epilogue = [&](auto has_scale, auto has_res) {
 #pragma unroll
@@ -613,7 +752,27 @@ static int conv3d_g_launch(const dfm_conv3d_desc *desc, const void *x, const voi
     dim3 grid((unsigned)tiles, pl.g.cout_tiles * pl.classes, desc->n);
     hipStream_t st = (hipStream_t)stream;
     const int lds = (int)pl.lds;
-#define G_LAUNCH(CW_, PFW_)                                                                              \
+    // the row-walking body: plain correlations (no transposed axis) with the 3-tap kernel along w and at least
+    // along one of d, h (DFM_CONV_GENERIC=1 pins the generic body: A/B runs)
+    static const bool pin_generic = getenv("DFM_CONV_GENERIC") != nullptr;
+    const bool fast = !pin_generic && !pl.g.resident && !pl.g.d.up && !pl.g.h.up && !pl.g.w.up && !pl.g.w.k1 &&
+                      !(pl.g.d.k1 && pl.g.h.k1);
+#define G_LAUNCH1(CW_, PFW_, F32_, FAST_)                                                            \
+    do {                                                                                             \
+        const int rc_ = ensure_dynamic_lds((const void *)conv3d_g_kernel<CW_, PFW_, F32_, FAST_>, 160 * 1024); \
+        if (rc_ != DFM_OK) return rc_;                                                               \
+        hipLaunchKernelGGL((conv3d_g_kernel<CW_, PFW_, F32_, FAST_>), grid, dim3(256), lds, st, pl.g, \
+                           (const bf16_t *)x, wfrag, scale, shift, (const bf16_t *)residual,         \
+                           (bf16_t *)out, zero);                                                     \
+    } while (0)
+#define G_LAUNCH(CW_, PFW_)                                                                          \
+    do {                                                                                             \
+        if (f32 && fast && CW_ * PFW_ < 8) G_LAUNCH1(CW_, PFW_, true, true); /* (the 128-accumulator fp32 form spills) */ \
+        else if (f32) G_LAUNCH1(CW_, PFW_, true, false);                                             \
+        else if (fast) G_LAUNCH1(CW_, PFW_, false, true);                                            \
+        else G_LAUNCH1(CW_, PFW_, false, false);                                                     \
+    } while (0)
+#define G_LAUNCH_OLD(CW_, PFW_)                                                                      \
     do {                                                                                             \
         if (f32) {                                                                                   \
             const int rc_ = ensure_dynamic_lds((const void *)conv3d_g_kernel<CW_, PFW_, true>, 160 * 1024); \
@@ -645,6 +804,8 @@ static int conv3d_g_launch(const dfm_conv3d_desc *desc, const void *x, const voi
         }
     }
 #undef G_LAUNCH
+#undef G_LAUNCH1
+#undef G_LAUNCH_OLD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
