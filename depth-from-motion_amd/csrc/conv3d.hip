@@ -143,10 +143,18 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
     // LDS byte offset (inside a slab) of this lane's pixel in slab row (r0 + rr), before kw / ks
     const int r0 = wave * 4;
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;  // LDS offset
-    auto frag_addr = [&](int slot, int rr, int kw, int ks) -> uint32_t {
-        const int pix = (r0 + rr) * CV_SW + l32 + kw;
-        return ring_base + slot * CV_SLAB_BYTES + pix * 64 + ((((2 * ks + half) ^ ((pix >> 2) & 3))) << 4);
-    };
+    // the 18 k-step-0 fragment addresses of a wave (6 slab rows x 3 column shifts) inside ring slot 0, computed
+    // ONCE: a read is this + the slot's (workgroup-uniform) base, k-step 1 the same ^ 32 (slot ^ 2).  Re-deriving
+    // pix / the swizzle per read cost 3 VALU operations per MFMA (round-5 counters: 3.8 VALU per MFMA in this
+    // kernel, one wave per SIMD -- over the ~5 issue slots an MFMA hides)
+    uint32_t fa[6][3];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int pix = (r0 + rr) * CV_SW + l32 + kw;
+            fa[rr][kw] = ring_base + pix * 64 + (((half ^ ((pix >> 2) & 3))) << 4);
+        }
 
     // prologue: slabs d0-1, d0, d0+1
     stage(d0 - 1);
@@ -189,9 +197,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
         auto issue = [&](int step, u32x4_t (&dst)[6]) {
             const int kd = step / 6, kw = (step / 2) % 3, ks = step & 1;
             const int slot = (d - d0 + kd) & (CV_RING - 1);  // depth d-1+kd
+            const uint32_t sbase = (uint32_t)slot * CV_SLAB_BYTES;  // uniform
 #pragma unroll
             for (int rr = 0; rr < 6; ++rr) {
-                const uint32_t a = frag_addr(slot, rr, kw, ks);
+                const uint32_t a0 = fa[rr][kw] + sbase;
+                const uint32_t a = ks ? (a0 ^ 32u) : a0;
                 asm volatile("ds_read_b128 %0, %1" : "=v"(dst[rr]) : "v"(a));
             }
         };
