@@ -451,15 +451,27 @@ def secondary(args, pkg, dev, job, emit=True):
         # the tile kernel -- what plane_sweep_backward() does for them; everything else dfm_plane_sweep_bwd
         walk = [w['csf'] >= 1.5 and tdt == torch.float32]
         prev_only = sweep.make_opts(kernel=8)
+        # ... and, since round 5, the prev map from the gather kernel (a lane per map pixel, stores instead of
+        # atomics: csrc/plane_sweep_bwd_gather.hip); DFM_NO_PREV_GATHER=1 pins the tile kernel (A/B)
+        gather = [walk[0] and os.environ.get('DFM_NO_PREV_GATHER') != '1']
+        gws_bytes = lib.dfm_plane_sweep_bwd_prev_gather_workspace_bytes(ctypes.byref(desc))
+        gws = torch.empty(max(int(gws_bytes), 256), dtype=torch.uint8, device=dev)
 
         def step():
             g_cur.zero_()
-            g_prev.zero_()
+            if not gather[0]:
+                g_prev.zero_()    # (the gather kernel stores the prev map: no zero fill)
             a = (ctypes.byref(desc), gout.data_ptr(), depths.data_ptr(), P.data_ptr(), Pinv.data_ptr(), T.data_ptr())
             st = torch.cuda.current_stream(dev).cuda_stream
             if walk[0]:
                 rc = lib.dfm_plane_sweep_bwd_cur_nhwc(*a, g_cur.data_ptr(), st)
                 if rc == 0:
+                    if gather[0]:
+                        rc = lib.dfm_plane_sweep_bwd_prev_gather(*a, g_prev.data_ptr(), gws.data_ptr(), gws_bytes, st)
+                        if rc == 0:
+                            return
+                        gather[0] = False
+                        g_prev.zero_()
                     pkg._capi.check(lib.dfm_plane_sweep_bwd_opts(*a, g_prev.data_ptr(), g_prev.data_ptr(), st,
                                                                  ctypes.byref(prev_only)))
                     return
@@ -560,6 +572,7 @@ def secondary(args, pkg, dev, job, emit=True):
         # 1 scatter, 5 LDS-atomic tiles, 6 matrix product
         line['config']['bwd_kernel'] = int(pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel())
         line['config']['cur_map_window_kernel'] = bool(walk[0])
+        line['config']['prev_map_gather_kernel'] = bool(gather[0])
     if rank == 0 and emit:
         print(json.dumps(line), flush=True)
     if emit and torch.distributed.is_available() and torch.distributed.is_initialized() and world == 1:

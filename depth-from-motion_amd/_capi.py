@@ -33,6 +33,8 @@ EXPORTS = (
     'dfm_plane_sweep_bwd_opts',
     'dfm_plane_sweep_bwd_channels_last',
     'dfm_plane_sweep_bwd_cur_nhwc',
+    'dfm_plane_sweep_bwd_prev_gather_workspace_bytes',
+    'dfm_plane_sweep_bwd_prev_gather',
     'dfm_plane_sweep_autotune',
     'dfm_plane_sweep_tuning',
     'dfm_plane_sweep_reset_tuning',
@@ -269,6 +271,10 @@ def lib():
     h.dfm_plane_sweep_bwd_channels_last.argtypes = [dp, vp, fp, fp, fp, fp, fp, fp, vp, sz, vp]
     h.dfm_plane_sweep_bwd_cur_nhwc.restype = ctypes.c_int
     h.dfm_plane_sweep_bwd_cur_nhwc.argtypes = [dp, vp, fp, fp, fp, fp, fp, vp]
+    h.dfm_plane_sweep_bwd_prev_gather_workspace_bytes.restype = ctypes.c_size_t
+    h.dfm_plane_sweep_bwd_prev_gather_workspace_bytes.argtypes = [dp]
+    h.dfm_plane_sweep_bwd_prev_gather.restype = ctypes.c_int
+    h.dfm_plane_sweep_bwd_prev_gather.argtypes = [dp, vp, fp, fp, fp, fp, fp, vp, sz, vp]
     h.dfm_plane_sweep_autotune.restype = ctypes.c_int
     h.dfm_plane_sweep_autotune.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp, op]
     h.dfm_plane_sweep_tuning.restype = ctypes.c_int

@@ -9,6 +9,7 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
     centre) give 0 like torch's GPU grid_sample; torch's CPU kernel gives NaN.
 """
 import contextlib
+import os
 import ctypes
 import threading
 
@@ -169,6 +170,20 @@ def launch_options(**kw):
         yield _tls.opts
     finally:
         _tls.opts = prev
+
+
+# strided fp32 sweeps: the prev map's gradient by the gather kernel (True) or the LDS-atomic tile kernel (A/B runs,
+# tests: ``prev_gather(False)``)
+_PREV_GATHER = {'on': os.environ.get('DFM_NO_PREV_GATHER') != '1'}
+
+
+@contextlib.contextmanager
+def prev_gather(on):
+    prev, _PREV_GATHER['on'] = _PREV_GATHER['on'], bool(on)
+    try:
+        yield
+    finally:
+        _PREV_GATHER['on'] = prev
 
 
 _bwd_kernel = None  # process-wide (autograd runs backward functions on its own threads)
@@ -361,12 +376,24 @@ def plane_sweep_backward(desc, grad_out, depths, P, Pinv, T):
         # necks' backward wants); the prev map stays with the LDS-atomic tile kernel
         g_cur = torch.zeros((desc.batch, desc.h_in, desc.w_in, desc.channels), dtype=torch.float32,
                             device=device).permute(0, 3, 1, 2)
-        g_prev = torch.zeros(shape, dtype=torch.float32, device=device)
-        prev_only = make_opts(kernel=8)
+        g_prev = torch.empty(shape, dtype=torch.float32, device=device)
         with torch.cuda.device(device):
-            rc = lib.dfm_plane_sweep_bwd_opts(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P), _ptr(Pinv),
-                                              _ptr(T), _ptr(g_prev), _ptr(g_prev), _stream_ptr(device),
-                                              ctypes.byref(prev_only))
+            # the prev map: a lane per map pixel gathers its contributions plane by plane through the planes'
+            # inverse homographies and STORES the sums -- no zero-filled map (csrc/plane_sweep_bwd_gather.hip;
+            # round 5) -- the LDS-atomic tile kernel (kernel 8, prev map only) where that form does not apply
+            rc = _capi.DFM_ERR_UNSUPPORTED
+            if _PREV_GATHER['on']:
+                nb = lib.dfm_plane_sweep_bwd_prev_gather_workspace_bytes(ctypes.byref(desc))
+                gws = _Workspace.get(device, nb)
+                rc = lib.dfm_plane_sweep_bwd_prev_gather(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P),
+                                                         _ptr(Pinv), _ptr(T), _ptr(g_prev), _ptr(gws), nb,
+                                                         _stream_ptr(device))
+            if rc == _capi.DFM_ERR_UNSUPPORTED:
+                g_prev.zero_()
+                prev_only = make_opts(kernel=8)
+                rc = lib.dfm_plane_sweep_bwd_opts(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P),
+                                                  _ptr(Pinv), _ptr(T), _ptr(g_prev), _ptr(g_prev), _stream_ptr(device),
+                                                  ctypes.byref(prev_only))
             if rc == 0:
                 rc = lib.dfm_plane_sweep_bwd_cur_nhwc(ctypes.byref(desc), _ptr(grad_out), _ptr(depths), _ptr(P),
                                                       _ptr(Pinv), _ptr(T), _ptr(g_cur), _stream_ptr(device))

@@ -300,6 +300,22 @@ DFM_API int dfm_plane_sweep_bwd_channels_last(const dfm_sweep_desc *desc, const 
 DFM_API int dfm_plane_sweep_bwd_cur_nhwc(const dfm_sweep_desc *desc, const void *grad_out, const float *depths,
                                          const float *cam2img, const float *cam2img_inv,
                                          const float *cur2prev, float *grad_cur, void *stream);
+/* Backward of a STRIDED fp32 sweep, PREV map only, as a gather (csrc/plane_sweep_bwd_gather.hip): a lane owns
+ * a map pixel, walks the depth planes, finds through the plane's inverse homography (fitted on the device from
+ * the forward map's own values at the lattice corners, fp64) the lattice points whose footprint can hold the
+ * pixel, confirms each with the forward's fp32 arithmetic, gathers the 32 channels of the gradient volume and
+ * STORES the sums: grad_prev is (B, C, H, W) fp32 in the reference layout, overwritten (planes the fit cannot
+ * vouch for -- behind the camera, lattice step under ~1.1 pixels -- are added with atomics by a second kernel
+ * of the same call).  grad_out: (B, 2C, D, h_out, w_out) fp32, of which the last C channels are read.
+ * workspace: >= dfm_plane_sweep_bwd_prev_gather_workspace_bytes(desc) (12 floats per sample and plane).
+ * DFM_ERR_UNSUPPORTED unless fp32, channels % 32 == 0 and cost_sample_factor >= 2.  Replaces autograd of the
+ * second F.grid_sample call of build_dfm_cost (reference dfm_backbone.py:304-311); reports 9 through
+ * dfm_plane_sweep_bwd_last_kernel. */
+DFM_API size_t dfm_plane_sweep_bwd_prev_gather_workspace_bytes(const dfm_sweep_desc *desc);
+DFM_API int dfm_plane_sweep_bwd_prev_gather(const dfm_sweep_desc *desc, const void *grad_out, const float *depths,
+                                            const float *cam2img, const float *cam2img_inv,
+                                            const float *cur2prev, float *grad_prev, void *workspace,
+                                            size_t workspace_bytes, void *stream);
 /* Times the candidate launch shapes / workgroup orders of the LDS-staged kernel with the caller's
  * own arguments (a few launches per candidate; SYNCHRONOUS, `out` is overwritten with valid
  * results) and caches the fastest for this (device, problem shape); later dfm_plane_sweep_fwd

@@ -110,7 +110,7 @@ def test_walk_backward_matches_torch_cpu_autograd(pkg, B, C, H, W, D, t_z):
     (test_plane_sweep_gpu._check_backward's bar), and the kernel the call took"""
     from tests.test_plane_sweep_gpu import _check_backward
     _check_backward(pkg, B, C, H, W, D, 1, 4, (0, 0), seed=D + C, img_shape=(375, 1242), t_z=t_z)
-    assert pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel() == 5  # (the prev map: tile kernel, prev only)
+    assert pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel() == 9  # (the prev map: the gather kernel of round 5)
 
 
 def test_walk_backward_overlapping_windows(pkg):
@@ -187,3 +187,87 @@ def test_walk_backward_raw_call_returns_a_pixel_major_cur_gradient(pkg):
     assert t_cur.is_contiguous()
     assert torch.allclose(g_cur, t_cur, rtol=1e-5, atol=1e-5 * float(t_cur.abs().max()))
     assert torch.equal(g_prev, t_prev) or torch.allclose(g_prev, t_prev, rtol=1e-5, atol=1e-6)
+
+
+# ---- backward of strided fp32 sweeps, PREV map: a lane per map pixel gathers through the planes' inverse
+# ---- homographies (dfm_plane_sweep_bwd_prev_gather, csrc/plane_sweep_bwd_gather.hip) ---------------------------
+
+def _prev_grads(pkg, cur, prev, gout, args, gather):
+    sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+    dev = torch.device('cuda:0')
+    c = torch.from_numpy(cur).to(dev).requires_grad_(True)
+    p = torch.from_numpy(prev).to(dev).requires_grad_(True)
+    with sweep.prev_gather(gather):
+        pkg.build_dfm_cost(c, p, *args).backward(gout)
+    torch.cuda.synchronize()
+    return c.grad, p.grad, pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel()
+
+
+@pytest.mark.parametrize('csf,flip,crop,scale,t_z', [(4, False, (0, 55), 1.0, None), (4, True, (7, 55), 0.97, None),
+                                                     (2, False, (0, 0), 1.0, None), (4, False, (0, 0), 1.0, -6.0),
+                                                     (8, False, (0, 0), 1.03, 1.5)])
+def test_prev_gather_equals_the_tile_kernel(pkg, csf, flip, crop, scale, t_z):
+    """the same (point, tap, weight) set summed in another order: gather (stores) against the LDS-atomic tile kernel
+    (atomics), augmentation and strong forward / backward motion included; cur gradients are the same call's"""
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(17 + csf)
+    B, C, H, W, D = 2, 32, 64, 256, 11
+    T = util.random_poses(B, seed=5)
+    if t_z is not None:
+        T[:, 2, 3] = t_z
+    args = (torch.from_numpy(util.depth_planes(D)).to(dev), 1, csf, torch.from_numpy(np.stack([util.KITTI_P2] * B)),
+            torch.from_numpy(T), (375, 1242), flip, crop, scale)
+    cur = rng.randn(B, C, H, W).astype(np.float32)
+    prev = rng.randn(B, C, H, W).astype(np.float32)
+    ho, wo = int(round(H / csf)), int(round(W / csf))
+    gout = torch.from_numpy(rng.randn(B, 2 * C, D, ho, wo).astype(np.float32)).to(dev)
+    gc1, gp1, k1 = _prev_grads(pkg, cur, prev, gout, args, True)
+    gc0, gp0, k0 = _prev_grads(pkg, cur, prev, gout, args, False)
+    assert (k1, k0) == (9, 5)
+    # (the cur map's window kernel flushes with atomics: at csf = 2 neighbouring windows overlap and the order varies)
+    assert torch.allclose(gc1, gc0, rtol=1e-5, atol=2e-6 * float(gc0.abs().max()))
+    assert float(gp0.abs().max()) > 0
+    diff = (gp1 - gp0).abs()
+    bar = 1e-5 * gp0.abs() + 2e-6 * float(gp0.abs().max())
+    assert bool((diff <= bar).all()), (
+        f'max |diff| {float(diff.max()):.3e} at {np.unravel_index(int(diff.argmax()), diff.shape)}, '
+        f'{int((diff > bar).sum())} of {diff.numel()} over the bar, max |g| {float(gp0.abs().max()):.3e}')
+
+
+def test_prev_gather_planes_without_an_inverse_are_scattered(pkg):
+    """a plane at z = 0 in the previous camera (non-finite sample positions: nothing to add) and a plane right
+    behind it (mirrored, finite, huge coordinates at the corners): the fit does not vouch for them, the second
+    kernel of the call scatters what they contribute; the other planes are gathered.  Against the tile kernel."""
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(2)
+    B, C, H, W, D = 1, 32, 64, 256, 6
+    depths = util.depth_planes(D)
+    P = np.array([[720.0, 0, 608.0, 0], [0, 720.0, 176.0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    T = np.eye(4, dtype=np.float32)[None].copy()
+    T[0, 2, 3] = -float(depths[1])           # plane 1 lands at z = 0, plane 0 behind the camera
+    T[0, 0, 3] = 0.3
+    args = (torch.from_numpy(depths).to(dev), 1, 4, torch.from_numpy(P[None]), torch.from_numpy(T), (375, 1242))
+    cur = rng.randn(B, C, H, W).astype(np.float32)
+    prev = rng.randn(B, C, H, W).astype(np.float32)
+    gout = torch.from_numpy(rng.randn(B, 2 * C, D, H // 4, W // 4).astype(np.float32)).to(dev)
+    _, gp1, k1 = _prev_grads(pkg, cur, prev, gout, args, True)
+    _, gp0, k0 = _prev_grads(pkg, cur, prev, gout, args, False)
+    assert (k1, k0) == (9, 5) and torch.isfinite(gp1).all()
+    assert torch.allclose(gp1, gp0, rtol=1e-5, atol=2e-6 * float(gp0.abs().max()))
+
+
+def test_prev_gather_propagates_nonfinite_gradients_like_the_scatter(pkg):
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(4)
+    C, H, W, D = 32, 32, 128, 4
+    args = (torch.from_numpy(util.depth_planes(D)).to(dev), 1, 4, torch.from_numpy(util.KITTI_P2[None]),
+            torch.from_numpy(util.random_poses(1, seed=1)), (375, 1242))
+    cur = rng.randn(1, C, H, W).astype(np.float32)
+    prev = rng.randn(1, C, H, W).astype(np.float32)
+    g = torch.zeros(1, 2 * C, D, H // 4, W // 4, device=dev)
+    g[0, C + 3, 1, 4, 16] = float('inf')    # (a lattice point in the middle of the map: its taps are in bounds)
+    _, gp1, _ = _prev_grads(pkg, cur, prev, g, args, True)
+    _, gp0, _ = _prev_grads(pkg, cur, prev, g, args, False)
+    assert not torch.isfinite(gp0).all(), 'the poisoned point must reach the map in the scatter kernel'
+    assert torch.equal(torch.isfinite(gp1), torch.isfinite(gp0))
+    assert torch.equal(torch.isnan(gp1), torch.isnan(gp0))
