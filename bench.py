@@ -104,7 +104,7 @@ KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0
                      [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
 
 # secondary workloads (other rows of SURVEY.md 8a), reported with the same JSON shape
-SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd_kitti', 'voxel_sample', 'voxel_sample_bwd',
+SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd_kitti', 'sweep_bwd_kitti_cl', 'voxel_sample', 'voxel_sample_bwd',
              'backbone', 'backbone_train', 'neck', 'dfm_neck',
              # the same rows in the layout the bf16 NDHWC pipeline hands them (channels-last sources
              # sampled in place, channels-last results for the MFMA convolutions that follow)
@@ -430,6 +430,27 @@ def secondary(args, pkg, dev, job, emit=True):
         nbytes = B * esz * (72 * 80 * 320 + 2 * 288 * 320 * 1280 + 320 * 1280)
         name = f'DepthHead.forward (1,72,80,320)->2x(288,320,1280)+map, {"bf16" if esz == 2 else "fp32"}'
         unit = 'depth-volumes/s'
+    elif args.workload == 'sweep_bwd_kitti_cl':
+        # config K's backward as the bf16 NDHWC training stack sees it: a channels-last bf16 gradient volume read
+        # in place by the gather kernel (both maps), pixel-major fp32 map gradients -- the public function
+        sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+        w = WORKLOADS['kitti']
+        B, dtype_name = w['B'], 'bf16'
+        cur = torch.empty(B, w['C'], w['H'], w['W'], dtype=torch.bfloat16, device=dev)
+        desc = sweep._make_desc(cur, w['D'], w['fsf'], w['csf'], (375, 1242), False, w['crop'], 1.0)
+        depths = torch.from_numpy(depth_planes(w['D'], w['dmin'], w['dmax'])).to(dev)
+        P, Pinv, T = sweep.camera_matrices(torch.from_numpy(np.stack([KITTI_P2] * B)),
+                                           torch.from_numpy(poses(B, 2 + rank)), B, dev)
+        gout = torch.randn(B, 2 * w['C'], w['D'], desc.h_out, desc.w_out, device=dev).bfloat16().contiguous(
+            memory_format=torch.channels_last_3d)
+        walk, gather = [False], [os.environ.get('DFM_NO_PREV_GATHER') != '1']
+
+        def step():
+            with sweep.prev_gather(gather[0]):
+                return sweep.plane_sweep_backward(desc, gout, depths, P, Pinv, T)
+        nbytes = gout.numel() * 2 + 2 * B * w['C'] * w['H'] * w['W'] * 4
+        name = 'plane-sweep backward (bf16 channels-last grad volume read in place -> 2 fp32 feature grads)'
+        unit = 'cost-volume-grads/s'
     elif args.workload in ('sweep_bwd', 'sweep_bwd_kitti'):
         # backward of the plane sweep on the N* / K shape: grad volume -> fp32 feature grads
         sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')

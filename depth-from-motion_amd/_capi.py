@@ -35,6 +35,7 @@ EXPORTS = (
     'dfm_plane_sweep_bwd_cur_nhwc',
     'dfm_plane_sweep_bwd_prev_gather_workspace_bytes',
     'dfm_plane_sweep_bwd_prev_gather',
+    'dfm_plane_sweep_bwd_gather',
     'dfm_plane_sweep_autotune',
     'dfm_plane_sweep_tuning',
     'dfm_plane_sweep_reset_tuning',
@@ -275,6 +276,8 @@ def lib():
     h.dfm_plane_sweep_bwd_prev_gather_workspace_bytes.argtypes = [dp]
     h.dfm_plane_sweep_bwd_prev_gather.restype = ctypes.c_int
     h.dfm_plane_sweep_bwd_prev_gather.argtypes = [dp, vp, fp, fp, fp, fp, fp, vp, sz, vp]
+    h.dfm_plane_sweep_bwd_gather.restype = ctypes.c_int
+    h.dfm_plane_sweep_bwd_gather.argtypes = [dp, i32, vp, i32, fp, fp, fp, fp, fp, i32, vp, sz, vp]
     h.dfm_plane_sweep_autotune.restype = ctypes.c_int
     h.dfm_plane_sweep_autotune.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, sz, vp, op]
     h.dfm_plane_sweep_tuning.restype = ctypes.c_int

@@ -30,6 +30,11 @@
 // vouch for (a corner behind the camera or non-finite, a lattice step below ~1.1 pixels): those few planes
 // are scattered with atomics by a second small kernel after the gather has written the map.
 //
+// The same kernel serves the CUR half and gradient volumes in the NDHWC stack's own layout (bf16 or fp32,
+// channels-last: a hit is ONE contiguous run of 32 channels instead of 32 loads a channel plane apart -- the
+// reference-layout form is bound by the number of load instructions, not by bytes), writing the map gradient
+// in the reference layout or pixel-major: dfm_plane_sweep_bwd_gather.
+//
 // Traffic: the prev half of the gradient volume is read once from HBM (a point's 2x2 pixels are two lanes of
 // a wave and two rows of the same workgroup), the map is written once: 2.36 + 0.42 GB at config K.
 #include <algorithm>
@@ -43,7 +48,8 @@ namespace {
 constexpr int GP_REC = 12;  // floats per (sample, plane): Hinv[9], ok, 2 spare
 constexpr float GP_MAX_TOL = 1.75f;  // lattice half-width of the candidate box a plane may need (<= 4 per axis)
 
-// ---- per (sample, plane): inverse homography of the prev half's lattice -> map correspondence ----------
+// ---- per (sample, plane): inverse homography of one half's lattice -> map correspondence ----------------
+template <int HALF>
 __global__ __launch_bounds__(64) void gather_fit_kernel(SweepGeom g, SweepFast fast, int batch,
                                                         const float *__restrict__ depths,
                                                         const float *__restrict__ P,
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(64) void gather_fit_kernel(SweepGeom g, SweepFast f
     double A[8][9];
     for (int k = 0; k < 4; ++k) {
         float sx, sy;
-        sweep_point_map<1>(g, fast, Pb, Pib, Tb, depth, ch[k], cw[k], sx, sy);
+        sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, ch[k], cw[k], sx, sy);
         if (!(fabsf(sx) < 1.0e6f) || !(fabsf(sy) < 1.0e6f)) return;  // non-finite / far off: not vouched for
         const double u = cw[k], v = ch[k], X = sx, Y = sy;
         // X = (h0 u + h1 v + h2) / (h6 u + h7 v + 1), Y = (h3 u + h4 v + h5) / (...)
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(64) void gather_fit_kernel(SweepGeom g, SweepFast f
     const int tw[5] = {wl / 2, wl / 3, (2 * wl) / 3, 0, wl}, th[5] = {hl / 2, (2 * hl) / 3, hl / 3, 0, hl};
     for (int k = 0; k < 5; ++k) {
         float sx, sy;
-        sweep_point_map<1>(g, fast, Pb, Pib, Tb, depth, th[k], tw[k], sx, sy);
+        sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, th[k], tw[k], sx, sy);
         if (!(fabsf(sx) < 1.0e6f) || !(fabsf(sy) < 1.0e6f)) return;
         const float den = hi[6] * sx + hi[7] * sy + hi[8];
         const float inv = 1.0f / den;
@@ -118,11 +124,50 @@ __global__ __launch_bounds__(64) void gather_fit_kernel(SweepGeom g, SweepFast f
     rec[9] = 1.0f;
 }
 
+// the 32 channels of one lattice point of the gradient volume, as fp32
+//   CL == false: the reference layout (B, 2C, D, h, w): 32 loads a channel plane apart (cstride elements)
+//   CL == true : channels-last (B, D, h, w, 2C) -- what the NDHWC aggregation stack's backward hands over: ONE
+//                contiguous run of 32 * sizeof(T) bytes, 16-byte loads
+template <typename T, bool CL>
+__device__ __forceinline__ void gather_load32(const T *__restrict__ gp, size_t cstride, float (&v)[32])
+{
+    if constexpr (CL) {
+        constexpr int VEC = 16 / (int)sizeof(T);
+#pragma unroll
+        for (int q = 0; q < 32 / VEC; ++q) {
+            const uint4 u = *(const uint4 *)(gp + q * VEC);
+            if constexpr (sizeof(T) == 4) {
+                v[4 * q] = __uint_as_float(u.x); v[4 * q + 1] = __uint_as_float(u.y);
+                v[4 * q + 2] = __uint_as_float(u.z); v[4 * q + 3] = __uint_as_float(u.w);
+            } else {
+                const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[8 * q + 2 * k] = __uint_as_float(w4[k] << 16);
+                    v[8 * q + 2 * k + 1] = __uint_as_float(w4[k] & 0xffff0000u);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {  // (cacheable: the map row below re-reads the line)
+            if constexpr (sizeof(T) == 4) v[c] = __uint_as_float(*(const uint32_t *)(gp + (size_t)c * cstride));
+            else v[c] = __uint_as_float((uint32_t)(*(const uint16_t *)(gp + (size_t)c * cstride)) << 16);
+        }
+    }
+}
+
 // ---- the gather: lane = map pixel, 32 channels per pass -----------------------------------------------
-__global__ __launch_bounds__(256) void sweep_bwd_prev_gather_kernel(
+// HALF: 0 cur map (channels [0, C) of the volume; its sample positions do not move with depth, the same
+// kernel walks them anyway: the footprint flips between neighbouring pixel pairs with the rounding of each
+// plane), 1 prev map.  T: dtype of the gradient volume (fp32 | bf16 bits).  CL_IN: the volume is channels-last.
+// CL_OUT: the map gradient is written pixel-major (B, H, W, C) -- a lane's 32 sums are one 128-byte run --
+// instead of the reference layout (B, C, H, W).
+template <int HALF, typename T, bool CL_IN, bool CL_OUT>
+__global__ __launch_bounds__(256) void sweep_bwd_gather_kernel(
     SweepGeom g, SweepFast fast, int batch, int passes, int xtiles, const float *__restrict__ planes,
-    const float *__restrict__ gout, const float *__restrict__ depths, const float *__restrict__ P,
-    const float *__restrict__ Pinv, const float *__restrict__ Tm, float *__restrict__ gprev)
+    const T *__restrict__ gout, const float *__restrict__ depths, const float *__restrict__ P,
+    const float *__restrict__ Pinv, const float *__restrict__ Tm, float *__restrict__ gmap)
 {
     // block id = ((ytile * xtiles + xtile) * passes + pass) * B + b: sample fastest (id % 8 == XCD keeps a
     // sample's gradient volume in one L2), then the channel passes of one pixel tile
@@ -138,8 +183,11 @@ __global__ __launch_bounds__(256) void sweep_bwd_prev_gather_kernel(
     const bool inside = y < H && x < W;
     const float xf = (float)x, yf = (float)y;
     const int hw = g.h_out * g.w_out;
-    const size_t cstride = (size_t)g.D * hw;  // elements between channels of the volume
-    const float *gb = gout + ((size_t)b * 2 * g.C + g.C + (size_t)pass * 32) * cstride;
+    const int C2 = 2 * g.C, ch0 = HALF * g.C + pass * 32;
+    const size_t cstride = (size_t)g.D * hw;  // reference layout: elements between channels of the volume
+    // element (d, lh, lw) of this pass's first channel: gb + (d * hw + lh * w_out + lw) * pstride
+    const T *gb = CL_IN ? gout + (size_t)b * cstride * C2 + ch0 : gout + ((size_t)b * C2 + ch0) * cstride;
+    const size_t pstride = CL_IN ? (size_t)C2 : 1;
     const float *Pb = P + b * 16, *Pib = Pinv + b * 16, *Tb = Tm + b * 16;
     float acc[32];
 #pragma unroll
@@ -162,7 +210,7 @@ __global__ __launch_bounds__(256) void sweep_bwd_prev_gather_kernel(
         const int w0 = some ? max((int)w0f, 0) : 0, w1 = some ? min((int)w1f, g.w_out - 1) : -1;
         const int h0 = some ? max((int)h0f, 0) : 0, h1 = some ? min((int)h1f, g.h_out - 1) : -1;
         const float depth = depths[d];
-        const float *gd = gb + (size_t)d * hw;
+        const T *gd = gb + (size_t)d * hw * pstride;
         for (int kh = 0; kh < 4; ++kh) {
             const int lh = h0 + kh;
             if (!__any(lh <= h1)) break;
@@ -173,7 +221,7 @@ __global__ __launch_bounds__(256) void sweep_bwd_prev_gather_kernel(
                 if (cand) {
                     // the forward's own arithmetic decides: does this lattice point's footprint hold (x, y)?
                     float sx, sy, fw, fn;
-                    sweep_point_map<1>(g, fast, Pb, Pib, Tb, depth, lh, lw, sx, sy);
+                    sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, lh, lw, sx, sy);
                     const uint32_t f = bwd_footprint(sx, sy, H, W, fw, fn);
                     const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
                     const int dx = x - ixw, dy = y - iyn;
@@ -184,10 +232,8 @@ __global__ __launch_bounds__(256) void sweep_bwd_prev_gather_kernel(
                     if (f != 0u && (unsigned)dx <= 1u && (unsigned)dy <= 1u && colok && rowok) {
                         // ATen's weights: (row factor) * (column factor), nw = (1 - fn) * (1 - fw) ...
                         const float wgt = (dy ? fn : 1.0f - fn) * (dx ? fw : 1.0f - fw);
-                        const float *gp = gd + (size_t)lh * g.w_out + lw;
                         float v[32];
-#pragma unroll
-                        for (int c = 0; c < 32; ++c) v[c] = gp[(size_t)c * cstride];  // (cacheable: the row below re-reads it)
+                        gather_load32<T, CL_IN>(gd + ((size_t)lh * g.w_out + lw) * pstride, cstride, v);
 #pragma unroll
                         for (int c = 0; c < 32; ++c) acc[c] += v[c] * wgt;  // (0 x Inf = NaN reaches the tap, as in ATen)
                     }
@@ -196,30 +242,40 @@ __global__ __launch_bounds__(256) void sweep_bwd_prev_gather_kernel(
         }
     }
     if (inside) {
-        float *o = gprev + (((size_t)b * g.C + (size_t)pass * 32) * H + y) * W + x;
-        const size_t ps = (size_t)H * W;
+        if constexpr (CL_OUT) {
+            float *o = gmap + (((size_t)b * H + y) * W + x) * g.C + (size_t)pass * 32;
 #pragma unroll
-        for (int c = 0; c < 32; ++c) o[(size_t)c * ps] = acc[c];
+            for (int q = 0; q < 8; ++q)
+                *(float4 *)(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        } else {
+            float *o = gmap + (((size_t)b * g.C + (size_t)pass * 32) * H + y) * W + x;
+            const size_t ps = (size_t)H * W;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) o[(size_t)c * ps] = acc[c];
+        }
     }
 }
 
 // ---- planes without a vouched-for inverse: plain scatter with atomics (rare; runs after the gather) ------
-__global__ __launch_bounds__(256) void sweep_bwd_prev_scatter_planes_kernel(
-    SweepGeom g, SweepFast fast, int batch, const float *__restrict__ planes, const float *__restrict__ gout,
+template <int HALF, typename T, bool CL_IN, bool CL_OUT>
+__global__ __launch_bounds__(256) void sweep_bwd_scatter_planes_kernel(
+    SweepGeom g, SweepFast fast, int batch, const float *__restrict__ planes, const T *__restrict__ gout,
     const float *__restrict__ depths, const float *__restrict__ P, const float *__restrict__ Pinv,
-    const float *__restrict__ Tm, float *__restrict__ gprev)
+    const float *__restrict__ Tm, float *__restrict__ gmap)
 {
     const int i = blockIdx.x;  // (sample, plane)
     if (planes[(size_t)i * GP_REC + 9] != 0.0f) return;
     const int b = i / g.D, d = i - b * g.D;
     const int hw = g.h_out * g.w_out, H = g.h_in, W = g.w_in;
+    const int C2 = 2 * g.C;
     const size_t cstride = (size_t)g.D * hw;
-    const float *gd = gout + ((size_t)b * 2 * g.C + g.C) * cstride + (size_t)d * hw;
+    const T *gd = CL_IN ? gout + ((size_t)b * cstride + (size_t)d * hw) * C2 + HALF * g.C
+                        : gout + ((size_t)b * C2 + HALF * g.C) * cstride + (size_t)d * hw;
     const float depth = depths[d];
     for (int p = blockIdx.y * 256 + threadIdx.x; p < hw; p += gridDim.y * 256) {
         const int lh = p / g.w_out, lw = p - lh * g.w_out;
         float sx, sy, fw, fn;
-        sweep_point_map<1>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, depth, lh, lw, sx, sy);
+        sweep_point_map<HALF>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, depth, lh, lw, sx, sy);
         const uint32_t f = bwd_footprint(sx, sy, H, W, fw, fn);
         if (f == 0u) continue;
         const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
@@ -227,13 +283,44 @@ __global__ __launch_bounds__(256) void sweep_bwd_prev_scatter_planes_kernel(
                             (f & (1u << 27)) && (f & (1u << 30)), (f & (1u << 28)) && (f & (1u << 30))};
         const float wq[4] = {(1.0f - fn) * (1.0f - fw), (1.0f - fn) * fw, fn * (1.0f - fw), fn * fw};
         for (int c = 0; c < g.C; ++c) {
-            const float gv = gd[(size_t)c * cstride + p];
-            float *m = gprev + ((size_t)b * g.C + c) * H * W;
+            const T raw = CL_IN ? gd[(size_t)p * C2 + c] : gd[(size_t)c * cstride + p];
+            float gv;
+            if constexpr (sizeof(T) == 4) gv = raw;
+            else gv = __uint_as_float((uint32_t)raw << 16);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (ok[k]) atomicAdd(m + (size_t)(iyn + (k >> 1)) * W + ixw + (k & 1), gv * wq[k]);
+                if (ok[k]) {
+                    const size_t py = (size_t)(iyn + (k >> 1)), px = (size_t)(ixw + (k & 1));
+                    float *m = CL_OUT ? gmap + (((size_t)b * H + py) * W + px) * g.C + c
+                                      : gmap + (((size_t)b * g.C + c) * H + py) * W + px;
+                    atomicAdd(m, gv * wq[k]);
+                }
         }
     }
+}
+
+template <int HALF, typename T, bool CL_IN, bool CL_OUT>
+int gather_launch(const dfm_sweep_desc *d, const void *grad_out, const float *depths, const float *cam2img,
+                  const float *cam2img_inv, const float *cur2prev, float *grad_map, float *planes, hipStream_t st)
+{
+    const SweepGeom g = sweep_make_geom(d);
+    const SweepFast fast = sweep_make_fast(d);
+    const int np = d->batch * d->num_depths;
+    hipLaunchKernelGGL(gather_fit_kernel<HALF>, dim3((np + 63) / 64), dim3(64), 0, st, g, fast, d->batch, depths,
+                       cam2img, cam2img_inv, cur2prev, planes);
+    const int xtiles = (d->w_in + 63) / 64, ytiles = (d->h_in + 3) / 4, passes = d->channels / 32;
+    const long long nb = (long long)xtiles * ytiles * passes * d->batch;
+    if (nb > 2147483647ll) return set_error(DFM_ERR_UNSUPPORTED, "feature map too large");
+    hipLaunchKernelGGL((sweep_bwd_gather_kernel<HALF, T, CL_IN, CL_OUT>), dim3((unsigned)nb), dim3(256), 0, st, g, fast,
+                       d->batch, passes, xtiles, (const float *)planes, (const T *)grad_out, depths, cam2img,
+                       cam2img_inv, cur2prev, grad_map);
+    const int ychunks = std::max(1, std::min(64, (d->h_out * d->w_out + 255) / 256));
+    hipLaunchKernelGGL((sweep_bwd_scatter_planes_kernel<HALF, T, CL_IN, CL_OUT>), dim3(np, ychunks), dim3(256), 0, st, g,
+                       fast, d->batch, (const float *)planes, (const T *)grad_out, depths, cam2img, cam2img_inv,
+                       cur2prev, grad_map);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
 }
 
 }  // namespace
@@ -246,40 +333,56 @@ DFM_API size_t dfm_plane_sweep_bwd_prev_gather_workspace_bytes(const dfm_sweep_d
     return (((size_t)d->batch * d->num_depths * GP_REC * sizeof(float)) + 255) & ~(size_t)255;
 }
 
+DFM_API int dfm_plane_sweep_bwd_gather(const dfm_sweep_desc *d, int32_t half, const void *grad_out,
+                                       int32_t grad_channels_last, const float *depths, const float *cam2img,
+                                       const float *cam2img_inv, const float *cur2prev, float *grad_map,
+                                       int32_t map_pixel_major, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = sweep_check_desc(d);
+    if (rc != DFM_OK) return rc;
+    if (!grad_out || !depths || !cam2img || !cam2img_inv || !cur2prev || !grad_map || !workspace)
+        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (half != 0 && half != 1) return set_error(DFM_ERR_INVALID_ARG, "half is 0 (cur map) or 1 (prev map)");
+    if (workspace_bytes < dfm_plane_sweep_bwd_prev_gather_workspace_bytes(d))
+        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_plane_sweep_bwd_prev_gather_workspace_bytes");
+    if (d->channels % 32 || d->cost_sample_factor < 1.5f || d->h_in >= 4096 || d->w_in >= 8192 || d->h_out < 2 ||
+        d->w_out < 2 || (grad_channels_last && ((uintptr_t)grad_out & 15)) || (map_pixel_major && ((uintptr_t)grad_map & 15)))
+        return set_error(DFM_ERR_UNSUPPORTED,
+                         "gather backward: channels % 32 == 0, cost_sample_factor >= 2, lattice >= 2 x 2, 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    float *planes = (float *)workspace;
+#define DFM_GL(H_, T_, CI_, CO_) \
+    rc = gather_launch<H_, T_, CI_, CO_>(d, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_map, planes, st)
+#define DFM_GL_T(H_, CI_, CO_)                                \
+    do {                                                      \
+        if (d->dtype == DFM_BF16) DFM_GL(H_, uint16_t, CI_, CO_); \
+        else DFM_GL(H_, float, CI_, CO_);                     \
+    } while (0)
+#define DFM_GL_L(H_)                                                          \
+    do {                                                                      \
+        if (grad_channels_last && map_pixel_major) DFM_GL_T(H_, true, true);  \
+        else if (grad_channels_last) DFM_GL_T(H_, true, false);               \
+        else if (map_pixel_major) DFM_GL_T(H_, false, true);                  \
+        else DFM_GL_T(H_, false, false);                                      \
+    } while (0)
+    if (half) DFM_GL_L(1);
+    else DFM_GL_L(0);
+#undef DFM_GL_L
+#undef DFM_GL_T
+#undef DFM_GL
+    if (rc != DFM_OK) return rc;
+    sweep_set_last_bwd_kernel(9);
+    return DFM_OK;
+}
+
 DFM_API int dfm_plane_sweep_bwd_prev_gather(const dfm_sweep_desc *d, const void *grad_out, const float *depths,
                                             const float *cam2img, const float *cam2img_inv, const float *cur2prev,
                                             float *grad_prev, void *workspace, size_t workspace_bytes, void *stream)
 {
-    int rc = sweep_check_desc(d);
-    if (rc != DFM_OK) return rc;
-    if (!grad_out || !depths || !cam2img || !cam2img_inv || !cur2prev || !grad_prev || !workspace)
-        return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
-    if (workspace_bytes < dfm_plane_sweep_bwd_prev_gather_workspace_bytes(d))
-        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_plane_sweep_bwd_prev_gather_workspace_bytes");
-    if (d->dtype != DFM_F32 || d->channels % 32 || d->cost_sample_factor < 1.5f || d->h_in >= 4096 || d->w_in >= 8192 ||
-        d->h_out < 2 || d->w_out < 2)
-        return set_error(DFM_ERR_UNSUPPORTED,
-                         "prev-map gather backward: fp32, channels % 32 == 0, cost_sample_factor >= 2, lattice >= 2 x 2");
-    const SweepGeom g = sweep_make_geom(d);
-    const SweepFast fast = sweep_make_fast(d);
-    hipStream_t st = (hipStream_t)stream;
-    float *planes = (float *)workspace;
-    const int np = d->batch * d->num_depths;
-    hipLaunchKernelGGL(gather_fit_kernel, dim3((np + 63) / 64), dim3(64), 0, st, g, fast, d->batch, depths, cam2img,
-                       cam2img_inv, cur2prev, planes);
-    const int xtiles = (d->w_in + 63) / 64, ytiles = (d->h_in + 3) / 4, passes = d->channels / 32;
-    const long long nb = (long long)xtiles * ytiles * passes * d->batch;
-    if (nb > 2147483647ll) return set_error(DFM_ERR_UNSUPPORTED, "feature map too large");
-    hipLaunchKernelGGL(sweep_bwd_prev_gather_kernel, dim3((unsigned)nb), dim3(256), 0, st, g, fast, d->batch, passes,
-                       xtiles, (const float *)planes, (const float *)grad_out, depths, cam2img, cam2img_inv, cur2prev,
-                       grad_prev);
-    const int ychunks = std::max(1, std::min(64, (d->h_out * d->w_out + 255) / 256));
-    hipLaunchKernelGGL(sweep_bwd_prev_scatter_planes_kernel, dim3(np, ychunks), dim3(256), 0, st, g, fast, d->batch,
-                       (const float *)planes, (const float *)grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_prev);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
-    sweep_set_last_bwd_kernel(9);
-    return DFM_OK;
+    if (d && d->dtype != DFM_F32)
+        return set_error(DFM_ERR_UNSUPPORTED, "prev-map gather backward (reference layout): fp32 gradient volumes");
+    return dfm_plane_sweep_bwd_gather(d, 1, grad_out, 0, depths, cam2img, cam2img_inv, cur2prev, grad_prev, 0, workspace,
+                                      workspace_bytes, stream);
 }
 
 }  // extern "C"

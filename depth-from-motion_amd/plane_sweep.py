@@ -354,6 +354,27 @@ def plane_sweep_backward(desc, grad_out, depths, P, Pinv, T):
         # layout cost 2.2 ms of a 20 ms training step at config K)
         # up to 2 GB: re-laid by the library's LDS-tile transpose (copy speed) into a scratch of the
         # volume's size; larger volumes are read in place (no extra memory)
+        if (_PREV_GATHER['on'] and desc.cost_sample_factor >= 1.5 and desc.channels % 32 == 0 and
+                _DTYPES.get(grad_out.dtype) == desc.dtype):
+            # strided sweeps (config K): both maps by the gather kernel, the volume read where it lies -- a hit is
+            # one contiguous run of 32 channels -- and the map gradients written pixel-major (returned as
+            # channels_last (B, C, H, W) tensors: the layout the NHWC necks' backward wants).  No re-layout
+            # pass, no scratch of the volume's size, no atomics, no zero-filled maps.
+            nb = lib.dfm_plane_sweep_bwd_prev_gather_workspace_bytes(ctypes.byref(desc))
+            gws = _Workspace.get(device, nb)
+            maps = [torch.empty((desc.batch, desc.h_in, desc.w_in, desc.channels), dtype=torch.float32,
+                                device=device) for _ in range(2)]
+            rc = 0
+            with torch.cuda.device(device):
+                for half in (0, 1):
+                    if rc == 0:
+                        rc = lib.dfm_plane_sweep_bwd_gather(ctypes.byref(desc), half, _ptr(grad_out), 1, _ptr(depths),
+                                                            _ptr(P), _ptr(Pinv), _ptr(T), _ptr(maps[half]), 1,
+                                                            _ptr(gws), nb, _stream_ptr(device))
+            if rc == 0:
+                return maps[0].permute(0, 3, 1, 2), maps[1].permute(0, 3, 1, 2)
+            if rc != _capi.DFM_ERR_UNSUPPORTED:
+                _capi.check(rc)
         nbytes = grad_out.numel() * grad_out.element_size()
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes <= (2 << 30) else None
         g_cur = torch.zeros(shape, dtype=torch.float32, device=device)

@@ -312,6 +312,19 @@ DFM_API int dfm_plane_sweep_bwd_cur_nhwc(const dfm_sweep_desc *desc, const void 
  * second F.grid_sample call of build_dfm_cost (reference dfm_backbone.py:304-311); reports 9 through
  * dfm_plane_sweep_bwd_last_kernel. */
 DFM_API size_t dfm_plane_sweep_bwd_prev_gather_workspace_bytes(const dfm_sweep_desc *desc);
+/* The general form of the same kernel: half = 0 the CUR map (channels [0, C) of the volume), 1 the PREV map;
+ * the gradient volume in desc->dtype (DFM_F32 | DFM_BF16), in the reference layout (grad_channels_last == 0) or
+ * channels-last (B, D, h_out, w_out, 2C) -- what the NDHWC aggregation stack's backward hands over: a hit is then
+ * one contiguous run of 32 channels, read in place, no re-layout pass and no scratch of the volume's size;
+ * grad_map fp32, overwritten, in the reference layout (B, C, H, W) or pixel-major (B, H, W, C)
+ * (map_pixel_major != 0: torch's channels_last, what the NHWC necks' backward wants).  Same workspace.
+ * DFM_ERR_UNSUPPORTED unless channels % 32 == 0 and cost_sample_factor >= 2 (16-byte aligned channels-last
+ * buffers). */
+DFM_API int dfm_plane_sweep_bwd_gather(const dfm_sweep_desc *desc, int32_t half, const void *grad_out,
+                                       int32_t grad_channels_last, const float *depths, const float *cam2img,
+                                       const float *cam2img_inv, const float *cur2prev, float *grad_map,
+                                       int32_t map_pixel_major, void *workspace, size_t workspace_bytes,
+                                       void *stream);
 DFM_API int dfm_plane_sweep_bwd_prev_gather(const dfm_sweep_desc *desc, const void *grad_out, const float *depths,
                                             const float *cam2img, const float *cam2img_inv,
                                             const float *cur2prev, float *grad_prev, void *workspace,

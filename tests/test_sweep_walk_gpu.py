@@ -271,3 +271,32 @@ def test_prev_gather_propagates_nonfinite_gradients_like_the_scatter(pkg):
     assert not torch.isfinite(gp0).all(), 'the poisoned point must reach the map in the scatter kernel'
     assert torch.equal(torch.isfinite(gp1), torch.isfinite(gp0))
     assert torch.equal(torch.isnan(gp1), torch.isnan(gp0))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('csf,flip,crop,scale', [(4, False, (0, 55), 1.0), (4, True, (7, 55), 0.97), (2, False, (0, 0), 1.0)])
+def test_gather_reads_the_channels_last_volume_in_place(pkg, dtype, csf, flip, crop, scale):
+    """the NDHWC stack hands the volume's gradient channels-last: both maps by the gather kernel, read where the
+    volume lies, map gradients pixel-major -- against the same call on the reference layout"""
+    sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(31 + csf)
+    B, C, H, W, D = 2, 64, 64, 256, 9
+    cur = torch.from_numpy(rng.randn(B, C, H, W).astype(np.float32)).to(dev).to(dtype)
+    prev = torch.from_numpy(rng.randn(B, C, H, W).astype(np.float32)).to(dev).to(dtype)
+    depths = torch.from_numpy(util.depth_planes(D)).to(dev)
+    Pm, Pinv, Tm = sweep.camera_matrices(torch.from_numpy(np.stack([util.KITTI_P2] * B)),
+                                         torch.from_numpy(util.random_poses(B, seed=8)), B, dev)
+    desc = sweep._make_desc(cur, D, 1, csf, (375, 1242), flip, crop, scale)
+    g = torch.from_numpy(rng.randn(B, 2 * C, D, desc.h_out, desc.w_out).astype(np.float32)).to(dev).to(dtype)
+    g_cl = g.contiguous(memory_format=torch.channels_last_3d)
+    assert not g_cl.is_contiguous()
+    ref_c, ref_p = sweep.plane_sweep_backward(desc, g, depths, Pm, Pinv, Tm)
+    got_c, got_p = sweep.plane_sweep_backward(desc, g_cl, depths, Pm, Pinv, Tm)
+    torch.cuda.synchronize()
+    assert pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel() == 9
+    assert got_c.dtype == torch.float32 and got_c.shape == (B, C, H, W)
+    assert got_c.is_contiguous(memory_format=torch.channels_last) and got_p.is_contiguous(memory_format=torch.channels_last)
+    for a, b in ((got_c, ref_c), (got_p, ref_p)):
+        assert float(b.abs().max()) > 0
+        assert torch.allclose(a, b, rtol=1e-5, atol=3e-6 * float(b.abs().max()))
