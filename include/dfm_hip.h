@@ -491,7 +491,10 @@ DFM_API int dfm_frustum_to_voxel_fused_fwd(const dfm_f2v_desc *desc, const void 
                                            const float *coords, const float *cam2img, void *out,
                                            void *workspace, size_t workspace_bytes, void *stream);
 /* Backward w.r.t. stereo_feat and cur_sem_feats (the depth distribution is
- * detached in the reference, :136).  grad_out: (B, C+Cs, nz, ny, nx) dtype;
+ * detached in the reference, :136).  grad_out: dtype, in the layout the forward wrote
+ * `out` in -- (B, C+Cs, nz, ny, nx), or channels-last (B, nz, ny, nx, C+Cs) when
+ * desc->out_channels_last (since round 5: an NDHWC voxel_convs backward hands its gradient
+ * over in that layout and it is read in place; rounds 1-4 took the planar form only);
  * grad_stereo (B,C,d,h,w) and grad_sem (B,Cs,hsem,wsem): FP32, zero-filled by
  * the caller, accumulated with atomics. */
 /* workspace (optional): >= dfm_frustum_to_voxel_bwd_workspace_bytes(desc) bytes of
