@@ -984,6 +984,240 @@ __global__ __launch_bounds__(256) void f2v_bwd_pm_kernel(F2vGeom g, const T *__r
     }
 }
 
+
+// 32 consecutive channels of one voxel's gradient row (channels-last), as fp32
+template <typename T>
+__device__ __forceinline__ void gather_row32(const T *__restrict__ gp, float (&v)[32])
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+#pragma unroll
+    for (int q = 0; q < 32 / VEC; ++q) {
+        const uint4 u = *(const uint4 *)(gp + q * VEC);
+        if constexpr (sizeof(T) == 4) {
+            v[4 * q] = __uint_as_float(u.x); v[4 * q + 1] = __uint_as_float(u.y);
+            v[4 * q + 2] = __uint_as_float(u.z); v[4 * q + 3] = __uint_as_float(u.w);
+        } else {
+            const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[8 * q + 2 * k] = __uint_as_float(w4[k] << 16);
+                v[8 * q + 2 * k + 1] = __uint_as_float(w4[k] & 0xffff0000u);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward as a GATHER (round 5).  The pixel-major scatter above runs at the part's fp32 atomic rate: 1.75 M
+// voxels x 8 corners x 64 channels = 0.9 G atomics = 2.9 ms per sample at config K, the third-largest kernel of
+// the training step.  Turned around: a lane owns a cell column of the cost volume -- pixel (h, w), a run of depth
+// planes -- and finds the voxels whose trilinear footprint holds each cell.  The voxel grid is REGULAR
+// (prepare_coordinates_3d: linspace centres, x fastest; the host checks it and passes origin and steps) and the
+// voxel -> frustum map is explicit: depth is affine in the voxel's x index, and for a given x the image position
+// is a projective function of (y, z) -- so for every x slab that can touch the plane a 2 x 2 linear system gives
+// the (y, z) voxel position that projects onto the pixel, and solving it again one pixel further along u and v
+// gives the box of voxel indices that can touch the pixel.  Every voxel in the box is then run through the
+// FORWARD's own arithmetic (projection, normalisation, floor): it counts only if one of its eight corners IS this
+// cell, with the forward's weight -- the (voxel, corner, weight) set is exactly the scatter's.  A hit gathers the
+// voxel's gradient row (channels-last: one contiguous run).  The stereo gradient of a cell is STORED when its
+// plane is done; the semantic map's gradient (same pixel, every plane: taken from the hits whose LOWER depth
+// corner is the cell, so a voxel counts once) leaves as 32 atomics per lane and depth chunk instead of 128 per
+// voxel.  The per-voxel factors (validity, pred_disp) come from a lane-per-voxel pre-pass into 8 bytes per voxel.
+// ---------------------------------------------------------------------------------------------------------
+struct F2vGrid {
+    float x0, dx, y0, dy, z0, dz;  // coords[(iz * Ny + iy) * Nx + ix] == (x0 + ix dx, y0 + iy dy, z0 + iz dz)
+};
+
+// pre-pass, lane = voxel: the factors the scatter's first phase computes.  sfac = the stereo branch's factor
+// (pred_disp when stereo_atten, else 1) or -1 for a voxel that contributes nothing; mfac likewise for the
+// semantic branch (pred_disp * valid when sem_atten, else valid2d).  Same arithmetic as f2v_bwd_pm_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void f2v_bwd_prep_kernel(F2vGeom g, const T *__restrict__ soft, FusedHead fh,
+                                                           const float *__restrict__ coords,
+                                                           const float *__restrict__ cam2img,
+                                                           float *__restrict__ sfac, float *__restrict__ mfac)
+{
+    const long long N = (long long)g.Nz * g.Ny * g.Nx;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= N) return;
+    const float xs = coords[3 * i], ys = coords[3 * i + 1], zs = coords[3 * i + 2];
+    const float *P = cam2img + 16 * b;
+    const float a = dot4_chain(-ys, -zs, xs, 1.0f, P + 0);
+    const float bb = dot4_chain(-ys, -zs, xs, 1.0f, P + 4);
+    const float c = dot4_chain(-ys, -zs, xs, 1.0f, P + 8);
+    const float u = a / c, v = bb / c;
+    const bool valid2d = (u >= 0.0f) && (u <= g.pad_w) && (v >= 0.0f) && (v <= g.pad_h);
+    float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
+    float gz = (xs - g.depth_min) / g.depth_span;
+    gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
+    const bool valid = valid2d && gz >= -1.0f && gz <= 1.0f;
+    float disp = 1.0f;
+    if (valid && (g.st_att || (g.Cs > 0 && g.sem_att))) {
+        if (fh.cost) {
+            disp = fused_disp<T>(g, (const T *)fh.cost + (size_t)b * g.cd * g.ch * g.cw,
+                                 fh.col_max + (size_t)b * g.Hs * g.Ws, fh.col_sum + (size_t)b * g.Hs * g.Ws, gx, gy, gz);
+        } else {
+            const Tri ts = make_tri(gx, gy, gz, g.Ds, g.Hs, g.Ws);
+            disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
+        }
+    }
+    sfac[(size_t)b * N + i] = valid ? (g.st_att ? disp : 1.0f) : -1.0f;
+    mfac[(size_t)b * N + i] = (g.Cs > 0 && (g.sem_att ? valid : valid2d)) ? (g.sem_att ? disp : 1.0f) : -1.0f;
+}
+
+constexpr int F2G_DCH = 9;  // depth planes per lane (a chunk): 72 planes -> 8 chunks
+
+// lane = pixel (h, w) of the cost volume x a chunk of depth planes; C == 32, Cs in {0, 32} with the semantic
+// map at the cost volume's resolution.  gvs / gcs: element strides of grad_out between voxels / channels.
+template <typename T, bool SEM>
+__global__ __launch_bounds__(256) void f2v_bwd_gather_kernel(F2vGeom g, F2vGrid gr, int dchunks,
+                                                             const T *__restrict__ gout, size_t gvs, size_t gcs,
+                                                             const float *__restrict__ coords,
+                                                             const float *__restrict__ cam2img,
+                                                             const float *__restrict__ sfac,
+                                                             const float *__restrict__ mfac,
+                                                             float *__restrict__ gst, float *__restrict__ gsem)
+{
+    // block id = ((ytile * xtiles + xtile) * dchunks + chunk); blockIdx.y = sample
+    const int xtiles = (g.W + 63) / 64;
+    int t = blockIdx.x;
+    const int chunk = t % dchunks;
+    t /= dchunks;
+    const int xt = t % xtiles, yt = t / xtiles;
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = yt * 4 + wave, w = xt * 64 + lane;
+    const bool inside = h < g.H && w < g.W;
+    const long long N = (long long)g.Nz * g.Ny * g.Nx;
+    const float *P = cam2img + 16 * b;
+    const int CT = g.C + g.Cs;
+    // image position of this pixel's centre and of its neighbours one pixel further (the box's extent)
+    const float su = (g.pad_w - 1.0f) / (float)(g.W - 1), sv = (g.pad_h - 1.0f) / (float)(g.H - 1);
+    const float ut = (float)w * su, vt = (float)h * sv;
+    // (y, z) of the voxel position that projects onto image point (uu, vv) in the slab x = xs
+    auto solve = [&](float uu, float vv, float xs, float &ys, float &zs) {
+        const float a11 = uu * P[8] - P[0], a12 = uu * P[9] - P[1], r1 = -((P[2] - uu * P[10]) * xs + (P[3] - uu * P[11]));
+        const float a21 = vv * P[8] - P[4], a22 = vv * P[9] - P[5], r2 = -((P[6] - vv * P[10]) * xs + (P[7] - vv * P[11]));
+        const float det = a11 * a22 - a12 * a21, inv = 1.0f / det;
+        ys = (r1 * a22 - a12 * r2) * inv;
+        zs = (a11 * r2 - r1 * a21) * inv;
+    };
+    const float pd_per_x = (float)(g.D - 1) / g.depth_span;  // plane index per metre of depth
+    const float idx = 1.0f / gr.dx, idy = 1.0f / gr.dy, idz = 1.0f / gr.dz;
+    const T *gb = gout + (size_t)b * N * CT;  // (both layouts: a sample is N * (C + Cs) elements)
+    float asem[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) asem[c] = 0.0f;
+    const int d0 = chunk * F2G_DCH, d1 = min(g.D, d0 + F2G_DCH);
+    for (int d = d0; d < d1; ++d) {
+        float ast[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) ast[c] = 0.0f;
+        // x slabs whose plane position lies in (d - 1, d + 1): uniform for the workgroup
+        const float xlo = g.depth_min + ((float)d - 1.0f) / pd_per_x, xhi = g.depth_min + ((float)d + 1.0f) / pd_per_x;
+        const float fa = (xlo - gr.x0) * idx, fb = (xhi - gr.x0) * idx;
+        const int ixa = max(0, (int)ceilf(fminf(fa, fb) - 0.02f)), ixb = min(g.Nx - 1, (int)floorf(fmaxf(fa, fb) + 0.02f));
+        for (int ix = ixa; ix <= ixb; ++ix) {
+            const float xs = gr.x0 + (float)ix * gr.dx;
+            float yc, zc, yu, zu, yv, zv;
+            solve(ut, vt, xs, yc, zc);
+            solve(ut + su, vt, xs, yu, zu);
+            solve(ut, vt + sv, xs, yv, zv);
+            const float iyf = (yc - gr.y0) * idy, izf = (zc - gr.z0) * idz;
+            const float ty = (fabsf(yu - yc) + fabsf(yv - yc)) * fabsf(idy) * 1.15f + 0.05f;
+            const float tz = (fabsf(zu - zc) + fabsf(zv - zc)) * fabsf(idz) * 1.15f + 0.05f;
+            const float y0f = ceilf(iyf - ty), y1f = floorf(iyf + ty), z0f = ceilf(izf - tz), z1f = floorf(izf + tz);
+            // (non-finite solutions compare false; a box of more than 8 voxels per axis -- far beyond what the
+            //  path's grids produce -- is clipped: the host only selects this kernel for grids where it is not)
+            const bool some = inside && y0f <= y1f && z0f <= z1f && y1f >= 0.0f && z1f >= 0.0f &&
+                              y0f <= (float)(g.Ny - 1) && z0f <= (float)(g.Nz - 1) && ty < 4.0f && tz < 4.0f;
+            if (!__any(some)) continue;
+            const int iy0 = some ? max((int)y0f, 0) : 0, iy1 = some ? min((int)y1f, g.Ny - 1) : -1;
+            const int iz0 = some ? max((int)z0f, 0) : 0, iz1 = some ? min((int)z1f, g.Nz - 1) : -1;
+            for (int jz = 0; jz < 8; ++jz) {
+                const int iz = iz0 + jz;
+                if (!__any(iz <= iz1)) break;
+                for (int jy = 0; jy < 8; ++jy) {
+                    const int iy = iy0 + jy;
+                    const bool cand = iz <= iz1 && iy <= iy1;
+                    if (!__any(cand)) break;
+                    if (!cand) continue;
+                    const long long i = ((long long)iz * g.Ny + iy) * g.Nx + ix;
+                    const float sf = sfac[(size_t)b * N + i];
+                    const float mf = SEM ? mfac[(size_t)b * N + i] : -1.0f;
+                    if (sf < 0.0f && mf < 0.0f) continue;
+                    // the forward's arithmetic on the voxel's own coordinates
+                    const float vx = coords[3 * i], vy = coords[3 * i + 1], vz = coords[3 * i + 2];
+                    const float a = dot4_chain(-vy, -vz, vx, 1.0f, P + 0);
+                    const float bb = dot4_chain(-vy, -vz, vx, 1.0f, P + 4);
+                    const float c = dot4_chain(-vy, -vz, vx, 1.0f, P + 8);
+                    const float u = a / c, v = bb / c;
+                    float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
+                    float gz = (vx - g.depth_min) / g.depth_span;
+                    gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
+                    // make_tri's positions and weights, corner by corner
+                    const float px = ((gx + 1.0f) / 2.0f) * (float)(g.W - 1);
+                    const float py = ((gy + 1.0f) / 2.0f) * (float)(g.H - 1);
+                    const float pz = ((gz + 1.0f) / 2.0f) * (float)(g.D - 1);
+                    if (!(fabsf(px) <= 1.0e9f && fabsf(py) <= 1.0e9f && fabsf(pz) <= 1.0e9f)) continue;
+                    const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+                    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
+                    const float wf = (float)w, hf = (float)h, df = (float)d;
+                    const int kx = wf == x0 ? 0 : (wf == x1 ? 1 : -1), ky = hf == y0 ? 0 : (hf == y1 ? 1 : -1);
+                    const int kz = df == z0 ? 0 : (df == z1 ? 1 : -1);
+                    if (kx < 0 || ky < 0) continue;
+                    const float wx = kx ? px - x0 : x1 - px, wy = ky ? py - y0 : y1 - py;
+                    const T *gp = gb + (size_t)i * gvs;
+                    if (kz >= 0 && sf >= 0.0f) {
+                        const float wgt = ((wx * wy) * (kz ? pz - z0 : z1 - pz)) * sf;
+                        float vv[32];
+                        if (gcs == 1) {
+                            gather_row32<T>(gp, vv);
+                        } else {
+#pragma unroll
+                            for (int cc = 0; cc < 32; ++cc) vv[cc] = elem<T>::load(gp[(size_t)cc * gcs]);
+                        }
+#pragma unroll
+                        for (int cc = 0; cc < 32; ++cc) ast[cc] += vv[cc] * wgt;
+                    }
+                    if constexpr (SEM) {
+                        // the semantic map's pixel (h, w): once per voxel, from the hit on its lower depth corner
+                        // (a valid voxel's lower corner is inside the volume); make_tri(gx, gy, 0, 1, H, W): z1 - iz = 1
+                        if (kz == 0 && mf >= 0.0f) {
+                            const float mw = ((wx * wy) * 1.0f) * mf;
+                            float vv[32];
+                            if (gcs == 1) {
+                                gather_row32<T>(gp + 32, vv);
+                            } else {
+#pragma unroll
+                                for (int cc = 0; cc < 32; ++cc) vv[cc] = elem<T>::load(gp[(size_t)(32 + cc) * gcs]);
+                            }
+#pragma unroll
+                            for (int cc = 0; cc < 32; ++cc) asem[cc] += vv[cc] * mw;
+                        }
+                    }
+                }
+            }
+        }
+        if (inside) {
+            float *o = gst + ((size_t)b * g.C * g.D + d) * g.H * g.W + (size_t)h * g.W + w;
+            const size_t cs = (size_t)g.D * g.H * g.W;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) o[(size_t)c * cs] = ast[c];
+        }
+    }
+    if constexpr (SEM) {
+        if (inside) {
+            float *o = gsem + (size_t)b * g.Cs * g.Hsem * g.Wsem + (size_t)h * g.Wsem + w;
+            const size_t cs = (size_t)g.Hsem * g.Wsem;
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+                if (asem[c] != 0.0f) atomicAdd(o + (size_t)c * cs, asem[c]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" DFM_API size_t dfm_frustum_to_voxel_bwd_workspace_bytes(const dfm_f2v_desc *d)
@@ -1090,6 +1324,87 @@ extern "C" DFM_API int dfm_frustum_to_voxel_fused_bwd(const dfm_f2v_desc *d, con
     if (!cost || !col_max || !col_sum) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     return f2v_bwd_impl(d, grad_out, nullptr, FusedHead{cost, col_max, col_sum}, head_scale, coords, cam2img,
                         grad_stereo, grad_sem, workspace, workspace_bytes, stream);
+}
+
+// The gather form of the backward (f2v_bwd_gather_kernel).  grid6 (HOST memory): {x0, dx, y0, dy, z0, dz} of the
+// regular voxel grid `coords` is (the caller has checked it: coords[(iz * Ny + iy) * Nx + ix] == origin + index *
+// step).  grad_stereo is OVERWRITTEN (reference layout, fp32); grad_sem zero-filled by the caller, accumulated.
+// workspace: >= dfm_frustum_to_voxel_bwd_gather_workspace_bytes (8 bytes per voxel).  DFM_ERR_UNSUPPORTED unless
+// C == 32, Cs in {0, 32} with the semantic map at the cost volume's resolution and sem_atten (a voxel outside
+// the depth range then contributes nothing and every contributing voxel has a cell), and non-zero grid steps.
+extern "C" DFM_API size_t dfm_frustum_to_voxel_bwd_gather_workspace_bytes(const dfm_f2v_desc *d)
+{
+    if (!d || d->batch <= 0 || d->nz <= 0 || d->ny <= 0 || d->nx <= 0) return 0;
+    return (((size_t)2 * d->batch * d->nz * d->ny * d->nx * sizeof(float)) + 255) & ~(size_t)255;
+}
+
+extern "C" DFM_API int dfm_frustum_to_voxel_bwd_gather(const dfm_f2v_desc *d, const void *grad_out, const void *softmax,
+                                                       const void *cost, const float *col_max, const float *col_sum,
+                                                       int32_t head_scale, const float *coords, const float *grid6,
+                                                       const float *cam2img, float *grad_stereo, float *grad_sem,
+                                                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
+    if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
+    if (!grad_out || !coords || !grid6 || !cam2img || !grad_stereo || !workspace || (d->sem_channels > 0 && !grad_sem))
+        return set_error(DFM_ERR_INVALID_ARG, "NULL pointer");
+    const bool need_disp = d->stereo_atten || (d->sem_channels > 0 && !d->no_sem_atten);
+    if (need_disp && !softmax && !cost) return set_error(DFM_ERR_INVALID_ARG, "the attended branches need the depth distribution");
+    if (cost && (!col_max || !col_sum)) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (d->channels != 32 || !(d->sem_channels == 0 || (d->sem_channels == 32 && d->hsem == d->h && d->wsem == d->w &&
+                                                          !d->no_sem_atten)) ||
+        d->d < 2 || d->h < 2 || d->w < 2 || grid6[1] == 0.0f || grid6[3] == 0.0f || grid6[5] == 0.0f ||
+        d->batch > 65535 || (d->out_channels_last && ((uintptr_t)grad_out & 15)))
+        return set_error(DFM_ERR_UNSUPPORTED,
+                         "gather backward: C == 32, Cs in {0, 32} at the cost volume's resolution with sem_atten, regular grid");
+    if (workspace_bytes < dfm_frustum_to_voxel_bwd_gather_workspace_bytes(d))
+        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_frustum_to_voxel_bwd_gather_workspace_bytes");
+    F2vGeom g;
+    g.C = d->channels; g.D = d->d; g.H = d->h; g.W = d->w;
+    g.Ds = d->ds; g.Hs = d->hs; g.Ws = d->ws;
+    g.Cs = d->sem_channels; g.Hsem = d->hsem; g.Wsem = d->wsem;
+    g.Nz = d->nz; g.Ny = d->ny; g.Nx = d->nx;
+    g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.depth_min = d->depth_min; g.depth_span = d->depth_span;
+    g.cd = g.ch = g.cw = 0;
+    FusedHead fh{nullptr, nullptr, nullptr};
+    if (cost) {
+        if (head_scale <= 0 || d->ds % head_scale || d->hs % head_scale || d->ws % head_scale)
+            return set_error(DFM_ERR_INVALID_ARG, "ds, hs, ws must be multiples of the depth head's scale");
+        g.cd = d->ds / head_scale; g.ch = d->hs / head_scale; g.cw = d->ws / head_scale;
+        fh = FusedHead{cost, col_max, col_sum};
+    }
+    g.out_cl = d->out_channels_last ? 1 : 0;
+    g.st_att = d->stereo_atten ? 1 : 0;
+    g.sem_att = d->no_sem_atten ? 0 : 1;
+    const F2vGrid gr{grid6[0], grid6[1], grid6[2], grid6[3], grid6[4], grid6[5]};
+    const long long N = (long long)d->nz * d->ny * d->nx;
+    hipStream_t st = (hipStream_t)stream;
+    float *sfac = (float *)workspace, *mfac = sfac + (size_t)d->batch * N;
+    const dim3 pgrid((unsigned)((N + 255) / 256), d->batch);
+    const int CT = d->channels + d->sem_channels;
+    const size_t gvs = g.out_cl ? (size_t)CT : 1, gcs = g.out_cl ? 1 : (size_t)N;
+    const int dchunks = (d->d + F2G_DCH - 1) / F2G_DCH;
+    const dim3 ggrid((unsigned)(((d->w + 63) / 64) * ((d->h + 3) / 4) * dchunks), d->batch);
+#define DFM_F2G(T_)                                                                                              \
+    do {                                                                                                         \
+        hipLaunchKernelGGL(f2v_bwd_prep_kernel<T_>, pgrid, dim3(256), 0, st, g, (const T_ *)softmax, fh, coords, \
+                           cam2img, sfac, mfac);                                                                 \
+        if (d->sem_channels > 0)                                                                                 \
+            hipLaunchKernelGGL((f2v_bwd_gather_kernel<T_, true>), ggrid, dim3(256), 0, st, g, gr, dchunks,       \
+                               (const T_ *)grad_out, gvs, gcs, coords, cam2img, (const float *)sfac,             \
+                               (const float *)mfac, grad_stereo, grad_sem);                                      \
+        else                                                                                                     \
+            hipLaunchKernelGGL((f2v_bwd_gather_kernel<T_, false>), ggrid, dim3(256), 0, st, g, gr, dchunks,      \
+                               (const T_ *)grad_out, gvs, gcs, coords, cam2img, (const float *)sfac,             \
+                               (const float *)mfac, grad_stereo, grad_sem);                                      \
+    } while (0)
+    if (d->dtype == DFM_F32) DFM_F2G(float);
+    else DFM_F2G(bf16_t);
+#undef DFM_F2G
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
 }
 
 // ---------------------------------------------------------------------------

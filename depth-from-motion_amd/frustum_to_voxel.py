@@ -46,6 +46,8 @@ class _F2vFn(torch.autograd.Function):
         go = _grad_in_output_layout(grad_out, desc, dtype)
         g_st = torch.zeros(st_shape, dtype=torch.float32, device=device)
         g_sem = torch.zeros(sem_shape, dtype=torch.float32, device=device) if ctx.has_sem else None
+        if _try_gather_backward(desc, go, soft, None, 0, coords, cam4, g_st, g_sem, device):
+            return g_st.to(dtype), (g_sem.to(dtype) if g_sem is not None else None), None, None, None, None
         nbytes = lib.dfm_frustum_to_voxel_bwd_workspace_bytes(ctypes.byref(desc))
         ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
@@ -93,6 +95,9 @@ class _F2vFusedFn(torch.autograd.Function):
         g_st = torch.zeros(st_shape, dtype=torch.float32, device=device)
         g_sem = torch.zeros(sem_shape, dtype=torch.float32, device=device) if ctx.has_sem else None
         bdesc = desc
+        if _try_gather_backward(desc, go, None, (cost, col_max, col_sum), ctx.scale, coords, cam4, g_st, g_sem, device):
+            return (g_st.to(dtype), (g_sem.to(dtype) if g_sem is not None else None), None, None, None, None, None,
+                    None, None)
         nbytes = lib.dfm_frustum_to_voxel_bwd_workspace_bytes(ctypes.byref(bdesc))
         ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
@@ -102,6 +107,83 @@ class _F2vFusedFn(torch.autograd.Function):
                 _stream_ptr(device)))
         return (g_st.to(dtype), (g_sem.to(dtype) if g_sem is not None else None), None, None, None, None, None,
                 None, None)
+
+
+_GRID_CACHE = {}
+_BWD_GATHER = {'on': __import__('os').environ.get('DFM_NO_F2V_GATHER') != '1'}
+
+
+def bwd_gather(on):
+    """context manager: backward by the gather kernel (default) or the pixel-major scatter (A/B runs, tests)"""
+    import contextlib
+
+    @contextlib.contextmanager
+    def _cm():
+        prev, _BWD_GATHER['on'] = _BWD_GATHER['on'], bool(on)
+        try:
+            yield
+        finally:
+            _BWD_GATHER['on'] = prev
+    return _cm()
+
+
+def _regular_grid(coords, desc):
+    """(x0, dx, y0, dy, z0, dz) if ``coords`` (nz * ny * nx, 3) is the regular grid prepare_coordinates_3d builds
+    (x fastest, centres origin + index * step), else None.  Checked ON THE DEVICE once per tensor (one small
+    reduction and one host read, cached on the tensor's identity and version): the gather form of the backward
+    enumerates voxels by index arithmetic."""
+    key = (coords.data_ptr(), coords._version, tuple(coords.shape), desc.nz, desc.ny, desc.nx)
+    hit = _GRID_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    nz, ny, nx = desc.nz, desc.ny, desc.nx
+    grid = None
+    if coords.numel() == 3 * nz * ny * nx and min(nz, ny, nx) >= 1:
+        c = coords.reshape(nz, ny, nx, 3)
+        o = c[0, 0, 0]
+        dx = (c[0, 0, nx - 1, 0] - o[0]) / max(nx - 1, 1)
+        dy = (c[0, ny - 1, 0, 1] - o[1]) / max(ny - 1, 1)
+        dz = (c[nz - 1, 0, 0, 2] - o[2]) / max(nz - 1, 1)
+        ix = torch.arange(nx, device=c.device, dtype=torch.float32)
+        iy = torch.arange(ny, device=c.device, dtype=torch.float32)
+        iz = torch.arange(nz, device=c.device, dtype=torch.float32)
+        err = torch.stack([(c[..., 0] - (o[0] + ix.view(1, 1, nx) * dx)).abs().max(),
+                           (c[..., 1] - (o[1] + iy.view(1, ny, 1) * dy)).abs().max(),
+                           (c[..., 2] - (o[2] + iz.view(nz, 1, 1) * dz)).abs().max()])
+        vals = torch.cat([torch.stack([o[0], dx, o[1], dy, o[2], dz]), err]).tolist()
+        step = min(abs(vals[1]) if nx > 1 else 1.0, abs(vals[3]) if ny > 1 else 1.0, abs(vals[5]) if nz > 1 else 1.0)
+        if max(vals[6:]) <= 1e-3 * step and all(np.isfinite(vals)) and step > 0:
+            # (an axis of extent 1 has no step: any non-zero value serves the index arithmetic)
+            grid = tuple(v if (i % 2 == 0 or v != 0.0) else 1.0 for i, v in enumerate(vals[:6]))
+    if len(_GRID_CACHE) > 16:
+        _GRID_CACHE.clear()
+    _GRID_CACHE[key] = (grid,)
+    return grid
+
+
+def _try_gather_backward(desc, go, soft, fused, scale, coords, cam4, g_st, g_sem, device):
+    """the gather form of the backward (csrc/frustum_to_voxel.hip: f2v_bwd_gather_kernel); False: not applicable"""
+    if not _BWD_GATHER['on']:
+        return False
+    grid = _regular_grid(coords, desc)
+    if grid is None:
+        return False
+    lib = _capi.lib()
+    nbytes = lib.dfm_frustum_to_voxel_bwd_gather_workspace_bytes(ctypes.byref(desc))
+    ws = _Workspace.get(device, nbytes)
+    g6 = (ctypes.c_float * 6)(*grid)
+    cost, cmax, csum = fused if fused is not None else (None, None, None)
+    with torch.cuda.device(device):
+        rc = lib.dfm_frustum_to_voxel_bwd_gather(
+            ctypes.byref(desc), _ptr(go), _ptr(soft) if soft is not None else None,
+            _ptr(cost) if cost is not None else None, _ptr(cmax) if cmax is not None else None,
+            _ptr(csum) if csum is not None else None, int(scale), _ptr(coords), g6, _ptr(cam4), _ptr(g_st),
+            _ptr(g_sem) if g_sem is not None else None, _ptr(ws), nbytes, _stream_ptr(device))
+    if rc == _capi.DFM_ERR_UNSUPPORTED:
+        return False
+    _capi.check(rc)
+    _BWD_GATHER['calls'] = _BWD_GATHER.get('calls', 0) + 1   # (tests read it: which form took the call)
+    return True
 
 
 def _grad_in_output_layout(grad_out, desc, dtype):

@@ -505,6 +505,22 @@ DFM_API int dfm_frustum_to_voxel_bwd(const dfm_f2v_desc *desc, const void *grad_
                                      const void *softmax, const float *coords,
                                      const float *cam2img, float *grad_stereo, float *grad_sem,
                                      void *workspace, size_t workspace_bytes, void *stream);
+/* The backward as a GATHER (round 5; csrc/frustum_to_voxel.hip: f2v_bwd_gather_kernel): a lane owns a pixel of
+ * the cost volume and a run of depth planes, finds through the REGULAR voxel grid -- grid6, HOST memory:
+ * {x0, dx, y0, dy, z0, dz} with coords[(iz * ny + iy) * nx + ix] == (x0 + ix dx, y0 + iy dy, z0 + iz dz), checked
+ * by the caller -- the voxels whose trilinear footprint holds each cell, confirms every one with the forward's own
+ * arithmetic, gathers the voxel's gradient row and STORES the cell's sum: grad_stereo is OVERWRITTEN (no
+ * zero fill, no atomics); grad_sem (zero-filled by the caller) receives 32 atomics per lane and depth chunk
+ * instead of 128 per voxel.  grad_out in the forward output's layout (desc->out_channels_last).  The depth
+ * distribution: `softmax` (materialised) or `cost` + column statistics + head_scale (fused head), whichever the
+ * forward used; the other NULL.  DFM_ERR_UNSUPPORTED unless channels == 32, sem_channels in {0, 32} at the cost
+ * volume's resolution with sem_atten (the scatter form then takes the call): config K's shapes. */
+DFM_API size_t dfm_frustum_to_voxel_bwd_gather_workspace_bytes(const dfm_f2v_desc *desc);
+DFM_API int dfm_frustum_to_voxel_bwd_gather(const dfm_f2v_desc *desc, const void *grad_out, const void *softmax,
+                                            const void *cost, const float *col_max, const float *col_sum,
+                                            int32_t head_scale, const float *coords, const float *grid6,
+                                            const float *cam2img, float *grad_stereo, float *grad_sem,
+                                            void *workspace, size_t workspace_bytes, void *stream);
 /* The same backward with the depth head fused (training): pred_disp, which scales the gradients of the
  * attended branches, is evaluated from the low-resolution cost + column statistics exactly as
  * dfm_frustum_to_voxel_fused_fwd does; no (B, 1, ds, hs, ws) tensor is read. */

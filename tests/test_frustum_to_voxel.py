@@ -294,3 +294,87 @@ def test_backward_reads_a_channels_last_gradient_in_place(dtype):
         assert float(a.abs().max()) > 0
         tol = 1e-5 if dtype == torch.float32 else 2e-2
         assert torch.allclose(a, b, rtol=tol, atol=tol * float(a.abs().max()))
+
+
+# ---- backward as a gather (dfm_frustum_to_voxel_bwd_gather): a lane per cost-volume pixel x depth chunk -------
+
+def _config_k_like(dtype, seed, Cs=32, yaw=0.0):
+    """a small problem with config K's structure: 32 + 32 channels, the semantic map at the cost volume's
+    resolution, a regular voxel grid (prepare_coordinates_3d's construction), KITTI-like intrinsics on the padded
+    image, materialised and fused depth distributions"""
+    pkg = importlib.import_module('depth-from-motion_amd')
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(seed)
+    D, H, W = 18, 20, 80
+    pad_h, pad_w = 4 * H, 4 * W
+    stereo = torch.randn(1, 32, D, H, W, generator=gen)
+    sem = torch.randn(1, Cs, H, W, generator=gen) if Cs else None
+    cost = (torch.randn(1, 1, D, H, W, generator=gen) * 3).to(dev).to(dtype)
+    dmin, dmax = 2.0, 16.4
+    samples = torch.tensor([dmin + (k + 0.5) * ((dmax - dmin) / (4 * D)) for k in range(4 * D)])
+    # voxel centres: x (depth) 2 .. 16.4 in 0.2 m steps, y -5 .. 5, z -1.5 .. 0.9 (pseudo-LiDAR frame), x fastest
+    nx, ny, nz = 72, 50, 6
+    xs = torch.linspace(dmin + 0.1, dmax - 0.1, nx)
+    ys = torch.linspace(-5 + 0.1, 5 - 0.1, ny)
+    zs = torch.linspace(-1.5 + 0.2, 0.9 - 0.2, nz)
+    zz, yy, xx = torch.meshgrid(zs, ys, xs, indexing='ij')
+    coords = torch.stack([xx, yy, zz], -1)
+    f = 180.0
+    K = np.array([[f, 0, pad_w / 2 - 3.3, 4.4], [0, f, pad_h / 2 + 1.7, 0.2], [0, 0, 1, 0.003], [0, 0, 0, 1]], np.float32)
+    if yaw:
+        K[0, 1] = yaw   # a skewed projection: the (y, z) solve is a genuine 2 x 2 system
+    metas = [{'cam2img': K.tolist(), 'pad_shape': (pad_h, pad_w, 3)}]
+    cfg = dict(depth_min=dmin, depth_max=dmax)
+    _, soft, _ = pkg.depth_head_forward(cost, samples, 4)
+    lazy, _ = pkg.depth_head_statistics(cost, samples, 4)
+    return pkg, dev, stereo, sem, soft, lazy, metas, coords, cfg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('fused', [False, True], ids=['materialised', 'fused_head'])
+@pytest.mark.parametrize('fmt', [torch.contiguous_format, torch.channels_last_3d], ids=['planar', 'channels_last'])
+@pytest.mark.parametrize('Cs,yaw', [(32, 0.0), (32, 9.0), (0, 0.0)])
+def test_backward_gather_equals_the_scatter(dtype, fused, fmt, Cs, yaw):
+    """the same (voxel, corner, weight) set summed in another order: gather (stores + a few atomics) against the
+    pixel-major scatter; materialised and fused depth head, both gradient layouts, a skewed projection, no semantic
+    branch"""
+    f2v = importlib.import_module('depth-from-motion_amd.frustum_to_voxel')
+    pkg, dev, stereo, sem, soft, lazy, metas, coords, cfg = _config_k_like(dtype, 40 + Cs + int(yaw), Cs, yaw)
+    rng = torch.Generator().manual_seed(3)
+    res = {}
+    gout = None
+    for gather in (True, False):
+        st = stereo.to(dev).to(dtype).contiguous(memory_format=fmt).requires_grad_(True)
+        sm = sem.to(dev).to(dtype).requires_grad_(True) if sem is not None else None
+        calls = f2v._BWD_GATHER.get('calls', 0)
+        with f2v.bwd_gather(gather):
+            out = pkg.frustum_to_voxel_sample(st, lazy if fused else soft, metas, sm, coords, cfg)
+            if gout is None:
+                gout = torch.randn(out.shape, generator=rng).to(dev).to(dtype).contiguous(memory_format=fmt)
+            out.backward(gout)
+        torch.cuda.synchronize()
+        assert f2v._BWD_GATHER.get('calls', 0) - calls == (1 if gather else 0), 'which form took the call'
+        res[gather] = (st.grad.float().contiguous(), sm.grad.float() if sm is not None else None)
+    for a, b in zip(res[True], res[False]):
+        if a is None:
+            continue
+        assert float(b.abs().max()) > 0
+        tol = 2e-5 if dtype == torch.float32 else 1.6e-2   # (bf16: the gradients themselves are rounded to bf16)
+        diff = (a - b).abs()
+        assert bool((diff <= tol * b.abs() + tol * float(b.abs().max())).all()), \
+            f'max |diff| {float(diff.max()):.3e} of max |g| {float(b.abs().max()):.3e}, {int((diff > tol * float(b.abs().max())).sum())} cells off'
+
+
+@pytest.mark.gpu
+def test_backward_gather_needs_a_regular_grid_and_says_so():
+    """an irregular voxel grid (jittered centres) is detected on the device and takes the scatter form"""
+    f2v = importlib.import_module('depth-from-motion_amd.frustum_to_voxel')
+    pkg, dev, stereo, sem, soft, lazy, metas, coords, cfg = _config_k_like(torch.float32, 7)
+    desc = type('D', (), dict(nz=coords.shape[0], ny=coords.shape[1], nx=coords.shape[2]))()
+    flat = coords.reshape(-1, 3).to(dev)
+    g = f2v._regular_grid(flat, desc)
+    assert g is not None and abs(g[1] - 0.2) < 1e-4 and abs(g[0] - 2.1) < 1e-4
+    jit = flat.clone()
+    jit[12345, 1] += 0.05
+    assert f2v._regular_grid(jit, desc) is None
