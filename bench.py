@@ -291,6 +291,8 @@ def secondary(args, pkg, dev, job, emit=True):
             # DFM_NO_SWEEP_FUSION=1: the materialised cost volume instead of the fused plane sweep +
             # dres0 / dres0_mono kernel (csrc/sweep_conv.hip) -- the A/B of SURVEY 8f rank 1
             m.fuse_sweep_dres0 = os.environ.get('DFM_NO_SWEEP_FUSION') != '1'
+            # DFM_BACKBONE_ONE_STREAM=1: the stereo and mono stacks on one stream (the A/B of round 5's two streams)
+            m.two_streams = os.environ.get('DFM_BACKBONE_ONE_STREAM') != '1'
             meta = dict(ori_cam2img=KITTI_P2, cur2prevs=torch.from_numpy(poses(1, 2 + rank)),
                         ori_shape=(375, 1242, 3), pad_shape=(320, 1280, 3), crop_offset=[0, 55], flip=False,
                         scale_factor=[1.0])
@@ -357,6 +359,8 @@ def secondary(args, pkg, dev, job, emit=True):
             big = args.workload == 'dfm_neck'
             m = (mods.DfMNeck(in_channels=64, out_channels=256, num_frames=2) if big else
                  mods.OutdoorImVoxelNeck(in_channels=64, out_channels=256)).to(dev).to(torch.bfloat16).eval()
+            if big:
+                m.two_streams = os.environ.get('DFM_BACKBONE_ONE_STREAM') != '1'  # (A/B of round 5's two streams)
             x = torch.randn(1, 128 if big else 64, 220, 300, 12, generator=gen).to(dev).bfloat16() \
                 .contiguous(memory_format=cl)
 

@@ -321,6 +321,44 @@ class DfMBackbone(nn.Module):
             outs.append(cost)
         return outs if outs else [cost]
 
+    # The stereo and the mono aggregation stacks (dfm_backbone.py:175-183 / 189-198) share nothing until
+    # `_predict`: at inference they run on TWO HIP streams (round 5).  Each stack is a chain of ~30 launches --
+    # full-resolution convolutions that leave a quarter of the CUs idle in their second round of workgroups,
+    # hourglass levels of 250 workgroups (half a chip), GroupNorm passes -- and the other stack's kernels fill
+    # what one leaves free.  The side stream waits for what the main stream has produced so far, the main stream
+    # joins it before the prediction heads; scratch is per (device, stream) (plane_sweep._Workspace) and the
+    # side stream's results are handed to the main stream with record_stream.  Training keeps one stream
+    # (autograd replays the forward's streams; nothing there was measured).  two_streams = False pins one stream.
+    two_streams = True
+    _side_streams = {}
+
+    def _two_branches(self, stereo_fn, mono_fn, device):
+        # each branch ends with its own prediction head (dfm_backbone.py:120-127): -> (features, cost)
+        def stereo_all():
+            st = stereo_fn()
+            assert len(st) == 1, 'Only support num_hg=1 for now.'
+            return st, self.pred_stereo[0](st[0])
+
+        def mono_all():
+            mo = mono_fn()
+            assert len(mo) == 1, 'Only support num_hg=1 for now.'
+            return mo, self.pred_mono[0](mo[0])
+        if not (self.two_streams and device.type == 'cuda' and not torch.is_grad_enabled() and
+                not torch.cuda.is_current_stream_capturing()):
+            return stereo_all(), mono_all()
+        main = torch.cuda.current_stream(device)
+        side = DfMBackbone._side_streams.get(device)
+        if side is None:
+            side = DfMBackbone._side_streams[device] = torch.cuda.Stream(device=device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            mono, m_cost = mono_all()
+        stereo, s_cost = stereo_all()
+        main.wait_stream(side)
+        for t in list(mono) + [m_cost]:
+            t.record_stream(main)
+        return (stereo, s_cost), (mono, m_cost)
+
     def _sweep_dres0_fusable(self, cur, prev=None):
         """the fused plane sweep + dres0 / dres0_mono kernel takes this call: inference, bf16 32-channel
         maps, the NDHWC stack, both first blocks Conv3d(-> 32) + GroupNorm(one channel per group) + ReLU"""
@@ -354,9 +392,11 @@ class DfMBackbone(nn.Module):
                 self.feat_sample_factor, self.cost_sample_factor, ori_cam2imgs, cur2prevs[:, 0],
                 meta0['ori_shape'][:2], self._sweep_conv_packed(), meta0.get('flip', False), meta0['crop_offset'],
                 img_scale_factor=meta0.get('scale_factor', [1.0])[0])
-            stereo = self._aggregate_rest(self.dres1, self.hg_stereo, self.dres0.gn(ys, relu=True, partials=ps))
-            mono = self._aggregate_rest(self.dres1_mono, self.hg_mono, self.dres0_mono.gn(ym, relu=True, partials=pm))
-            return self._predict(stereo, mono)
+            stereo, mono = self._two_branches(
+                lambda: self._aggregate_rest(self.dres1, self.hg_stereo, self.dres0.gn(ys, relu=True, partials=ps)),
+                lambda: self._aggregate_rest(self.dres1_mono, self.hg_mono,
+                                             self.dres0_mono.gn(ym, relu=True, partials=pm)), ys.device)
+            return self._predict(*stereo, *mono)
         # plane sweep: HIP kernel (reference: build_dfm_cost, batch semantics per sample)
         cost_raw = build_dfm_cost(
             cur_stereo_feats, prev_stereo_feats,
@@ -365,15 +405,13 @@ class DfMBackbone(nn.Module):
             meta0.get('flip', False), meta0['crop_offset'],
             img_scale_factor=meta0.get('scale_factor', [1.0])[0],
             memory_format=self.volume_memory_format)
-        stereo = self._aggregate(self.dres0, self.dres1, self.hg_stereo, cost_raw)
-        mono = self._aggregate(self.dres0_mono, self.dres1_mono, self.hg_mono,
-                               channel_slice(cost_raw, 0, self.in_channels))
-        return self._predict(stereo, mono)
+        stereo, mono = self._two_branches(
+            lambda: self._aggregate(self.dres0, self.dres1, self.hg_stereo, cost_raw),
+            lambda: self._aggregate(self.dres0_mono, self.dres1_mono, self.hg_mono,
+                                    channel_slice(cost_raw, 0, self.in_channels)), cost_raw.device)
+        return self._predict(*stereo, *mono)
 
-    def _predict(self, stereo, mono):
-        assert len(stereo) == 1 and len(mono) == 1, 'Only support num_hg=1 for now.'
-        s_cost = self.pred_stereo[0](stereo[0])
-        m_cost = self.pred_mono[0](mono[0])
+    def _predict(self, stereo, s_cost, mono, m_cost):
         both = torch.cat((s_cost, m_cost), dim=1).flatten(start_dim=1, end_dim=2)
         if both.is_cuda:
             # the 1x1 Conv2d(2D -> D) as a GEMM over the flattened image (hipBLASLt forward and
@@ -607,10 +645,28 @@ class DfMNeck(nn.Module):
         self.stereo_layers = _bev_stack(widths[0] * num_frames, widths, out_channels, norm_cfg)
         self.aggregate_layer = nn.Conv2d(2 * out_channels, 1, kernel_size=1, bias=False)
 
+    two_streams = True
+
     def forward(self, x):
         assert x.shape[1] == self.in_channels[0] * self.num_frames
-        mono = _to_bev(self.mono_layers(channel_slice(x, 0, self.in_channels[0])))
-        stereo = _to_bev(self.stereo_layers(x))
+        # the mono and the stereo stacks (dfm_neck.py:108-111) are independent: two HIP streams at inference, like
+        # DfMBackbone's branches (the stacks' launches are 4.2 rounds of workgroups each: one fills the other's
+        # last round); two_streams = False pins one stream
+        if (self.two_streams and x.is_cuda and not torch.is_grad_enabled() and
+                not torch.cuda.is_current_stream_capturing()):
+            main = torch.cuda.current_stream(x.device)
+            side = DfMBackbone._side_streams.get(x.device)
+            if side is None:
+                side = DfMBackbone._side_streams[x.device] = torch.cuda.Stream(device=x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                mono = _to_bev(self.mono_layers(channel_slice(x, 0, self.in_channels[0])))
+            stereo = _to_bev(self.stereo_layers(x))
+            main.wait_stream(side)
+            mono.record_stream(main)
+        else:
+            mono = _to_bev(self.mono_layers(channel_slice(x, 0, self.in_channels[0])))
+            stereo = _to_bev(self.stereo_layers(x))
         # 1x1 Conv2d(2 C_out -> 1): MIOpen's kernel for this shape is a 58 ms naive convolution in
         # bf16 (profiles/r02_c26_*); it is a weighted channel sum of the two maps
         w = self.aggregate_layer.weight.view(2, -1, 1, 1).to(mono.dtype)
