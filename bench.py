@@ -615,8 +615,8 @@ def secondary_block(pkg, sweep, dev, job, budget_s=45.0):
     import types
     out = {}
     t_start = time.perf_counter()
-    for wl in ('sweep_bwd', 'kitti_nhwc', 'sweep_bwd_kitti', 'f2v_cl', 'backbone', 'neck', 'nstar_negzero',
-               'nstar_negzero_all'):
+    for wl in ('sweep_bwd', 'kitti_nhwc', 'sweep_bwd_kitti', 'sweep_bwd_kitti_cl', 'f2v_cl', 'backbone', 'neck',
+               'dfm_neck', 'backbone_train', 'waymo_cl', 'nstar_negzero', 'nstar_negzero_all'):
         if time.perf_counter() - t_start > budget_s:
             out[wl] = {'skipped': 'wall-clock budget of the secondary block spent'}
             continue

@@ -330,6 +330,9 @@ class DfMBackbone(nn.Module):
     # side stream's results are handed to the main stream with record_stream.  Training keeps one stream
     # (autograd replays the forward's streams; nothing there was measured).  two_streams = False pins one stream.
     two_streams = True
+    # with autograd recording: every backward node runs on the stream its forward ran on (the engine inserts the
+    # cross-stream waits), so the two stacks overlap in the backward pass as well
+    two_streams_training = os.environ.get('DFM_TRAIN_ONE_STREAM') != '1'
     _side_streams = {}
 
     def _two_branches(self, stereo_fn, mono_fn, device):
@@ -343,7 +346,8 @@ class DfMBackbone(nn.Module):
             mo = mono_fn()
             assert len(mo) == 1, 'Only support num_hg=1 for now.'
             return mo, self.pred_mono[0](mo[0])
-        if not (self.two_streams and device.type == 'cuda' and not torch.is_grad_enabled() and
+        if not (self.two_streams and device.type == 'cuda' and
+                (self.two_streams_training or not torch.is_grad_enabled()) and
                 not torch.cuda.is_current_stream_capturing()):
             return stereo_all(), mono_all()
         main = torch.cuda.current_stream(device)
