@@ -508,8 +508,13 @@ def test_channels_last_gradient_without_a_torch_layout_conversion(pkg, shape, fs
             calls.append(real(*a))
             return calls[-1]
     lib.dfm_plane_sweep_bwd_channels_last = Spy()
+    sweep = importlib.import_module('depth-from-motion_amd.plane_sweep')
     try:
-        out.backward(g.contiguous(memory_format=torch.channels_last_3d))
+        # (strided sweeps with whole 32-channel passes take the gather kernel since round 5 -- it reads the
+        #  channels-last volume in place by construction, tests/test_sweep_walk_gpu.py; pinned off here: this
+        #  test is about the re-layout / strided-read forms of the older entry point)
+        with sweep.prev_gather(False):
+            out.backward(g.contiguous(memory_format=torch.channels_last_3d))
     finally:
         lib.dfm_plane_sweep_bwd_channels_last = real
     assert calls == [0]
