@@ -125,6 +125,7 @@ class GradientBucketReducer:
         self._flat = [None] * len(self.buckets)
         self._ready = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
+        self._copied = [[] for _ in self.buckets]  # events of the gradient copies into each bucket (CUDA)
         self._next = 0  # first bucket not launched yet
         self._filled = set()
         self.launched_during_backward = 0
@@ -143,6 +144,11 @@ class GradientBucketReducer:
                                                   self._ready[self._next] == len(self.buckets[self._next])):
             bi = self._next
             buf = self._buffer(bi)
+            if self._copied[bi]:
+                cur = torch.cuda.current_stream(buf.device)
+                for ev in self._copied[bi]:
+                    cur.wait_event(ev)
+                self._copied[bi] = []
             if _active():
                 self._work[bi] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
             if not final:
@@ -157,6 +163,12 @@ class GradientBucketReducer:
             raise RuntimeError('GradientBucketReducer: call finalize() after every backward()')
         self._filled.add(p)
         self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        if p.grad.is_cuda:
+            # backward nodes run on the stream their forward ran on (DfMBackbone's two stacks use two): the copy
+            # above is ordered on THIS hook's stream only -- the stream that launches the bucket waits for it
+            ev = torch.cuda.Event()
+            ev.record()
+            self._copied[bi].append(ev)
         self._ready[bi] += 1
         self._launch_ready()
 

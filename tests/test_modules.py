@@ -313,9 +313,15 @@ def _wide_inputs():
                 dfmneck=torch.randn(1, 128, 10, 12, 12, generator=gen))
 
 
-def _close_bf16(got, ref):
-    """bf16 activations through 6-8 convolution layers: 5 % relative + 3 % of the output range"""
-    np.testing.assert_allclose(got, ref, rtol=5e-2, atol=0.03 * float(np.abs(ref).max()))
+# 2x the largest values measured on MI355X in round 5 (max 0.0128 of full scale, rms 0.0088; the bar was
+# rtol 5e-2 + 3 % of full scale before): bf16 activations through 6-8 convolution layers
+BF16_MODULE_MAX, BF16_MODULE_RMS = 0.026, 0.018
+
+
+def _close_bf16(got, ref, what='module'):
+    """bf16 activations through 6-8 convolution layers against the reference module's fp32 output"""
+    e_max, e_rms = util.bf16_end_to_end_error(got, ref, what)
+    assert e_max <= BF16_MODULE_MAX and e_rms <= BF16_MODULE_RMS, (e_max, e_rms)
 
 
 @pytest.mark.gpu

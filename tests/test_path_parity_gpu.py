@@ -29,6 +29,9 @@ from tests import util
 pytestmark = pytest.mark.gpu
 CONV_TOL = dict(rtol=1e-3, atol=1e-4)
 BF16_BAR = 2.0 ** -7
+# whole MultiViewVoxelPath in bf16 vs the reference's fp32 output: 2x what the suite measures on MI355X
+# (round 5: max |d| / max |ref| 0.0098, rms 0.0075; the bar was rtol 5e-2 + 3 % of full scale)
+BF16_PATH_MAX, BF16_PATH_RMS = 0.02, 0.016
 
 
 @pytest.fixture(scope='module')
@@ -131,7 +134,8 @@ def test_multiview_voxel_path_mfma_vs_reference_detector_and_neck(pkg, cv, cfgs,
     assert calls['g'] == launches, calls
     assert out.dtype == torch.bfloat16 and out.shape == z['ref_out'].shape
     ref = z['ref_out']
-    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=5e-2, atol=0.03 * float(np.abs(ref).max()))
+    e_max, e_rms = util.bf16_end_to_end_error(out.float().cpu().numpy(), ref, 'MultiViewVoxelPath ' + name)
+    assert e_max <= BF16_PATH_MAX and e_rms <= BF16_PATH_RMS, (e_max, e_rms)
 
 
 # ---------------------------------------------------------------------------------------------
