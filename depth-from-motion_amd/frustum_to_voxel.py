@@ -2,7 +2,9 @@
 (mmdet3d/models/necks/feature_transformation.py:82-158): one HIP launch
 (``dfm_frustum_to_voxel_fwd``) produces cat(Voxel, Voxel_2D), the input of
 ``voxel_convs``."""
+import contextlib
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -110,21 +112,17 @@ class _F2vFusedFn(torch.autograd.Function):
 
 
 _GRID_CACHE = {}
-_BWD_GATHER = {'on': __import__('os').environ.get('DFM_NO_F2V_GATHER') != '1'}
+_BWD_GATHER = {'on': os.environ.get('DFM_NO_F2V_GATHER') != '1'}
 
 
+@contextlib.contextmanager
 def bwd_gather(on):
-    """context manager: backward by the gather kernel (default) or the pixel-major scatter (A/B runs, tests)"""
-    import contextlib
-
-    @contextlib.contextmanager
-    def _cm():
-        prev, _BWD_GATHER['on'] = _BWD_GATHER['on'], bool(on)
-        try:
-            yield
-        finally:
-            _BWD_GATHER['on'] = prev
-    return _cm()
+    """backward by the gather kernel (default) or the pixel-major scatter (A/B runs, tests)"""
+    prev, _BWD_GATHER['on'] = _BWD_GATHER['on'], bool(on)
+    try:
+        yield
+    finally:
+        _BWD_GATHER['on'] = prev
 
 
 def _regular_grid(coords, desc):
