@@ -22,6 +22,8 @@ Three ways to use this package from there, all routed to the HIP kernels:
 """
 import importlib
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -105,6 +107,8 @@ class DfMStereoPath(nn.Module):
         self.hip_graphs = False
         self._graphed = {}
 
+    two_streams = os.environ.get('DFM_PATH_ONE_STREAM') != '1'
+
     def _run_2d(self, name, module, tensors):
         """module(tensors) -- through a captured hipGraph when ``hip_graphs`` is on and nothing records
         gradients.  Each call site has its own graph (the outputs are static buffers: the neck's
@@ -118,8 +122,25 @@ class DfMStereoPath(nn.Module):
         return g(tensors)
 
     def forward(self, cur_feats, prev_feats, img_metas):
-        cur_stereo, cur_sem = self._run_2d('neck_cur', self.neck, list(cur_feats))
-        prev_stereo, _ = self._run_2d('neck_prev', self.neck, list(prev_feats))
+        # the two frames' 2-D necks are independent calls of the same module: at inference (eval mode: no running
+        # statistics to update, nothing recorded) the previous frame's runs on a side HIP stream
+        if (self.two_streams and cur_feats[0].is_cuda and not torch.is_grad_enabled() and not self.training and
+                not torch.cuda.is_current_stream_capturing()):
+            from .modules import DfMBackbone
+            d0 = cur_feats[0].device
+            main = torch.cuda.current_stream(d0)
+            side = DfMBackbone._side_streams.get(d0)
+            if side is None:
+                side = DfMBackbone._side_streams[d0] = torch.cuda.Stream(device=d0)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                prev_stereo, _ = self._run_2d('neck_prev', self.neck, list(prev_feats))
+            cur_stereo, cur_sem = self._run_2d('neck_cur', self.neck, list(cur_feats))
+            main.wait_stream(side)
+            prev_stereo.record_stream(main)
+        else:
+            cur_stereo, cur_sem = self._run_2d('neck_cur', self.neck, list(cur_feats))
+            prev_stereo, _ = self._run_2d('neck_prev', self.neck, list(prev_feats))
         dev = cur_stereo.device
         for meta in img_metas:  # dfm.py:288-293: (N-1,4,4) tensors on the device
             meta['cur2prevs'] = torch.as_tensor(np.asarray(meta['cur2prevs'], dtype=np.float32)
