@@ -547,6 +547,26 @@ def secondary(args, pkg, dev, job, emit=True):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    graphed = False
+    if os.environ.get('DFM_BENCH_GRAPH') == '1' and args.workload in ('backbone', 'neck', 'dfm_neck'):
+        # the inference step captured ONCE into a HIP graph and replayed: the same launches on the same
+        # streams, without the ~100 host-side launch calls per step (matrices staged on the device first: a
+        # capture takes no host-to-device copies)
+        if args.workload == 'backbone':
+            importlib.import_module('depth-from-motion_amd.data_geometry').stage_geometry([meta], dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = step()
+        eager_step, step, graphed = step, graph.replay, True
+        step()
+        torch.cuda.synchronize()
     if comm is not None:
         # the same step WITHOUT the gradient exchange, timed first: what the all-reduce adds on top of
         # it in the headline below is the communication that backward did not hide
@@ -593,6 +613,8 @@ def secondary(args, pkg, dev, job, emit=True):
         'roofline': roof, 'per_rank_ms_per_step': [round(v * 1e3 / args.steps, 4) for v in every],
         **rank_census(job),
         **({'gradient_exchange': comm} if comm is not None else {})}
+    if graphed:
+        line['config']['hip_graph_replay'] = True
     if args.workload.startswith('sweep_bwd'):
         # 1 scatter, 5 LDS-atomic tiles, 6 matrix product
         line['config']['bwd_kernel'] = int(pkg._capi.lib().dfm_plane_sweep_bwd_last_kernel())

@@ -61,6 +61,9 @@ EXPORTS = (
     'dfm_sweep_conv_pack_weights',
     'dfm_sweep_conv_stats_splits',
     'dfm_sweep_conv_fwd',
+    'dfm_cost_gate_weight_bytes',
+    'dfm_cost_gate_pack_weights',
+    'dfm_cost_gate_fwd',
     'dfm_conv3d_k3_c32_weight_bytes',
     'dfm_conv3d_k3_c32_pack_weights',
     'dfm_conv3d_k3_c32_stats_splits',
@@ -330,6 +333,12 @@ def lib():
     h.dfm_sweep_conv_stats_splits.argtypes = [dp, i32]
     h.dfm_sweep_conv_fwd.restype = ctypes.c_int
     h.dfm_sweep_conv_fwd.argtypes = [dp, vp, vp, fp, fp, fp, fp, vp, vp, vp, fp, fp, i32, vp]
+    h.dfm_cost_gate_fwd.restype = ctypes.c_int
+    h.dfm_cost_gate_fwd.argtypes = [i32, i32, ctypes.c_int64, i32, vp, vp, vp, vp, vp]
+    h.dfm_cost_gate_weight_bytes.restype = sz
+    h.dfm_cost_gate_weight_bytes.argtypes = [i32]
+    h.dfm_cost_gate_pack_weights.restype = ctypes.c_int
+    h.dfm_cost_gate_pack_weights.argtypes = [vp, i32, i32, vp, vp]
     h.dfm_conv3d_k3_c32_weight_bytes.restype = sz
     h.dfm_conv3d_k3_c32_pack_weights.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_pack_weights.argtypes = [vp, i32, i32, i32, i32, vp, vp]

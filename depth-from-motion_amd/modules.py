@@ -37,7 +37,7 @@ from .frustum_to_voxel import frustum_to_voxel_sample
 from .geometry import stack_meta
 from .group_norm import HipBatchNorm3d, HipGroupNorm
 from . import _capi
-from .plane_sweep import _Workspace, build_dfm_cost
+from .plane_sweep import _DTYPES, _Workspace, _ptr, _stream_ptr, build_dfm_cost
 from .sweep_conv import pack_sweep_conv_weights, sweep_conv_supported, sweep_dres0
 from .registry import register_module
 
@@ -415,7 +415,38 @@ class DfMBackbone(nn.Module):
                                     channel_slice(cost_raw, 0, self.in_channels)), cost_raw.device)
         return self._predict(*stereo, *mono)
 
+    # DFM_GATE_TORCH=1 keeps the torch sequence of the gate at inference too (A/B runs)
+    fused_gate = os.environ.get('DFM_GATE_TORCH') != '1'
+
+    def _gate_fused(self, s_cost, m_cost):
+        """cat + Conv2d(2D -> D, 1x1) + sigmoid + blend (dfm_backbone.py:136-141) as one launch
+        (csrc/cost_gate.hip): inference, both costs (B, 1, D, H, W) contiguous on the GPU; None otherwise."""
+        w = self.aggregate_cost.weight
+        if not (self.fused_gate and s_cost.is_cuda and not torch.is_grad_enabled() and s_cost.dtype in _DTYPES
+                and w.dtype in _DTYPES and m_cost.dtype == s_cost.dtype and m_cost.shape == s_cost.shape
+                and s_cost.dim() == 5 and s_cost.shape[1] == 1 and s_cost.shape[2] <= 96
+                and s_cost.is_contiguous() and m_cost.is_contiguous() and w.is_contiguous()
+                and w.shape[0] == s_cost.shape[2] and w.shape[1] == 2 * s_cost.shape[2]):
+            return None
+        B, _, D, H, W = s_cost.shape
+        lib = _capi.lib()
+        out = torch.empty_like(s_cost)
+        key = (w._version, w.data_ptr(), str(w.device), w.dtype)
+        with torch.cuda.device(s_cost.device):
+            if self.__dict__.get('_gate_pack', (None, None))[0] != key:  # packed once per weight version
+                packed = torch.empty(lib.dfm_cost_gate_weight_bytes(D), dtype=torch.uint8, device=w.device)
+                _capi.check(lib.dfm_cost_gate_pack_weights(_ptr(w.detach()), _DTYPES[w.dtype], D, _ptr(packed),
+                                                           _stream_ptr(s_cost.device)))
+                self.__dict__['_gate_pack'] = (key, packed)
+            _capi.check(lib.dfm_cost_gate_fwd(B, D, H * W, _DTYPES[s_cost.dtype], _ptr(s_cost), _ptr(m_cost),
+                                              _ptr(self.__dict__['_gate_pack'][1]), _ptr(out),
+                                              _stream_ptr(s_cost.device)))
+        return out
+
     def _predict(self, stereo, s_cost, mono, m_cost):
+        fused = self._gate_fused(s_cost, m_cost)
+        if fused is not None:
+            return fused, stereo[0], mono[0]
         both = torch.cat((s_cost, m_cost), dim=1).flatten(start_dim=1, end_dim=2)
         if both.is_cuda:
             # the 1x1 Conv2d(2D -> D) as a GEMM over the flattened image (hipBLASLt forward and

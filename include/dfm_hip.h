@@ -623,6 +623,25 @@ DFM_API int dfm_sweep_conv_fwd(const dfm_sweep_desc *desc, const void *cur_nhwc,
                                void *stream);
 
 /* ---------------------------------------------------------------------- */
+/* The gate of DfMBackbone.forward (dfm_backbone.py:136-141)                   */
+/* ---------------------------------------------------------------------- */
+/*
+ * out = g * stereo + (1 - g) * mono,  g = sigmoid(W . cat(stereo, mono)) per pixel -- the reference's
+ * cat + Conv2d(2D -> D, kernel 1, bias=False) + sigmoid + blend as ONE launch (inference; fp32 arithmetic,
+ * one rounding at the store).
+ * stereo, mono, out : (batch, num_depths, hw) contiguous, DFM_F32 or DFM_BF16 (`dtype`)      [device]
+ * weight            : (num_depths, 2 * num_depths) row-major, DFM_F32 or DFM_BF16, packed once per weight
+ *                     version into dfm_cost_gate_weight_bytes(num_depths) bytes (fp32, plane-major) [device]
+ * num_depths <= 96 (DFM_ERR_UNSUPPORTED / 0 bytes otherwise: run the torch sequence).
+ */
+DFM_API size_t dfm_cost_gate_weight_bytes(int32_t num_depths);
+DFM_API int dfm_cost_gate_pack_weights(const void *weight, int32_t weight_dtype, int32_t num_depths,
+                                       void *packed, void *stream);
+DFM_API int dfm_cost_gate_fwd(int32_t batch, int32_t num_depths, int64_t hw, int32_t dtype,
+                              const void *stereo, const void *mono, const void *packed_weights,
+                              void *out, void *stream);
+
+/* ---------------------------------------------------------------------- */
 /* MFMA Conv3d 3x3x3, stride 1, pad 1, 32 -> 32 channels, NDHWC bf16         */
 /* (ConvModule / convbn_3d of the aggregation stacks: dfm_backbone.py:50-128, */
 /*  utils/conv_modules.py:27-43)                                              */
