@@ -15,6 +15,7 @@ Backward: the input gradient runs in the same MFMA kernel (transposed, mirrored 
 fragments); the weight gradient is torch's convolution backward (MIOpen).
 """
 import ctypes
+import os
 import warnings
 
 import torch
@@ -248,6 +249,67 @@ def _mm_f32(a, b):
     if _MM_OUT_DTYPE[0]:
         return torch.mm(a, b, out_dtype=torch.float32)
     return torch.mm(a, b).float()
+
+
+_BMM_OUT_DTYPE = [None]
+_SPLIT_LONG_AXIS = os.environ.get('DFM_PLAIN_WGRAD_1X1') != '1'
+
+
+def _bmm_f32(a, b):
+    if a.dtype == torch.float32:
+        return torch.bmm(a, b)
+    if _BMM_OUT_DTYPE[0] is None:
+        try:
+            r = torch.bmm(a, b, out_dtype=torch.float32)
+            _BMM_OUT_DTYPE[0] = True
+            return r
+        except (RuntimeError, TypeError, NotImplementedError):
+            _BMM_OUT_DTYPE[0] = False
+    if _BMM_OUT_DTYPE[0]:
+        return torch.bmm(a, b, out_dtype=torch.float32)
+    return torch.bmm(a, b).float()
+
+
+def long_axis_gram(a, b, rows_per_batch=2048):
+    """``a``: (P, M), ``b``: (P, N), any strides, P long and M, N small -> ``a.t() @ b`` as (M, N) float32.
+    The weight gradient of a 1x1 convolution (P = pixels) is such a product; as ONE library GEMM it is a
+    handful of output tiles each walking the whole P axis (M = N = 32, P = 409 600 -- ``lastconv`` of
+    SPPUNetNeck at config K: hipBLASLt MT16x32x512, 2 workgroups, 0.36 ms per call, two calls per training
+    step).  Here P is cut into batches of ~``rows_per_batch`` rows -- a batched GEMM of S x (M x N) tiles, fp32
+    partial products where the build has ``out_dtype`` -- and the S partials are summed in fp32."""
+    P = a.shape[0]
+    S = max(1, min(512, P // max(1, rows_per_batch))) if _SPLIT_LONG_AXIS else 1  # (DFM_PLAIN_WGRAD_1X1=1: A/B runs)
+    while S > 1 and P % S:
+        S -= 1
+    if S < 4:
+        return _mm_f32(a.t(), b) if a.dtype != torch.float32 else torch.mm(a.t(), b)
+    ab = a.reshape(S, P // S, a.shape[1]).transpose(1, 2)   # (S, M, P/S)
+    bb = b.reshape(S, P // S, b.shape[1])                   # (S, P/S, N)
+    return _bmm_f32(ab, bb).sum(0)
+
+
+class _PixelLinearFn(torch.autograd.Function):
+    """``F.linear`` over the pixel rows of an NHWC tensor (a 1x1 convolution), with the weight gradient as a
+    batched product over slices of the pixel axis (``long_axis_gram``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.matmul(gy, weight)
+        g2 = gy.reshape(-1, gy.shape[-1])
+        if ctx.needs_input_grad[1]:
+            gw = long_axis_gram(g2, x.reshape(-1, x.shape[-1])).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0, dtype=torch.float32).to(weight.dtype)
+        return gx, gw, gb
 
 
 def _ndhwc_strides(t):
@@ -1016,7 +1078,11 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
             # a 1x1 convolution of an NHWC tensor IS a matrix product over its pixel rows: hipBLASLt forward
             # and backward instead of MIOpen's NHWC kernels (naive on this stack: 14 ms per call,
             # profiles/r03_c43_*); the result is the same channels_last tensor torch would return
-            y = F.linear(x.permute(0, 2, 3, 1), self.weight.view(self.out_channels, self.in_channels), self.bias)
+            w2 = self.weight.view(self.out_channels, self.in_channels)
+            if torch.is_grad_enabled() and self.weight.requires_grad:
+                y = _PixelLinearFn.apply(x.permute(0, 2, 3, 1), w2, self.bias)
+            else:
+                y = F.linear(x.permute(0, 2, 3, 1), w2, self.bias)
             return y.permute(0, 3, 1, 2)
         recording = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)
         if recording:

@@ -30,7 +30,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import (MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose2d,
+from .conv3d import (long_axis_gram, MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose2d,
                      MfmaConvTranspose3d, channel_slice)
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
@@ -452,11 +452,35 @@ class DfMBackbone(nn.Module):
             # the 1x1 Conv2d(2D -> D) as a GEMM over the flattened image (hipBLASLt forward and
             # backward): MIOpen's kernels for this shape are naive fallbacks in bf16 (1.2 ms backward-weight)
             w2 = self.aggregate_cost.weight.flatten(1)
-            gate = torch.matmul(w2, both.flatten(2)).view(both.shape[0], -1, *both.shape[2:])
+            if torch.is_grad_enabled() and w2.requires_grad:
+                gate = _GateLogitsFn.apply(w2, both.flatten(2)).view(both.shape[0], -1, *both.shape[2:])
+            else:
+                gate = torch.matmul(w2, both.flatten(2)).view(both.shape[0], -1, *both.shape[2:])
             gate = gate.unsqueeze(dim=1).sigmoid()
         else:
             gate = self.aggregate_cost(both).unsqueeze(dim=1).sigmoid()
         return gate * s_cost + (1 - gate) * m_cost, stereo[0], mono[0]
+
+
+class _GateLogitsFn(torch.autograd.Function):
+    """``w2 @ both`` (the 1x1 Conv2d(2D -> D) of the gate as a GEMM over the flattened image) whose weight gradient is a
+    batched product over slices of the pixel axis (``conv3d.long_axis_gram``: D x 2D output tiles that each walk all
+    H * W pixels are a few workgroups for the whole chip)."""
+
+    @staticmethod
+    def forward(ctx, w2, both):
+        ctx.save_for_backward(w2, both)
+        return torch.matmul(w2, both)
+
+    @staticmethod
+    def backward(ctx, g):
+        w2, both = ctx.saved_tensors
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gb = torch.matmul(w2.t(), g)
+        if ctx.needs_input_grad[0]:
+            gw = sum(long_axis_gram(g[i].t(), both[i].t()) for i in range(g.shape[0])).to(w2.dtype)
+        return gw, gb
 
 
 # --------------------------------------------------------------------------
