@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where do the ATen layout copies of a DfMStereoPath bf16 training step come from?  One profiled step
 (torch.profiler, with_stack), `aten::copy_` / `aten::contiguous` / `aten::clone` device time grouped by the innermost
-frame inside this repository.  GPU box.  usage: python tools/train_copy_sources.py"""
+frame inside this repository.  GPU box.  usage: python tools/train_copy_sources.py [--all]"""
 import collections
 import importlib
 import json
@@ -55,8 +55,11 @@ def main():
     by_site = collections.defaultdict(lambda: [0.0, 0])
     total = 0.0
     for ev in prof.events():
-        if ev.name not in ('aten::copy_', 'aten::clone', 'aten::contiguous', 'aten::_to_copy', 'aten::add', 'aten::add_',
-                           'aten::fill_', 'aten::zero_'):
+        if '--all' in sys.argv:  # every ATen operator with device time of its own (what is left on torch)
+            if not ev.name.startswith('aten::'):
+                continue
+        elif ev.name not in ('aten::copy_', 'aten::clone', 'aten::contiguous', 'aten::_to_copy', 'aten::add', 'aten::add_',
+                             'aten::fill_', 'aten::zero_'):
             continue
         t = getattr(ev, 'self_device_time_total', None)
         if t is None:
