@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""MFMA weight gradient (csrc/conv3d_wgrad.hip) on the layer shapes of the path.  GPU box."""
+"""Time of the MFMA weight-gradient launch (csrc/conv3d_wgrad.hip) on the convolution shapes of config K's backbone.
+usage: [DFM_WGRAD_WALK=0|1] [DFM_WGRAD_CHUNK=n] python tools/wgrad_timing.py"""
 import importlib
 import os
 import sys
@@ -7,37 +8,29 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-cv = importlib.import_module('depth-from-motion_amd.conv3d')
-dev = torch.device('cuda:0')
-CASES = [  # name, a (g channels), b (x channels), x size, stride, padding
-    ('dres1 32->32', 32, 32, (72, 80, 320), 1, 1),
-    ('hg.conv1 32->64 s2', 64, 32, (72, 80, 320), 2, 1),
-    ('hg.conv2 64->64', 64, 64, (36, 40, 160), 1, 1),
-    ('neck 64->64', 64, 64, (220, 300, 12), 1, 1),
-    ('neck 64->128 s(1,1,2)', 128, 64, (220, 300, 12), (1, 1, 2), 1),
-    ('neck 128->128', 128, 128, (220, 300, 6), 1, 1),
-    ('neck 256->256', 256, 256, (220, 300, 3), 1, 1),
-]
 
 
 def main():
-    for name, a, b, size, stride, padding in CASES:
-        st, pd = cv._triple(stride), cv._triple(padding)
-        osz = cv.conv3d_g_out_size(size, st, pd, (False,) * 3)
-        x = torch.randn(1, b, *size, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
-        g = torch.randn(1, a, *osz, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+    cv = importlib.import_module('depth-from-motion_amd.conv3d')
+    dev = torch.device('cuda:0')
+    cl = torch.channels_last_3d
+    for (a, b, size, stride) in ((32, 32, (72, 80, 320), 1), (64, 32, (72, 80, 320), 2), (64, 64, (36, 40, 160), 1)):
+        x = torch.randn(1, b, *size, device=dev).bfloat16().contiguous(memory_format=cl)
+        osz = tuple((s - 1) // stride + 1 for s in size)
+        gy = torch.randn(1, a, *osz, device=dev).bfloat16().contiguous(memory_format=cl)
         for _ in range(3):
-            cv.conv3d_weight_grad(x, g, st, pd)
+            cv.conv3d_weight_grad(x, gy, stride, 1)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
-            cv.conv3d_weight_grad(x, g, st, pd)
+        for _ in range(20):
+            cv.conv3d_weight_grad(x, gy, stride, 1)
         e1.record()
         torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / 10
-        flops = 2 * 27 * a * b * osz[0] * osz[1] * osz[2]
-        print(f'{name:24s} {str(size):16s} {t:7.3f} ms {flops / t / 1e9:7.1f} TFLOP/s ({flops / t / 1e9 / 25:4.1f} %)', flush=True)
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        flops = 2.0 * 27 * a * b * osz[0] * osz[1] * osz[2]
+        print('wgrad %d<-%d %s stride %d: %.1f us  %.0f TFLOP/s (kernel + reduce)  walk=%s chunk=%s' % (
+            a, b, size, stride, us, flops / us / 1e6, os.environ.get('DFM_WGRAD_WALK', '-'), os.environ.get('DFM_WGRAD_CHUNK', '-')))
 
 
 if __name__ == '__main__':
