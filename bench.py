@@ -105,7 +105,7 @@ KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0
 
 # secondary workloads (other rows of SURVEY.md 8a), reported with the same JSON shape
 SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd_kitti', 'sweep_bwd_kitti_cl', 'voxel_sample', 'voxel_sample_bwd',
-             'backbone', 'backbone_train', 'neck', 'dfm_neck',
+             'backbone', 'backbone_train', 'neck', 'dfm_neck', 'stereo_infer', 'stereo_train',
              # the same rows in the layout the bf16 NDHWC pipeline hands them (channels-last sources
              # sampled in place, channels-last results for the MFMA convolutions that follow)
              'waymo_cl', 'depth_head_bf16', 'f2v_cl', 'group_norm_cl')
@@ -371,6 +371,57 @@ def secondary(args, pkg, dev, job, emit=True):
             name = ('DfMNeck' if big else 'OutdoorImVoxelNeck') + \
                 '.forward config W (220x300x12 voxels, eval: BN folded into the MFMA conv epilogue, bf16 NDHWC)'
             unit = 'voxel-volumes/s'
+    elif args.workload in ('stereo_infer', 'stereo_train'):
+        # the WHOLE stereo path of configs/dfm/dfm_r34_1x8_kitti-3d-3class.py at config K (one 320 x 1280 frame
+        # pair): SPPUNetNeck x 2 -> DfMBackbone -> DepthHead (fused into its consumers) -> FrustumToVoxel ->
+        # voxel_convs -> BEVHourglass, built from the reference's own config dict (tests/golden/configs_dfm.json);
+        # stereo_train: forward + dense depth loss + backward (no optimizer), bf16 fast path
+        train = args.workload == 'stereo_train'
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'configs_dfm.json')) as f:
+            model_cfg = dict(json.load(f)['dfm_r34_1x8_kitti-3d-3class.py']['model'])
+        torch.manual_seed(0)
+        B, nbytes, dtype_name = 1, None, 'bf16'
+        H, W = 320, 1280
+        K2 = KITTI_P2.copy()
+        K2[1, 2] -= 55.0
+        if train:
+            path = pkg.DfMStereoPath(model_cfg).to(dev).train()
+            pkg.enable_fast_path(path)
+            path.fuse_depth_head = True
+        else:
+            path = pkg.DfMStereoPath(model_cfg).to(dev).eval().to(torch.bfloat16)
+            path.backbone_stereo.volume_memory_format = torch.channels_last_3d
+
+        def pyramid():
+            lv = [torch.randn(1, c, H // s_, W // s_, generator=gen).to(dev).bfloat16()
+                  for c, s_ in ((3, 1), (64, 2), (128, 4), (128, 4), (128, 4))]
+            return lv if train else [t.contiguous(memory_format=torch.channels_last) for t in lv]
+        cur, prev = pyramid(), pyramid()
+        depth_img = (torch.rand(1, 1, H, W, generator=gen) * 60).to(dev)
+        depth_img[torch.rand(1, 1, H, W, generator=gen).to(dev) < 0.93] = 0   # LiDAR: ~7 % of the pixels
+        fg = (torch.rand(1, 1, H, W, generator=gen) < 0.3).float().to(dev)
+
+        def meta():
+            return dict(ori_cam2img=KITTI_P2, cam2img=K2.tolist(), cur2prevs=torch.from_numpy(poses(1, 2 + rank)),
+                        ori_shape=(375, 1242, 3), pad_shape=(H, W, 3), crop_offset=[0, 55], flip=False,
+                        scale_factor=[1.0])
+
+        def step():
+            if train:
+                path.zero_grad(set_to_none=True)
+                out = path(cur, prev, [meta()])
+                loss = path.loss_dense_depth(out, depth_img, fg) + out['bev_feat'].float().square().mean()
+                loss.backward()
+                return None
+            with torch.no_grad():
+                return path(cur, prev, [meta()])
+        # the 3-D aggregation stacks' share of the step's arithmetic: what the fraction is quoted on
+        flops = (3 if train else 1) * 0.96e12
+        name = ('DfMStereoPath training step (forward + dense depth loss + backward)' if train else
+                'DfMStereoPath inference') + \
+            ' config K (2-D necks + plane sweep + 3-D aggregation + depth head + FrustumToVoxel + BEV hourglass, bf16; ' \
+            'the fraction counts the 3-D aggregation FLOPs only)'
+        unit = 'samples/s'
     elif args.workload in ('waymo', 'waymo_cl'):
         # config W: 5 views x 2 frames, 64 ch, 208x312 level-0 maps, 220x300x12 voxels, concat
         from tests.golden.make_golden import waymo_like_cameras
@@ -638,7 +689,8 @@ def secondary_block(pkg, sweep, dev, job, budget_s=45.0):
     out = {}
     t_start = time.perf_counter()
     for wl in ('sweep_bwd', 'kitti_nhwc', 'sweep_bwd_kitti', 'sweep_bwd_kitti_cl', 'f2v_cl', 'backbone', 'neck',
-               'dfm_neck', 'backbone_train', 'waymo_cl', 'nstar_negzero', 'nstar_negzero_all'):
+               'dfm_neck', 'backbone_train', 'waymo_cl', 'nstar_negzero', 'nstar_negzero_all', 'stereo_infer',
+               'stereo_train'):
         if time.perf_counter() - t_start > budget_s:
             out[wl] = {'skipped': 'wall-clock budget of the secondary block spent'}
             continue
