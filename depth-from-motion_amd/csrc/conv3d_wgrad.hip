@@ -45,6 +45,19 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 constexpr int WG_TH = 2;       // output rows per tile
 constexpr int WG_THREADS = 192;
 constexpr int WG_BATCH = 3;     // staging items a lane has in flight (4 x 16 bytes each)
+constexpr int WG_JMAX = 9;      // staging items per lane and tile, at most (the plan checks)
+constexpr int WG_IS_G = 1 << 13, WG_DEAD = 1 << 14;
+
+#ifdef DFM_DEBUG_HOOKS
+// s_memtime stamps of workgroup (0, 0): trace[wave][tile < 16][stamp < 8] (dfm_debug_set_wg_trace, tools/wgrad_trace.py)
+unsigned long long *g_wg_trace = nullptr;
+#define WG_STAMP(i)                                                                                       \
+    do {                                                                                                  \
+        if (trace && lane == 0 && tcount < 16) trace[((size_t)wave * 16 + tcount) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define WG_STAMP(i) do { } while (0)
+#endif
 
 struct WGeom {
     int32_t N, Do, Ho, Wo, Di, Hi, Wi;
@@ -76,9 +89,13 @@ __device__ __forceinline__ void transpose4x8(const V4 (&q)[4], u32x2_t (&t)[8])
 // slice is staged instead of three and the three waves take the three kernel ROWS (kh) instead of the
 // three depth slices: a third of the staging and of the MFMAs of the general form.
 template <int SW, bool FLAT = false>
-__global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const bf16_t *__restrict__ G,
+__global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, const bf16_t *__restrict__ G,
                                                                  const bf16_t *__restrict__ X,
-                                                                 float *__restrict__ part)
+                                                                 float *__restrict__ part
+#ifdef DFM_DEBUG_HOOKS
+                                                                 , unsigned long long *trace_buf
+#endif
+)
 {
     constexpr int TW = SW == 1 ? 64 : 32;   // output positions of a tile row
     constexpr int EP = TW + 16;             // staged elements per (row, phase, channel): 8 + TW + 8
@@ -105,7 +122,49 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    // ---- this lane's staging items (tile-invariant): packed coordinates and LDS offset ----
+    // item: depth slice z (bits 0-1) | row ihr / ohr (2-4) | channel block (5-6) | phase (7) | position group (8-12) |
+    // WG_IS_G | WG_DEAD; ilds: element offset from XS of the item's first 8-byte run
+    const int xitems = NZ * RH * NPH * 4 * (EP / 4);
+    const int gitems = WG_TH * 4 * (TW / 4);
+    const int nitems = xitems + gitems;
+    int item[WG_JMAX], ilds[WG_JMAX];
+#pragma unroll
+    for (int j = 0; j < WG_JMAX; ++j) {
+        const int it = tid + j * WG_THREADS;
+        if (it < xitems) {
+            // (channel block fastest: four consecutive lanes load the 64 contiguous bytes of one pixel -- with the
+            //  position group fastest every lane of a load sat in a line of its own, 256 bytes from its neighbour's,
+            //  and ISSUING a batch of 12 loads took 1900 cycles: profiles/r05_c45_*)
+            int q = it;
+            const int cb = q & 3; q >>= 2;
+            const int mg = q % (EP / 4); q /= (EP / 4);
+            const int ph = q % NPH; q /= NPH;
+            const int ihr = q % RH;
+            const int z = q / RH;
+            item[j] = z | (ihr << 2) | (cb << 5) | (ph << 7) | (mg << 8);
+            ilds[j] = (((z * RH + ihr) * NPH + ph) * 32 + cb * 8) * XP + mg * 4;
+        } else if (it < nitems) {
+            int q = it - xitems;
+            const int cb = q & 3; q >>= 2;
+            const int mg = q % (TW / 4);
+            const int ohr = q / (TW / 4);
+            item[j] = (ohr << 2) | (cb << 5) | (mg << 8) | WG_IS_G;
+            ilds[j] = NZ * RH * NPH * 32 * XP + (ohr * 32 + cb * 8) * GP + mg * 4;
+        } else {
+            item[j] = WG_DEAD;
+            ilds[j] = 0;
+        }
+    }
+#ifdef DFM_DEBUG_HOOKS
+    unsigned long long *trace = (blockIdx.x == 0 && blockIdx.y == 0) ? trace_buf : nullptr;
+    int tcount = -1;
+#endif
     for (int t = blockIdx.x; t < g.ntiles; t += g.wgs_per_pair) {
+#ifdef DFM_DEBUG_HOOKS
+        ++tcount;
+#endif
+        WG_STAMP(0);
         int r = t;
         const int twb = r % g.tiles_w; r /= g.tiles_w;
         const int thb = r % g.tiles_h; r /= g.tiles_h;
@@ -114,93 +173,84 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
         const int ow0 = twb * TW, oh0 = thb * WG_TH;
 
         // ---- stage x^T (rows (z, ihr), phases, 4 channel blocks, EP / 4 groups of 4 positions) and g^T ----
-        // One list of items (x items first, then g items); a lane takes WG_BATCH items at a time: ALL their
-        // 16-byte loads are issued first -- unconditionally, from a clamped address, through global-address-space
-        // pointers -- and only then selected against the bounds, transposed and written to LDS.  (Round 1-4: a
-        // `valid ? load : 0` per piece, compiled to a flat_load followed by s_waitcnt vmcnt(0) lgkmcnt(0): 20 to
-        // 32 dependent round trips to memory per tile, the tile's MFMAs were a tenth of its time.)
+        // One list of items (x items first, then g items), a lane's items are `tid + j * WG_THREADS`; their
+        // coordinates inside the tile do not depend on the tile and were decoded ONCE above (item[], ilds[]): per
+        // tile an item costs a few compares, clamps and 32-bit multiply-adds -- decoded per tile (divisions by
+        // run-time extents, 64-bit products) the address arithmetic of a batch was 2500 cycles and a tile's staging
+        // 10 000 of its 15 000 (round 5 trace: profiles/r05_c44_*).  WG_BATCH items at a time: ALL their 16-byte loads
+        // are issued first -- unconditionally, from a clamped address, through global-address-space pointers -- and
+        // only then selected against the bounds, transposed and written to LDS.  (Round 1-4: a `valid ? load : 0`
+        // per piece, compiled to a flat_load followed by s_waitcnt vmcnt(0) lgkmcnt(0): 20 to 32 dependent round
+        // trips to memory per tile.  Raw buffer loads with out-of-range offsets instead of clamp + select: the
+        // stride-2 form 177 -> 213 us, not kept.)
         {
             typedef const __attribute__((address_space(1))) u32x4_t *gv_t;
-            const int xitems = NZ * RH * NPH * 4 * (EP / 4);
-            const int gitems = WG_TH * 4 * (TW / 4);
             const bf16_t *xb = X + (size_t)n * g.xsN + b0;
             const bf16_t *gb = G + (size_t)n * g.gsN + (size_t)od * g.gsD + a0;
-            for (int base = tid; base < xitems + gitems; base += WG_BATCH * WG_THREADS) {
+            const int id0 = od * g.sd - g.pd, ih0 = oh0 * g.sh - g.ph;
+            const int iw0 = SW * (ow0 - 8) - g.pw + (SW == 1 ? 1 : 0);
+            const int xsD = (int)g.xsD, xsH = (int)g.xsH, xsW = (int)g.xsW, gsH = (int)g.gsH, gsW = (int)g.gsW;
+#pragma unroll
+            for (int bi = 0; bi < WG_JMAX / WG_BATCH; ++bi) {
+                if (bi * WG_BATCH * WG_THREADS >= nitems) break;
                 u32x4_t qv[WG_BATCH][4];
                 unsigned okm[WG_BATCH];
 #pragma unroll
                 for (int k = 0; k < WG_BATCH; ++k) {
-                    const int it = base + k * WG_THREADS;
+                    const int j = bi * WG_BATCH + k;
+                    int ge = item[j];
+                    asm volatile("" : "+v"(ge));  // (unpacked here, per tile: hoisted, the fields of 9 items are 60 registers)
+                    const int mg4 = ((ge >> 8) & 31) * 4, cb8 = ((ge >> 5) & 3) * 8;
                     okm[k] = 0u;
-                    if (it < xitems) {
-                        int q = it;
-                        const int mg = q % (EP / 4); q /= (EP / 4);
-                        const int cb = q & 3; q >>= 2;
-                        const int ph = q % NPH; q /= NPH;
-                        const int ihr = q % RH;
-                        const int z = q / RH;
-                        const int id = od * g.sd - g.pd + (FLAT ? 1 : z);
-                        const int ih = oh0 * g.sh - g.ph + ihr;
-                        const bool rok = (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi;
-                        const bf16_t *rowp = xb + (size_t)min(max(id, 0), g.Di - 1) * g.xsD +
-                                             (size_t)min(max(ih, 0), g.Hi - 1) * g.xsH + cb * 8;
+                    if (!(ge & WG_IS_G)) {
+                        const int id = id0 + (FLAT ? 1 : (ge & 3)), ih = ih0 + ((ge >> 2) & 7);
+                        const bool rok = !(ge & WG_DEAD) && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi;
+                        const int rowo = min(max(id, 0), g.Di - 1) * xsD + min(max(ih, 0), g.Hi - 1) * xsH + cb8;
+                        const int iwb = iw0 + SW * mg4 + ((ge >> 7) & 1);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const int m = mg * 4 + e;
-                            const int iw = SW * (ow0 + m - 8) - g.pw + (SW == 1 ? 1 : ph);
+                            const int iw = iwb + SW * e;
                             if (rok && (unsigned)iw < (unsigned)g.Wi) okm[k] |= 1u << e;
-                            qv[k][e] = *(gv_t)(rowp + (size_t)min(max(iw, 0), g.Wi - 1) * g.xsW);
+                            qv[k][e] = *(gv_t)(xb + (rowo + min(max(iw, 0), g.Wi - 1) * xsW));
                         }
                     } else {
-                        int q = min(it - xitems, gitems - 1);  // (lanes past the list load the last item and drop it)
-                        const int mg = q % (TW / 4); q /= (TW / 4);
-                        const int cb = q & 3;
-                        const int ohr = q >> 2;
-                        const int oh = oh0 + ohr;
-                        const bool rok = oh < g.Ho && it < xitems + gitems;
-                        const bf16_t *rowp = gb + (size_t)min(oh, g.Ho - 1) * g.gsH + cb * 8;
+                        const int oh = oh0 + ((ge >> 2) & 7);
+                        const bool rok = !(ge & WG_DEAD) && oh < g.Ho;
+                        const int rowo = min(oh, g.Ho - 1) * gsH + cb8;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const int ow = ow0 + mg * 4 + e;
+                            const int ow = ow0 + mg4 + e;
                             if (rok && ow < g.Wo) okm[k] |= 1u << e;
-                            qv[k][e] = *(gv_t)(rowp + (size_t)min(ow, g.Wo - 1) * g.gsW);
+                            qv[k][e] = *(gv_t)(gb + (rowo + min(ow, g.Wo - 1) * gsW));
                         }
                     }
                 }
+                if (bi == 0) WG_STAMP(1);   // first batch: loads issued
+#ifdef DFM_DEBUG_HOOKS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                if (bi == 0) WG_STAMP(2);   // ... arrived
 #pragma unroll
                 for (int k = 0; k < WG_BATCH; ++k) {
-                    const int it = base + k * WG_THREADS;
-                    if (it >= xitems + gitems) break;
+                    const int j = bi * WG_BATCH + k;
+                    int ge = item[j], lo = ilds[j];
+                    asm volatile("" : "+v"(ge), "+v"(lo));
+                    if (ge & WG_DEAD) continue;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (!((okm[k] >> e) & 1u)) qv[k][e] = u32x4_t{0u, 0u, 0u, 0u};
                     u32x2_t tt[8];
                     transpose4x8(qv[k], tt);
-                    bf16_t *dst;
-                    int pitch;
-                    if (it < xitems) {
-                        int q = it;
-                        const int mg = q % (EP / 4); q /= (EP / 4);
-                        const int cb = q & 3; q >>= 2;
-                        const int ph = q % NPH; q /= NPH;
-                        const int ihr = q % RH;
-                        const int z = q / RH;
-                        dst = XS + ((size_t)((z * RH + ihr) * NPH + ph) * 32 + cb * 8) * XP + mg * 4;
-                        pitch = XP;
-                    } else {
-                        int q = it - xitems;
-                        const int mg = q % (TW / 4); q /= (TW / 4);
-                        const int cb = q & 3;
-                        const int ohr = q >> 2;
-                        dst = GT + ((size_t)ohr * 32 + cb * 8) * GP + mg * 4;
-                        pitch = GP;
-                    }
+                    bf16_t *dst = XS + lo;
+                    const int pitch = (ge & WG_IS_G) ? GP : XP;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) *(u32x2_t *)(dst + (size_t)c * pitch) = tt[c];
                 }
             }
         }
+        WG_STAMP(3);   // staged
         __syncthreads();
+        WG_STAMP(4);
 
         // ---- MFMAs: wave = kernel depth slice (FLAT: kernel row of the one slice) ----
         const int z = FLAT ? 0 : wave;
@@ -248,7 +298,9 @@ __global__ __launch_bounds__(WG_THREADS) void conv3d_wgrad_kernel(WGeom g, const
                 }
             }
         }
+        WG_STAMP(5);   // multiplied
         __syncthreads();
+        WG_STAMP(6);
     }
 
     // ---- this workgroup's partial: part[pair][wg][tap][a][b] ----
@@ -344,6 +396,18 @@ int wgrad_plan(const dfm_conv3d_wgrad_desc *d, WPlan &pl)
     // a depth-1 volume with depth padding 1 (a 2-D convolution): the centre depth slice only
     pl.flat = (g.Di == 1 && g.Do == 1 && g.pd == 1 && g.sd == 1) ? 1 : 0;
     pl.lds = ((size_t)(pl.flat ? 1 : 3) * RH * pl.sw * 32 * XP + (size_t)WG_TH * 32 * GP) * 2;
+    {
+        // the kernel's staging: at most WG_JMAX items per lane, 32-bit element offsets inside a sample
+        const int NZ = pl.flat ? 1 : 3, EPx = TW + 16;
+        const long long items = (long long)NZ * RH * pl.sw * 4 * (EPx / 4) + (long long)WG_TH * 4 * (TW / 4);
+        if (items > (long long)WG_JMAX * WG_THREADS) return set_error(DFM_ERR_UNSUPPORTED, "tile stages too many pieces");
+        if ((long long)g.Di * g.xsD >= (1ll << 31) || (long long)g.Hi * g.xsH >= (1ll << 31) ||
+            (long long)g.Wi * g.xsW >= (1ll << 31) || (long long)g.Ho * g.gsH >= (1ll << 31) ||
+            (long long)g.Wo * g.gsW >= (1ll << 31) ||
+            (long long)g.Di * g.xsD + (long long)g.Hi * g.xsH + (long long)g.Wi * g.xsW >= (1ll << 31) ||
+            (long long)g.Ho * g.gsH + (long long)g.Wo * g.gsW >= (1ll << 31))
+            return set_error(DFM_ERR_UNSUPPORTED, "sample larger than 2^31 elements");
+    }
     pl.scratch = (size_t)pl.pairs * wpp * 27 * 1024 * sizeof(float);
     return DFM_OK;
 }
@@ -369,12 +433,17 @@ extern "C" DFM_API int dfm_conv3d_wgrad(const dfm_conv3d_wgrad_desc *desc, const
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(pl.g.wgs_per_pair, pl.pairs);
     if (pl.lds > 160 * 1024) return set_error(DFM_ERR_UNSUPPORTED, "tile does not fit the LDS");
+#ifdef DFM_DEBUG_HOOKS
+#define WG_TRACE_ARG , g_wg_trace
+#else
+#define WG_TRACE_ARG
+#endif
 #define W_LAUNCH(SW_, FLAT_)                                                                              \
     do {                                                                                               \
         rc = ensure_dynamic_lds((const void *)conv3d_wgrad_kernel<SW_, FLAT_>, 160 * 1024);            \
         if (rc != DFM_OK) return rc;                                                                   \
         hipLaunchKernelGGL((conv3d_wgrad_kernel<SW_, FLAT_>), grid, dim3(WG_THREADS), pl.lds, st, pl.g, \
-                           (const bf16_t *)g, (const bf16_t *)x, (float *)workspace);                  \
+                           (const bf16_t *)g, (const bf16_t *)x, (float *)workspace WG_TRACE_ARG);     \
     } while (0)
     if (pl.sw == 1) {
         if (pl.flat) W_LAUNCH(1, true); else W_LAUNCH(1, false);
@@ -388,3 +457,7 @@ extern "C" DFM_API int dfm_conv3d_wgrad(const dfm_conv3d_wgrad_desc *desc, const
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
 }
+
+#ifdef DFM_DEBUG_HOOKS
+extern "C" DFM_API void dfm_debug_set_wg_trace(void *buf) { g_wg_trace = (unsigned long long *)buf; }
+#endif
