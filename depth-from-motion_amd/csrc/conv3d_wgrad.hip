@@ -66,6 +66,7 @@ struct WGeom {
     int64_t xsN, xsD, xsH, xsW;            // element strides of x
     int32_t tiles_h, tiles_w, ntiles;      // tiles per (n, od) plane; N * Do * tiles_h * tiles_w
     int32_t wgs_per_pair, b_tiles;
+    int32_t dchunk, nchunks, nitems;       // COL: output planes per work item, chunks per column, work items
 };
 
 // 4 pixels x 8 channels (q[e] = the 8 bf16 channels of pixel e) -> per channel the 4 pixels
@@ -88,7 +89,11 @@ __device__ __forceinline__ void transpose4x8(const V4 (&q)[4], u32x2_t (&t)[8])
 // training path of the 2-D necks).  Only the centre depth slice of the 27 taps can be non-zero, so one
 // slice is staged instead of three and the three waves take the three kernel ROWS (kh) instead of the
 // three depth slices: a third of the staging and of the MFMAs of the general form.
-template <int SW, bool FLAT = false>
+// COL (row stride 1, depth stride 1, a volume): a workgroup's consecutive tiles are consecutive output planes of ONE
+// (h, w) window -- a column, cut into chunks of planes.  The three input slices then live in a ring of the three LDS
+// slots (slice id in slot id mod 3): only the first tile of a chunk stages all three, every other tile ONE new slice
+// (and its g rows) -- a third of the loads, transposes and LDS writes, which are 2/3 of a tile (profiles/r05_c44_*).
+template <int SW, bool FLAT = false, bool COL = false>
 __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, const bf16_t *__restrict__ G,
                                                                  const bf16_t *__restrict__ X,
                                                                  float *__restrict__ part
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, co
             const int ihr = q % RH;
             const int z = q / RH;
             item[j] = z | (ihr << 2) | (cb << 5) | (ph << 7) | (mg << 8);
-            ilds[j] = (((z * RH + ihr) * NPH + ph) * 32 + cb * 8) * XP + mg * 4;
+            ilds[j] = ((((COL ? 0 : z) * RH + ihr) * NPH + ph) * 32 + cb * 8) * XP + mg * 4;  // (COL: + the slice's slot, per tile)
         } else if (it < nitems) {
             int q = it - xitems;
             const int cb = q & 3; q >>= 2;
@@ -160,17 +165,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, co
     unsigned long long *trace = (blockIdx.x == 0 && blockIdx.y == 0) ? trace_buf : nullptr;
     int tcount = -1;
 #endif
-    for (int t = blockIdx.x; t < g.ntiles; t += g.wgs_per_pair) {
+    for (int t = blockIdx.x; t < (COL ? g.nitems : g.ntiles); t += g.wgs_per_pair) {
+      int r = t;
+      const int twb = r % g.tiles_w; r /= g.tiles_w;
+      const int thb = r % g.tiles_h; r /= g.tiles_h;
+      const int odq = COL ? r % g.nchunks : r % g.Do;
+      const int n = COL ? r / g.nchunks : r / g.Do;
+      const int od_lo = COL ? odq * g.dchunk : odq, od_hi = COL ? min(od_lo + g.dchunk, g.Do) : odq + 1;
+      for (int od = od_lo; od < od_hi; ++od) {
+        const bool first = !COL || od == od_lo;
 #ifdef DFM_DEBUG_HOOKS
         ++tcount;
 #endif
         WG_STAMP(0);
-        int r = t;
-        const int twb = r % g.tiles_w; r /= g.tiles_w;
-        const int thb = r % g.tiles_h; r /= g.tiles_h;
-        const int od = r % g.Do;
-        const int n = r / g.Do;
         const int ow0 = twb * TW, oh0 = thb * WG_TH;
+        // COL: the ring slots of the slices od - pd + {0, 1, 2}
+        const int s0 = COL ? (od * g.sd - g.pd + 3) % 3 : 0, s1 = COL ? (s0 + 1) % 3 : 1, s2 = COL ? (s0 + 2) % 3 : 2;
 
         // ---- stage x^T (rows (z, ihr), phases, 4 channel blocks, EP / 4 groups of 4 positions) and g^T ----
         // One list of items (x items first, then g items), a lane's items are `tid + j * WG_THREADS`; their
@@ -193,6 +203,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, co
 #pragma unroll
             for (int bi = 0; bi < WG_JMAX / WG_BATCH; ++bi) {
                 if (bi * WG_BATCH * WG_THREADS >= nitems) break;
+                // COL, not the chunk's first tile: only slice 2 is new, and with row stride 1 its 320 items and the
+                // 128 g items are exactly the lanes' items 3 .. 5 (the second batch)
+                if (COL && !first && bi == 0) continue;
                 u32x4_t qv[WG_BATCH][4];
                 unsigned okm[WG_BATCH];
 #pragma unroll
@@ -200,6 +213,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, co
                     const int j = bi * WG_BATCH + k;
                     int ge = item[j];
                     asm volatile("" : "+v"(ge));  // (unpacked here, per tile: hoisted, the fields of 9 items are 60 registers)
+                    if (COL && !first && !(ge & WG_IS_G) && (ge & 3) != 2) ge |= WG_DEAD;
                     const int mg4 = ((ge >> 8) & 31) * 4, cb8 = ((ge >> 5) & 3) * 8;
                     okm[k] = 0u;
                     if (!(ge & WG_IS_G)) {
@@ -235,7 +249,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, co
                     const int j = bi * WG_BATCH + k;
                     int ge = item[j], lo = ilds[j];
                     asm volatile("" : "+v"(ge), "+v"(lo));
+                    if (COL && !first && !(ge & WG_IS_G) && (ge & 3) != 2) ge |= WG_DEAD;
                     if (ge & WG_DEAD) continue;
+                    if (COL && !(ge & WG_IS_G)) {
+                        const int zz = ge & 3;
+                        lo += (zz == 0 ? s0 : zz == 1 ? s1 : s2) * (RH * NPH * 32 * XP);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (!((okm[k] >> e) & 1u)) qv[k][e] = u32x4_t{0u, 0u, 0u, 0u};
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, co
         WG_STAMP(4);
 
         // ---- MFMAs: wave = kernel depth slice (FLAT: kernel row of the one slice) ----
-        const int z = FLAT ? 0 : wave;
+        const int z = FLAT ? 0 : COL ? (wave == 0 ? s0 : wave == 1 ? s1 : s2) : wave;
 #pragma unroll
         for (int ohr = 0; ohr < WG_TH; ++ohr) {
 #pragma unroll
@@ -301,6 +320,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, co
         WG_STAMP(5);   // multiplied
         __syncthreads();
         WG_STAMP(6);
+      }
     }
 
     // ---- this workgroup's partial: part[pair][wg][tap][a][b] ----
@@ -349,7 +369,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *_
 
 struct WPlan {
     WGeom g;
-    int sw, swap, pairs, flat;
+    int sw, swap, pairs, flat, col;
     size_t lds, scratch;
 };
 
@@ -408,6 +428,31 @@ int wgrad_plan(const dfm_conv3d_wgrad_desc *d, WPlan &pl)
             (long long)g.Ho * g.gsH + (long long)g.Wo * g.gsW >= (1ll << 31))
             return set_error(DFM_ERR_UNSUPPORTED, "sample larger than 2^31 elements");
     }
+    // column mode (COL): row and depth stride 1 (and h stride 1: the item order the kernel relies on), a volume; work
+    // items = columns x chunks of output planes, about three per workgroup, chunks of at least 6 planes (a chunk's first
+    // tile stages all three slices).  DFM_WGRAD_COL=0 keeps a tile per step (A/B runs), DFM_WGRAD_CHUNK=<planes> (tests)
+    pl.col = 0;
+    g.dchunk = 1; g.nchunks = g.Do; g.nitems = g.ntiles;
+    {
+        const char *e = getenv("DFM_WGRAD_COL");
+        if (!(e && e[0] == '0') && pl.sw == 1 && g.sd == 1 && g.sh == 1 && !pl.flat && g.Do > 1) {
+            const long long cols = (long long)g.N * g.tiles_h * g.tiles_w;
+            const long long wgs = std::max<long long>(1, 512 / pl.pairs);
+            const long long chunks = std::max<long long>(1, (3 * wgs + cols - 1) / cols);
+            int dc = (int)std::max<long long>(6, (g.Do + chunks - 1) / chunks);
+            if (const char *c = getenv("DFM_WGRAD_CHUNK")) dc = std::max(1, atoi(c));
+            dc = std::min(dc, g.Do);
+            g.dchunk = dc;
+            g.nchunks = (g.Do + dc - 1) / dc;
+            const long long items = cols * g.nchunks;
+            if (items < (1ll << 31)) {
+                g.nitems = (int)items;
+                wpp = (int)std::max<long long>(1, std::min<long long>(wgs, items));
+                g.wgs_per_pair = wpp;
+                pl.col = 1;
+            }
+        }
+    }
     pl.scratch = (size_t)pl.pairs * wpp * 27 * 1024 * sizeof(float);
     return DFM_OK;
 }
@@ -445,7 +490,12 @@ extern "C" DFM_API int dfm_conv3d_wgrad(const dfm_conv3d_wgrad_desc *desc, const
         hipLaunchKernelGGL((conv3d_wgrad_kernel<SW_, FLAT_>), grid, dim3(WG_THREADS), pl.lds, st, pl.g, \
                            (const bf16_t *)g, (const bf16_t *)x, (float *)workspace WG_TRACE_ARG);     \
     } while (0)
-    if (pl.sw == 1) {
+    if (pl.col) {
+        rc = ensure_dynamic_lds((const void *)conv3d_wgrad_kernel<1, false, true>, 160 * 1024);
+        if (rc != DFM_OK) return rc;
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<1, false, true>), grid, dim3(WG_THREADS), pl.lds, st, pl.g,
+                           (const bf16_t *)g, (const bf16_t *)x, (float *)workspace WG_TRACE_ARG);
+    } else if (pl.sw == 1) {
         if (pl.flat) W_LAUNCH(1, true); else W_LAUNCH(1, false);
     } else {
         if (pl.flat) W_LAUNCH(2, true); else W_LAUNCH(2, false);
