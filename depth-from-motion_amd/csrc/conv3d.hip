@@ -27,6 +27,8 @@
 //     a wave writes 32 pixels x 64 B = 2 KiB contiguous.
 #include "dfm_common.h"
 
+#include <cstdlib>
+
 using namespace dfm;
 
 namespace {
@@ -311,15 +313,28 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
 }  // namespace
 
 namespace {
-// depth chunk: enough workgroups for >= 4 rounds over the 256 CUs, at least 8 planes per chunk
-// (each chunk re-stages 2 halo slabs)
+// depth chunk: one workgroup per CU at a time (156 KB of LDS), every workgroup walks `dc` planes behind a prologue of
+// three staged slabs (~1.5 plane times): the launch takes rounds(dc) x (dc + 1.5) plane times with
+// rounds = ceil(columns x chunks / 256).  Rounds 1-4 took "at least 8 planes, about four rounds": config K (50 columns,
+// 72 planes) got 9 chunks = 450 workgroups = 1.76 rounds, i.e. two rounds of 8 planes where ONE round of 15 does it.
 int conv_depth_chunk(int n, int d, int h, int w, int depth_chunk)
 {
     int dc = depth_chunk;
     if (dc <= 0) {
         const long long cols = (long long)((w + CV_TW - 1) / CV_TW) * ((h + CV_TH - 1) / CV_TH) * n;
-        const long long chunks = (4 * 256 + cols - 1) / cols;
-        dc = (int)std::max<long long>(8, (d + chunks - 1) / chunks);
+        double best = 1e30;
+        dc = d;
+        static const bool old_rule = [] { const char *e = getenv("DFM_CONV_OLD_CHUNK"); return e && e[0] == '1'; }();
+        if (old_rule) {  // (A/B runs: the rounds 1-4 rule)
+            const long long chunks = (4 * 256 + cols - 1) / cols;
+            return std::min((int)std::max<long long>(8, (d + chunks - 1) / chunks), d);
+        }
+        for (int c = std::min(d, 4); c <= d; ++c) {
+            const long long chunks = (d + c - 1) / c;
+            const long long rounds = (cols * chunks + 255) / 256;
+            const double cost = (double)rounds * (c + 1.5);
+            if (cost < best - 1e-9) { best = cost; dc = c; }
+        }
     }
     return std::min(dc, d);
 }
