@@ -429,8 +429,7 @@ int wgrad_plan(const dfm_conv3d_wgrad_desc *d, WPlan &pl)
             return set_error(DFM_ERR_UNSUPPORTED, "sample larger than 2^31 elements");
     }
     // column mode (COL): row and depth stride 1 (and h stride 1: the item order the kernel relies on), a volume; work
-    // items = columns x chunks of output planes, about three per workgroup, chunks of at least 6 planes (a chunk's first
-    // tile stages all three slices).  DFM_WGRAD_COL=0 keeps a tile per step (A/B runs), DFM_WGRAD_CHUNK=<planes> (tests)
+    // items = columns x chunks of output planes (a chunk's first tile stages all three slices).  DFM_WGRAD_COL=0 keeps a tile per step (A/B runs), DFM_WGRAD_CHUNK=<planes> (tests)
     pl.col = 0;
     g.dchunk = 1; g.nchunks = g.Do; g.nitems = g.ntiles;
     {
@@ -438,8 +437,17 @@ int wgrad_plan(const dfm_conv3d_wgrad_desc *d, WPlan &pl)
         if (!(e && e[0] == '0') && pl.sw == 1 && g.sd == 1 && g.sh == 1 && !pl.flat && g.Do > 1) {
             const long long cols = (long long)g.N * g.tiles_h * g.tiles_w;
             const long long wgs = std::max<long long>(1, 512 / pl.pairs);
-            const long long chunks = std::max<long long>(1, (3 * wgs + cols - 1) / cols);
-            int dc = (int)std::max<long long>(6, (g.Do + chunks - 1) / chunks);
+            // planes per chunk: the launch is rounds x (planes + the first tile's two extra slices, ~0.7 of a tile)
+            // long, rounds = items per workgroup, rounded UP ("about three items, at least 6 planes" gave config K
+            // 1600 items on 512 workgroups: 3.1 -> 4 rounds of 9 planes where 2 rounds of 15 do it)
+            int dc = g.Do;
+            double best = 1e30;
+            for (int c = std::min(g.Do, 3); c <= g.Do; ++c) {
+                const long long items = cols * ((g.Do + c - 1) / c);
+                const long long rounds = (items + wgs - 1) / wgs;
+                const double cost = (double)rounds * (c + 0.7);
+                if (cost < best - 1e-9) { best = cost; dc = c; }
+            }
             if (const char *c = getenv("DFM_WGRAD_CHUNK")) dc = std::max(1, atoi(c));
             dc = std::min(dc, g.Do);
             g.dchunk = dc;
