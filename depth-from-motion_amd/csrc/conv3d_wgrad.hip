@@ -434,7 +434,10 @@ int wgrad_plan(const dfm_conv3d_wgrad_desc *d, WPlan &pl)
     g.dchunk = 1; g.nchunks = g.Do; g.nitems = g.ntiles;
     {
         const char *e = getenv("DFM_WGRAD_COL");
-        if (!(e && e[0] == '0') && pl.sw == 1 && g.sd == 1 && g.sh == 1 && !pl.flat && g.Do > 1) {
+        // (the kernel takes "the second batch of a lane's items = the new slice + the g rows" from the item order:
+        //  3 slices x 4 rows x 4 channel blocks x 20 position groups = 5 items per lane exactly)
+        const bool order_ok = 3 * RH * 4 * ((TW + 16) / 4) == 5 * WG_THREADS && WG_BATCH == 3;
+        if (!(e && e[0] == '0') && order_ok && pl.sw == 1 && g.sd == 1 && g.sh == 1 && !pl.flat && g.Do > 1) {
             const long long cols = (long long)g.N * g.tiles_h * g.tiles_w;
             const long long wgs = std::max<long long>(1, 512 / pl.pairs);
             // planes per chunk: the launch is rounds x (planes + the first tile's two extra slices, ~0.7 of a tile)

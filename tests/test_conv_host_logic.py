@@ -156,3 +156,22 @@ def test_layout_predicates_and_graph_output_flattening_on_the_cpu():
     # the BEV view of a voxel volume is the reference's reshape
     vol = torch.arange(2 * 3 * 4 * 5 * 6, dtype=torch.float32).reshape(2, 3, 4, 5, 6)
     assert torch.equal(integ.bev_view(vol), vol.reshape(2, 12, 5, 6))
+
+
+def test_depth_chunk_of_the_32_channel_convolution_fills_whole_rounds(cv):
+    """dfm_conv3d_k3_c32_stats_splits = columns x chunks x 4 waves: the chunk of planes a workgroup walks is chosen
+    by rounds x (planes + prologue) with one workgroup per CU -- config K (50 columns of 16 x 32, 72 planes) is ONE
+    round of 250 workgroups (5 chunks of 15 planes), not 1.76 rounds of 8 planes (round 5)."""
+    lib = cv._capi.lib()
+    assert lib.dfm_conv3d_k3_c32_stats_splits(1, 72, 80, 320, 0) == 50 * 5 * 4
+    for (n, d, h, w) in ((1, 72, 80, 320), (1, 36, 40, 160), (2, 9, 21, 70), (8, 72, 80, 320), (1, 4, 16, 32)):
+        splits = lib.dfm_conv3d_k3_c32_stats_splits(n, d, h, w, 0)
+        cols = -(-w // 32) * -(-h // 16)
+        assert splits % (cols * 4) == 0
+        chunks = splits // (cols * 4)
+        dc = -(-d // chunks)
+        # no other chunk size has a smaller rounds x (planes + 1.5)
+        cost = lambda c: -(-(cols * n * -(-d // c)) // 256) * (c + 1.5)
+        assert all(cost(dc) <= cost(c) + 1e-9 for c in range(min(d, 4), d + 1)), (n, d, h, w, dc)
+    # an explicit chunk is taken as given
+    assert lib.dfm_conv3d_k3_c32_stats_splits(1, 72, 80, 320, 8) == 50 * 9 * 4
