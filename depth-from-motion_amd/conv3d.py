@@ -235,39 +235,36 @@ class MfmaConv3d(nn.Conv3d):
 # a depth chunk, one library GEMM (hipBLASLt, fp32 accumulation over the chunk) contracts it with
 # the output gradient, chunks are summed in fp32.
 # ---------------------------------------------------------------------------------------------
-_MM_OUT_DTYPE = [None]  # does torch.mm(..., out_dtype=torch.float32) work on this build?
-
-
-def _mm_f32(a, b):
-    if _MM_OUT_DTYPE[0] is None:
-        try:
-            r = torch.mm(a, b, out_dtype=torch.float32)
-            _MM_OUT_DTYPE[0] = True
-            return r
-        except (RuntimeError, TypeError, NotImplementedError):
-            _MM_OUT_DTYPE[0] = False
-    if _MM_OUT_DTYPE[0]:
-        return torch.mm(a, b, out_dtype=torch.float32)
-    return torch.mm(a, b).float()
-
-
-_BMM_OUT_DTYPE = [None]
+_OUT_DTYPE_OK = {}  # (op name, device type) -> does op(..., out_dtype=torch.float32) work on this build / backend?
 _SPLIT_LONG_AXIS = os.environ.get('DFM_PLAIN_WGRAD_1X1') != '1'
 
 
-def _bmm_f32(a, b):
+def _product_f32(op, a, b):
+    """``op(a, b)`` (torch.mm / torch.bmm) with an fp32 result: ``out_dtype=torch.float32`` where the backend of the
+    operands has it (the CUDA / HIP backend of this torch does, its CPU backend does not -- asked per device type, not
+    per process: a CPU call after a GPU call must not inherit the GPU's answer), else the product converted"""
     if a.dtype == torch.float32:
-        return torch.bmm(a, b)
-    if _BMM_OUT_DTYPE[0] is None:
+        return op(a, b)
+    key = (op.__name__, a.device.type)
+    ok = _OUT_DTYPE_OK.get(key)
+    if ok is None:
         try:
-            r = torch.bmm(a, b, out_dtype=torch.float32)
-            _BMM_OUT_DTYPE[0] = True
+            r = op(a, b, out_dtype=torch.float32)
+            _OUT_DTYPE_OK[key] = True
             return r
         except (RuntimeError, TypeError, NotImplementedError):
-            _BMM_OUT_DTYPE[0] = False
-    if _BMM_OUT_DTYPE[0]:
-        return torch.bmm(a, b, out_dtype=torch.float32)
-    return torch.bmm(a, b).float()
+            ok = _OUT_DTYPE_OK[key] = False
+    if ok:
+        return op(a, b, out_dtype=torch.float32)
+    return op(a, b).float()
+
+
+def _mm_f32(a, b):
+    return _product_f32(torch.mm, a, b)
+
+
+def _bmm_f32(a, b):
+    return _product_f32(torch.bmm, a, b)
 
 
 def long_axis_gram(a, b, rows_per_batch=2048):

@@ -62,3 +62,17 @@ def test_gate_logits_gradients_equal_autograd():
         res.append((y.detach(), ww.grad, bb.grad))
     for got, ref in zip(*res):
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-3)
+
+
+def test_fp32_product_capability_is_asked_per_backend():
+    """torch.mm / torch.bmm (..., out_dtype=float32) exists on the GPU backend of this torch and not on its CPU backend:
+    the answer is cached per (operator, device type) -- a CPU product after a GPU one must not inherit the GPU's."""
+    cv = importlib.import_module('depth-from-motion_amd.conv3d')
+    cv._OUT_DTYPE_OK[('mm', 'cuda')] = True
+    cv._OUT_DTYPE_OK[('bmm', 'cuda')] = True
+    a, b = torch.randn(6, 5).bfloat16(), torch.randn(5, 4).bfloat16()
+    r = cv._mm_f32(a, b)
+    assert r.dtype == torch.float32
+    np.testing.assert_allclose(r.numpy(), (a.float() @ b.float()).numpy(), rtol=2e-2, atol=2e-2)
+    r3 = cv._bmm_f32(a[None], b[None])
+    assert r3.dtype == torch.float32 and r3.shape == (1, 6, 4)
