@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time of the MFMA weight-gradient launch (csrc/conv3d_wgrad.hip) on the convolution shapes of config K's backbone.
-usage: [DFM_WGRAD_WALK=0|1] [DFM_WGRAD_CHUNK=n] python tools/wgrad_timing.py"""
+usage: [DFM_WGRAD_COL=0|1] [DFM_WGRAD_CHUNK=n] python tools/wgrad_timing.py"""
 import importlib
 import os
 import sys
@@ -29,8 +29,8 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         flops = 2.0 * 27 * a * b * osz[0] * osz[1] * osz[2]
-        print('wgrad %d<-%d %s stride %d: %.1f us  %.0f TFLOP/s (kernel + reduce)  walk=%s chunk=%s' % (
-            a, b, size, stride, us, flops / us / 1e6, os.environ.get('DFM_WGRAD_WALK', '-'), os.environ.get('DFM_WGRAD_CHUNK', '-')))
+        print('wgrad %d<-%d %s stride %d: %.1f us  %.0f TFLOP/s (kernel + reduce)  column mode=%s chunk=%s' % (
+            a, b, size, stride, us, flops / us / 1e6, os.environ.get('DFM_WGRAD_COL', 'default'), os.environ.get('DFM_WGRAD_CHUNK', '-')))
 
 
 if __name__ == '__main__':
