@@ -176,7 +176,30 @@ class _MfmaConvFn(torch.autograd.Function):
         return gx, gw, None, None
 
 
-class MfmaConv3d(nn.Conv3d):
+# Per-module state DERIVED from parameters or from tensors the detector injects: packed weight fragments, folded
+# norms, device copies of host tensors (some entries hold weak references, which do not pickle).  None of it is part
+# of a module's identity: `torch.save(model)`, `pickle` and `copy.deepcopy` (EMA hooks, `mp.spawn` arguments) leave
+# it behind and the copy rebuilds it on its first forward.  Names initialised in __init__ go back to their initial
+# value, the rest is dropped.
+_DERIVED_RESET = {'_packs': None, '_pack_key': None, '_sweep_conv_pack': (None, None)}
+_DERIVED_DROP = frozenset((
+    '_split_packs', '_split_key', '_pack2d', '_pack2d_key', '_gate_pack', '_dev_cache', '_coords_ref', '_coords_key',
+    '_coords_dev', '_spp_params', '_spp_key', '_fold', '_fold_key'))
+
+
+class DerivedStateMixin:
+    """first base of the path's modules: their pickled state carries parameters, buffers and configuration only"""
+
+    def __getstate__(self):
+        state = super().__getstate__()
+        state = {k: v for k, v in state.items() if k not in _DERIVED_DROP}
+        for k, v in _DERIVED_RESET.items():
+            if k in state:
+                state[k] = v
+        return state
+
+
+class MfmaConv3d(DerivedStateMixin, nn.Conv3d):
     """nn.Conv3d(C_in in {32, 64, ...}, 32, 3, stride=1, padding=1, bias=False) whose bf16 / NDHWC
     forward is the hand-written MFMA kernel.  Packed weight fragments are cached and rebuilt when
     the parameter changes (version counter)."""
@@ -424,6 +447,9 @@ class _PackCache:
     def __init__(self):
         self._pack, self._key = None, None
 
+    def __getstate__(self):  # a pickled / deep-copied module packs again on its first forward
+        return {'_pack': None, '_key': None}
+
     def get(self, weight, make):
         key = (weight._version, weight.data_ptr(), weight.device)
         if self._key != key:
@@ -470,7 +496,7 @@ class _MfmaConvTo1Fn(torch.autograd.Function):
         return gx, gw, None
 
 
-class MfmaConv3dTo1(nn.Conv3d):
+class MfmaConv3dTo1(DerivedStateMixin, nn.Conv3d):
     """nn.Conv3d(32, 1, 3, 1, 1, bias=False): the prediction convolutions of DfMBackbone
     (dfm_backbone.py:120-127).  bf16 / NDHWC input: the 32 -> 32 MFMA kernel with a zero-padded
     weight, storing channel 0 only (MIOpen's untuned kernel for this shape takes 3.4 ms at config K,
@@ -972,7 +998,7 @@ class _Mfma2dMixin:
         return self.__dict__['_pack2d']
 
 
-class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
+class MfmaConv2d(DerivedStateMixin, nn.Conv2d, _Mfma2dMixin):
     """nn.Conv2d (same parameters / state_dict keys).  kernel 3, padding 1, stride 1 | 2, dilation 1,
     groups 1, channels = 32 k, bf16 channels_last input under no_grad: the hand-written MFMA kernel
     (csrc/conv3d_g.hip with a (1, 3, 3) kernel); anything else: torch's convolution, the module's other
@@ -1118,7 +1144,7 @@ class MfmaConv2d(nn.Conv2d, _Mfma2dMixin):
         return y if keep_cl else y.contiguous()
 
 
-class MfmaConvTranspose2d(nn.ConvTranspose2d, _Mfma2dMixin):
+class MfmaConvTranspose2d(DerivedStateMixin, nn.ConvTranspose2d, _Mfma2dMixin):
     """nn.ConvTranspose2d kernel 3, stride 2, padding 1, output_padding 1 (hourglass2d's up-convs,
     conv_modules.py:196-214) through the MFMA kernel under the conditions of ``MfmaConv2d``."""
 
@@ -1231,7 +1257,7 @@ class _ConvGFn(torch.autograd.Function):
         return gx, gw, None, None, None, None
 
 
-class MfmaConv3dG(nn.Conv3d):
+class MfmaConv3dG(DerivedStateMixin, nn.Conv3d):
     """nn.Conv3d(32 j, 32 k, 3, stride in {1, 2}, padding in {0, 1, 2}, bias=False) whose bf16 /
     NDHWC forward is the general MFMA kernel; any other input takes torch's convolution (MIOpen),
     the module's other documented path.  ``forward_fused`` folds a per-channel scale / shift (an
@@ -1290,7 +1316,7 @@ class MfmaConv3dG(nn.Conv3d):
                         scale=scale, shift=shift, residual=residual)
 
 
-class MfmaConvTranspose3d(nn.ConvTranspose3d):
+class MfmaConvTranspose3d(DerivedStateMixin, nn.ConvTranspose3d):
     """nn.ConvTranspose3d(32 j, 32 k, 3, stride=2, padding=1, output_padding=1, bias=False) of the
     hourglass (conv_modules.py:101-117): evaluated per output parity class on the low-resolution
     input by the general MFMA kernel when the input is bf16 / NDHWC."""

@@ -30,7 +30,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import (long_axis_gram, MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose2d,
+from .conv3d import (DerivedStateMixin, long_axis_gram, MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose2d,
                      MfmaConvTranspose3d, channel_slice)
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
@@ -79,7 +79,7 @@ def _make_norm(norm_cfg, channels):
     return name, layer
 
 
-class ConvModule(nn.Module):
+class ConvModule(DerivedStateMixin, nn.Module):
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0,
                  conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU')):
@@ -259,7 +259,7 @@ class hourglass(nn.Module):  # noqa: N801  (reference class name)
 # DfMBackbone
 # --------------------------------------------------------------------------
 @register_module
-class DfMBackbone(nn.Module):
+class DfMBackbone(DerivedStateMixin, nn.Module):
 
     def __init__(self,
                  in_channels,
@@ -487,7 +487,7 @@ class _GateLogitsFn(torch.autograd.Function):
 # DepthHead (forward path; the loss is outside SURVEY.md 8a)
 # --------------------------------------------------------------------------
 @register_module
-class DepthHead(nn.Module):
+class DepthHead(DerivedStateMixin, nn.Module):
 
     def __init__(self, depth_cfg, in_channels=32, with_convs=True,
                  depth_loss=dict(type='ce', loss_weight=1.0), downsample_factor=4, num_views=5,
@@ -580,7 +580,7 @@ class DepthHead(nn.Module):
 # FrustumToVoxel
 # --------------------------------------------------------------------------
 @register_module
-class FrustumToVoxel(nn.Module):
+class FrustumToVoxel(DerivedStateMixin, nn.Module):
 
     def __init__(self, num_3dconvs=1, cv_channels=32, out_channels=32, in_sem_channels=32,
                  sem_atten_feat=True, stereo_atten_feat=False, cat_img_feature=True,
@@ -674,7 +674,7 @@ def _to_bev(x):
 
 
 @register_module
-class OutdoorImVoxelNeck(nn.Module):
+class OutdoorImVoxelNeck(DerivedStateMixin, nn.Module):
 
     def __init__(self, in_channels, out_channels, norm_cfg=dict(type='BN3d'), output_bev=True):
         super().__init__()
@@ -692,7 +692,7 @@ class OutdoorImVoxelNeck(nn.Module):
 
 
 @register_module
-class DfMNeck(nn.Module):
+class DfMNeck(DerivedStateMixin, nn.Module):
 
     def __init__(self, in_channels, out_channels, norm_cfg=dict(type='BN3d'), num_frames=2):
         super().__init__()
@@ -918,7 +918,7 @@ class hourglass2d(nn.Module):  # noqa: N801  (reference class name)
 
 
 @register_module
-class BEVHourglass(nn.Module):
+class BEVHourglass(DerivedStateMixin, nn.Module):
 
     def __init__(self, in_channels, out_channels, norm_cfg=None, output_prehg_feat=True,
                  init_cfg=None):
@@ -942,7 +942,7 @@ class BEVHourglass(nn.Module):
 
 
 @register_module
-class SPPUNetNeck(nn.Module):
+class SPPUNetNeck(DerivedStateMixin, nn.Module):
 
     def __init__(self, in_channels, start_level, sem_channels=[128, 32], stereo_channels=[32, 32],
                  spp_channel=32, with_upconv=True, cat_img_feature=True, norm_cfg=None,
