@@ -53,6 +53,7 @@ EXPORTS = (
     'dfm_frustum_to_voxel_fused_bwd',
     'dfm_frustum_to_voxel_bwd_gather_workspace_bytes',
     'dfm_frustum_to_voxel_bwd_gather',
+    'dfm_frustum_to_voxel_bwd_gather_cl',
     'dfm_point_sample_mv_fwd_batched',
     'dfm_point_sample_mv_bwd_workspace_bytes',
     'dfm_point_sample_mv_bwd',
@@ -318,6 +319,9 @@ def lib():
     h.dfm_frustum_to_voxel_bwd_gather.restype = ctypes.c_int
     h.dfm_frustum_to_voxel_bwd_gather.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, vp, fp, fp, i32, fp,
                                                   ctypes.POINTER(ctypes.c_float), fp, fp, fp, vp, sz, vp]
+    h.dfm_frustum_to_voxel_bwd_gather_cl.restype = ctypes.c_int
+    h.dfm_frustum_to_voxel_bwd_gather_cl.argtypes = [ctypes.POINTER(F2vDesc), vp, vp, vp, fp, fp, i32, fp,
+                                                     ctypes.POINTER(ctypes.c_float), fp, vp, fp, vp, sz, vp]
     h.dfm_frustum_to_voxel_bwd_workspace_bytes.restype = ctypes.c_size_t
     h.dfm_frustum_to_voxel_bwd_workspace_bytes.argtypes = [ctypes.POINTER(F2vDesc)]
     h.dfm_point_sample_mv_bwd.restype = ctypes.c_int

@@ -1070,14 +1070,16 @@ constexpr int F2G_DCH = 9;  // depth planes per lane (a chunk): 72 planes -> 8 c
 
 // lane = pixel (h, w) of the cost volume x a chunk of depth planes; C == 32, Cs in {0, 32} with the semantic
 // map at the cost volume's resolution.  gvs / gcs: element strides of grad_out between voxels / channels.
-template <typename T, bool SEM>
+// GCL: the stereo gradient is written (B, D, H, W, 32) in T -- the layout and type of a channels-last cost volume,
+// a lane's 32 sums as one contiguous row (a wave: 64 consecutive rows), rounded once; else planar fp32.
+template <typename T, bool SEM, bool GCL>
 __global__ __launch_bounds__(256) void f2v_bwd_gather_kernel(F2vGeom g, F2vGrid gr, int dchunks,
                                                              const T *__restrict__ gout, size_t gvs, size_t gcs,
                                                              const float *__restrict__ coords,
                                                              const float *__restrict__ cam2img,
                                                              const float *__restrict__ sfac,
                                                              const float *__restrict__ mfac,
-                                                             float *__restrict__ gst, float *__restrict__ gsem)
+                                                             void *__restrict__ gstv, float *__restrict__ gsem)
 {
     // block id = ((ytile * xtiles + xtile) * dchunks + chunk); blockIdx.y = sample
     const int xtiles = (g.W + 63) / 64;
@@ -1201,10 +1203,22 @@ __global__ __launch_bounds__(256) void f2v_bwd_gather_kernel(F2vGeom g, F2vGrid 
             }
         }
         if (inside) {
-            float *o = gst + ((size_t)b * g.C * g.D + d) * g.H * g.W + (size_t)h * g.W + w;
-            const size_t cs = (size_t)g.D * g.H * g.W;
+            if constexpr (GCL) {
+                constexpr int VEC = dfm::vec16<T>::N;
+                T *o = (T *)gstv + ((((size_t)b * g.D + d) * g.H + h) * g.W + w) * 32;
 #pragma unroll
-            for (int c = 0; c < 32; ++c) o[(size_t)c * cs] = ast[c];
+                for (int q = 0; q < 32 / VEC; ++q) {
+                    float r[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) r[e] = ast[q * VEC + e];
+                    dfm::store16<T>(o + q * VEC, r);
+                }
+            } else {
+                float *o = (float *)gstv + ((size_t)b * g.C * g.D + d) * g.H * g.W + (size_t)h * g.W + w;
+                const size_t cs = (size_t)g.D * g.H * g.W;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) o[(size_t)c * cs] = ast[c];
+            }
         }
     }
     if constexpr (SEM) {
@@ -1338,11 +1352,10 @@ extern "C" DFM_API size_t dfm_frustum_to_voxel_bwd_gather_workspace_bytes(const 
     return (((size_t)2 * d->batch * d->nz * d->ny * d->nx * sizeof(float)) + 255) & ~(size_t)255;
 }
 
-extern "C" DFM_API int dfm_frustum_to_voxel_bwd_gather(const dfm_f2v_desc *d, const void *grad_out, const void *softmax,
-                                                       const void *cost, const float *col_max, const float *col_sum,
-                                                       int32_t head_scale, const float *coords, const float *grid6,
-                                                       const float *cam2img, float *grad_stereo, float *grad_sem,
-                                                       void *workspace, size_t workspace_bytes, void *stream)
+static int f2v_bwd_gather_impl(const dfm_f2v_desc *d, const void *grad_out, const void *softmax, const void *cost,
+                               const float *col_max, const float *col_sum, int32_t head_scale, const float *coords,
+                               const float *grid6, const float *cam2img, void *grad_stereo, bool grad_cl,
+                               float *grad_sem, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!d) return set_error(DFM_ERR_INVALID_ARG, "desc is NULL");
     if (d->dtype != DFM_F32 && d->dtype != DFM_BF16)
@@ -1355,7 +1368,8 @@ extern "C" DFM_API int dfm_frustum_to_voxel_bwd_gather(const dfm_f2v_desc *d, co
     if (d->channels != 32 || !(d->sem_channels == 0 || (d->sem_channels == 32 && d->hsem == d->h && d->wsem == d->w &&
                                                           !d->no_sem_atten)) ||
         d->d < 2 || d->h < 2 || d->w < 2 || grid6[1] == 0.0f || grid6[3] == 0.0f || grid6[5] == 0.0f ||
-        d->batch > 65535 || (d->out_channels_last && ((uintptr_t)grad_out & 15)))
+        d->batch > 65535 || (d->out_channels_last && ((uintptr_t)grad_out & 15)) ||
+        (grad_cl && ((uintptr_t)grad_stereo & 15)))
         return set_error(DFM_ERR_UNSUPPORTED,
                          "gather backward: C == 32, Cs in {0, 32} at the cost volume's resolution with sem_atten, regular grid");
     if (workspace_bytes < dfm_frustum_to_voxel_bwd_gather_workspace_bytes(d))
@@ -1386,25 +1400,54 @@ extern "C" DFM_API int dfm_frustum_to_voxel_bwd_gather(const dfm_f2v_desc *d, co
     const size_t gvs = g.out_cl ? (size_t)CT : 1, gcs = g.out_cl ? 1 : (size_t)N;
     const int dchunks = (d->d + F2G_DCH - 1) / F2G_DCH;
     const dim3 ggrid((unsigned)(((d->w + 63) / 64) * ((d->h + 3) / 4) * dchunks), d->batch);
+#define DFM_F2G_K(T_, SEM_, GCL_)                                                                                 \
+    hipLaunchKernelGGL((f2v_bwd_gather_kernel<T_, SEM_, GCL_>), ggrid, dim3(256), 0, st, g, gr, dchunks,         \
+                       (const T_ *)grad_out, gvs, gcs, coords, cam2img, (const float *)sfac, (const float *)mfac, \
+                       grad_stereo, grad_sem)
 #define DFM_F2G(T_)                                                                                              \
     do {                                                                                                         \
         hipLaunchKernelGGL(f2v_bwd_prep_kernel<T_>, pgrid, dim3(256), 0, st, g, (const T_ *)softmax, fh, coords, \
                            cam2img, sfac, mfac);                                                                 \
-        if (d->sem_channels > 0)                                                                                 \
-            hipLaunchKernelGGL((f2v_bwd_gather_kernel<T_, true>), ggrid, dim3(256), 0, st, g, gr, dchunks,       \
-                               (const T_ *)grad_out, gvs, gcs, coords, cam2img, (const float *)sfac,             \
-                               (const float *)mfac, grad_stereo, grad_sem);                                      \
-        else                                                                                                     \
-            hipLaunchKernelGGL((f2v_bwd_gather_kernel<T_, false>), ggrid, dim3(256), 0, st, g, gr, dchunks,      \
-                               (const T_ *)grad_out, gvs, gcs, coords, cam2img, (const float *)sfac,             \
-                               (const float *)mfac, grad_stereo, grad_sem);                                      \
+        if (d->sem_channels > 0) {                                                                               \
+            if (grad_cl) DFM_F2G_K(T_, true, true); else DFM_F2G_K(T_, true, false);                             \
+        } else {                                                                                                 \
+            if (grad_cl) DFM_F2G_K(T_, false, true); else DFM_F2G_K(T_, false, false);                           \
+        }                                                                                                        \
     } while (0)
     if (d->dtype == DFM_F32) DFM_F2G(float);
     else DFM_F2G(bf16_t);
 #undef DFM_F2G
+#undef DFM_F2G_K
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
+}
+
+extern "C" DFM_API int dfm_frustum_to_voxel_bwd_gather(const dfm_f2v_desc *d, const void *grad_out, const void *softmax,
+                                                       const void *cost, const float *col_max, const float *col_sum,
+                                                       int32_t head_scale, const float *coords, const float *grid6,
+                                                       const float *cam2img, float *grad_stereo, float *grad_sem,
+                                                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    return f2v_bwd_gather_impl(d, grad_out, softmax, cost, col_max, col_sum, head_scale, coords, grid6, cam2img,
+                               grad_stereo, false, grad_sem, workspace, workspace_bytes, stream);
+}
+
+// The same, with the stereo gradient in the layout and type of a channels-last cost volume: grad_stereo is
+// (B, d, h, w, C) in memory (torch channels_last_3d of (B, C, d, h, w)), desc->dtype, 16-byte aligned, OVERWRITTEN
+// -- the fp32 sums rounded once at the store, the bits `dfm_frustum_to_voxel_bwd_gather` + a conversion give.  What
+// the NDHWC stack's autograd wants: the engine adds this gradient to the one the prediction convolution's backward
+// hands over in that layout (a planar fp32 result cost a zero fill, a conversion and a strided addition: 0.6 ms of
+// a 22.5 ms training step).  grad_sem as above (fp32, planar, accumulated).
+extern "C" DFM_API int dfm_frustum_to_voxel_bwd_gather_cl(const dfm_f2v_desc *d, const void *grad_out,
+                                                          const void *softmax, const void *cost, const float *col_max,
+                                                          const float *col_sum, int32_t head_scale, const float *coords,
+                                                          const float *grid6, const float *cam2img, void *grad_stereo,
+                                                          float *grad_sem, void *workspace, size_t workspace_bytes,
+                                                          void *stream)
+{
+    return f2v_bwd_gather_impl(d, grad_out, softmax, cost, col_max, col_sum, head_scale, coords, grid6, cam2img,
+                               grad_stereo, true, grad_sem, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------

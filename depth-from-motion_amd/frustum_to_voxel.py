@@ -46,10 +46,11 @@ class _F2vFn(torch.autograd.Function):
         st_shape, sem_shape, dtype = ctx.shapes
         device = grad_out.device
         go = _grad_in_output_layout(grad_out, desc, dtype)
-        g_st = torch.zeros(st_shape, dtype=torch.float32, device=device)
         g_sem = torch.zeros(sem_shape, dtype=torch.float32, device=device) if ctx.has_sem else None
-        if _try_gather_backward(desc, go, soft, None, 0, coords, cam4, g_st, g_sem, device):
+        g_st = _try_gather_backward(desc, go, soft, None, 0, coords, cam4, st_shape, dtype, g_sem, device)
+        if g_st is not None:
             return g_st.to(dtype), (g_sem.to(dtype) if g_sem is not None else None), None, None, None, None
+        g_st = torch.zeros(st_shape, dtype=torch.float32, device=device)
         nbytes = lib.dfm_frustum_to_voxel_bwd_workspace_bytes(ctypes.byref(desc))
         ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
@@ -94,12 +95,14 @@ class _F2vFusedFn(torch.autograd.Function):
         st_shape, sem_shape, dtype = ctx.shapes
         device = grad_out.device
         go = _grad_in_output_layout(grad_out, desc, dtype)
-        g_st = torch.zeros(st_shape, dtype=torch.float32, device=device)
         g_sem = torch.zeros(sem_shape, dtype=torch.float32, device=device) if ctx.has_sem else None
         bdesc = desc
-        if _try_gather_backward(desc, go, None, (cost, col_max, col_sum), ctx.scale, coords, cam4, g_st, g_sem, device):
+        g_st = _try_gather_backward(desc, go, None, (cost, col_max, col_sum), ctx.scale, coords, cam4, st_shape, dtype,
+                                    g_sem, device)
+        if g_st is not None:
             return (g_st.to(dtype), (g_sem.to(dtype) if g_sem is not None else None), None, None, None, None, None,
                     None, None)
+        g_st = torch.zeros(st_shape, dtype=torch.float32, device=device)
         nbytes = lib.dfm_frustum_to_voxel_bwd_workspace_bytes(ctypes.byref(bdesc))
         ws = _Workspace.get(device, nbytes)
         with torch.cuda.device(device):
@@ -112,17 +115,23 @@ class _F2vFusedFn(torch.autograd.Function):
 
 
 _GRID_CACHE = {}
-_BWD_GATHER = {'on': os.environ.get('DFM_NO_F2V_GATHER') != '1'}
+_BWD_GATHER = {'on': os.environ.get('DFM_NO_F2V_GATHER') != '1',
+               # the gradient of a channels-last cost volume in that layout and type (DFM_F2V_PLANAR_GRAD=1: A/B runs)
+               'native': os.environ.get('DFM_F2V_PLANAR_GRAD') != '1'}
 
 
 @contextlib.contextmanager
-def bwd_gather(on):
-    """backward by the gather kernel (default) or the pixel-major scatter (A/B runs, tests)"""
-    prev, _BWD_GATHER['on'] = _BWD_GATHER['on'], bool(on)
+def bwd_gather(on, native=None):
+    """backward by the gather kernel (default) or the pixel-major scatter (A/B runs, tests); ``native=False``: the
+    gather writes the planar fp32 gradient also for a channels-last cost volume"""
+    prev = dict(_BWD_GATHER)
+    _BWD_GATHER['on'] = bool(on)
+    if native is not None:
+        _BWD_GATHER['native'] = bool(native)
     try:
         yield
     finally:
-        _BWD_GATHER['on'] = prev
+        _BWD_GATHER['on'], _BWD_GATHER['native'] = prev['on'], prev['native']
 
 
 def _regular_grid(coords, desc):
@@ -159,29 +168,39 @@ def _regular_grid(coords, desc):
     return grid
 
 
-def _try_gather_backward(desc, go, soft, fused, scale, coords, cam4, g_st, g_sem, device):
-    """the gather form of the backward (csrc/frustum_to_voxel.hip: f2v_bwd_gather_kernel); False: not applicable"""
+def _try_gather_backward(desc, go, soft, fused, scale, coords, cam4, st_shape, dtype, g_sem, device):
+    """the gather form of the backward (csrc/frustum_to_voxel.hip: f2v_bwd_gather_kernel) -> the gradient of the cost
+    volume (the kernel overwrites it: no zero fill), None: not applicable.  A channels-last cost volume (the NDHWC
+    stack) gets its gradient in its own layout and type -- what the prediction convolution's backward produces for
+    the same tensor, so that autograd's accumulation is one contiguous addition; a planar volume gets planar fp32."""
     if not _BWD_GATHER['on']:
-        return False
+        return None
     grid = _regular_grid(coords, desc)
     if grid is None:
-        return False
+        return None
     lib = _capi.lib()
     nbytes = lib.dfm_frustum_to_voxel_bwd_gather_workspace_bytes(ctypes.byref(desc))
     ws = _Workspace.get(device, nbytes)
     g6 = (ctypes.c_float * 6)(*grid)
     cost, cmax, csum = fused if fused is not None else (None, None, None)
+    native = bool(desc.stereo_channels_last) and _BWD_GATHER['native']
+    if native:
+        B, C, D, H, W = st_shape
+        g_st = torch.empty((B, D, H, W, C), dtype=dtype, device=device).permute(0, 4, 1, 2, 3)
+        entry = lib.dfm_frustum_to_voxel_bwd_gather_cl
+    else:
+        g_st = torch.empty(st_shape, dtype=torch.float32, device=device)
+        entry = lib.dfm_frustum_to_voxel_bwd_gather
     with torch.cuda.device(device):
-        rc = lib.dfm_frustum_to_voxel_bwd_gather(
-            ctypes.byref(desc), _ptr(go), _ptr(soft) if soft is not None else None,
-            _ptr(cost) if cost is not None else None, _ptr(cmax) if cmax is not None else None,
-            _ptr(csum) if csum is not None else None, int(scale), _ptr(coords), g6, _ptr(cam4), _ptr(g_st),
-            _ptr(g_sem) if g_sem is not None else None, _ptr(ws), nbytes, _stream_ptr(device))
+        rc = entry(ctypes.byref(desc), _ptr(go), _ptr(soft) if soft is not None else None,
+                   _ptr(cost) if cost is not None else None, _ptr(cmax) if cmax is not None else None,
+                   _ptr(csum) if csum is not None else None, int(scale), _ptr(coords), g6, _ptr(cam4), _ptr(g_st),
+                   _ptr(g_sem) if g_sem is not None else None, _ptr(ws), nbytes, _stream_ptr(device))
     if rc == _capi.DFM_ERR_UNSUPPORTED:
-        return False
+        return None
     _capi.check(rc)
     _BWD_GATHER['calls'] = _BWD_GATHER.get('calls', 0) + 1   # (tests read it: which form took the call)
-    return True
+    return g_st
 
 
 def _grad_in_output_layout(grad_out, desc, dtype):

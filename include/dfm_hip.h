@@ -521,6 +521,17 @@ DFM_API int dfm_frustum_to_voxel_bwd_gather(const dfm_f2v_desc *desc, const void
                                             int32_t head_scale, const float *coords, const float *grid6,
                                             const float *cam2img, float *grad_stereo, float *grad_sem,
                                             void *workspace, size_t workspace_bytes, void *stream);
+/* The same gather with the stereo gradient in the layout and type of a channels-last cost volume: grad_stereo is
+ * (B, d, h, w, C) in memory (torch channels_last_3d of (B, C, d, h, w)), desc->dtype, 16-byte aligned, OVERWRITTEN:
+ * a lane stores its 32 fp32 sums as one contiguous row, rounded once -- the bits the planar fp32 form followed by a
+ * conversion gives.  The NDHWC stack's autograd adds this gradient to the one the prediction convolution's backward
+ * produces in that layout (the feature volume feeds pred_stereo, dfm_backbone.py:120-127, AND FrustumToVoxel, dfm.py:317-319); the planar fp32 result
+ * cost a zero fill, a conversion and a strided addition there.  grad_sem as above (fp32, planar, accumulated). */
+DFM_API int dfm_frustum_to_voxel_bwd_gather_cl(const dfm_f2v_desc *desc, const void *grad_out, const void *softmax,
+                                               const void *cost, const float *col_max, const float *col_sum,
+                                               int32_t head_scale, const float *coords, const float *grid6,
+                                               const float *cam2img, void *grad_stereo, float *grad_sem,
+                                               void *workspace, size_t workspace_bytes, void *stream);
 /* The same backward with the depth head fused (training): pred_disp, which scales the gradients of the
  * attended branches, is evaluated from the low-resolution cost + column statistics exactly as
  * dfm_frustum_to_voxel_fused_fwd does; no (B, 1, ds, hs, ws) tensor is read. */

@@ -367,6 +367,42 @@ def test_backward_gather_equals_the_scatter(dtype, fused, fmt, Cs, yaw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('fused', [False, True], ids=['materialised', 'fused_head'])
+@pytest.mark.parametrize('Cs', [32, 0])
+def test_backward_gather_hands_a_channels_last_volume_its_gradient_in_place(dtype, fused, Cs):
+    """a channels-last cost volume (the NDHWC stack) receives its gradient channels-last in its own type
+    (dfm_frustum_to_voxel_bwd_gather_cl: the fp32 sums rounded once at the store) -- bit for bit the planar fp32
+    gradient converted, and the layout the prediction convolution's backward produces for the same tensor"""
+    f2v = importlib.import_module('depth-from-motion_amd.frustum_to_voxel')
+    pkg, dev, stereo, sem, soft, lazy, metas, coords, cfg = _config_k_like(dtype, 90 + Cs, Cs)
+    rng = torch.Generator().manual_seed(4)
+    res, gout = {}, None
+    for native in (True, False):
+        st = stereo.to(dev).to(dtype).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        sm = sem.to(dev).to(dtype).requires_grad_(True) if sem is not None else None
+        calls = f2v._BWD_GATHER.get('calls', 0)
+        with f2v.bwd_gather(True, native=native):
+            out = pkg.frustum_to_voxel_sample(st, lazy if fused else soft, metas, sm, coords, cfg)
+            if gout is None:
+                gout = torch.randn(out.shape, generator=rng).to(dev).to(dtype).contiguous(
+                    memory_format=torch.channels_last_3d)
+            out.backward(gout)
+        torch.cuda.synchronize()
+        assert f2v._BWD_GATHER.get('calls', 0) - calls == 1, 'the gather form took the call'
+        assert st.grad.dtype == dtype and st.grad.shape == st.shape
+        if native:
+            assert st.grad.is_contiguous(memory_format=torch.channels_last_3d) and not st.grad.is_contiguous()
+        res[native] = (st.grad, sm.grad if sm is not None else None)
+    assert float(res[False][0].abs().max()) > 0
+    assert torch.equal(res[True][0], res[False][0])
+    if sem is not None:  # (atomics: the order of the additions differs from run to run)
+        a, b = res[True][1].float(), res[False][1].float()
+        assert torch.allclose(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
+    assert f2v._BWD_GATHER['native'] and f2v._BWD_GATHER['on']
+
+
+@pytest.mark.gpu
 def test_backward_gather_needs_a_regular_grid_and_says_so():
     """an irregular voxel grid (jittered centres) is detected on the device and takes the scatter form"""
     f2v = importlib.import_module('depth-from-motion_amd.frustum_to_voxel')
