@@ -161,7 +161,12 @@ def cpu_baseline(w, budget_s=12.0):
     proportional to the channel count)."""
     from oracle import dfm_oracle as orc
     lib = orc.lib()
-    cores = max(1, min(lib.dfm_oracle_max_threads(), os.cpu_count() or 1))
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    # (the host's cores, not omp_get_max_threads(): torchrun exports OMP_NUM_THREADS=1 to its ranks)
     lib.dfm_oracle_set_threads(cores)
     rng = np.random.RandomState(0)
     P = KITTI_P2
@@ -209,8 +214,8 @@ def cpu_baseline(w, budget_s=12.0):
     except Exception as e:  # never fail the bench line over a reported baseline
         res['torch_cpu_grid_sample_this_box'] = {'error': repr(e)[:200]}
         return res
-    # The line's CPU baseline is the REFERENCE'S compute through the REFERENCE'S library on this box's host
-    # cores: the two F.grid_sample calls + cat of build_dfm_cost (dfm_backbone.py:296-313) on PyTorch-CPU.
+    # The line's CPU baseline is the REFERENCE'S whole compute through the REFERENCE'S library on this box's host
+    # cores: every torch call of build_dfm_cost (dfm_backbone.py:217-314) on PyTorch-CPU, one sample at full C.
     # (/root/reference cannot travel to the GPU box, so the function's own file is timed in the build
     # container only: `reference_torch_cpu`.)  The C port of the oracle -- faster than torch on the same
     # cores -- is reported beside it.
@@ -223,40 +228,79 @@ def cpu_baseline(w, budget_s=12.0):
     return out
 
 
-def torch_cpu_sampling(w, prm, depths, orc, budget_s=8.0):
-    """The reference's own compute for this path is two ``F.grid_sample`` calls (dfm_backbone.py:296-311;
-    building the grids is negligible next to them).  /root/reference does not exist on the GPU box, so its
-    file cannot be timed here -- but the same library function can: ``F.grid_sample`` (bilinear, zeros,
-    align_corners=True) on PyTorch-CPU with this host's cores, on the grids the oracle builds for the same
-    geometry, one sample, a channel subset sized to the budget, scaled by C.  A reported baseline."""
-    import torch.nn.functional as F
-    cg, pg = orc.plane_sweep_grid(prm, depths)
-    cg = torch.from_numpy(cg).view(1, 1, -1, 2)
-    pg = torch.from_numpy(pg).view(1, 1, -1, 2)
-    threads = torch.get_num_threads()
+def torch_cpu_sampling(w, prm, depths, orc, budget_s=14.0):
+    """The reference's WHOLE ``build_dfm_cost`` (dfm_backbone.py:217-314) on PyTorch-CPU with this host's cores:
+    lattice + meshgrid, un-projection / re-projection (the ~25 element-wise and matmul calls of :247-294), the
+    two ``F.grid_sample`` calls and the channel ``cat`` -- every library call the reference issues, through
+    ``oracle/dfm_torch_baseline.py`` (checked bit for bit against the reference-generated fixtures by the CPU
+    tests; /root/reference itself does not exist on the GPU box).  ONE sample at the workload's FULL channel
+    count, nothing scaled -- when the host has the memory for it (N*: 27 GB of fp32 for the two halves and
+    their cat); otherwise a channel subset, scaled by C, and the line says so.  A reported baseline."""
+    from oracle import dfm_torch_baseline as tb
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(threads)   # (torchrun exports OMP_NUM_THREADS=1 to its ranks)
+    C, H, W = w['C'], w['H'], w['W']
+    need = 4 * 4 * C * prm.D * prm.h_out * prm.w_out * 1.15   # a, b, cat(a, b) + slack, bytes
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 0
+    c_run = C if need < 0.6 * avail else int(max(2, min(C, C * 0.6 * avail / need)))
+    dt = torch.from_numpy(np.asarray(depths, np.float32))
+    P = torch.from_numpy(KITTI_P2.copy())[None]
+    T = torch.from_numpy(poses(1, 2))
 
     def run(c_sub):
-        cur = torch.randn(1, c_sub, w['H'], w['W'])
-        prev = torch.randn(1, c_sub, w['H'], w['W'])
+        cur = torch.randn(1, c_sub, H, W)
+        prev = torch.randn(1, c_sub, H, W)
         t0 = time.perf_counter()
         with torch.no_grad():
-            a = F.grid_sample(cur, cg, mode='bilinear', padding_mode='zeros', align_corners=True)
-            b = F.grid_sample(prev, pg, mode='bilinear', padding_mode='zeros', align_corners=True)
-            torch.cat([a.view(1, c_sub, prm.D, prm.h_out, prm.w_out), b.view(1, c_sub, prm.D, prm.h_out, prm.w_out)], 1)
-        return time.perf_counter() - t0
-    run(1)
-    t1 = run(2)
-    c_sub = int(max(2, min(w['C'], round(2 * (budget_s / 3.0) / max(t1, 1e-6)))))
+            vol = tb.build_dfm_cost(cur, prev, dt, w['fsf'], w['csf'], P, T, (375, 1242), w['flip'],
+                                    tuple(w['crop']), w['scale'])
+        dtm = time.perf_counter() - t0
+        assert vol.shape == (1, 2 * c_sub, prm.D, prm.h_out, prm.w_out)
+        return dtm
+    t1 = run(min(2, c_run))   # pages the library in, warms the thread pool
+    if c_run < C:
+        c_run = int(max(2, min(c_run, round(2 * (budget_s / 3.0) / max(t1, 1e-6)))))
+    run(c_run)                # first touch of the large allocations
     reps, total = 0, 0.0
-    while total < budget_s and reps < 8:
-        total += run(c_sub)
+    while reps < 2 or (total < budget_s and reps < 8):
+        total += run(c_run)
         reps += 1
-    sec_per_volume = total / reps * (w['C'] / c_sub)
+    sec_per_volume = total / reps * (C / c_run)
     return {'value': 1.0 / sec_per_volume, 'unit': 'cost-volumes/s', 'threads': threads,
-            'what': 'F.grid_sample x 2 + cat (the reference function\'s compute, dfm_backbone.py:296-313) on '
-                    'PyTorch-CPU fp32, this host',
-            'sample': f'1 sample, {c_sub} of {w["C"]} channels x D={w["D"]} x {prm.h_out}x{prm.w_out}, '
-                      f'{reps} repetitions, {total:.1f} s, scaled by C'}
+            'what': 'the reference\'s build_dfm_cost in full (dfm_backbone.py:217-314: grid construction, '
+                    'points_img2cam / points_cam2img, F.grid_sample x 2, cat) on PyTorch-CPU fp32, this host, '
+                    'via oracle/dfm_torch_baseline.py (bit-identical to the reference on the golden fixtures)',
+            'sample': (f'1 sample at the full C={C} x D={w["D"]} x {prm.h_out}x{prm.w_out}, nothing scaled, '
+                       if c_run == C else
+                       f'1 sample, {c_run} of {C} channels (host memory) x D={w["D"]} x {prm.h_out}x{prm.w_out}, '
+                       'scaled by C, ') + f'{reps} repetitions, {total:.1f} s'}
+
+
+def line_extras(args, w, elem, explicit, last_kernel):
+    """names of the reported blocks rank 0 adds to the headline line after the timed region, in order.  A pure
+    function of the command line and the workload -- NOT of the world size: `--gpus 8` prints the fields
+    `--gpus 1` prints (tests/test_distributed_cpu.py holds that)."""
+    ex = []
+    if not args.channels_last:
+        ex.append('api_build_dfm_cost')
+        if w['C'] % (16 // elem) == 0:
+            ex.append('channels_last_variant')
+    if (args.traffic_bytes is None and not args.no_traffic and not args.channels_last and last_kernel == 2
+            and not w.get('nhwc')):
+        ex.append('traffic')
+    if args.workload == 'nstar' and not explicit and not args.channels_last and not args.no_secondary:
+        ex.append('secondary')
+    if not args.no_cpu_baseline:
+        ex.append('cpu_baseline')
+    return ex
 
 
 def rank_census(job):
@@ -406,15 +450,48 @@ def secondary(args, pkg, dev, job, emit=True):
                         ori_shape=(375, 1242, 3), pad_shape=(H, W, 3), crop_offset=[0, 55], flip=False,
                         scale_factor=[1.0])
 
+        fwd_module, reducer = path, None
+        if train and getattr(args, 'reducer', 'none') != 'none':
+            # the training step's one collective (apis/train.py:222-230), overlapped with backward:
+            # torch DDP around the path, or GradientBucketReducer's xGMI-sized buckets
+            par = importlib.import_module('depth-from-motion_amd.parallel')
+            if args.reducer == 'ddp':
+                if not torch.distributed.is_initialized():  # a one-rank group: same code path
+                    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                    os.environ.setdefault('MASTER_PORT', '29534')
+                    torch.distributed.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+                fwd_module = torch.nn.parallel.DistributedDataParallel(
+                    path, device_ids=[dev.index], broadcast_buffers=False, bucket_cap_mb=32,
+                    find_unused_parameters=True)
+            else:
+                reducer = par.GradientBucketReducer(path.parameters())
+            comm = {'reducer': args.reducer,
+                    'gradient_bytes': sum(p.numel() * p.element_size() for p in path.parameters() if p.requires_grad),
+                    'buckets': len(reducer.buckets) if reducer is not None else None}
+
+        def train_step(module):
+            path.zero_grad(set_to_none=True)
+            out = module(cur, prev, [meta()])
+            loss = path.loss_dense_depth(out, depth_img, fg) + out['bev_feat'].float().square().mean()
+            loss.backward()
+
         def step():
             if train:
-                path.zero_grad(set_to_none=True)
-                out = path(cur, prev, [meta()])
-                loss = path.loss_dense_depth(out, depth_img, fg) + out['bev_feat'].float().square().mean()
-                loss.backward()
+                train_step(fwd_module)
+                if reducer is not None:
+                    reducer.finalize()
                 return None
             with torch.no_grad():
                 return path(cur, prev, [meta()])
+        if comm is not None:
+            if reducer is not None:
+                def no_exchange():
+                    reducer.enabled = False
+                    train_step(path)
+                    reducer.enabled = True
+                comm.update(step_without_exchange=no_exchange, reducer_obj=reducer)
+            else:
+                comm.update(step_without_exchange=lambda: train_step(path))
         # the 3-D aggregation stacks' share of the step's arithmetic: what the fraction is quoted on
         flops = (3 if train else 1) * 0.96e12
         name = ('DfMStereoPath training step (forward + dense depth loss + backward)' if train else
@@ -782,7 +859,7 @@ def main():
                     help='skip dfm_plane_sweep_autotune (workgroup schedule stays at its default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--reducer', default='none', choices=['none', 'ddp', 'bucket'],
-                    help='backbone_train: gradient exchange of the step (DDP, or GradientBucketReducer)')
+                    help='backbone_train / stereo_train: gradient exchange of the step (DDP, or GradientBucketReducer)')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass (default: measured in this run)')
     ap.add_argument('--no-traffic', action='store_true', help='skip the in-run rocprofv3 --pmc passes')
@@ -895,7 +972,7 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
                 'note': "zeros in 4 KiB runs walking every channel plane (dfm_store_probe), a linear fill, the shader "
                         'clock under an FMA load on every CU (dfm_clock_probe); smi: amd-smi / rocm-smi readings, '
                         'clocks and power sampled while the sweep runs'}
-        if rank == 0 and not args.no_smi:
+        if world == 1 and not args.no_smi:   # (N > 1: rank 0 must not run 400 extra launches while the others go ahead)
             try:
                 sys.path.insert(0, os.path.join(ROOT, 'tools'))
                 import part_info
@@ -962,6 +1039,9 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
     value = job.value(B, args.steps, elapsed)
 
     if rank == 0:
+        # everything below is rank 0 on its own, AFTER the job's closing barrier (the other ranks leave): the
+        # line carries the same fields at every N (line_extras: nothing in it depends on the world size)
+        extras = line_extras(args, w, elem, explicit, lib.dfm_plane_sweep_last_kernel())
         bytes_per_launch = algorithmic_bytes(w, elem) * B
         avg_kernel_ms = kms.value / max(klaunches.value, 1)
         achieved = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
@@ -1017,7 +1097,7 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
             **census,
             'part': part,
         }
-        if world == 1 and not args.channels_last:
+        if 'api_build_dfm_cost' in extras:
             # the public API (what DfMBackbone.forward calls): build_dfm_cost with device-resident
             # intrinsics / poses -- pads, inverts and packs them on the device, allocates the
             # volume, launches.  Reported beside the raw launch, never as `value`.
@@ -1044,7 +1124,7 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
                 'note': 'public build_dfm_cost(): device-side pad/inverse/pack of the camera '
                         'matrices + output allocation (caching allocator) + the same launch'}
             out = None
-        if world == 1 and not args.channels_last and w['C'] % (16 // elem) == 0:
+        if 'channels_last_variant' in extras:
             # the same volume written channels-last (opt-in layout, identical values): reported
             # beside the headline, never instead of it
             out_cl = torch.empty((B, w['D'], desc.h_out, desc.w_out, 2 * w['C']), dtype=tdtype,
@@ -1072,17 +1152,18 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
             del out_cl
         ran = tuned if tuned is not None else pkg._capi.SweepOpts(
             **{sweep._OPT_FIELDS[k]: v for k, v in explicit.items()}).as_dict()
-        if (world == 1 and args.traffic_bytes is None and not args.no_traffic and not args.channels_last
-                and lib.dfm_plane_sweep_last_kernel() == 2 and not w.get('nhwc')):
+        if 'traffic' in extras:
+            out = None
             torch.cuda.empty_cache()
             tr = measure_traffic(args.workload, ran)
             if tr is not None:
                 line['roofline']['traffic'] = tr['hbm_bytes_per_launch']
                 line['roofline']['traffic_detail'] = tr
-        if world == 1 and args.workload == 'nstar' and not explicit and not args.channels_last and not args.no_secondary:
+        if 'secondary' in extras:
+            out = None
             torch.cuda.empty_cache()
-            line['secondary'] = secondary_block(pkg, sweep, dev, job)
-        if world == 1 and not args.no_cpu_baseline:
+            line['secondary'] = secondary_block(pkg, sweep, dev, job.solo())
+        if 'cpu_baseline' in extras:
             line['cpu_baseline'] = cpu_baseline(w)
         print(json.dumps(line), flush=True)
     if world > 1:

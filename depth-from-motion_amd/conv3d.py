@@ -91,6 +91,7 @@ def pack_conv3d_weights(weight, cin_offset=0, transposed=False):
     """(32, C_in >= 32, 3, 3, 3) fp32/bf16 GPU weight -> MFMA A-operand fragments (+ zero page) for
     the 32 input channels starting at ``cin_offset``.  ``transposed``: fragments of the
     backward-data convolution (grad_in[:, cin_offset:cin_offset+32] = conv(grad_out, W'))."""
+    note_derived_build()
     assert weight.is_cuda and weight.dim() == 5 and weight.shape[0] == 32 and tuple(weight.shape[2:]) == (3, 3, 3)
     w = weight.detach().contiguous()
     if w.dtype not in _WDT:
@@ -185,6 +186,21 @@ _DERIVED_RESET = {'_packs': None, '_pack_key': None, '_sweep_conv_pack': (None, 
 _DERIVED_DROP = frozenset((
     '_split_packs', '_split_key', '_pack2d', '_pack2d_key', '_gate_pack', '_dev_cache', '_coords_ref', '_coords_key',
     '_coords_dev', '_spp_params', '_spp_key', '_fold', '_fold_key'))
+
+# Derived state is built lazily by the FIRST call that needs it, with kernels on that call's HIP stream.  A module
+# that runs on two streams (DfMStereoPath: the same 2-D neck for the previous frame on a side stream and for the
+# current frame on the main stream) would let the second stream read packed weights the first has not finished
+# writing.  Every build site bumps this counter; a caller that forks streams compares it around the first call and
+# makes the other stream wait when anything was built (integration.DfMStereoPath.forward).
+_DERIVED_BUILDS = [0]
+
+
+def note_derived_build():
+    _DERIVED_BUILDS[0] += 1
+
+
+def derived_builds():
+    return _DERIVED_BUILDS[0]
 
 
 class DerivedStateMixin:
@@ -559,6 +575,7 @@ def pack_conv3d_g_weights(weight, cin, cout, swap=False, flip=0):
     page) for a convolution with ``cin`` input and ``cout`` output channels.  ``swap``: dim0 is the
     input-channel axis of that convolution; ``flip``: bit mask (4 = d, 2 = h, 1 = w) of mirrored
     kernel axes (see include/dfm_hip.h)."""
+    note_derived_build()
     assert weight.is_cuda and weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3)
     assert tuple(weight.shape[:2]) == ((cin, cout) if swap else (cout, cin))
     w = weight.detach().contiguous()

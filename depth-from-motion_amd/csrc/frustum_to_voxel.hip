@@ -1130,17 +1130,19 @@ __global__ __launch_bounds__(256) void f2v_bwd_gather_kernel(F2vGeom g, F2vGrid 
             const float ty = (fabsf(yu - yc) + fabsf(yv - yc)) * fabsf(idy) * 1.15f + 0.05f;
             const float tz = (fabsf(zu - zc) + fabsf(zv - zc)) * fabsf(idz) * 1.15f + 0.05f;
             const float y0f = ceilf(iyf - ty), y1f = floorf(iyf + ty), z0f = ceilf(izf - tz), z1f = floorf(izf + tz);
-            // (non-finite solutions compare false; a box of more than 8 voxels per axis -- far beyond what the
-            //  path's grids produce -- is clipped: the host only selects this kernel for grids where it is not)
+            // (non-finite solutions compare false.)  The box is walked in FULL whatever its size, clamped to the
+            // grid in fp32 before the int conversion: a coarser cost volume, finer voxels or a long depth range
+            // make a cost-volume pixel span many voxels, and the former cut at 8 x 8 / t < 4 dropped those
+            // contributions silently.  Larger boxes only cost more iterations.
             const bool some = inside && y0f <= y1f && z0f <= z1f && y1f >= 0.0f && z1f >= 0.0f &&
-                              y0f <= (float)(g.Ny - 1) && z0f <= (float)(g.Nz - 1) && ty < 4.0f && tz < 4.0f;
+                              y0f <= (float)(g.Ny - 1) && z0f <= (float)(g.Nz - 1);
             if (!__any(some)) continue;
-            const int iy0 = some ? max((int)y0f, 0) : 0, iy1 = some ? min((int)y1f, g.Ny - 1) : -1;
-            const int iz0 = some ? max((int)z0f, 0) : 0, iz1 = some ? min((int)z1f, g.Nz - 1) : -1;
-            for (int jz = 0; jz < 8; ++jz) {
+            const int iy0 = some ? (int)fmaxf(y0f, 0.0f) : 0, iy1 = some ? (int)fminf(y1f, (float)(g.Ny - 1)) : -1;
+            const int iz0 = some ? (int)fmaxf(z0f, 0.0f) : 0, iz1 = some ? (int)fminf(z1f, (float)(g.Nz - 1)) : -1;
+            for (int jz = 0;; ++jz) {
                 const int iz = iz0 + jz;
                 if (!__any(iz <= iz1)) break;
-                for (int jy = 0; jy < 8; ++jy) {
+                for (int jy = 0;; ++jy) {
                     const int iy = iy0 + jy;
                     const bool cand = iz <= iz1 && iy <= iy1;
                     if (!__any(cand)) break;

@@ -570,9 +570,12 @@ __device__ __forceinline__ int tile_body(
         if constexpr (MXK) {
             // a staged row with a non-finite / denormal / -0 value (pack_blocked_kernel's row flags): this body
             // has no VALU unpack -- the caller runs the one that has (same rows for every wave: uniform)
-            const int nrows = y1 - y0 + 1;  // <= 8: the tile fits one pipelined buffer
+            // (`fits` bounds staged PIXELS, not rows: a narrow map, W <= 38, stages more than 64 rows in one
+            //  pipelined buffer -- every row is looked at, 64 per trip)
+            const int nrows = y1 - y0 + 1;
             const int *rf = tg.flags + ((size_t)half * batch + b) * H + y0;
-            const bool odd_row = (tid & 63) < nrows && rf[tid & 63] != 0;
+            bool odd_row = false;
+            for (int r = tid & 63; r < nrows; r += 64) odd_row |= rf[r] != 0;
             if (__any(odd_row)) {
                 if (retry_inline) return 2;
                 if (tid == 0 && blk_lo_ovr <= 0) spill_list[1 + atomicAdd(&spill_list[0], 1)] = bid;

@@ -205,16 +205,20 @@ __global__ __launch_bounds__(256) void sweep_bwd_gather_kernel(
         // candidate lattice box [w0, w1] x [h0, h1] (empty for most pixels); non-finite wf / hf compare false
         const float w0f = ceilf(wf - tolw), w1f = floorf(wf + tolw), h0f = ceilf(hf - tolh), h1f = floorf(hf + tolh);
         const bool some = inside && w0f <= w1f && h0f <= h1f && w1f >= 0.0f && h1f >= 0.0f &&
-                          w0f <= (float)(g.w_out - 1) && h0f <= (float)(g.h_out - 1) && tolw < 2.0f && tolh < 2.0f;
+                          w0f <= (float)(g.w_out - 1) && h0f <= (float)(g.h_out - 1);
         if (!__any(some)) continue;
-        const int w0 = some ? max((int)w0f, 0) : 0, w1 = some ? min((int)w1f, g.w_out - 1) : -1;
-        const int h0 = some ? max((int)h0f, 0) : 0, h1 = some ? min((int)h1f, g.h_out - 1) : -1;
+        // The box is walked in FULL, whatever its size (clamped to the lattice in fp32 first: an infinite
+        // tolerance must not reach the int conversion).  The fit vouches for boxes below GP_MAX_TOL at five
+        // sample points only; a pixel elsewhere on the plane whose box is larger used to be cut at 4 x 4 and
+        // tol < 2 -- contributions silently dropped.  Larger boxes only cost more iterations.
+        const int w0 = some ? (int)fmaxf(w0f, 0.0f) : 0, w1 = some ? (int)fminf(w1f, (float)(g.w_out - 1)) : -1;
+        const int h0 = some ? (int)fmaxf(h0f, 0.0f) : 0, h1 = some ? (int)fminf(h1f, (float)(g.h_out - 1)) : -1;
         const float depth = depths[d];
         const T *gd = gb + (size_t)d * hw * pstride;
-        for (int kh = 0; kh < 4; ++kh) {
+        for (int kh = 0;; ++kh) {
             const int lh = h0 + kh;
             if (!__any(lh <= h1)) break;
-            for (int kw = 0; kw < 4; ++kw) {
+            for (int kw = 0;; ++kw) {
                 const int lw = w0 + kw;
                 const bool cand = lh <= h1 && lw <= w1;
                 if (!__any(cand)) break;

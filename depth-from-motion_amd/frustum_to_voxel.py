@@ -5,6 +5,7 @@
 import contextlib
 import ctypes
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -139,9 +140,13 @@ def _regular_grid(coords, desc):
     (x fastest, centres origin + index * step), else None.  Checked ON THE DEVICE once per tensor (one small
     reduction and one host read, cached on the tensor's identity and version): the gather form of the backward
     enumerates voxels by index arithmetic."""
-    key = (coords.data_ptr(), coords._version, tuple(coords.shape), desc.nz, desc.ny, desc.nx)
+    # the entry is tied to the tensor OBJECT that owns the memory (a view's base; views of one tensor share it): the
+    # caching allocator hands a freed address to the next coordinate tensor of the same shape, version 0 again, and
+    # an address-only key would serve it the previous tensor's verdict (ADVICE round 5)
+    owner = coords._base if coords._base is not None else coords
+    key = (id(owner), coords.data_ptr(), coords._version, tuple(coords.shape), desc.nz, desc.ny, desc.nx)
     hit = _GRID_CACHE.get(key)
-    if hit is not None:
+    if hit is not None and hit[1]() is owner:
         return hit[0]
     nz, ny, nx = desc.nz, desc.ny, desc.nx
     grid = None
@@ -164,7 +169,7 @@ def _regular_grid(coords, desc):
             grid = tuple(v if (i % 2 == 0 or v != 0.0) else 1.0 for i, v in enumerate(vals[:6]))
     if len(_GRID_CACHE) > 16:
         _GRID_CACHE.clear()
-    _GRID_CACHE[key] = (grid,)
+    _GRID_CACHE[key] = (grid, weakref.ref(owner))
     return grid
 
 

@@ -127,14 +127,21 @@ class DfMStereoPath(nn.Module):
         if (self.two_streams and cur_feats[0].is_cuda and not torch.is_grad_enabled() and not self.training and
                 not torch.cuda.is_current_stream_capturing()):
             from .modules import DfMBackbone
+            from .conv3d import derived_builds
             d0 = cur_feats[0].device
             main = torch.cuda.current_stream(d0)
             side = DfMBackbone._side_streams.get(d0)
             if side is None:
                 side = DfMBackbone._side_streams[d0] = torch.cuda.Stream(device=d0)
             side.wait_stream(main)
+            built = derived_builds()
             with torch.cuda.stream(side):
                 prev_stereo, _ = self._run_2d('neck_prev', self.neck, list(prev_feats))
+            if derived_builds() != built:
+                # the first call after a weight load / change built the neck's derived state (packed weights,
+                # folded norms) with kernels on the SIDE stream: the main-stream call finds the caches filled
+                # and would read them unordered.  That one forward runs the two frames back to back.
+                main.wait_stream(side)
             cur_stereo, cur_sem = self._run_2d('neck_cur', self.neck, list(cur_feats))
             main.wait_stream(side)
             prev_stereo.record_stream(main)

@@ -30,7 +30,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import (DerivedStateMixin, long_axis_gram, MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose2d,
+from .conv3d import (DerivedStateMixin, long_axis_gram, note_derived_build, MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose2d,
                      MfmaConvTranspose3d, channel_slice)
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
@@ -55,6 +55,7 @@ def _on_device(owner, name, device):
     hit = cache.get(name)
     if hit is None or hit[0]() is not t or hit[1] != key:
         hit = cache[name] = (weakref.ref(t), key, t.to(device=device, dtype=torch.float32).contiguous())
+        note_derived_build()
     return hit[2]
 
 
@@ -166,6 +167,7 @@ class ConvModule(DerivedStateMixin, nn.Module):
             if norm.affine:
                 shift = shift + norm.bias.float()
             self._fold, self._fold_key = (scale.contiguous(), shift.contiguous()), key
+            note_derived_build()
         return self._fold
 
     def forward_fused(self, x, residual=None, relu=None):
@@ -327,11 +329,17 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
     # hourglass levels of 250 workgroups (half a chip), GroupNorm passes -- and the other stack's kernels fill
     # what one leaves free.  The side stream waits for what the main stream has produced so far, the main stream
     # joins it before the prediction heads; scratch is per (device, stream) (plane_sweep._Workspace) and the
-    # side stream's results are handed to the main stream with record_stream.  Training keeps one stream
-    # (autograd replays the forward's streams; nothing there was measured).  two_streams = False pins one stream.
+    # side stream's results are handed to the main stream with record_stream.  two_streams = False pins one stream.
     two_streams = True
-    # with autograd recording: every backward node runs on the stream its forward ran on (the engine inserts the
-    # cross-stream waits), so the two stacks overlap in the backward pass as well
+    # With autograd recording: every backward node runs on the stream its forward ran on (the engine inserts the
+    # cross-stream waits), so the two stacks overlap in the backward pass as well (backbone_train 12.5 -> 10.7 ms,
+    # profiles/r05_c16_*).  The mono stack's PARAMETER gradients, however, must not be produced on the side stream:
+    # gradient hooks (DistributedDataParallel's reducer, GradientBucketReducer) run under the stream of the
+    # AccumulateGrad node and order their bucket copies / collectives against that stream only.  An AccumulateGrad
+    # node takes the stream that is current when it is CREATED, so `_two_branches` creates the mono parameters'
+    # nodes on the main stream before it forks (`_pin_accumulators`): the weight-gradient kernels still run on the
+    # side stream, the accumulation -- and every hook -- on the main stream behind the engine's event wait
+    # (tests/test_backward_gpu.py checks the stream the hooks see).  DFM_TRAIN_ONE_STREAM=1 pins one stream.
     two_streams_training = os.environ.get('DFM_TRAIN_ONE_STREAM') != '1'
     _side_streams = {}
 
@@ -354,14 +362,23 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
         side = DfMBackbone._side_streams.get(device)
         if side is None:
             side = DfMBackbone._side_streams[device] = torch.cuda.Stream(device=device)
+        pins = self._pin_accumulators() if torch.is_grad_enabled() else None
         side.wait_stream(main)
         with torch.cuda.stream(side):
             mono, m_cost = mono_all()
+        del pins  # (the recorded graph holds the nodes from here on)
         stereo, s_cost = stereo_all()
         main.wait_stream(side)
         for t in list(mono) + [m_cost]:
             t.record_stream(main)
         return (stereo, s_cost), (mono, m_cost)
+
+    def _pin_accumulators(self):
+        """views of the mono stack's trainable parameters taken on the CURRENT (main) stream: each creates the
+        parameter's AccumulateGrad node, which keeps the stream it was created under; holding the views keeps the
+        nodes alive until the side-stream forward has linked them into the graph"""
+        return [p.view_as(p) for m in (self.dres0_mono, self.dres1_mono, self.hg_mono, self.pred_mono)
+                for p in m.parameters() if p.requires_grad]
 
     def _sweep_dres0_fusable(self, cur, prev=None):
         """the fused plane sweep + dres0 / dres0_mono kernel takes this call: inference, bf16 32-channel
@@ -381,6 +398,7 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
         key = (ws._version, ws.data_ptr(), wm._version, wm.data_ptr(), str(ws.device))
         if self._sweep_conv_pack[0] != key:
             self._sweep_conv_pack = (key, pack_sweep_conv_weights(ws, wm))
+            note_derived_build()
         return self._sweep_conv_pack[1]
 
     def forward(self, cur_stereo_feats, prev_stereo_feats, img_metas, cur_sem_feats=None):
@@ -438,6 +456,7 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
                 _capi.check(lib.dfm_cost_gate_pack_weights(_ptr(w.detach()), _DTYPES[w.dtype], D, _ptr(packed),
                                                            _stream_ptr(s_cost.device)))
                 self.__dict__['_gate_pack'] = (key, packed)
+                note_derived_build()
             _capi.check(lib.dfm_cost_gate_fwd(B, D, H * W, _DTYPES[s_cost.dtype], _ptr(s_cost), _ptr(m_cost),
                                               _ptr(self.__dict__['_gate_pack'][1]), _ptr(out),
                                               _stream_ptr(s_cost.device)))
@@ -620,6 +639,7 @@ class FrustumToVoxel(DerivedStateMixin, nn.Module):
         if ref is None or ref() is not c or self.__dict__.get('_coords_key') != key:
             self.__dict__['_coords_dev'] = c.to(device=device, dtype=torch.float32).contiguous()
             self.__dict__['_coords_ref'], self.__dict__['_coords_key'] = weakref.ref(c), key
+            note_derived_build()
         return self._coords_dev
 
     def forward(self, stereo_feat, stereo_feat_softmax, img_metas, cur_sem_feats=None):
@@ -768,6 +788,7 @@ def _conv_norm_2d(seq, x, residual=None, relu=False):
             scale = norm.weight.float() / torch.sqrt(norm.running_var.float() + norm.eps)
             seq.__dict__['_fold'] = (scale, norm.bias.float() - norm.running_mean.float() * scale)
             seq.__dict__['_fold_key'] = key
+            note_derived_build()
         scale, shift = seq.__dict__['_fold']
         return conv.forward_fused(x, scale, shift, residual=residual, relu=relu)
     y = norm(conv(x))
@@ -1041,6 +1062,7 @@ class SPPUNetNeck(DerivedStateMixin, nn.Module):
                  getattr(m, m.norm_name).weight.detach().float().contiguous(),
                  getattr(m, m.norm_name).bias.detach().float().contiguous()) for m in cms]
             self.__dict__['_spp_key'] = key
+            note_derived_build()
         params = self.__dict__['_spp_params']
         B, _, H, W = srcs[0].shape
         d = _capi.SppDesc()

@@ -126,10 +126,13 @@ class GradientBucketReducer:
         self._ready = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._copied = [[] for _ in self.buckets]  # events of the gradient copies into each bucket (CUDA)
+        self._zeroed = [None] * len(self.buckets)  # event behind the last zero fill of each bucket (CUDA)
         self._next = 0  # first bucket not launched yet
         self._filled = set()
         self.launched_during_backward = 0
         self.enabled = True  # False: hooks and finalize() do nothing (a step without the exchange, for A/B timing)
+        for bi in range(len(self.buckets)):  # allocated and zeroed now, not inside the first hook
+            self._buffer(bi)
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
     def _buffer(self, bi):
@@ -137,7 +140,18 @@ class GradientBucketReducer:
             b = self.buckets[bi]
             self._flat[bi] = torch.zeros(sum(p.numel() for p in b), dtype=b[0].dtype,
                                          device=b[0].device)
+            self._mark_zeroed(bi)
         return self._flat[bi]
+
+    def _mark_zeroed(self, bi):
+        """the zero fill of a bucket runs on the stream that is current HERE; a hook on another stream (the mono
+        stack's backward runs on DfMBackbone's side stream) must not copy its gradient in before the fill has
+        executed -- hooks wait for this event"""
+        buf = self._flat[bi]
+        if buf.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(buf.device))
+            self._zeroed[bi] = ev
 
     def _launch_ready(self, final=False):
         while self._next < len(self.buckets) and (final or
@@ -162,7 +176,10 @@ class GradientBucketReducer:
         if p in self._filled:  # a second backward before finalize(): gradients accumulate
             raise RuntimeError('GradientBucketReducer: call finalize() after every backward()')
         self._filled.add(p)
-        self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        buf = self._buffer(bi)
+        if self._zeroed[bi] is not None:
+            torch.cuda.current_stream(buf.device).wait_event(self._zeroed[bi])
+        buf[off:off + p.numel()].copy_(p.grad.reshape(-1))
         if p.grad.is_cuda:
             # backward nodes run on the stream their forward ran on (DfMBackbone's two stacks use two): the copy
             # above is ordered on THIS hook's stream only -- the stream that launches the bucket waits for it
@@ -193,6 +210,7 @@ class GradientBucketReducer:
                     p.grad.copy_(piece)
                 off += p.numel()
             buf.zero_()
+            self._mark_zeroed(bi)
         n = len(self.buckets)
         self._ready = [0] * n
         self._work = [None] * n
@@ -214,13 +232,23 @@ class BenchJob:
 
     ``sync``: the device synchronisation (``torch.cuda.synchronize`` on a GPU; a no-op on CPU)."""
 
-    def __init__(self, rank=0, world=1, device=None, sync=None):
+    def __init__(self, rank=0, world=1, device=None, sync=None, solo=False):
         self.rank, self.world, self.device = int(rank), int(world), device
         self._sync = sync or (lambda: None)
+        self._solo = bool(solo)
+        if self._solo:
+            return
         if self.world > 1 and not _active():
             raise RuntimeError('BenchJob(world > 1) needs an initialised torch.distributed process group')
         if _active() and dist.get_world_size() != self.world:
             raise RuntimeError(f'process group has {dist.get_world_size()} ranks, the job says {self.world}')
+
+    def solo(self):
+        """this rank on its own, whatever process group exists: a one-rank job whose methods issue NO
+        collective.  bench.py's rank 0 measures the reported extras of the line (HBM counter passes, the CPU
+        baseline, the secondary rows) with it AFTER the job's closing barrier, while the other ranks leave --
+        so the line carries the same fields at every N."""
+        return BenchJob(0, 1, self.device, self._sync, solo=True)
 
     def barrier(self):
         if self.world > 1:
@@ -250,12 +278,14 @@ class BenchJob:
         # own time is no longer padded with its wait for the straggler)
         elapsed = clock() - t0
         self.barrier()
+        if self._solo:
+            return float(elapsed), [float(elapsed)]
         return gather_rank_times(elapsed, self.device)
 
     def ranks_seen(self):
         """How many ranks the collective library actually reached: an all-reduce (SUM) of a one per rank
         over the job's process group (RCCL on a GPU node).  bench.py prints it next to ``n_gpus``."""
-        if self.world == 1 and not _active():
+        if self._solo or (self.world == 1 and not _active()):
             return 1
         t = torch.ones(1, dtype=torch.int32, device=self.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

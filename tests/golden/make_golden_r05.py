@@ -7,8 +7,10 @@ the inputs and the outputs it produced are stored.
   plane_sweep_zero_depth.npz   a sweep that REACHES NON-FINITE SAMPLING COORDINATES: cur2prev is a pure
       translation by -depths[1] along the optical axis and the intrinsics have no fourth column, so every
       lattice point of plane 1 lands at z = 0 in the previous camera and the reference's unguarded
-      projection (core/bbox/structures/utils.py:209) divides by zero: x / 0 = +-Inf, and 0 / 0 = NaN on the
-      principal axis.  F.grid_sample on PyTorch-CPU answers such coordinates with NaN (its bilinear weights
+      projection (core/bbox/structures/utils.py:209) divides by zero: x / 0 = +-Inf.  (NO coordinate of this
+      fixture is NaN: with f = 720 the principal-axis pixel does not un-project to exactly 0 in fp32 -- the
+      generator prints `of which NaN: 0`.  make_golden_r06.py's plane_sweep_nan_coords.npz reaches 0 / 0.)
+      F.grid_sample on PyTorch-CPU answers such coordinates with NaN (its bilinear weights
       are Inf - Inf); the oracle and the HIP kernels answer 0 -- the value `padding_mode='zeros'` gives
       every other coordinate outside the map.  The fixture stores the reference's output (NaNs included)
       and its grids; tests/test_oracle_golden.py and tests/test_plane_sweep_gpu.py pin both facts: equal

@@ -235,3 +235,54 @@ def test_mv_lifting_backward(pkg, case):
     np.testing.assert_allclose(ref.detach().numpy(), z['ref_out'][0], rtol=1e-6, atol=1e-6)
     (ref * go[0]).sum().backward()
     np.testing.assert_allclose(fg.grad[0].cpu().numpy(), fr.grad.numpy(), **TOL)
+
+
+def test_backbone_two_stream_training_hooks_see_the_main_stream(pkg):
+    """DfMBackbone trains its mono stack on a side HIP stream (modules.DfMBackbone._two_branches).  Gradient
+    hooks -- DistributedDataParallel's reducer, parallel.GradientBucketReducer -- order their work against the
+    stream that is current INSIDE the hook only, so every parameter's AccumulateGrad (and with it every hook)
+    has to run on the main stream; and the gradients must be those of the one-stream run."""
+    mods = importlib.import_module('depth-from-motion_amd.modules')
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    m = mods.DfMBackbone(in_channels=32, depth_cfg=dict(mode='UD', num_bins=32, depth_min=2, depth_max=59.6,
+                                                        downsample_factor=4)).to(dev).to(torch.bfloat16).train()
+    m.downsampled_depth = pkg.prepare_depth(dict(num_bins=32, depth_min=2, depth_max=59.6, downsample_factor=4))[0]
+    m.volume_memory_format = torch.channels_last_3d
+    P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791],
+                   [0, 0, 1, 0.002745884], [0, 0, 0, 1]], dtype=np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = -0.8
+    meta = dict(ori_cam2img=P2, cur2prevs=torch.from_numpy(T[None]), ori_shape=(375, 1242, 3),
+                pad_shape=(64, 256, 3), crop_offset=[0, 55], flip=False, scale_factor=[1.0])
+    cur = torch.randn(1, 32, 64, 256, device=dev).bfloat16().requires_grad_(True)
+    prev = torch.randn(1, 32, 64, 256, device=dev).bfloat16().requires_grad_(True)
+    main = torch.cuda.current_stream(dev)
+    seen = {}
+    handles = [p.register_post_accumulate_grad_hook(
+        lambda p, n=n: seen.__setitem__(n, torch.cuda.current_stream(dev) == main))
+        for n, p in m.named_parameters() if p.requires_grad]
+
+    def run(two):
+        m.two_streams = two
+        m.zero_grad(set_to_none=True)
+        cur.grad = prev.grad = None
+        outs = m(cur, prev, [meta])
+        g = torch.Generator(device=dev).manual_seed(5)
+        torch.autograd.backward(list(outs), [torch.randn(o.shape, device=dev, generator=g).to(o.dtype) * 1e-2
+                                             for o in outs])
+        torch.cuda.synchronize()
+        return {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    assert m.two_streams_training
+    g2 = run(True)
+    assert mods.DfMBackbone._side_streams.get(dev) is not None, 'the side stream was never used'
+    off = [n for n, ok in seen.items() if not ok]
+    assert seen and not off, f'hooks ran off the main stream for {off[:4]}'
+    assert any(n.startswith('dres1_mono') for n in seen) and any(n.startswith('hg_mono') for n in seen)
+    g1 = run(False)
+    for h in handles:
+        h.remove()
+    assert g1.keys() == g2.keys()
+    for n in g1:   # same kernels, same order per stack: bit-identical
+        assert torch.equal(g1[n], g2[n]), n

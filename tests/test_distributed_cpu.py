@@ -283,3 +283,70 @@ def test_bench_py_launches_itself_when_asked_for_more_than_one_gpu():
     assert i < j and 'self_launch' in src[i:j]
     par = importlib.import_module('depth-from-motion_amd.parallel')
     assert par.BenchJob().ranks_seen() == 1 and par.collective_library() is None
+
+
+# ---------------------------------------------------------------------------------------------
+# the N > 1 line carries the fields of the N = 1 line: rank 0 measures the reported extras (HBM counter
+# passes, CPU baseline, secondary rows) on its own AFTER the closing barrier, through BenchJob.solo(),
+# while the other ranks leave
+# ---------------------------------------------------------------------------------------------
+def _solo_worker(rank, world, port, q):
+    import time
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    par = importlib.import_module('depth-from-motion_amd.parallel')
+    job = par.BenchJob(rank, world)
+    job_s, every = job.timed_steps(lambda: time.sleep(0.005), 3)
+    seen = job.ranks_seen()
+    if rank != 0:
+        # what bench.py's other ranks do after the timed region: leave
+        dist.destroy_process_group()
+        q.put((rank, seen, None))
+        return
+    time.sleep(1.0)          # rank 1 is gone by now: any collective below would hang or fail
+    solo = job.solo()
+    n = []
+    s, ev = solo.timed_steps(lambda: n.append(1), 4)
+    key, agreed = solo.agree_fastest({'a': 2.0, 'b': 1.0})
+    solo.barrier()
+    q.put((rank, seen, dict(world=solo.world, rank=solo.rank, steps=len(n), every=len(ev), seen=solo.ranks_seen(),
+                            key=key, seed=solo.seed(3), value=solo.value(8, 4, 2.0))))
+    dist.destroy_process_group()
+
+
+def test_rank0_measures_the_line_extras_alone_after_the_job():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_solo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (seen, solo)) for r, seen, solo in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == 2
+    assert res[0][1] == dict(world=1, rank=0, steps=4, every=1, seen=1, key='b', seed=3, value=16.0)
+
+
+def test_bench_line_has_the_same_fields_at_every_world_size():
+    """bench.py decides the extras of the headline line (api_build_dfm_cost, channels_last_variant, roofline.traffic,
+    secondary, cpu_baseline) from the command line and the workload only; nothing after `if rank == 0:` in run()
+    may look at the world size again (round 5's line dropped traffic / cpu_baseline / secondary at N > 1)."""
+    import inspect
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    assert 'world' not in inspect.signature(bench.line_extras).parameters
+    tail = inspect.getsource(bench.run).split('if rank == 0:', 1)[1]
+    assert 'world == 1' not in tail and 'world > 1' not in tail.split('print(json.dumps(line)')[0]
+    a = types.SimpleNamespace(workload='nstar', channels_last=False, traffic_bytes=None, no_traffic=False,
+                              no_secondary=False, no_cpu_baseline=False)
+    ex = bench.line_extras(a, bench.WORKLOADS['nstar'], 2, {}, 2)
+    assert ex == ['api_build_dfm_cost', 'channels_last_variant', 'traffic', 'secondary', 'cpu_baseline']
+    # the SMI load loop (400 extra launches on rank 0 only) is a one-GPU probe
+    head = inspect.getsource(bench.run).split('if rank == 0:', 1)[0]
+    assert 'if world == 1 and not args.no_smi' in head

@@ -298,7 +298,7 @@ def test_backward_reads_a_channels_last_gradient_in_place(dtype):
 
 # ---- backward as a gather (dfm_frustum_to_voxel_bwd_gather): a lane per cost-volume pixel x depth chunk -------
 
-def _config_k_like(dtype, seed, Cs=32, yaw=0.0):
+def _config_k_like(dtype, seed, Cs=32, yaw=0.0, ny=50, nz=6):
     """a small problem with config K's structure: 32 + 32 channels, the semantic map at the cost volume's
     resolution, a regular voxel grid (prepare_coordinates_3d's construction), KITTI-like intrinsics on the padded
     image, materialised and fused depth distributions"""
@@ -313,7 +313,7 @@ def _config_k_like(dtype, seed, Cs=32, yaw=0.0):
     dmin, dmax = 2.0, 16.4
     samples = torch.tensor([dmin + (k + 0.5) * ((dmax - dmin) / (4 * D)) for k in range(4 * D)])
     # voxel centres: x (depth) 2 .. 16.4 in 0.2 m steps, y -5 .. 5, z -1.5 .. 0.9 (pseudo-LiDAR frame), x fastest
-    nx, ny, nz = 72, 50, 6
+    nx = 72
     xs = torch.linspace(dmin + 0.1, dmax - 0.1, nx)
     ys = torch.linspace(-5 + 0.1, 5 - 0.1, ny)
     zs = torch.linspace(-1.5 + 0.2, 0.9 - 0.2, nz)
@@ -400,6 +400,35 @@ def test_backward_gather_hands_a_channels_last_volume_its_gradient_in_place(dtyp
         a, b = res[True][1].float(), res[False][1].float()
         assert torch.allclose(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
     assert f2v._BWD_GATHER['native'] and f2v._BWD_GATHER['on']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fused', [False, True], ids=['materialised', 'fused_head'])
+def test_backward_gather_walks_boxes_of_any_size(fused):
+    """voxels much finer than a cost-volume pixel's footprint (0.06 m x 0.1 m against 0.36 m at the far planes): a
+    pixel's candidate box is 6+ voxels wide.  The kernel used to cut boxes at 8 x 8 voxels and skip pixels whose
+    half-width exceeded 4 -- contributions dropped without an error; it now walks the whole box."""
+    f2v = importlib.import_module('depth-from-motion_amd.frustum_to_voxel')
+    pkg, dev, stereo, sem, soft, lazy, metas, coords, cfg = _config_k_like(torch.float32, 77, 32, 0.0, ny=160, nz=24)
+    rng = torch.Generator().manual_seed(6)
+    res, gout = {}, None
+    for gather in (True, False):
+        st = stereo.to(dev).requires_grad_(True)
+        sm = sem.to(dev).requires_grad_(True)
+        calls = f2v._BWD_GATHER.get('calls', 0)
+        with f2v.bwd_gather(gather):
+            out = pkg.frustum_to_voxel_sample(st, lazy if fused else soft, metas, sm, coords, cfg)
+            if gout is None:
+                gout = torch.randn(out.shape, generator=rng).to(dev)
+            out.backward(gout)
+        torch.cuda.synchronize()
+        assert f2v._BWD_GATHER.get('calls', 0) - calls == (1 if gather else 0), 'which form took the call'
+        res[gather] = (st.grad.clone(), sm.grad.clone())
+    for a, b in zip(res[True], res[False]):
+        assert float(b.abs().max()) > 0
+        diff = (a - b).abs()
+        assert bool((diff <= 2e-5 * b.abs() + 2e-5 * float(b.abs().max())).all()), \
+            f'max |diff| {float(diff.max()):.3e} of max |g| {float(b.abs().max()):.3e}'
 
 
 @pytest.mark.gpu
