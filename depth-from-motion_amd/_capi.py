@@ -71,6 +71,8 @@ EXPORTS = (
     'dfm_conv3d_k3_c32_fwd',
     'dfm_conv3d_k3_c32_fwd_strided',
     'dfm_conv3d_k3_c32_to1_fwd',
+    'dfm_group_norm_coefficients',
+    'dfm_conv3d_to1_norm_fwd',
     'dfm_conv3d_g_weight_bytes',
     'dfm_conv3d_g_pack_weights',
     'dfm_conv3d_g_fwd',
@@ -352,6 +354,10 @@ def lib():
     h.dfm_conv3d_k3_c32_fwd_strided.argtypes = [i32, i32, i32, i32, vp, i32, vp, fp, vp, i32, i32, i32, fp, vp]
     h.dfm_conv3d_k3_c32_to1_fwd.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_to1_fwd.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, i32, vp]
+    h.dfm_group_norm_coefficients.restype = ctypes.c_int
+    h.dfm_group_norm_coefficients.argtypes = [i32, i32, i32, ctypes.c_float, vp, i32, vp, vp, vp, vp]
+    h.dfm_conv3d_to1_norm_fwd.restype = ctypes.c_int
+    h.dfm_conv3d_to1_norm_fwd.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp]
     h.dfm_conv3d_k3_c32_stats_splits.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_stats_splits.argtypes = [i32, i32, i32, i32, i32]
     cp = ctypes.POINTER(Conv3dDesc)

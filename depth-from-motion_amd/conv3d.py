@@ -473,6 +473,31 @@ class _PackCache:
         return self._pack
 
 
+def conv3d_to1_norm(y, partials, gamma, beta, eps, weight, relu=True, depth_chunk=0):
+    """GroupNorm(32 groups of one channel)(+ReLU) applied ON LOAD inside the Conv3d(32 -> 1, 3, 1, 1) that consumes it
+    (csrc/conv3d_to1n.hip; dfm_backbone.py:120-127, inference).  ``y``: (N, 32, D, H, W) bf16 channels_last_3d, the RAW
+    output of the 32 -> 32 convolution; ``partials``: its moment partials (N, 32, splits, 3) from
+    ``MfmaConv3d.forward_with_stats``; ``gamma`` / ``beta``: the norm's fp32 parameters; ``weight``: (1, 32, 3, 3, 3).
+    Returns (N, 1, D, H, W) bf16 -- the normalised volume is never written."""
+    assert y.is_cuda and y.dtype == torch.bfloat16 and y.shape[1] == 32 and _is_ndhwc(y)
+    N, _, D, H, W = y.shape
+    assert partials.shape[:2] == (N, 32) and partials.is_contiguous() and partials.dtype == torch.float32
+    w = weight.detach().contiguous()
+    if w.dtype not in _WDT:
+        w = w.float()
+    lib = _capi.lib()
+    dev = y.device
+    coef = torch.empty((N, 32, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((N, 1, D, H, W), dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        st = _stream_ptr(dev)
+        _capi.check(lib.dfm_group_norm_coefficients(N, 32, 32, float(eps), _ptr(partials), partials.shape[2],
+                                                    _ptr(gamma), _ptr(beta), _ptr(coef), st))
+        _capi.check(lib.dfm_conv3d_to1_norm_fwd(N, D, H, W, _ptr(y), _ptr(coef), _ptr(w), _WDT[w.dtype],
+                                                1 if relu else 0, 0, _ptr(out), int(depth_chunk), st))
+    return out
+
+
 class _MfmaConvTo1Fn(torch.autograd.Function):
     """Conv3d(32, 1, 3, 1, 1) through the MFMA kernel (weight rows 1..31 zero, channel 0 stored);
     backward is torch's convolution backward (MIOpen) -- the op is memory-bound either way."""

@@ -26,6 +26,7 @@
 //   * epilogue in registers: per-channel scale/shift (folded BatchNorm or bias), residual add, ReLU,
 //     8-byte bf16 stores of 4 consecutive channels.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -616,16 +617,24 @@ bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
     bool found = false;
     const int sp[3] = {g.d.up ? g.d.in : g.d.out, g.h.up ? g.h.in : g.h.out, g.w.up ? g.w.in : g.w.out};
     // pass 0 keeps tiles inside (twice) the volume; pass 1 (tiny volumes) takes any factorisation
+    // DFM_CONV_G_PLAN="pfw,td,th,tw": perf experiments only -- the planner considers this tiling alone
+    int force[4] = {0, 0, 0, 0};
+    if (const char *fp = getenv("DFM_CONV_G_PLAN")) {
+        if (sscanf(fp, "%d,%d,%d,%d", &force[0], &force[1], &force[2], &force[3]) != 4) force[0] = 0;
+    }
     for (int pass = 0; pass < 2 && !found; ++pass)
     for (int pfw = 4; pfw >= 1; --pfw) {
         const int P = 128 * pfw;
+        if (force[0] && pfw != force[0]) continue;
         for (int td = 1; td <= P; ++td) {
             if (P % td) continue;
             if (pass == 0 && td > sp[0] && td > 1) continue;
+            if (force[0] && td != force[1]) continue;
             for (int th = 1; th <= P / td; ++th) {
                 if ((P / td) % th) continue;
                 const int tw = P / td / th;
                 if (pass == 0 && ((th > 2 * sp[1] && th > 1) || (tw > 2 * sp[2] && tw > 1))) continue;
+                if (force[0] && (th != force[2] || tw != force[3])) continue;
                 GGeom c = g;
                 axis_fill(c.d, td); axis_fill(c.h, th); axis_fill(c.w, tw);
                 const long long bpx = (long long)c.d.block * c.h.block * c.w.block;

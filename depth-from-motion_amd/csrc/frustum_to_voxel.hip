@@ -1139,67 +1139,90 @@ __global__ __launch_bounds__(256) void f2v_bwd_gather_kernel(F2vGeom g, F2vGrid 
             if (!__any(some)) continue;
             const int iy0 = some ? (int)fmaxf(y0f, 0.0f) : 0, iy1 = some ? (int)fminf(y1f, (float)(g.Ny - 1)) : -1;
             const int iz0 = some ? (int)fmaxf(z0f, 0.0f) : 0, iz1 = some ? (int)fminf(z1f, (float)(g.Nz - 1)) : -1;
-            for (int jz = 0;; ++jz) {
-                const int iz = iz0 + jz;
-                if (!__any(iz <= iz1)) break;
-                for (int jy = 0;; ++jy) {
-                    const int iy = iy0 + jy;
-                    const bool cand = iz <= iz1 && iy <= iy1;
-                    if (!__any(cand)) break;
-                    if (!cand) continue;
-                    const long long i = ((long long)iz * g.Ny + iy) * g.Nx + ix;
-                    const float sf = sfac[(size_t)b * N + i];
-                    const float mf = SEM ? mfac[(size_t)b * N + i] : -1.0f;
-                    if (sf < 0.0f && mf < 0.0f) continue;
-                    // the forward's arithmetic on the voxel's own coordinates
-                    const float vx = coords[3 * i], vy = coords[3 * i + 1], vz = coords[3 * i + 2];
-                    const float a = dot4_chain(-vy, -vz, vx, 1.0f, P + 0);
-                    const float bb = dot4_chain(-vy, -vz, vx, 1.0f, P + 4);
-                    const float c = dot4_chain(-vy, -vz, vx, 1.0f, P + 8);
-                    const float u = a / c, v = bb / c;
-                    float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
-                    float gz = (vx - g.depth_min) / g.depth_span;
-                    gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
-                    // make_tri's positions and weights, corner by corner
-                    const float px = ((gx + 1.0f) / 2.0f) * (float)(g.W - 1);
-                    const float py = ((gy + 1.0f) / 2.0f) * (float)(g.H - 1);
-                    const float pz = ((gz + 1.0f) / 2.0f) * (float)(g.D - 1);
-                    if (!(fabsf(px) <= 1.0e9f && fabsf(py) <= 1.0e9f && fabsf(pz) <= 1.0e9f)) continue;
-                    const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
-                    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
-                    const float wf = (float)w, hf = (float)h, df = (float)d;
-                    const int kx = wf == x0 ? 0 : (wf == x1 ? 1 : -1), ky = hf == y0 ? 0 : (hf == y1 ? 1 : -1);
-                    const int kz = df == z0 ? 0 : (df == z1 ? 1 : -1);
-                    if (kx < 0 || ky < 0) continue;
-                    const float wx = kx ? px - x0 : x1 - px, wy = ky ? py - y0 : y1 - py;
-                    const T *gp = gb + (size_t)i * gvs;
-                    if (kz >= 0 && sf >= 0.0f) {
-                        const float wgt = ((wx * wy) * (kz ? pz - z0 : z1 - pz)) * sf;
+            // one candidate voxel (ix, iy, iz)
+            auto visit = [&](int iy, int iz) {
+                const long long i = ((long long)iz * g.Ny + iy) * g.Nx + ix;
+                const float sf = sfac[(size_t)b * N + i];
+                const float mf = SEM ? mfac[(size_t)b * N + i] : -1.0f;
+                if (sf < 0.0f && mf < 0.0f) return;
+                // the forward's arithmetic on the voxel's own coordinates
+                const float vx = coords[3 * i], vy = coords[3 * i + 1], vz = coords[3 * i + 2];
+                const float a = dot4_chain(-vy, -vz, vx, 1.0f, P + 0);
+                const float bb = dot4_chain(-vy, -vz, vx, 1.0f, P + 4);
+                const float c = dot4_chain(-vy, -vz, vx, 1.0f, P + 8);
+                const float u = a / c, v = bb / c;
+                float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
+                float gz = (vx - g.depth_min) / g.depth_span;
+                gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
+                // make_tri's positions and weights, corner by corner
+                const float px = ((gx + 1.0f) / 2.0f) * (float)(g.W - 1);
+                const float py = ((gy + 1.0f) / 2.0f) * (float)(g.H - 1);
+                const float pz = ((gz + 1.0f) / 2.0f) * (float)(g.D - 1);
+                if (!(fabsf(px) <= 1.0e9f && fabsf(py) <= 1.0e9f && fabsf(pz) <= 1.0e9f)) return;
+                const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+                const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
+                const float wf = (float)w, hf = (float)h, df = (float)d;
+                const int kx = wf == x0 ? 0 : (wf == x1 ? 1 : -1), ky = hf == y0 ? 0 : (hf == y1 ? 1 : -1);
+                const int kz = df == z0 ? 0 : (df == z1 ? 1 : -1);
+                if (kx < 0 || ky < 0) return;
+                const float wx = kx ? px - x0 : x1 - px, wy = ky ? py - y0 : y1 - py;
+                const T *gp = gb + (size_t)i * gvs;
+                if (kz >= 0 && sf >= 0.0f) {
+                    const float wgt = ((wx * wy) * (kz ? pz - z0 : z1 - pz)) * sf;
+                    float vv[32];
+                    if (gcs == 1) {
+                        gather_row32<T>(gp, vv);
+                    } else {
+#pragma unroll
+                        for (int cc = 0; cc < 32; ++cc) vv[cc] = elem<T>::load(gp[(size_t)cc * gcs]);
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 32; ++cc) ast[cc] += vv[cc] * wgt;
+                }
+                if constexpr (SEM) {
+                    // the semantic map's pixel (h, w): once per voxel, from the hit on its lower depth corner
+                    // (a valid voxel's lower corner is inside the volume); make_tri(gx, gy, 0, 1, H, W): z1 - iz = 1
+                    if (kz == 0 && mf >= 0.0f) {
+                        const float mw = ((wx * wy) * 1.0f) * mf;
                         float vv[32];
                         if (gcs == 1) {
-                            gather_row32<T>(gp, vv);
+                            gather_row32<T>(gp + 32, vv);
                         } else {
 #pragma unroll
-                            for (int cc = 0; cc < 32; ++cc) vv[cc] = elem<T>::load(gp[(size_t)cc * gcs]);
+                            for (int cc = 0; cc < 32; ++cc) vv[cc] = elem<T>::load(gp[(size_t)(32 + cc) * gcs]);
                         }
 #pragma unroll
-                        for (int cc = 0; cc < 32; ++cc) ast[cc] += vv[cc] * wgt;
+                        for (int cc = 0; cc < 32; ++cc) asem[cc] += vv[cc] * mw;
                     }
-                    if constexpr (SEM) {
-                        // the semantic map's pixel (h, w): once per voxel, from the hit on its lower depth corner
-                        // (a valid voxel's lower corner is inside the volume); make_tri(gx, gy, 0, 1, H, W): z1 - iz = 1
-                        if (kz == 0 && mf >= 0.0f) {
-                            const float mw = ((wx * wy) * 1.0f) * mf;
-                            float vv[32];
-                            if (gcs == 1) {
-                                gather_row32<T>(gp + 32, vv);
-                            } else {
-#pragma unroll
-                                for (int cc = 0; cc < 32; ++cc) vv[cc] = elem<T>::load(gp[(size_t)(32 + cc) * gcs]);
-                            }
-#pragma unroll
-                            for (int cc = 0; cc < 32; ++cc) asem[cc] += vv[cc] * mw;
-                        }
+                }
+            };
+            // boxes of up to 8 x 8 voxels -- what the path's grids produce -- take the counted loops; a wave that
+            // holds a larger box walks it in full (uniform choice)
+#ifdef DFM_GATHER_R5_LOOPS   // (A/B builds only: the round-5 form -- boxes cut at 8 x 8)
+            const bool small_box = true;
+#else
+            const bool small_box = !__any(some && (iy1 - iy0 > 7 || iz1 - iz0 > 7));
+#endif
+            if (small_box) {
+                for (int jz = 0; jz < 8; ++jz) {
+                    const int iz = iz0 + jz;
+                    if (!__any(iz <= iz1)) break;
+                    for (int jy = 0; jy < 8; ++jy) {
+                        const int iy = iy0 + jy;
+                        const bool cand = iz <= iz1 && iy <= iy1;
+                        if (!__any(cand)) break;
+                        if (cand) visit(iy, iz);
+                    }
+                }
+            } else {
+                for (int jz = 0;; ++jz) {
+                    const int iz = iz0 + jz;
+                    if (!__any(iz <= iz1)) break;
+                    for (int jy = 0;; ++jy) {
+                        const int iy = iy0 + jy;
+                        const bool cand = iz <= iz1 && iy <= iy1;
+                        if (!__any(cand)) break;
+                        if (cand) visit(iy, iz);
                     }
                 }
             }

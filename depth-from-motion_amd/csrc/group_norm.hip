@@ -584,9 +584,48 @@ __global__ __launch_bounds__(64) void gn_merge_partials_kernel(const float *__re
     }
 }
 
+// (a, b) of y = x * a + b per (sample, channel) from a producer's moment partials [n * groups][splits][3]: the
+// merge of gn_merge_partials_kernel and the arithmetic of gn_apply_cl_kernel (mean / rstd of the group,
+// a = rstd * gamma, b = beta - mean * a), for consumers that normalise ON LOAD (csrc/conv3d_to1n.hip); one wave per
+// (sample, group)
+__global__ __launch_bounds__(64) void gn_coefficients_kernel(const float *__restrict__ partial, int splits,
+                                                             int C, int groups, float eps,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta,
+                                                             float *__restrict__ coef)
+{
+    const float *p = partial + (size_t)blockIdx.x * splits * 3;
+    Moments r = {0.0f, 0.0f, 0.0f};
+    for (int k = threadIdx.x; k < splits; k += 64) r = merge(r, Moments{p[3 * k], p[3 * k + 1], p[3 * k + 2]});
+    r = wave_merge(r);
+    const int cpg = C / groups;
+    const int n = blockIdx.x / groups, gi = blockIdx.x - n * groups;
+    const float mean = r.mean, rstd = 1.0f / sqrtf(r.m2 / r.n + eps);
+    for (int c = gi * cpg + threadIdx.x; c < (gi + 1) * cpg; c += 64) {
+        const float a = rstd * gamma[c];
+        coef[((size_t)n * C + c) * 2] = a;
+        coef[((size_t)n * C + c) * 2 + 1] = beta[c] - mean * a;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+DFM_API int dfm_group_norm_coefficients(int32_t n, int32_t c, int32_t groups, float eps, const float *partials,
+                                        int32_t splits, const float *gamma, const float *beta, float *coef,
+                                        void *stream)
+{
+    if (n <= 0 || c <= 0 || groups <= 0 || c % groups || splits <= 0)
+        return set_error(DFM_ERR_INVALID_ARG, "bad sizes in dfm_group_norm_coefficients");
+    if (!partials || !gamma || !beta || !coef) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    hipLaunchKernelGGL(gn_coefficients_kernel, dim3(n * groups), dim3(64), 0, (hipStream_t)stream, partials, splits,
+                       c, groups, eps, gamma, beta, coef);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
 
 DFM_API size_t dfm_group_norm_workspace_bytes(int32_t n, int32_t c, int64_t spatial, int32_t groups)
 {

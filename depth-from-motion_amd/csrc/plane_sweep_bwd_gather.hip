@@ -215,32 +215,53 @@ __global__ __launch_bounds__(256) void sweep_bwd_gather_kernel(
         const int h0 = some ? (int)fmaxf(h0f, 0.0f) : 0, h1 = some ? (int)fminf(h1f, (float)(g.h_out - 1)) : -1;
         const float depth = depths[d];
         const T *gd = gb + (size_t)d * hw * pstride;
-        for (int kh = 0;; ++kh) {
-            const int lh = h0 + kh;
-            if (!__any(lh <= h1)) break;
-            for (int kw = 0;; ++kw) {
-                const int lw = w0 + kw;
-                const bool cand = lh <= h1 && lw <= w1;
-                if (!__any(cand)) break;
-                if (cand) {
-                    // the forward's own arithmetic decides: does this lattice point's footprint hold (x, y)?
-                    float sx, sy, fw, fn;
-                    sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, lh, lw, sx, sy);
-                    const uint32_t f = bwd_footprint(sx, sy, H, W, fw, fn);
-                    const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
-                    const int dx = x - ixw, dy = y - iyn;
-                    // (a valid footprint has its taps inside the map or masked; this pixel is inside the map, so
-                    //  a tap that equals it is in bounds: the ok bits agree by construction, checked anyway)
-                    const bool colok = dx == 0 ? (f & (1u << 27)) != 0 : (f & (1u << 28)) != 0;
-                    const bool rowok = dy == 0 ? (f & (1u << 29)) != 0 : (f & (1u << 30)) != 0;
-                    if (f != 0u && (unsigned)dx <= 1u && (unsigned)dy <= 1u && colok && rowok) {
-                        // ATen's weights: (row factor) * (column factor), nw = (1 - fn) * (1 - fw) ...
-                        const float wgt = (dy ? fn : 1.0f - fn) * (dx ? fw : 1.0f - fw);
-                        float v[32];
-                        gather_load32<T, CL_IN>(gd + ((size_t)lh * g.w_out + lw) * pstride, cstride, v);
+        // one candidate lattice point: the forward's own arithmetic decides whether its footprint holds (x, y)
+        auto visit = [&](int lh, int lw) {
+            float sx, sy, fw, fn;
+            sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, lh, lw, sx, sy);
+            const uint32_t f = bwd_footprint(sx, sy, H, W, fw, fn);
+            const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
+            const int dx = x - ixw, dy = y - iyn;
+            // (a valid footprint has its taps inside the map or masked; this pixel is inside the map, so
+            //  a tap that equals it is in bounds: the ok bits agree by construction, checked anyway)
+            const bool colok = dx == 0 ? (f & (1u << 27)) != 0 : (f & (1u << 28)) != 0;
+            const bool rowok = dy == 0 ? (f & (1u << 29)) != 0 : (f & (1u << 30)) != 0;
+            if (f != 0u && (unsigned)dx <= 1u && (unsigned)dy <= 1u && colok && rowok) {
+                // ATen's weights: (row factor) * (column factor), nw = (1 - fn) * (1 - fw) ...
+                const float wgt = (dy ? fn : 1.0f - fn) * (dx ? fw : 1.0f - fw);
+                float v[32];
+                gather_load32<T, CL_IN>(gd + ((size_t)lh * g.w_out + lw) * pstride, cstride, v);
 #pragma unroll
-                        for (int c = 0; c < 32; ++c) acc[c] += v[c] * wgt;  // (0 x Inf = NaN reaches the tap, as in ATen)
-                    }
+                for (int c = 0; c < 32; ++c) acc[c] += v[c] * wgt;  // (0 x Inf = NaN reaches the tap, as in ATen)
+            }
+        };
+        // boxes of up to 4 x 4 points -- every box of a plane the fit vouches for at its sample points -- take the
+        // counted loops the kernel has always had; a wave that holds a LARGER box walks it in full (uniform choice)
+#ifdef DFM_GATHER_R5_LOOPS   // (A/B builds only: the round-5 form -- boxes cut at 4 x 4, tol < 2)
+        const bool small_box = true;
+#else
+        const bool small_box = !__any(some && (w1 - w0 > 3 || h1 - h0 > 3));
+#endif
+        if (small_box) {
+            for (int kh = 0; kh < 4; ++kh) {
+                const int lh = h0 + kh;
+                if (!__any(lh <= h1)) break;
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int lw = w0 + kw;
+                    const bool cand = lh <= h1 && lw <= w1;
+                    if (!__any(cand)) break;
+                    if (cand) visit(lh, lw);
+                }
+            }
+        } else {
+            for (int kh = 0;; ++kh) {
+                const int lh = h0 + kh;
+                if (!__any(lh <= h1)) break;
+                for (int kw = 0;; ++kw) {
+                    const int lw = w0 + kw;
+                    const bool cand = lh <= h1 && lw <= w1;
+                    if (!__any(cand)) break;
+                    if (cand) visit(lh, lw);
                 }
             }
         }

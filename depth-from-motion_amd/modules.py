@@ -30,12 +30,12 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .conv3d import (DerivedStateMixin, long_axis_gram, note_derived_build, MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose2d,
+from .conv3d import (DerivedStateMixin, conv3d_to1_norm, long_axis_gram, note_derived_build, MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose2d,
                      MfmaConvTranspose3d, channel_slice)
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .geometry import stack_meta
-from .group_norm import HipBatchNorm3d, HipGroupNorm
+from .group_norm import HipBatchNorm3d, HipGroupNorm, _f32_params
 from . import _capi
 from .plane_sweep import _DTYPES, _Workspace, _ptr, _stream_ptr, build_dfm_cost
 from .sweep_conv import pack_sweep_conv_weights, sweep_conv_supported, sweep_dres0
@@ -348,12 +348,12 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
         def stereo_all():
             st = stereo_fn()
             assert len(st) == 1, 'Only support num_hg=1 for now.'
-            return st, self.pred_stereo[0](st[0])
+            return st, self._pred_head(self.pred_stereo[0], st[0])
 
         def mono_all():
             mo = mono_fn()
             assert len(mo) == 1, 'Only support num_hg=1 for now.'
-            return mo, self.pred_mono[0](mo[0])
+            return mo, self._pred_head(self.pred_mono[0], mo[0])
         if not (self.two_streams and device.type == 'cuda' and
                 (self.two_streams_training or not torch.is_grad_enabled()) and
                 not torch.cuda.is_current_stream_capturing()):
@@ -373,12 +373,40 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
             t.record_stream(main)
         return (stereo, s_cost), (mono, m_cost)
 
+    # DFM_PRED_UNFUSED=1 keeps the three-launch prediction head at inference too (A/B runs)
+    fused_pred = os.environ.get('DFM_PRED_UNFUSED') != '1'
+
+    def _pred_head(self, seq, x):
+        """ConvModule(32 -> 32, GN, ReLU) -> Conv3d(32 -> 1) (dfm_backbone.py:120-127).  Inference on the bf16 NDHWC
+        stack: the 32 -> 32 MFMA convolution emits its GroupNorm statistics, and the 32 -> 1 convolution normalises
+        (+ReLU) the raw volume ON LOAD (csrc/conv3d_to1n.hip) -- the normalisation pass (a read and a write of the
+        118 MB volume per stack at config K) and the 31 zero weight rows of the former 32 -> 1 kernel are gone."""
+        cm, last = seq[0], seq[1]
+        norm = getattr(cm, cm.norm_name or '', None)
+        if (self.fused_pred and not torch.is_grad_enabled() and isinstance(cm.conv, MfmaConv3d) and
+                isinstance(last, MfmaConv3dTo1) and isinstance(norm, HipGroupNorm) and norm.num_groups == 32 and
+                norm.affine and cm.conv.out_channels == 32 and cm.activate is not None and cm.conv.eligible(x) and
+                last.weight.shape == (1, 32, 3, 3, 3) and last.bias is None):
+            y, partials = cm.conv.forward_with_stats(x)
+            gamma, beta = _f32_params(norm.weight, norm.bias)
+            return conv3d_to1_norm(y, partials, gamma, beta, norm.eps, last.weight, relu=True)
+        return seq(x)
+
     def _pin_accumulators(self):
         """views of the mono stack's trainable parameters taken on the CURRENT (main) stream: each creates the
         parameter's AccumulateGrad node, which keeps the stream it was created under; holding the views keeps the
         nodes alive until the side-stream forward has linked them into the graph"""
+        if not DfMBackbone._pin_warned_off:
+            # torch >= 2.10 warns when an AccumulateGrad node's stream differs from its producer's: here that is
+            # the point (the engine's event wait orders them), so the once-per-process warning is switched off
+            DfMBackbone._pin_warned_off = True
+            off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+            if off is not None:
+                off(False)
         return [p.view_as(p) for m in (self.dres0_mono, self.dres1_mono, self.hg_mono, self.pred_mono)
                 for p in m.parameters() if p.requires_grad]
+
+    _pin_warned_off = False
 
     def _sweep_dres0_fusable(self, cur, prev=None):
         """the fused plane sweep + dres0 / dres0_mono kernel takes this call: inference, bf16 32-channel

@@ -702,6 +702,24 @@ DFM_API int dfm_conv3d_k3_c32_to1_fwd(int32_t n, int32_t d, int32_t h, int32_t w
                                       const void *packed_weights, void *out, int32_t relu,
                                       int32_t depth_chunk, void *stream);
 
+/* Round 6 -- the prediction head's tail as ONE pass (csrc/conv3d_to1n.hip): GroupNorm(+ReLU) of the 32-channel
+ * volume applied ON LOAD inside the 32 -> 1 convolution that consumes it (dfm_backbone.py:120-127:
+ * ConvModule(32 -> 32, GN, ReLU) -> Conv3d(32, 1, 3, 1, 1)); the normalised volume is never written.
+ *   dfm_group_norm_coefficients: moment partials [n][groups][splits][3] (count / mean / M2, what
+ *     dfm_conv3d_k3_c32_fwd emits as `stats`) -> coef fp32 [n][c][2] = (a, b) of y = x * a + b, with the merge and
+ *     the arithmetic of dfm_group_norm_apply_channels_last (mean / rstd per group, a = rstd * gamma,
+ *     b = beta - mean * a): a consumer that computes bf16(relu(x * a + b)) reproduces that pass bit for bit.
+ *   dfm_conv3d_to1_norm_fwd: x (n, d, h, w, 32) bf16 RAW convolution output, coef as above, weight
+ *     (1, 32, 3, 3, 3) fp32 / bf16 (unpacked: the 27 x 32 operand is built in registers), out (n, d, h, w) bf16;
+ *     relu_in: ReLU behind the normalisation; relu_out: ReLU of the result; depth_chunk 0 = automatic.
+ *     Zero padding pads the NORMALISED tensor, as the unfused sequence does. */
+DFM_API int dfm_group_norm_coefficients(int32_t n, int32_t c, int32_t groups, float eps, const float *partials,
+                                        int32_t splits, const float *gamma, const float *beta, float *coef,
+                                        void *stream);
+DFM_API int dfm_conv3d_to1_norm_fwd(int32_t n, int32_t d, int32_t h, int32_t w, const void *x, const float *coef,
+                                    const void *weight, int32_t weight_dtype, int32_t relu_in, int32_t relu_out,
+                                    void *out, int32_t depth_chunk, void *stream);
+
 /* ---------------------------------------------------------------------- */
 /* General MFMA Conv3d / ConvTranspose3d 3x3x3, NDHWC bf16, channels = 32 k    */
 /* (hourglass conv1..conv6: utils/conv_modules.py:73-149; Conv3d+BN3d+ReLU     */

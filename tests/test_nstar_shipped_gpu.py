@@ -108,3 +108,28 @@ def test_nstar_augmented_run_bitexact(pkg, nstar_inputs):
         out = _run(pkg, w, cur, prev, depths, T, a['flip'], a['crop'], a['scale'], CANDIDATES[cand])
         _compare(out, w, cur, prev, depths, T, a['flip'], a['crop'], a['scale'])
         del out
+
+
+def test_shipped_nstar_launch_whole_volume_of_one_sample(pkg, nstar_inputs):
+    """EVERY value of one sample's (512, 112, 94, 311) volume -- 1.68 G values, not the 0.4 % of the plane / channel
+    selection above -- under the library's default (shipped) launch at the full B = 8, bit for bit against
+    bf16(oracle(bf16 inputs)); the C port walks it in 32-channel pieces (missing item 5).
+    Sample 5: an interior sample of the batch (neither the first nor the last workgroup of a plane's schedule)."""
+    w, cur, prev, depths, T = nstar_inputs
+    out = _run(pkg, w, cur, prev, depths, T, False, (0, 0), 1.0, dict(kernel=2))
+    b, C = 5, w['C']
+    P = util.KITTI_P2[None]
+    Pinv = util.host_inverse(P)
+    checked = 0
+    for c0 in range(0, C, 32):
+        ref = orc.bf16_round(orc.build_dfm_cost(
+            cur[b:b + 1, c0:c0 + 32].float().numpy(), prev[b:b + 1, c0:c0 + 32].float().numpy(), depths,
+            w['fsf'], w['csf'], P, Pinv, T[b:b + 1], (375, 1242), False, (0, 0), 1.0))[0]
+        for half in (0, 1):
+            got = out[b, half * C + c0:half * C + c0 + 32].float().cpu().numpy()
+            want = ref[half * 32:(half + 1) * 32]
+            assert got.shape == want.shape == (32, 112, 94, 311)
+            bad = util.bits(got) != util.bits(want)
+            assert not bad.any(), f'half {half} channels {c0}..{c0 + 31}: {int(bad.sum())} values differ'
+            checked += got.size
+    assert checked == 512 * 112 * 94 * 311
