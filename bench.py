@@ -610,12 +610,19 @@ def secondary(args, pkg, dev, job, emit=True):
         gws_bytes = lib.dfm_plane_sweep_bwd_prev_gather_workspace_bytes(ctypes.byref(desc))
         gws = torch.empty(max(int(gws_bytes), 256), dtype=torch.uint8, device=dev)
 
+        dense = [os.environ.get('DFM_GATHER_DENSE') == '1']   # (experiments: both maps by the gather kernel)
+
         def step():
+            a = (ctypes.byref(desc), gout.data_ptr(), depths.data_ptr(), P.data_ptr(), Pinv.data_ptr(), T.data_ptr())
+            st = torch.cuda.current_stream(dev).cuda_stream
+            if dense[0]:
+                for half, gm in ((0, g_cur), (1, g_prev)):
+                    pkg._capi.check(lib.dfm_plane_sweep_bwd_gather(a[0], half, a[1], 0, *a[2:], gm.data_ptr(), 0,
+                                                                  gws.data_ptr(), gws_bytes, st))
+                return
             g_cur.zero_()
             if not gather[0]:
                 g_prev.zero_()    # (the gather kernel stores the prev map: no zero fill)
-            a = (ctypes.byref(desc), gout.data_ptr(), depths.data_ptr(), P.data_ptr(), Pinv.data_ptr(), T.data_ptr())
-            st = torch.cuda.current_stream(dev).cuda_stream
             if walk[0]:
                 rc = lib.dfm_plane_sweep_bwd_cur_nhwc(*a, g_cur.data_ptr(), st)
                 if rc == 0:

@@ -73,6 +73,8 @@ EXPORTS = (
     'dfm_conv3d_k3_c32_to1_fwd',
     'dfm_group_norm_coefficients',
     'dfm_conv3d_to1_norm_fwd',
+    'dfm_depth_pool_fwd',
+    'dfm_depth_pool_bwd',
     'dfm_conv3d_g_weight_bytes',
     'dfm_conv3d_g_pack_weights',
     'dfm_conv3d_g_fwd',
@@ -358,6 +360,9 @@ def lib():
     h.dfm_group_norm_coefficients.argtypes = [i32, i32, i32, ctypes.c_float, vp, i32, vp, vp, vp, vp]
     h.dfm_conv3d_to1_norm_fwd.restype = ctypes.c_int
     h.dfm_conv3d_to1_norm_fwd.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp]
+    for fn in (h.dfm_depth_pool_fwd, h.dfm_depth_pool_bwd):
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_int64, i32, ctypes.c_int64, i32, vp, vp, vp]
     h.dfm_conv3d_k3_c32_stats_splits.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_stats_splits.argtypes = [i32, i32, i32, i32, i32]
     cp = ctypes.POINTER(Conv3dDesc)

@@ -497,8 +497,11 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_cl_kernel(
 }
 
 // pass 2 (tiny): per (sample, channel) the coefficients of dx = k1 * dy' + k2 * x + k3 and the
-// parameter gradients: one workgroup per (sample, group)
-__global__ __launch_bounds__(64) void gn_bwd_coef_kernel(const float *__restrict__ partial, int C, int cpg,
+// parameter gradients: one workgroup per GROUP, walking the samples -- the parameter gradients are sums over
+// the batch, so they are plain STORES (round 6: the per-(sample, group) workgroups added them atomically into
+// buffers every caller had to zero first: 64 fill launches per training step of the stereo path, and an order
+// of additions that changed from run to run)
+__global__ __launch_bounds__(64) void gn_bwd_coef_kernel(const float *__restrict__ partial, int N, int C, int cpg,
                                                         int splits, long long spatial,
                                                         const float *__restrict__ mean,
                                                         const float *__restrict__ rstd,
@@ -507,31 +510,37 @@ __global__ __launch_bounds__(64) void gn_bwd_coef_kernel(const float *__restrict
                                                         float *__restrict__ dbeta)
 {
     const int groups = C / cpg;
-    const int n = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const int grp = blockIdx.x;
     __shared__ float ab[2];
-    float A = 0.0f, B = 0.0f;
-    for (int cc = grp * cpg; cc < (grp + 1) * cpg; ++cc) {
-        float a = 0.0f, b = 0.0f;
-        for (int k = threadIdx.x; k < splits; k += 64) {
-            const float *p = partial + ((size_t)(n * C + cc) * splits + k) * 2;
-            a += p[0]; b += p[1];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-        if (threadIdx.x == 0) { atomicAdd(dbeta + cc, a); atomicAdd(dgamma + cc, b); }
-        A += gamma[cc] * a; B += gamma[cc] * b;
-    }
-    if (threadIdx.x == 0) { ab[0] = A; ab[1] = B; }
-    __syncthreads();
     const float invL = 1.0f / ((float)cpg * (float)spatial);
-    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
-    const float Am = ab[0] * invL, Bm = ab[1] * invL;
-    // dx = rs * (gm * g - Am - xh * Bm), xh = (x - mu) * rs  ->  k1 g + k2 x + k3
-    for (int cc = grp * cpg + threadIdx.x; cc < (grp + 1) * cpg; cc += 64) {
-        float *o = coef + ((size_t)n * C + cc) * 3;
-        o[0] = rs * gamma[cc];
-        o[1] = -rs * rs * Bm;
-        o[2] = rs * (rs * mu * Bm - Am);
+    for (int cc = grp * cpg + threadIdx.x; cc < (grp + 1) * cpg; cc += 64) { dbeta[cc] = 0.0f; dgamma[cc] = 0.0f; }
+    __syncthreads();
+    for (int n = 0; n < N; ++n) {
+        float A = 0.0f, B = 0.0f;
+        for (int cc = grp * cpg; cc < (grp + 1) * cpg; ++cc) {
+            float a = 0.0f, b = 0.0f;
+            for (int k = threadIdx.x; k < splits; k += 64) {
+                const float *p = partial + ((size_t)(n * C + cc) * splits + k) * 2;
+                a += p[0]; b += p[1];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            if (threadIdx.x == 0) { dbeta[cc] += a; dgamma[cc] += b; }   // (this workgroup owns the group's channels)
+            A += gamma[cc] * a; B += gamma[cc] * b;
+        }
+        __syncthreads();  // (the previous sample's readers of ab are done)
+        if (threadIdx.x == 0) { ab[0] = A; ab[1] = B; }
+        __syncthreads();
+        const int sg = n * groups + grp;
+        const float mu = mean[sg], rs = rstd[sg];
+        const float Am = ab[0] * invL, Bm = ab[1] * invL;
+        // dx = rs * (gm * g - Am - xh * Bm), xh = (x - mu) * rs  ->  k1 g + k2 x + k3
+        for (int cc = grp * cpg + threadIdx.x; cc < (grp + 1) * cpg; cc += 64) {
+            float *o = coef + ((size_t)n * C + cc) * 3;
+            o[0] = rs * gamma[cc];
+            o[1] = -rs * rs * Bm;
+            o[2] = rs * (rs * mu * Bm - Am);
+        }
     }
 }
 
@@ -861,7 +870,7 @@ DFM_API int dfm_group_norm_bwd_channels_last(int32_t n, int32_t c, int64_t spati
         hipLaunchKernelGGL(gn_bwd_stats_cl_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)grad_y,
                            (const bf16_t *)x, (const bf16_t *)y, (long long)spatial, c, groups, splits, relu, mean,
                            rstd, partial);
-    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(n * groups), dim3(64), 0, st, partial, c, c / groups, splits,
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(groups), dim3(64), 0, st, partial, n, c, c / groups, splits,
                        (long long)spatial, mean, rstd, gamma, coef, grad_gamma, grad_beta);
     if (dtype == DFM_F32)
         hipLaunchKernelGGL(gn_bwd_apply_cl_kernel<float>, agrid, dim3(256), 0, st, (const float *)grad_y,

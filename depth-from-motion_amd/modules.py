@@ -196,14 +196,43 @@ class _WindowMean2d(nn.AvgPool2d):
         return v.float().mean(dim=(3, 5)).to(x.dtype)
 
 
+class _DepthPoolFn(torch.autograd.Function):
+    """mean over groups of ``k`` consecutive depth planes of a channels_last_3d (N, C, D, H, W) tensor, forward and
+    backward one HIP pass each (csrc/depth_pool.hip)"""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        N, C, D, H, W = x.shape
+        ctx.k, ctx.shape = k, tuple(x.shape)
+        y = torch.empty((N, D // k, H, W, C), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _capi.check(_capi.lib().dfm_depth_pool_fwd(N * (D // k), k, H * W * C, _DTYPES[x.dtype], _ptr(x), _ptr(y),
+                                                       _stream_ptr(x.device)))
+        return y.permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, D, H, W = ctx.shape
+        k = ctx.k
+        gy = gy.contiguous(memory_format=torch.channels_last_3d)
+        gx = torch.empty((N, D, H, W, C), dtype=gy.dtype, device=gy.device)
+        with torch.cuda.device(gy.device):
+            _capi.check(_capi.lib().dfm_depth_pool_bwd(N * (D // k), k, H * W * C, _DTYPES[gy.dtype], _ptr(gy), _ptr(gx),
+                                                       _stream_ptr(gy.device)))
+        return gx.permute(0, 4, 1, 2, 3), None
+
+
 def _depth_pool4(pool, x):
     """AvgPool3d((4,1,1)) of FrustumToVoxel (feature_transformation.py:167).  torch's kernel makes a
-    channels_last_3d input contiguous first (a 224 MB copy at config K); on the NDHWC path the pooled
-    depth axis is a plain reshape + mean and the result stays channels-last."""
+    channels_last_3d input contiguous first (a 224 MB copy at config K); on the NDHWC path the pooled depth axis is
+    the slowest axis of a sample: one pass of csrc/depth_pool.hip each way (round 6; rounds 3-5 ran
+    float() -> mean -> cast, three kernels and their autograd twins), and the result stays channels-last."""
     k = pool.kernel_size if isinstance(pool.kernel_size, tuple) else (pool.kernel_size,) * 3
     if (x.is_cuda and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last_3d) and
             k[1:] == (1, 1) and tuple(pool.stride) == tuple(k) and x.shape[2] % k[0] == 0):
         B, C, D, H, W = x.shape
+        if x.dtype in _DTYPES and (H * W * C * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0:
+            return _DepthPoolFn.apply(x, k[0])
         v = x.permute(0, 2, 3, 4, 1).reshape(B, D // k[0], k[0], H, W, C)
         return v.float().mean(dim=2).to(x.dtype).permute(0, 4, 1, 2, 3)
     return pool(x)

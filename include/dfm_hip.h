@@ -931,13 +931,25 @@ DFM_API int dfm_group_norm_bwd(int32_t n, int32_t c, int64_t spatial, int32_t gr
 /* The same backward on channels-last data (x, y, grad_y, grad_x: (n, spatial, c) contiguous): the
  * NDHWC stacks train without converting three tensors per layer to NC(D)HW and back.
  * grad_residual: NULL, or a tensor of grad_y's shape receiving grad_y behind the ReLU mask -- the
- * gradient of the residual input of dfm_group_norm_*_channels_last_res.  Same workspace size. */
+ * gradient of the residual input of dfm_group_norm_*_channels_last_res.  Same workspace size.
+ * grad_gamma / grad_beta are OVERWRITTEN here (round 6: one workgroup per group sums over the batch and
+ * stores; no zero fill by the caller, no atomics, a fixed order of additions). */
 DFM_API int dfm_group_norm_bwd_channels_last(int32_t n, int32_t c, int64_t spatial, int32_t groups,
                                              int32_t dtype, int32_t relu, const void *grad_y,
                                              const void *x, const void *y, const float *mean,
                                              const float *rstd, const float *gamma, void *grad_x,
                                              void *grad_residual, float *grad_gamma, float *grad_beta,
                                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* AvgPool3d((k, 1, 1)) of FrustumToVoxel (necks/feature_transformation.py:167) on a channels-last volume, forward
+ * and backward, one pass each (csrc/depth_pool.hip): the tensor as (outer, k, inner) contiguous -- for an
+ * (N, C, D, H, W) channels_last_3d volume outer = N * D / k, inner = H * W * C -- y (outer, inner) the mean over
+ * the middle axis in fp32, rounded once; grad_x[o][j][i] = grad_y[o][i] / k.  dtype DFM_F32 | DFM_BF16, inner in
+ * whole 16-byte vectors, 16-byte aligned buffers. */
+DFM_API int dfm_depth_pool_fwd(int64_t outer, int32_t k, int64_t inner, int32_t dtype, const void *x, void *y,
+                               void *stream);
+DFM_API int dfm_depth_pool_bwd(int64_t outer, int32_t k, int64_t inner, int32_t dtype, const void *grad_y,
+                               void *grad_x, void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* SPPUNetNeck: tail of the pyramid-pooling branches  */

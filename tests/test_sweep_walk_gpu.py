@@ -300,3 +300,31 @@ def test_gather_reads_the_channels_last_volume_in_place(pkg, dtype, csf, flip, c
     for a, b in ((got_c, ref_c), (got_p, ref_p)):
         assert float(b.abs().max()) > 0
         assert torch.allclose(a, b, rtol=1e-5, atol=3e-6 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize('yaw_deg,csf', [(20.0, 2), (35.0, 4), (-28.0, 2)])
+def test_prev_gather_under_strong_perspective(pkg, yaw_deg, csf):
+    """a large yaw between the frames: the lattice -> prev-map homography zooms by a factor that varies strongly
+    across the map, so the candidate box the gather needs differs from pixel to pixel.  The fit kernel vouches for
+    a plane only if its bound on the box over EVERY map pixel stays below 4 x 4 (round 6, ADVICE round 5: it used to
+    look at five sample points while the gather cut larger boxes silently); the other planes are scattered.  Either
+    way the result must be the tile kernel's."""
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(23)
+    B, C, H, W, D = 1, 32, 96, 320, 9     # (feat_sample_factor 4: the maps span the whole image; h_out * w_out % 16 == 0)
+    a = np.radians(yaw_deg)
+    T = np.eye(4, dtype=np.float32)[None].copy()
+    T[0, 0, 0], T[0, 0, 2], T[0, 2, 0], T[0, 2, 2] = np.cos(a), np.sin(a), -np.sin(a), np.cos(a)
+    T[0, 2, 3] = -1.0
+    args = (torch.from_numpy(util.depth_planes(D)).to(dev), 4, csf, torch.from_numpy(util.KITTI_P2[None]),
+            torch.from_numpy(T), (375, 1242))
+    cur = rng.randn(B, C, H, W).astype(np.float32)
+    prev = rng.randn(B, C, H, W).astype(np.float32)
+    gout = torch.from_numpy(rng.randn(B, 2 * C, D, H // csf, W // csf).astype(np.float32)).to(dev)
+    _, gp1, k1 = _prev_grads(pkg, cur, prev, gout, args, True)
+    _, gp0, k0 = _prev_grads(pkg, cur, prev, gout, args, False)
+    assert (k1, k0) == (9, 5)
+    assert float((gp0 != 0).float().mean()) > 0.2, 'the rotated view must still see a good part of the map'
+    diff = (gp1 - gp0).abs()
+    bar = 1e-5 * gp0.abs() + 2e-6 * float(gp0.abs().max())
+    assert bool((diff <= bar).all()), f'max |diff| {float(diff.max()):.3e}, {int((diff > bar).sum())} over the bar'
