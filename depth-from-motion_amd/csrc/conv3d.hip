@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
                 }
                 continue;
             }
+            [[maybe_unused]] dfm_u32x2 pk4[4];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 float v0 = acc[r][4 * gq], v1 = acc[r][4 * gq + 1], v2 = acc[r][4 * gq + 2], v3 = acc[r][4 * gq + 3];
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
                     *(float4 *)((float *)yout + vox * CV_C + c) = make_float4(v0, v1, v2, v3);
                 } else {
                     const u32x2_t pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-                    *(u32x2_t *)((bf16_t *)yout + vox * CV_C + c) = pk;
+                    pk4[gq] = dfm_u32x2{pk.x, pk.y};
                     if constexpr (STATS) {
                         // the values as stored (bf16-rounded): what the normalisation will read
                         const float q[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
@@ -295,6 +296,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
                         }
                     }
                 }
+            }
+            if constexpr (!OUT_F32) {
+                // two 16-byte stores per lane (the halves of the wave trade pieces of their pixel: dfm_common.h,
+                // acc_rows_to_16B) instead of four 8-byte ones; a pixel's two lanes are stored or skipped together
+                dfm_u32x4 q16[2];
+                acc_rows_to_16B(pk4, q16);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+                    *(dfm_u32x4 *)((bf16_t *)yout + vox * CV_C + 16 * pr + 8 * half) = q16[pr];
             }
             if constexpr (STATS && !OUT_F32) scnt += 1.0f;
         }

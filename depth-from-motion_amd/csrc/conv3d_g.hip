@@ -60,7 +60,8 @@ struct GGeom {
     GAxis d, h, w;
     int32_t cin, cout, nchunk, cout_tiles, relu, nrounds, block_px;
     int32_t resident, classes;  // resident != 0: all chunks in LDS, the workgroup loops the parity classes
-    int32_t ablate;      // perf experiments only (DFM_DEBUG_HOOKS builds, env DFM_CONV_ABLATE): bit 0 stage only
+    int32_t ablate;      // perf experiments only (DFM_DEBUG_HOOKS builds, env DFM_CONV_ABLATE; bit 3: no output stores,
+                         // bit 4: lane-contiguous output stores): bit 0 stage only
                          // the first chunk, bit 1 load weights only for the first tap, bit 2 conflict-free
                          // (wrong) LDS read addresses
     int32_t cin_stride;  // elements between consecutive input pixels (>= cin: a channel slice of a wider tensor)
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
                 }
 #pragma unroll
                 for (int c = 0; c < CW; ++c) {
+                    dfm_u32x2 pk[4];
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const int ch = (ct * CW + c) * 32 + 8 * gq + 4 * half;
@@ -535,9 +537,31 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
                             v2 += __uint_as_float(rr[c][gq].y << 16); v3 += __uint_as_float(rr[c][gq].y & 0xffff0000u);
                         }
                         if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                        const u32x2_t pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-                        *(u32x2_t *)(out + vox * g.cout + ch) = pk;
+                        pk[gq] = dfm_u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
                     }
+#ifdef DFM_DEBUG_HOOKS
+                    if ((g.ablate & 8) && pk[0].x != 0x12345678u) continue;  // what the output stores cost
+                    if (g.ablate & 16) {  // ... and what their pattern costs: lane-contiguous 8-byte stores
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq)
+                            *(dfm_u32x2 *)(out + ((size_t)blockIdx.x * 256 + tid) * 4 + (size_t)(c * 4 + gq) * 1024) = pk[gq];
+                        continue;
+                    }
+                    if (g.ablate & 32) {  // the round-5 form: four 8-byte stores per pixel and lane
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq)
+                            *(dfm_u32x2 *)(out + vox * g.cout + (ct * CW + c) * 32 + 8 * gq + 4 * half) = pk[gq];
+                        continue;
+                    }
+#endif
+                    // the two halves of the wave trade pieces of their pixel: two 16-byte stores per lane, 32 contiguous
+                    // bytes per pixel and instruction (dfm_common.h: acc_rows_to_16B), instead of four 8-byte ones
+                    // (both lanes of a pixel are active or skipped together: opix depends on the pixel only)
+                    dfm_u32x4 q16[2];
+                    acc_rows_to_16B(pk, q16);
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr)
+                        *(dfm_u32x4 *)(out + vox * g.cout + (ct * CW + c) * 32 + 16 * pr + 8 * half) = q16[pr];
                 }
             }
         };

@@ -67,6 +67,28 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b)
     return u;
 }
 
+// MFMA 32x32 accumulator rows -> 16-byte stores.  A lane of the 32x32 accumulator layout holds, per pixel, four
+// groups gq of 4 consecutive channels (8 gq + 4 half + 0..3): packed to bf16 that is four 8-byte pieces a pixel and
+// lane, 16 bytes apart -- four store instructions whose 64 lanes write 8 bytes each (profiles/r06_c8_*: the pattern
+// costs 10-18 % of a convolution).  The two halves of the wave hold complementary pieces of the SAME pixel, so they
+// trade: lanes 0..31 give away groups 1 and 3 and receive the partner's 0 and 2 (v_permlane32_swap: one instruction
+// per dword, no LDS), after which lane (pixel, half) owns channels [16 p + 8 half, + 8) for p = 0, 1 -- two 16-byte
+// stores, the two halves together 32 contiguous bytes per pixel and instruction.
+// pk[gq] = {ch 8gq+4half+0|1, ch 8gq+4half+2|3} on entry; on return q[p] = the 8 channels 16p + 8half .. + 7.
+typedef uint32_t dfm_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t dfm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void acc_rows_to_16B(const dfm_u32x2 (&pk)[4], dfm_u32x4 (&q)[2])
+{
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        // first operand: group 2p (kept by the low half), second: group 2p + 1 (kept by the high half)
+        const auto x = __builtin_amdgcn_permlane32_swap(pk[2 * p].x, pk[2 * p + 1].x, false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(pk[2 * p].y, pk[2 * p + 1].y, false, false);
+        // low half: {own 2p, partner's 2p}; high half: {partner's 2p + 1, own 2p + 1}
+        q[p] = dfm_u32x4{x[0], y[0], x[1], y[1]};
+    }
+}
+
 template <typename T> struct elem;
 template <> struct elem<float> {
     static constexpr int CB = 4;  // elements per 16-byte channel block
