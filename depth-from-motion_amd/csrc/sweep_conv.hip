@@ -340,32 +340,49 @@ __device__ __forceinline__ void epilogue_t(const SCGeom &sc, const f32x4_t (&acc
 {
     const SweepGeom &g = sc.g;
     const int px = lane & 15, cg = lane >> 4;
+    static_assert(SC_TR % 2 == 0, "rows are stored in pairs");
 #pragma unroll
     for (int fr = 0; fr < 2; ++fr) {
 #pragma unroll
-        for (int r = 0; r < SC_TR; ++r) {
+        for (int r2 = 0; r2 < SC_TR; r2 += 2) {
+            u32x2_t pks[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = r2 + e;
+                const int h = h0 + r, w = w0 + fr * 16 + px;
+                const bool ok = FULL || (h < g.h_out && w < g.w_out);
+                const u32x2_t pk = {pack_bf16x2(acc[fr][r][0], acc[fr][r][1]), pack_bf16x2(acc[fr][r][2], acc[fr][r][3])};
+                pks[e] = pk;
+                const float q[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                                    __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+                if (!m.seeded) {
+                    // the shift is common to the 16 pixel lanes of a channel group: the value of the group's
+                    // first lane at the wave's first output position (in bounds by construction)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m.k[j] = __shfl(q[j], lane & 48);
+                    m.seeded = true;
+                }
+                const float mk = ok ? 1.0f : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dv = ok ? q[j] - m.k[j] : 0.0f;
+                    m.s1[j] += dv;
+                    m.s2[j] = __builtin_fmaf(dv, dv, m.s2[j]);
+                }
+                m.cnt += mk;
+            }
+            // 16-byte stores (round 6): a lane holds 4 channels of its pixel for each of the two rows; the lane 16
+            // further holds the next 4 channels of the same pixels.  The even channel group keeps row r2 and receives
+            // the partner's piece of it, the odd group gets both pieces of row r2 + 1 (v_permlane16_swap, one
+            // instruction per dword): one 16-byte store per lane and row pair instead of two 8-byte ones.
+            const auto sx = __builtin_amdgcn_permlane16_swap(pks[0].x, pks[1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(pks[0].y, pks[1].y, false, false);
+            const dfm_u32x4 q16 = {sx[0], sy[0], sx[1], sy[1]};
+            const int r = r2 + (cg & 1);
             const int h = h0 + r, w = w0 + fr * 16 + px;
             const bool ok = FULL || (h < g.h_out && w < g.w_out);
-            const u32x2_t pk = {pack_bf16x2(acc[fr][r][0], acc[fr][r][1]), pack_bf16x2(acc[fr][r][2], acc[fr][r][3])};
-            const float q[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
-                                __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
-            if (!m.seeded) {
-                // the shift is common to the 16 pixel lanes of a channel group: the value of the group's
-                // first lane at the wave's first output position (in bounds by construction)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) m.k[j] = __shfl(q[j], lane & 48);
-                m.seeded = true;
-            }
             const size_t vox = (((size_t)n * g.D + d) * g.h_out + h) * g.w_out + w;
-            if (ok) *(u32x2_t *)(y + vox * SC_C + cbase + 4 * cg) = pk;
-            const float mk = ok ? 1.0f : 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dv = ok ? q[j] - m.k[j] : 0.0f;
-                m.s1[j] += dv;
-                m.s2[j] = __builtin_fmaf(dv, dv, m.s2[j]);
-            }
-            m.cnt += mk;
+            if (ok) *(dfm_u32x4 *)(y + vox * SC_C + cbase + 4 * (cg & ~1)) = q16;
         }
     }
 }
