@@ -369,7 +369,7 @@ def secondary(args, pkg, dev, job, emit=True):
                 # the module's own forward + backward: output gradients are fed directly, in the outputs'
                 # layout and dtype (what DepthHead / FrustumToVoxel's backward hands over).  A synthetic
                 # scalar loss on the channels-last bf16 outputs (round 2: .float().square().mean()) runs
-                # ATen's strided elementwise kernels for 3.3 of 19 ms per step (profiles/r03_c14_*).
+                # ATen's strided elementwise kernels for 3.3 of 19 ms per step (profiles/archive/r03_c14_*).
                 m.zero_grad(set_to_none=True)
                 outs = module(cur, prev, [meta])
                 if not grads:
@@ -950,7 +950,7 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
     # which part did the lease land on?  Rounds 1-3 saw the same binary at 0.63 of the roofline on some
     # parts and at 0.48 on others; round 4 found the cause in the kernel's own store stream -- every band
     # cut of every channel plane left two partial 64-byte writes behind, which some parts absorb and others
-    # do not (profiles/r04_c1..c4_*) -- and removed it.  The probes stay as a record of the part: the tile
+    # do not (profiles/archive/r04_c1..c4_*) -- and removed it.  The probes stay as a record of the part: the tile
     # kernel's store pattern replayed as zeros, a linear fill, the shader clock under an FMA load, and what
     # the SMI tools report under load (tools/part_info.py).
     torch.cuda.synchronize()

@@ -107,7 +107,7 @@ def build_hip(force=False, verbose=False, debug_hooks=False, out=None, jobs=None
     debug_hooks=True adds -DDFM_DEBUG_HOOKS: the DFM_ABLATE switches and the
     per-phase s_memtime trace of the tile kernel (tools/trace_phases.py).  They
     are compiled out by default -- even never-taken runtime branches in the
-    blend loop changed hipcc's schedule by up to 25 % (profiles/r01_v8_*)."""
+    blend loop changed hipcc's schedule by up to 25 % (profiles/archive/r01_v8_*)."""
     out = out or LIB
     if not force and out == LIB and not _stale():
         return LIB

@@ -268,7 +268,7 @@ class MfmaConv3d(DerivedStateMixin, nn.Conv3d):
 
 # ---------------------------------------------------------------------------------------------
 # backward-weight: MIOpen's untuned bf16 NDHWC kernels for these shapes are 84 ms .. 1.26 s PER
-# CONVOLUTION (naive fallbacks; profiles/r02_c31_train_step_kernel_stats.txt: 2.1 s per training
+# CONVOLUTION (naive fallbacks; profiles/archive/r02_c31_train_step_kernel_stats.txt: 2.1 s per training
 # step of DfMBackbone).  Until the MFMA weight-gradient kernel exists, the gradient is a chunked
 # implicit-im2col GEMM: a strided view of the padded input gives the (rows, 27 C_in) patch matrix of
 # a depth chunk, one library GEMM (hipBLASLt, fp32 accumulation over the chunk) contracts it with
@@ -746,7 +746,7 @@ def conv3d_g_f32(x, packed, cout, stride=1, padding=1, transposed=False, kernel1
 # six launches whose exact bf16 x bf16 products accumulate in fp32 (conv3d_g_f32) -- fp32-equivalent; with
 # two pieces / three launches ('split2') 2^-17 of the sum of |products|.  torch's own fp32 convolution on
 # this stack is MIOpen's naive kernel: 1.4 s per 32 -> 1 Conv3d, 31 ms per 2-D convolution, 2.9 s per
-# DfMStereoPath training step (profiles/r03_c46_*, r04_c13_*).  Forward, backward-data, backward-weight.
+# DfMStereoPath training step (profiles/archive/r03_c46_*, r04_c13_*).  Forward, backward-data, backward-weight.
 # ---------------------------------------------------------------------------------------------
 _FP32_MODE = {'mode': 'split'}
 _SPLIT_PIECES = {'split': 3, 'split2': 2}
@@ -1142,7 +1142,7 @@ class MfmaConv2d(DerivedStateMixin, nn.Conv2d, _Mfma2dMixin):
                 x.is_contiguous(memory_format=torch.channels_last) and x.dtype == self.weight.dtype):
             # a 1x1 convolution of an NHWC tensor IS a matrix product over its pixel rows: hipBLASLt forward
             # and backward instead of MIOpen's NHWC kernels (naive on this stack: 14 ms per call,
-            # profiles/r03_c43_*); the result is the same channels_last tensor torch would return
+            # profiles/archive/r03_c43_*); the result is the same channels_last tensor torch would return
             w2 = self.weight.view(self.out_channels, self.in_channels)
             if torch.is_grad_enabled() and self.weight.requires_grad:
                 y = _PixelLinearFn.apply(x.permute(0, 2, 3, 1), w2, self.bias)

@@ -9,7 +9,7 @@
 // Why not a generic implicit GEMM: with N = C_out = 32 every activation fragment feeds ONE MFMA,
 // so a tiling that stages an (M x K) operand per tap moves 27x the input through LDS-DMA and is
 // staging-bound at ~15 % of the MFMA peak (MIOpen: 350-370 TFLOP/s on these shapes,
-// profiles/r01_miopen_conv3d_baseline.txt).  This kernel instead:
+// profiles/archive/r01_miopen_conv3d_baseline.txt).  This kernel instead:
 //   * keeps ALL weights (27 taps x 32 x 32 bf16 = 54 fragments = 216 registers per lane) in the
 //     register file of every wave for the whole launch (one wave per SIMD: 512 registers,
 //     MFMA A operands straight from them) -- no LDS or cache traffic for weights at all;

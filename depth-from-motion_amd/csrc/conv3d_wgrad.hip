@@ -92,7 +92,7 @@ __device__ __forceinline__ void transpose4x8(const V4 (&q)[4], u32x2_t (&t)[8])
 // COL (row stride 1, depth stride 1, a volume): a workgroup's consecutive tiles are consecutive output planes of ONE
 // (h, w) window -- a column, cut into chunks of planes.  The three input slices then live in a ring of the three LDS
 // slots (slice id in slot id mod 3): only the first tile of a chunk stages all three, every other tile ONE new slice
-// (and its g rows) -- a third of the loads, transposes and LDS writes, which are 2/3 of a tile (profiles/r05_c44_*).
+// (and its g rows) -- a third of the loads, transposes and LDS writes, which are 2/3 of a tile (profiles/archive/r05_c44_*).
 template <int SW, bool FLAT = false, bool COL = false>
 __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, const bf16_t *__restrict__ G,
                                                                  const bf16_t *__restrict__ X,
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, co
         if (it < xitems) {
             // (channel block fastest: four consecutive lanes load the 64 contiguous bytes of one pixel -- with the
             //  position group fastest every lane of a load sat in a line of its own, 256 bytes from its neighbour's,
-            //  and ISSUING a batch of 12 loads took 1900 cycles: profiles/r05_c45_*)
+            //  and ISSUING a batch of 12 loads took 1900 cycles: profiles/archive/r05_c45_*)
             int q = it;
             const int cb = q & 3; q >>= 2;
             const int mg = q % (EP / 4); q /= (EP / 4);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, co
         // coordinates inside the tile do not depend on the tile and were decoded ONCE above (item[], ilds[]): per
         // tile an item costs a few compares, clamps and 32-bit multiply-adds -- decoded per tile (divisions by
         // run-time extents, 64-bit products) the address arithmetic of a batch was 2500 cycles and a tile's staging
-        // 10 000 of its 15 000 (round 5 trace: profiles/r05_c44_*).  WG_BATCH items at a time: ALL their 16-byte loads
+        // 10 000 of its 15 000 (round 5 trace: profiles/archive/r05_c44_*).  WG_BATCH items at a time: ALL their 16-byte loads
         // are issued first -- unconditionally, from a clamped address, through global-address-space pointers -- and
         // only then selected against the bounds, transposed and written to LDS.  (Round 1-4: a `valid ? load : 0`
         // per piece, compiled to a flat_load followed by s_waitcnt vmcnt(0) lgkmcnt(0): 20 to 32 dependent round

@@ -26,7 +26,7 @@
 // A lane (= one voxel) writes its channels-last row as 16-byte pieces; the lanes of a store instruction
 // are 128-256 B apart, so one instruction touches 64 partial lines that the row's other stores complete.
 // PLAIN stores let the L2 merge them: the non-temporal form pushed partial lines out and measured 1.9x
-// slower here (f2v_cl 1.93 -> 3.59 ms, profiles/r04_c7_lift_nt_vs_plain.txt) -- while the batched
+// slower here (f2v_cl 1.93 -> 3.59 ms, profiles/archive/r04_c7_lift_nt_vs_plain.txt) -- while the batched
 // multi-view kernel (point_sample.hip), whose lanes write whole contiguous KiBs, gains 6 % from nt.
 #define DFM_LIFT_PLAIN 1
 template <typename T>
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void f2v_pm_kernel(F2vGeom g, const uint4 *__r
 // voxel cover the corner's contiguous channels --, two voxels per lane are in flight (16 / 8 independent taps),
 // and a voxel's half of the row leaves as whole 64-byte runs of neighbouring voxels (non-temporal: nothing
 // re-reads it here).  Same arithmetic, corner by corner in ATen's order.  f2v_cl (config K, bf16): 1.93 ->
-// 1.35 ms (profiles/r04_c51_*); a first version with both sources in one pass (lanes 0-3 stereo, 4-7
+// 1.35 ms (profiles/archive/r04_c51_*); a first version with both sources in one pass (lanes 0-3 stereo, 4-7
 // semantic: divergent halves, one voxel per lane in flight) measured 2.57 ms (r04_c50).  PLANAR: the
 // reference layout (B, C + Cs, Nz, Ny, Nx) from the same gather (gather_planar below): f2v fp32 3.86 ->
 // 2.93 ms (r04_c59).
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void f2v_bwd_kernel(F2vGeom g, const T *__rest
 }
 
 // Pixel-major backward.  Scattered global fp32 atomics run at ~20 G/s, a wave whose 64
-// addresses are consecutive at ~320 G/s (profiles/r01_atomic_microbench.txt).  So the gradients
+// addresses are consecutive at ~320 G/s (profiles/archive/r01_atomic_microbench.txt).  So the gradients
 // are accumulated in pixel-major scratch ([d*h*w][C] and [h*w][Cs], fp32): the lanes of a wave
 // are the CHANNELS of a voxel, a tap is one contiguous run of C atomics.  A workgroup takes 64
 // voxels: their grad_out rows come in through an LDS tile (read along voxels, used along
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void f2v_bwd_pm_kernel(F2vGeom g, const T *__r
     if (g.out_cl) {
         // channels-last gradient (what an NDHWC voxel_convs backward hands over): the tile's 64 voxels x CT
         // channels are ONE contiguous run, read in place -- torch's strided re-layout of this tensor to the
-        // planar form cost 2.1 ms of a 31 ms training step (profiles/r05_c11_*)
+        // planar form cost 2.1 ms of a 31 ms training step (profiles/archive/r05_c11_*)
         const T *go = gout + ((size_t)b * N + v0) * CT;
         for (int i = tid; i < CT * F2V_VT; i += 256) {
             const int v = i / CT, c = i - v * CT;

@@ -7,7 +7,7 @@
 // ConvModule).  With C = 32 that is a per-channel normalisation over the whole
 // (D,H,W) volume.  torch's kernel runs it at ~0.26 TB/s
 // (1.8 ms at 72x80x320, more than the bf16 convolution in front of it:
-// profiles/r01_miopen_conv3d_baseline.txt); it is a pure HBM-bound
+// profiles/archive/r01_miopen_conv3d_baseline.txt); it is a pure HBM-bound
 // reduction + elementwise op.
 //
 // Layout: NC(D)HW contiguous: the elements of group g of sample n are ONE

@@ -121,7 +121,7 @@ namespace {
 // ---------------------------------------------------------------------------
 // Each lane re-blocks PACK_PPL pixels (256 apart).  One pixel per lane measured fastest in
 // isolation (0.083 ms for the N* maps, 5.8 TB/s read+write; 4 pixels per lane: 0.20 ms --
-// tools/pack_microbench.hip, profiles/r02_c3_pack_microbench.txt).  Inside the pipeline its
+// tools/pack_microbench.hip, profiles/archive/r02_c3_pack_microbench.txt).  Inside the pipeline its
 // rocprofv3 duration is ~0.19 ms either way: it starts while the previous launch's 26.8 GB of
 // volume writes are still draining to HBM.
 constexpr int PACK_PPL = 1;
@@ -323,7 +323,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // How the volume's 16-byte vectors leave the CU.  Default: non-temporal (global_store_dwordx4 ... nt).
 // -DDFM_STORE_FLAVOUR=1 plain, 2 sc1, 3 sc0 sc1 (write-through), 4 sc1 nt: experiment builds
-// (build.build_variant), measured in profiles/r04_c6_*.
+// (build.build_variant), measured in profiles/archive/r04_c6_*.
 #ifndef DFM_STORE_FLAVOUR
 #define DFM_STORE_FLAVOUR 0
 #endif
@@ -468,7 +468,7 @@ __device__ __forceinline__ int tile_body(
     // tg.align points of the flat index (band_pts is one), so that two workgroups never share a
     // memory-side write: with 16-byte-aligned cuts every band boundary of every channel plane left
     // two partial 64-byte writes behind, and the store stream alone ran 27 % slower
-    // (profiles/r04_c2_*: 5.52 -> 4.35 ms with nothing but the stores left in the kernel).
+    // (profiles/archive/r04_c2_*: 5.52 -> 4.35 ms with nothing but the stores left in the kernel).
     const long long a0 = (d_tile * hw_ll) & ~7ll;
     const long long a1 = d_tile >= g.D - 1 ? g.N : (((d_tile + 1) * hw_ll) & ~7ll);
     const long long base = a0 & ~(long long)(tg.align - 1);
@@ -649,7 +649,7 @@ __device__ __forceinline__ int tile_body(
     // leaves column i of the product in lane i: against the identity that is the lane's four channels in
     // fp32 (1.0 x v is exact, the other three terms are +0).  Two such products replace a tap's eight VALU
     // unpacks (v_and_b32 2.5 clocks, v_lshlrev_b32 4.0: 26 of the ~54 clocks a point's tap costs this
-    // wave, profiles/r04_c6_valu_microbench.txt) on a pipe this kernel does not use otherwise, 8 clocks each.
+    // wave, profiles/archive/r04_c6_valu_microbench.txt) on a pipe this kernel does not use otherwise, 8 clocks each.
     // Exact for finite normal values and +0 -- pack_blocked_kernel flags anything else (0 x Inf would be
     // NaN for the lane's other channels; -0 and denormals) and the VALU path runs.
     // pk: per channel, one 16- (or 8-) byte vector of V points
@@ -717,7 +717,7 @@ __device__ __forceinline__ int tile_body(
                 // of the chain step that consumes it: two 4x4x4 products back to back hold the wave's issue for
                 // the matrix pipe (8 clocks), and products placed right in front of their consumers wait out
                 // the latency.  hipcc's own placement varies from build to build between 5.16 and 5.7 ms
-                // (profiles/r04_c21/c22/c23), so the order is pinned with scheduling fences.
+                // (profiles/archive/r04_c21/c22/c23), so the order is pinned with scheduling fences.
 #if DFM_MX_MODE == 2
                 const float e = 1.0f - w, s2 = 1.0f - n;
                 const float wt[4] = {s2 * e, s2 * w, n * e, n * w};  // nw ne sw se: blend_nomask's chain
@@ -925,7 +925,7 @@ __device__ __forceinline__ int tile_body(
         };
         // stage -> barrier -> blend+store -> barrier.  (A double-buffered variant
         // with counted vmcnt measured no faster on MI355X and doubled the LDS per
-        // workgroup; profiles/r01_v6_double_buffer_variants.txt.)
+        // workgroup; profiles/archive/r01_v6_double_buffer_variants.txt.)
         if constexpr (!PIPE) {
             for (int blk = blk_lo; blk < blk_hi; ++blk) {
                 stage(SLAB, src);
@@ -947,7 +947,7 @@ __device__ __forceinline__ int tile_body(
             // vmcnt(CB) (one store per channel of the block and lane).  The serial body above waits vmcnt(0) before
             // its barrier -- for the DMA AND for the acknowledgement of the previous block's stores,
             // which on parts with a slow HBM write path is what the kernel then runs at
-            // (profiles/r03_c53_*: the stores add 1.2 ms on a fast part, 2.7 ms on a slow one, to a
+            // (profiles/archive/r03_c53_*: the stores add 1.2 ms on a fast part, 2.7 ms on a slow one, to a
             // sampling skeleton of the same 4.5 ms).  Here a store has a whole block (~3 us) to be
             // acknowledged, the DMA of the next rows flies under the blend, and the barrier that
             // protected the single buffer against its refill is gone.
@@ -965,7 +965,7 @@ __device__ __forceinline__ int tile_body(
             stage(SLAB, src);
             TRACE_STAMP();
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            // (Tried and dropped, profiles/r04_c21..c26: issuing the stores of block k AFTER its barrier -- a
+            // (Tried and dropped, profiles/archive/r04_c21..c26: issuing the stores of block k AFTER its barrier -- a
             // store then has two block periods to be acknowledged -- 8 % slower on a box where it mattered:
             // the four waves store in one synchronised burst; the block in two half passes, channels 0-3,
             // their stores, channels 4-7 -- no faster; starting every second workgroup of a CU half a
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256) void sweep_bwd_kernel(
 //     VALU-bound on exactly that: 34 of 39 ms at N*.)
 //   * Per pass of CW channels the taps' gradients are added into a slab of feature rows in LDS
 //     ([channel][row][x], 64-bit two's-complement fixed point: integer LDS atomics run at 10-14
-//     lanes per clock, ds_add_f32 at 0.33 -- profiles/r01_atomic_microbench.txt); the slab goes
+//     lanes per clock, ds_add_f32 at 0.33 -- profiles/archive/r01_atomic_microbench.txt); the slab goes
 //     to the global gradient with ONE coalesced fp32 atomic per touched pixel at the end of each
 //     slab window (the longest run of planes whose rows fit; the chunk, unless the footprint
 //     drifts far).
@@ -2158,7 +2158,7 @@ DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur
 {
     // The workgroup order trades HBM write locality against L2 reuse of the staged rows, and the
     // tile shape trades waves per CU against registers per lane; which side wins depends on the
-    // part the process landed on (profiles/r01_store_microbench3.txt, r02_*): time the candidates
+    // part the process landed on (profiles/archive/r01_store_microbench3.txt, r02_*): time the candidates
     // on the caller's own tensors and remember the fastest for this (device, shape).  Synchronous.
     int rc = check_fwd_args(desc, cur, prev, depths, cam2img, cam2img_inv, cur2prev, out, workspace,
                             workspace_bytes);
@@ -2169,11 +2169,11 @@ DFM_API int dfm_plane_sweep_autotune(const dfm_sweep_desc *desc, const void *cur
     // candidates: 8 points per lane x 256 lanes, 4 points per lane x 512 lanes (bf16, lane pairs storing
     // 16-byte vectors); both with the pipelined body, band cuts on 128-byte boundaries and
     // bands_per_chunk 1.  Since round 4 the two are within 0-4 % of each other on every part seen
-    // (profiles/r04_c2..c4_*): with whole 64-byte writes the parts that ran round 3's binary at 0.48 of
+    // (profiles/archive/r04_c2..c4_*): with whole 64-byte writes the parts that ran round 3's binary at 0.48 of
     // the roofline run either shape at 0.59-0.60.  The re-fetching schedules are no candidates:
     // bands_per_chunk 29 moved 41 GB and 15 moves 37 GB of HBM traffic per N* launch against 28 GB
-    // (profiles/r02_nstar_traffic.json), and a short timing window once picked 15 on a part where it
-    // then ran 20 % slower in steady state (profiles/r02_c43_bench_default_mispick.json); with aligned
+    // (profiles/archive/r02_nstar_traffic.json), and a short timing window once picked 15 on a part where it
+    // then ran 20 % slower in steady state (profiles/archive/r02_c43_bench_default_mispick.json); with aligned
     // cuts chunks of 2 / 4 measure 3-8 % slower (r04_c4).  bands_per_chunk stays in dfm_sweep_opts.
     std::vector<dfm_sweep_opts> cand;
     {
@@ -2271,7 +2271,7 @@ DFM_API int dfm_plane_sweep_tuning(const dfm_sweep_desc *desc, dfm_sweep_opts *o
 // Which part did the process land on?  The tile kernel's store stream -- every workgroup writes a 4 KiB
 // run into each of the 2C channel planes of a sample, planes D*h*w elements apart -- sustains 5.1-5.3 TB/s
 // on most MI355X parts and ~3.9-4.1 TB/s on others (same binary, same clocks; a linear fill runs at
-// 6.8 TB/s on both: profiles/r03_c17_*).  This probe writes zeros in exactly that pattern so that a
+// 6.8 TB/s on both: profiles/archive/r03_c17_*).  This probe writes zeros in exactly that pattern so that a
 // bench line can say which kind of part produced it.  `out` is overwritten with zeros.
 __global__ __launch_bounds__(256) void store_probe_kernel(uint4 *__restrict__ out, long long plane_vec,
                                                           long long runs_per_plane, int planes, int pieces, int group)

@@ -5,7 +5,7 @@
 // The scatter forms of this gradient all pay for the same thing: a lattice point's four taps move along
 // its epipolar line from plane to plane, so every accumulation scheme that follows the lattice (LDS tiles
 // over the map rows: 15 of 16 staged pixels receive nothing at csf = 4; per-wave windows flushed when the
-// footprint moves; a dense pixel-major scatter -- DESIGN.md 4, profiles/r04_c40..c56) re-visits the lines
+// footprint moves; a dense pixel-major scatter -- DESIGN.md 4, profiles/archive/r04_c40..c56) re-visits the lines
 // of the 0.42 GB gradient map tens of times with the 2.4 GB of gradient volume streaming through the L2 in
 // between: 7.7 ms of config K's 8.7 ms backward.
 //

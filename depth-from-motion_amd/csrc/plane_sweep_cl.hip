@@ -9,7 +9,7 @@
 // a lattice point's 2C values are ONE contiguous run (1 KiB at C=256 bf16), a wave
 // writes whole KiBs back to back and a workgroup one contiguous 256 KiB region --
 // the streaming-fill pattern (6.2-6.8 TB/s on this part) instead of 2 KiB pieces
-// spread over 512 channel planes (4.6-5.4 TB/s, profiles/r01_store_microbench*.txt).
+// spread over 512 channel planes (4.6-5.4 TB/s, profiles/archive/r01_store_microbench*.txt).
 //
 // Layout in HBM
 //   workspace : [zero pixel][cur maps][prev maps], pixel-major [b][h][w][C]: a tap is
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void sweep_clt_kernel(
 //
 // sweep_clt_kernel fetches the four taps of every (point, plane) anew: 8 x 128 bytes per point and
 // plane for both maps, 15 GB of L2 -> L1 traffic for a 3.8 GB volume, and its time is the sum of its
-// store time and its gather time (profiles/r03_c39_*).  But a point's footprint barely moves from one
+// store time and its gather time (profiles/archive/r03_c39_*).  But a point's footprint barely moves from one
 // plane to the next: the cur position is the lattice pixel up to rounding noise (the footprint flips
 // between two neighbouring pixel pairs), the prev position slides along its epipolar line by less
 // than a pixel per plane beyond ~20 m: over the planes of config K 60 % of the footprints equal the
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void sweep_clt_kernel(
 // which is also where the previous plane's offsets and the weights are re-read from (registers go to
 // the taps: 114 VGPRs, four waves per SIMD).  No workgroup barrier: the four waves of a workgroup (four
 // neighbouring 32-point tiles) only share the launch.
-// Measured (profiles/r04_c28..c34): 1.22 ms against the per-plane kernel's 1.36-1.47 ms on the same
+// Measured (profiles/archive/r04_c28..c34): 1.22 ms against the per-plane kernel's 1.36-1.47 ms on the same
 // boxes (0.47 of 8 TB/s against 0.39-0.43).  Not more, because with the volume's stores streaming
 // through the L2 a tap re-read a few planes (10+ us) later misses it: the L2 -> L1 requests drop
 // three-fold, the fabric reads grow from 0.87 to 2.4 GB, and with both loads and stores in flight the
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void sweep_clt_kernel(
 #define DFM_WALK_ABLATE 0
 #endif
 #ifndef DFM_WALK_WAVES
-#define DFM_WALK_WAVES 4  // waves per SIMD the walking kernel is compiled for (5 spills, 3 is 8 % slower: profiles/r04_c33_*)
+#define DFM_WALK_WAVES 4  // waves per SIMD the walking kernel is compiled for (5 spills, 3 is 8 % slower: profiles/archive/r04_c33_*)
 #endif
 struct WalkGrid {
     int batch, tiles, chunks, chunk_planes, passes;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, DFM_WALK_WAVES) void sweep_cltw_kernel(
 // The gradient volume is read in the reference layout, 32 channels x 16 points per plane as 64-byte
 // rows, and transposed through a wave-private LDS tile; plane d + 1 is requested before plane d is
 // processed.
-// (Two schemes for BOTH maps were built first and dropped, profiles/r04_c40..c53: flushing an accumulator
+// (Two schemes for BOTH maps were built first and dropped, profiles/archive/r04_c40..c53: flushing an accumulator
 // whenever its tap moves -- the forward's walking scheme mirrored -- 19.5 ms; a dense pixel-major scatter
 // of every (point, plane) with full-wave atomics 21.7 ms and 26 GB of HBM writes for a 0.42 GB map, ~5 ms per
 // dword atomic per lane and tap, proportional to their number: each of them re-visits every map line tens of

@@ -20,7 +20,7 @@
 
 // The lifted volume (hundreds of MB, written once, read by a later kernel) leaves the CU with
 // non-temporal 16-byte stores: the batched channels-last kernel writes whole contiguous KiBs per
-// instruction and gains 6 % (waymo_cl 0.2366 -> 0.2235 ms, profiles/r04_c7_lift_nt_vs_plain.txt);
+// instruction and gains 6 % (waymo_cl 0.2366 -> 0.2235 ms, profiles/archive/r04_c7_lift_nt_vs_plain.txt);
 // -DDFM_LIFT_PLAIN builds the plain-store variant.  (FrustumToVoxel's lane-per-voxel kernel must NOT
 // use nt: its stores are partial lines per instruction, see frustum_to_voxel.hip.)
 template <typename T>

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256, 1) void sweep_conv_kernel(
     // position arithmetic and tap loads of a pair are issued BEFORE an MFMA phase and blended after it:
     // the loads' latency passes under the phase's MFMAs (sched_barrier pins the stage boundaries -- left
     // to itself the scheduler hoists the blend arithmetic into the MFMA stream, which then stalls on vmcnt).
-    // Measured alternatives (tools/sweep_conv_trace.py, profiles/r03_*sweep_conv*): a chunk costs an M wave
+    // Measured alternatives (tools/sweep_conv_trace.py, profiles/archive/r03_*sweep_conv*): a chunk costs an M wave
     // ~3.4k cycles this way; produced inside an S wave (512-register pressure, latency exposed) 6.5-7k, so
     // the S waves only run MFMAs in the steady state.
     if (stereo) {

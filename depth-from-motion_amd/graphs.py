@@ -4,7 +4,7 @@ The 2-D necks either side of the path (SPPUNetNeck, BEVHourglass; SURVEY.md 8f r
 kernels each -- window means, 1x1 convolutions on a few hundred pixels, GroupNorm passes, bilinear
 up-samplings, the MFMA 3x3 convolutions -- whose host-side launch cost (~10 us each through Python) is
 longer than their device time: 0.98 ms of wall clock for ~0.5 ms of device work per SPPUNetNeck
-forward at config K (profiles/r02_c62_neck2d_timing.txt).  ``GraphedCallable`` records such a callable
+forward at config K (profiles/archive/r02_c62_neck2d_timing.txt).  ``GraphedCallable`` records such a callable
 once per input signature into a hipGraph (``torch.cuda.CUDAGraph`` is hipGraph on ROCm; the package's
 own kernels launch on torch's current stream, which is the capture stream) and replays it with one
 launch.  Only tensor -> tensor callables without host synchronisation qualify: no ``.item()``, no

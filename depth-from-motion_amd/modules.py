@@ -362,7 +362,7 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
     two_streams = True
     # With autograd recording: every backward node runs on the stream its forward ran on (the engine inserts the
     # cross-stream waits), so the two stacks overlap in the backward pass as well (backbone_train 12.5 -> 10.7 ms,
-    # profiles/r05_c16_*).  The mono stack's PARAMETER gradients, however, must not be produced on the side stream:
+    # profiles/archive/r05_c16_*).  The mono stack's PARAMETER gradients, however, must not be produced on the side stream:
     # gradient hooks (DistributedDataParallel's reducer, GradientBucketReducer) run under the stream of the
     # AccumulateGrad node and order their bucket copies / collectives against that stream only.  An AccumulateGrad
     # node takes the stream that is current when it is CREATED, so `_two_branches` creates the mono parameters'
@@ -804,7 +804,7 @@ class DfMNeck(DerivedStateMixin, nn.Module):
             mono = _to_bev(self.mono_layers(channel_slice(x, 0, self.in_channels[0])))
             stereo = _to_bev(self.stereo_layers(x))
         # 1x1 Conv2d(2 C_out -> 1): MIOpen's kernel for this shape is a 58 ms naive convolution in
-        # bf16 (profiles/r02_c26_*); it is a weighted channel sum of the two maps
+        # bf16 (profiles/archive/r02_c26_*); it is a weighted channel sum of the two maps
         w = self.aggregate_layer.weight.view(2, -1, 1, 1).to(mono.dtype)
         gate = ((mono * w[0]).sum(1, keepdim=True) + (stereo * w[1]).sum(1, keepdim=True)).sigmoid() \
             if mono.is_cuda and mono.dtype == torch.bfloat16 else \
@@ -876,7 +876,7 @@ class _BilinearResizeFn(torch.autograd.Function):
     """F.interpolate(mode='bilinear') whose BACKWARD is two small matrix products, gX = A_h^T gY A_w
     (bilinear resampling is separable and linear).  ATen's upsample_bilinear2d_backward scatters with
     atomics: 0.67 ms per call on the necks' maps, 12 calls = 8 of the 41 ms of a DfMStereoPath training
-    step at config K (profiles/r04_c8_*); the SPP branches' few-pixel maps serialise on a handful of
+    step at config K (profiles/archive/r04_c8_*); the SPP branches' few-pixel maps serialise on a handful of
     addresses.  The forward is ATen's own (bit-identical to the reference's)."""
 
     @staticmethod
@@ -931,7 +931,7 @@ class upconv_module(nn.Module):  # noqa: N801  (reference class name)
 def _channels_last_2d(module, feats):
     """The 2-D producers / consumers either side of the path (SPPUNetNeck,
     BEVHourglass) run NHWC on the GPU at INFERENCE: the MFMA convolution kernel and the fused SPP tail
-    read NHWC, MIOpen's own NHWC kernels wrap an NCHW call in two transposes each (profiles/r02_c29: 588
+    read NHWC, MIOpen's own NHWC kernels wrap an NCHW call in two transposes each (profiles/archive/r02_c29: 588
     batched_transpose launches per DfMStereoPath forward), and the stereo / semantic maps they emit are
     then already in the pixel-major layout the plane sweep and FrustumToVoxel sample (no pack pass).
     The 4-D weights are re-laid once; shapes, values and state_dict keys are untouched.
@@ -941,7 +941,7 @@ def _channels_last_2d(module, feats):
     NHWC tensor are matrix products, GroupNorm is the HIP kernel in either layout and the bilinear resizes
     have a matrix-product backward (bilinear_resize) -- the three things that made torch's NHWC training
     path 2.1 s per DfMStereoPath step in round 3 (MIOpen's naive NHWC convolutions, ATen's channels-last
-    bilinear backward; profiles/r03_c43_*).  ``DFM_TRAIN_NCHW=1`` (or ``module.train_nhwc = False``) keeps the
+    bilinear backward; profiles/archive/r03_c43_*).  ``DFM_TRAIN_NCHW=1`` (or ``module.train_nhwc = False``) keeps the
     round-3 behaviour: NCHW between the layers, each MFMA convolution converting its operands."""
     if not feats[0].is_cuda:
         return feats

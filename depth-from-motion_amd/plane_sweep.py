@@ -109,7 +109,7 @@ def _make_desc(cur_feats, num_depths, feat_sample_factor, cost_sample_factor, im
 def _upload(t, device):
     """small host tensor -> device without blocking the host on the stream: a pageable H2D copy
     waits for everything queued before it, which serialises the Python launch loop of the next
-    step with the GPU work of the previous one (profiles/r02_c26_*: 2x on the multi-view path)"""
+    step with the GPU work of the previous one (profiles/archive/r02_c26_*: 2x on the multi-view path)"""
     if t.device.type != 'cpu':
         return t.to(device)
     return t.contiguous().pin_memory().to(device, non_blocking=True)

@@ -224,7 +224,7 @@ DFM_API int dfm_plane_sweep_bwd_last_kernel(void);
  *                        back before the next depth group.  1 (default) keeps all depth planes
  *                        of one band resident together (best L2 reuse of the staged rows);
  *                        larger values make the resident workgroups write longer contiguous
- *                        runs of every channel plane (profiles/r01_store_microbench3.txt)
+ *                        runs of every channel plane (profiles/archive/r01_store_microbench3.txt)
  *   points_per_lane      16/sizeof(T) (default: one 16-byte store per channel), or 4 with
  *                        DFM_BF16 and 512/1024 lanes: 8-byte stores, half the registers per
  *                        lane, twice the waves per CU for the same tile

@@ -1,7 +1,7 @@
 // atomic_microbench.hip -- rates of the building blocks of a scatter-add backward on
 // gfx950: LDS fp32 atomic add (conflict-free / 2 lanes per address), LDS read-modify-
 // write without atomics, coalesced and strided global fp32 atomics.
-// (profiles/r01_atomic_microbench.txt)
+// (profiles/archive/r01_atomic_microbench.txt)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

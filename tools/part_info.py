@@ -1,7 +1,7 @@
 """What the SMI tools say about the part a process landed on (bench.py's ``part.smi``).
 
 The same binary runs the N* forward at 0.63 of the HBM roofline on some MI355X parts and at 0.48 on
-others (profiles/r03_c53_*); the store and clock probes of the library bracket the difference, they
+others (profiles/archive/r03_c53_*); the store and clock probes of the library bracket the difference, they
 do not name it.  This records what can be read without privileges -- VRAM vendor, VBIOS part number,
 memory / fabric / shader clocks UNDER LOAD, socket power and cap, partition modes, throttle state --
 so that every bench line says which kind of part produced it and slow parts can be told apart by

@@ -11,7 +11,7 @@ torch-free harness ``tools/sweep_bench`` and writes
 
 hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the kernels of one launch (pack,
 tile, spill, patch): FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (the guide's
-HBM section), WRITE_SIZE is taken as is.  bench.py reads the file (profiles/r02_nstar_traffic.json)
+HBM section), WRITE_SIZE is taken as is.  bench.py reads the file (profiles/archive/r02_nstar_traffic.json)
 to fill ``roofline.traffic`` for the configuration that actually ran.
 
 usage (GPU box): python tools/pmc_traffic.py --out gpurun_out/r02_nstar_traffic.json [--workload nstar]

@@ -1,5 +1,5 @@
 // store_microbench.hip -- write-pattern calibration for the plane-sweep volume
-// (profiles/r01_store_microbench.txt).  Not part of the product library.
+// (profiles/archive/r01_store_microbench.txt).  Not part of the product library.
 //
 // The volume write is >99 % of the path's HBM bytes, so the achievable write
 // bandwidth of the candidate store shapes bounds every kernel design:

@@ -1,5 +1,5 @@
 // store_microbench2.hip -- how close to the HBM write peak can a streaming
-// store get on this box?  (profiles/r01_store_microbench2.txt)
+// store get on this box?  (profiles/archive/r01_store_microbench2.txt)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

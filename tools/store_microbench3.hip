@@ -1,7 +1,7 @@
 // store_microbench3.hip -- which workgroup->address schedule writes the N* cost volume
 // ([B][2C][D][H*W] bf16, 26.8 GB) fastest?  Stores only, one 16-B vector per lane per
 // channel, same loop structure as sweep_tile_kernel (32 channel blocks x 8 channels).
-// (profiles/r01_store_microbench3.txt)
+// (profiles/archive/r01_store_microbench3.txt)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

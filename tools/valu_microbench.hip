@@ -1,5 +1,5 @@
 // valu_microbench.hip -- issue cost (cycles per wave-instruction per SIMD) of the
-// VALU ops the blend loop is made of (profiles/r01_valu_microbench.txt).
+// VALU ops the blend loop is made of (profiles/archive/r01_valu_microbench.txt).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1;} } while (0)
