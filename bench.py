@@ -64,41 +64,56 @@ def sweep_bench_cfg(opts):
     return ','.join(items) or 'default'
 
 
+# secondary rows whose step the torch-free harness can replay for the counter passes: bench workload -> (harness
+# workload, mode, kernel-name filter)
+TRAFFIC_ROWS = {
+    'sweep_bwd': ('nstar', 'bwd', ('sweep_bwd', 'gather_fit', 'fillBuffer')),
+    'sweep_bwd_kitti': ('kitti', 'bwd', ('sweep_bwd', 'gather_fit', 'fillBuffer')),
+    'kitti_nhwc': ('kitti', 'nhwc', ('sweep_', 'pack_')),
+}
+
+
 def measure_traffic(workload, opts, timeout=90):
     """HBM bytes per launch of the configuration that ran, measured NOW on this part: two separate
     rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; no trace domains beside --pmc) over the torch-free
     tools/sweep_bench, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over the launch's kernels
     (tools/pmc_traffic.py; the x2 is MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads).
-    None when rocprofv3 or the harness is missing or a pass fails -- never a number from another run."""
+    None when rocprofv3 or the harness is missing or a pass fails -- never a number from another run.
+    Round 6: also the secondary rows of TRAFFIC_ROWS (the plane-sweep backward at N* and at config K, the strided
+    forward from NHWC maps), replayed by the harness's --mode bwd / nhwc."""
     import shutil
     import subprocess
-    if workload not in ('nstar', 'nstar_aug', 'kitti') or not shutil.which('rocprofv3'):
+    row = TRAFFIC_ROWS.get(workload)
+    if (workload not in ('nstar', 'nstar_aug', 'kitti') and row is None) or not shutil.which('rocprofv3'):
         return None
     exe = os.path.join(ROOT, 'tools', 'sweep_bench')
     try:
-        if not os.path.exists(exe):
+        src = os.path.join(ROOT, 'tools', 'sweep_bench.cpp')
+        if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
             subprocess.run(['hipcc', '--offload-arch=gfx950', '-O2', '-std=c++17', '-I', os.path.join(ROOT, 'include'),
-                            os.path.join(ROOT, 'tools', 'sweep_bench.cpp'), '-L',
-                            os.path.join(ROOT, 'depth-from-motion_amd', 'lib'), '-ldfm_hip',
+                            src, '-L', os.path.join(ROOT, 'depth-from-motion_amd', 'lib'), '-ldfm_hip',
                             '-Wl,-rpath,$ORIGIN/../depth-from-motion_amd/lib', '-o', exe],
                            check=True, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import pmc_traffic
         cfg = sweep_bench_cfg(opts)
-        fetch = pmc_traffic.one_pass('FETCH_SIZE', cfg, workload, '/tmp/bench_pmc', timeout)
-        write = pmc_traffic.one_pass('WRITE_SIZE', cfg, workload, '/tmp/bench_pmc', timeout)
+        hw, mode, names = (workload, 'fwd', None) if row is None else row
+        fetch = pmc_traffic.one_pass('FETCH_SIZE', cfg, hw, '/tmp/bench_pmc', timeout, mode)
+        write = pmc_traffic.one_pass('WRITE_SIZE', cfg, hw, '/tmp/bench_pmc', timeout, mode)
         # the library's kernels only (the harness also fills and checksums the volume)
-        fetch = {k: v for k, v in fetch.items() if pmc_traffic.is_library_kernel(k)}
-        write = {k: v for k, v in write.items() if pmc_traffic.is_library_kernel(k)}
+        keep = pmc_traffic.is_library_kernel if names is None else (lambda k: any(t in k for t in names))
+        fetch = {k: v for k, v in fetch.items() if keep(k)}
+        write = {k: v for k, v in write.items() if keep(k)}
         kernels = set(fetch) | set(write)
         total = sum(2 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in kernels) * 1024
         return {'hbm_bytes_per_launch': total,
                 'fetch_bytes_x2': sum(2 * v for v in fetch.values()) * 1024,
                 'write_bytes': sum(write.values()) * 1024,
                 'how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/sweep_bench '
-                       f'{cfg}, this part, this run'} if total > 0 else None
+                       f'{cfg}' + ('' if row is None else f' --mode {mode}') + ', this part, this run'} if total > 0 else None
     except Exception:  # a failed pass must not fail the bench
         return None
+
 
 KITTI_P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791],
                      [0, 0, 1, 0.002745884], [0, 0, 0, 1]], np.float32)
@@ -762,7 +777,7 @@ def secondary(args, pkg, dev, job, emit=True):
     return line
 
 
-def secondary_block(pkg, sweep, dev, job, budget_s=45.0):
+def secondary_block(pkg, sweep, dev, job, budget_s=45.0, traffic=True):
     """What else the default run witnesses, after the timed headline and never as ``value``: other rows
     of SURVEY.md 8a on their config shapes, a few steps each -- the plane-sweep backward at N*, the
     shipped config's strided sweep (config K, NHWC maps) and its backward, FrustumToVoxel's channels-last sampling,
@@ -771,18 +786,20 @@ def secondary_block(pkg, sweep, dev, job, budget_s=45.0):
     the wall-clock budget is reported as skipped, not silently dropped."""
     import types
     out = {}
-    t_start = time.perf_counter()
+    t_start, t_traffic = time.perf_counter(), 0.0
     for wl in ('sweep_bwd', 'kitti_nhwc', 'sweep_bwd_kitti', 'sweep_bwd_kitti_cl', 'f2v_cl', 'backbone', 'neck',
                'dfm_neck', 'backbone_train', 'waymo_cl', 'nstar_negzero', 'nstar_negzero_all', 'stereo_infer',
                'stereo_train'):
-        if time.perf_counter() - t_start > budget_s:
+        if time.perf_counter() - t_start - t_traffic > budget_s:   # (the counter passes have their own time)
             out[wl] = {'skipped': 'wall-clock budget of the secondary block spent'}
             continue
         try:
             if wl in WORKLOADS:
                 line = quick_sweep_row(pkg, sweep, dev, wl, steps=10, warmup=3)
             else:
-                a = types.SimpleNamespace(workload=wl, steps=10, warmup=3, reducer='none')
+                # (the launch-heavy module rows settle later than the single-kernel ones: more steps, still < 1 s each)
+                nsteps = {'backbone': 30, 'neck': 30, 'dfm_neck': 20, 'backbone_train': 20, 'stereo_infer': 20}.get(wl, 10)
+                a = types.SimpleNamespace(workload=wl, steps=nsteps, warmup=5 if nsteps > 10 else 3, reducer='none')
                 if wl == 'backbone':
                     os.environ.setdefault('DFM_FEATS_NHWC', '1')  # the layout SPPUNetNeck hands over
                 line = secondary(a, pkg, dev, job, emit=False)
@@ -790,11 +807,23 @@ def secondary_block(pkg, sweep, dev, job, budget_s=45.0):
             out[wl] = {'what': line['config']['workload'], 'value': line['value'], 'unit': line['unit'],
                        'ms_per_step': line['ms_per_step'], 'bound': r['bound'], 'achieved': r['achieved'],
                        'roofline_unit': r['unit'], 'frac': r['frac'], 'steps': line['steps']}
+            if traffic and wl in TRAFFIC_ROWS:
+                # counter bytes of the row's step, measured now (two ~5 s passes over the torch-free harness)
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                tt = time.perf_counter()
+                tr = measure_traffic(wl, None, timeout=60)
+                t_traffic += time.perf_counter() - tt
+                out[wl]['traffic'] = tr['hbm_bytes_per_launch'] if tr else None
+                if tr and r.get('algorithmic_bytes_per_launch'):
+                    out[wl]['traffic_over_algorithmic'] = round(tr['hbm_bytes_per_launch'] /
+                                                                r['algorithmic_bytes_per_launch'], 3)
         except Exception as e:  # a secondary row must not take the headline down with it
             out[wl] = {'skipped': f'{type(e).__name__}: {e}'[:200]}
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
     out['wall_s'] = round(time.perf_counter() - t_start, 1)
+    out['traffic_passes_s'] = round(t_traffic, 1)
     return out
 
 
@@ -843,7 +872,7 @@ def quick_sweep_row(pkg, sweep, dev, wl, steps, warmup):
                                    f'{desc.h_out}x{desc.w_out}) {w["dtype"]}, csf={w["csf"]}'
                                    + (', NHWC maps sampled in place' if w.get('nhwc') else '')},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBPS, 4)}}
+                         'frac': round(achieved / HBM_PEAK_GBPS, 4), 'algorithmic_bytes_per_launch': nbytes}}
 
 
 def main():
@@ -1169,7 +1198,7 @@ def run(args, pkg, sweep, lib, dev, job, explicit):
         if 'secondary' in extras:
             out = None
             torch.cuda.empty_cache()
-            line['secondary'] = secondary_block(pkg, sweep, dev, job.solo())
+            line['secondary'] = secondary_block(pkg, sweep, dev, job.solo(), traffic=not args.no_traffic)
         if 'cpu_baseline' in extras:
             line['cpu_baseline'] = cpu_baseline(w)
         print(json.dumps(line), flush=True)

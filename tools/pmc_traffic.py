@@ -39,14 +39,14 @@ def key_of(cfg):
 
 def is_library_kernel(name):
     """the plane sweep's own kernels (tools/sweep_bench also fills and checksums the volume)"""
-    return any(t in name for t in ('sweep_', 'pack_blocked', 'pack_pixel_major'))
+    return any(t in name for t in ('sweep_', 'pack_blocked', 'pack_pixel_major', 'gather_fit'))
 
 
-def one_pass(counter, cfg, workload, scratch, timeout):
-    d = os.path.join(scratch, f'{counter}_{key_of(cfg)}')
+def one_pass(counter, cfg, workload, scratch, timeout, mode='fwd'):
+    d = os.path.join(scratch, f'{counter}_{mode}_{key_of(cfg)}')
     shutil.rmtree(d, ignore_errors=True)
     cmd = ['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', d, '--',
-           os.path.join(ROOT, 'tools', 'sweep_bench'), '--workload', workload, '--rounds', '1',
+           os.path.join(ROOT, 'tools', 'sweep_bench'), '--workload', workload, '--mode', mode, '--rounds', '1',
            '--launches', '2', cfg]
     subprocess.run(cmd, check=True, timeout=timeout, stdout=subprocess.DEVNULL,
                    stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR='/tmp'), cwd='/tmp')
@@ -55,6 +55,10 @@ def one_pass(counter, cfg, workload, scratch, timeout):
         for row in csv.DictReader(open(f)):
             if row['Counter_Name'] == counter:
                 per_kernel[row['Kernel_Name']].append(float(row['Counter_Value']))
+    if mode != 'fwd':
+        # a step of these rows is several kernels, some launched more than once: total per kernel name over the
+        # 3 steps the harness ran (1 warm-up + 1 round x 2 launches), per step
+        return {k: sum(v) / 3.0 for k, v in per_kernel.items()}
     return {k: sum(v) / len(v) for k, v in per_kernel.items()}
 
 

@@ -3,8 +3,11 @@
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include tools/sweep_bench.cpp \
 //         -L depth-from-motion_amd/lib -ldfm_hip -Wl,-rpath,'$ORIGIN/../depth-from-motion_amd/lib' \
 //         -o tools/sweep_bench
-//   tools/sweep_bench [--workload nstar|nstar_aug|kitti] [--rounds R] [--launches L] [--batch B]
-//                     cfg [cfg ...]
+//   tools/sweep_bench [--workload nstar|nstar_aug|kitti] [--mode fwd|nhwc|bwd] [--rounds R] [--launches L]
+//                     [--batch B] cfg [cfg ...]
+//   --mode nhwc: dfm_plane_sweep_fwd_nhwc (channels-last maps sampled in place; kitti); --mode bwd: the backward of the
+//   workload -- dfm_plane_sweep_bwd (nstar) / dfm_plane_sweep_bwd_cur_nhwc + dfm_plane_sweep_bwd_prev_gather (kitti) --
+//   with the volume as the gradient (round 6: the counter passes of bench.py's secondary rows)
 //   cfg = comma list of kernel= lanes= lds= bpg= planes= chunk= ppl= pipe= align= pair=   ("default" = library defaults)
 //
 // Every round times each configuration once (L back-to-back launches between two HIP events on
@@ -123,12 +126,13 @@ static dfm_sweep_opts parse_cfg(const std::string &s)
 
 int main(int argc, char **argv)
 {
-    std::string workload = "nstar";
+    std::string workload = "nstar", mode = "fwd";
     int rounds = 7, launches = 3, batch = 8;
     std::vector<std::string> cfgs;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--workload" && i + 1 < argc) workload = argv[++i];
+        else if (a == "--mode" && i + 1 < argc) mode = argv[++i];
         else if (a == "--rounds" && i + 1 < argc) rounds = atoi(argv[++i]);
         else if (a == "--launches" && i + 1 < argc) launches = atoi(argv[++i]);
         else if (a == "--batch" && i + 1 < argc) batch = atoi(argv[++i]);
@@ -197,6 +201,56 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+
+    if (mode != "fwd") {
+        // ---- the other rows: one configuration (the library's own dispatch), timed and left to the counters ----------
+        float *g_cur = nullptr, *g_prev = nullptr;
+        void *gws = nullptr;
+        size_t gwsb = 0;
+        double bytes = alg_bytes;
+        if (mode == "bwd") {
+            CK(hipMalloc((void **)&g_cur, feat_elems * 4));
+            CK(hipMalloc((void **)&g_prev, feat_elems * 4));
+            gwsb = dfm_plane_sweep_bwd_prev_gather_workspace_bytes(&d);
+            CK(hipMalloc(&gws, gwsb ? gwsb : 256));
+            // the gradient volume: the forward's result (finite, varied values)
+            int rc = dfm_plane_sweep_fwd(&d, cur, prev, depths, P, Pinv, T, out, ws, wsb, st);
+            if (rc != DFM_OK) { fprintf(stderr, "fwd: %s\n", dfm_last_error()); return 3; }
+            bytes = (double)esz * out_elems + 2.0 * 4.0 * feat_elems;
+        } else if (mode != "nhwc") { fprintf(stderr, "unknown mode\n"); return 2; }
+        auto run_other = [&]() {
+            int rc;
+            if (mode == "nhwc") {
+                rc = dfm_plane_sweep_fwd_nhwc(&d, cur, prev, depths, P, Pinv, T, out, ws, wsb, st);
+            } else if (workload == "kitti") {
+                CK(hipMemsetAsync(g_cur, 0, feat_elems * 4, st));
+                rc = dfm_plane_sweep_bwd_cur_nhwc(&d, out, depths, P, Pinv, T, g_cur, st);
+                if (rc == DFM_OK) rc = dfm_plane_sweep_bwd_prev_gather(&d, out, depths, P, Pinv, T, g_prev, gws, gwsb, st);
+            } else {
+                CK(hipMemsetAsync(g_cur, 0, feat_elems * 4, st));
+                CK(hipMemsetAsync(g_prev, 0, feat_elems * 4, st));
+                rc = dfm_plane_sweep_bwd(&d, out, depths, P, Pinv, T, g_cur, g_prev, st);
+            }
+            if (rc != DFM_OK) { fprintf(stderr, "%s %s: %s\n", workload.c_str(), mode.c_str(), dfm_last_error()); exit(3); }
+        };
+        run_other();
+        CK(hipStreamSynchronize(st));
+        std::vector<float> tms;
+        for (int r = 0; r < rounds; ++r) {
+            CK(hipEventRecord(e0, st));
+            for (int l = 0; l < launches; ++l) run_other();
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float t = 0;
+            CK(hipEventElapsedTime(&t, e0, e1));
+            tms.push_back(t / launches);
+        }
+        std::sort(tms.begin(), tms.end());
+        printf("# workload %s mode %s  B=%d  algorithmic %.3f GB per step\n", workload.c_str(), mode.c_str(), batch, bytes / 1e9);
+        printf("%-44s median %8.4f ms  min %8.4f ms   %7.1f GB/s (median)\n", "library dispatch", tms[tms.size() / 2], tms[0],
+               bytes / (tms[tms.size() / 2] * 1e-3) / 1e9);
+        return 0;
+    }
 
     std::vector<dfm_sweep_opts> opts;
     for (auto &c : cfgs) opts.push_back(parse_cfg(c));
