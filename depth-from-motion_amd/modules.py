@@ -425,17 +425,11 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
         """views of the mono stack's trainable parameters taken on the CURRENT (main) stream: each creates the
         parameter's AccumulateGrad node, which keeps the stream it was created under; holding the views keeps the
         nodes alive until the side-stream forward has linked them into the graph"""
-        if not DfMBackbone._pin_warned_off:
-            # torch >= 2.10 warns when an AccumulateGrad node's stream differs from its producer's: here that is
-            # the point (the engine's event wait orders them), so the once-per-process warning is switched off
-            DfMBackbone._pin_warned_off = True
-            off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
-            if off is not None:
-                off(False)
+        # (torch >= 2.10 notes once per process that these nodes' stream differs from their producers': intended --
+        #  the engine's event wait orders them; the process-wide switch for that note is left to the application)
         return [p.view_as(p) for m in (self.dres0_mono, self.dres1_mono, self.hg_mono, self.pred_mono)
                 for p in m.parameters() if p.requires_grad]
 
-    _pin_warned_off = False
 
     def _sweep_dres0_fusable(self, cur, prev=None):
         """the fused plane sweep + dres0 / dres0_mono kernel takes this call: inference, bf16 32-channel
