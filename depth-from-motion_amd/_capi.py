@@ -75,6 +75,9 @@ EXPORTS = (
     'dfm_conv3d_to1_norm_fwd',
     'dfm_depth_pool_fwd',
     'dfm_depth_pool_bwd',
+    'dfm_cost_gate_mfma_weight_bytes',
+    'dfm_cost_gate_mfma_pack_weights',
+    'dfm_cost_gate_mfma_fwd',
     'dfm_conv3d_g_weight_bytes',
     'dfm_conv3d_g_pack_weights',
     'dfm_conv3d_g_fwd',
@@ -360,6 +363,12 @@ def lib():
     h.dfm_group_norm_coefficients.argtypes = [i32, i32, i32, ctypes.c_float, vp, i32, vp, vp, vp, vp]
     h.dfm_conv3d_to1_norm_fwd.restype = ctypes.c_int
     h.dfm_conv3d_to1_norm_fwd.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp]
+    h.dfm_cost_gate_mfma_weight_bytes.restype = sz
+    h.dfm_cost_gate_mfma_weight_bytes.argtypes = [i32]
+    h.dfm_cost_gate_mfma_pack_weights.restype = ctypes.c_int
+    h.dfm_cost_gate_mfma_pack_weights.argtypes = [vp, i32, i32, vp, vp]
+    h.dfm_cost_gate_mfma_fwd.restype = ctypes.c_int
+    h.dfm_cost_gate_mfma_fwd.argtypes = [i32, i32, ctypes.c_int64, vp, vp, vp, vp, vp]
     for fn in (h.dfm_depth_pool_fwd, h.dfm_depth_pool_bwd):
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.c_int64, i32, ctypes.c_int64, i32, vp, vp, vp]

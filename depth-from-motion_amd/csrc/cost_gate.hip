@@ -122,7 +122,136 @@ __global__ __launch_bounds__(256) void cost_gate_kernel(int D, long long HW, con
     }
 }
 
+// ---- round 6: the same gate on the matrix cores (bf16 costs AND a bf16 weight: every product exact, fp32 sums) -------
+// The kernel above makes each of a workgroup's four waves load all 2D input planes of its 64 pixels (each wave owns a
+// quarter of the OUTPUT planes) and reads its weights as broadcast LDS vectors: 42 us at config K, alone on the main
+// stream behind the join of the backbone's two stacks.  As a product out[d][p] = sum_k W[d][k] x[k][p] it is 3 x 9
+// v_mfma_f32_32x32x16_bf16 per 32 pixels: a wave loads its pixels' 2D values ONCE, straight into B-operand order
+// (lane = pixel, 8 consecutive planes per k-step half), the A operands are pre-packed fragments (27 KB, cache
+// resident), and the epilogue (sigmoid, blend, one rounding) is the kernel's above.
+static_assert(CG_MAX_D <= 96, "three row blocks of 32 output planes at most");
+
+template <typename TW>
+__global__ __launch_bounds__(64) void cost_gate_mfma_pack_kernel(int D, const TW *__restrict__ weight, bf16_t *__restrict__ frag)
+{
+    // blockIdx.x = mb * nks + ks; lane l: row d = mb * 32 + (l & 31), k = ks * 16 + (l >> 5) * 8 + j
+    const int nks = (2 * D + 15) / 16;
+    const int mb = blockIdx.x / nks, ks = blockIdx.x - mb * nks, l = threadIdx.x;
+    const int d = mb * 32 + (l & 31), k0 = ks * 16 + (l >> 5) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        float v = 0.0f;
+        if (d < D && k < 2 * D) {
+            if constexpr (sizeof(TW) == 2) v = bf16_to_f32(weight[(size_t)d * 2 * D + k]); else v = weight[(size_t)d * 2 * D + k];
+        }
+        frag[((size_t)blockIdx.x * 64 + l) * 8 + j] = f32_to_bf16(v);
+    }
+}
+
+typedef __bf16 cg_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float cg_f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int MB>
+__global__ __launch_bounds__(256) void cost_gate_mfma_kernel(int D, long long HW, const bf16_t *__restrict__ stereo,
+                                                             const bf16_t *__restrict__ mono,
+                                                             const uint4 *__restrict__ wfrag, bf16_t *__restrict__ out)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l32 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.y;
+    const long long p = ((long long)blockIdx.x * 4 + wave) * 32 + l32;
+    const long long pc = min(p, HW - 1);  // lanes past the image read the last pixel and store nothing
+    const bf16_t *sb = stereo + (size_t)b * D * HW + pc, *mb_ = mono + (size_t)b * D * HW + pc;
+    const int nks = (2 * D + 15) / 16;
+    cg_f32x16_t acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.0f;
+    for (int ks = 0; ks < nks; ++ks) {
+        // this lane's 8 consecutive input planes of its pixel: k = ks * 16 + half * 8 + j
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + half * 8 + j;
+            const int kc = min(k, 2 * D - 1);
+            const bf16_t raw = kc < D ? sb[(size_t)kc * HW] : mb_[(size_t)(kc - D) * HW];
+            v[j] = k < 2 * D ? (uint32_t)raw : 0u;
+        }
+        const uint32_t pk[4] = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+        cg_bf16x8_t xf;
+        __builtin_memcpy(&xf, pk, 16);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const uint4 q = wfrag[((size_t)m * nks + ks) * 64 + lane];
+            cg_bf16x8_t wf;
+            __builtin_memcpy(&wf, &q, 16);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[m], 0, 0, 0);
+        }
+    }
+    if (p >= HW) return;
+    bf16_t *ob = out + (size_t)b * D * HW + p;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int d = m * 32 + 8 * (i >> 2) + 4 * half + (i & 3);   // the 32x32 accumulator's row of element i
+            if (d >= D) continue;
+            const float g = 1.0f / (1.0f + __expf(-acc[m][i]));
+            const float s = bf16_to_f32(sb[(size_t)d * HW]), mm = bf16_to_f32(mb_[(size_t)d * HW]);
+            ob[(size_t)d * HW] = f32_to_bf16(g * s + (1.0f - g) * mm);
+        }
+}
+
 }  // namespace
+
+extern "C" DFM_API size_t dfm_cost_gate_mfma_weight_bytes(int32_t num_depths)
+{
+    if (num_depths <= 0 || num_depths > CG_MAX_D) return 0;
+    return (size_t)((num_depths + 31) / 32) * ((2 * num_depths + 15) / 16) * 64 * 16;
+}
+
+extern "C" DFM_API int dfm_cost_gate_mfma_pack_weights(const void *weight, int32_t weight_dtype, int32_t num_depths,
+                                                       void *packed, void *stream)
+{
+    if (!weight || !packed) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (weight_dtype != DFM_F32 && weight_dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "weight dtype must be DFM_F32 or DFM_BF16");
+    if (num_depths <= 0 || num_depths > CG_MAX_D) return set_error(DFM_ERR_UNSUPPORTED, "1 .. 96 depth planes");
+    if ((uintptr_t)packed & 15) return set_error(DFM_ERR_INVALID_ARG, "packed weights must be 16-byte aligned");
+    const dim3 grid((unsigned)(((num_depths + 31) / 32) * ((2 * num_depths + 15) / 16)));
+    if (weight_dtype == DFM_BF16)
+        hipLaunchKernelGGL(cost_gate_mfma_pack_kernel<bf16_t>, grid, dim3(64), 0, (hipStream_t)stream, (int)num_depths,
+                           (const bf16_t *)weight, (bf16_t *)packed);
+    else
+        hipLaunchKernelGGL(cost_gate_mfma_pack_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, (int)num_depths,
+                           (const float *)weight, (bf16_t *)packed);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
+
+extern "C" DFM_API int dfm_cost_gate_mfma_fwd(int32_t batch, int32_t num_depths, int64_t hw, const void *stereo,
+                                              const void *mono, const void *packed_weights, void *out, void *stream)
+{
+    if (batch <= 0 || num_depths <= 0 || hw <= 0) return set_error(DFM_ERR_INVALID_ARG, "non-positive size");
+    if (!stereo || !mono || !packed_weights || !out) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    if (num_depths > CG_MAX_D) return set_error(DFM_ERR_UNSUPPORTED, "more than 96 depth planes");
+    if ((uintptr_t)packed_weights & 15) return set_error(DFM_ERR_INVALID_ARG, "packed weights must be 16-byte aligned");
+    if (batch > 65535 || (hw + 127) / 128 > 0x7fffffffll) return set_error(DFM_ERR_UNSUPPORTED, "grid too large");
+    const dim3 grid((unsigned)((hw + 127) / 128), (unsigned)batch);
+    hipStream_t st = (hipStream_t)stream;
+    const int mb = (num_depths + 31) / 32;
+#define CGM_LAUNCH(MB_)                                                                                      \
+    hipLaunchKernelGGL((cost_gate_mfma_kernel<MB_>), grid, dim3(256), 0, st, (int)num_depths, (long long)hw, \
+                       (const bf16_t *)stereo, (const bf16_t *)mono, (const uint4 *)packed_weights, (bf16_t *)out)
+    if (mb == 1) CGM_LAUNCH(1); else if (mb == 2) CGM_LAUNCH(2); else CGM_LAUNCH(3);
+#undef CGM_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    return DFM_OK;
+}
 
 static int cg_pitch(int d) { return 4 * (((d + 3) / 4 + 3) / 4) * 4; }
 

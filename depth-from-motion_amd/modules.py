@@ -486,6 +486,7 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
 
     # DFM_GATE_TORCH=1 keeps the torch sequence of the gate at inference too (A/B runs)
     fused_gate = os.environ.get('DFM_GATE_TORCH') != '1'
+    mfma_gate = os.environ.get('DFM_GATE_VALU') != '1'
 
     def _gate_fused(self, s_cost, m_cost):
         """cat + Conv2d(2D -> D, 1x1) + sigmoid + blend (dfm_backbone.py:136-141) as one launch
@@ -500,17 +501,26 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
         B, _, D, H, W = s_cost.shape
         lib = _capi.lib()
         out = torch.empty_like(s_cost)
-        key = (w._version, w.data_ptr(), str(w.device), w.dtype)
+        # bf16 costs and a bf16 weight (the fast path's model): the product on the matrix cores (round 6; every
+        # bf16 x bf16 product is exact, sums in fp32) -- DFM_GATE_VALU=1 keeps the VALU kernel (A/B runs)
+        mfma = (self.mfma_gate and s_cost.dtype == torch.bfloat16 and w.dtype == torch.bfloat16)
+        key = (w._version, w.data_ptr(), str(w.device), w.dtype, mfma)
         with torch.cuda.device(s_cost.device):
             if self.__dict__.get('_gate_pack', (None, None))[0] != key:  # packed once per weight version
-                packed = torch.empty(lib.dfm_cost_gate_weight_bytes(D), dtype=torch.uint8, device=w.device)
-                _capi.check(lib.dfm_cost_gate_pack_weights(_ptr(w.detach()), _DTYPES[w.dtype], D, _ptr(packed),
-                                                           _stream_ptr(s_cost.device)))
+                nb = lib.dfm_cost_gate_mfma_weight_bytes(D) if mfma else lib.dfm_cost_gate_weight_bytes(D)
+                packed = torch.empty(nb, dtype=torch.uint8, device=w.device)
+                pack = lib.dfm_cost_gate_mfma_pack_weights if mfma else lib.dfm_cost_gate_pack_weights
+                _capi.check(pack(_ptr(w.detach()), _DTYPES[w.dtype], D, _ptr(packed), _stream_ptr(s_cost.device)))
                 self.__dict__['_gate_pack'] = (key, packed)
                 note_derived_build()
-            _capi.check(lib.dfm_cost_gate_fwd(B, D, H * W, _DTYPES[s_cost.dtype], _ptr(s_cost), _ptr(m_cost),
-                                              _ptr(self.__dict__['_gate_pack'][1]), _ptr(out),
-                                              _stream_ptr(s_cost.device)))
+            if mfma:
+                _capi.check(lib.dfm_cost_gate_mfma_fwd(B, D, H * W, _ptr(s_cost), _ptr(m_cost),
+                                                       _ptr(self.__dict__['_gate_pack'][1]), _ptr(out),
+                                                       _stream_ptr(s_cost.device)))
+            else:
+                _capi.check(lib.dfm_cost_gate_fwd(B, D, H * W, _DTYPES[s_cost.dtype], _ptr(s_cost), _ptr(m_cost),
+                                                  _ptr(self.__dict__['_gate_pack'][1]), _ptr(out),
+                                                  _stream_ptr(s_cost.device)))
         return out
 
     def _predict(self, stereo, s_cost, mono, m_cost):

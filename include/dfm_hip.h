@@ -651,6 +651,16 @@ DFM_API int dfm_cost_gate_pack_weights(const void *weight, int32_t weight_dtype,
 DFM_API int dfm_cost_gate_fwd(int32_t batch, int32_t num_depths, int64_t hw, int32_t dtype,
                               const void *stereo, const void *mono, const void *packed_weights,
                               void *out, void *stream);
+/* Round 6: the same gate on the matrix cores for bf16 costs and a bf16-exact weight (csrc/cost_gate.hip:
+ * out[d][p] = sum_k W[d][k] x[k][p] as v_mfma_f32_32x32x16_bf16, a wave loads its 32 pixels' 2D values once; same
+ * epilogue, same single rounding).  packed: dfm_cost_gate_mfma_weight_bytes(D) bytes of A-operand fragments written
+ * by dfm_cost_gate_mfma_pack_weights (an fp32 weight is rounded to bf16 there: use the entry above for fp32
+ * parameters).  stereo / mono / out: (batch, D, hw) bf16. */
+DFM_API size_t dfm_cost_gate_mfma_weight_bytes(int32_t num_depths);
+DFM_API int dfm_cost_gate_mfma_pack_weights(const void *weight, int32_t weight_dtype, int32_t num_depths,
+                                            void *packed, void *stream);
+DFM_API int dfm_cost_gate_mfma_fwd(int32_t batch, int32_t num_depths, int64_t hw, const void *stereo,
+                                   const void *mono, const void *packed_weights, void *out, void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* MFMA Conv3d 3x3x3, stride 1, pad 1, 32 -> 32 channels, NDHWC bf16         */

@@ -41,6 +41,35 @@ def test_fused_gate_equals_the_reference_sequence(dtype, wdtype, shape):
         assert float((err - ref.abs() * 2.0 ** -8 - 1e-6).max()) <= 0.0
 
 
+@pytest.mark.parametrize('shape', [(1, 72, 20, 80), (2, 7, 5, 13), (1, 96, 3, 70), (3, 1, 1, 1), (1, 33, 9, 67)])
+def test_matrix_core_gate_is_taken_for_bf16_and_matches_the_valu_kernel(shape):
+    """bf16 costs + a bf16 weight: the product runs on the matrix cores (round 6); every product is exact and the sums
+    are fp32 in both kernels, so the two results differ by summation order only -- within one bf16 rounding of the
+    fp64 reference each, and within one bf16 ulp of each other"""
+    mods = importlib.import_module('depth-from-motion_amd.modules')
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(B * 77 + D)
+    s = (torch.randn(B, 1, D, H, W, generator=g) * 2).bfloat16().cuda()
+    m = (torch.randn(B, 1, D, H, W, generator=g) * 2 + 0.5).bfloat16().cuda()
+    bb = mods.DfMBackbone(in_channels=32, depth_cfg=dict(num_bins=D, downsample_factor=1)).cuda()
+    with torch.no_grad():
+        bb.aggregate_cost.weight.copy_(torch.randn(D, 2 * D, 1, 1, generator=g) * 0.3)
+    bb.aggregate_cost.to(torch.bfloat16)
+    lib = importlib.import_module('depth-from-motion_amd._capi').lib()
+    with torch.no_grad():
+        assert bb.mfma_gate
+        a = bb._gate_fused(s, m)
+        assert bb.__dict__['_gate_pack'][1].numel() == lib.dfm_cost_gate_mfma_weight_bytes(D)
+        bb.mfma_gate = False
+        b = bb._gate_fused(s, m)
+        assert bb.__dict__['_gate_pack'][1].numel() == lib.dfm_cost_gate_weight_bytes(D)
+    ref = _reference(s, m, bb.aggregate_cost.weight.detach().flatten(1))
+    for got in (a, b):
+        err = (got.double() - ref).abs()
+        assert float((err - ref.abs() * 2.0 ** -8 - 1e-6).max()) <= 0.0
+    assert float(((a.double() - b.double()).abs() - b.double().abs() * 2.0 ** -7 - 1e-6).max()) <= 0.0
+
+
 def test_gate_falls_back_with_autograd_or_too_many_planes():
     mods = importlib.import_module('depth-from-motion_amd.modules')
     bb = mods.DfMBackbone(in_channels=32, depth_cfg=dict(num_bins=8, downsample_factor=1)).cuda()
