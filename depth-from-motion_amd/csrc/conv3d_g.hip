@@ -125,7 +125,8 @@ typedef bf16_t *__restrict__ g_out_restrict_t;
 //   * the taps are walked as rows of 3 (6 k-steps, unrolled): row offsets are a handful of scalar operations
 //     per 6 * PFW * CW MFMAs, no per-tap counters or selects;
 //   * weight fragments rotate through THREE register buffers with the row's period (6 k-steps = 2 x 3), loaded
-//     two k-steps ahead through a uniform base + lane offset: no copies, no per-lane pointer arithmetic;
+//     two k-steps ahead through a uniform base + lane offset: no copies, no per-lane pointer arithmetic (round 6:
+//     SIX buffers, five k-steps ahead, for waves of one pixel fragment, whose k-steps are too short to cover L2);
 //   * all rows but the last run in a do-while (at least two rows), the last row is peeled and prefetches
 //     nothing: no branch joins while an LDS read is in flight except the loop header's own back edge
 //     (tools/verify_async_asm.py checks the build).
@@ -293,7 +294,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
 #endif
                 stage(chunk, 0);
                 const char *wchunk = (const char *)(wfrag + (size_t)(ct * g.nchunk + chunk) * 27 * 2 * CW * 64);
-                bf16x8_t w[3][CW];   // weight fragments of k-steps s, s + 1, s + 2 (mod 3)
+                // weight fragments travel WD k-steps ahead of their MFMAs through a ring of WR register buffers (WR divides
+                // the row's 6 k-steps: the ring's phase is the same in every row).  A k-step of a one-fragment wave is
+                // CW MFMAs = 64 clocks: two steps ahead (round 5) is 128 clocks against an L2 round trip of ~700 -- the
+                // small hourglass layers (250 workgroups, PFW = 1) stalled on every step (profiles/r06_c8_*: conv1 102 ->
+                // 72 us with the weight loads ablated).  Round 6: five steps ahead for PFW = 1 (48 registers at CW = 2).
+#ifdef DFM_WRING3   // (A/B builds: the round-5 ring)
+                constexpr int WR = 3, WD = WR - 1;
+#else
+                constexpr int WR = PFW == 1 ? 6 : 3, WD = WR - 1;
+#endif
+                bf16x8_t w[WR][CW];  // weight fragments of k-steps s .. s + WD (mod WR)
                 u32x4_t q[2][PFW];   // activation fragments of k-steps s, s + 1 (mod 2)
                 uint32_t addr[PFW];  // the k-step-0 addresses of the tap being read (k-step 1 = ^ 32)
                 auto wld = [&](const char *wrow, int t, bf16x8_t (&dst)[CW]) {  // k-step t of a row: tap t >> 1
@@ -350,8 +361,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
 #ifdef DFM_DEBUG_HOOKS
                         if (!(g.ablate & 2)) {
 #endif
-                        if (st + 2 < 6) wld(wcur, st + 2, w[(st + 2) % 3]);
-                        else if constexpr (!LAST) wld(wnext, st + 2 - 6, w[(st + 2) % 3]);
+                        if (st + WD < 6) wld(wcur, st + WD, w[(st + WD) % WR]);
+                        else if constexpr (!LAST) wld(wnext, st + WD - 6, w[(st + WD) % WR]);
 #ifdef DFM_DEBUG_HOOKS
                         }
 #endif
@@ -363,15 +374,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
                             __builtin_memcpy(&xf, &q[st & 1][f], 16);
 #pragma unroll
                             for (int c = 0; c < CW; ++c)
-                                acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[st % 3][c], xf, acc[f][c], 0, 0, 0);
+                                acc[f][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[st % WR][c], xf, acc[f][c], 0, 0, 0);
                         }
                     }
                 };
-                // weights of the first two k-steps travel while the block lands
+                // weights of the first WD k-steps travel while the block lands
                 uint32_t lcur = row_lds(0);
                 const char *wcur = wchunk + row_wt(0);
-                wld(wcur, 0, w[0]);
-                wld(wcur, 1, w[1]);
+#pragma unroll
+                for (int t = 0; t < WD; ++t) wld(wcur, t, w[t]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();  // the block has landed
                 rd0(0, lcur, q[0]);
