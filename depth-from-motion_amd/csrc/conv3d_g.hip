@@ -302,7 +302,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
 #ifdef DFM_WRING3   // (A/B builds: the round-5 ring)
                 constexpr int WR = 3, WD = WR - 1;
 #else
-                constexpr int WR = PFW == 1 ? 6 : 3, WD = WR - 1;
+#ifndef DFM_WRING6_MAXPFW
+#define DFM_WRING6_MAXPFW 3
+#endif
+                constexpr int WR = PFW <= DFM_WRING6_MAXPFW ? 6 : 3, WD = WR - 1;
 #endif
                 bf16x8_t w[WR][CW];  // weight fragments of k-steps s .. s + WD (mod WR)
                 u32x4_t q[2][PFW];   // activation fragments of k-steps s, s + 1 (mod 2)
