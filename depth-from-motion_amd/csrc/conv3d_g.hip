@@ -256,6 +256,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[f][c][i] = 0.0f;
 
+#ifdef DFM_DEBUG_HOOKS
+        if (g.ablate & 64) goto taps_done;  // what everything around the tap loops costs
+#endif
         if constexpr (FAST) {
             // ---- the row-walking tap loop (see the template's comment) ----------------------------------
             uint32_t A[PFW][3];  // LDS address of the fragment's pixel at column shift jw, row (0, 0), k-step 0
@@ -519,6 +522,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_g_kernel(
         }
 
         }
+#ifdef DFM_DEBUG_HOOKS
+    taps_done:
+#endif
         // ---- epilogue: lane = pixel (l32) x 4 groups of 4 consecutive channels per channel fragment ----
         auto epilogue = [&](auto has_scale, auto has_res) {
 #pragma unroll

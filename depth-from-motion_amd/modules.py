@@ -279,10 +279,26 @@ class hourglass(nn.Module):  # noqa: N801  (reference class name)
         """forward with ``out_residual`` added to the first output (DfMBackbone's
         ``cost = cost + hourglass(cost)[0]``, dfm_backbone.py:180-183).  GroupNorm, the residual adds
         and the ReLUs that follow them are one pass of the fused kernel each."""
+        steps = self.forward_add_steps(x, presqu, postsqu, out_residual)
+        while True:
+            try:
+                next(steps)
+            except StopIteration as done:
+                return done.value
+
+    def forward_add_steps(self, x, presqu, postsqu, out_residual):
+        """``forward_add`` as a generator that yields after every layer (conv + norm: four launches) and returns the
+        result: DfMBackbone issues the layers of its two stacks alternately, each on its own HIP stream"""
         down1 = _gn_relu(self.conv1[0], x, True)
+        yield
         pre = _gn_relu(self.conv2, down1, True, postsqu)
-        bottom = _gn_relu(self.conv4[0], _gn_relu(self.conv3[0], pre, True), True)
+        yield
+        mid = _gn_relu(self.conv3[0], pre, True)
+        yield
+        bottom = _gn_relu(self.conv4[0], mid, True)
+        yield
         post = _gn_relu(self.conv5, bottom, True, pre if presqu is None else presqu)
+        yield
         return _gn_relu(self.conv6, post, False, out_residual), pre, post
 
 
@@ -372,6 +388,58 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
     two_streams_training = os.environ.get('DFM_TRAIN_ONE_STREAM') != '1'
     _side_streams = {}
 
+    # DFM_BACKBONE_SEQUENTIAL_ISSUE=1: the round-5 issue order (all of the mono stack, then all of the stereo stack)
+    interleaved_issue = os.environ.get('DFM_BACKBONE_SEQUENTIAL_ISSUE') != '1'
+
+    def _stack_steps(self, first, second, hgs, pred):
+        """one aggregation stack + its prediction head as a generator: ``first()`` produces the stack's input (the
+        first block, or its normalisation on the fused-sweep path), then dres1, the hourglasses and the head; yields
+        after every layer, returns (features, cost)"""
+        cost = first()
+        yield
+        cost = second(cost, residual=cost)
+        yield
+        outs = []
+        for hg in hgs:
+            cost, _, _ = yield from hg.forward_add_steps(cost, None, None, cost)  # cost + hourglass(cost)[0]
+            outs.append(cost)
+            yield
+        outs = outs if outs else [cost]
+        assert len(outs) == 1, 'Only support num_hg=1 for now.'
+        return outs, self._pred_head(pred, outs[0])
+
+    def _two_stacks_interleaved(self, stereo_first, mono_first, device):
+        """Inference: the two stacks on two HIP streams with their layers ISSUED ALTERNATELY (round 6).  A layer costs
+        the host 20-27 us to enqueue (tools/host_overhead_probe.py) against 15-60 us on the device, and round 5
+        enqueued the whole mono stack (~0.5 ms of host time) before the first stereo launch: the main stream sat idle
+        behind the fused sweep for as long, and the forward took sweep + host(mono) + stereo.  Alternating the two
+        generators keeps both streams fed from the start."""
+        main = torch.cuda.current_stream(device)
+        side = DfMBackbone._side_streams.get(device)
+        if side is None:
+            side = DfMBackbone._side_streams[device] = torch.cuda.Stream(device=device)
+        side.wait_stream(main)
+        gens = [(side, self._stack_steps(mono_first, self.dres1_mono, self.hg_mono, self.pred_mono[0])),
+                (main, self._stack_steps(stereo_first, self.dres1, self.hg_stereo, self.pred_stereo[0]))]
+        results = {}
+        try:
+            while gens:
+                for item in list(gens):
+                    st, gen = item
+                    torch.cuda.set_stream(st)
+                    try:
+                        next(gen)
+                    except StopIteration as done:
+                        results[st is side] = done.value
+                        gens.remove(item)
+        finally:
+            torch.cuda.set_stream(main)
+        (mono, m_cost), (stereo, s_cost) = results[True], results[False]
+        main.wait_stream(side)
+        for t in list(mono) + [m_cost]:
+            t.record_stream(main)
+        return (stereo, s_cost), (mono, m_cost)
+
     def _two_branches(self, stereo_fn, mono_fn, device):
         # each branch ends with its own prediction head (dfm_backbone.py:120-127): -> (features, cost)
         def stereo_all():
@@ -421,6 +489,10 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
             return conv3d_to1_norm(y, partials, gamma, beta, norm.eps, last.weight, relu=True)
         return seq(x)
 
+    def _interleave_ok(self, device):
+        return (self.interleaved_issue and self.two_streams and device.type == 'cuda' and
+                not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing())
+
     def _pin_accumulators(self):
         """views of the mono stack's trainable parameters taken on the CURRENT (main) stream: each creates the
         parameter's AccumulateGrad node, which keeps the stream it was created under; holding the views keeps the
@@ -465,6 +537,11 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
                 self.feat_sample_factor, self.cost_sample_factor, ori_cam2imgs, cur2prevs[:, 0],
                 meta0['ori_shape'][:2], self._sweep_conv_packed(), meta0.get('flip', False), meta0['crop_offset'],
                 img_scale_factor=meta0.get('scale_factor', [1.0])[0])
+            if self._interleave_ok(ys.device):
+                stereo, mono = self._two_stacks_interleaved(
+                    lambda: self.dres0.gn(ys, relu=True, partials=ps),
+                    lambda: self.dres0_mono.gn(ym, relu=True, partials=pm), ys.device)
+                return self._predict(*stereo, *mono)
             stereo, mono = self._two_branches(
                 lambda: self._aggregate_rest(self.dres1, self.hg_stereo, self.dres0.gn(ys, relu=True, partials=ps)),
                 lambda: self._aggregate_rest(self.dres1_mono, self.hg_mono,
@@ -478,6 +555,11 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
             meta0.get('flip', False), meta0['crop_offset'],
             img_scale_factor=meta0.get('scale_factor', [1.0])[0],
             memory_format=self.volume_memory_format)
+        if self._interleave_ok(cost_raw.device):
+            stereo, mono = self._two_stacks_interleaved(
+                lambda: self.dres0(cost_raw),
+                lambda: self.dres0_mono(channel_slice(cost_raw, 0, self.in_channels)), cost_raw.device)
+            return self._predict(*stereo, *mono)
         stereo, mono = self._two_branches(
             lambda: self._aggregate(self.dres0, self.dres1, self.hg_stereo, cost_raw),
             lambda: self._aggregate(self.dres0_mono, self.dres1_mono, self.hg_mono,
