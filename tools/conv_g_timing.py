@@ -36,10 +36,34 @@ NECK = [
 ]
 
 
+GRAPH = [False]
+
+
 def timeit(fn, iters=10):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if GRAPH[0]:
+        # device time: `iters` launches captured once into a HIP graph and replayed -- a call costs the host ~21 us
+        # to enqueue (tools/host_overhead_probe.py), more than the hourglass's small layers take on the device
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (3 * iters)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -55,7 +79,9 @@ def main():
     ap.add_argument('--no-miopen', action='store_true')
     ap.add_argument('--case', default='', help='only the cases whose name contains this')
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--graph', action='store_true', help='device time: launches replayed from a captured HIP graph')
     args = ap.parse_args()
+    GRAPH[0] = args.graph
     cases = (HG if args.only != 'neck' else []) + (NECK if args.only != 'hg' else [])
     for name, kind, cin, cout, size, stride, padding in cases:
         if args.case and args.case not in name:
