@@ -1066,14 +1066,25 @@ __global__ __launch_bounds__(256) void f2v_bwd_prep_kernel(F2vGeom g, const T *_
     mfac[(size_t)b * N + i] = (g.Cs > 0 && (g.sem_att ? valid : valid2d)) ? (g.sem_att ? disp : 1.0f) : -1.0f;
 }
 
-constexpr int F2G_DCH = 9;  // depth planes per lane (a chunk): 72 planes -> 8 chunks
+// Depth planes per lane.  Round 5 ran 9 (72 planes -> 8 chunks): 800 workgroups of a kernel that holds 256 + 16
+// registers a lane -- ONE workgroup per CU, 3.1 rounds over the chip, each wave waiting out its own chain of
+// dependent loads: 1.80 ms.  Three planes a chunk (2400 workgroups; the semantic map takes 3x the atomics, still
+// 0.3 M wave-level instructions): 0.97 ms; 1, 2 planes measure the same, 4 is 9 % slower, and capping the registers
+// for 3 or 4 workgroups per CU spills (3.3 / 5.7 ms) -- profiles/r06_c28_f2v_bwd_depth_chunk.txt
+#ifndef DFM_F2G_DCH
+#define DFM_F2G_DCH 3
+#endif
+#ifndef DFM_F2G_WGS
+#define DFM_F2G_WGS 1
+#endif
+constexpr int F2G_DCH = DFM_F2G_DCH;  // depth planes per lane (a chunk): 72 planes -> 8 chunks
 
 // lane = pixel (h, w) of the cost volume x a chunk of depth planes; C == 32, Cs in {0, 32} with the semantic
 // map at the cost volume's resolution.  gvs / gcs: element strides of grad_out between voxels / channels.
 // GCL: the stereo gradient is written (B, D, H, W, 32) in T -- the layout and type of a channels-last cost volume,
 // a lane's 32 sums as one contiguous row (a wave: 64 consecutive rows), rounded once; else planar fp32.
 template <typename T, bool SEM, bool GCL>
-__global__ __launch_bounds__(256) void f2v_bwd_gather_kernel(F2vGeom g, F2vGrid gr, int dchunks,
+__global__ __launch_bounds__(256, DFM_F2G_WGS) void f2v_bwd_gather_kernel(F2vGeom g, F2vGrid gr, int dchunks,
                                                              const T *__restrict__ gout, size_t gvs, size_t gcs,
                                                              const float *__restrict__ coords,
                                                              const float *__restrict__ cam2img,

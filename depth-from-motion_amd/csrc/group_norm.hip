@@ -293,31 +293,26 @@ __global__ __launch_bounds__(256) void gn_stats_cl_kernel(const T *__restrict__ 
                                                           float *__restrict__ partial)
 {
     constexpr int VEC = vec16<T>::N;
-    __shared__ Moments sh[256][VEC + 1];
+    __shared__ float sh1[4][256], sh2[4][256], shK[256];
     __shared__ Moments chm[256];
     const int n = blockIdx.y, s = blockIdx.x;
     const int nvb = C / VEC, vpi = 256 / nvb;  // voxels per iteration
     const int vb = threadIdx.x % nvb, v0 = threadIdx.x / nvb;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long per = (spatial + splits - 1) / splits;
     const long long lo = min((long long)s * per, spatial), hi = min(lo + per, spatial);
     const T *xs = x + (size_t)n * spatial * C + (size_t)vb * VEC;
-    // shifted sums, K = the lane's first value of the channel: s1 = sum(v - K), s2 = sum((v - K)^2) --
-    // 3 VALU operations per value, no division in the loop, as robust as Welford's update when
-    // |mean| >> std (the first version ran Welford with one IEEE division per vector and a single
-    // load in flight: 2.4 TB/s); four 16-byte loads in flight per lane
+    // shifted sums, K = the slice's first value of the channel (the same in every lane that holds the channel: the
+    // lanes' sums add up as they are, round 6 -- the first form shifted by each lane's own first value and merged
+    // (count, mean, M2) triples with a division per step, 32 steps per channel: more than the loads of a slice):
+    // s1 = sum(v - K), s2 = sum((v - K)^2) -- 3 VALU operations per value, as robust as Welford's update when
+    // |mean| >> std; four 16-byte loads in flight per lane
     constexpr int U = 4;
-    float cnt = 0.0f, K[VEC], s1[VEC], s2[VEC];
+    float K[VEC], s1[VEC], s2[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { K[k] = 0.0f; s1[k] = 0.0f; s2[k] = 0.0f; }
+    if (lo < hi) load16<T>(xs + (size_t)lo * C, K);
     long long v = lo + v0;
-    if (v < hi) {
-        float f[VEC];
-        load16<T>(xs + (size_t)v * C, f);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) K[k] = f[k];  // d = 0 for this one: only the count moves
-        cnt = 1.0f;
-        v += vpi;
-    }
     for (; v + (long long)(U - 1) * vpi < hi; v += (long long)U * vpi) {
         float f[U][VEC];
 #pragma unroll
@@ -330,7 +325,6 @@ __global__ __launch_bounds__(256) void gn_stats_cl_kernel(const T *__restrict__ 
                 s1[k] += d;
                 s2[k] = __builtin_fmaf(d, d, s2[k]);
             }
-        cnt += (float)U;
     }
     for (; v < hi; v += vpi) {
         float f[VEC];
@@ -341,23 +335,37 @@ __global__ __launch_bounds__(256) void gn_stats_cl_kernel(const T *__restrict__ 
             s1[k] += d;
             s2[k] = __builtin_fmaf(d, d, s2[k]);
         }
-        cnt += 1.0f;
     }
-    float mean[VEC], m2[VEC];
+    // the lanes of a wave that hold the same channels (lane % nvb == vb) added up, then the four waves through LDS
+    for (int o = 32; o >= nvb; o >>= 1) {
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        const float a = cnt > 0.0f ? s1[k] / cnt : 0.0f;
-        mean[k] = K[k] + a;
-        m2[k] = fmaxf(s2[k] - s1[k] * a, 0.0f);
+        for (int k = 0; k < VEC; ++k) {
+            s1[k] += __shfl_xor(s1[k], o);
+            s2[k] += __shfl_xor(s2[k], o);
+        }
     }
+    if (lane < nvb) {  // (nvb <= 64; lane % nvb == vb)
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) sh[threadIdx.x][k] = Moments{cnt, mean[k], m2[k]};
+        for (int k = 0; k < VEC; ++k) {
+            sh1[wave][vb * VEC + k] = s1[k];
+            sh2[wave][vb * VEC + k] = s2[k];
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) shK[vb * VEC + k] = K[k];
+        }
+    }
     __syncthreads();
     if ((int)threadIdx.x < C) {
-        // channel c = vb*VEC + k is held by the lanes with tid % nvb == vb
-        const int c = threadIdx.x, cvb = c / VEC, k = c % VEC;
+        const int c = threadIdx.x;
+        float a1 = 0.0f, a2 = 0.0f;
+        for (int w = 0; w < 4; ++w) { a1 += sh1[w][c]; a2 += sh2[w][c]; }
+        const float cnt = (float)(hi - lo);
         Moments r = {0.0f, 0.0f, 0.0f};
-        for (int t = cvb; t < 256; t += nvb) r = merge(r, sh[t][k]);
+        if (cnt > 0.0f) {
+            const float a = a1 / cnt;
+            r = Moments{cnt, shK[c] + a, fmaxf(a2 - a1 * a, 0.0f)};
+        }
         chm[c] = r;
     }
     __syncthreads();
@@ -579,14 +587,68 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_cl_kernel(
     }
 }
 
-// partials [n*groups][splits][3] -> merged [n*groups][3]; one wave per (sample, group)
-__global__ __launch_bounds__(64) void gn_merge_partials_kernel(const float *__restrict__ partial,
-                                                               int splits, float *__restrict__ merged)
+// (count, mean, M2) of `splits` moment partials p[3 k + {0, 1, 2}], in every thread of a 256-thread workgroup.  Plain
+// sums around a reference mean (round 6: the convolutions' epilogues hand over 2000-7000 partials per group; the first
+// form chained Chan's pairwise update -- a division per partial -- through one wave: 12-35 us a launch):
+//   N = sum n_i,  S1 = sum n_i (mean_i - ref),  S2 = sum M2_i + n_i (mean_i - ref)^2
+//   mean = ref + S1 / N,  M2 = S2 - S1^2 / N            (ref = the mean of the first non-empty partial)
+__device__ __forceinline__ Moments merge_partials_256(const float *__restrict__ p, int splits, float (*sh)[4])
 {
-    const float *p = partial + (size_t)blockIdx.x * splits * 3;
+    const int tid = threadIdx.x;
+    // the reference: the first partial with a count (the first 256 are looked at; any value serves, a mean of the data
+    // keeps the shifted sums small)
+    float ref = 0.0f;
+    {
+        float cand = 0.0f;
+        int idx = 0x7fffffff;
+        if (tid < splits && p[3 * tid] > 0.0f) { cand = p[3 * tid + 1]; idx = tid; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int oi = __shfl_xor(idx, o);
+            const float oc = __shfl_xor(cand, o);
+            if (oi < idx) { idx = oi; cand = oc; }
+        }
+        if ((tid & 63) == 0) { sh[tid >> 6][0] = cand; sh[tid >> 6][1] = __int_as_float(idx); }
+        __syncthreads();
+        int best = 0x7fffffff;
+        for (int w = 0; w < 4; ++w) {
+            const int wi = __float_as_int(sh[w][1]);
+            if (wi < best) { best = wi; ref = sh[w][0]; }
+        }
+        __syncthreads();
+    }
+    float N = 0.0f, S1 = 0.0f, S2 = 0.0f;
+    for (int k = tid; k < splits; k += 256) {
+        const float n = p[3 * k], d = p[3 * k + 1] - ref, nd = n * d;
+        N += n;
+        S1 += nd;
+        S2 += p[3 * k + 2] + nd * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        N += __shfl_xor(N, o);
+        S1 += __shfl_xor(S1, o);
+        S2 += __shfl_xor(S2, o);
+    }
+    if ((tid & 63) == 0) { sh[tid >> 6][0] = N; sh[tid >> 6][1] = S1; sh[tid >> 6][2] = S2; }
+    __syncthreads();
+    N = sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0];
+    S1 = sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1];
+    S2 = sh[0][2] + sh[1][2] + sh[2][2] + sh[3][2];
     Moments r = {0.0f, 0.0f, 0.0f};
-    for (int k = threadIdx.x; k < splits; k += 64) r = merge(r, Moments{p[3 * k], p[3 * k + 1], p[3 * k + 2]});
-    r = wave_merge(r);
+    if (N > 0.0f) {
+        const float a = S1 / N;
+        r = Moments{N, ref + a, fmaxf(S2 - S1 * a, 0.0f)};
+    }
+    return r;
+}
+
+// partials [n*groups][splits][3] -> merged [n*groups][3]; one workgroup per (sample, group)
+__global__ __launch_bounds__(256) void gn_merge_partials_kernel(const float *__restrict__ partial,
+                                                                int splits, float *__restrict__ merged)
+{
+    __shared__ float sh[4][4];
+    const Moments r = merge_partials_256(partial + (size_t)blockIdx.x * splits * 3, splits, sh);
     if (threadIdx.x == 0) {
         float *o = merged + (size_t)blockIdx.x * 3;
         o[0] = r.n; o[1] = r.mean; o[2] = r.m2;
@@ -597,20 +659,18 @@ __global__ __launch_bounds__(64) void gn_merge_partials_kernel(const float *__re
 // merge of gn_merge_partials_kernel and the arithmetic of gn_apply_cl_kernel (mean / rstd of the group,
 // a = rstd * gamma, b = beta - mean * a), for consumers that normalise ON LOAD (csrc/conv3d_to1n.hip); one wave per
 // (sample, group)
-__global__ __launch_bounds__(64) void gn_coefficients_kernel(const float *__restrict__ partial, int splits,
-                                                             int C, int groups, float eps,
-                                                             const float *__restrict__ gamma,
-                                                             const float *__restrict__ beta,
-                                                             float *__restrict__ coef)
+__global__ __launch_bounds__(256) void gn_coefficients_kernel(const float *__restrict__ partial, int splits,
+                                                              int C, int groups, float eps,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta,
+                                                              float *__restrict__ coef)
 {
-    const float *p = partial + (size_t)blockIdx.x * splits * 3;
-    Moments r = {0.0f, 0.0f, 0.0f};
-    for (int k = threadIdx.x; k < splits; k += 64) r = merge(r, Moments{p[3 * k], p[3 * k + 1], p[3 * k + 2]});
-    r = wave_merge(r);
+    __shared__ float sh[4][4];
+    const Moments r = merge_partials_256(partial + (size_t)blockIdx.x * splits * 3, splits, sh);
     const int cpg = C / groups;
     const int n = blockIdx.x / groups, gi = blockIdx.x - n * groups;
     const float mean = r.mean, rstd = 1.0f / sqrtf(r.m2 / r.n + eps);
-    for (int c = gi * cpg + threadIdx.x; c < (gi + 1) * cpg; c += 64) {
+    for (int c = gi * cpg + threadIdx.x; c < (gi + 1) * cpg; c += 256) {
         const float a = rstd * gamma[c];
         coef[((size_t)n * C + c) * 2] = a;
         coef[((size_t)n * C + c) * 2 + 1] = beta[c] - mean * a;
@@ -628,7 +688,7 @@ DFM_API int dfm_group_norm_coefficients(int32_t n, int32_t c, int32_t groups, fl
     if (n <= 0 || c <= 0 || groups <= 0 || c % groups || splits <= 0)
         return set_error(DFM_ERR_INVALID_ARG, "bad sizes in dfm_group_norm_coefficients");
     if (!partials || !gamma || !beta || !coef) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
-    hipLaunchKernelGGL(gn_coefficients_kernel, dim3(n * groups), dim3(64), 0, (hipStream_t)stream, partials, splits,
+    hipLaunchKernelGGL(gn_coefficients_kernel, dim3(n * groups), dim3(256), 0, (hipStream_t)stream, partials, splits,
                        c, groups, eps, gamma, beta, coef);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
@@ -639,9 +699,10 @@ DFM_API int dfm_group_norm_coefficients(int32_t n, int32_t c, int32_t groups, fl
 DFM_API size_t dfm_group_norm_workspace_bytes(int32_t n, int32_t c, int64_t spatial, int32_t groups)
 {
     if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups) return 0;
-    // forward partials (N*G*splits*3) and backward partials (N*C*splits*2), splits <= 256
+    // forward partials (N*G*splits*3, splits <= 2048 -- round 6: 256 workgroups were one per CU, a slice of 28 load
+    // round trips each) + the merged triples, and backward partials (N*C*splits*2, splits <= 256)
     // (+ n*c*4 floats: coefficients of the channels-last backward)
-    const size_t fw = (size_t)n * groups * 257 * 3, bw = (size_t)n * c * (256 * 2 + 4);
+    const size_t fw = (size_t)n * groups * 2049 * 3, bw = (size_t)n * c * (256 * 2 + 4);
     return ((fw > bw ? fw : bw) * sizeof(float) + 255) & ~(size_t)255;
 }
 
@@ -713,19 +774,19 @@ DFM_API int dfm_group_norm_fwd_channels_last_res(int32_t n, int32_t c, int64_t s
         ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
         return set_error(DFM_ERR_UNSUPPORTED,
                          "channels-last GroupNorm needs C = 16-byte vectors x a power of two, C <= 256");
-    const int splits = std::min(256, pick_splits_cl((long long)spatial * c));  // stats partials (workspace layout)
-    const int asplits = pick_splits_cl((long long)spatial * c);                // workgroups of the apply pass
+    const int splits = pick_splits_cl((long long)spatial * c);  // workgroups of the statistics and of the apply pass
+    const int asplits = splits;
     dim3 grid(splits, n), agrid(asplits, n);
     hipStream_t st = (hipStream_t)stream;
     float *partial = (float *)workspace;
-    float *merged = partial + (size_t)n * groups * splits * 3;  // behind the partials (fits: bw partials are larger)
+    float *merged = partial + (size_t)n * groups * splits * 3;  // behind the partials
     if (dtype == DFM_F32)
         hipLaunchKernelGGL(gn_stats_cl_kernel<float>, grid, dim3(256), 0, st, (const float *)x,
                            (long long)spatial, c, groups, splits, partial);
     else
         hipLaunchKernelGGL(gn_stats_cl_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x,
                            (long long)spatial, c, groups, splits, partial);
-    hipLaunchKernelGGL(gn_merge_partials_kernel, dim3(n * groups), dim3(64), 0, st, partial, splits, merged);
+    hipLaunchKernelGGL(gn_merge_partials_kernel, dim3(n * groups), dim3(256), 0, st, partial, splits, merged);
     if (dtype == DFM_F32)
         hipLaunchKernelGGL(gn_apply_cl_kernel<float>, agrid, dim3(256), 0, st, (const float *)x,
                            (long long)spatial, c, groups, asplits, eps, merged, gamma, beta, relu,
@@ -774,7 +835,7 @@ DFM_API int dfm_group_norm_apply_channels_last_res(int32_t n, int32_t c, int64_t
                          "channels-last GroupNorm needs C = 16-byte vectors x a power of two, C <= 256");
     hipStream_t st = (hipStream_t)stream;
     float *merged = (float *)workspace;
-    hipLaunchKernelGGL(gn_merge_partials_kernel, dim3(n * groups), dim3(64), 0, st, partials, splits, merged);
+    hipLaunchKernelGGL(gn_merge_partials_kernel, dim3(n * groups), dim3(256), 0, st, partials, splits, merged);
     const int asplits = pick_splits_cl((long long)spatial * c);  // workgroups of the apply pass
     dim3 grid(asplits, n);
     // the apply kernel slices the tensor by ITS grid and merges `1` partial per group
