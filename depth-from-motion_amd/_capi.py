@@ -101,6 +101,7 @@ EXPORTS = (
     'dfm_group_norm_apply_channels_last_res',
     'dfm_group_norm_bwd',
     'dfm_group_norm_bwd_channels_last',
+    'dfm_group_norm_bwd_channels_last_xmask',
 )
 
 
@@ -427,6 +428,8 @@ def lib():
     h.dfm_group_norm_bwd.restype = ctypes.c_int
     h.dfm_group_norm_bwd.argtypes = [i32, i32, i64, i32, i32, i32, vp, vp, vp, fp, fp, fp, vp, fp, fp, vp, sz,
                                      vp]
+    h.dfm_group_norm_bwd_channels_last_xmask.restype = ctypes.c_int
+    h.dfm_group_norm_bwd_channels_last_xmask.argtypes = [i32, i32, i64, i32, i32, vp, vp, fp, fp, fp, fp, vp, fp, fp, vp, sz, vp]
     h.dfm_group_norm_bwd_channels_last.restype = ctypes.c_int
     h.dfm_group_norm_bwd_channels_last.argtypes = [i32, i32, i64, i32, i32, i32, vp, vp, vp, fp, fp, fp, vp, vp, fp,
                                                    fp, vp, sz, vp]

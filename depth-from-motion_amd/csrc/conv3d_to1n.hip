@@ -144,8 +144,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_to1_norm_kernel(T1Geom g, const
                     uint32_t pk[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float r0 = f[2 * j] * ca[ks][2 * j] + cb[ks][2 * j];
-                        float r1 = f[2 * j + 1] * ca[ks][2 * j + 1] + cb[ks][2 * j + 1];
+                        // (explicit fma: gn_apply_cl_kernel's expression, bit for bit)
+                        float r0 = __builtin_fmaf(f[2 * j], ca[ks][2 * j], cb[ks][2 * j]);
+                        float r1 = __builtin_fmaf(f[2 * j + 1], ca[ks][2 * j + 1], cb[ks][2 * j + 1]);
                         if (g.relu_in) { r0 = fmaxf(r0, 0.0f); r1 = fmaxf(r1, 0.0f); }
                         pk[j] = ok ? pack_bf16x2(r0, r1) : 0u;  // zero padding of the NORMALISED tensor
                     }

@@ -270,6 +270,8 @@ int pick_splits(long long L)
 // channels-last passes: up to 2048 workgroups per sample (config K at batch 1 is ONE sample of
 // 118 MB: 256 workgroups were one per CU, 3.5 TB/s); the partials are merged once by
 // gn_merge_partials_kernel, not by every workgroup of the apply pass
+constexpr int GN_BW_SPLITS = 1024;  // workgroups per sample of the channels-last backward's statistics pass
+
 int pick_splits_cl(long long L)
 {
     long long s = L / (256 * 16 * 4);  // >= 4 vectors per thread
@@ -410,7 +412,8 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
             const float a = rstd * gamma[c];
             ca[c] = a;
-            cb[c] = beta[c] - mean * a;
+            cb[c] = __builtin_fmaf(-mean, a, beta[c]);  // (explicit: the backward's recomputed mask and the on-load
+                                                        //  normalisation of conv3d_to1n.hip use the same expression)
         }
     }
     __syncthreads();
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                float r = f[u][k] * a[k] + b[k];
+                float r = __builtin_fmaf(f[u][k], a[k], b[k]);
                 if (res) r += q[u][k];
                 f[u][k] = relu ? fmaxf(r, 0.0f) : r;
             }
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
         if (res) load16<T>(res + base + (size_t)v * C, q);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            float r = f[k] * a[k] + b[k];
+            float r = __builtin_fmaf(f[k], a[k], b[k]);
             if (res) r += q[k];
             f[k] = relu ? fmaxf(r, 0.0f) : r;
         }
@@ -460,11 +463,21 @@ __global__ __launch_bounds__(256) void gn_apply_cl_kernel(const T *__restrict__ 
 // ---- channels-last backward (the NDHWC stacks train without a layout round trip) ----------------
 // pass 1: per (sample, channel) partial sums of dy' and dy' * xhat over a spatial slice
 //         (dy' = dy behind the ReLU mask of y); same partial layout as gn_bwd_stats_kernel
+// the ReLU mask of y = relu(x * a + b) from x (round 6): the forward's own expression -- fma, rounded through the
+// storage type -- so a layer without a fused residual reads two tensors in pass 1 and three in pass 3 instead of
+// three and four, and autograd keeps no second 118 MB tensor per layer alive
 template <typename T>
+__device__ __forceinline__ bool relu_on(float xv, float a, float b)
+{
+    return elem<T>::load(elem<T>::store(fmaxf(__builtin_fmaf(xv, a, b), 0.0f))) > 0.0f;
+}
+
+// XMASK: y is not read; the mask comes from x and the affine map (gamma, beta, mean, rstd)
+template <typename T, bool XMASK>
 __global__ __launch_bounds__(256) void gn_bwd_stats_cl_kernel(
     const T *__restrict__ dy, const T *__restrict__ x, const T *__restrict__ y, long long spatial, int C,
     int groups, int splits, int relu, const float *__restrict__ mean, const float *__restrict__ rstd,
-    float *__restrict__ partial)
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ partial)
 {
     constexpr int VEC = vec16<T>::N;
     __shared__ float sh[256][2 * VEC + 1];
@@ -475,22 +488,46 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_cl_kernel(
     const long long lo = min((long long)s * per, spatial), hi = min(lo + per, spatial);
     const size_t base = (size_t)n * spatial * C + (size_t)vb * VEC;
     float mu[VEC], rs[VEC], s1[VEC], s2[VEC];
+    [[maybe_unused]] float fa[VEC], fb[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         const int grp = n * groups + (vb * VEC + k) / cpg;
         mu[k] = mean[grp]; rs[k] = rstd[grp]; s1[k] = 0.0f; s2[k] = 0.0f;
+        if constexpr (XMASK) {
+            fa[k] = rs[k] * gamma[vb * VEC + k];             // gn_apply_cl_kernel's a and b
+            fb[k] = __builtin_fmaf(-mu[k], fa[k], beta[vb * VEC + k]);
+        }
     }
-    for (long long v = lo + v0; v < hi; v += vpi) {
-        float g[VEC], xv[VEC], yv[VEC];
-        load16<T>(dy + base + (size_t)v * C, g);
-        load16<T>(x + base + (size_t)v * C, xv);
-        if (relu) load16<T>(y + base + (size_t)v * C, yv);
+    constexpr int U = 2;  // voxels in flight per lane
+    auto take = [&](const float (&g)[VEC], const float (&xv)[VEC], const float (&yv)[VEC]) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const float gk = (relu && !(yv[k] > 0.0f)) ? 0.0f : g[k];
+            bool on = true;
+            if constexpr (XMASK) on = relu_on<T>(xv[k], fa[k], fb[k]);
+            else on = !relu || yv[k] > 0.0f;
+            const float gk = on ? g[k] : 0.0f;
             s1[k] += gk;
             s2[k] += gk * ((xv[k] - mu[k]) * rs[k]);
         }
+    };
+    long long v = lo + v0;
+    for (; v + (long long)(U - 1) * vpi < hi; v += (long long)U * vpi) {
+        float g[U][VEC], xv[U][VEC], yv[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            load16<T>(dy + base + (size_t)(v + (long long)u * vpi) * C, g[u]);
+            load16<T>(x + base + (size_t)(v + (long long)u * vpi) * C, xv[u]);
+            if (!XMASK && relu) load16<T>(y + base + (size_t)(v + (long long)u * vpi) * C, yv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) take(g[u], xv[u], yv[u]);
+    }
+    for (; v < hi; v += vpi) {
+        float g[VEC], xv[VEC], yv[VEC];
+        load16<T>(dy + base + (size_t)v * C, g);
+        load16<T>(x + base + (size_t)v * C, xv);
+        if (!XMASK && relu) load16<T>(y + base + (size_t)v * C, yv);
+        take(g, xv, yv);
     }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { sh[threadIdx.x][2 * k] = s1[k]; sh[threadIdx.x][2 * k + 1] = s2[k]; }
@@ -554,20 +591,28 @@ __global__ __launch_bounds__(64) void gn_bwd_coef_kernel(const float *__restrict
 
 // pass 3: dx = k1[c] * dy' + k2[c] * x + k3[c]; optionally the masked dy' itself (the gradient of
 // a fused residual input)
-template <typename T>
+template <typename T, bool XMASK>
 __global__ __launch_bounds__(256) void gn_bwd_apply_cl_kernel(
     const T *__restrict__ dy, const T *__restrict__ x, const T *__restrict__ y, long long spatial, int C,
-    int splits, int relu, const float *__restrict__ coef, T *__restrict__ dx, T *__restrict__ dres)
+    int groups, int splits, int relu, const float *__restrict__ coef, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+    T *__restrict__ dx, T *__restrict__ dres)
 {
     constexpr int VEC = vec16<T>::N;
     const int n = blockIdx.y, s = blockIdx.x;
     const int nvb = C / VEC, vpi = 256 / nvb;
     const int vb = threadIdx.x % nvb, v0 = threadIdx.x / nvb;
     float k1[VEC], k2[VEC], k3[VEC];
+    [[maybe_unused]] float fa[VEC], fb[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         const float *o = coef + ((size_t)n * C + vb * VEC + k) * 3;
         k1[k] = o[0]; k2[k] = o[1]; k3[k] = o[2];
+        if constexpr (XMASK) {
+            const int grp = n * groups + (vb * VEC + k) / (C / groups);
+            fa[k] = rstd[grp] * gamma[vb * VEC + k];
+            fb[k] = __builtin_fmaf(-mean[grp], fa[k], beta[vb * VEC + k]);
+        }
     }
     const long long per = (spatial + splits - 1) / splits;
     const long long lo = min((long long)s * per, spatial), hi = min(lo + per, spatial);
@@ -576,10 +621,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_cl_kernel(
         float g[VEC], xv[VEC], yv[VEC];
         load16<T>(dy + base + (size_t)v * C, g);
         load16<T>(x + base + (size_t)v * C, xv);
-        if (relu) load16<T>(y + base + (size_t)v * C, yv);
+        if (!XMASK && relu) load16<T>(y + base + (size_t)v * C, yv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            if (relu && !(yv[k] > 0.0f)) g[k] = 0.0f;
+            bool on = true;
+            if constexpr (XMASK) on = relu_on<T>(xv[k], fa[k], fb[k]);
+            else on = !relu || yv[k] > 0.0f;
+            if (!on) g[k] = 0.0f;
             xv[k] = k1[k] * g[k] + k2[k] * xv[k] + k3[k];
         }
         store16<T>(dx + base + (size_t)v * C, xv);
@@ -673,7 +721,7 @@ __global__ __launch_bounds__(256) void gn_coefficients_kernel(const float *__res
     for (int c = gi * cpg + threadIdx.x; c < (gi + 1) * cpg; c += 256) {
         const float a = rstd * gamma[c];
         coef[((size_t)n * C + c) * 2] = a;
-        coef[((size_t)n * C + c) * 2 + 1] = beta[c] - mean * a;
+        coef[((size_t)n * C + c) * 2 + 1] = __builtin_fmaf(-mean, a, beta[c]);
     }
 }
 
@@ -702,7 +750,7 @@ DFM_API size_t dfm_group_norm_workspace_bytes(int32_t n, int32_t c, int64_t spat
     // forward partials (N*G*splits*3, splits <= 2048 -- round 6: 256 workgroups were one per CU, a slice of 28 load
     // round trips each) + the merged triples, and backward partials (N*C*splits*2, splits <= 256)
     // (+ n*c*4 floats: coefficients of the channels-last backward)
-    const size_t fw = (size_t)n * groups * 2049 * 3, bw = (size_t)n * c * (256 * 2 + 4);
+    const size_t fw = (size_t)n * groups * 2049 * 3, bw = (size_t)n * c * (GN_BW_SPLITS * 2 + 4);
     return ((fw > bw ? fw : bw) * sizeof(float) + 255) & ~(size_t)255;
 }
 
@@ -894,18 +942,17 @@ DFM_API int dfm_group_norm_bwd(int32_t n, int32_t c, int64_t spatial, int32_t gr
     return DFM_OK;
 }
 
-DFM_API int dfm_group_norm_bwd_channels_last(int32_t n, int32_t c, int64_t spatial, int32_t groups,
-                                             int32_t dtype, int32_t relu, const void *grad_y, const void *x,
-                                             const void *y, const float *mean, const float *rstd,
-                                             const float *gamma, void *grad_x, void *grad_residual,
-                                             float *grad_gamma, float *grad_beta, void *workspace,
-                                             size_t workspace_bytes, void *stream)
+static int gn_bwd_cl_impl(int32_t n, int32_t c, int64_t spatial, int32_t groups, int32_t dtype, int32_t relu,
+                          const void *grad_y, const void *x, const void *y, const float *mean, const float *rstd,
+                          const float *gamma, const float *beta, void *grad_x, void *grad_residual,
+                          float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream)
 {
+    const bool xmask = relu && !y && beta;
     if (n <= 0 || c <= 0 || spatial <= 0 || groups <= 0 || c % groups)
         return set_error(DFM_ERR_INVALID_ARG, "bad sizes in dfm_group_norm_bwd_channels_last");
     if (dtype != DFM_F32 && dtype != DFM_BF16)
         return set_error(DFM_ERR_UNSUPPORTED, "dtype must be DFM_F32 or DFM_BF16");
-    if (!grad_y || !x || (relu && !y) || !mean || !rstd || !gamma || !grad_x || !grad_gamma || !grad_beta ||
+    if (!grad_y || !x || (relu && !y && !beta) || !mean || !rstd || !gamma || !grad_x || !grad_gamma || !grad_beta ||
         !workspace)
         return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     if (workspace_bytes < dfm_group_norm_workspace_bytes(n, c, spatial, groups))
@@ -917,33 +964,56 @@ DFM_API int dfm_group_norm_bwd_channels_last(int32_t n, int32_t c, int64_t spati
         ((uintptr_t)grad_residual & 15))
         return set_error(DFM_ERR_UNSUPPORTED,
                          "channels-last GroupNorm needs C = 16-byte vectors x a power of two, C <= 256");
-    const int splits = std::min(256, pick_splits_cl((long long)spatial * c));
+    // (round 6: up to GN_BW_SPLITS workgroups in the statistics pass -- 256 were one per CU, one voxel in flight a lane)
     const int asplits = pick_splits_cl((long long)spatial * c);
+    const int splits = std::min(GN_BW_SPLITS, asplits);
     hipStream_t st = (hipStream_t)stream;
     float *partial = (float *)workspace;
-    float *coef = partial + (size_t)n * c * 256 * 2;
+    float *coef = partial + (size_t)n * c * GN_BW_SPLITS * 2;
     dim3 grid(splits, n), agrid(asplits, n);
-    if (dtype == DFM_F32)
-        hipLaunchKernelGGL(gn_bwd_stats_cl_kernel<float>, grid, dim3(256), 0, st, (const float *)grad_y,
-                           (const float *)x, (const float *)y, (long long)spatial, c, groups, splits, relu, mean,
-                           rstd, partial);
-    else
-        hipLaunchKernelGGL(gn_bwd_stats_cl_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)grad_y,
-                           (const bf16_t *)x, (const bf16_t *)y, (long long)spatial, c, groups, splits, relu, mean,
-                           rstd, partial);
-    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(groups), dim3(64), 0, st, partial, n, c, c / groups, splits,
-                       (long long)spatial, mean, rstd, gamma, coef, grad_gamma, grad_beta);
-    if (dtype == DFM_F32)
-        hipLaunchKernelGGL(gn_bwd_apply_cl_kernel<float>, agrid, dim3(256), 0, st, (const float *)grad_y,
-                           (const float *)x, (const float *)y, (long long)spatial, c, asplits, relu, coef,
-                           (float *)grad_x, (float *)grad_residual);
-    else
-        hipLaunchKernelGGL(gn_bwd_apply_cl_kernel<bf16_t>, agrid, dim3(256), 0, st, (const bf16_t *)grad_y,
-                           (const bf16_t *)x, (const bf16_t *)y, (long long)spatial, c, asplits, relu, coef,
-                           (bf16_t *)grad_x, (bf16_t *)grad_residual);
+#define GN_BW(T_, X_)                                                                                             \
+    do {                                                                                                          \
+        hipLaunchKernelGGL((gn_bwd_stats_cl_kernel<T_, X_>), grid, dim3(256), 0, st, (const T_ *)grad_y,          \
+                           (const T_ *)x, (const T_ *)y, (long long)spatial, c, groups, splits, relu, mean, rstd, \
+                           gamma, beta, partial);                                                                 \
+        hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(groups), dim3(64), 0, st, partial, n, c, c / groups, splits,  \
+                           (long long)spatial, mean, rstd, gamma, coef, grad_gamma, grad_beta);                   \
+        hipLaunchKernelGGL((gn_bwd_apply_cl_kernel<T_, X_>), agrid, dim3(256), 0, st, (const T_ *)grad_y,         \
+                           (const T_ *)x, (const T_ *)y, (long long)spatial, c, groups, asplits, relu, coef, mean, \
+                           rstd, gamma, beta, (T_ *)grad_x, (T_ *)grad_residual);                                 \
+    } while (0)
+    if (dtype == DFM_F32) { if (xmask) GN_BW(float, true); else GN_BW(float, false); }
+    else { if (xmask) GN_BW(bf16_t, true); else GN_BW(bf16_t, false); }
+#undef GN_BW
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;
+}
+
+DFM_API int dfm_group_norm_bwd_channels_last(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                             int32_t dtype, int32_t relu, const void *grad_y, const void *x,
+                                             const void *y, const float *mean, const float *rstd,
+                                             const float *gamma, void *grad_x, void *grad_residual,
+                                             float *grad_gamma, float *grad_beta, void *workspace,
+                                             size_t workspace_bytes, void *stream)
+{
+    if (relu && !y) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    return gn_bwd_cl_impl(n, c, spatial, groups, dtype, relu, grad_y, x, y, mean, rstd, gamma, nullptr, grad_x,
+                          grad_residual, grad_gamma, grad_beta, workspace, workspace_bytes, stream);
+}
+
+// the same for y = relu(GroupNorm(x)) WITHOUT a fused residual, y not kept: the ReLU mask is recomputed from x with
+// the forward's expression (beta: the norm's bias, fp32 [c])
+DFM_API int dfm_group_norm_bwd_channels_last_xmask(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                                   int32_t dtype, const void *grad_y, const void *x,
+                                                   const float *mean, const float *rstd, const float *gamma,
+                                                   const float *beta, void *grad_x, float *grad_gamma,
+                                                   float *grad_beta, void *workspace, size_t workspace_bytes,
+                                                   void *stream)
+{
+    if (!beta) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
+    return gn_bwd_cl_impl(n, c, spatial, groups, dtype, 1, grad_y, x, nullptr, mean, rstd, gamma, beta, grad_x,
+                          nullptr, grad_gamma, grad_beta, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

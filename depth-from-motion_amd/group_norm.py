@@ -7,6 +7,7 @@ GroupNorm kernel followed by a separate ReLU.
 touching checkpoints.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -35,6 +36,9 @@ def _f32_params(weight, bias):
                weakref.ref(weight), weakref.ref(bias))
         _F32_CACHE[key] = hit
     return hit[1], hit[2]
+
+
+_XMASK = os.environ.get('DFM_GN_KEEP_Y') != '1'   # (A/B runs: the backward reads the ReLU mask from the kept output)
 
 
 class _GroupNormFn(torch.autograd.Function):
@@ -85,16 +89,19 @@ class _GroupNormFn(torch.autograd.Function):
             y = y + residual
             if relu:
                 y = torch.relu_(y)
-        ctx.save_for_backward(x, y if relu else x, mean, rstd, w32)
-        ctx.cfg = (groups, bool(relu), weight.dtype, bias.dtype, cl, residual is not None)
+        # y = relu(gn(x)) of a channels-last tensor without a residual: the backward recomputes the ReLU mask from x
+        # (dfm_group_norm_bwd_channels_last_xmask) -- y is not kept for it, one activation less per layer in the graph
+        xmask = bool(relu) and cl and residual is None and _XMASK
+        ctx.save_for_backward(x, y if (relu and not xmask) else x, mean, rstd, w32, b32)
+        ctx.cfg = (groups, bool(relu), weight.dtype, bias.dtype, cl, residual is not None, xmask)
         if stats_out is not None:  # (mean, rstd) per (sample, group): HipBatchNorm3d's running statistics
             stats_out.append((mean, rstd))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, mean, rstd, w32 = ctx.saved_tensors
-        groups, relu, wdt, bdt, cl, has_res = ctx.cfg
+        x, y, mean, rstd, w32, b32 = ctx.saved_tensors
+        groups, relu, wdt, bdt, cl, has_res, xmask = ctx.cfg
         lib = _capi.lib()
         device = x.device
         n, c = x.shape[:2]
@@ -112,6 +119,12 @@ class _GroupNormFn(torch.autograd.Function):
             gy = gy.to(x.dtype).contiguous(memory_format=fmt)
             gx = torch.empty_like(x)
             gres = torch.empty_like(x) if want_res and relu else None
+            if xmask:
+                with torch.cuda.device(device):
+                    _capi.check(lib.dfm_group_norm_bwd_channels_last_xmask(
+                        n, c, spatial, groups, _DTYPES[x.dtype], _ptr(gy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w32),
+                        _ptr(b32), _ptr(gx), _ptr(gw), _ptr(gb), _ptr(ws), nbytes, _stream_ptr(device)))
+                return gx, gw.to(wdt), gb.to(bdt), None, None, None, None, None, None
             with torch.cuda.device(device):
                 _capi.check(lib.dfm_group_norm_bwd_channels_last(
                     n, c, spatial, groups, _DTYPES[x.dtype], int(relu), _ptr(gy), _ptr(x), _ptr(y), _ptr(mean),

@@ -950,6 +950,18 @@ DFM_API int dfm_group_norm_bwd_channels_last(int32_t n, int32_t c, int64_t spati
                                              const float *rstd, const float *gamma, void *grad_x,
                                              void *grad_residual, float *grad_gamma, float *grad_beta,
                                              void *workspace, size_t workspace_bytes, void *stream);
+/* dfm_group_norm_bwd_channels_last for y = relu(GroupNorm(x)) without a fused residual, y NOT kept (round 6): the ReLU
+ * mask is recomputed from x with the forward's own expression (fma(x, rstd * gamma, beta - mean * rstd * gamma),
+ * rounded through the storage type), so the statistics pass reads two tensors instead of three, the gradient pass
+ * three instead of four, and the caller's autograd graph holds no second activation per layer
+ * (mmdet3d/models/utils/conv_modules.py:27-43: every Conv3d + GN + ReLU block of the aggregation stacks).
+ * beta: the norm's bias, fp32 [c] [device]; grad_gamma / grad_beta are OVERWRITTEN */
+DFM_API int dfm_group_norm_bwd_channels_last_xmask(int32_t n, int32_t c, int64_t spatial, int32_t groups,
+                                                   int32_t dtype, const void *grad_y, const void *x,
+                                                   const float *mean, const float *rstd, const float *gamma,
+                                                   const float *beta, void *grad_x, float *grad_gamma,
+                                                   float *grad_beta, void *workspace, size_t workspace_bytes,
+                                                   void *stream);
 
 /* AvgPool3d((k, 1, 1)) of FrustumToVoxel (necks/feature_transformation.py:167) on a channels-last volume, forward
  * and backward, one pass each (csrc/depth_pool.hip): the tensor as (outer, k, inner) contiguous -- for an

@@ -240,3 +240,48 @@ def test_hip_batch_norm3d_training_matches_torch(pkg, relu, with_res, dtype):
     # eval mode is torch's BatchNorm (the necks fold it into the convolution epilogue instead)
     m.eval(); ref.eval()
     torch.testing.assert_close(m(xg.detach()).float(), ref(x.float()), **tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,c,sp,groups,partials', [(2, 32, (8, 12, 20), 32, False), (1, 64, (9, 7, 13), 32, False),
+                                                    (1, 32, (6, 16, 40), 32, True), (3, 16, (6, 10), 4, False)])
+def test_relu_mask_recomputed_from_x_is_the_mask_of_the_kept_output(pkg, monkeypatch, n, c, sp, groups, partials, dtype):
+    """dfm_group_norm_bwd_channels_last_xmask: y = relu(GroupNorm(x)) without a residual keeps no y for its backward --
+    the mask comes from x through the forward's own expression.  Same sums in the same order otherwise: the three
+    gradients are BIT-IDENTICAL to the backward that reads the mask from the kept output (values spread around the
+    ReLU's kink: a third of them within a few ulp of zero after the affine map would show a one-ulp disagreement)."""
+    gn = importlib.import_module('depth-from-motion_amd.group_norm')
+    if partials and dtype != torch.bfloat16:
+        pytest.skip('the convolution epilogue that produces statistics partials is bf16')
+    gen = torch.Generator().manual_seed(c + len(sp))
+    fmt = torch.channels_last_3d if len(sp) == 3 else torch.channels_last
+    x = (torch.randn(n, c, *sp, generator=gen) * 1.5 + 0.4).cuda().to(dtype).contiguous(memory_format=fmt)
+    w = (1 + 0.2 * torch.randn(c, generator=gen)).cuda()
+    b = torch.zeros(c).cuda()          # beta = 0: the kink sits at the group mean, where the values are dense
+    gy = torch.randn(n, c, *sp, generator=gen).cuda().to(dtype).contiguous(memory_format=fmt)
+    res = {}
+    for xmask in (True, False):
+        monkeypatch.setattr(gn, '_XMASK', xmask)
+        xg = x.clone().requires_grad_(True)
+        wg, bg = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        if partials:
+            mods = importlib.import_module('depth-from-motion_amd.modules')
+            conv = mods.MfmaConv3d(32, 32, 3, 1, 1, bias=False).cuda().to(torch.bfloat16).to(memory_format=fmt)
+            torch.manual_seed(1)
+            with torch.no_grad():
+                conv.weight.copy_(torch.randn_like(conv.weight) * 0.05)
+                yc, pt = conv.forward_with_stats(x)
+            xg = yc.clone().requires_grad_(True)
+            out = pkg.group_norm(xg, groups, wg, bg, 1e-5, True, partials=pt)
+        else:
+            out = pkg.group_norm(xg, groups, wg, bg, 1e-5, True)
+        saved = [t for t in out.grad_fn.saved_tensors] if hasattr(out.grad_fn, 'saved_tensors') else []
+        kept_y = any(t.data_ptr() == out.data_ptr() for t in saved)
+        assert kept_y == (not xmask), 'the recomputing backward keeps no output tensor'
+        out.backward(gy)
+        res[xmask] = (out.detach(), xg.grad, wg.grad, bg.grad)
+    frac_on = float((res[True][0] > 0).float().mean())
+    assert 0.2 < frac_on < 0.8
+    for a_, b_ in zip(res[True], res[False]):
+        assert torch.equal(a_, b_)
