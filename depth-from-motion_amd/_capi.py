@@ -85,6 +85,7 @@ EXPORTS = (
     'dfm_conv3d_g_plan',
     'dfm_conv3d_wgrad_workspace_bytes',
     'dfm_conv3d_wgrad',
+    'dfm_conv3d_wgrad_to',
     'dfm_depth_loss_fwd',
     'dfm_depth_loss_bwd',
     'dfm_depth_loss_fused_fwd',
@@ -389,6 +390,8 @@ def lib():
     wp = ctypes.POINTER(Conv3dWgradDesc)
     h.dfm_conv3d_wgrad_workspace_bytes.restype = sz
     h.dfm_conv3d_wgrad_workspace_bytes.argtypes = [wp]
+    h.dfm_conv3d_wgrad_to.restype = ctypes.c_int
+    h.dfm_conv3d_wgrad_to.argtypes = [wp, vp, vp, vp, i32, vp, sz, vp]
     h.dfm_conv3d_wgrad.restype = ctypes.c_int
     h.dfm_conv3d_wgrad.argtypes = [wp, vp, vp, fp, vp, sz, vp]
     lp = ctypes.POINTER(DepthLossDesc)

@@ -173,7 +173,7 @@ class _MfmaConvFn(torch.autograd.Function):
                 torch.cat(halves, dim=1).contiguous(memory_format=torch.channels_last_3d)
         gw = None
         if ctx.needs_input_grad[1]:  # backward-weight: chunked implicit-im2col GEMM (see above)
-            gw = conv3d_weight_grad(x, gy, 1, 1).to(weight.dtype)
+            gw = conv3d_weight_grad(x, gy, 1, 1, out_dtype=weight.dtype)
         return gx, gw, None, None
 
 
@@ -358,12 +358,13 @@ def _ndhwc_strides(t):
     return st if all(s > 0 and s % 8 == 0 for s in st) else None
 
 
-def conv3d_weight_grad(x_in, g_out, stride, padding):
+def conv3d_weight_grad(x_in, g_out, stride, padding, out_dtype=torch.float32):
     """Weight gradient of a 3x3x3 convolution,
         out[a][b][kd][kh][kw] = sum_o g_out[:, a, o] * x_in[:, b, o * stride - padding + k],
-    for bf16 channels-last x_in (N, B, D, H, W) and g_out (N, A, Do, Ho, Wo); fp32 (A, B, 3, 3, 3).
-    The hand-written MFMA kernel (csrc/conv3d_wgrad.hip) when the channel counts are multiples of 32,
-    else the chunked implicit-im2col GEMM below."""
+    for bf16 channels-last x_in (N, B, D, H, W) and g_out (N, A, Do, Ho, Wo); (A, B, 3, 3, 3) in ``out_dtype``
+    (fp32, or bf16: the kernel's reduction pass rounds its fp32 sums once -- a bf16 parameter's gradient without a
+    conversion launch).  The hand-written MFMA kernel (csrc/conv3d_wgrad.hip) when the channel counts are multiples
+    of 32, else the chunked implicit-im2col GEMM below."""
     stride, padding = _triple(stride), _triple(padding)
     A, B = g_out.shape[1], x_in.shape[1]
     gs, xs = _ndhwc_strides(g_out), _ndhwc_strides(x_in)
@@ -380,19 +381,21 @@ def conv3d_weight_grad(x_in, g_out, stride, padding):
         lib = _capi.lib()
         nbytes = lib.dfm_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
         if nbytes:
-            out = torch.empty((A, B, 3, 3, 3), dtype=torch.float32, device=x_in.device)
+            direct = out_dtype in (torch.float32, torch.bfloat16)
+            out = torch.empty((A, B, 3, 3, 3), dtype=out_dtype if direct else torch.float32, device=x_in.device)
             ws = _Workspace.get(x_in.device, nbytes)
             with torch.cuda.device(x_in.device):
-                rc = lib.dfm_conv3d_wgrad(ctypes.byref(d), _ptr(g_out), _ptr(x_in), _ptr(out), _ptr(ws),
-                                          nbytes, _stream_ptr(x_in.device))
+                rc = lib.dfm_conv3d_wgrad_to(ctypes.byref(d), _ptr(g_out), _ptr(x_in), _ptr(out),
+                                             _capi.DFM_BF16 if out.dtype == torch.bfloat16 else _capi.DFM_F32,
+                                             _ptr(ws), nbytes, _stream_ptr(x_in.device))
             if rc == 0:
-                return out
+                return out if direct else out.to(out_dtype)
             if rc != _capi.DFM_ERR_UNSUPPORTED:  # a tile that does not fit the LDS falls through to the GEMM
                 _capi.check(rc)
     if x_in.is_cuda and _POLICY['mode'] == 'raise':
         raise MfmaPathError(f'weight gradient of a {B}->{A} convolution outside the MFMA kernel\'s coverage '
                             '(channels not multiples of 32, layout, or a tile that does not fit the LDS)')
-    return _weight_grad_gemm(x_in, g_out, stride, padding)
+    return _weight_grad_gemm(x_in, g_out, stride, padding).to(out_dtype)
 
 
 def _weight_grad_gemm(x_in, g_out, stride, padding, chunk_bytes=256 << 20):
@@ -447,6 +450,44 @@ class _ChannelSliceFn(torch.autograd.Function):
         g = torch.zeros((N, D, H, W, C), dtype=gy.dtype, device=gy.device).permute(0, 4, 1, 2, 3)
         g[:, lo:hi] = gy
         return g, None, None
+
+
+class _ChannelSplitFn(torch.autograd.Function):
+    """(x, x[:, lo:hi]) for a tensor with two consumers -- the whole tensor and a channel slice of it (DfMBackbone: the
+    cost volume feeds dres0 whole and dres0_mono by its first C channels, dfm_backbone.py:175,189; DfMNeck likewise,
+    dfm_neck.py:78-84).  As two separate uses the slice's gradient came back as a zero-filled tensor of x's size with
+    the slice copied in (_ChannelSliceFn) and the engine added the two full-size gradients: a fill, a copy and a
+    full-size addition (0.2 ms per training step at config K).  Here the backward receives both gradients and adds
+    the slice's INTO the whole tensor's, in place, over the slice's channels only.  (The whole tensor's gradient is
+    the fresh result of its single consumer's backward; nothing else holds it.)"""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        ctx.cfg = (x.shape, lo, hi)
+        return x.view_as(x), x[:, lo:hi]
+
+    @staticmethod
+    def backward(ctx, g_full, g_part):
+        shape, lo, hi = ctx.cfg
+        if g_full is None:
+            if g_part is None:
+                return None, None, None
+            N, C, D, H, W = shape   # only the slice was used: its gradient in a zero tensor of x's layout
+            g_full = torch.zeros((N, D, H, W, C), dtype=g_part.dtype, device=g_part.device).permute(0, 4, 1, 2, 3)
+            g_full[:, lo:hi] = g_part
+            return g_full, None, None
+        if g_part is not None:
+            g_full[:, lo:hi] += g_part.to(g_full.dtype)
+        return g_full, None, None
+
+
+def channel_split(x, lo, hi):
+    """``(x, x[:, lo:hi])`` for the two consumers of a channels-last 5-D GPU tensor under autograd: one backward node
+    that adds the slice's gradient into the whole tensor's in place (see _ChannelSplitFn); plain views otherwise"""
+    if x.is_cuda and x.dim() == 5 and x.requires_grad and torch.is_grad_enabled() and \
+            x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous():
+        return _ChannelSplitFn.apply(x, lo, hi)
+    return x, x[:, lo:hi]
 
 
 def channel_slice(x, lo, hi):
@@ -1288,14 +1329,14 @@ class _ConvGFn(torch.autograd.Function):
                         gy, x, weight.to(x.dtype), None, list(stride), list(padding), [1, 1, 1], False,
                         [0, 0, 0], 1, [True, False, False])[0]
             if ctx.needs_input_grad[1]:
-                gw = conv3d_weight_grad(x, gy, stride, padding).to(weight.dtype)
+                gw = conv3d_weight_grad(x, gy, stride, padding, out_dtype=weight.dtype)
         else:
             cin, cout = weight.shape[:2]
             if ctx.needs_input_grad[0]:
                 pk = pack_conv3d_g_weights(weight, cout, cin, swap=False, flip=0)
                 gx = conv3d_g(gy, pk, cin, stride=2, padding=1)
             if ctx.needs_input_grad[1]:
-                gw = conv3d_weight_grad(gy, x, 2, 1).to(weight.dtype)
+                gw = conv3d_weight_grad(gy, x, 2, 1, out_dtype=weight.dtype)
         return gx, gw, None, None, None, None
 
 

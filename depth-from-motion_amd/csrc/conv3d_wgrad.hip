@@ -342,9 +342,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv3d_wgrad_kernel(WGeom g, co
 // out[(a0 + a) * B + b0 + b][tap'] = sum over the pair's workgroups; tap' undoes the h/w swap.
 // 64 consecutive elements per block, the workgroup partials split over 4 thread groups (the sum of
 // up to 512 partials per element is latency-bound when one thread walks them all)
+// TO: the gradient's type (fp32, or bf16 -- the parameter's own type: the sums rounded once, no conversion launch)
+template <typename TO>
 __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *__restrict__ part, int wgs_per_pair,
                                                                   int b_tiles, int B, int swap_hw, int flat,
-                                                                  float *__restrict__ out)
+                                                                  TO *__restrict__ out)
 {
     __shared__ float sh[4][64];
     const int pair = blockIdx.y;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *_
     const int kd = tap / 9, k1 = (tap / 3) % 3, k2 = tap % 3;
     const int tp = swap_hw ? (kd * 3 + k2) * 3 + k1 : tap;
     const int a0 = (pair / b_tiles) * 32, b0 = (pair % b_tiles) * 32;
-    out[((size_t)(a0 + a) * B + b0 + b) * 27 + tp] = s;
+    out[((size_t)(a0 + a) * B + b0 + b) * 27 + tp] = elem<TO>::store(s);
 }
 
 struct WPlan {
@@ -477,8 +479,28 @@ extern "C" DFM_API size_t dfm_conv3d_wgrad_workspace_bytes(const dfm_conv3d_wgra
     return pl.scratch;
 }
 
+static int wgrad_impl(const dfm_conv3d_wgrad_desc *desc, const void *g, const void *x, void *out, int out_dtype,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" DFM_API int dfm_conv3d_wgrad(const dfm_conv3d_wgrad_desc *desc, const void *g, const void *x,
                                         float *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return wgrad_impl(desc, g, x, out, DFM_F32, workspace, workspace_bytes, stream);
+}
+
+// the same with the gradient written in out_dtype (DFM_F32 | DFM_BF16): a bf16 parameter's gradient leaves the
+// reduction kernel in the parameter's type -- the fp32 sums rounded once -- instead of through a conversion launch
+extern "C" DFM_API int dfm_conv3d_wgrad_to(const dfm_conv3d_wgrad_desc *desc, const void *g, const void *x,
+                                           void *out, int32_t out_dtype, void *workspace, size_t workspace_bytes,
+                                           void *stream)
+{
+    if (out_dtype != DFM_F32 && out_dtype != DFM_BF16)
+        return set_error(DFM_ERR_UNSUPPORTED, "gradient dtype must be DFM_F32 or DFM_BF16");
+    return wgrad_impl(desc, g, x, out, out_dtype, workspace, workspace_bytes, stream);
+}
+
+static int wgrad_impl(const dfm_conv3d_wgrad_desc *desc, const void *g, const void *x, void *out, int out_dtype,
+                      void *workspace, size_t workspace_bytes, void *stream)
 {
     WPlan pl;
     int rc = wgrad_plan(desc, pl);
@@ -512,8 +534,14 @@ extern "C" DFM_API int dfm_conv3d_wgrad(const dfm_conv3d_wgrad_desc *desc, const
         if (pl.flat) W_LAUNCH(2, true); else W_LAUNCH(2, false);
     }
 #undef W_LAUNCH
-    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(27 * 1024 / 64, pl.pairs), dim3(256), 0, st,
-                       (const float *)workspace, pl.g.wgs_per_pair, pl.g.b_tiles, desc->b, pl.swap, pl.flat, out);
+    if (out_dtype == DFM_BF16)
+        hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel<bf16_t>, dim3(27 * 1024 / 64, pl.pairs), dim3(256), 0, st,
+                           (const float *)workspace, pl.g.wgs_per_pair, pl.g.b_tiles, desc->b, pl.swap, pl.flat,
+                           (bf16_t *)out);
+    else
+        hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel<float>, dim3(27 * 1024 / 64, pl.pairs), dim3(256), 0, st,
+                           (const float *)workspace, pl.g.wgs_per_pair, pl.g.b_tiles, desc->b, pl.swap, pl.flat,
+                           (float *)out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;

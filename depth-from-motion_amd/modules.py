@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .conv3d import (DerivedStateMixin, conv3d_to1_norm, long_axis_gram, note_derived_build, MfmaConv2d, MfmaConv3d, MfmaConv3dG, MfmaConv3dTo1, MfmaConvTranspose2d,
-                     MfmaConvTranspose3d, channel_slice)
+                     MfmaConvTranspose3d, channel_slice, channel_split)
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .geometry import stack_meta
@@ -555,15 +555,16 @@ class DfMBackbone(DerivedStateMixin, nn.Module):
             meta0.get('flip', False), meta0['crop_offset'],
             img_scale_factor=meta0.get('scale_factor', [1.0])[0],
             memory_format=self.volume_memory_format)
+        # the volume's two consumers: dres0 (whole) and dres0_mono (the cur half) -- one autograd node whose backward adds
+        # the half's gradient into the whole volume's in place (conv3d.channel_split)
+        cost_all, cost_cur = channel_split(cost_raw, 0, self.in_channels)
         if self._interleave_ok(cost_raw.device):
             stereo, mono = self._two_stacks_interleaved(
-                lambda: self.dres0(cost_raw),
-                lambda: self.dres0_mono(channel_slice(cost_raw, 0, self.in_channels)), cost_raw.device)
+                lambda: self.dres0(cost_all), lambda: self.dres0_mono(cost_cur), cost_raw.device)
             return self._predict(*stereo, *mono)
         stereo, mono = self._two_branches(
-            lambda: self._aggregate(self.dres0, self.dres1, self.hg_stereo, cost_raw),
-            lambda: self._aggregate(self.dres0_mono, self.dres1_mono, self.hg_mono,
-                                    channel_slice(cost_raw, 0, self.in_channels)), cost_raw.device)
+            lambda: self._aggregate(self.dres0, self.dres1, self.hg_stereo, cost_all),
+            lambda: self._aggregate(self.dres0_mono, self.dres1_mono, self.hg_mono, cost_cur), cost_raw.device)
         return self._predict(*stereo, *mono)
 
     # DFM_GATE_TORCH=1 keeps the torch sequence of the gate at inference too (A/B runs)
@@ -887,8 +888,9 @@ class DfMNeck(DerivedStateMixin, nn.Module):
             main.wait_stream(side)
             mono.record_stream(main)
         else:
-            mono = _to_bev(self.mono_layers(channel_slice(x, 0, self.in_channels[0])))
-            stereo = _to_bev(self.stereo_layers(x))
+            x_all, x_mono = channel_split(x, 0, self.in_channels[0])   # (one backward node for the two uses of x)
+            mono = _to_bev(self.mono_layers(x_mono))
+            stereo = _to_bev(self.stereo_layers(x_all))
         # 1x1 Conv2d(2 C_out -> 1): MIOpen's kernel for this shape is a 58 ms naive convolution in
         # bf16 (profiles/archive/r02_c26_*); it is a weighted channel sum of the two maps
         w = self.aggregate_layer.weight.view(2, -1, 1, 1).to(mono.dtype)
@@ -977,6 +979,15 @@ class _BilinearResizeFn(torch.autograd.Function):
         B, C, h_out, w_out = gy.shape
         a_w = _interp_matrix(w_in, w_out, ac, scale, gy.device)            # (w_out, w_in)
         a_h = _interp_matrix(h_in, h_out, ac, scale, gy.device)            # (h_out, h_in)
+        if gy.stride(1) == 1 and C > 1 and gy.is_contiguous(memory_format=torch.channels_last):
+            # an NHWC gradient (the 2-D necks train channels-last): the same two products on the memory as it lies --
+            # rows of C channels ride along as the matrices' columns, gX[b, hi, wi, :] = sum A_h[ho, hi] A_w[wo, wi]
+            # gY[b, ho, wo, :] -- and an NHWC result.  (Round 5 reshaped to (B C, h, w): a transposing copy of the
+            # gradient, a second one inside bmm and a third of the result: 0.47 ms of copies per training step.)
+            g = gy.permute(0, 2, 3, 1).float()                                          # (B, h_out, w_out, C), no move
+            g = torch.matmul(a_w.t(), g.view(B * h_out, w_out, C))                      # (B h_out, w_in, C)
+            g = torch.matmul(a_h.t(), g.view(B, h_out, w_in * C))                       # (B, h_in, w_in C)
+            return g.view(B, h_in, w_in, C).to(gy.dtype).permute(0, 3, 1, 2), None, None, None
         g = gy.reshape(B * C, h_out, w_out).float()
         g = torch.matmul(g, a_w)                                           # (BC, h_out, w_in)
         g = torch.matmul(a_h.t(), g)                                       # (BC, h_in, w_in)

@@ -821,6 +821,10 @@ typedef struct dfm_conv3d_wgrad_desc {
 DFM_API size_t dfm_conv3d_wgrad_workspace_bytes(const dfm_conv3d_wgrad_desc *desc);
 DFM_API int dfm_conv3d_wgrad(const dfm_conv3d_wgrad_desc *desc, const void *g, const void *x, float *out,
                              void *workspace, size_t workspace_bytes, void *stream);
+/* the same with `out` in out_dtype (DFM_F32 | DFM_BF16; (a, b, 27), overwritten): a bf16 parameter's gradient in the
+ * parameter's own type, the fp32 sums rounded once in the reduction kernel (round 6: no conversion launch) */
+DFM_API int dfm_conv3d_wgrad_to(const dfm_conv3d_wgrad_desc *desc, const void *g, const void *x, void *out,
+                                int32_t out_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------- */
 /* DepthHead.loss, dense_heads/depth_head.py:75-188 (called at dfm.py:348) */

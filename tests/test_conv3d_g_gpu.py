@@ -416,23 +416,31 @@ def test_conv2d_modules_train_through_the_mfma_kernels(cv, monkeypatch, kind, ci
 
 @pytest.mark.parametrize('hin,win,size,scale,ac', [(3, 7, (20, 33), None, True), (5, 8, None, 2.0, False),
                                                    (1, 4, (80, 320), None, True), (40, 160, None, 2.0, False)])
-def test_bilinear_resize_backward_as_matrix_products(hin, win, size, scale, ac):
-    """modules.bilinear_resize: ATen's forward, backward gX = A_h^T gY A_w (spp_unet_neck.py:60-70, 83-91)"""
+@pytest.mark.parametrize('nhwc', [False, True], ids=['nchw', 'nhwc'])
+def test_bilinear_resize_backward_as_matrix_products(hin, win, size, scale, ac, nhwc):
+    """modules.bilinear_resize: ATen's forward, backward gX = A_h^T gY A_w (spp_unet_neck.py:60-70, 83-91); an NHWC
+    gradient (the necks train channels-last) takes the products on its memory as it lies and comes back NHWC"""
     import importlib
     mods = importlib.import_module('depth-from-motion_amd.modules')
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(hin + win)
     x = torch.randn(2, 32, hin, win, generator=g).bfloat16()
-    xb = x.to(dev).requires_grad_(True)
+    xb = x.to(dev)
+    if nhwc:
+        xb = xb.contiguous(memory_format=torch.channels_last)
+    xb = xb.requires_grad_(True)
     y = mods.bilinear_resize(xb, size=size, scale_factor=scale, align_corners=ac)
     xr = x.float().requires_grad_(True)
     kw = dict(scale_factor=scale) if scale is not None else dict(size=size)
     yr = F.interpolate(xr, mode='bilinear', align_corners=ac, **kw)
     assert torch.equal(y.detach().cpu(), F.interpolate(x.to(dev), mode='bilinear', align_corners=ac, **kw).cpu())
     gy = torch.randn(yr.shape, generator=g).bfloat16()
-    y.backward(gy.to(dev))
+    gyd = gy.to(dev).contiguous(memory_format=torch.channels_last) if nhwc else gy.to(dev)
+    y.backward(gyd)
     yr.backward(gy.float())
     ref = xr.grad.numpy()
+    if nhwc and hin > 1 and win > 1:
+        assert xb.grad.is_contiguous(memory_format=torch.channels_last)
     np.testing.assert_allclose(xb.grad.float().cpu().numpy(), ref, rtol=2.0 ** -7, atol=2.0 ** -8 * float(np.abs(ref).max()))
 
 
@@ -540,3 +548,47 @@ def test_fp32_prediction_and_2d_convolutions_in_split_precision(cv, monkeypatch)
         if br is not None:
             np.testing.assert_allclose(m.bias.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-5,
                                        atol=1e-5 * float(br.grad.abs().max()))
+
+
+def test_weight_gradient_in_the_parameters_type_is_the_fp32_gradient_rounded_once(cv):
+    """dfm_conv3d_wgrad_to(DFM_BF16): the reduction kernel stores bf16 -- bit for bit the fp32 result converted"""
+    dev = torch.device('cuda:0')
+    for a, b, size, stride in ((32, 32, (5, 9, 12), 1), (64, 32, (6, 10, 12), 2), (64, 64, (4, 6, 9), 1)):
+        x = _cl(_x(2, b, size, seed=a + b), dev)
+        out_size = tuple((s + 2 - 3) // stride + 1 for s in size)
+        g = _cl(_x(2, a, out_size, seed=a * 3), dev)
+        w32 = cv.conv3d_weight_grad(x, g, stride, 1)
+        w16 = cv.conv3d_weight_grad(x, g, stride, 1, out_dtype=torch.bfloat16)
+        assert w32.dtype == torch.float32 and w16.dtype == torch.bfloat16 and w16.shape == w32.shape
+        assert float(w32.abs().max()) > 0 and torch.equal(w16, w32.to(torch.bfloat16))
+
+
+def test_channel_split_adds_the_slice_gradient_into_the_whole_tensors(cv):
+    """conv3d.channel_split: (x, x[:, :32]) for the cost volume's two consumers -- the gradient of x equals the one
+    autograd builds from two separate uses (bf16 additions of the same two values: bit-identical), and stays
+    channels-last"""
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 6, 10, 16, generator=gen).bfloat16().to(dev).contiguous(memory_format=torch.channels_last_3d)
+    w_all = torch.randn(1, 64, 6, 10, 16, generator=gen).bfloat16().to(dev).contiguous(memory_format=torch.channels_last_3d)
+    w_cur = torch.randn(1, 32, 6, 10, 16, generator=gen).bfloat16().to(dev).contiguous(memory_format=torch.channels_last_3d)
+    xa = x.clone().requires_grad_(True)
+    a_all, a_cur = cv.channel_split(xa, 0, 32)
+    assert a_all.shape == x.shape and a_cur.shape == (1, 32, 6, 10, 16) and a_cur.data_ptr() == xa.data_ptr()
+    ((a_all * w_all).sum() + (a_cur * w_cur).sum()).backward()
+    xb = x.clone().requires_grad_(True)
+    ((xb * w_all).sum() + (xb[:, :32] * w_cur).sum()).backward()
+    assert torch.equal(xa.grad, xb.grad)
+    assert xa.grad.is_contiguous(memory_format=torch.channels_last_3d)
+    # only one of the two outputs used
+    xc = x.clone().requires_grad_(True)
+    (cv.channel_split(xc, 0, 32)[1] * w_cur).sum().backward()
+    ref = torch.zeros_like(x)
+    ref[:, :32] = w_cur
+    assert torch.equal(xc.grad, ref)
+    xd = x.clone().requires_grad_(True)
+    (cv.channel_split(xd, 0, 32)[0] * w_all).sum().backward()
+    assert torch.equal(xd.grad, w_all)
+    with torch.no_grad():
+        p, q = cv.channel_split(x, 0, 32)
+        assert p.data_ptr() == x.data_ptr() and q.shape[1] == 32

@@ -17,7 +17,7 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
 print('   total kernel ms', round(tot/1e6, 3))
 print('    calls   total ms    avg us    min us    max us     pct  name')
-for r in sorted(rows,key=lambda r:-float(r['TotalDurationNs']))[:28]:
+for r in sorted(rows,key=lambda r:-float(r['TotalDurationNs']))[:int(__import__("os").environ.get("ROWS", "28"))]:
     print('   %6s %9.3f %9.1f %9.1f %9.1f  %5.1f  %s' % (r['Calls'], float(r['TotalDurationNs'])/1e6, float(r['AverageNs'])/1e3,
           float(r['MinNs'])/1e3, float(r['MaxNs'])/1e3, 100*float(r['TotalDurationNs'])/tot, r['Name'][:120]))
 PY

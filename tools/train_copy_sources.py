@@ -66,18 +66,26 @@ def main():
             t = getattr(ev, 'self_cuda_time_total', 0.0)
         if not t:
             continue
-        site = 'outside the repository (autograd engine / torch)'
+        site = None
         for fr in ev.stack or []:
             if ROOT in fr or 'depth-from-motion_amd' in fr:
                 site = fr.replace(ROOT + '/', '')
                 break
+        if site is None:
+            # no Python frame (this build's profiler hands the backward thread's operators over without one): the chain
+            # of enclosing operators instead -- the autograd node or the ATen operator the copy was issued for
+            chain, p_ = [], ev.cpu_parent
+            while p_ is not None and len(chain) < 4:
+                chain.append(p_.name.replace('autograd::engine::evaluate_function: ', ''))
+                p_ = p_.cpu_parent
+            site = ' < '.join(chain) if chain else 'top level (autograd engine: gradient accumulation / layout contract)'
         key = (ev.name, site, str(ev.input_shapes)[:90] if ev.input_shapes else '')
         by_site[key][0] += t
         by_site[key][1] += 1
         total += t
     print(f'# one bf16 training step of DfMStereoPath: device time of copy-like ATen ops by call site, total {total / 1e3:.2f} ms')
-    for (name, site, shp), (t, n) in sorted(by_site.items(), key=lambda kv: -kv[1][0])[:40]:
-        print(f'{t / 1e3:8.3f} ms {n:4d}x  {name:14s} {shp:90s} {site[:60]}')
+    for (name, site, shp), (t, n) in sorted(by_site.items(), key=lambda kv: -kv[1][0])[:60]:
+        print(f'{t / 1e3:8.3f} ms {n:4d}x  {name:14s} {shp:70s} {site[:110]}')
 
 
 if __name__ == '__main__':
