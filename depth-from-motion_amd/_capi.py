@@ -70,9 +70,11 @@ EXPORTS = (
     'dfm_conv3d_k3_c32_stats_splits',
     'dfm_conv3d_k3_c32_fwd',
     'dfm_conv3d_k3_c32_fwd_strided',
+    'dfm_conv3d_k3_c32_fwd_slices',
     'dfm_conv3d_k3_c32_to1_fwd',
     'dfm_group_norm_coefficients',
     'dfm_conv3d_to1_norm_fwd',
+    'dfm_bilinear_resize_bwd_nhwc',
     'dfm_depth_pool_fwd',
     'dfm_depth_pool_bwd',
     'dfm_cost_gate_mfma_weight_bytes',
@@ -357,6 +359,8 @@ def lib():
     h.dfm_conv3d_k3_c32_pack_weights.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     h.dfm_conv3d_k3_c32_fwd.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_fwd.argtypes = [i32, i32, i32, i32, vp, vp, fp, vp, i32, i32, i32, fp, vp]
+    h.dfm_conv3d_k3_c32_fwd_slices.restype = ctypes.c_int
+    h.dfm_conv3d_k3_c32_fwd_slices.argtypes = [i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, i32, vp]
     h.dfm_conv3d_k3_c32_fwd_strided.restype = ctypes.c_int
     h.dfm_conv3d_k3_c32_fwd_strided.argtypes = [i32, i32, i32, i32, vp, i32, vp, fp, vp, i32, i32, i32, fp, vp]
     h.dfm_conv3d_k3_c32_to1_fwd.restype = ctypes.c_int
@@ -371,6 +375,8 @@ def lib():
     h.dfm_cost_gate_mfma_pack_weights.argtypes = [vp, i32, i32, vp, vp]
     h.dfm_cost_gate_mfma_fwd.restype = ctypes.c_int
     h.dfm_cost_gate_mfma_fwd.argtypes = [i32, i32, ctypes.c_int64, vp, vp, vp, vp, vp]
+    h.dfm_bilinear_resize_bwd_nhwc.restype = ctypes.c_int
+    h.dfm_bilinear_resize_bwd_nhwc.argtypes = [i32, i32, i32, i32, i32, i32, i32, vp, vp, fp, i32, vp, fp, i32, vp, vp]
     for fn in (h.dfm_depth_pool_fwd, h.dfm_depth_pool_bwd):
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.c_int64, i32, ctypes.c_int64, i32, vp, vp, vp]

@@ -167,10 +167,24 @@ class _MfmaConvFn(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             # backward-data = the same MFMA kernel on the gradient with transposed, mirrored weights
-            halves = [conv3d_k3_c32(gy, pack_conv3d_weights(weight, 32 * i, transposed=True))
-                      for i in range(weight.shape[1] // 32)]
-            gx = halves[0] if len(halves) == 1 else \
-                torch.cat(halves, dim=1).contiguous(memory_format=torch.channels_last_3d)
+            k = weight.shape[1] // 32
+            if k == 1:
+                gx = conv3d_k3_c32(gy, pack_conv3d_weights(weight, 0, transposed=True))
+            elif os.environ.get('DFM_C32_CAT') == '1':   # (A/B runs: the round-5 form)
+                halves = [conv3d_k3_c32(gy, pack_conv3d_weights(weight, 32 * i, transposed=True)) for i in range(k)]
+                gx = torch.cat(halves, dim=1).contiguous(memory_format=torch.channels_last_3d)
+            else:
+                # the k halves written straight into the (N, D, H, W, 32 k) gradient (dfm_conv3d_k3_c32_fwd_slices)
+                N, _, D, H, W = gy.shape
+                buf = torch.empty((N, D, H, W, 32 * k), dtype=torch.bfloat16, device=gy.device)
+                lib = _capi.lib()
+                with torch.cuda.device(gy.device):
+                    for i in range(k):
+                        pk = pack_conv3d_weights(weight, 32 * i, transposed=True)
+                        _capi.check(lib.dfm_conv3d_k3_c32_fwd_slices(
+                            N, D, H, W, _ptr(gy), 32, _ptr(pk), buf.data_ptr() + 64 * i, 32 * k, 0, 0,
+                            _stream_ptr(gy.device)))
+                gx = buf.permute(0, 4, 1, 2, 3)
         gw = None
         if ctx.needs_input_grad[1]:  # backward-weight: chunked implicit-im2col GEMM (see above)
             gw = conv3d_weight_grad(x, gy, 1, 1, out_dtype=weight.dtype)

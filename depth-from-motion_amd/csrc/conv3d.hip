@@ -63,6 +63,7 @@ struct ConvGeom {
     int32_t N, D, H, W;
     int32_t tiles_w, tiles_h, dchunk, relu;
     int32_t xcs;  // elements between consecutive input pixels (32, or more: a channel slice of a wider tensor)
+    int32_t ycs;  // ... and between consecutive pixels of the bf16 output (32, or more: a slice of a wider tensor)
 };
 
 // weights (C_out, C_in, 3, 3, 3) -> MFMA A-operand fragments [tap*2 + ks][lane][8]:
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_c32_kernel(
                 acc_rows_to_16B(pk4, q16);
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr)
-                    *(dfm_u32x4 *)((bf16_t *)yout + vox * CV_C + 16 * pr + 8 * half) = q16[pr];
+                    *(dfm_u32x4 *)((bf16_t *)yout + vox * g.ycs + 16 * pr + 8 * half) = q16[pr];
             }
             if constexpr (STATS && !OUT_F32) scnt += 1.0f;
         }
@@ -425,7 +426,7 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_to1_fwd(int32_t n, int32_t d, int32_t h
     if ((long long)h * w * x_channel_stride * 2 >= (1ll << 31)) return set_error(DFM_ERR_UNSUPPORTED, "depth plane too large");
     if (n > 65535) return set_error(DFM_ERR_UNSUPPORTED, "batch > 65535");
     ConvGeom g;
-    g.N = n; g.D = d; g.H = h; g.W = w; g.xcs = x_channel_stride;
+    g.N = n; g.D = d; g.H = h; g.W = w; g.xcs = x_channel_stride; g.ycs = 32;
     g.tiles_w = (w + CV_TW - 1) / CV_TW;
     g.tiles_h = (h + CV_TH - 1) / CV_TH;
     g.relu = relu ? 1 : 0;
@@ -448,11 +449,40 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_to1_fwd(int32_t n, int32_t d, int32_t h
     return DFM_OK;
 }
 
+static int conv_c32_impl(int32_t n, int32_t d, int32_t h, int32_t w, const void *x, int32_t x_channel_stride,
+                         const void *packed_weights, const float *acc_in, void *out, int32_t out_channel_stride,
+                         int32_t out_f32, int32_t relu, int32_t depth_chunk, float *stats, void *stream);
+
 extern "C" DFM_API int dfm_conv3d_k3_c32_fwd_strided(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
                                                      int32_t x_channel_stride, const void *packed_weights,
                                                      const float *acc_in, void *out, int32_t out_f32,
                                                      int32_t relu, int32_t depth_chunk, float *stats,
                                                      void *stream)
+{
+    return conv_c32_impl(n, d, h, w, x, x_channel_stride, packed_weights, acc_in, out, 32, out_f32, relu, depth_chunk,
+                         stats, stream);
+}
+
+// ... whose bf16 OUTPUT is a 32-channel slice of a wider channels-last tensor too: out points at the slice's first
+// channel of the first pixel, out_channel_stride (>= 32, a multiple of 8) elements lie between pixels.  The
+// backward-data of a 32 k -> 32 convolution writes its k halves straight into the (N, D, H, W, 32 k) gradient
+// (round 6: torch.cat of the halves and its layout conversion were two copies of a 236 MB tensor per step).
+extern "C" DFM_API int dfm_conv3d_k3_c32_fwd_slices(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
+                                                    int32_t x_channel_stride, const void *packed_weights,
+                                                    void *out, int32_t out_channel_stride, int32_t relu,
+                                                    int32_t depth_chunk, void *stream)
+{
+    if (out_channel_stride < 32 || out_channel_stride % 8 || ((uintptr_t)out & 15))
+        return set_error(DFM_ERR_INVALID_ARG, "out_channel_stride must be >= 32 and a multiple of 8, out 16-byte aligned");
+    if ((long long)n * d * h * w * out_channel_stride >= (1ll << 40))
+        return set_error(DFM_ERR_UNSUPPORTED, "output too large");
+    return conv_c32_impl(n, d, h, w, x, x_channel_stride, packed_weights, nullptr, out, out_channel_stride, 0, relu,
+                         depth_chunk, nullptr, stream);
+}
+
+static int conv_c32_impl(int32_t n, int32_t d, int32_t h, int32_t w, const void *x, int32_t x_channel_stride,
+                         const void *packed_weights, const float *acc_in, void *out, int32_t out_channel_stride,
+                         int32_t out_f32, int32_t relu, int32_t depth_chunk, float *stats, void *stream)
 {
     if (x_channel_stride < 32 || x_channel_stride % 8)
         return set_error(DFM_ERR_INVALID_ARG, "x_channel_stride must be >= 32 and a multiple of 8");
@@ -462,7 +492,7 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_fwd_strided(int32_t n, int32_t d, int32
     if ((long long)h * w * x_channel_stride * 2 >= (1ll << 31)) return set_error(DFM_ERR_UNSUPPORTED, "depth plane too large");
     if (n > 65535) return set_error(DFM_ERR_UNSUPPORTED, "batch > 65535");
     ConvGeom g;
-    g.N = n; g.D = d; g.H = h; g.W = w; g.xcs = x_channel_stride;
+    g.N = n; g.D = d; g.H = h; g.W = w; g.xcs = x_channel_stride; g.ycs = out_channel_stride;
     g.tiles_w = (w + CV_TW - 1) / CV_TW;
     g.tiles_h = (h + CV_TH - 1) / CV_TH;
     g.relu = relu ? 1 : 0;

@@ -943,6 +943,7 @@ def _conv_norm_2d(seq, x, residual=None, relu=False):
 
 
 _INTERP_MATRICES = {}
+_BILINEAR_GATHER = os.environ.get('DFM_BILINEAR_MATMUL') != '1'   # (A/B runs: the matrix-product backward)
 
 
 def _interp_matrix(n_in, n_out, align_corners, scale, device):
@@ -958,6 +959,32 @@ def _interp_matrix(n_in, n_out, align_corners, scale, device):
             _INTERP_MATRICES.clear()
         _INTERP_MATRICES[key] = m
     return m
+
+
+_INTERP_TABLES = {}
+
+
+def _interp_table(n_in, n_out, align_corners, scale, device):
+    """the non-zeros of the transposed interpolation matrix, padded: (idx (n_in, K) int32, w (n_in, K) fp32, K) --
+    for input index i the outputs that interpolate from it and their weights (dfm_bilinear_resize_bwd_nhwc)"""
+    key = (n_in, n_out, bool(align_corners), scale, str(device))
+    t = _INTERP_TABLES.get(key)
+    if t is None:
+        m = _interp_matrix(n_in, n_out, align_corners, scale, device).t().cpu().numpy()   # (n_in, n_out)
+        nz = m != 0
+        K = max(1, int(nz.sum(1).max()))
+        idx = np.zeros((n_in, K), np.int32)
+        w = np.zeros((n_in, K), np.float32)
+        for i in range(n_in):
+            j = np.nonzero(nz[i])[0]
+            idx[i, :len(j)] = j
+            w[i, :len(j)] = m[i, j]
+        t = (torch.from_numpy(idx).to(device), torch.from_numpy(w).to(device), K)
+        if len(_INTERP_TABLES) > 256:
+            _INTERP_TABLES.clear()
+        _INTERP_TABLES[key] = t
+        note_derived_build()
+    return t
 
 
 class _BilinearResizeFn(torch.autograd.Function):
@@ -979,6 +1006,21 @@ class _BilinearResizeFn(torch.autograd.Function):
         B, C, h_out, w_out = gy.shape
         a_w = _interp_matrix(w_in, w_out, ac, scale, gy.device)            # (w_out, w_in)
         a_h = _interp_matrix(h_in, h_out, ac, scale, gy.device)            # (h_out, h_in)
+        vec = 16 // gy.element_size()
+        if (gy.stride(1) == 1 and C % vec == 0 and gy.is_contiguous(memory_format=torch.channels_last) and
+                gy.dtype in (torch.float32, torch.bfloat16) and _BILINEAR_GATHER):
+            # NHWC: the gather kernel (csrc/bilinear_bwd.hip) -- a lane per input pixel and 16-byte channel vector walks
+            # the few output pixels that interpolate from it (an up-sampling by 2 has at most 4 x 4)
+            ri, rw, kh = _interp_table(h_in, h_out, ac, scale, gy.device)
+            ci, cw, kw = _interp_table(w_in, w_out, ac, scale, gy.device)
+            if kh * kw <= 64 and gy.data_ptr() % 16 == 0:
+                gx = torch.empty((B, h_in, w_in, C), dtype=gy.dtype, device=gy.device)
+                with torch.cuda.device(gy.device):
+                    _capi.check(_capi.lib().dfm_bilinear_resize_bwd_nhwc(
+                        B, C, h_in, w_in, h_out, w_out, _capi.DFM_BF16 if gy.dtype == torch.bfloat16 else _capi.DFM_F32,
+                        gy.data_ptr(), ri.data_ptr(), rw.data_ptr(), kh, ci.data_ptr(), cw.data_ptr(), kw,
+                        gx.data_ptr(), torch.cuda.current_stream(gy.device).cuda_stream))
+                return gx.permute(0, 3, 1, 2), None, None, None
         if gy.stride(1) == 1 and C > 1 and gy.is_contiguous(memory_format=torch.channels_last):
             # an NHWC gradient (the 2-D necks train channels-last): the same two products on the memory as it lies --
             # rows of C channels ride along as the matrices' columns, gX[b, hi, wi, :] = sum A_h[ho, hi] A_w[wo, wi]

@@ -705,6 +705,14 @@ DFM_API int dfm_conv3d_k3_c32_fwd_strided(int32_t n, int32_t d, int32_t h, int32
                                           const float *acc_in, void *out, int32_t out_f32,
                                           int32_t relu, int32_t depth_chunk, float *stats,
                                           void *stream);
+/* ... whose bf16 output is a 32-channel slice of a wider channels-last tensor too (round 6): `out` points at the
+ * slice's first channel of the first pixel, out_channel_stride (>= 32, a multiple of 8) elements between pixels; no
+ * fp32 partial, no statistics.  Backward-data of a 32 k -> 32 convolution (dfm_backbone.py:175: dres0 reads the 2 C
+ * channels of the cost volume) writes its k halves straight into the (N, D, H, W, 32 k) gradient. */
+DFM_API int dfm_conv3d_k3_c32_fwd_slices(int32_t n, int32_t d, int32_t h, int32_t w, const void *x,
+                                         int32_t x_channel_stride, const void *packed_weights, void *out,
+                                         int32_t out_channel_stride, int32_t relu, int32_t depth_chunk,
+                                         void *stream);
 /* The 32 -> 1 prediction convolutions (dfm_backbone.py:120-127, Conv3d(32, 1, 3, 1, 1)): the same
  * kernel with packed weights whose output rows 1..31 are zero (pack a (32, 32, 3, 3, 3) tensor with
  * the (1, 32, 3, 3, 3) weight in row 0); only channel 0 is stored: out = (n, d, h, w) bf16. */
@@ -966,6 +974,18 @@ DFM_API int dfm_group_norm_bwd_channels_last_xmask(int32_t n, int32_t c, int64_t
                                                    const float *beta, void *grad_x, float *grad_gamma,
                                                    float *grad_beta, void *workspace, size_t workspace_bytes,
                                                    void *stream);
+
+/* Backward of F.interpolate(mode='bilinear') on an NHWC map as a gather (round 6; the up-sampling steps of the 2-D
+ * necks either side of the path: mmdet3d/models/necks/spp_unet_neck.py:60-70, 83-91, training only):
+ *   gx[b, hi, wi, :] = sum_a sum_c row_w[hi][a] * col_w[wi][c] * gy[b, row_idx[hi][a], col_idx[wi][c], :]
+ * gy : (n, h_out, w_out, c), gx : (n, h_in, w_in, c), `dtype`, 16-byte aligned, c whole 16-byte vectors; gx OVERWRITTEN
+ * row_idx / row_w : [h_in][kh] the output rows interpolating from input row hi and their weights (padding: weight 0);
+ * col_idx / col_w : [w_in][kw] likewise -- the non-zeros of the transposed 1-D interpolation matrices (the Python
+ * host takes them from ATen's own forward, so the gradient is the adjoint of exactly what F.interpolate applied). */
+DFM_API int dfm_bilinear_resize_bwd_nhwc(int32_t n, int32_t c, int32_t h_in, int32_t w_in, int32_t h_out,
+                                         int32_t w_out, int32_t dtype, const void *gy, const int32_t *row_idx,
+                                         const float *row_w, int32_t kh, const int32_t *col_idx, const float *col_w,
+                                         int32_t kw, void *gx, void *stream);
 
 /* AvgPool3d((k, 1, 1)) of FrustumToVoxel (necks/feature_transformation.py:167) on a channels-last volume, forward
  * and backward, one pass each (csrc/depth_pool.hip): the tensor as (outer, k, inner) contiguous -- for an
