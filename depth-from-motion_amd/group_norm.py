@@ -193,6 +193,49 @@ class HipGroupNorm(nn.GroupNorm):
         return torch.relu_(y) if relu else y
 
 
+def batch_norm_train_channels_last(bn, x, relu=False, residual=None):
+    """Training-mode BatchNorm (nn.BatchNorm2d / 3d / SyncBatchNorm in a single-process job) of a channels-last GPU
+    tensor through the fused GroupNorm kernels, or None when it does not apply.  The batch statistics of a
+    channels-last (N, C, *spatial) tensor are the per-channel GroupNorm statistics of the same memory viewed as ONE
+    sample (1, C, N * s0, ...): normalisation (+ residual) (+ ReLU) is one statistics pass and one apply pass, the
+    backward the channels-last GroupNorm backward; running statistics are updated as torch does (unbiased variance,
+    momentum / cumulative average).  y = relu?(bn(x) + residual)."""
+    vec = 16 // x.element_size() if x.dtype in _DTYPES else 0
+    c = x.shape[1]
+    fmt = torch.channels_last_3d if x.dim() == 5 else torch.channels_last
+    if not (bn.training and x.is_cuda and vec and x.dim() in (4, 5) and bn.affine and bn.track_running_stats and
+            c % vec == 0 and c <= 256 and ((c // vec) & (c // vec - 1)) == 0 and
+            not x.is_contiguous() and x.is_contiguous(memory_format=fmt)):
+        return None
+    if isinstance(bn, nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1:
+        return None   # statistics across ranks: torch's implementation
+
+    def one_sample(t):   # (N, C, s0, ...) channels-last -> (1, C, N * s0, ...) channels-last, the same memory
+        n = t.shape[0]
+        perm = (0,) + tuple(range(2, t.dim())) + (1,)
+        back = (0, t.dim() - 1) + tuple(range(1, t.dim() - 1))
+        v = t.permute(*perm)
+        return v.reshape(1, n * v.shape[1], *v.shape[2:]).permute(*back)
+
+    res = None
+    if residual is not None:
+        res = one_sample(residual if residual.is_contiguous(memory_format=fmt) else residual.contiguous(memory_format=fmt))
+    stats = []
+    y = _GroupNormFn.apply(one_sample(x), bn.weight, bn.bias, c, float(bn.eps), bool(relu), None, res, stats)
+    mean, rstd = stats[0]
+    with torch.no_grad():
+        m = x.numel() // c
+        var = (1.0 / (rstd * rstd) - bn.eps).clamp_min_(0.0) * (m / max(m - 1, 1))  # unbiased
+        bn.num_batches_tracked += 1
+        f = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        bn.running_mean.mul_(1 - f).add_(mean.to(bn.running_mean.dtype), alpha=f)
+        bn.running_var.mul_(1 - f).add_(var.to(bn.running_var.dtype), alpha=f)
+    perm = (0,) + tuple(range(2, x.dim())) + (1,)
+    back = (0, x.dim() - 1) + tuple(range(1, x.dim() - 1))
+    return y.permute(*perm).reshape(x.shape[0], *x.shape[2:], c).permute(*back)
+
+
 class HipBatchNorm3d(nn.BatchNorm3d):
     """nn.BatchNorm3d (same parameters, buffers and ``state_dict`` keys) whose TRAINING forward /
     backward on channels-last GPU tensors run in the fused HIP kernels: the batch statistics of a
@@ -221,21 +264,4 @@ class HipBatchNorm3d(nn.BatchNorm3d):
             if residual is not None:
                 y = y + residual
             return torch.relu_(y) if relu else y
-        N, C, D, H, W = x.shape
-        res = None
-        if residual is not None:
-            res = residual if residual.is_contiguous(memory_format=torch.channels_last_3d) else \
-                residual.contiguous(memory_format=torch.channels_last_3d)
-            res = self._as_one_sample(res)
-        stats = []
-        y = _GroupNormFn.apply(self._as_one_sample(x), self.weight, self.bias, C, float(self.eps), bool(relu), None,
-                               res, stats)
-        mean, rstd = stats[0]
-        with torch.no_grad():
-            m = N * D * H * W
-            var = (1.0 / (rstd * rstd) - self.eps).clamp_min_(0.0) * (m / max(m - 1, 1))  # unbiased
-            self.num_batches_tracked += 1
-            f = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
-            self.running_mean.mul_(1 - f).add_(mean.to(self.running_mean.dtype), alpha=f)
-            self.running_var.mul_(1 - f).add_(var.to(self.running_var.dtype), alpha=f)
-        return y.permute(0, 2, 3, 4, 1).reshape(N, D, H, W, C).permute(0, 4, 1, 2, 3)
+        return batch_norm_train_channels_last(self, x, relu, residual)

@@ -35,7 +35,7 @@ from .conv3d import (DerivedStateMixin, conv3d_to1_norm, long_axis_gram, note_de
 from .depth_head import depth_distribution_loss, depth_head_forward, depth_head_statistics
 from .frustum_to_voxel import frustum_to_voxel_sample
 from .geometry import stack_meta
-from .group_norm import HipBatchNorm3d, HipGroupNorm, _f32_params
+from .group_norm import HipBatchNorm3d, HipGroupNorm, _f32_params, batch_norm_train_channels_last
 from . import _capi
 from .plane_sweep import _DTYPES, _Workspace, _ptr, _stream_ptr, build_dfm_cost
 from .sweep_conv import pack_sweep_conv_weights, sweep_conv_supported, sweep_dres0
@@ -936,12 +936,21 @@ def _conv_norm_2d(seq, x, residual=None, relu=False):
             note_derived_build()
         scale, shift = seq.__dict__['_fold']
         return conv.forward_fused(x, scale, shift, residual=residual, relu=relu)
-    y = norm(conv(x))
+    y = conv(x)
+    if isinstance(norm, nn.modules.batchnorm._BatchNorm) and _BN2D_FUSED:
+        # training: the batch statistics, the normalisation, the residual and the ReLU in the fused GroupNorm kernels on
+        # the NHWC map as it lies (round 6; MIOpen's training BatchNorm + separate add / ReLU passes were 0.9 ms of
+        # the DfMStereoPath step) -- None when it does not apply (eval mode, NCHW, SyncBatchNorm across ranks)
+        out = batch_norm_train_channels_last(norm, y, relu=relu, residual=residual)
+        if out is not None:
+            return out
+    y = norm(y)
     if residual is not None:
         y = y + residual
     return F.relu(y) if relu else y
 
 
+_BN2D_FUSED = os.environ.get('DFM_BN2D_TORCH') != '1'   # (A/B runs: torch's training BatchNorm in the 2-D necks)
 _INTERP_MATRICES = {}
 _BILINEAR_GATHER = os.environ.get('DFM_BILINEAR_MATMUL') != '1'   # (A/B runs: the matrix-product backward)
 

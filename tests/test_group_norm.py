@@ -285,3 +285,59 @@ def test_relu_mask_recomputed_from_x_is_the_mask_of_the_kept_output(pkg, monkeyp
     assert 0.2 < frac_on < 0.8
     for a_, b_ in zip(res[True], res[False]):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('relu,with_res', [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('cls', [torch.nn.BatchNorm2d, torch.nn.SyncBatchNorm])
+def test_training_batch_norm_of_an_nhwc_map_through_the_fused_kernels(pkg, relu, with_res, dtype, cls):
+    """group_norm.batch_norm_train_channels_last on a 4-D channels-last batch (the BatchNorm blocks of the 2-D necks'
+    up-convolutions, mmdet3d/models/necks/spp_unet_neck.py:83-91 -- nn.SyncBatchNorm in a single-process job): output,
+    running statistics and every gradient against torch's own module on the same values"""
+    gn = importlib.import_module('depth-from-motion_amd.group_norm')
+    torch.manual_seed(6)
+    N, C, sp = 2, 64, (18, 40)
+    ref = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.2 * torch.randn(C))
+        ref.bias.copy_(0.3 * torch.randn(C))
+    m = cls(C).cuda().train()
+    m.load_state_dict(ref.state_dict())
+    x = (torch.randn(N, C, *sp, device='cuda') * 2 + 0.5).to(dtype)
+    res = torch.randn(N, C, *sp, device='cuda').to(dtype)
+    gy = torch.randn(N, C, *sp, device='cuda').to(dtype)
+    cl = torch.channels_last
+    xr, rr = x.float().clone().requires_grad_(True), res.float().clone().requires_grad_(True)
+    yr = ref(xr)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(gy.float())
+    xg = x.contiguous(memory_format=cl).requires_grad_(True)
+    rg = res.contiguous(memory_format=cl).requires_grad_(True)
+    y = gn.batch_norm_train_channels_last(m, xg, relu=relu, residual=rg if with_res else None)
+    assert y is not None and y.shape == x.shape and y.is_contiguous(memory_format=cl) and y.dtype == dtype
+    y.backward(gy.contiguous(memory_format=cl))
+    tol = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+
+    def close(a, b):
+        if dtype == torch.float32:
+            return torch.testing.assert_close(a, b, **tol)
+        bad = (a - b).abs() > tol['atol'] + tol['rtol'] * b.abs()   # (bf16: a ReLU flip at a rounded zero)
+        assert float(bad.float().mean()) < 0.01, float(bad.float().mean())
+    close(y.float(), yr)
+    close(xg.grad.float(), xr.grad)
+    if with_res:
+        close(rg.grad.float(), rr.grad)
+    ptol = 6e-2 if dtype == torch.bfloat16 else 1e-3
+    torch.testing.assert_close(m.weight.grad.float(), ref.weight.grad, rtol=ptol, atol=ptol * float(ref.weight.grad.abs().max()))
+    torch.testing.assert_close(m.bias.grad.float(), ref.bias.grad, rtol=ptol, atol=ptol * float(ref.bias.grad.abs().max()))
+    torch.testing.assert_close(m.running_mean.float(), ref.running_mean, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(m.running_var.float(), ref.running_var, rtol=1e-2, atol=1e-2)
+    assert int(m.num_batches_tracked) == 1
+    # what it does not take: eval mode, an NCHW tensor
+    assert gn.batch_norm_train_channels_last(m, x.contiguous(), relu=relu) is None
+    m.eval()
+    assert gn.batch_norm_train_channels_last(m, xg.detach(), relu=relu) is None
