@@ -1007,6 +1007,25 @@ __device__ __forceinline__ void gather_row32(const T *__restrict__ gp, float (&v
     }
 }
 
+// 8 consecutive channels of one voxel's gradient row, as fp32 (one 16-byte load in bf16, two in fp32)
+template <typename T>
+__device__ __forceinline__ void gather_row8(const T *__restrict__ gp, float (&v)[8])
+{
+    if constexpr (sizeof(T) == 4) {
+        const uint4 u0 = *(const uint4 *)gp, u1 = *(const uint4 *)(gp + 4);
+        v[0] = __uint_as_float(u0.x); v[1] = __uint_as_float(u0.y); v[2] = __uint_as_float(u0.z); v[3] = __uint_as_float(u0.w);
+        v[4] = __uint_as_float(u1.x); v[5] = __uint_as_float(u1.y); v[6] = __uint_as_float(u1.z); v[7] = __uint_as_float(u1.w);
+    } else {
+        const uint4 u = *(const uint4 *)gp;
+        const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = __uint_as_float(w4[k] << 16);
+            v[2 * k + 1] = __uint_as_float(w4[k] & 0xffff0000u);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Backward as a GATHER (round 5).  The pixel-major scatter above runs at the part's fp32 atomic rate: 1.75 M
 // voxels x 8 corners x 64 channels = 0.9 G atomics = 2.9 ms per sample at config K, the third-largest kernel of
@@ -1028,6 +1047,8 @@ struct F2vGrid {
     float x0, dx, y0, dy, z0, dz;  // coords[(iz * Ny + iy) * Nx + ix] == (x0 + ix dx, y0 + iy dy, z0 + iz dz)
 };
 
+constexpr uint32_t F2G_NONE = 0xffffffffu;  // cell code of a voxel the gather skips
+
 // pre-pass, lane = voxel: the factors the scatter's first phase computes.  sfac = the stereo branch's factor
 // (pred_disp when stereo_atten, else 1) or -1 for a voxel that contributes nothing; mfac likewise for the
 // semantic branch (pred_disp * valid when sem_atten, else valid2d).  Same arithmetic as f2v_bwd_pm_kernel.
@@ -1035,7 +1056,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void f2v_bwd_prep_kernel(F2vGeom g, const T *__restrict__ soft, FusedHead fh,
                                                            const float *__restrict__ coords,
                                                            const float *__restrict__ cam2img,
-                                                           float *__restrict__ sfac, float *__restrict__ mfac)
+                                                           float *__restrict__ sfac, float *__restrict__ mfac,
+                                                           uint32_t *__restrict__ cell, float4 *__restrict__ pos)
 {
     const long long N = (long long)g.Nz * g.Ny * g.Nx;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1062,15 +1084,29 @@ __global__ __launch_bounds__(256) void f2v_bwd_prep_kernel(F2vGeom g, const T *_
             disp = tri_sample<T>(ts, soft + (size_t)b * g.Ds * g.Hs * g.Ws);
         }
     }
-    sfac[(size_t)b * N + i] = valid ? (g.st_att ? disp : 1.0f) : -1.0f;
-    mfac[(size_t)b * N + i] = (g.Cs > 0 && (g.sem_att ? valid : valid2d)) ? (g.sem_att ? disp : 1.0f) : -1.0f;
+    const float sf = valid ? (g.st_att ? disp : 1.0f) : -1.0f;
+    const float mf = (g.Cs > 0 && (g.sem_att ? valid : valid2d)) ? (g.sem_att ? disp : 1.0f) : -1.0f;
+    if (sfac) sfac[(size_t)b * N + i] = sf;
+    mfac[(size_t)b * N + i] = mf;
+    if (cell) {
+        // round 6: the voxel's lower corner cell, packed, and its position in the cost volume -- make_tri's arithmetic,
+        // done ONCE per voxel here instead of once per (candidate pixel, plane) in the gather.  A voxel that
+        // contributes nothing (or whose position is not finite, or lies outside the packable range: it then has no
+        // cell inside the volume either) is F2G_NONE.
+        const float px = ((gx + 1.0f) / 2.0f) * (float)(g.W - 1);
+        const float py = ((gy + 1.0f) / 2.0f) * (float)(g.H - 1);
+        const float pz = ((gz + 1.0f) / 2.0f) * (float)(g.D - 1);
+        uint32_t c = F2G_NONE;
+        if ((sf >= 0.0f || mf >= 0.0f) && fabsf(px) <= 1.0e9f && fabsf(py) <= 1.0e9f && fabsf(pz) <= 1.0e9f) {
+            const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+            if (x0 >= -1.0f && x0 <= 2045.0f && y0 >= -1.0f && y0 <= 1021.0f && z0 >= -1.0f && z0 <= 1021.0f)
+                c = (uint32_t)((int)x0 + 1) | ((uint32_t)((int)y0 + 1) << 11) | ((uint32_t)((int)z0 + 1) << 21);
+        }
+        cell[(size_t)b * N + i] = c;
+        pos[(size_t)b * N + i] = make_float4(px, py, pz, sf);
+    }
 }
 
-// Depth planes per lane.  Round 5 ran 9 (72 planes -> 8 chunks): 800 workgroups of a kernel that holds 256 + 16
-// registers a lane -- ONE workgroup per CU, 3.1 rounds over the chip, each wave waiting out its own chain of
-// dependent loads: 1.80 ms.  Three planes a chunk (2400 workgroups; the semantic map takes 3x the atomics, still
-// 0.3 M wave-level instructions): 0.97 ms; 1, 2 planes measure the same, 4 is 9 % slower, and capping the registers
-// for 3 or 4 workgroups per CU spills (3.3 / 5.7 ms) -- profiles/r06_c28_f2v_bwd_depth_chunk.txt
 #ifndef DFM_F2G_DCH
 #define DFM_F2G_DCH 3
 #endif
@@ -1088,19 +1124,25 @@ __global__ __launch_bounds__(256, DFM_F2G_WGS) void f2v_bwd_gather_kernel(F2vGeo
                                                              const T *__restrict__ gout, size_t gvs, size_t gcs,
                                                              const float *__restrict__ coords,
                                                              const float *__restrict__ cam2img,
-                                                             const float *__restrict__ sfac,
+                                                             const uint32_t *__restrict__ cell,
+                                                             const float4 *__restrict__ pos,
                                                              const float *__restrict__ mfac,
                                                              void *__restrict__ gstv, float *__restrict__ gsem)
 {
     // block id = ((ytile * xtiles + xtile) * dchunks + chunk); blockIdx.y = sample
-    const int xtiles = (g.W + 63) / 64;
+    // (round 6) FOUR lanes per pixel, 8 channels each: a wave covers 16 pixels of a row.  A hit's gradient row is then
+    // one 16-byte load per lane whose four lanes read one contiguous 64-byte row (a wave-level load touches 16 rows,
+    // not 4 x 64), the accumulators are 8 + 8 registers instead of 32 + 32, and the candidate test the four lanes
+    // repeat is a 4-byte load of the same word.
+    const int xtiles = (g.W + 15) / 16;
     int t = blockIdx.x;
     const int chunk = t % dchunks;
     t /= dchunks;
     const int xt = t % xtiles, yt = t / xtiles;
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int h = yt * 4 + wave, w = xt * 64 + lane;
+    const int h = yt * 4 + wave, w = xt * 16 + (lane >> 2);
+    const int cq = (lane & 3) * 8;  // this lane's channels: cq .. cq + 7
     const bool inside = h < g.H && w < g.W;
     const long long N = (long long)g.Nz * g.Ny * g.Nx;
     const float *P = cam2img + 16 * b;
@@ -1108,38 +1150,47 @@ __global__ __launch_bounds__(256, DFM_F2G_WGS) void f2v_bwd_gather_kernel(F2vGeo
     // image position of this pixel's centre and of its neighbours one pixel further (the box's extent)
     const float su = (g.pad_w - 1.0f) / (float)(g.W - 1), sv = (g.pad_h - 1.0f) / (float)(g.H - 1);
     const float ut = (float)w * su, vt = (float)h * sv;
-    // (y, z) of the voxel position that projects onto image point (uu, vv) in the slab x = xs
-    auto solve = [&](float uu, float vv, float xs, float &ys, float &zs) {
-        const float a11 = uu * P[8] - P[0], a12 = uu * P[9] - P[1], r1 = -((P[2] - uu * P[10]) * xs + (P[3] - uu * P[11]));
-        const float a21 = vv * P[8] - P[4], a22 = vv * P[9] - P[5], r2 = -((P[6] - vv * P[10]) * xs + (P[7] - vv * P[11]));
-        const float det = a11 * a22 - a12 * a21, inv = 1.0f / det;
-        ys = (r1 * a22 - a12 * r2) * inv;
-        zs = (a11 * r2 - r1 * a21) * inv;
-    };
-    const float pd_per_x = (float)(g.D - 1) / g.depth_span;  // plane index per metre of depth
+    // (y, z) of the voxel position that projects onto image point (uu, vv) in the slab x = xs: a 2 x 2 system whose
+    // right-hand side is affine in xs -- and xs is affine in the slab index, so the voxel-index position of the
+    // solution is iy = Ay + By * ix, iz = Az + Bz * ix: four coefficients per image point, worked out ONCE per lane
+    // (round 5 solved the three systems per slab, with a division each: 200 of the ~250 instructions of a slab with
+    // no candidate in it).  The box only bounds the candidates (15 % + 0.05 voxels of slack); the voxels inside it are
+    // still tested with the forward's own arithmetic.
     const float idx = 1.0f / gr.dx, idy = 1.0f / gr.dy, idz = 1.0f / gr.dz;
+    auto affine = [&](float uu, float vv, float &ay, float &by, float &az, float &bz) {
+        const float a11 = uu * P[8] - P[0], a12 = uu * P[9] - P[1], c1 = P[2] - uu * P[10], d1 = P[3] - uu * P[11];
+        const float a21 = vv * P[8] - P[4], a22 = vv * P[9] - P[5], c2 = P[6] - vv * P[10], d2 = P[7] - vv * P[11];
+        const float det = a11 * a22 - a12 * a21, inv = 1.0f / det;
+        // ys = ((-c1 xs - d1) a22 + a12 (c2 xs + d2)) inv,  zs = (a11 (-c2 xs - d2) + (c1 xs + d1) a21) inv
+        const float ys1 = (a12 * c2 - c1 * a22) * inv, ys0 = (a12 * d2 - d1 * a22) * inv;
+        const float zs1 = (c1 * a21 - a11 * c2) * inv, zs0 = (d1 * a21 - a11 * d2) * inv;
+        // xs = x0 + ix dx;  index = (pos - origin) / step
+        by = ys1 * gr.dx * idy; ay = (ys0 + ys1 * gr.x0 - gr.y0) * idy;
+        bz = zs1 * gr.dx * idz; az = (zs0 + zs1 * gr.x0 - gr.z0) * idz;
+    };
+    float cAy, cBy, cAz, cBz, uAy, uBy, uAz, uBz, vAy, vBy, vAz, vBz;
+    affine(ut, vt, cAy, cBy, cAz, cBz);
+    affine(ut + su, vt, uAy, uBy, uAz, uBz);
+    affine(ut, vt + sv, vAy, vBy, vAz, vBz);
+    const float pd_per_x = (float)(g.D - 1) / g.depth_span;  // plane index per metre of depth
     const T *gb = gout + (size_t)b * N * CT;  // (both layouts: a sample is N * (C + Cs) elements)
-    float asem[32];
+    float asem[8];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) asem[c] = 0.0f;
+    for (int c = 0; c < 8; ++c) asem[c] = 0.0f;
     const int d0 = chunk * F2G_DCH, d1 = min(g.D, d0 + F2G_DCH);
     for (int d = d0; d < d1; ++d) {
-        float ast[32];
+        float ast[8];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) ast[c] = 0.0f;
+        for (int c = 0; c < 8; ++c) ast[c] = 0.0f;
         // x slabs whose plane position lies in (d - 1, d + 1): uniform for the workgroup
         const float xlo = g.depth_min + ((float)d - 1.0f) / pd_per_x, xhi = g.depth_min + ((float)d + 1.0f) / pd_per_x;
         const float fa = (xlo - gr.x0) * idx, fb = (xhi - gr.x0) * idx;
         const int ixa = max(0, (int)ceilf(fminf(fa, fb) - 0.02f)), ixb = min(g.Nx - 1, (int)floorf(fmaxf(fa, fb) + 0.02f));
         for (int ix = ixa; ix <= ixb; ++ix) {
-            const float xs = gr.x0 + (float)ix * gr.dx;
-            float yc, zc, yu, zu, yv, zv;
-            solve(ut, vt, xs, yc, zc);
-            solve(ut + su, vt, xs, yu, zu);
-            solve(ut, vt + sv, xs, yv, zv);
-            const float iyf = (yc - gr.y0) * idy, izf = (zc - gr.z0) * idz;
-            const float ty = (fabsf(yu - yc) + fabsf(yv - yc)) * fabsf(idy) * 1.15f + 0.05f;
-            const float tz = (fabsf(zu - zc) + fabsf(zv - zc)) * fabsf(idz) * 1.15f + 0.05f;
+            const float fx = (float)ix;
+            const float iyf = __builtin_fmaf(cBy, fx, cAy), izf = __builtin_fmaf(cBz, fx, cAz);
+            const float ty = (fabsf(__builtin_fmaf(uBy, fx, uAy) - iyf) + fabsf(__builtin_fmaf(vBy, fx, vAy) - iyf)) * 1.15f + 0.05f;
+            const float tz = (fabsf(__builtin_fmaf(uBz, fx, uAz) - izf) + fabsf(__builtin_fmaf(vBz, fx, vAz) - izf)) * 1.15f + 0.05f;
             const float y0f = ceilf(iyf - ty), y1f = floorf(iyf + ty), z0f = ceilf(izf - tz), z1f = floorf(izf + tz);
             // (non-finite solutions compare false.)  The box is walked in FULL whatever its size, clamped to the
             // grid in fp32 before the int conversion: a coarser cost volume, finer voxels or a long depth range
@@ -1151,59 +1202,52 @@ __global__ __launch_bounds__(256, DFM_F2G_WGS) void f2v_bwd_gather_kernel(F2vGeo
             const int iy0 = some ? (int)fmaxf(y0f, 0.0f) : 0, iy1 = some ? (int)fminf(y1f, (float)(g.Ny - 1)) : -1;
             const int iz0 = some ? (int)fmaxf(z0f, 0.0f) : 0, iz1 = some ? (int)fminf(z1f, (float)(g.Nz - 1)) : -1;
             // one candidate voxel (ix, iy, iz)
+            // one candidate voxel (ix, iy, iz): its packed lower-corner cell against this lane's (w, h, d) -- a 4-byte
+            // load and three subtractions reject it (round 5 re-ran the forward's projection for every candidate: three
+            // dependent loads, three dot products and two divisions before the first test)
             auto visit = [&](int iy, int iz) {
                 const long long i = ((long long)iz * g.Ny + iy) * g.Nx + ix;
-                const float sf = sfac[(size_t)b * N + i];
+                const uint32_t cc = cell[(size_t)b * N + i];
+                if (cc == F2G_NONE) return;
+                const int kx = w - ((int)(cc & 0x7ffu) - 1), ky = h - ((int)((cc >> 11) & 0x3ffu) - 1);
+                const int kz = d - ((int)(cc >> 21) - 1);
+                if ((unsigned)kx > 1u || (unsigned)ky > 1u) return;
+                const bool zhit = (unsigned)kz <= 1u;
+                if (!zhit && !(SEM && kz == 0)) return;
+                const float4 pp = pos[(size_t)b * N + i];
+                const float px = pp.x, py = pp.y, pz = pp.z, sf = pp.w;
                 const float mf = SEM ? mfac[(size_t)b * N + i] : -1.0f;
-                if (sf < 0.0f && mf < 0.0f) return;
-                // the forward's arithmetic on the voxel's own coordinates
-                const float vx = coords[3 * i], vy = coords[3 * i + 1], vz = coords[3 * i + 2];
-                const float a = dot4_chain(-vy, -vz, vx, 1.0f, P + 0);
-                const float bb = dot4_chain(-vy, -vz, vx, 1.0f, P + 4);
-                const float c = dot4_chain(-vy, -vz, vx, 1.0f, P + 8);
-                const float u = a / c, v = bb / c;
-                float gx = (u - 0.0f) / (g.pad_w - 1.0f), gy = (v - 0.0f) / (g.pad_h - 1.0f);
-                float gz = (vx - g.depth_min) / g.depth_span;
-                gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f; gz = gz * 2.0f - 1.0f;
-                // make_tri's positions and weights, corner by corner
-                const float px = ((gx + 1.0f) / 2.0f) * (float)(g.W - 1);
-                const float py = ((gy + 1.0f) / 2.0f) * (float)(g.H - 1);
-                const float pz = ((gz + 1.0f) / 2.0f) * (float)(g.D - 1);
-                if (!(fabsf(px) <= 1.0e9f && fabsf(py) <= 1.0e9f && fabsf(pz) <= 1.0e9f)) return;
+                // make_tri's weights, corner by corner (the forward's expressions on the forward's values)
                 const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
                 const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
-                const float wf = (float)w, hf = (float)h, df = (float)d;
-                const int kx = wf == x0 ? 0 : (wf == x1 ? 1 : -1), ky = hf == y0 ? 0 : (hf == y1 ? 1 : -1);
-                const int kz = df == z0 ? 0 : (df == z1 ? 1 : -1);
-                if (kx < 0 || ky < 0) return;
                 const float wx = kx ? px - x0 : x1 - px, wy = ky ? py - y0 : y1 - py;
                 const T *gp = gb + (size_t)i * gvs;
-                if (kz >= 0 && sf >= 0.0f) {
+                if (zhit && sf >= 0.0f) {
                     const float wgt = ((wx * wy) * (kz ? pz - z0 : z1 - pz)) * sf;
-                    float vv[32];
+                    float vv[8];
                     if (gcs == 1) {
-                        gather_row32<T>(gp, vv);
+                        gather_row8<T>(gp + cq, vv);
                     } else {
 #pragma unroll
-                        for (int cc = 0; cc < 32; ++cc) vv[cc] = elem<T>::load(gp[(size_t)cc * gcs]);
+                        for (int cc2 = 0; cc2 < 8; ++cc2) vv[cc2] = elem<T>::load(gp[(size_t)(cq + cc2) * gcs]);
                     }
 #pragma unroll
-                    for (int cc = 0; cc < 32; ++cc) ast[cc] += vv[cc] * wgt;
+                    for (int cc2 = 0; cc2 < 8; ++cc2) ast[cc2] += vv[cc2] * wgt;
                 }
                 if constexpr (SEM) {
                     // the semantic map's pixel (h, w): once per voxel, from the hit on its lower depth corner
                     // (a valid voxel's lower corner is inside the volume); make_tri(gx, gy, 0, 1, H, W): z1 - iz = 1
                     if (kz == 0 && mf >= 0.0f) {
                         const float mw = ((wx * wy) * 1.0f) * mf;
-                        float vv[32];
+                        float vv[8];
                         if (gcs == 1) {
-                            gather_row32<T>(gp + 32, vv);
+                            gather_row8<T>(gp + 32 + cq, vv);
                         } else {
 #pragma unroll
-                            for (int cc = 0; cc < 32; ++cc) vv[cc] = elem<T>::load(gp[(size_t)(32 + cc) * gcs]);
+                            for (int cc2 = 0; cc2 < 8; ++cc2) vv[cc2] = elem<T>::load(gp[(size_t)(32 + cq + cc2) * gcs]);
                         }
 #pragma unroll
-                        for (int cc = 0; cc < 32; ++cc) asem[cc] += vv[cc] * mw;
+                        for (int cc2 = 0; cc2 < 8; ++cc2) asem[cc2] += vv[cc2] * mw;
                     }
                 }
             };
@@ -1241,9 +1285,9 @@ __global__ __launch_bounds__(256, DFM_F2G_WGS) void f2v_bwd_gather_kernel(F2vGeo
         if (inside) {
             if constexpr (GCL) {
                 constexpr int VEC = dfm::vec16<T>::N;
-                T *o = (T *)gstv + ((((size_t)b * g.D + d) * g.H + h) * g.W + w) * 32;
+                T *o = (T *)gstv + ((((size_t)b * g.D + d) * g.H + h) * g.W + w) * 32 + cq;
 #pragma unroll
-                for (int q = 0; q < 32 / VEC; ++q) {
+                for (int q = 0; q < 8 / VEC; ++q) {
                     float r[VEC];
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) r[e] = ast[q * VEC + e];
@@ -1253,7 +1297,7 @@ __global__ __launch_bounds__(256, DFM_F2G_WGS) void f2v_bwd_gather_kernel(F2vGeo
                 float *o = (float *)gstv + ((size_t)b * g.C * g.D + d) * g.H * g.W + (size_t)h * g.W + w;
                 const size_t cs = (size_t)g.D * g.H * g.W;
 #pragma unroll
-                for (int c = 0; c < 32; ++c) o[(size_t)c * cs] = ast[c];
+                for (int c = 0; c < 8; ++c) o[(size_t)(cq + c) * cs] = ast[c];
             }
         }
     }
@@ -1262,8 +1306,8 @@ __global__ __launch_bounds__(256, DFM_F2G_WGS) void f2v_bwd_gather_kernel(F2vGeo
             float *o = gsem + (size_t)b * g.Cs * g.Hsem * g.Wsem + (size_t)h * g.Wsem + w;
             const size_t cs = (size_t)g.Hsem * g.Wsem;
 #pragma unroll
-            for (int c = 0; c < 32; ++c)
-                if (asem[c] != 0.0f) atomicAdd(o + (size_t)c * cs, asem[c]);
+            for (int c = 0; c < 8; ++c)
+                if (asem[c] != 0.0f) atomicAdd(o + (size_t)(cq + c) * cs, asem[c]);
         }
     }
 }
@@ -1379,13 +1423,14 @@ extern "C" DFM_API int dfm_frustum_to_voxel_fused_bwd(const dfm_f2v_desc *d, con
 // The gather form of the backward (f2v_bwd_gather_kernel).  grid6 (HOST memory): {x0, dx, y0, dy, z0, dz} of the
 // regular voxel grid `coords` is (the caller has checked it: coords[(iz * Ny + iy) * Nx + ix] == origin + index *
 // step).  grad_stereo is OVERWRITTEN (reference layout, fp32); grad_sem zero-filled by the caller, accumulated.
-// workspace: >= dfm_frustum_to_voxel_bwd_gather_workspace_bytes (8 bytes per voxel).  DFM_ERR_UNSUPPORTED unless
+// workspace: >= dfm_frustum_to_voxel_bwd_gather_workspace_bytes (24 bytes per voxel), 16-byte aligned.  DFM_ERR_UNSUPPORTED unless
 // C == 32, Cs in {0, 32} with the semantic map at the cost volume's resolution and sem_atten (a voxel outside
 // the depth range then contributes nothing and every contributing voxel has a cell), and non-zero grid steps.
 extern "C" DFM_API size_t dfm_frustum_to_voxel_bwd_gather_workspace_bytes(const dfm_f2v_desc *d)
 {
     if (!d || d->batch <= 0 || d->nz <= 0 || d->ny <= 0 || d->nx <= 0) return 0;
-    return (((size_t)2 * d->batch * d->nz * d->ny * d->nx * sizeof(float)) + 255) & ~(size_t)255;
+    // per voxel: its position and stereo factor (16 bytes), its packed cell (4), its semantic factor (4)
+    return (((size_t)d->batch * d->nz * d->ny * d->nx * 24) + 255) & ~(size_t)255;
 }
 
 static int f2v_bwd_gather_impl(const dfm_f2v_desc *d, const void *grad_out, const void *softmax, const void *cost,
@@ -1405,7 +1450,8 @@ static int f2v_bwd_gather_impl(const dfm_f2v_desc *d, const void *grad_out, cons
                                                           !d->no_sem_atten)) ||
         d->d < 2 || d->h < 2 || d->w < 2 || grid6[1] == 0.0f || grid6[3] == 0.0f || grid6[5] == 0.0f ||
         d->batch > 65535 || (d->out_channels_last && ((uintptr_t)grad_out & 15)) ||
-        (grad_cl && ((uintptr_t)grad_stereo & 15)))
+        (grad_cl && ((uintptr_t)grad_stereo & 15)) || d->w > 2044 || d->h > 1020 || d->d > 1020 ||
+        ((uintptr_t)workspace & 15))
         return set_error(DFM_ERR_UNSUPPORTED,
                          "gather backward: C == 32, Cs in {0, 32} at the cost volume's resolution with sem_atten, regular grid");
     if (workspace_bytes < dfm_frustum_to_voxel_bwd_gather_workspace_bytes(d))
@@ -1430,20 +1476,23 @@ static int f2v_bwd_gather_impl(const dfm_f2v_desc *d, const void *grad_out, cons
     const F2vGrid gr{grid6[0], grid6[1], grid6[2], grid6[3], grid6[4], grid6[5]};
     const long long N = (long long)d->nz * d->ny * d->nx;
     hipStream_t st = (hipStream_t)stream;
-    float *sfac = (float *)workspace, *mfac = sfac + (size_t)d->batch * N;
+    float4 *pos = (float4 *)workspace;
+    uint32_t *cell = (uint32_t *)(pos + (size_t)d->batch * N);
+    float *mfac = (float *)(cell + (size_t)d->batch * N);
     const dim3 pgrid((unsigned)((N + 255) / 256), d->batch);
     const int CT = d->channels + d->sem_channels;
     const size_t gvs = g.out_cl ? (size_t)CT : 1, gcs = g.out_cl ? 1 : (size_t)N;
     const int dchunks = (d->d + F2G_DCH - 1) / F2G_DCH;
-    const dim3 ggrid((unsigned)(((d->w + 63) / 64) * ((d->h + 3) / 4) * dchunks), d->batch);
+    const dim3 ggrid((unsigned)(((d->w + 15) / 16) * ((d->h + 3) / 4) * dchunks), d->batch);
 #define DFM_F2G_K(T_, SEM_, GCL_)                                                                                 \
     hipLaunchKernelGGL((f2v_bwd_gather_kernel<T_, SEM_, GCL_>), ggrid, dim3(256), 0, st, g, gr, dchunks,         \
-                       (const T_ *)grad_out, gvs, gcs, coords, cam2img, (const float *)sfac, (const float *)mfac, \
+                       (const T_ *)grad_out, gvs, gcs, coords, cam2img, (const uint32_t *)cell, (const float4 *)pos,  \
+                       (const float *)mfac,                                                                      \
                        grad_stereo, grad_sem)
 #define DFM_F2G(T_)                                                                                              \
     do {                                                                                                         \
         hipLaunchKernelGGL(f2v_bwd_prep_kernel<T_>, pgrid, dim3(256), 0, st, g, (const T_ *)softmax, fh, coords, \
-                           cam2img, sfac, mfac);                                                                 \
+                           cam2img, (float *)nullptr, mfac, cell, pos);                                          \
         if (d->sem_channels > 0) {                                                                               \
             if (grad_cl) DFM_F2G_K(T_, true, true); else DFM_F2G_K(T_, true, false);                             \
         } else {                                                                                                 \
