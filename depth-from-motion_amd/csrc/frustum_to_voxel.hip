@@ -985,28 +985,6 @@ __global__ __launch_bounds__(256) void f2v_bwd_pm_kernel(F2vGeom g, const T *__r
 }
 
 
-// 32 consecutive channels of one voxel's gradient row (channels-last), as fp32
-template <typename T>
-__device__ __forceinline__ void gather_row32(const T *__restrict__ gp, float (&v)[32])
-{
-    constexpr int VEC = 16 / (int)sizeof(T);
-#pragma unroll
-    for (int q = 0; q < 32 / VEC; ++q) {
-        const uint4 u = *(const uint4 *)(gp + q * VEC);
-        if constexpr (sizeof(T) == 4) {
-            v[4 * q] = __uint_as_float(u.x); v[4 * q + 1] = __uint_as_float(u.y);
-            v[4 * q + 2] = __uint_as_float(u.z); v[4 * q + 3] = __uint_as_float(u.w);
-        } else {
-            const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[8 * q + 2 * k] = __uint_as_float(w4[k] << 16);
-                v[8 * q + 2 * k + 1] = __uint_as_float(w4[k] & 0xffff0000u);
-            }
-        }
-    }
-}
-
 // 8 consecutive channels of one voxel's gradient row, as fp32 (one 16-byte load in bf16, two in fp32)
 template <typename T>
 __device__ __forceinline__ void gather_row8(const T *__restrict__ gp, float (&v)[8])
@@ -1107,13 +1085,19 @@ __global__ __launch_bounds__(256) void f2v_bwd_prep_kernel(F2vGeom g, const T *_
     }
 }
 
+// Depth planes per lane.  Round 5 ran 9 (72 planes -> 8 chunks): 800 workgroups of a kernel that held 256 + 16
+// registers a lane -- ONE workgroup per CU, 3.1 rounds over the chip, each wave waiting out its own chain of
+// dependent loads: 1.80 ms.  Three planes a chunk: 0.97 ms (1, 2 planes measure the same, 4 is 9 % slower; capping
+// the registers for 3 or 4 workgroups per CU spilled: 3.3 / 5.7 ms).  Then the candidate test on a packed cell word
+// from the pre-pass, four lanes per pixel (150 registers, three waves per SIMD) and the slab positions as affine
+// functions of the slab index: 0.75 ms -- profiles/r06_c28_f2v_bwd_depth_chunk.txt
 #ifndef DFM_F2G_DCH
 #define DFM_F2G_DCH 3
 #endif
 #ifndef DFM_F2G_WGS
 #define DFM_F2G_WGS 1
 #endif
-constexpr int F2G_DCH = DFM_F2G_DCH;  // depth planes per lane (a chunk): 72 planes -> 8 chunks
+constexpr int F2G_DCH = DFM_F2G_DCH;  // depth planes per lane (a chunk): 72 planes -> 24 chunks
 
 // lane = pixel (h, w) of the cost volume x a chunk of depth planes; C == 32, Cs in {0, 32} with the semantic
 // map at the cost volume's resolution.  gvs / gcs: element strides of grad_out between voxels / channels.
