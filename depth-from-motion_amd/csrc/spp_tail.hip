@@ -65,6 +65,52 @@ __global__ __launch_bounds__(256) void spp_branch_kernel(SppBranches br, float *
         wT[k * C + c] = w[i];
     }
     const int c = threadIdx.x % C, pg = threadIdx.x / C, npg = 256 / C;  // C in {8, 16, 32, 64}: divides 256
+    if (K % 16 == 0) {
+        // round 6: the 1x1 convolution on the matrix cores -- D[pixel][channel] += X[pixel][k] W^T[k][channel],
+        // v_mfma_f32_32x32x16_bf16.  The pooled pixels ARE bf16 (a lane's operand is one 16-byte load of 8
+        // consecutive input channels of its pixel); the fp32 weights go in as hi + lo bf16 halves (two products per
+        // k-step: 16 significand bits, the dropped term is 2^-17 of a product -- below the bf16 rounding of the
+        // result by 2^-9).  A wave takes every fourth tile of 32 pixels.
+        // (The scalar loop below read 5 LDS words per 4 multiply-adds and staged each tile through fp32 LDS behind
+        // two barriers: 160 us for the 10 x 40-pixel branch of config K, on the critical path of the neck.)
+        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+        typedef float f32x16_t __attribute__((ext_vector_type(16)));
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l32 = lane & 31, half = lane >> 5;
+        const int nks = K / 16;
+        for (int n0 = 0; n0 < C; n0 += 32) {
+            const int cn = n0 + l32;  // this lane's output channel (B operand column)
+            for (int p0 = wave * 32; p0 < P; p0 += 4 * 32) {
+                f32x16_t acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+                const int pm = p0 + l32;  // this lane's pixel (A operand row)
+                for (int ks = 0; ks < nks; ++ks) {
+                    uint4 xa = make_uint4(0u, 0u, 0u, 0u);
+                    if (pm < P) xa = *(const uint4 *)(x + (size_t)pm * K + ks * 16 + half * 8);
+                    float wf[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wf[j] = cn < C ? w[(size_t)cn * K + ks * 16 + half * 8 + j] : 0.0f;
+                    bf16x8_t a, bh, bl;
+                    __builtin_memcpy(&a, &xa, 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bf16_t hi = f32_to_bf16(wf[j]);
+                        const bf16_t lo = f32_to_bf16(wf[j] - bf16_to_f32(hi));
+                        __builtin_memcpy((char *)&bh + 2 * j, &hi, 2);
+                        __builtin_memcpy((char *)&bl + 2 * j, &lo, 2);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc, 0, 0, 0);
+                }
+                // acc[r]: row (pixel) 8 (r >> 2) + 4 half + (r & 3), column (channel) l32
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pr = p0 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    if (pr < P && cn < C) ys[(size_t)pr * C + cn] = f32_to_bf16(acc[r]);
+                }
+            }
+        }
+    } else
     for (int p0 = 0; p0 < P; p0 += SPP_TP) {
         const int np = min(SPP_TP, P - p0);
         __syncthreads();  // wT ready / previous tile consumed
