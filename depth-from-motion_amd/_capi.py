@@ -82,6 +82,7 @@ EXPORTS = (
     'dfm_cost_gate_mfma_fwd',
     'dfm_conv3d_g_weight_bytes',
     'dfm_conv3d_g_pack_weights',
+    'dfm_conv3d_g_pack_weights_2d',
     'dfm_conv3d_g_fwd',
     'dfm_conv3d_g_fwd_f32',
     'dfm_conv3d_g_plan',
@@ -387,6 +388,8 @@ def lib():
     h.dfm_conv3d_g_weight_bytes.argtypes = [i32, i32]
     h.dfm_conv3d_g_pack_weights.restype = ctypes.c_int
     h.dfm_conv3d_g_pack_weights.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+    h.dfm_conv3d_g_pack_weights_2d.restype = ctypes.c_int
+    h.dfm_conv3d_g_pack_weights_2d.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     h.dfm_conv3d_g_fwd.restype = ctypes.c_int
     h.dfm_conv3d_g_fwd.argtypes = [cp, vp, vp, fp, fp, vp, vp, vp]
     h.dfm_conv3d_g_fwd_f32.restype = ctypes.c_int

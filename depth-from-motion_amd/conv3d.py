@@ -656,16 +656,18 @@ def pack_conv3d_g_weights(weight, cin, cout, swap=False, flip=0):
     input-channel axis of that convolution; ``flip``: bit mask (4 = d, 2 = h, 1 = w) of mirrored
     kernel axes (see include/dfm_hip.h)."""
     note_derived_build()
-    assert weight.is_cuda and weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3)
+    two_d = weight.dim() == 4   # a 2-D weight (dim0, dim1, 3, 3): packed into the centre depth slice, no embedding copy
+    assert weight.is_cuda and weight.dim() in (4, 5) and tuple(weight.shape[2:]) == ((3, 3) if two_d else (3, 3, 3))
     assert tuple(weight.shape[:2]) == ((cin, cout) if swap else (cout, cin))
     w = weight.detach().contiguous()
     if w.dtype not in _WDT:
         w = w.float()
     lib = _capi.lib()
     packed = torch.empty(lib.dfm_conv3d_g_weight_bytes(cin, cout), dtype=torch.uint8, device=w.device)
+    entry = lib.dfm_conv3d_g_pack_weights_2d if two_d else lib.dfm_conv3d_g_pack_weights
     with torch.cuda.device(w.device):
-        _capi.check(lib.dfm_conv3d_g_pack_weights(_ptr(w), _WDT[w.dtype], cin, cout, 1 if swap else 0,
-                                                  int(flip), _ptr(packed), _stream_ptr(w.device)))
+        _capi.check(entry(_ptr(w), _WDT[w.dtype], cin, cout, 1 if swap else 0, int(flip), _ptr(packed),
+                          _stream_ptr(w.device)))
     return packed
 
 
@@ -964,9 +966,7 @@ def pack_conv2d_g_weights(weight, cin, cout, swap=False):
     """torch 2-D weight (dim0, dim1, 3, 3) -> the 27-tap fragment buffer with the 2-D kernel in its
     centre depth slice (the depth axis runs with kernel extent 1)"""
     assert weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
-    w3 = weight.new_zeros((*weight.shape[:2], 3, 3, 3))
-    w3[:, :, 1] = weight.detach()
-    return pack_conv3d_g_weights(w3, cin, cout, swap=swap)
+    return pack_conv3d_g_weights(weight, cin, cout, swap=swap)
 
 
 def conv2d_g_why_not(x, cin, cout):
@@ -1066,7 +1066,7 @@ class _Conv2dGFn(torch.autograd.Function):
                 # backward-data = the same kernel on the mirrored, channel-swapped weights; a stride-2 axis
                 # becomes a transposed axis (even extents, padding 1: MfmaConv2d.train_why_not)
                 up = stride == 2
-                pk = pack_conv3d_g_weights(_embed2d(w), cout, cin_p, swap=True, flip=4 if up else 7)
+                pk = pack_conv3d_g_weights(w, cout, cin_p, swap=True, flip=4 if up else 7)
                 gx = conv3d_g(g5, pk, cin_p, stride=1, padding=(0, 1, 1), transposed=(False, up, up),
                               kernel1=k1).squeeze(2)[:, :cin]
             if ctx.needs_input_grad[1]:
@@ -1075,7 +1075,7 @@ class _Conv2dGFn(torch.autograd.Function):
                 gb = gcl.float().sum((0, 2, 3)).to(weight.dtype)
         else:
             if ctx.needs_input_grad[0]:
-                pk = pack_conv3d_g_weights(_embed2d(w), cout, cin, swap=False, flip=0)
+                pk = pack_conv3d_g_weights(w, cout, cin, swap=False, flip=0)
                 gx = conv3d_g(g5, pk, cin, stride=(1, 2, 2), padding=(0, 1, 1), kernel1=k1).squeeze(2)
             if ctx.needs_input_grad[1]:
                 gw = conv3d_weight_grad(g5, x5, (1, 2, 2), (1, 1, 1))[:, :, 1].to(weight.dtype)

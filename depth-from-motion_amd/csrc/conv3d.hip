@@ -93,6 +93,12 @@ __global__ void conv3d_pack_weights_kernel(const TW *__restrict__ w, int cin_tot
                                : ((size_t)row * cin_total + cin_off + k0 + j) * 27 + tap;
         frag[((size_t)f * 64 + l) * 8 + j] = f32_to_bf16(conv3d_wload<TW>(w, idx));
     }
+    // the zero page behind the fragments (out-of-bounds pixels read it): written here, by the first workgroup --
+    // round 6: a hipMemsetAsync per pack was a launch of its own, ~50 per training step
+    if (f == 0) {
+        uint4 *z = (uint4 *)(frag + (size_t)CV_NFRAG * 64 * 8);
+        for (int i = l; i < 256; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
 }
 
 // OUT_F32: write the fp32 partial (N,D,H,W,32) instead of bf16;  ACC_IN: start from a fp32 partial
@@ -402,9 +408,8 @@ extern "C" DFM_API int dfm_conv3d_k3_c32_pack_weights(const void *weight, int32_
     if (weight_dtype != DFM_F32 && weight_dtype != DFM_BF16)
         return set_error(DFM_ERR_UNSUPPORTED, "weight dtype must be DFM_F32 or DFM_BF16");
     hipStream_t st = (hipStream_t)stream;
-    // the zero page (out-of-bounds pixels read it) sits behind the fragments
-    hipError_t e = hipMemsetAsync((char *)packed + (size_t)CV_NFRAG * 64 * 16, 0, 4096, st);
-    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    hipError_t e;
+    // (the zero page behind the fragments is the pack kernel's)
     if (weight_dtype == DFM_F32)
         hipLaunchKernelGGL(conv3d_pack_weights_kernel<float>, dim3(CV_NFRAG), dim3(64), 0, st,
                            (const float *)weight, cin_total, cin_offset, transposed, (bf16_t *)packed);

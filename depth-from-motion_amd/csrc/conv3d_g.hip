@@ -80,9 +80,11 @@ __device__ __forceinline__ float g_wload<float>(const float *w, size_t idx) { re
 template <>
 __device__ __forceinline__ float g_wload<bf16_t>(const bf16_t *w, size_t idx) { return bf16_to_f32(w[idx]); }
 
+// w2d != 0: W is a 2-D weight (dim0 x dim1 x 9) that sits in the CENTRE depth slice of the 27 taps (a 2-D convolution
+// run as a depth-1 volume, kernel extent 1 along depth); the other two slices are packed as zeros
 template <typename TW>
 __global__ void conv3d_g_pack_kernel(const TW *__restrict__ w, int rows, int kk, int cw_n, int swap,
-                                     int flip, bf16_t *__restrict__ frag)
+                                     int flip, bf16_t *__restrict__ frag, int w2d)
 {
     // blockIdx.x = ((ct*nchunk + chunk)*27 + tap)*2 + ks, blockIdx.y = cw
     const int nchunk = kk / 32;
@@ -101,9 +103,19 @@ __global__ void conv3d_g_pack_kernel(const TW *__restrict__ w, int rows, int kk,
     const size_t o = (((size_t)blockIdx.x * cw_n + cw) * 64 + l) * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+        if (w2d) {
+            const size_t idx2 = (swap ? (size_t)(k0 + j) * rows + row : (size_t)row * kk + k0 + j) * 9 + (kh * 3 + kw);
+            frag[o + j] = kd == 1 ? f32_to_bf16(g_wload<TW>(w, idx2)) : f32_to_bf16(0.0f);
+            continue;
+        }
         const size_t idx = swap ? ((size_t)(k0 + j) * rows + row) * 27 + t
                                 : ((size_t)row * kk + k0 + j) * 27 + t;
         frag[o + j] = f32_to_bf16(g_wload<TW>(w, idx));
+    }
+    // the zero page behind the fragments, by the first workgroup (round 6: no hipMemsetAsync launch per pack)
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        uint4 *z = (uint4 *)(frag + (size_t)rows * kk * 27);
+        for (int i = l; i < 256; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -757,9 +769,27 @@ extern "C" DFM_API size_t dfm_conv3d_g_weight_bytes(int32_t cin, int32_t cout)
     return (size_t)cin * cout * 27 * 2 + 4096;  // fragments + the zero page
 }
 
+static int g_pack_impl(const void *weight, int32_t weight_dtype, int32_t cin, int32_t cout, int32_t swap, int32_t flip,
+                       void *packed, void *stream, int w2d);
+
 extern "C" DFM_API int dfm_conv3d_g_pack_weights(const void *weight, int32_t weight_dtype, int32_t cin,
                                                  int32_t cout, int32_t swap, int32_t flip, void *packed,
                                                  void *stream)
+{
+    return g_pack_impl(weight, weight_dtype, cin, cout, swap, flip, packed, stream, 0);
+}
+
+// the same for a 2-D weight (dim0, dim1, 3, 3): its taps in the centre depth slice of the 27, zeros in the other two --
+// what a 2-D convolution run as a depth-1 volume (dfm_conv3d_desc.kernel1[0] = 1) reads; flip bits 2 (h), 1 (w)
+extern "C" DFM_API int dfm_conv3d_g_pack_weights_2d(const void *weight, int32_t weight_dtype, int32_t cin,
+                                                    int32_t cout, int32_t swap, int32_t flip, void *packed,
+                                                    void *stream)
+{
+    return g_pack_impl(weight, weight_dtype, cin, cout, swap, flip & 3, packed, stream, 1);
+}
+
+static int g_pack_impl(const void *weight, int32_t weight_dtype, int32_t cin, int32_t cout, int32_t swap, int32_t flip,
+                       void *packed, void *stream, int w2d)
 {
     if (!weight || !packed) return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     if (cin <= 0 || cout <= 0 || cin % 32 || cout % 32)
@@ -767,18 +797,16 @@ extern "C" DFM_API int dfm_conv3d_g_pack_weights(const void *weight, int32_t wei
     if (weight_dtype != DFM_F32 && weight_dtype != DFM_BF16)
         return set_error(DFM_ERR_UNSUPPORTED, "weight dtype must be DFM_F32 or DFM_BF16");
     hipStream_t st = (hipStream_t)stream;
-    const size_t fb = (size_t)cin * cout * 27 * 2;
-    hipError_t e = hipMemsetAsync((char *)packed + fb, 0, 4096, st);
-    if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
+    hipError_t e;   // (the zero page behind the cin * cout * 27 fragments' elements is the pack kernel's)
     const int cw = cout % 64 == 0 ? 2 : 1;
     const int cts = cout / (32 * cw), nchunk = cin / 32;
     dim3 grid(cts * nchunk * 27 * 2, cw);
     if (weight_dtype == DFM_F32)
         hipLaunchKernelGGL(conv3d_g_pack_kernel<float>, grid, dim3(64), 0, st, (const float *)weight, cout, cin,
-                           cw, swap, flip, (bf16_t *)packed);
+                           cw, swap, flip, (bf16_t *)packed, w2d);
     else
         hipLaunchKernelGGL(conv3d_g_pack_kernel<bf16_t>, grid, dim3(64), 0, st, (const bf16_t *)weight, cout,
-                           cin, cw, swap, flip, (bf16_t *)packed);
+                           cin, cw, swap, flip, (bf16_t *)packed, w2d);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(DFM_ERR_HIP, hipGetErrorString(e));
     return DFM_OK;

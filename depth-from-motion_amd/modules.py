@@ -1100,6 +1100,17 @@ def _channels_last_2d(module, feats):
     want = torch.channels_last if nhwc else torch.contiguous_format
     if module.__dict__.get('_weights_format') is not want:
         module.to(memory_format=want)
+        if nhwc:
+            # ... except the weights of the convolutions that run in the MFMA kernels: those are packed from the
+            # parameter's logical (cout, cin, kh, kw) view, and a channels-last PARAMETER costs a strided copy wherever
+            # it is made contiguous (each pack, forward and backward) and another when autograd lays the incoming
+            # gradient out like the parameter (80 small launches per training step of the stereo path, round 6)
+            for m in module.modules():
+                if isinstance(m, (MfmaConv2d, MfmaConvTranspose2d)) and m.weight.dim() == 4 and \
+                        MfmaConv2d.covers(m.weight.shape[1] if isinstance(m, MfmaConv2d) else m.weight.shape[0],
+                                          m.weight.shape[0] if isinstance(m, MfmaConv2d) else m.weight.shape[1],
+                                          tuple(m.weight.shape[2:]), m.stride, m.padding):
+                    m.weight.data = m.weight.data.contiguous()
         module.__dict__['_weights_format'] = want
         module.__dict__['_weights_channels_last'] = nhwc
     if not nhwc:

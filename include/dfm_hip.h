@@ -778,6 +778,13 @@ DFM_API size_t dfm_conv3d_g_weight_bytes(int32_t cin, int32_t cout);
 DFM_API int dfm_conv3d_g_pack_weights(const void *weight, int32_t weight_dtype, int32_t cin,
                                       int32_t cout, int32_t swap, int32_t flip, void *packed,
                                       void *stream);
+/* the same for a 2-D weight (dim0, dim1, 3, 3) (round 6): its 9 taps land in the centre depth slice of the 27, the
+ * other two slices are zeros -- what a 2-D convolution run as a depth-1 volume (kernel1[0] = 1) reads, without the
+ * caller embedding the weight into a (.., 3, 3, 3) tensor first (SPPUNetNeck / BEVHourglass: spp_unet_neck.py:93-119,
+ * bev_hourglass.py:36-137); flip bits 2 (h) and 1 (w) */
+DFM_API int dfm_conv3d_g_pack_weights_2d(const void *weight, int32_t weight_dtype, int32_t cin,
+                                         int32_t cout, int32_t swap, int32_t flip, void *packed,
+                                         void *stream);
 /*
  * x        : (n, d, h, w, cin) bf16, channels-last (pixel stride desc->in_channel_stride) [device]
  * scale / shift : NULL, or fp32 [cout]: y = conv * scale[c] + shift[c] (a folded BatchNorm3d in

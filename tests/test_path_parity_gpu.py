@@ -157,7 +157,12 @@ class LayerReplay:
 
         def pack_g(weight, cin, cout, swap=False, flip=0):
             pk = real['pack_conv3d_g_weights'](weight, cin, cout, swap=swap, flip=flip)
-            self.packs[pk.data_ptr()] = (pk, weight.detach().float().clone(), swap, flip)
+            w = weight.detach().float().clone()
+            if w.dim() == 4:   # a 2-D weight, packed into the centre depth slice (dfm_conv3d_g_pack_weights_2d)
+                w3 = w.new_zeros((*w.shape[:2], 3, 3, 3))
+                w3[:, :, 1] = w
+                w = w3
+            self.packs[pk.data_ptr()] = (pk, w, swap, flip)
             return pk
 
         def pack_c32(weight, cin_offset=0, transposed=False):
