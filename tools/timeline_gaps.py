@@ -17,7 +17,8 @@ def main(d, steps=10):
     ks = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r.get('Queue_Id', '0'), r['Kernel_Name'])
                  for r in rows), key=lambda t: t[0])
     # the timed region: the last `steps` occurrences of the step's first kernel
-    first = [i for i, k in enumerate(ks) if 'sweep_conv_kernel' in k[3] or 'camera_prepare' in k[3]]
+    marker = os.environ.get('TIMELINE_MARKER')   # (a kernel that runs once per step; default: the sweep's first launch)
+    first = [i for i, k in enumerate(ks) if (marker in k[3] if marker else ('sweep_conv_kernel' in k[3] or 'camera_prepare' in k[3]))]
     if len(first) < steps + 1:
         print('not enough steps in the trace', len(first))
         return
