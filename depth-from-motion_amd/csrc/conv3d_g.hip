@@ -716,7 +716,9 @@ bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
                 const double mf = std::max(mf_tap, wt_tap) * taps * g.nchunk;
                 const double st = ((double)bpx * 64 * 0.1 + 1500.0) * g.nchunk;
                 const double cost = (double)waves * (mf + st);
-                if (cost < best) {
+                // (a tie between two tilings of the same block size goes to the one that is deeper along d: measured,
+                //  256 -> 256 at (220, 300, 3): (16, 8, 3) 0.648 ms, (8, 16, 3) 0.691 ms -- profiles/r06_c39_*)
+                if (cost < best || (found && cost == best && tw > 1 && td > pl.g.d.tile)) {   // (tw = 1: no preference measured)
                     best = cost; found = true;
                     c.block_px = (int)bpx; c.nrounds = rounds;
                     c.r_bw = 1.0f / (float)c.w.block; c.r_bhw = 1.0f / (float)(c.h.block * c.w.block);
