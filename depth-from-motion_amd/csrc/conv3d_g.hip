@@ -682,6 +682,10 @@ bool g_plan(const dfm_conv3d_desc *d, GPlan &pl)
     for (int pfw = 4; pfw >= 1; --pfw) {
         const int P = 128 * pfw;
         if (force[0] && pfw != force[0]) continue;
+        // x2 transposed on all three axes (8 parity classes, the generic tap loop): two pixel fragments a wave at most --
+        // measured, hourglass conv6 64 -> 32 at (36, 40, 160): pfw 2 (4, 8, 8) 0.071 ms, pfw 4 (8, 8, 8) 0.079 ms
+        // (profiles/r06_c39_conv_g_plan_sweep_hourglass_layers.txt)
+        if (!force[0] && classes == 8 && pfw > 2) continue;
         for (int td = 1; td <= P; ++td) {
             if (P % td) continue;
             if (pass == 0 && td > sp[0] && td > 1) continue;
