@@ -74,6 +74,9 @@ EXPORTS = (
     'dfm_conv3d_k3_c32_to1_fwd',
     'dfm_group_norm_coefficients',
     'dfm_conv3d_to1_norm_fwd',
+    'dfm_conv3d_to1_bwd_data',
+    'dfm_conv3d_to1_wgrad_workspace_bytes',
+    'dfm_conv3d_to1_wgrad',
     'dfm_bilinear_resize_bwd_nhwc',
     'dfm_depth_pool_fwd',
     'dfm_depth_pool_bwd',
@@ -368,6 +371,12 @@ def lib():
     h.dfm_conv3d_k3_c32_to1_fwd.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, i32, vp]
     h.dfm_group_norm_coefficients.restype = ctypes.c_int
     h.dfm_group_norm_coefficients.argtypes = [i32, i32, i32, ctypes.c_float, vp, i32, vp, vp, vp, vp]
+    h.dfm_conv3d_to1_bwd_data.restype = ctypes.c_int
+    h.dfm_conv3d_to1_bwd_data.argtypes = [i32, i32, i32, i32, vp, vp, i32, vp, vp]
+    h.dfm_conv3d_to1_wgrad_workspace_bytes.restype = sz
+    h.dfm_conv3d_to1_wgrad_workspace_bytes.argtypes = []
+    h.dfm_conv3d_to1_wgrad.restype = ctypes.c_int
+    h.dfm_conv3d_to1_wgrad.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, vp, sz, vp]
     h.dfm_conv3d_to1_norm_fwd.restype = ctypes.c_int
     h.dfm_conv3d_to1_norm_fwd.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, vp]
     h.dfm_cost_gate_mfma_weight_bytes.restype = sz

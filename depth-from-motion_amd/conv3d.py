@@ -570,13 +570,33 @@ class _MfmaConvTo1Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        gx = gw = g32 = None
+        gx = gw = None
         gy = gy.contiguous()
+        N, _, D, H, W = gy.shape
+        lib = _capi.lib()
+        direct = (gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and _is_ndhwc(x) and
+                  _ndhwc_channel_stride(x) == 32 and weight.dtype in _WDT and os.environ.get('DFM_TO1_PADDED_BWD') != '1')
+        if direct:
+            # round 6 (csrc/conv3d_to1_bwd.hip): both gradients as matrix products over the 27 taps -- no gradient padded
+            # to 32 channels (a 118 MB fill + copy), no 32 -> 32 convolution / weight gradient for one useful row
+            wc = weight.detach().contiguous()
+            with torch.cuda.device(gy.device):
+                if ctx.needs_input_grad[0]:
+                    gxb = torch.empty((N, D, H, W, 32), dtype=torch.bfloat16, device=gy.device)
+                    _capi.check(lib.dfm_conv3d_to1_bwd_data(N, D, H, W, _ptr(gy), _ptr(wc), _WDT[wc.dtype], _ptr(gxb),
+                                                            _stream_ptr(gy.device)))
+                    gx = gxb.permute(0, 4, 1, 2, 3)
+                if ctx.needs_input_grad[1]:
+                    gw = torch.empty((1, 32, 3, 3, 3), dtype=weight.dtype, device=gy.device)
+                    nbytes = lib.dfm_conv3d_to1_wgrad_workspace_bytes()
+                    ws = _Workspace.get(gy.device, nbytes)
+                    _capi.check(lib.dfm_conv3d_to1_wgrad(N, D, H, W, _ptr(x), _ptr(gy), _ptr(gw), _WDT[gw.dtype],
+                                                         _ptr(ws), nbytes, _stream_ptr(gy.device)))
+            return gx, gw, None
+        g32 = None
         if ctx.needs_input_grad[0]:
-            # backward-data through the same MFMA kernel: the one gradient channel zero-padded to 32,
-            # transposed / mirrored fragments of the zero-padded weight (MIOpen's kernel for this
-            # 1 -> 32 shape is a 34 ms naive fallback)
-            N, _, D, H, W = gy.shape
+            # (the former route, other dtypes / layouts: the one gradient channel zero-padded to 32 through the
+            # 32 -> 32 MFMA kernel with transposed / mirrored fragments of the zero-padded weight)
             g32 = torch.zeros((N, D, H, W, 32), dtype=gy.dtype, device=gy.device)
             g32[..., 0] = gy[:, 0]
             w32 = torch.zeros((32, 32, 3, 3, 3), dtype=torch.float32, device=weight.device)
@@ -584,7 +604,6 @@ class _MfmaConvTo1Fn(torch.autograd.Function):
             gx = conv3d_k3_c32(g32.permute(0, 4, 1, 2, 3), pack_conv3d_weights(w32, 0, transposed=True))
         if ctx.needs_input_grad[1]:
             if g32 is None:
-                N, _, D, H, W = gy.shape
                 g32 = torch.zeros((N, D, H, W, 32), dtype=gy.dtype, device=gy.device)
                 g32[..., 0] = gy[:, 0]
             # rows 1..31 of the padded gradient are zero: row 0 is the (1, 32, 3, 3, 3) gradient

@@ -720,6 +720,22 @@ DFM_API int dfm_conv3d_k3_c32_to1_fwd(int32_t n, int32_t d, int32_t h, int32_t w
                                       const void *packed_weights, void *out, int32_t relu,
                                       int32_t depth_chunk, void *stream);
 
+/* Backward of the prediction heads' Conv3d(32 -> 1, 3, 1, 1) (mmdet3d/models/backbones/dfm_backbone.py:120-127), round 6
+ * (csrc/conv3d_to1_bwd.hip): both gradients as matrix products with the 27 taps as a matrix dimension, no padded
+ * tensors.
+ *   grad_out : (n, d, h, w) bf16 -- the (n, 1, d, h, w) gradient of the convolution's output [device]
+ *   weight   : (1, 32, 3, 3, 3) contiguous, weight_dtype DFM_F32 | DFM_BF16
+ *   grad_x   : (n, d, h, w, 32) bf16 channels-last, 16-byte aligned, OVERWRITTEN
+ *   x        : (n, d, h, w, 32) bf16 channels-last (the convolution's input)
+ *   grad_weight : (1, 32, 3, 3, 3) in out_dtype, OVERWRITTEN (fp32 sums over per-wave partials added in a fixed order)
+ *   workspace   : >= dfm_conv3d_to1_wgrad_workspace_bytes() */
+DFM_API int dfm_conv3d_to1_bwd_data(int32_t n, int32_t d, int32_t h, int32_t w, const void *grad_out,
+                                    const void *weight, int32_t weight_dtype, void *grad_x, void *stream);
+DFM_API size_t dfm_conv3d_to1_wgrad_workspace_bytes(void);
+DFM_API int dfm_conv3d_to1_wgrad(int32_t n, int32_t d, int32_t h, int32_t w, const void *x, const void *grad_out,
+                                 void *grad_weight, int32_t out_dtype, void *workspace, size_t workspace_bytes,
+                                 void *stream);
+
 /* Round 6 -- the prediction head's tail as ONE pass (csrc/conv3d_to1n.hip): GroupNorm(+ReLU) of the 32-channel
  * volume applied ON LOAD inside the 32 -> 1 convolution that consumes it (dfm_backbone.py:120-127:
  * ConvModule(32 -> 32, GN, ReLU) -> Conv3d(32, 1, 3, 1, 1)); the normalised volume is never written.

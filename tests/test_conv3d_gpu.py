@@ -176,3 +176,37 @@ def test_prediction_conv_32_to_1(cv):
     np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
     y.sum().backward()
     assert xb.grad is not None and m.weight.grad is not None and torch.isfinite(m.weight.grad).all()
+
+
+@pytest.mark.parametrize('wdtype', [torch.float32, torch.bfloat16], ids=['w_fp32', 'w_bf16'])
+@pytest.mark.parametrize('shape', [(2, 5, 19, 45), (1, 3, 8, 32), (1, 9, 10, 70), (1, 1, 1, 1), (2, 2, 3, 5)])
+def test_prediction_conv_32_to_1_backward_vs_torch_autograd(cv, monkeypatch, shape, wdtype):
+    """both gradients of Conv3d(32, 1, 3, 1, 1) through csrc/conv3d_to1_bwd.hip (matrix products over the 27 taps)
+    against torch's fp32 autograd on the same bf16-rounded values, and against the former route (the gradient padded to
+    32 channels through the 32 -> 32 kernels): ragged rows, volumes smaller than the kernel's reach, both weight types"""
+    dev = torch.device('cuda:0')
+    N, D, H, W = shape
+    g = torch.Generator().manual_seed(D * 100 + W)
+    x = torch.randn(N, 32, D, H, W, generator=g).bfloat16()
+    w = (torch.randn(1, 32, 3, 3, 3, generator=g) * 0.1).bfloat16()
+    gy = torch.randn(N, 1, D, H, W, generator=g).bfloat16()
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    F.conv3d(xr, wr, padding=1).backward(gy.float())
+    res = {}
+    for padded in ('0', '1'):
+        monkeypatch.setenv('DFM_TO1_PADDED_BWD', padded)
+        m = cv.MfmaConv3dTo1(32, 1, 3, 1, 1, bias=False).to(dev).to(wdtype)
+        with torch.no_grad():
+            m.weight.copy_(w.to(dev))
+        xb = x.to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        m(xb).backward(gy.to(dev))
+        res[padded] = (xb.grad.float().cpu(), m.weight.grad.float().cpu())
+        assert xb.grad.dtype == torch.bfloat16 and m.weight.grad.dtype == wdtype and m.weight.grad.shape == (1, 32, 3, 3, 3)
+    gx, gw = res['0']
+    # backward-data: 27 products accumulated in fp32, rounded once to bf16
+    np.testing.assert_allclose(gx.numpy(), xr.grad.numpy(), rtol=2.0 ** -7, atol=2.0 ** -8 * float(xr.grad.abs().max()) + 1e-6)
+    # weight gradient: fp32 sums over the volume (order differs), rounded to the parameter's type
+    tol = 2.0 ** -7 if wdtype == torch.bfloat16 else 1e-4
+    np.testing.assert_allclose(gw.numpy(), wr.grad.numpy(), rtol=tol, atol=tol * float(wr.grad.abs().max()) + 1e-6)
+    np.testing.assert_allclose(gx.numpy(), res['1'][0].numpy(), rtol=2.0 ** -7, atol=2.0 ** -7 * float(gx.abs().max()) + 1e-6)
+    np.testing.assert_allclose(gw.numpy(), res['1'][1].numpy(), rtol=2.0 ** -6, atol=2.0 ** -6 * float(gw.abs().max()) + 1e-6)
