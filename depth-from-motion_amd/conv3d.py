@@ -553,6 +553,34 @@ def conv3d_to1_norm(y, partials, gamma, beta, eps, weight, relu=True, depth_chun
     return out
 
 
+_IDENTITY_COEF = {}
+
+
+def conv3d_to1(x, weight, depth_chunk=0):
+    """Conv3d(32 -> 1, 3, 1, 1) of a bf16 NDHWC tensor through the lean 32 -> 1 kernel (csrc/conv3d_to1n.hip: two MFMAs
+    per 32 pixels with the 27 taps as a matrix dimension) with the IDENTITY as its on-load map (a = 1, b = 0, no
+    ReLU: x * 1 + 0 is x): what the training path and a head without a fusable norm run instead of the 32 -> 32 kernel
+    on a weight zero-padded to 32 output channels (122-150 us against ~50 at config K)."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 32 and _is_ndhwc(x)
+    N, _, D, H, W = x.shape
+    w = weight.detach().contiguous()
+    if w.dtype not in _WDT:
+        w = w.float()
+    key = (str(x.device), N)
+    coef = _IDENTITY_COEF.get(key)
+    if coef is None:
+        coef = torch.tensor([1.0, 0.0], dtype=torch.float32, device=x.device).repeat(N * 32).view(N, 32, 2).contiguous()
+        if len(_IDENTITY_COEF) > 64:
+            _IDENTITY_COEF.clear()
+        _IDENTITY_COEF[key] = coef
+        note_derived_build()
+    out = torch.empty((N, 1, D, H, W), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().dfm_conv3d_to1_norm_fwd(N, D, H, W, _ptr(x), _ptr(coef), _ptr(w), _WDT[w.dtype], 0, 0,
+                                                        _ptr(out), int(depth_chunk), _stream_ptr(x.device)))
+    return out
+
+
 class _MfmaConvTo1Fn(torch.autograd.Function):
     """Conv3d(32, 1, 3, 1, 1) through the MFMA kernel (weight rows 1..31 zero, channel 0 stored);
     backward is torch's convolution backward (MIOpen) -- the op is memory-bound either way."""
@@ -560,6 +588,8 @@ class _MfmaConvTo1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, packed):
         ctx.save_for_backward(x, weight)
+        if packed is None:   # the lean 32 -> 1 kernel (round 6)
+            return conv3d_to1(x, weight)
         N, _, D, H, W = x.shape
         out = torch.empty((N, 1, D, H, W), dtype=torch.bfloat16, device=x.device)
         with torch.cuda.device(x.device):
@@ -646,7 +676,9 @@ class MfmaConv3dTo1(DerivedStateMixin, nn.Conv3d):
     def forward(self, x):
         why = self.why_not(x)
         if why is None:
-            return _MfmaConvTo1Fn.apply(x, self.weight, self._packed())
+            # DFM_TO1_C32_FWD=1: the 32 -> 32 kernel on the zero-padded weight (A/B runs)
+            lean = os.environ.get('DFM_TO1_C32_FWD') != '1' and _ndhwc_channel_stride(x) == 32
+            return _MfmaConvTo1Fn.apply(x, self.weight, None if lean else self._packed())
         if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and 'coverage' not in why and
                 _FP32_MODE['mode'] != 'torch' and x.shape[1] == 32 and
                 conv3d_g_plannable(x.shape[0], 32, 32, tuple(x.shape[2:]), 1, 1)):
