@@ -183,17 +183,47 @@ __device__ __forceinline__ void gather_load32(const T *__restrict__ gp, size_t c
     }
 }
 
+// ---- pre-pass of the gather: the footprint of every (sample, plane, lattice point), 12 bytes each -------
+// {bwd_footprint's packed corner + in-bounds bits, fw, fn}: the forward's own arithmetic, once per pair
+template <int HALF>
+__global__ __launch_bounds__(256) void gather_foot_kernel(SweepGeom g, SweepFast fast, int batch,
+                                                          const float *__restrict__ planes,
+                                                          const float *__restrict__ depths, const float *__restrict__ P,
+                                                          const float *__restrict__ Pinv, const float *__restrict__ Tm,
+                                                          uint32_t *__restrict__ foot)
+{
+    const int hw = g.h_out * g.w_out;
+    const int bd = blockIdx.y;  // (sample, plane)
+    if (planes[(size_t)bd * GP_REC + 9] == 0.0f) return;  // (the fallback scatter takes this plane)
+    const int b = bd / g.D, d = bd - b * g.D;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const int lh = p / g.w_out, lw = p - lh * g.w_out;
+    float sx, sy, fw, fn;
+    sweep_point_map<HALF>(g, fast, P + b * 16, Pinv + b * 16, Tm + b * 16, depths[d], lh, lw, sx, sy);
+    const uint32_t f = bwd_footprint(sx, sy, g.h_in, g.w_in, fw, fn);
+    uint32_t *e = foot + ((size_t)bd * hw + p) * 3;
+    e[0] = f; e[1] = __float_as_uint(fw); e[2] = __float_as_uint(fn);
+}
+
 // ---- the gather: lane = map pixel, 32 channels per pass -----------------------------------------------
 // HALF: 0 cur map (channels [0, C) of the volume; its sample positions do not move with depth, the same
 // kernel walks them anyway: the footprint flips between neighbouring pixel pairs with the rounding of each
 // plane), 1 prev map.  T: dtype of the gradient volume (fp32 | bf16 bits).  CL_IN: the volume is channels-last.
 // CL_OUT: the map gradient is written pixel-major (B, H, W, C) -- a lane's 32 sums are one 128-byte run --
 // instead of the reference layout (B, C, H, W).
-template <int HALF, typename T, bool CL_IN, bool CL_OUT>
+// TABLE (round 6): the footprints of all (plane, lattice point) pairs come from a table a pre-pass wrote
+// (gather_foot_kernel: the forward's projection and bwd_footprint, ONCE per pair) -- a candidate costs a 12-byte load
+// and a few integer compares instead of ~80 instructions of projection.  The wave executes a candidate slot whenever
+// ANY of its lanes has a candidate there, so that arithmetic ran ~3 times per wave and plane whatever the hit rate:
+// 1.7 of the kernel's 2.8 ms at config K (profiles/r06_c41_*).  Without the table (a workspace that is too small):
+// the projection per candidate, as before.
+template <int HALF, typename T, bool CL_IN, bool CL_OUT, bool TABLE>
 __global__ __launch_bounds__(256) void sweep_bwd_gather_kernel(
     SweepGeom g, SweepFast fast, int batch, int passes, int xtiles, const float *__restrict__ planes,
     const T *__restrict__ gout, const float *__restrict__ depths, const float *__restrict__ P,
-    const float *__restrict__ Pinv, const float *__restrict__ Tm, float *__restrict__ gmap)
+    const float *__restrict__ Pinv, const float *__restrict__ Tm, float *__restrict__ gmap,
+    const uint32_t *__restrict__ foot)
 {
     // block id = ((ytile * xtiles + xtile) * passes + pass) * B + b: sample fastest (id % 8 == XCD keeps a
     // sample's gradient volume in one L2), then the channel passes of one pixel tile
@@ -242,10 +272,19 @@ __global__ __launch_bounds__(256) void sweep_bwd_gather_kernel(
         const float depth = depths[d];
         const T *gd = gb + (size_t)d * hw * pstride;
         // one candidate lattice point: the forward's own arithmetic decides whether its footprint holds (x, y)
+        // (recording the hits and gathering the k-th hit of every lane together afterwards measured 18-26 % slower:
+        //  the gather's loads then start after the whole candidate walk, profiles/r06_c41_*)
         auto visit = [&](int lh, int lw) {
-            float sx, sy, fw, fn;
-            sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, lh, lw, sx, sy);
-            const uint32_t f = bwd_footprint(sx, sy, H, W, fw, fn);
+            float fw, fn;
+            uint32_t f;
+            if constexpr (TABLE) {
+                const uint32_t *e = foot + (((size_t)b * g.D + d) * hw + (size_t)lh * g.w_out + lw) * 3;
+                f = e[0]; fw = __uint_as_float(e[1]); fn = __uint_as_float(e[2]);
+            } else {
+                float sx, sy;
+                sweep_point_map<HALF>(g, fast, Pb, Pib, Tb, depth, lh, lw, sx, sy);
+                f = bwd_footprint(sx, sy, H, W, fw, fn);
+            }
             const int iyn = (int)(f & 0x1fffu) - 1, ixw = (int)((f >> 13) & 0x1fffu) - 1;
             const int dx = x - ixw, dy = y - iyn;
             // (a valid footprint has its taps inside the map or masked; this pixel is inside the map, so
@@ -334,7 +373,8 @@ __global__ __launch_bounds__(256) void sweep_bwd_scatter_planes_kernel(
 
 template <int HALF, typename T, bool CL_IN, bool CL_OUT>
 int gather_launch(const dfm_sweep_desc *d, const void *grad_out, const float *depths, const float *cam2img,
-                  const float *cam2img_inv, const float *cur2prev, float *grad_map, float *planes, hipStream_t st)
+                  const float *cam2img_inv, const float *cur2prev, float *grad_map, float *planes, uint32_t *foot,
+                  hipStream_t st)
 {
     const SweepGeom g = sweep_make_geom(d);
     const SweepFast fast = sweep_make_fast(d);
@@ -344,9 +384,18 @@ int gather_launch(const dfm_sweep_desc *d, const void *grad_out, const float *de
     const int xtiles = (d->w_in + 63) / 64, ytiles = (d->h_in + 3) / 4, passes = d->channels / 32;
     const long long nb = (long long)xtiles * ytiles * passes * d->batch;
     if (nb > 2147483647ll) return set_error(DFM_ERR_UNSUPPORTED, "feature map too large");
-    hipLaunchKernelGGL((sweep_bwd_gather_kernel<HALF, T, CL_IN, CL_OUT>), dim3((unsigned)nb), dim3(256), 0, st, g, fast,
-                       d->batch, passes, xtiles, (const float *)planes, (const T *)grad_out, depths, cam2img,
-                       cam2img_inv, cur2prev, grad_map);
+    if (foot) {
+        const int hwl = d->h_out * d->w_out;
+        hipLaunchKernelGGL(gather_foot_kernel<HALF>, dim3((hwl + 255) / 256, np), dim3(256), 0, st, g, fast, d->batch,
+                           (const float *)planes, depths, cam2img, cam2img_inv, cur2prev, foot);
+        hipLaunchKernelGGL((sweep_bwd_gather_kernel<HALF, T, CL_IN, CL_OUT, true>), dim3((unsigned)nb), dim3(256), 0, st,
+                           g, fast, d->batch, passes, xtiles, (const float *)planes, (const T *)grad_out, depths, cam2img,
+                           cam2img_inv, cur2prev, grad_map, (const uint32_t *)foot);
+    } else {
+        hipLaunchKernelGGL((sweep_bwd_gather_kernel<HALF, T, CL_IN, CL_OUT, false>), dim3((unsigned)nb), dim3(256), 0, st,
+                           g, fast, d->batch, passes, xtiles, (const float *)planes, (const T *)grad_out, depths, cam2img,
+                           cam2img_inv, cur2prev, grad_map, (const uint32_t *)nullptr);
+    }
     const int ychunks = std::max(1, std::min(64, (d->h_out * d->w_out + 255) / 256));
     hipLaunchKernelGGL((sweep_bwd_scatter_planes_kernel<HALF, T, CL_IN, CL_OUT>), dim3(np, ychunks), dim3(256), 0, st, g,
                        fast, d->batch, (const float *)planes, (const T *)grad_out, depths, cam2img, cam2img_inv,
@@ -360,10 +409,27 @@ int gather_launch(const dfm_sweep_desc *d, const void *grad_out, const float *de
 
 extern "C" {
 
+static size_t gather_planes_bytes(const dfm_sweep_desc *d)
+{
+    return (((size_t)d->batch * d->num_depths * GP_REC * sizeof(float)) + 255) & ~(size_t)255;
+}
+
+// the footprint table: 12 bytes per (sample, plane, lattice point); 0 when it would not fit 2 GiB (the gather then
+// projects per candidate)
+static size_t gather_foot_bytes(const dfm_sweep_desc *d)
+{
+    if (d->h_out <= 0 || d->w_out <= 0) return 0;
+    const size_t n = (size_t)d->batch * d->num_depths * d->h_out * d->w_out * 12;
+    if (n > ((size_t)2 << 30) || getenv("DFM_GATHER_NO_TABLE")) return 0;
+    return (n + 255) & ~(size_t)255;
+}
+
+// the plane records, then (round 6) the footprint table; a workspace of the plane records' size alone is accepted too
+// (dfm_plane_sweep_bwd_gather then runs without the table)
 DFM_API size_t dfm_plane_sweep_bwd_prev_gather_workspace_bytes(const dfm_sweep_desc *d)
 {
     if (!d || d->batch <= 0 || d->num_depths <= 0) return 0;
-    return (((size_t)d->batch * d->num_depths * GP_REC * sizeof(float)) + 255) & ~(size_t)255;
+    return gather_planes_bytes(d) + gather_foot_bytes(d);
 }
 
 DFM_API int dfm_plane_sweep_bwd_gather(const dfm_sweep_desc *d, int32_t half, const void *grad_out,
@@ -376,8 +442,8 @@ DFM_API int dfm_plane_sweep_bwd_gather(const dfm_sweep_desc *d, int32_t half, co
     if (!grad_out || !depths || !cam2img || !cam2img_inv || !cur2prev || !grad_map || !workspace)
         return set_error(DFM_ERR_INVALID_ARG, "NULL device pointer");
     if (half != 0 && half != 1) return set_error(DFM_ERR_INVALID_ARG, "half is 0 (cur map) or 1 (prev map)");
-    if (workspace_bytes < dfm_plane_sweep_bwd_prev_gather_workspace_bytes(d))
-        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than dfm_plane_sweep_bwd_prev_gather_workspace_bytes");
+    if (workspace_bytes < gather_planes_bytes(d))
+        return set_error(DFM_ERR_WORKSPACE, "workspace smaller than the plane records of dfm_plane_sweep_bwd_prev_gather_workspace_bytes");
     // (DFM_GATHER_DENSE=1: dense sweeps too -- cost_sample_factor 1, several hits per pixel and plane; experiments)
     const char *dense_e = getenv("DFM_GATHER_DENSE");
     const bool dense_ok = dense_e && dense_e[0] == '1';
@@ -387,8 +453,11 @@ DFM_API int dfm_plane_sweep_bwd_gather(const dfm_sweep_desc *d, int32_t half, co
                          "gather backward: channels % 32 == 0, cost_sample_factor >= 2, lattice >= 2 x 2, 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     float *planes = (float *)workspace;
+    const size_t fbytes = gather_foot_bytes(d);
+    uint32_t *foot = (fbytes && workspace_bytes >= gather_planes_bytes(d) + fbytes)
+                         ? (uint32_t *)((char *)workspace + gather_planes_bytes(d)) : nullptr;
 #define DFM_GL(H_, T_, CI_, CO_) \
-    rc = gather_launch<H_, T_, CI_, CO_>(d, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_map, planes, st)
+    rc = gather_launch<H_, T_, CI_, CO_>(d, grad_out, depths, cam2img, cam2img_inv, cur2prev, grad_map, planes, foot, st)
 #define DFM_GL_T(H_, CI_, CO_)                                \
     do {                                                      \
         if (d->dtype == DFM_BF16) DFM_GL(H_, uint16_t, CI_, CO_); \
