@@ -175,3 +175,36 @@ def test_depth_chunk_of_the_32_channel_convolution_fills_whole_rounds(cv):
         assert all(cost(dc) <= cost(c) + 1e-9 for c in range(min(d, 4), d + 1)), (n, d, h, w, dc)
     # an explicit chunk is taken as given
     assert lib.dfm_conv3d_k3_c32_stats_splits(1, 72, 80, 320, 8) == 50 * 9 * 4
+
+
+def test_planner_choices_that_came_out_of_the_round_6_plan_sweeps(cv):
+    """profiles/r06_c39_*: between two tilings of the same block size the one deeper along d wins (tw > 1), and a
+    convolution transposed on all three axes takes two pixel fragments a wave at most (host logic: no GPU)"""
+    p = cv.conv3d_g_plan(1, 256, 256, (220, 300, 3))                    # neck.res2: (8, 16, 3) and (16, 8, 3) tie
+    assert p['pfw'] == 3 and p['tile'] == (16, 8, 3)
+    p = cv.conv3d_g_plan(1, 64, 128, (220, 300, 12), (1, 1, 2), 1)      # neck.down0
+    assert p['tile'][0] >= p['tile'][1]
+    p = cv.conv3d_g_plan(1, 64, 32, (36, 40, 160), 1, 1, True)          # hourglass conv6 (x2 on d, h, w)
+    assert p['pfw'] <= 2
+    p = cv.conv3d_g_plan(1, 64, 64, (18, 20, 80), 1, 1, True)           # conv5
+    assert p['pfw'] <= 2
+    p = cv.conv3d_g_plan(1, 64, 32, (4, 6, 5), 1, 1, (False, False, True))  # one transposed axis: no cap
+    assert p['pfw'] in (1, 2, 3, 4)
+
+
+def test_workspace_sizes_of_the_round_6_entry_points(cv):
+    """byte counts the Python host allocates from (no GPU): the strided backward's workspace holds the plane records
+    AND the footprint table (12 bytes per sample, plane and lattice point); the 32 -> 1 weight gradient's partials"""
+    capi = importlib.import_module('depth-from-motion_amd._capi')
+    lib = capi.lib()
+    assert lib.dfm_conv3d_to1_wgrad_workspace_bytes() == 1024 * 1024 * 4
+    d = capi.SweepDesc()
+    d.batch, d.channels, d.num_depths = 8, 32, 72
+    d.h_in, d.w_in, d.h_out, d.w_out = 320, 1280, 80, 320
+    d.feat_sample_factor, d.cost_sample_factor, d.dtype = 4.0, 4.0, capi.DFM_F32
+    n = lib.dfm_plane_sweep_bwd_prev_gather_workspace_bytes(ctypes.byref(d))
+    table = 8 * 72 * 80 * 320 * 12
+    assert table <= n <= table + 8 * 72 * 12 * 4 + 1024
+    d.batch, d.num_depths, d.h_out, d.w_out = 64, 288, 376, 1248      # a table beyond 2 GiB is not asked for
+    n = lib.dfm_plane_sweep_bwd_prev_gather_workspace_bytes(ctypes.byref(d))
+    assert n == ((64 * 288 * 12 * 4 + 255) // 256) * 256
