@@ -123,7 +123,7 @@ SECONDARY = ('waymo', 'depth_head', 'f2v', 'group_norm', 'sweep_bwd', 'sweep_bwd
              'backbone', 'backbone_train', 'neck', 'dfm_neck', 'stereo_infer', 'stereo_train',
              # the same rows in the layout the bf16 NDHWC pipeline hands them (channels-last sources
              # sampled in place, channels-last results for the MFMA convolutions that follow)
-             'waymo_cl', 'depth_head_bf16', 'f2v_cl', 'group_norm_cl')
+             'waymo_cl', 'depth_head_bf16', 'f2v_cl', 'f2v_bwd', 'group_norm_cl')
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 
 WORKLOADS = {
@@ -655,6 +655,35 @@ def secondary(args, pkg, dev, job, emit=True):
         nbytes = gout.numel() * esz + 2 * g_cur.numel() * 4
         name = f'plane-sweep backward ({w["dtype"]} grad volume -> 2 fp32 feature grads)'
         unit = 'cost-volume-grads/s'
+    elif args.workload == 'f2v_bwd':
+        # FrustumToVoxel's backward as DfMStereoPath trains through it at config K: one frame's bf16 NDHWC cost
+        # volume + semantic map, the depth head fused (lazy statistics), gradient of the 64-channel voxel volume
+        # gathered back per frustum cell (the cell pre-pass, the gather kernel, the semantic map's reduction)
+        B, C, D, H, W = 1, 32, 72, 80, 320
+        dtype_name = 'bf16'
+        stereo = torch.randn(B, C, D, H, W, generator=gen).to(dev).bfloat16().contiguous(
+            memory_format=torch.channels_last_3d).requires_grad_(True)
+        cost = (torch.randn(B, 1, D, H, W, generator=gen) * 4).to(dev).bfloat16()
+        sem = torch.randn(B, C, H, W, generator=gen).to(dev).bfloat16().requires_grad_(True)
+        ds = torch.tensor([(k + 0.5) * (57.6 / 288) + 2 for k in range(288)])
+        zz, yy, xx = torch.meshgrid(torch.linspace(-2.9, 0.9, 20), torch.linspace(-30.3, 30.3, 304),
+                                    torch.linspace(2.1, 59.5, 288), indexing='ij')
+        coords = torch.stack([xx, yy, zz], -1).to(dev)
+        K = KITTI_P2.copy()
+        K[1, 2] -= 55.0
+        metas = [{'cam2img': K.tolist(), 'pad_shape': (320, 1280, 3)}] * B
+        lazy, _ = pkg.depth_head_statistics(cost, ds, 4)
+        vox = pkg.frustum_to_voxel_sample(stereo, lazy, metas, sem, coords, dict(depth_min=2, depth_max=59.6))
+        go = torch.randn(vox.shape, generator=gen).to(dev).bfloat16()
+        if not vox.is_contiguous():
+            go = go.contiguous(memory_format=torch.channels_last_3d)
+
+        def step():
+            return torch.autograd.grad(vox, [stereo, sem], go, retain_graph=True)
+        # the voxel gradient read once, both input gradients written once
+        nbytes = B * 2 * (2 * C * 20 * 304 * 288 + C * D * H * W + C * H * W)
+        name = 'FrustumToVoxel backward (grad 64x20x304x288 -> 32x72x80x320 + 32x80x320, bf16 channels-last, fused depth head)'
+        unit = 'voxel-volumes/s'
     elif args.workload in ('group_norm', 'group_norm_cl'):
         B = 8
         x = (torch.randn(B, 32, 72, 80, 320, generator=gen) + 0.5).to(dev)
@@ -787,7 +816,7 @@ def secondary_block(pkg, sweep, dev, job, budget_s=45.0, traffic=True):
     import types
     out = {}
     t_start, t_traffic = time.perf_counter(), 0.0
-    for wl in ('sweep_bwd', 'kitti_nhwc', 'sweep_bwd_kitti', 'sweep_bwd_kitti_cl', 'f2v_cl', 'backbone', 'neck',
+    for wl in ('sweep_bwd', 'kitti_nhwc', 'sweep_bwd_kitti', 'sweep_bwd_kitti_cl', 'f2v_cl', 'f2v_bwd', 'backbone', 'neck',
                'dfm_neck', 'backbone_train', 'waymo_cl', 'nstar_negzero', 'nstar_negzero_all', 'stereo_infer',
                'stereo_train'):
         if time.perf_counter() - t_start - t_traffic > budget_s:   # (the counter passes have their own time)

@@ -1185,7 +1185,6 @@ __global__ __launch_bounds__(256, DFM_F2G_WGS) void f2v_bwd_gather_kernel(F2vGeo
             if (!__any(some)) continue;
             const int iy0 = some ? (int)fmaxf(y0f, 0.0f) : 0, iy1 = some ? (int)fminf(y1f, (float)(g.Ny - 1)) : -1;
             const int iz0 = some ? (int)fmaxf(z0f, 0.0f) : 0, iz1 = some ? (int)fminf(z1f, (float)(g.Nz - 1)) : -1;
-            // one candidate voxel (ix, iy, iz)
             // one candidate voxel (ix, iy, iz): its packed lower-corner cell against this lane's (w, h, d) -- a 4-byte
             // load and three subtractions reject it (round 5 re-ran the forward's projection for every candidate: three
             // dependent loads, three dot products and two divisions before the first test)
